@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REAL REFERENCE.
+
+Run in the build container only (the reference is mounted at /root/reference there and
+does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports pierluigiferrari/ssd_keras's NumPy half unmodified (three removed NumPy aliases
+are restored first), feeds it seeded inputs and stores inputs + outputs as .npz files.
+`tests/test_oracle_golden.py` pins `oracle/np_oracle.py` to these files; the `-m gpu`
+tests compare the HIP path with them.  The TensorFlow half of the reference (SSDLoss,
+DecodeDetections layers, L2Normalization) cannot run here -> no goldens for it.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("SSD_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+np.float = float   # noqa: aliases removed in NumPy >= 1.24, used by the reference
+np.int = int       # noqa
+np.bool = bool     # noqa
+
+from bounding_box_utils.bounding_box_utils import convert_coordinates, iou            # noqa: E402
+from ssd_encoder_decoder.matching_utils import match_bipartite_greedy, match_multi     # noqa: E402
+from ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder                      # noqa: E402
+from ssd_encoder_decoder.ssd_output_decoder import (decode_detections, decode_detections_debug,  # noqa: E402
+                                                    decode_detections_fast, greedy_nms)
+
+from ssd_keras_amd import synthetic as syn                                             # noqa: E402
+
+
+def encoder_from(cfg, **over):
+    kw = dict(cfg)
+    kw.update(over)
+    kw["predictor_sizes"] = np.array(kw["predictor_sizes"])
+    return SSDInputEncoder(**kw)
+
+
+def anchors_var(enc):
+    t = enc.generate_encoding_template(batch_size=1)
+    return t[0, :, -8:]
+
+
+def ragged(list_of_arrays, width):
+    rows = [np.asarray(a, dtype=np.float64).reshape(-1, width) for a in list_of_arrays]
+    off = np.cumsum([0] + [r.shape[0] for r in rows]).astype(np.int64)
+    return (np.concatenate(rows, axis=0) if rows else np.zeros((0, width))), off
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024.0, len(arrays)))
+
+
+# ----------------------------------------------------------------------------------------
+def gen_box_utils():
+    rng = np.random.RandomState(11)
+    out = {}
+    a = rng.uniform(0, 50, size=(7, 2))
+    b = rng.uniform(0, 50, size=(9, 2))
+    c1 = np.concatenate([a, a + rng.uniform(1, 40, size=(7, 2))], axis=1)   # corners
+    c2 = np.concatenate([b, b + rng.uniform(1, 40, size=(9, 2))], axis=1)
+    out["corners1"], out["corners2"] = c1, c2
+    for conv in ("minmax2centroids", "centroids2minmax", "corners2centroids", "centroids2corners",
+                 "minmax2corners", "corners2minmax"):
+        for bp in ("half", "include", "exclude"):
+            out["cc_%s_%s" % (conv, bp)] = convert_coordinates(c1, 0, conv, bp)
+        out["cc32_%s" % conv] = convert_coordinates(c1.astype(np.float32), 0, conv, "half")
+    for coords in ("corners", "minmax", "centroids"):
+        if coords == "corners":
+            p, q = c1, c2
+        elif coords == "minmax":
+            p, q = c1[:, [0, 2, 1, 3]], c2[:, [0, 2, 1, 3]]
+        else:
+            p, q = convert_coordinates(c1, 0, "corners2centroids"), convert_coordinates(c2, 0, "corners2centroids")
+        for bp in ("half", "include", "exclude"):
+            out["iou_outer_%s_%s" % (coords, bp)] = iou(p, q, coords, "outer_product", bp)
+            out["iou_elem_%s_%s" % (coords, bp)] = iou(p, q[:7], coords, "element-wise", bp)
+            out["iou_bcast_%s_%s" % (coords, bp)] = iou(p, q[3], coords, "element-wise", bp)
+    # matching, including the zero-row / duplicate-anchor quirks
+    mats = [np.array([[0, 0, 0, 0], [0, .6, 0, 0], [0, 0, 0, 0]], dtype=np.float64),
+            np.array([[.5, .6], [0, 0]], dtype=np.float64),
+            np.array([[.3, .3, .1], [.3, .3, .2]], dtype=np.float64),
+            rng.uniform(0, 1, size=(5, 40)) * (rng.uniform(0, 1, size=(5, 40)) > 0.6),
+            rng.uniform(0, 1, size=(8, 8))]
+    for i, m in enumerate(mats):
+        out["match_in_%d" % i] = m
+        out["match_bip_%d" % i] = match_bipartite_greedy(m)
+        g, a_ = match_multi(m, 0.5)
+        out["match_multi_gt_%d" % i], out["match_multi_anchor_%d" % i] = g, a_
+    save("box_utils", **out)
+
+
+def gen_anchors():
+    out = {}
+    for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
+        for coords in ("centroids", "corners", "minmax"):
+            for clip in (False, True):
+                if name in ("ssd300", "ssd512") and (coords != "centroids" or clip):
+                    continue
+                enc = encoder_from(cfg, coords=coords, clip_boxes=clip)
+                out["%s_%s_clip%d" % (name, coords, clip)] = np.concatenate([b.reshape(-1, 4) for b in enc.boxes_list])
+    enc = encoder_from(syn.TINY, normalize_coords=False, steps=[8, (16, 20), 32, 64], offsets=[0.5, (0.3, 0.7), 0.5, 0.5])
+    out["tiny_abs_steps"] = np.concatenate([b.reshape(-1, 4) for b in enc.boxes_list])
+    save("anchors", **out)
+
+
+def sparse_encoding(y, n_classes_incl_bg, background_id=0):
+    """Rows of y_encoded that differ from the all-background template + checksums."""
+    B = y.shape[0]
+    touched = np.argwhere(y[:, :, background_id] != 1)
+    # also rows whose offsets are non-zero (cannot happen for background rows, but be safe)
+    extra = np.argwhere(np.any(y[:, :, -12:-8] != 0, axis=-1) & (y[:, :, background_id] == 1))
+    idx = np.concatenate([touched, extra], axis=0) if extra.size else touched
+    rows = y[idx[:, 0], idx[:, 1], :] if idx.size else np.zeros((0, y.shape[2]))
+    return idx.astype(np.int32), rows, y.reshape(B, -1).sum(axis=1)
+
+
+def gen_encoder():
+    out = {}
+    cases = []
+    k = 0
+    for coords in ("centroids", "corners", "minmax"):
+        for matching in ("multi", "bipartite"):
+            for bp, neg in (("half", 0.3), ("include", 0.5), ("exclude", 0.2)):
+                cases.append(dict(cfg="tiny", coords=coords, matching_type=matching, border_pixels=bp,
+                                  neg_iou_limit=neg, pos_iou_threshold=0.5, seed=100 + k, B=4, max_boxes=6))
+                k += 1
+    cases.append(dict(cfg="tiny", coords="centroids", matching_type="multi", border_pixels="half",
+                      neg_iou_limit=0.3, pos_iou_threshold=0.5, seed=300, B=3, max_boxes=6, normalize_coords=False))
+    cases.append(dict(cfg="tiny", coords="centroids", matching_type="multi", border_pixels="half",
+                      neg_iou_limit=0.3, pos_iou_threshold=0.5, seed=301, B=3, max_boxes=6, background_id=2))
+    cases.append(dict(cfg="ssd7", coords="centroids", matching_type="multi", border_pixels="half",
+                      neg_iou_limit=0.3, pos_iou_threshold=0.5, seed=7, B=4, max_boxes=8))
+    cases.append(dict(cfg="ssd300", coords="centroids", matching_type="multi", border_pixels="half",
+                      neg_iou_limit=0.5, pos_iou_threshold=0.5, seed=7, B=4, max_boxes=8))
+    cases.append(dict(cfg="ssd300", coords="centroids", matching_type="multi", border_pixels="half",
+                      neg_iou_limit=0.3, pos_iou_threshold=0.5, seed=8, B=2, max_boxes=16, min_boxes=16))
+    cfgs = dict(tiny=syn.TINY, ssd7=syn.SSD7_300, ssd300=syn.SSD300_VOC)
+    for ci, case in enumerate(cases):
+        cfg = cfgs[case["cfg"]]
+        over = {k_: v for k_, v in case.items() if k_ not in ("cfg", "seed", "B", "max_boxes", "min_boxes")}
+        enc = encoder_from(cfg, **over)
+        gt = syn.make_ground_truth(case["B"], cfg["n_classes"], cfg["img_height"], cfg["img_width"],
+                                   max_boxes=case["max_boxes"], seed=case["seed"], min_boxes=case.get("min_boxes", 1))
+        if case["cfg"] == "tiny":
+            # quirk coverage: an empty image, a far-away sliver that overlaps nothing, duplicates
+            gt[1] = np.zeros((0, 5))
+            gt[2] = np.concatenate([gt[2], [[1, 0.0, 0.0, 0.4, 0.4]], gt[2][:1]], axis=0)
+        y, y_diag = enc(gt, diagnostics=True)
+        idx, rows, sums = sparse_encoding(y, enc.n_classes, enc.background_id)
+        gt_cat, gt_off = ragged(gt, 5)
+        pre = "c%02d_" % ci
+        out[pre + "gt"], out[pre + "gt_off"] = gt_cat, gt_off
+        out[pre + "idx"], out[pre + "rows"], out[pre + "sums"] = idx, rows, sums
+        out[pre + "diag_sums"] = y_diag.reshape(y.shape[0], -1).sum(axis=1)
+        out[pre + "params"] = np.array(repr(case))
+    out["n_cases"] = np.array(len(cases))
+    save("encoder", **out)
+
+
+def gen_decoder():
+    out = {}
+    cases = []
+    # exp probe: lets a test tell whether the local np.exp(float32) is the one that made these files
+    probe = np.linspace(-3, 3, 4001).astype(np.float32)
+    out["exp_probe_in"], out["exp_probe_out"] = probe, np.exp(probe)
+
+    def add(name, fn, y_pred, store_input, **kw):
+        res = fn(y_pred, **kw)
+        width = 7 if fn is decode_detections_debug else 6
+        cat, off = ragged(res, width)
+        pre = name + "_"
+        out[pre + "out"], out[pre + "off"] = cat, off
+        out[pre + "kw"] = np.array(repr(kw))
+        out[pre + "fn"] = np.array(fn.__name__)
+        if store_input is not None:
+            out[pre + "y_pred"] = store_input
+        cases.append(name)
+
+    # --- TINY sweeps: every coords format / dtype / border mode --------------------------
+    k = 0
+    for coords in ("centroids", "corners", "minmax"):
+        enc = encoder_from(syn.TINY, coords=coords)
+        av = anchors_var(enc)
+        for dtype in (np.float32, np.float64):
+            for bias, thr in ((0.0, 0.05), (2.0, 0.01)):
+                y = syn.make_y_pred(av, 3, enc.n_classes, bias=bias, seed=500 + k, dtype=dtype)
+                tag = "tiny_%s_%s_b%d" % (coords, np.dtype(dtype).name, int(bias))
+                out[tag + "_y_pred"] = y
+                for bp in ("half", "include", "exclude"):
+                    add("%s_%s" % (tag, bp), decode_detections, y, None, confidence_thresh=thr, iou_threshold=0.45,
+                        top_k=200, input_coords=coords, normalize_coords=True, img_height=96, img_width=128,
+                        border_pixels=bp)
+                add(tag + "_top10", decode_detections, y, None, confidence_thresh=thr, iou_threshold=0.45, top_k=10,
+                    input_coords=coords, normalize_coords=True, img_height=96, img_width=128)
+                add(tag + "_all", decode_detections, y, None, confidence_thresh=thr, iou_threshold=0.3, top_k="all",
+                    input_coords=coords, normalize_coords=False)
+                add(tag + "_fast", decode_detections_fast, y, None, confidence_thresh=0.2, iou_threshold=0.45,
+                    top_k="all", input_coords=coords, normalize_coords=True, img_height=96, img_width=128)
+                add(tag + "_fast_top5", decode_detections_fast, y, None, confidence_thresh=0.1, iou_threshold=0.45,
+                    top_k=5, input_coords=coords, normalize_coords=True, img_height=96, img_width=128)
+                add(tag + "_fast_nonms", decode_detections_fast, y, None, confidence_thresh=0.3, iou_threshold=None,
+                    top_k="all", input_coords=coords, normalize_coords=True, img_height=96, img_width=128)
+                k += 1
+    enc = encoder_from(syn.TINY)
+    y = syn.make_y_pred(anchors_var(enc), 2, enc.n_classes, bias=1.0, seed=77)
+    add("tiny_debug", decode_detections_debug, y, y, confidence_thresh=0.02, iou_threshold=0.45, top_k=50,
+        input_coords="centroids", normalize_coords=True, img_height=96, img_width=128)
+    add("tiny_nothing", decode_detections, y, y, confidence_thresh=0.999, iou_threshold=0.45, top_k=200,
+        input_coords="centroids", normalize_coords=True, img_height=96, img_width=128)
+
+    # --- SSD7 dense (random-weights-like), SSD300 sparse (trained-like) --------------------
+    enc = encoder_from(syn.SSD7_300)
+    y = syn.make_y_pred(anchors_var(enc), 1, enc.n_classes, bias=0.0, seed=1234)
+    out["ssd7_dense_conf_loc"] = y[:, :, :-8]
+    add("ssd7_dense", decode_detections, y, None, confidence_thresh=0.01, iou_threshold=0.45, top_k=200,
+        input_coords="centroids", normalize_coords=True, img_height=300, img_width=300)
+    add("ssd7_dense_conf05", decode_detections, y, None, confidence_thresh=0.5, iou_threshold=0.45, top_k=200,
+        input_coords="centroids", normalize_coords=True, img_height=300, img_width=300)
+    enc = encoder_from(syn.SSD300_VOC)
+    y = syn.make_y_pred(anchors_var(enc), 1, enc.n_classes, bias=7.0, seed=1234)
+    out["ssd300_sparse_conf_loc"] = y[:, :, :-8]
+    add("ssd300_sparse", decode_detections, y, None, confidence_thresh=0.01, iou_threshold=0.45, top_k=200,
+        input_coords="centroids", normalize_coords=True, img_height=300, img_width=300)
+    add("ssd300_sparse_include", decode_detections, y, None, confidence_thresh=0.01, iou_threshold=0.45, top_k=200,
+        input_coords="centroids", normalize_coords=True, img_height=300, img_width=300, border_pixels="include")
+    add("ssd300_fast", decode_detections_fast, y, None, confidence_thresh=0.1, iou_threshold=0.45, top_k=200,
+        input_coords="centroids", normalize_coords=True, img_height=300, img_width=300)
+
+    # --- public greedy_nms ------------------------------------------------------------------
+    rng = np.random.RandomState(5)
+    items = []
+    for n in (0, 1, 37, 120):
+        xy = rng.uniform(0, 80, size=(n, 2))
+        box = np.concatenate([xy, xy + rng.uniform(5, 40, size=(n, 2))], axis=1)
+        items.append(np.concatenate([rng.randint(1, 4, size=(n, 1)).astype(float), rng.uniform(size=(n, 1)), box], axis=1))
+    cat, off = ragged(items, 6)
+    out["gnms_in"], out["gnms_in_off"] = cat, off
+    for bp in ("half", "include"):
+        cat, off = ragged(greedy_nms([it for it in items if it.shape[0] > 0], 0.45, "corners", bp), 6)
+        out["gnms_out_" + bp], out["gnms_out_off_" + bp] = cat, off
+    out["cases"] = np.array(cases)
+    save("decoder", **out)
+
+
+if __name__ == "__main__":
+    gen_box_utils()
+    gen_anchors()
+    gen_encoder()
+    gen_decoder()

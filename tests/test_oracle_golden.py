@@ -1,0 +1,198 @@
+"""Pin `oracle/np_oracle.py` against fixtures produced by the REAL reference
+(`tests/golden/make_golden.py`).  CPU only.  Bit-exact unless stated otherwise."""
+import ast
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+from ssd_keras_amd import synthetic as syn
+from tests import util
+
+
+def _encoder(cfg, **over):
+    kw = dict(cfg)
+    kw.update(over)
+    return orc.EncoderOracle(**kw)
+
+
+def test_convert_coordinates_and_iou():
+    z = util.load("box_utils")
+    c1, c2 = z["corners1"], z["corners2"]
+    for conv in ("minmax2centroids", "centroids2minmax", "corners2centroids", "centroids2corners",
+                 "minmax2corners", "corners2minmax"):
+        for bp in ("half", "include", "exclude"):
+            assert np.array_equal(orc.convert_coordinates(c1, 0, conv, bp), z["cc_%s_%s" % (conv, bp)])
+        got = orc.convert_coordinates(c1.astype(np.float32), 0, conv, "half")
+        assert got.dtype == np.float64 and np.array_equal(got, z["cc32_%s" % conv])
+    for coords in ("corners", "minmax", "centroids"):
+        if coords == "corners":
+            p, q = c1, c2
+        elif coords == "minmax":
+            p, q = c1[:, [0, 2, 1, 3]], c2[:, [0, 2, 1, 3]]
+        else:
+            p, q = orc.convert_coordinates(c1, 0, "corners2centroids"), orc.convert_coordinates(c2, 0, "corners2centroids")
+        for bp in ("half", "include", "exclude"):
+            assert np.array_equal(orc.iou(p, q, coords, "outer_product", bp), z["iou_outer_%s_%s" % (coords, bp)])
+            assert np.array_equal(orc.iou(p, q[:7], coords, "element-wise", bp), z["iou_elem_%s_%s" % (coords, bp)])
+            assert np.array_equal(orc.iou(p, q[3], coords, "element-wise", bp), z["iou_bcast_%s_%s" % (coords, bp)])
+
+
+def test_iou_border_pixel_quirk():
+    # only the union sees border_pixels
+    a, b = np.array([0., 0, 10, 10]), np.array([5., 5, 15, 15])
+    assert abs(orc.iou(a, b, "corners", "element-wise", "half")[0] - 0.142857) < 1e-6
+    assert abs(orc.iou(a, b, "corners", "element-wise", "include")[0] - 0.115207) < 1e-6
+    assert abs(orc.iou(a, b, "corners", "element-wise", "exclude")[0] - 0.182482) < 1e-6
+
+
+def test_matching():
+    z = util.load("box_utils")
+    i = 0
+    while "match_in_%d" % i in z:
+        m = z["match_in_%d" % i]
+        assert np.array_equal(orc.match_bipartite_greedy(m), z["match_bip_%d" % i])
+        g, a = orc.match_multi(m, 0.5)
+        assert np.array_equal(g, z["match_multi_gt_%d" % i]) and np.array_equal(a, z["match_multi_anchor_%d" % i])
+        i += 1
+    assert i >= 5
+    # the two quirks spelled out
+    assert list(orc.match_bipartite_greedy(np.array([[0, 0, 0, 0], [0, .6, 0, 0], [0, 0, 0, 0.]]))) == [0, 1, 0]
+    assert list(orc.match_bipartite_greedy(np.array([[.5, .6], [0, 0.]]))) == [0, 0]
+
+
+def test_anchors():
+    z = util.load("anchors")
+    n = 0
+    for key in z.files:
+        if key == "tiny_abs_steps":
+            enc = _encoder(syn.TINY, normalize_coords=False, steps=[8, (16, 20), 32, 64],
+                           offsets=[0.5, (0.3, 0.7), 0.5, 0.5])
+        else:
+            name, coords, clip = key.split("_")
+            enc = _encoder(util.CFGS[name], coords=coords, clip_boxes=clip == "clip1")
+        assert np.array_equal(enc.anchors(), z[key]), key
+        n += 1
+    assert n >= 10
+    assert _encoder(syn.SSD300_VOC).anchors().shape == (8732, 4)
+    assert _encoder(syn.SSD512_COCO).anchors().shape == (24564, 4)
+    assert _encoder(syn.SSD7_300).anchors().shape == (7160, 4)
+
+
+def test_encoder():
+    z = util.load("encoder")
+    n_cases = int(z["n_cases"])
+    assert n_cases >= 20
+    for ci in range(n_cases):
+        pre = "c%02d_" % ci
+        case = ast.literal_eval(str(z[pre + "params"]))
+        cfg = util.CFGS[case["cfg"]]
+        over = {k: v for k, v in case.items() if k not in ("cfg", "seed", "B", "max_boxes", "min_boxes")}
+        enc = _encoder(cfg, **over)
+        gt = util.unragged(z[pre + "gt"], z[pre + "gt_off"])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            y, y_diag, mm = enc(gt, diagnostics=True, return_matches=True)
+        idx, rows = z[pre + "idx"], z[pre + "rows"]
+        # every row the reference changed is identical ...
+        assert np.array_equal(y[idx[:, 0], idx[:, 1], :], rows, equal_nan=True), pre
+        # ... and every other row is still the all-background template (checksum + direct test)
+        mask = np.ones(y.shape[:2], bool)
+        mask[idx[:, 0], idx[:, 1]] = False
+        tmpl = enc.generate_encoding_template(len(gt))
+        tmpl[:, :, enc.background_id] = 1
+        tmpl[:, :, -12:-8] = 0
+        assert np.array_equal(y[mask], tmpl[mask]), pre
+        assert np.array_equal(y.reshape(len(gt), -1).sum(axis=1), z[pre + "sums"], equal_nan=True), pre
+        assert np.array_equal(y_diag.reshape(len(gt), -1).sum(axis=1), z[pre + "diag_sums"], equal_nan=True), pre
+        # match map is consistent with the encoded classes
+        C = enc.n_classes
+        cls_sum = y[:, :, :C].sum(axis=-1)
+        assert np.array_equal(mm == -2, (cls_sum == 0)), pre
+        if enc.background_id == 0:      # (a GT class equal to a non-zero background_id re-sets that slot)
+            assert np.array_equal(mm >= 0, (cls_sum == 1) & (y[:, :, 0] == 0)), pre
+
+
+def test_encoder_degenerate_box_raises():
+    enc = _encoder(syn.TINY)
+    with pytest.raises(orc.DegenerateBoxError):
+        enc([np.array([[1, 10, 10, 10, 20.]])])
+
+
+def _y_pred_for(z, name):
+    if name.startswith("ssd7") or name.startswith("ssd300"):
+        cfg_name = "ssd7" if name.startswith("ssd7") else "ssd300"
+        key = "ssd7_dense_conf_loc" if cfg_name == "ssd7" else "ssd300_sparse_conf_loc"
+        enc = _encoder(util.CFGS[cfg_name])
+        cl = z[key]
+        av = enc.generate_encoding_template(1)[0, :, -8:]
+        y = np.empty(cl.shape[:2] + (cl.shape[2] + 8,), dtype=cl.dtype)
+        y[:, :, :-8] = cl
+        y[:, :, -8:] = av
+        return y
+    if name + "_y_pred" in z:
+        return z[name + "_y_pred"]
+    return z["_".join(name.split("_")[:4]) + "_y_pred"]
+
+
+def test_decoder():
+    z = util.load("decoder")
+    strict = util.local_exp_matches_golden()
+    fns = dict(decode_detections=orc.decode_detections, decode_detections_fast=orc.decode_detections_fast)
+    n = 0
+    for name in [str(s) for s in z["cases"]]:
+        kw = util.kw_of(z, name)
+        fn_name = str(z[name + "_fn"])
+        y = _y_pred_for(z, name)
+        want = util.unragged(z[name + "_out"], z[name + "_off"])
+        if fn_name == "decode_detections_debug":
+            got = orc.decode_detections(y, with_anchor_index=True, decode_order="debug", **kw)
+            n_meta = 3
+        else:
+            got = fns[fn_name](y, **kw)
+            n_meta = 2
+        for g, w in zip(got, want):                      # container quirks: empty -> shape (0,)
+            if w.shape[0] == 0 and fn_name != "decode_detections_fast":
+                assert g.shape == (0,), name
+        exact = strict or y.dtype == np.float64 or kw["input_coords"] != "centroids"
+        util.dets_equal(got, want, exact=exact, rtol=1e-6, atol=1e-6, n_meta=n_meta)
+        n += 1
+    assert n >= 100
+
+
+def test_decoder_det_exp_selection_matches_reference():
+    """With the deterministic exp the *selection* (anchor, class, conf) still equals the reference's on every
+    golden case and boxes move by < 1e-5 px: no fixture sits on an NMS knife edge."""
+    z = util.load("decoder")
+    for name in [str(s) for s in z["cases"]]:
+        kw = util.kw_of(z, name)
+        if str(z[name + "_fn"]) != "decode_detections" or kw["input_coords"] != "centroids":
+            continue
+        y = _y_pred_for(z, name)
+        if y.dtype != np.float32:
+            continue
+        got = orc.decode_detections(y, exp_mode="det", **kw)
+        want = util.unragged(z[name + "_out"], z[name + "_off"])
+        util.dets_equal(got, want, exact=False, rtol=1e-6, atol=1e-5)
+
+
+def test_det_expf_accuracy():
+    x = np.concatenate([np.linspace(-104, 89, 200001), np.linspace(-2, 2, 200001)]).astype(np.float32)
+    got = orc.det_expf(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    ok = np.isfinite(ref) & (ref > 1e-37) & (ref < 3e38)
+    ulp = np.spacing(ref[ok].astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(got[ok] - ref[ok]) / ulp) <= 0.5000001
+    assert orc.det_expf(np.float32(0.0)) == 1.0
+    assert np.isnan(orc.det_expf(np.array([np.nan], np.float32))[0])
+    assert orc.det_expf(np.array([200.0], np.float32))[0] == np.inf
+    assert orc.det_expf(np.array([-200.0], np.float32))[0] == 0.0
+
+
+def test_greedy_nms_public():
+    z = util.load("decoder")
+    items = [it for it in util.unragged(z["gnms_in"], z["gnms_in_off"]) if it.shape[0] > 0]
+    for bp in ("half", "include"):
+        got = orc.greedy_nms(items, 0.45, "corners", bp)
+        want = util.unragged(z["gnms_out_" + bp], z["gnms_out_off_" + bp])
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
