@@ -1,0 +1,141 @@
+/*
+ * ssdhip.h -- C ABI of libssdhip.so: the per-anchor hot path of an SSD detector
+ * (target encoding, multibox loss, prediction decoding + NMS) as hand-written
+ * gfx950 (MI355X / CDNA4) HIP kernels.
+ *
+ * The reference (pierluigiferrari/ssd_keras) is pure Python and has no FFI of its own;
+ * each entry point below replaces the arithmetic of one of its Python callables, cited
+ * as file:line relative to the reference root.  The Python package `ssd_keras_amd`
+ * re-creates the reference's classes/functions on top of these calls (INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed or a torch CUDA tensor's data_ptr);
+ *   - the caller allocates all outputs and the scratch workspace (`*_workspace_bytes`);
+ *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and return at once: no allocation, no host sync, no global mutable state,
+ *     so they are re-entrant for distinct workspaces/streams and graph-capturable;
+ *   - tensors are dense row-major with the reference's layout: last axis of y_pred /
+ *     y_true = [C class scores (index 0 = background) | 4 offsets | 4 anchor coords |
+ *     4 variances];
+ *   - return value: SSDHIP_OK or a negative SSDHIP_E_* code (`ssdhip_strerror`).
+ */
+#ifndef SSDHIP_H
+#define SSDHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDHIP_ABI_VERSION 1
+
+enum {
+    SSDHIP_OK = 0,
+    SSDHIP_E_BADARG = -1,    /* inconsistent sizes / unsupported option combination */
+    SSDHIP_E_WORKSPACE = -2, /* ws == NULL or ws_bytes too small                      */
+    SSDHIP_E_LAUNCH = -3     /* hipGetLastError() after a launch was not hipSuccess   */
+};
+
+/* element types of tensors crossing the boundary */
+enum { SSDHIP_F32 = 0, SSDHIP_F64 = 1 };
+/* box coordinate formats (reference: 'centroids' (cx,cy,w,h), 'corners' (xmin,ymin,xmax,ymax),
+ * 'minmax' (xmin,xmax,ymin,ymax)) */
+enum { SSDHIP_CENTROIDS = 0, SSDHIP_CORNERS = 1, SSDHIP_MINMAX = 2 };
+/* border_pixels: 'half' d=0, 'include' d=+1, 'exclude' d=-1.  As in the reference's iou()
+ * (bounding_box_utils/bounding_box_utils.py:345) only the two box AREAS see d; the
+ * intersection is always computed with d = 0. */
+enum { SSDHIP_BORDER_HALF = 0, SSDHIP_BORDER_INCLUDE = 1, SSDHIP_BORDER_EXCLUDE = 2 };
+/* which reference callable's arithmetic the decoder follows */
+enum {
+    SSDHIP_SEM_NUMPY = 0,  /* ssd_encoder_decoder/ssd_output_decoder.py decode_detections(_fast):
+                              d*(var*a)+c decode, float64 IoU/compare for float32 input routed through
+                              convert_coordinates (centroids, minmax), input-dtype arithmetic for 'corners';
+                              unsorted top-k                                                              */
+    SSDHIP_SEM_KERAS = 1,  /* keras_layers/keras_layer_DecodeDetections(Fast).py: (d*var)*a+c decode,
+                              float32 strict '>' threshold, rows sorted by confidence, zero padded       */
+    SSDHIP_SEM_DEBUG = 2   /* decode_detections_debug (:342-467): (d*a)*var+c decode, otherwise NUMPY   */
+};
+
+int ssdhip_abi_version(void);
+const char* ssdhip_strerror(int rc);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder: box decode + confidence threshold + per-class (or class-agnostic) greedy NMS + top-k.
+ * Replaces ssd_output_decoder.py: decode_detections :111-226, decode_detections_fast :228-333,
+ * decode_detections_debug :342-467, _greedy_nms* :77-109, and the in-graph
+ * keras_layer_DecodeDetections.py:109-265 / keras_layer_DecodeDetectionsFast.py:111-248.
+ *
+ *   y_pred        [B, N, C+12] of `in_dtype` (SSDHIP_F32 today; F64 -> SSDHIP_E_BADARG)
+ *   C             number of classes INCLUDING background (class 0)
+ *   conf_thresh   candidates need score > conf_thresh (class_agnostic + SEM_NUMPY: >=, and class != 0)
+ *   iou_thresh    a box is dropped when IoU with an already kept box is NOT <= iou_thresh
+ *   top_k         rows kept per image by confidence; <= 0: keep all NMS survivors
+ *   nms_cap       max NMS survivors per class (tf.image.non_max_suppression max_output_size);
+ *                 <= 0: the reference-NumPy behaviour (uncapped, internally stops at top_k survivors
+ *                 per class when top_k > 0, which cannot change the top-k set)
+ *   class_agnostic 0: one NMS per (image, class 1..C-1); 1: class = first argmax, one NMS per image
+ *   out           [B, out_rows, 6] of `out_dtype`: class, conf, xmin, ymin, xmax, ymax; rows beyond
+ *                 out_count[b] are zero.  Row order: SEM_KERAS -> confidence descending (ties: lower
+ *                 class, then higher NMS rank first); otherwise class ascending / confidence descending
+ *                 when nothing had to be cut, else unspecified (the reference uses np.argpartition).
+ *   out_count     [B] valid rows per image
+ *   out_anchor_idx [B, out_rows] anchor index of each row (-1 padding) or NULL
+ */
+size_t ssdhip_decode_workspace_bytes(int B, int N, int C, int top_k, int nms_cap, int class_agnostic, int in_dtype);
+int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B, int N, int C,
+                             double conf_thresh, double iou_thresh, int top_k, int nms_cap,
+                             int class_agnostic, int semantics,
+                             int coords, int normalize_coords, double img_height, double img_width,
+                             int border_pixels,
+                             void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder: ground truth -> training targets.  Replaces SSDInputEncoder.__call__
+ * (ssd_encoder_decoder/ssd_input_encoder.py:277-418) including iou() (bounding_box_utils.py:283-383),
+ * match_bipartite_greedy / match_multi (matching_utils.py:22-116) and the template tiling
+ * (generate_encoding_template :550-611).  All arithmetic in float64 with the reference's operation order.
+ *
+ *   anchors       [N,4] float64, in `coords` format, exactly the values of SSDInputEncoder.boxes_list
+ *   variances     [4] float64
+ *   gt            [G_total,5] float64 rows class,xmin,ymin,xmax,ymax in absolute pixels ('corners'),
+ *                 images concatenated; gt_offsets [B+1] int32 CSR offsets (an image may have 0 rows)
+ *   matching_type 0 'bipartite', 1 'multi'
+ *   y_encoded_f32 / y_encoded_f64  [B,N,C+12] outputs, either may be NULL
+ *   match_gt      [B,N] int32: >=0 index (within the image) of the matched GT, -1 background,
+ *                 -2 neutral (class vector all zero); may be NULL
+ * Degenerate GT boxes (xmax<=xmin or ymax<=ymin) must be rejected by the caller (DegenerateBoxError).
+ */
+size_t ssdhip_encode_workspace_bytes(int B, int N, int C, int G_total);
+int ssdhip_encode(const double* anchors, const double* variances, const double* gt, const int* gt_offsets,
+                  int G_total, int B, int N, int C, double img_height, double img_width,
+                  int matching_type, double pos_iou_threshold, double neg_iou_limit,
+                  int coords, int normalize_coords, int border_pixels, int background_id,
+                  float* y_encoded_f32, double* y_encoded_f64, int* match_gt,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss: SSDLoss.compute_loss (keras_loss_function/keras_ssd_loss.py:98-211; smooth_L1_loss :53-75,
+ * log_loss :77-96), float32, hard-negative mining global over the batch it is given.
+ *
+ *   loss_per_item [B] float32
+ *   stats         [4] float32: n_positive, n_neg_losses, k (negatives kept), k-th largest negative loss
+ *   keep_mask     [B,N] uint8: 1 where the anchor's classification loss enters the sum
+ *                 (positive, or a kept hard negative) -- saved for backward
+ *   backward: grad_y_pred [B,N,C+12] = d(sum_b grad_out[b]*loss[b]) / d y_pred (last 8 columns zero)
+ */
+size_t ssdhip_loss_workspace_bytes(int B, int N, int C);
+int ssdhip_loss_forward(const float* y_true, const float* y_pred, int B, int N, int C,
+                        int neg_pos_ratio, int n_neg_min, float alpha,
+                        float* loss_per_item, float* stats, unsigned char* keep_mask,
+                        void* ws, size_t ws_bytes, void* stream);
+int ssdhip_loss_backward(const float* y_true, const float* y_pred, const unsigned char* keep_mask,
+                         const float* stats, const float* grad_out, int B, int N, int C, float alpha,
+                         float* grad_y_pred, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDHIP_H */

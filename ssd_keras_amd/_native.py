@@ -1,0 +1,162 @@
+"""ctypes binding of libssdhip.so (C ABI: include/ssdhip.h) + torch-side buffer plumbing.
+
+PyTorch is used for device memory and streams only: tensors' `data_ptr()` and the current
+HIP stream cross the boundary as plain pointers.  There is NO fallback: if the library
+is missing, or a tensor is not on a GPU, these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libssdhip.so")
+_lib = None
+_lock = threading.Lock()
+
+F32, F64 = 0, 1
+COORDS = {"centroids": 0, "corners": 1, "minmax": 2}
+BORDER = {"half": 0, "include": 1, "exclude": 2}
+SEM_NUMPY, SEM_KERAS, SEM_DEBUG = 0, 1, 2
+ABI_VERSION = 1
+
+
+class SsdHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libssdhip.so (once).  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise SsdHipError("libssdhip.so not found at %s: build it with `python -m ssd_keras_amd.build` "
+                              "(hipcc, gfx950).  ssd_keras_amd has no CPU fallback." % _LIB_PATH)
+        lib = ctypes.CDLL(_LIB_PATH)
+        c_int, c_dbl, c_vp, c_sz, c_flt = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float
+        lib.ssdhip_abi_version.restype = c_int
+        lib.ssdhip_abi_version.argtypes = []
+        lib.ssdhip_strerror.restype = ctypes.c_char_p
+        lib.ssdhip_strerror.argtypes = [c_int]
+        lib.ssdhip_decode_workspace_bytes.restype = c_sz
+        lib.ssdhip_decode_workspace_bytes.argtypes = [c_int] * 7
+        lib.ssdhip_decode_detections.restype = c_int
+        lib.ssdhip_decode_detections.argtypes = ([c_vp, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
+                                                  c_int, c_int, c_dbl, c_dbl, c_int,
+                                                  c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp])
+        if hasattr(lib, "ssdhip_encode"):
+            lib.ssdhip_encode_workspace_bytes.restype = c_sz
+            lib.ssdhip_encode_workspace_bytes.argtypes = [c_int] * 4
+            lib.ssdhip_encode.restype = c_int
+            lib.ssdhip_encode.argtypes = ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, c_dbl,
+                                           c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
+                                           c_vp, c_vp, c_vp, c_vp, c_sz, c_vp])
+        if hasattr(lib, "ssdhip_loss_forward"):
+            lib.ssdhip_loss_workspace_bytes.restype = c_sz
+            lib.ssdhip_loss_workspace_bytes.argtypes = [c_int] * 3
+            lib.ssdhip_loss_forward.restype = c_int
+            lib.ssdhip_loss_forward.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_flt,
+                                                c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]
+            lib.ssdhip_loss_backward.restype = c_int
+            lib.ssdhip_loss_backward.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_flt, c_vp, c_vp]
+        if lib.ssdhip_abi_version() != ABI_VERSION:
+            raise SsdHipError("libssdhip.so ABI %d != expected %d" % (lib.ssdhip_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SsdHipError("%s failed: %s (rc=%d)" % (what, load().ssdhip_strerror(rc).decode(), rc))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise SsdHipError("%s must live on a GPU (got device %s): ssd_keras_amd has no CPU path" % (name, t.device))
+    if not t.is_contiguous():
+        raise SsdHipError("%s must be contiguous" % name)
+
+
+def current_stream_ptr(device):
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _Workspaces:
+    """One growable scratch buffer per (device, purpose).  Kernels on one stream serialise, so a
+    buffer is reused across calls on that stream; callers running several streams pass their own."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, device, purpose, nbytes):
+        torch = _torch()
+        key = (str(device), purpose)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+workspaces = _Workspaces()
+
+
+def decode(y_pred, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords, normalize_coords,
+           img_height, img_width, border_pixels, out_dtype, out_rows, want_anchor_idx=False, workspace=None):
+    """Enqueue ssdhip_decode_detections on the current stream.
+    y_pred: CUDA float32 (B, N, C+12).  Returns (out (B,out_rows,6), count (B,) int32, anchor_idx or None)."""
+    torch = _torch()
+    lib = load()
+    require_cuda(y_pred, "y_pred")
+    if y_pred.dtype != torch.float32:
+        raise SsdHipError("y_pred must be float32 (float64 predictions are not built yet)")
+    B, N, L = y_pred.shape
+    C = L - 12
+    dev = y_pred.device
+    k = int(top_k) if top_k else 0
+    cap = int(nms_cap) if nms_cap else 0
+    need = lib.ssdhip_decode_workspace_bytes(B, N, C, k, cap, int(bool(class_agnostic)), F32)
+    if need == 0:
+        raise SsdHipError("unsupported decode shape B=%d N=%d C=%d" % (B, N, C))
+    ws = workspace if workspace is not None else workspaces.get(dev, "decode", need)
+    out = torch.empty((B, out_rows, 6), dtype=torch.float64 if out_dtype == F64 else torch.float32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    aidx = torch.empty((B, out_rows), dtype=torch.int32, device=dev) if want_anchor_idx else None
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_decode_detections(
+            ctypes.c_void_p(y_pred.data_ptr()), F32, B, N, C, float(conf_thresh), float(iou_thresh), k, cap,
+            int(bool(class_agnostic)), int(semantics), COORDS[coords], int(bool(normalize_coords)),
+            float(img_height if img_height is not None else 1.0), float(img_width if img_width is not None else 1.0),
+            BORDER[border_pixels], ctypes.c_void_p(out.data_ptr()), out_dtype, int(out_rows),
+            ctypes.c_void_p(count.data_ptr()), ctypes.c_void_p(aidx.data_ptr()) if aidx is not None else None,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), current_stream_ptr(dev))
+    check(rc, "ssdhip_decode_detections")
+    return out, count, aidx
+
+
+def to_device(a, device=None, dtype=None):
+    """NumPy array or torch tensor -> contiguous CUDA tensor (host buffers cross PCIe here)."""
+    torch = _torch()
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(a))
+    if device is None:
+        device = a.device if a.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    if dtype is not None and a.dtype != dtype:
+        a = a.to(dtype)
+    return a.to(device, non_blocking=False).contiguous()

@@ -1,0 +1,628 @@
+// ssdhip_decode.hip -- prediction decoding for SSD on gfx950 (MI355X).
+//
+// Replaces (reference pierluigiferrari/ssd_keras):
+//   ssd_encoder_decoder/ssd_output_decoder.py  decode_detections :111-226, decode_detections_fast :228-333,
+//                                              decode_detections_debug :342-467, _greedy_nms* :77-109
+//   keras_layers/keras_layer_DecodeDetections.py :109-265, keras_layer_DecodeDetectionsFast.py :111-248
+//
+// Three kernels per call, all enqueued on the caller's stream:
+//   K3 scan_kernel   grid (anchor tiles, B).  One coalesced pass over y_pred: each workgroup copies a
+//                    contiguous tile of rows into LDS, decodes the boxes (float32 'corners', one float4
+//                    per anchor) and appends every (class, anchor) pair over the confidence threshold to
+//                    that (image, class)'s candidate list as one sortable 64-bit key
+//                    [score bits | inverted anchor index].  Slots are reserved with one global atomic per
+//                    (workgroup, class); wave ballots give the positions inside the workgroup.
+//   K4 nms_kernel    one workgroup per (image, class) [or per image when class-agnostic], mapped so that
+//                    all classes of an image run on the same XCD (shared L2 for its boxes).  Repeats:
+//                    radix-select the next <= M best keys -> bitonic sort in LDS -> greedy NMS in batches
+//                    of 64 (each wave tests the batch against a quarter of the kept list, 64x64 in-batch
+//                    suppression masks by wave ballot, scalar resolve), until `cap` survivors or no
+//                    candidates are left.  IoU in float64 with IEEE division, exactly the reference's
+//                    operation order.
+//   K5 topk_kernel   one workgroup per image: global top-k over the per-class survivors (radix select on
+//                    [score | class-major position]), optional sort, zero padding, final rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+constexpr int IDX_BITS = 20;                 // anchor index field of a candidate key: N <= 2^20
+constexpr u32 IDX_MASK = (1u << IDX_BITS) - 1u;
+constexpr int DIGIT_BITS = 13;               // radix-select digit
+constexpr int NBINS = 1 << DIGIT_BITS;       // 8192 LDS counters = 32 KiB
+constexpr int NMS_THREADS = 256;
+constexpr int MAX_CHUNK = 2048;              // keys sorted per round in K4
+constexpr int KEPT_LDS = 512;                // survivors whose pixel boxes are cached in LDS
+constexpr int TOPK_SORT_MAX = 4096;          // rows K5 can return sorted
+
+struct DecodeParams {
+    int B, N, C, L, G;          // L = C + 12, G = groups per image (C-1, or 1 when class-agnostic)
+    int class_agnostic, semantics, coords, border;
+    int thr_f32, thr_inclusive; // threshold compare: in float32?  '>=' instead of '>'?
+    int iou_f32;                // NMS arithmetic in float32 (reference: float32 input + 'corners')
+    double conf_thresh, iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
+    int top_k, cap, cap_store, out_rows, sorted;
+};
+
+// ======================================================================================
+// K3
+// ======================================================================================
+template <int SEM>
+__device__ __forceinline__ float decode_center(float off, float var, float a_wh, float a_c) {
+    if (SEM == SSDHIP_SEM_KERAS) return (off * var) * a_wh + a_c;      // keras_layer_DecodeDetections.py:124-125
+    if (SEM == SSDHIP_SEM_DEBUG) return (off * a_wh) * var + a_c;      // ssd_output_decoder.py:400
+    return off * (var * a_wh) + a_c;                                   // ssd_output_decoder.py:177-178
+}
+
+__device__ __forceinline__ bool over_threshold(float s, const DecodeParams& p) {
+    if (p.thr_f32) {
+        const float t = (float)p.conf_thresh;
+        return p.thr_inclusive ? (s >= t) : (s > t);
+    }
+    const double t = p.conf_thresh;
+    return p.thr_inclusive ? ((double)s >= t) : ((double)s > t);
+}
+
+__global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, DecodeParams p,
+                                                   float4* __restrict__ boxes, u64* __restrict__ cand,
+                                                   int* __restrict__ cand_count, unsigned short* __restrict__ cls_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int TA = blockDim.x;                       // anchors per tile = threads per block
+    const int b = blockIdx.y;
+    const int a0 = blockIdx.x * TA;
+    const int na = min(TA, p.N - a0);
+    const int L = p.L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = TA >> 6;
+
+    // ---- coalesced tile copy: rows [a0, a0+na) are one contiguous run of na*L floats ----
+    const float* src = y + ((size_t)b * p.N + a0) * (size_t)L;
+    const int total = na * L;
+    const int phase = (int)(((uintptr_t)src & 15u) >> 2);         // keep the 16-byte phase of global memory in LDS
+    float* tile = reinterpret_cast<float*>(smem_raw) + phase;      // tile[i] <-> src[i]
+    int* wave_cnt = reinterpret_cast<int*>(smem_raw + (((size_t)TA * L + 4) * sizeof(float) + 15) / 16 * 16);
+    {
+        const int head = min(total, (4 - phase) & 3);
+        if (tid < head) tile[tid] = src[tid];
+        const int nvec = (total - head) >> 2;
+        const float4* vsrc = reinterpret_cast<const float4*>(src + head);
+        float4* vdst = reinterpret_cast<float4*>(tile + head);
+        for (int i = tid; i < nvec; i += TA) vdst[i] = vsrc[i];
+        const int done = head + (nvec << 2);
+        if (tid < total - done) tile[done + tid] = src[done + tid];
+    }
+    __syncthreads();
+
+    const bool active = tid < na;
+    const float* row = tile + (size_t)tid * L;
+    const int C = p.C;
+
+    // ---- decode this thread's box (float32, the reference's operation order) ----
+    int fast_cls = 0;
+    float fast_conf = 0.f;
+    if (active) {
+        const float o0 = row[C], o1 = row[C + 1], o2 = row[C + 2], o3 = row[C + 3];
+        const float a_0 = row[C + 4], a_1 = row[C + 5], a_2 = row[C + 6], a_3 = row[C + 7];
+        const float v0 = row[C + 8], v1 = row[C + 9], v2 = row[C + 10], v3 = row[C + 11];
+        float4 box;
+        if (p.coords == SSDHIP_CENTROIDS) {
+            float cx, cy;
+            if (p.semantics == SSDHIP_SEM_KERAS) {
+                cx = decode_center<SSDHIP_SEM_KERAS>(o0, v0, a_2, a_0);
+                cy = decode_center<SSDHIP_SEM_KERAS>(o1, v1, a_3, a_1);
+            } else if (p.semantics == SSDHIP_SEM_DEBUG) {
+                cx = decode_center<SSDHIP_SEM_DEBUG>(o0, v0, a_2, a_0);
+                cy = decode_center<SSDHIP_SEM_DEBUG>(o1, v1, a_3, a_1);
+            } else {
+                cx = decode_center<SSDHIP_SEM_NUMPY>(o0, v0, a_2, a_0);
+                cy = decode_center<SSDHIP_SEM_NUMPY>(o1, v1, a_3, a_1);
+            }
+            const float w = det_expf(o2 * v2) * a_2;
+            const float h = det_expf(o3 * v3) * a_3;
+            const float hw = w / 2.0f, hh = h / 2.0f;          // == 0.5f*w exactly
+            box = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);   // bounding_box_utils.py:76-80
+        } else if (p.coords == SSDHIP_MINMAX) {                    // anchors (xmin,xmax,ymin,ymax), :181-186
+            const float aw = a_1 - a_0, ah = a_3 - a_2;
+            const float t0 = (o0 * v0) * aw + a_0, t1 = (o1 * v1) * aw + a_1;
+            const float t2 = (o2 * v2) * ah + a_2, t3 = (o3 * v3) * ah + a_3;
+            box = make_float4(t0, t2, t1, t3);
+        } else {                                                   // corners, :187-191
+            const float aw = a_2 - a_0, ah = a_3 - a_1;
+            box = make_float4((o0 * v0) * aw + a_0, (o1 * v1) * ah + a_1, (o2 * v2) * aw + a_2, (o3 * v3) * ah + a_3);
+        }
+        boxes[(size_t)b * p.N + a0 + tid] = box;
+        if (p.class_agnostic) {                                    // first argmax / max over ALL classes, :291-293
+            float best = row[0];
+            int bi = 0;
+            for (int c = 1; c < C; ++c) {
+                const float s = row[c];
+                if (s > best || (best != best && s == s)) { best = s; bi = c; }
+            }
+            // np.argmax/np.amax propagate NaN (first NaN wins); mirror that
+            for (int c = 0; c < C; ++c) if (row[c] != row[c]) { best = row[c]; bi = c; break; }
+            fast_cls = bi;
+            fast_conf = best;
+            cls_out[(size_t)b * p.N + a0 + tid] = (unsigned short)bi;
+        }
+    }
+
+    // ---- pass 1: how many candidates does each wave hold per group ----
+    const int G = p.G;
+    for (int g = 0; g < G; ++g) {
+        bool pred = false;
+        if (active) {
+            if (p.class_agnostic) pred = (fast_cls != 0) && over_threshold(fast_conf, p);
+            else pred = over_threshold(row[g + 1], p);
+        }
+        const u64 m = __ballot(pred);
+        if (lane == 0) wave_cnt[wave * G + g] = __popcll(m);
+    }
+    __syncthreads();
+    // ---- one global atomic per (workgroup, group) reserves the slots ----
+    for (int g = tid; g < G; g += TA) {
+        int tot = 0;
+        for (int w = 0; w < nwaves; ++w) tot += wave_cnt[w * G + g];
+        int base = 0;
+        if (tot) base = atomicAdd(&cand_count[b * G + g], tot);
+        for (int w = 0; w < nwaves; ++w) {
+            const int c = wave_cnt[w * G + g];
+            wave_cnt[w * G + g] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: write the keys ----
+    const u64 lt = lanemask_lt();
+    const u32 inv_idx = IDX_MASK - (u32)(a0 + tid);
+    for (int g = 0; g < G; ++g) {
+        bool pred = false;
+        float s = 0.f;
+        if (active) {
+            if (p.class_agnostic) { s = fast_conf; pred = (fast_cls != 0) && over_threshold(s, p); }
+            else { s = row[g + 1]; pred = over_threshold(s, p); }
+        }
+        const u64 m = __ballot(pred);
+        if (pred) {
+            const int slot = wave_cnt[wave * G + g] + __popcll(m & lt);
+            cand[((size_t)b * G + g) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
+        }
+    }
+}
+
+// ======================================================================================
+// block-wide helpers (256 threads)
+// ======================================================================================
+// k-th largest (k >= 1) of {key : key < upper (if has_upper)} over a list in global memory.
+// `hist` = NBINS LDS counters, `red` = 260 LDS ints.  Keys are unique, so exactly k keys are >= result.
+template <int KEY_BITS, typename KeyF>
+__device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, int k, u32* hist, int* red) {
+    const int tid = threadIdx.x;
+    u64 prefix = 0, pmask = 0;
+    constexpr int NPASS = (KEY_BITS + DIGIT_BITS - 1) / DIGIT_BITS;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int shift = (NPASS - 1 - pass) * DIGIT_BITS;
+        for (int i = tid; i < NBINS; i += NMS_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += NMS_THREADS) {
+            const u64 key = key_at(i);
+            if (has_upper && !(key < upper)) continue;
+            if ((key & pmask) != prefix) continue;
+            atomicAdd(&hist[(u32)(key >> shift) & (NBINS - 1)], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins [t*32, t*32+32); suffix sums over threads locate the digit
+        constexpr int PER = NBINS / NMS_THREADS;
+        u32 local = 0;
+        for (int j = 0; j < PER; ++j) local += hist[tid * PER + j];
+        red[tid] = (int)local;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, t = NMS_THREADS - 1;
+            for (; t > 0; --t) {                    // counts of bins strictly above thread t's range
+                if (acc + red[t] >= k) break;
+                acc += red[t];
+            }
+            int d = t * PER + PER - 1;
+            for (; d > t * PER; --d) {
+                if (acc + (int)hist[d] >= k) break;
+                acc += (int)hist[d];
+            }
+            red[256] = d;
+            red[257] = acc;                        // number of keys with a larger digit
+        }
+        __syncthreads();
+        const int d = red[256];
+        k -= red[257];
+        prefix |= (u64)d << shift;
+        pmask |= (u64)(NBINS - 1) << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// in-LDS bitonic sort, descending, P a power of two >= 2 (P/2 compare-exchanges per step spread over the block)
+__device__ void block_bitonic_desc(u64* buf, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += NMS_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const u64 a = buf[i], b = buf[ixj];
+                const bool desc = (i & k) == 0;
+                if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ======================================================================================
+// K4
+// ======================================================================================
+template <typename F>
+__device__ __forceinline__ PxBox<F> px_box(const float4 bx, F W, F H, F d) {
+    PxBox<F> r;
+    r.x0 = (F)bx.x * W;                 // exact in double; the float32 product when F = float (corners flow)
+    r.y0 = (F)bx.y * H;
+    r.x1 = (F)bx.z * W;
+    r.y1 = (F)bx.w * H;
+    r.area = box_area<F>(r.x0, r.y0, r.x1, r.y1, d);
+    return r;
+}
+
+template <typename F>
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
+                                                          const u64* __restrict__ cand, const int* __restrict__ cand_count,
+                                                          u64* __restrict__ kept, int* __restrict__ kept_count) {
+    // XCD-aware work mapping: hardware places block x on XCD x%8; give every XCD a contiguous range of
+    // (image, class) work items so that all classes of an image share one L2.
+    const int total_work = p.B * p.G;
+    const int per_xcd = (total_work + 7) >> 3;
+    const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || work >= total_work) return;
+    const int b = work / p.G;
+
+    __shared__ __attribute__((aligned(16))) u64 sortbuf[NBINS * sizeof(u32) / sizeof(u64)];   // 32 KiB, aliased with hist
+    __shared__ PxBox<F> kcache[KEPT_LDS];
+    __shared__ PxBox<F> cbox[64];
+    __shared__ u64 maskrow[64];
+    __shared__ u64 supp_a[NMS_THREADS / 64];
+    __shared__ int red[260];
+    __shared__ int fill;
+    u32* hist = reinterpret_cast<u32*>(sortbuf);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = cand_count[work];
+    const u64* keys = cand + (size_t)work * p.N;
+    u64* kept_out = kept + (size_t)work * p.cap_store;
+    const float4* img_boxes = boxes + (size_t)b * p.N;
+    const F W = (F)p.img_w, H = (F)p.img_h;
+    const F d = p.border == SSDHIP_BORDER_INCLUDE ? (F)1 : (p.border == SSDHIP_BORDER_EXCLUDE ? (F)-1 : (F)0);
+    const F thr = (F)p.iou_thresh;
+    const int cap_eff = min(p.cap_store, n);
+
+    int K = 0, consumed = 0;
+    u64 upper = 0;
+    bool has_upper = false;
+    while (consumed < n && K < cap_eff) {
+        const int remaining = n - consumed;
+        // chunk size: enough for the survivors still wanted (x2 headroom for suppressed ones), a power of two
+        int want = 2 * (cap_eff - K);
+        int M = 256;
+        while (M < want && M < MAX_CHUNK) M <<= 1;
+        int m;
+        u64 cutoff = 0;
+        if (remaining <= M) {
+            m = remaining;
+        } else {
+            m = M;
+            cutoff = block_select_kth<32 + IDX_BITS>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
+        }
+        if (tid == 0) fill = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += NMS_THREADS) {
+            const u64 key = keys[i];
+            if (key >= cutoff && (!has_upper || key < upper)) sortbuf[atomicAdd(&fill, 1)] = key;
+        }
+        int P = 2;
+        while (P < m) P <<= 1;
+        __syncthreads();
+        for (int i = m + tid; i < P; i += NMS_THREADS) sortbuf[i] = 0;
+        __syncthreads();
+        block_bitonic_desc(sortbuf, P);
+        upper = sortbuf[m - 1];
+        has_upper = true;
+        consumed += m;
+
+        for (int base = 0; base < m && K < cap_eff; base += 64) {
+            const int nb = min(64, m - base);
+            const bool valid = lane < nb;
+            const u64 key = valid ? sortbuf[base + lane] : 0;
+            PxBox<F> me = {};
+            if (valid) me = px_box<F>(img_boxes[IDX_MASK - (u32)(key & IDX_MASK)], W, H, d);
+            if (wave == 0) cbox[lane] = me;
+            // phase A: against survivors of earlier batches, kept list striped over the waves
+            bool supp = false;
+            for (int j = wave; j < K; j += NMS_THREADS / 64) {
+                PxBox<F> kb;
+                if (j < KEPT_LDS) kb = kcache[j];
+                else kb = px_box<F>(img_boxes[IDX_MASK - (u32)(kept_out[j] & IDX_MASK)], W, H, d);
+                const F v = iou_px<F>(me, kb);
+                supp = supp || !(v <= thr);
+            }
+            const u64 sa = __ballot(supp && valid);
+            if (lane == 0) supp_a[wave] = sa;
+            __syncthreads();
+            // phase B: in-batch suppression rows, 16 per wave: bit i of maskrow[j] = "j suppresses i" (i > j)
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = wave * 16 + jj;
+                if (j >= nb) break;
+                const F v = iou_px<F>(me, cbox[j]);
+                const u64 mrow = __ballot(valid && lane > j && !(v <= thr));
+                if (lane == 0) maskrow[j] = mrow;
+            }
+            __syncthreads();
+            // resolve (every wave computes the same scalars)
+            u64 alive = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) & ~(supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3]);
+            u64 keptmask = 0;
+            int cnt = 0;
+            while (alive) {
+                const int j = __ffsll((long long)alive) - 1;
+                keptmask |= 1ull << j;
+                ++cnt;
+                if (K + cnt >= cap_eff) break;
+                alive &= ~maskrow[j];
+                alive &= ~(1ull << j);
+            }
+            if (wave == 0 && ((keptmask >> lane) & 1ull)) {
+                const int pos = K + __popcll(keptmask & lanemask_lt());
+                kept_out[pos] = key;
+                if (pos < KEPT_LDS) kcache[pos] = me;
+            }
+            K += cnt;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) kept_count[work] = K;
+}
+
+// ======================================================================================
+// K5
+// ======================================================================================
+template <typename OutT>
+__device__ __forceinline__ void write_row(OutT* out, int* out_idx, int row, int cls, u64 key, const float4* img_boxes,
+                                          const DecodeParams& p) {
+    const u32 idx = IDX_MASK - (u32)(key & IDX_MASK);
+    const float s = key_float((u32)(key >> IDX_BITS));
+    const float4 bx = img_boxes[idx];
+    OutT* r = out + (size_t)row * 6;
+    r[0] = (OutT)cls;
+    r[1] = (OutT)s;
+    if (p.iou_f32) {             // float32 flow end to end ('corners' + float32 input)
+        r[2] = (OutT)(bx.x * (float)p.img_w);
+        r[3] = (OutT)(bx.y * (float)p.img_h);
+        r[4] = (OutT)(bx.z * (float)p.img_w);
+        r[5] = (OutT)(bx.w * (float)p.img_h);
+    } else {
+        r[2] = (OutT)((double)bx.x * p.img_w);
+        r[3] = (OutT)((double)bx.y * p.img_h);
+        r[4] = (OutT)((double)bx.z * p.img_w);
+        r[5] = (OutT)((double)bx.w * p.img_h);
+    }
+    if (out_idx) out_idx[row] = (int)idx;
+}
+
+// entry e of the class-major concatenation of an image's survivor lists -> (group, rank)
+__device__ __forceinline__ int find_group(const int* offs, int G, int e) {
+    int lo = 0, hi = G;                  // offs[g] <= e < offs[g+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const float4* __restrict__ boxes,
+                                                           const u64* __restrict__ kept, const int* __restrict__ kept_count,
+                                                           const unsigned short* __restrict__ cls_map,
+                                                           OutT* __restrict__ out, int* __restrict__ out_count,
+                                                           int* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64* sortbuf = reinterpret_cast<u64*>(smem_raw);                       // 32 KiB (aliased with hist)
+    u32* hist = reinterpret_cast<u32*>(smem_raw);
+    int* offs = reinterpret_cast<int*>(smem_raw + NBINS * sizeof(u32));    // G+1 ints
+    __shared__ int red[260];
+    __shared__ int fill;
+    __shared__ int wave_tot[NMS_THREADS / 64];
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = p.G;
+    const float4* img_boxes = boxes + (size_t)b * p.N;
+    const u64* img_kept = kept + (size_t)b * G * p.cap_store;
+    OutT* img_out = out + (size_t)b * p.out_rows * 6;
+    int* img_idx = out_idx ? out_idx + (size_t)b * p.out_rows : nullptr;
+    const unsigned short* img_cls = p.class_agnostic ? cls_map + (size_t)b * p.N : nullptr;
+
+    if (tid == 0) {
+        int acc = 0;
+        for (int g = 0; g < G; ++g) { offs[g] = acc; acc += kept_count[b * G + g]; }
+        offs[G] = acc;
+    }
+    __syncthreads();
+    const int T = offs[G];
+    int rows = p.top_k > 0 ? min(T, p.top_k) : T;
+    rows = min(rows, p.out_rows);
+
+    // composite key of entry e: [score key (32) | inverted class-major position (32)] -> score desc, then class asc,
+    // then NMS rank asc -- tf.nn.top_k's tie order on the layer's class-major padded array.
+    auto comp_at = [&](int e) -> u64 {
+        const int g = find_group(offs, G, e);
+        const u64 key = img_kept[(size_t)g * p.cap_store + (e - offs[g])];
+        const u32 pos = (u32)g * (u32)p.cap_store + (u32)(e - offs[g]);
+        return ((key >> IDX_BITS) << 32) | (u64)(0xffffffffu - pos);
+    };
+    auto emit = [&](int row, u64 comp) {
+        const u32 pos = 0xffffffffu - (u32)comp;
+        const int g = (int)(pos / (u32)p.cap_store);
+        const u64 key = img_kept[(size_t)g * p.cap_store + (pos - (u32)g * (u32)p.cap_store)];
+        const int cls = p.class_agnostic ? (int)img_cls[IDX_MASK - (u32)(key & IDX_MASK)] : g + 1;
+        write_row<OutT>(img_out, img_idx, row, cls, key, img_boxes, p);
+    };
+
+    u64 cutoff = 0;
+    if (T > rows && rows > 0) cutoff = block_select_kth<64>(comp_at, T, 0, false, rows, hist, red);
+    __syncthreads();
+
+    if (rows > 0 && p.sorted) {
+        // collect the selected entries, sort them, write in order
+        if (tid == 0) fill = 0;
+        __syncthreads();
+        for (int e = tid; e < T; e += NMS_THREADS) {
+            const u64 c = comp_at(e);
+            if (c >= cutoff) sortbuf[atomicAdd(&fill, 1)] = c;
+        }
+        int P = 2;
+        while (P < rows) P <<= 1;
+        __syncthreads();
+        for (int i = rows + tid; i < P; i += NMS_THREADS) sortbuf[i] = 0;
+        __syncthreads();
+        block_bitonic_desc(sortbuf, P);
+        for (int r = tid; r < rows; r += NMS_THREADS) emit(r, sortbuf[r]);
+    } else if (rows > 0) {
+        // class-major order (the reference's order when nothing is cut); selected entries compacted by a block scan
+        int base = 0;
+        for (int e0 = 0; e0 < T; e0 += NMS_THREADS) {
+            const int e = e0 + tid;
+            u64 c = 0;
+            bool sel = false;
+            if (e < T) { c = comp_at(e); sel = c >= cutoff; }
+            const u64 m = __ballot(sel);
+            if (lane == 0) wave_tot[wave] = __popcll(m);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wave; ++w) off += wave_tot[w];
+            if (sel) emit(off + __popcll(m & lanemask_lt()), c);
+            for (int w = 0; w < NMS_THREADS / 64; ++w) base += wave_tot[w];
+            __syncthreads();
+        }
+    }
+    // zero padding
+    for (int i = rows * 6 + tid; i < p.out_rows * 6; i += NMS_THREADS) img_out[i] = (OutT)0;
+    if (img_idx) for (int i = rows + tid; i < p.out_rows; i += NMS_THREADS) img_idx[i] = -1;
+    if (tid == 0) out_count[b] = rows;
+}
+
+// ======================================================================================
+// host side
+// ======================================================================================
+struct DecodeWs {
+    size_t boxes, cand_count, kept_count, cls, cand, kept, total;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int cap_store_for(int N, int top_k, int nms_cap) {
+    int cap = N;                                   // uncapped: every candidate may survive
+    if (nms_cap > 0) cap = nms_cap < cap ? nms_cap : cap;
+    else if (top_k > 0) cap = top_k < cap ? top_k : cap;   // members of the global top-k are within a class's first top_k survivors
+    return cap < 1 ? 1 : cap;
+}
+
+static DecodeWs decode_ws_layout(int B, int N, int C, int top_k, int nms_cap, int class_agnostic) {
+    const size_t G = class_agnostic ? 1 : (size_t)(C - 1);
+    const size_t cap = (size_t)cap_store_for(N, top_k, nms_cap);
+    DecodeWs w;
+    size_t o = 0;
+    w.boxes = o;      o = align_up(o + (size_t)B * N * sizeof(float4), 256);
+    w.cand_count = o; o = align_up(o + (size_t)B * G * sizeof(int), 256);
+    w.kept_count = o; o = align_up(o + (size_t)B * G * sizeof(int), 256);
+    w.cls = o;        o = align_up(o + (class_agnostic ? (size_t)B * N * sizeof(unsigned short) : 0), 256);
+    w.cand = o;       o = align_up(o + (size_t)B * G * N * sizeof(u64), 256);
+    w.kept = o;       o = align_up(o + (size_t)B * G * cap * sizeof(u64), 256);
+    w.total = o;
+    return w;
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+extern "C" size_t ssdhip_decode_workspace_bytes(int B, int N, int C, int top_k, int nms_cap, int class_agnostic, int in_dtype) {
+    if (B <= 0 || N <= 0 || C < 2 || in_dtype != SSDHIP_F32) return 0;
+    return decode_ws_layout(B, N, C, top_k, nms_cap, class_agnostic).total;
+}
+
+extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B, int N, int C,
+                                        double conf_thresh, double iou_thresh, int top_k, int nms_cap,
+                                        int class_agnostic, int semantics,
+                                        int coords, int normalize_coords, double img_height, double img_width,
+                                        int border_pixels,
+                                        void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
+                                        void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!y_pred || !out || !out_count || B <= 0 || N <= 0 || C < 2 || out_rows <= 0) return SSDHIP_E_BADARG;
+    if (in_dtype != SSDHIP_F32) return SSDHIP_E_BADARG;           // float64 predictions: not built yet
+    if (out_dtype != SSDHIP_F32 && out_dtype != SSDHIP_F64) return SSDHIP_E_BADARG;
+    if (N > (1 << IDX_BITS) || C > 1025) return SSDHIP_E_BADARG;
+    if (coords < 0 || coords > 2 || border_pixels < 0 || border_pixels > 2) return SSDHIP_E_BADARG;
+    if (semantics < 0 || semantics > 2) return SSDHIP_E_BADARG;
+    if (semantics == SSDHIP_SEM_KERAS && coords != SSDHIP_CENTROIDS) return SSDHIP_E_BADARG;  // as the layer (:81-82)
+    const int sorted = semantics == SSDHIP_SEM_KERAS;
+    if (sorted && (top_k <= 0 || top_k > TOPK_SORT_MAX)) return SSDHIP_E_BADARG;
+    const DecodeWs lay = decode_ws_layout(B, N, C, top_k, nms_cap, class_agnostic);
+    if (!ws || ws_bytes < lay.total) return SSDHIP_E_WORKSPACE;
+
+    DecodeParams p;
+    p.B = B; p.N = N; p.C = C; p.L = C + 12; p.G = class_agnostic ? 1 : C - 1;
+    p.class_agnostic = class_agnostic ? 1 : 0;
+    p.semantics = semantics; p.coords = coords; p.border = border_pixels;
+    // dtype flow of the reference: float32 predictions stay float32 only on the 'corners' path (no convert_coordinates)
+    p.iou_f32 = (semantics != SSDHIP_SEM_KERAS && coords == SSDHIP_CORNERS) ? 1 : 0;
+    p.thr_f32 = (semantics == SSDHIP_SEM_KERAS || p.iou_f32) ? 1 : 0;
+    p.thr_inclusive = (class_agnostic && semantics != SSDHIP_SEM_KERAS) ? 1 : 0;   // ssd_output_decoder.py:325 vs layer :180
+    p.conf_thresh = conf_thresh; p.iou_thresh = iou_thresh;
+    p.img_w = normalize_coords ? img_width : 1.0;
+    p.img_h = normalize_coords ? img_height : 1.0;
+    p.top_k = top_k; p.cap = nms_cap; p.cap_store = cap_store_for(N, top_k, nms_cap);
+    p.out_rows = out_rows; p.sorted = sorted;
+
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    float4* boxes = reinterpret_cast<float4*>(base + lay.boxes);
+    int* cand_count = reinterpret_cast<int*>(base + lay.cand_count);
+    int* kept_count = reinterpret_cast<int*>(base + lay.kept_count);
+    unsigned short* cls_map = reinterpret_cast<unsigned short*>(base + lay.cls);
+    u64* cand = reinterpret_cast<u64*>(base + lay.cand);
+    u64* kept = reinterpret_cast<u64*>(base + lay.kept);
+
+    if (hipMemsetAsync(cand_count, 0, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+
+    // K3: tile = as many anchors as fit 64 KiB of LDS, 64..256 threads
+    int TA = 256;
+    while (TA > 64 && (size_t)TA * p.L * sizeof(float) > 64 * 1024) TA >>= 1;
+    const size_t k3_lds = align_up(((size_t)TA * p.L + 4) * sizeof(float), 16) + (size_t)(TA / 64) * p.G * sizeof(int);
+    if (k3_lds > 160 * 1024) return SSDHIP_E_BADARG;
+    dim3 g3((N + TA - 1) / TA, B);
+    hipLaunchKernelGGL(scan_kernel, g3, dim3(TA), k3_lds, stream, static_cast<const float*>(y_pred), p, boxes, cand,
+                       cand_count, cls_map);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+
+    const int work = B * p.G;
+    const int g4 = ((work + 7) / 8) * 8;
+    if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<float>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    else hipLaunchKernelGGL(nms_kernel<double>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+
+    const size_t k5_lds = NBINS * sizeof(u32) + align_up((size_t)(p.G + 1) * sizeof(int), 16);
+    if (out_dtype == SSDHIP_F32)
+        hipLaunchKernelGGL(topk_kernel<float>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
+                           static_cast<float*>(out), out_count, out_anchor_idx);
+    else
+        hipLaunchKernelGGL(topk_kernel<double>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
+                           static_cast<double*>(out), out_count, out_anchor_idx);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    return SSDHIP_OK;
+}

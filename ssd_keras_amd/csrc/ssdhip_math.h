@@ -1,0 +1,92 @@
+// Device-side leaf math shared by the decode / encode / loss kernels (gfx950 only).
+// Compiled with -ffp-contract=off: every + - * / below is one IEEE-754 operation, in the
+// order written, so results are reproducible against the CPU oracle bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ssdhip {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------------------
+// float32 exp through a fixed chain of float64 adds/multiplies (the reference decodes box
+// sizes with np.exp on float32, whose SIMD implementation is neither correctly rounded nor
+// the same on every host; this one is <= 0.5000001 ulp and identical everywhere).
+//   k = rint(x*log2 e);  r = x - k*ln2_hi - k*ln2_lo;  p = sum_{n<=13} r^n/n! (Horner);
+//   result = (float)(p * 2^k)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float det_expf(float xf) {
+    if (xf != xf) return xf;
+    double x = (double)xf;
+    x = x < -104.0 ? -104.0 : x;
+    x = x > 89.0 ? 89.0 : x;
+    const double t = x * 0x1.71547652b82fep+0 + 0x1.8p52;
+    const double k = t - 0x1.8p52;
+    const double r = (x - k * 0x1.62e42fee00000p-1) - k * 0x1.a39ef35793c76p-33;
+    double p = 0x1.6124613a86d09p-33;
+    p = p * r + 0x1.1eed8eff8d898p-29;
+    p = p * r + 0x1.ae64567f544e4p-26;
+    p = p * r + 0x1.27e4fb7789f5cp-22;
+    p = p * r + 0x1.71de3a556c734p-19;
+    p = p * r + 0x1.a01a01a01a01ap-16;
+    p = p * r + 0x1.a01a01a01a01ap-13;
+    p = p * r + 0x1.6c16c16c16c17p-10;
+    p = p * r + 0x1.1111111111111p-7;
+    p = p * r + 0x1.5555555555555p-5;
+    p = p * r + 0x1.5555555555555p-3;
+    p = p * r + 0x1.0000000000000p-1;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const long long ki = (long long)k;
+    const double scale = __longlong_as_double((ki + 1023LL) << 52);
+    return (float)(p * scale);
+}
+
+// ---------------------------------------------------------------------------------------
+// IoU of two 'corners' boxes exactly as bounding_box_utils.py:283-383 evaluates it in
+// 'element-wise' mode: intersection with d = 0 (the reference forgets to forward
+// border_pixels, :345), areas with d, union = (area_a + area_b) - inter, IEEE division.
+// ---------------------------------------------------------------------------------------
+template <typename F>
+struct PxBox {
+    F x0, y0, x1, y1, area;
+};
+
+template <typename F>
+__device__ __forceinline__ F clamp0(F v) { return v < (F)0 ? (F)0 : v; }   // np.maximum(0, v); NaN stays NaN
+
+template <typename F>
+__device__ __forceinline__ F box_area(F x0, F y0, F x1, F y1, F d) { return (x1 - x0 + d) * (y1 - y0 + d); }
+
+template <typename F>
+__device__ __forceinline__ F iou_px(const PxBox<F>& a, const PxBox<F>& b) {
+    const F ix0 = a.x0 > b.x0 ? a.x0 : b.x0;
+    const F iy0 = a.y0 > b.y0 ? a.y0 : b.y0;
+    const F ix1 = a.x1 < b.x1 ? a.x1 : b.x1;
+    const F iy1 = a.y1 < b.y1 ? a.y1 : b.y1;
+    const F iw = clamp0<F>(ix1 - ix0);
+    const F ih = clamp0<F>(iy1 - iy0);
+    const F inter = iw * ih;
+    const F uni = (a.area + b.area) - inter;
+    return inter / uni;
+}
+
+// order-preserving map float -> u32 (larger float <=> larger key; -0 < +0, NaNs at the ends)
+__device__ __forceinline__ u32 float_key(float f) {
+    const u32 u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(u32 k) {
+    const u32 u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ u64 lanemask_lt() {
+    const u32 lane = threadIdx.x & 63u;
+    return lane == 0 ? 0ull : (~0ull >> (64u - lane));
+}
+
+}  // namespace ssdhip

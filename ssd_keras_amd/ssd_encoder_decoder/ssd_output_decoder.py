@@ -1,0 +1,128 @@
+"""Drop-in for the reference's `ssd_encoder_decoder/ssd_output_decoder.py`, computed on the GPU.
+
+Same function names, keyword arguments, error behaviour and return containers as the
+reference (ssd_output_decoder.py:111-226 `decode_detections`, :228-333
+`decode_detections_fast`, :342-467 `decode_detections_debug`, :488-530 helpers); the
+arithmetic runs in libssdhip.so (`ssdhip_decode_detections`, include/ssdhip.h).
+
+`y_pred` may be a NumPy array (copied to the current GPU) or a CUDA torch tensor (used in
+place, no host round trip until the final, small result copy).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _native as nat
+
+
+def _as_device_f32(y_pred):
+    import torch
+    if isinstance(y_pred, np.ndarray):
+        if y_pred.dtype != np.float32:
+            raise TypeError("ssd_keras_amd decodes float32 predictions (what the model emits); got %s. "
+                            "float64 predictions are not supported yet." % y_pred.dtype)
+        return nat.to_device(y_pred)
+    if not torch.is_tensor(y_pred):
+        raise TypeError("y_pred must be a NumPy array or a torch tensor")
+    if y_pred.dtype != torch.float32:
+        raise TypeError("ssd_keras_amd decodes float32 predictions; got %s" % y_pred.dtype)
+    return nat.to_device(y_pred)
+
+
+def _check_common(y, normalize_coords, img_height, img_width, input_coords):
+    if normalize_coords and ((img_height is None) or (img_width is None)):
+        raise ValueError("If relative box coordinates are supposed to be converted to absolute coordinates, the decoder "
+                         "needs the image size in order to decode the predictions, but `img_height == {}` and "
+                         "`img_width == {}`".format(img_height, img_width))
+    if input_coords not in nat.COORDS:
+        raise ValueError("Unexpected value for `input_coords`. Supported input coordinate formats are 'minmax', "
+                         "'corners' and 'centroids'.")
+    if y.dim() != 3 or y.shape[2] < 14:
+        raise ValueError("y_pred must have shape (batch, #boxes, #classes + 12)")
+
+
+def _to_list(out, count, aidx=None, empty_1d=True):
+    out = out.cpu().numpy()
+    count = count.cpu().numpy()
+    aidx = aidx.cpu().numpy() if aidx is not None else None
+    res = []
+    for b in range(out.shape[0]):
+        k = int(count[b])
+        if k == 0 and empty_1d:
+            res.append(np.array([]))                  # the reference's container for "nothing left" (:223)
+            continue
+        rows = out[b, :k].astype(np.float64, copy=True)
+        if aidx is not None:
+            rows = np.concatenate([aidx[b, :k, None].astype(np.float64), rows], axis=1)
+        res.append(rows)
+    return res
+
+
+def decode_detections(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=200, input_coords='centroids',
+                      normalize_coords=True, img_height=None, img_width=None, border_pixels='half'):
+    '''Reference: ssd_output_decoder.py:111-226.  Per image and per non-background class: strict `>`
+    confidence threshold, greedy NMS (float64 IoU, keep `<= iou_threshold`), then the `top_k` most
+    confident rows.  Returns a list of `batch_size` float64 arrays `(k, 6)`
+    `[class_id, confidence, xmin, ymin, xmax, ymax]`; `np.array([])` for an image with nothing left.'''
+    y = _as_device_f32(y_pred)
+    _check_common(y, normalize_coords, img_height, img_width, input_coords)
+    B, N, L = y.shape
+    k = 0 if top_k == 'all' else int(top_k)
+    rows = (L - 13) * N if k == 0 else k
+    out, count, _ = nat.decode(y, confidence_thresh, iou_threshold, k, 0, False, nat.SEM_NUMPY, input_coords,
+                               normalize_coords, img_height, img_width, border_pixels, nat.F64, rows)
+    return _to_list(out, count)
+
+
+def decode_detections_fast(y_pred, confidence_thresh=0.5, iou_threshold=0.45, top_k='all', input_coords='centroids',
+                           normalize_coords=True, img_height=None, img_width=None, border_pixels='half'):
+    '''Reference: ssd_output_decoder.py:228-333.  Class = first argmax over all scores, background
+    dropped, `>=` confidence threshold, one class-agnostic NMS (skipped when `iou_threshold` is falsy).'''
+    y = _as_device_f32(y_pred)
+    _check_common(y, normalize_coords, img_height, img_width, input_coords)
+    B, N, L = y.shape
+    k = 0 if top_k == 'all' else int(top_k)
+    rows = N if k == 0 else k
+    no_nms = not iou_threshold
+    out, count, aidx = nat.decode(y, confidence_thresh, float('inf') if no_nms else iou_threshold, k, 0, True,
+                                  nat.SEM_NUMPY, input_coords, normalize_coords, img_height, img_width, border_pixels,
+                                  nat.F64, rows, want_anchor_idx=no_nms)
+    if no_nms:       # the reference leaves the rows in anchor order when it skips NMS
+        res = _to_list(out, count, aidx, empty_1d=False)
+        return [r[np.argsort(r[:, 0], kind='stable')][:, 1:] if r.shape[0] else np.zeros((0, 6)) for r in res]
+    return _to_list(out, count)
+
+
+def decode_detections_debug(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=200, input_coords='centroids',
+                            normalize_coords=True, img_height=None, img_width=None, variance_encoded_in_target=False,
+                            border_pixels='half'):
+    '''Reference: ssd_output_decoder.py:342-467.  As `decode_detections`, rows
+    `[box_id, class_id, confidence, xmin, ymin, xmax, ymax]`.'''
+    if variance_encoded_in_target:
+        raise NotImplementedError("variance_encoded_in_target=True is not supported")
+    y = _as_device_f32(y_pred)
+    _check_common(y, normalize_coords, img_height, img_width, input_coords)
+    out, count, aidx = nat.decode(y, confidence_thresh, iou_threshold, int(top_k), 0, False, nat.SEM_DEBUG, input_coords,
+                                  normalize_coords, img_height, img_width, border_pixels, nat.F64, int(top_k),
+                                  want_anchor_idx=True)
+    return _to_list(out, count, aidx, empty_1d=False)
+
+
+def get_num_boxes_per_pred_layer(predictor_sizes, aspect_ratios, two_boxes_for_ar1):
+    '''Reference: ssd_output_decoder.py:488-501.'''
+    return [int(predictor_sizes[i][0]) * int(predictor_sizes[i][1]) * (len(aspect_ratios[i]) + (1 if two_boxes_for_ar1 else 0))
+            for i in range(len(predictor_sizes))]
+
+
+def get_pred_layers(y_pred_decoded, num_boxes_per_pred_layer):
+    '''Reference: ssd_output_decoder.py:503-530: predictor layer of every row of a
+    `decode_detections_debug` result (host-side bookkeeping).'''
+    edges = np.cumsum(num_boxes_per_pred_layer)
+    res = []
+    for item in y_pred_decoded:
+        ids = np.asarray(item)[:, 0] if len(item) else np.zeros((0,))
+        if np.any(ids < 0) or np.any(ids >= edges[-1]):
+            raise ValueError("Box index is out of bounds of the possible indices as given by the values in "
+                             "`num_boxes_per_pred_layer`.")
+        res.append([int(v) for v in np.searchsorted(edges, ids, side='right')])
+    return res
