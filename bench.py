@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement: images/sec of SSD300 (VGG-16, 21 classes) forward + in-graph
+decode (DecodeDetections: threshold 0.01, NMS 0.45, top-200) at batch 32 per GPU, synthetic
+300x300x3 batches resident in HBM, random-init weights (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32]
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); the data path has no
+collective (every rank decodes its own 32 images: weak scaling), the barrier + max-over-ranks timing does.
+Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      the dominant hand-written kernel of the decode path against HBM bandwidth: algorithmic bytes of
+                the decode path per launch (N*(C+12)*4 read + top_k*6*4 written per image) / that
+                kernel's average launch duration, measured with events on the launch stream;
+  cpu_baseline  the NumPy port of the reference decoder (oracle/np_oracle.py) timed on this box's host cores on a
+                bounded sample of the same predictions (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+SSD300_FWD_GFLOP_PER_IMG = 62.747
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="images for the CPU baseline (0: auto, ~10-30 s)")
+    return ap.parse_args()
+
+
+def event_ms(fn, reps):
+    """Average milliseconds of `fn()` over `reps` back-to-back launches, events on the current stream."""
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / reps
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from ssd_keras_amd import _native as nat
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    nat.load()                                    # fail loudly when the HIP library is missing
+
+    B = args.batch
+    torch.manual_seed(1234 + rank)
+    cfg = syn.SSD300_VOC
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="inference", scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"],
+                    confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400).to(dev)
+    model = model.to(memory_format=torch.channels_last).eval()
+    if args.dtype == "bf16":
+        model = model.to(torch.bfloat16)
+    torch.backends.cudnn.benchmark = True
+    rng = np.random.RandomState(rank)
+    images = torch.from_numpy(rng.randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(images)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # ---- timed region: exactly K steps ---------------------------------------------------------
+    dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        with torch.no_grad():
+            pred = model.raw_predictions(images)
+            dec_ev[i][0].record()
+            out = model.decoder(pred)
+            dec_ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    decode_ms_in_step = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
+
+    # ---- per-kernel timing of the decode path on the step's own predictions ----------------------
+    N, C = pred.shape[1], pred.shape[2] - 12
+    algo_bytes = B * (N * (C + 12) * 4 + 200 * 6 * 4)
+    d = model.decoder
+    dkw = dict(conf_thresh=d.confidence_thresh, iou_thresh=d.iou_threshold, top_k=d.top_k, nms_cap=d.nms_max_output_size,
+               class_agnostic=False, semantics=nat.SEM_KERAS, coords="centroids", normalize_coords=True,
+               img_height=300, img_width=300, border_pixels="half", out_dtype=nat.F32, out_rows=d.top_k)
+    outs = nat.decode(pred, **dkw)
+    reps = 50
+    stage_ms = {}
+    for name, mask in (("scan_kernel", 1), ("nms_kernel<double>", 2), ("topk_kernel<float>", 4), ("decode_path", 7)):
+        nat.decode(pred, stages=mask, outputs=outs, **dkw)
+        torch.cuda.synchronize()
+        stage_ms[name] = event_ms(lambda m=mask: nat.decode(pred, stages=m, outputs=outs, **dkw), reps)
+    fwd_ms = event_ms(lambda: model.raw_predictions(images), 10) if True else 0.0
+    dom = max(("scan_kernel", "nms_kernel<double>", "topk_kernel<float>"), key=lambda k: stage_ms[k])
+    achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "decode_pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                "decode_ms_in_step": round(decode_ms_in_step, 5),
+                "decode_path_GBps": round(algo_bytes / (stage_ms["decode_path"] * 1e-3) / 1e9, 2)}
+    conv_tflops = B * SSD300_FWD_GFLOP_PER_IMG / 1e3 / (fwd_ms * 1e-3)
+    conv = {"bound": "mfma", "forward_ms": round(fwd_ms, 4), "achieved": round(conv_tflops, 2),
+            "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(conv_tflops / MFMA_PEAK_TFLOPS[args.dtype], 5),
+            "note": "PyTorch-ROCm (MIOpen) convolutions, %s" % args.dtype}
+
+    # ---- CPU baseline: NumPy port of the reference decoder on a bounded sample (rank 0, N=1) -----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import np_oracle as orc
+        y_host = pred.float().cpu().numpy()
+        kw = dict(confidence_thresh=0.01, iou_threshold=0.45, top_k=200, normalize_coords=True, img_height=300, img_width=300)
+        t = time.perf_counter()
+        orc.decode_detections(y_host[:1], **kw)
+        one = time.perf_counter() - t
+        n_img = args.cpu_sample or int(max(1, min(B, round(15.0 / max(one, 1e-3)))))
+        t = time.perf_counter()
+        ref = orc.decode_detections(y_host[:n_img], **kw)
+        cpu_s = time.perf_counter() - t
+        cpu = {"value": round(n_img / cpu_s, 4), "unit": "images/sec (decode_detections only)", "cores": 1, "kind": "port",
+               "ms_per_img": round(1e3 * cpu_s / n_img, 3),
+               "sample": "oracle/np_oracle.decode_detections (NumPy port of ssd_output_decoder.py:111-226) on the first %d of "
+                         "%d images of the step's own predictions (random-init weights: every anchor passes 0.01 -> dense "
+                         "regime); the forward pass has no CPU reference here (TensorFlow absent)" % (n_img, B),
+               "gpu_decode_ms_per_img": round(stage_ms["decode_path"] / B, 5),
+               "speedup_decode": round((cpu_s / n_img) / (stage_ms["decode_path"] * 1e-3 / B), 1),
+               "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        ips = world * B * args.steps / elapsed
+        line = {"metric": "images/sec SSD300 fwd+decode @batch32", "value": round(ips, 2), "unit": "images/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "SSD300 VGG-16 inference (mode='inference': forward + DecodeDetections), 21 classes, "
+                                       "batch %d per GPU, conf 0.01 / NMS 0.45 / top-200, random-init weights, synthetic "
+                                       "300x300x3 uint8-range images" % B,
+                           "per_gpu_batch": B, "global_batch": world * B, "anchors": int(N), "classes": int(C),
+                           "conv_dtype": args.dtype, "decode_dtype": "f32 decode, f64 IoU", "parallelism": "replicas x%d" % world},
+                "roofline": roofline, "conv_roofline": conv, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,16 @@ int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B, int N, int
                              int border_pixels,
                              void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
                              void* ws, size_t ws_bytes, void* stream);
+/* Profiling aid: run only the selected kernels of the decoder on the state left in `ws` by the previous ones.
+ * stages: bit 0 = scan (decode + threshold + candidate lists), bit 1 = per-class NMS, bit 2 = top-k/output.
+ * `ssdhip_decode_detections` == stages 7.  Used by bench.py to time each kernel with events on the stream. */
+int ssdhip_decode_stages(int stages, const void* y_pred, int in_dtype, int B, int N, int C,
+                         double conf_thresh, double iou_thresh, int top_k, int nms_cap,
+                         int class_agnostic, int semantics,
+                         int coords, int normalize_coords, double img_height, double img_width,
+                         int border_pixels,
+                         void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder: ground truth -> training targets.  Replaces SSDInputEncoder.__call__

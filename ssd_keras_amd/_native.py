@@ -54,6 +54,8 @@ def load():
         lib.ssdhip_decode_detections.argtypes = ([c_vp, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
                                                   c_int, c_int, c_dbl, c_dbl, c_int,
                                                   c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp])
+        lib.ssdhip_decode_stages.restype = c_int
+        lib.ssdhip_decode_stages.argtypes = [c_int] + lib.ssdhip_decode_detections.argtypes
         if hasattr(lib, "ssdhip_encode"):
             lib.ssdhip_encode_workspace_bytes.restype = c_sz
             lib.ssdhip_encode_workspace_bytes.argtypes = [c_int] * 4
@@ -118,7 +120,8 @@ workspaces = _Workspaces()
 
 
 def decode(y_pred, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords, normalize_coords,
-           img_height, img_width, border_pixels, out_dtype, out_rows, want_anchor_idx=False, workspace=None):
+           img_height, img_width, border_pixels, out_dtype, out_rows, want_anchor_idx=False, workspace=None,
+           stages=7, outputs=None):
     """Enqueue ssdhip_decode_detections on the current stream.
     y_pred: CUDA float32 (B, N, C+12).  Returns (out (B,out_rows,6), count (B,) int32, anchor_idx or None)."""
     torch = _torch()
@@ -135,12 +138,15 @@ def decode(y_pred, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, sema
     if need == 0:
         raise SsdHipError("unsupported decode shape B=%d N=%d C=%d" % (B, N, C))
     ws = workspace if workspace is not None else workspaces.get(dev, "decode", need)
-    out = torch.empty((B, out_rows, 6), dtype=torch.float64 if out_dtype == F64 else torch.float32, device=dev)
-    count = torch.empty((B,), dtype=torch.int32, device=dev)
-    aidx = torch.empty((B, out_rows), dtype=torch.int32, device=dev) if want_anchor_idx else None
+    if outputs is not None:
+        out, count, aidx = outputs
+    else:
+        out = torch.empty((B, out_rows, 6), dtype=torch.float64 if out_dtype == F64 else torch.float32, device=dev)
+        count = torch.empty((B,), dtype=torch.int32, device=dev)
+        aidx = torch.empty((B, out_rows), dtype=torch.int32, device=dev) if want_anchor_idx else None
     with torch.cuda.device(dev):
-        rc = lib.ssdhip_decode_detections(
-            ctypes.c_void_p(y_pred.data_ptr()), F32, B, N, C, float(conf_thresh), float(iou_thresh), k, cap,
+        rc = lib.ssdhip_decode_stages(
+            int(stages), ctypes.c_void_p(y_pred.data_ptr()), F32, B, N, C, float(conf_thresh), float(iou_thresh), k, cap,
             int(bool(class_agnostic)), int(semantics), COORDS[coords], int(bool(normalize_coords)),
             float(img_height if img_height is not None else 1.0), float(img_width if img_width is not None else 1.0),
             BORDER[border_pixels], ctypes.c_void_p(out.data_ptr()), out_dtype, int(out_rows),

@@ -556,13 +556,13 @@ extern "C" size_t ssdhip_decode_workspace_bytes(int B, int N, int C, int top_k, 
     return decode_ws_layout(B, N, C, top_k, nms_cap, class_agnostic).total;
 }
 
-extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B, int N, int C,
-                                        double conf_thresh, double iou_thresh, int top_k, int nms_cap,
-                                        int class_agnostic, int semantics,
-                                        int coords, int normalize_coords, double img_height, double img_width,
-                                        int border_pixels,
-                                        void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
-                                        void* ws, size_t ws_bytes, void* stream_) {
+static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N, int C,
+                      double conf_thresh, double iou_thresh, int top_k, int nms_cap,
+                      int class_agnostic, int semantics,
+                      int coords, int normalize_coords, double img_height, double img_width,
+                      int border_pixels,
+                      void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
+                      void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!y_pred || !out || !out_count || B <= 0 || N <= 0 || C < 2 || out_rows <= 0) return SSDHIP_E_BADARG;
     if (in_dtype != SSDHIP_F32) return SSDHIP_E_BADARG;           // float64 predictions: not built yet
@@ -598,6 +598,7 @@ extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B,
     u64* cand = reinterpret_cast<u64*>(base + lay.cand);
     u64* kept = reinterpret_cast<u64*>(base + lay.kept);
 
+    if (stages & 1) {
     if (hipMemsetAsync(cand_count, 0, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
 
     // K3: tile = as many anchors as fit 64 KiB of LDS, 64..256 threads
@@ -609,13 +610,17 @@ extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B,
     hipLaunchKernelGGL(scan_kernel, g3, dim3(TA), k3_lds, stream, static_cast<const float*>(y_pred), p, boxes, cand,
                        cand_count, cls_map);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    }
 
+    if (stages & 2) {
     const int work = B * p.G;
     const int g4 = ((work + 7) / 8) * 8;
     if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<float>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
     else hipLaunchKernelGGL(nms_kernel<double>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    }
 
+    if (stages & 4) {
     const size_t k5_lds = NBINS * sizeof(u32) + align_up((size_t)(p.G + 1) * sizeof(int), 16);
     if (out_dtype == SSDHIP_F32)
         hipLaunchKernelGGL(topk_kernel<float>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
@@ -624,5 +629,31 @@ extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B,
         hipLaunchKernelGGL(topk_kernel<double>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
                            static_cast<double*>(out), out_count, out_anchor_idx);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    }
     return SSDHIP_OK;
+}
+
+extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B, int N, int C,
+                                        double conf_thresh, double iou_thresh, int top_k, int nms_cap,
+                                        int class_agnostic, int semantics,
+                                        int coords, int normalize_coords, double img_height, double img_width,
+                                        int border_pixels,
+                                        void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    return decode_run(7, y_pred, in_dtype, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords,
+                      normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
+                      out_anchor_idx, ws, ws_bytes, stream);
+}
+
+extern "C" int ssdhip_decode_stages(int stages, const void* y_pred, int in_dtype, int B, int N, int C,
+                                    double conf_thresh, double iou_thresh, int top_k, int nms_cap,
+                                    int class_agnostic, int semantics,
+                                    int coords, int normalize_coords, double img_height, double img_width,
+                                    int border_pixels,
+                                    void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (stages <= 0 || stages > 7) return SSDHIP_E_BADARG;
+    return decode_run(stages, y_pred, in_dtype, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,
+                      coords, normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
+                      out_anchor_idx, ws, ws_bytes, stream);
 }

@@ -1,0 +1,31 @@
+"""`L2Normalization` -- drop-in for keras_layers/keras_layer_L2Normalization.py:25-70 as a torch module.
+
+`K.l2_normalize(x, axis=channels) * gamma` with TensorFlow's epsilon placement:
+x * rsqrt(max(sum_c x^2, 1e-12)), gamma a learnable per-channel scale initialised to 20.
+Operates on NCHW tensors (channels_last memory keeps the reduction contiguous).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class L2Normalization(nn.Module):
+    def __init__(self, gamma_init=20, n_channels=None, **kwargs):
+        super().__init__()
+        self.gamma_init = gamma_init
+        self.name = kwargs.get('name')
+        self.gamma = nn.Parameter(torch.full((n_channels,), float(gamma_init))) if n_channels else None
+
+    def build(self, n_channels, device=None):
+        self.gamma = nn.Parameter(torch.full((n_channels,), float(self.gamma_init), device=device))
+
+    def forward(self, x):
+        if self.gamma is None:
+            self.build(x.shape[1], x.device)
+        xf = x.float()
+        inv = torch.rsqrt(torch.clamp_min((xf * xf).sum(dim=1, keepdim=True), 1e-12))
+        return (xf * inv * self.gamma.view(1, -1, 1, 1)).to(x.dtype)
+
+    def get_config(self):
+        return {'gamma_init': self.gamma_init}

@@ -1,0 +1,164 @@
+"""Shared machinery of the SSD model builders (reference models/keras_ssd300.py:200-457 and twins).
+
+PyTorch-ROCm runs the convolutional stack (MIOpen / MFMA); this module only adds what the
+reference's graph does around it: in-graph input normalisation, NHWC-ordered head reshapes so
+the anchor axis factorises exactly like Keras' `Reshape((-1, n_classes))`, the resident anchor
+constant, softmax, the `(B, N, C+12)` prediction layout and the optional decode layer.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..anchor_math import n_boxes_for
+from ..keras_layers.keras_layer_AnchorBoxes import AnchorBoxes
+from ..keras_layers.keras_layer_DecodeDetections import DecodeDetections
+from ..keras_layers.keras_layer_DecodeDetectionsFast import DecodeDetectionsFast
+
+
+def conv_out(n, k, s=1, p=0, d=1):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def pool_out(n, k, s, p=0, ceil_mode=False):
+    if ceil_mode:
+        o = -(-(n + 2 * p - k) // s) + 1
+        if (o - 1) * s >= n + p:
+            o -= 1
+        return o
+    return (n + 2 * p - k) // s + 1
+
+
+def he_normal_(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_in', nonlinearity='relu')   # Keras 'he_normal'
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+
+def resolve_anchor_config(n_predictor_layers, min_scale, max_scale, scales, aspect_ratios_global,
+                          aspect_ratios_per_layer, two_boxes_for_ar1, steps, offsets, variances):
+    """The argument checks and defaults of the builders (keras_ssd300.py:178-237)."""
+    if aspect_ratios_global is None and aspect_ratios_per_layer is None:
+        raise ValueError("`aspect_ratios_global` and `aspect_ratios_per_layer` cannot both be None. At least one needs to be specified.")
+    if aspect_ratios_per_layer:
+        if len(aspect_ratios_per_layer) != n_predictor_layers:
+            raise ValueError("It must be either aspect_ratios_per_layer is None or len(aspect_ratios_per_layer) == {}, but "
+                             "len(aspect_ratios_per_layer) == {}.".format(n_predictor_layers, len(aspect_ratios_per_layer)))
+    if (min_scale is None or max_scale is None) and scales is None:
+        raise ValueError("Either `min_scale` and `max_scale` or `scales` need to be specified.")
+    if scales:
+        if len(scales) != n_predictor_layers + 1:
+            raise ValueError("It must be either scales is None or len(scales) == {}, but len(scales) == {}.".format(
+                n_predictor_layers + 1, len(scales)))
+    else:
+        scales = np.linspace(min_scale, max_scale, n_predictor_layers + 1)
+    if len(variances) != 4:
+        raise ValueError("4 variance values must be pased, but {} values were received.".format(len(variances)))
+    if np.any(np.array(variances) <= 0):
+        raise ValueError("All variances must be >0, but the variances given are {}".format(variances))
+    if (steps is not None) and (len(steps) != n_predictor_layers):
+        raise ValueError("You must provide at least one step value per predictor layer.")
+    if (offsets is not None) and (len(offsets) != n_predictor_layers):
+        raise ValueError("You must provide at least one offset value per predictor layer.")
+    ars = aspect_ratios_per_layer if aspect_ratios_per_layer else [aspect_ratios_global] * n_predictor_layers
+    n_boxes = [n_boxes_for(ar, two_boxes_for_ar1) for ar in ars]
+    steps = steps if steps is not None else [None] * n_predictor_layers
+    offsets = offsets if offsets is not None else [None] * n_predictor_layers
+    return list(scales), ars, n_boxes, steps, offsets
+
+
+class SSDModel(nn.Module):
+    """Base class: subclasses define `features(x) -> list of predictor feature maps` plus
+    `conf_heads`, `loc_heads` (ModuleLists) and `priorboxes` (ModuleList of AnchorBoxes)."""
+
+    def __init__(self, image_size, n_classes, mode, l2_regularization, subtract_mean, divide_by_stddev, swap_channels,
+                 confidence_thresh, iou_threshold, top_k, nms_max_output_size, coords, normalize_coords):
+        super().__init__()
+        if mode not in ('training', 'inference', 'inference_fast'):
+            raise ValueError("`mode` must be one of 'training', 'inference' or 'inference_fast', but received '{}'.".format(mode))
+        self.img_height, self.img_width, self.img_channels = image_size
+        self.n_classes = n_classes + 1               # incl. background, as in the reference (:175)
+        self.mode = mode
+        self.l2_regularization = l2_regularization
+        self.subtract_mean = subtract_mean
+        self.divide_by_stddev = divide_by_stddev
+        self.swap_channels = swap_channels
+        self.decoder = None
+        if mode != 'training':
+            layer = DecodeDetections if mode == 'inference' else DecodeDetectionsFast
+            self.decoder = layer(confidence_thresh=confidence_thresh, iou_threshold=iou_threshold, top_k=top_k,
+                                 nms_max_output_size=nms_max_output_size, coords=coords,
+                                 normalize_coords=normalize_coords, img_height=self.img_height,
+                                 img_width=self.img_width, name='decoded_predictions')
+        self._anchor_cache = {}
+
+    # -- in-graph input pipeline (keras_ssd300.py:247-272): NHWC 0..255 -> normalised NCHW (channels_last memory) --
+    def preprocess(self, images):
+        x = images
+        if x.dim() != 4:
+            raise ValueError("expected images of shape (batch, height, width, channels)")
+        if x.shape[-1] == self.img_channels and x.shape[1] != self.img_channels:
+            x = x.permute(0, 3, 1, 2)                # NHWC storage == channels_last NCHW: no copy
+        x = x.float()
+        if self.subtract_mean is not None:
+            x = x - torch.as_tensor(self.subtract_mean, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+        if self.divide_by_stddev is not None:
+            x = x / torch.as_tensor(self.divide_by_stddev, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+        if self.swap_channels:
+            x = x[:, list(self.swap_channels)]
+        return x.contiguous(memory_format=torch.channels_last)
+
+    def anchors_and_variances(self, feature_sizes, device):
+        """(N, 8) float32 constant, resident per device."""
+        key = (tuple(feature_sizes), str(device))
+        t = self._anchor_cache.get(key)
+        if t is None:
+            t = torch.cat([pb.constant(h, w, device).reshape(-1, 8) for pb, (h, w) in zip(self.priorboxes, feature_sizes)], dim=0)
+            self._anchor_cache[key] = t
+        return t
+
+    def predictor_sizes(self):
+        raise NotImplementedError
+
+    def raw_predictions(self, images):
+        x = self.preprocess(images)
+        dtype = next(self.parameters()).dtype
+        feats = self.features(x.to(dtype) if not torch.is_autocast_enabled() else x)
+        b = x.shape[0]
+        confs, locs, sizes = [], [], []
+        for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads):
+            # NCHW -> NHWC before the reshape so the channel axis splits as (box, class) like Keras (:363-383)
+            confs.append(ch(f).permute(0, 2, 3, 1).reshape(b, -1, self.n_classes))
+            locs.append(lh(f).permute(0, 2, 3, 1).reshape(b, -1, 4))
+            sizes.append((f.shape[2], f.shape[3]))
+        conf = torch.softmax(torch.cat(confs, dim=1).float(), dim=-1)          # 'mbox_conf_softmax' (:415)
+        loc = torch.cat(locs, dim=1).float()
+        anchors = self.anchors_and_variances(sizes, conf.device)
+        return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+
+    def forward(self, images):
+        pred = self.raw_predictions(images)
+        if self.decoder is None:
+            return pred
+        return self.decoder(pred)
+
+    predict = forward
+
+    def l2_regularization_loss(self):
+        """Keras adds l2(l2_reg) * sum(W^2) over every conv kernel (not biases) to the loss (:274 kernel_regularizer)."""
+        if not self.l2_regularization:
+            return torch.zeros((), device=next(self.parameters()).device)
+        return self.l2_regularization * sum((m.weight.float() ** 2).sum() for m in self.modules() if isinstance(m, nn.Conv2d))
+
+
+def make_priorboxes(img_height, img_width, scales, aspect_ratios, two_boxes_for_ar1, steps, offsets, clip_boxes,
+                    variances, coords, normalize_coords, names):
+    return nn.ModuleList([
+        AnchorBoxes(img_height, img_width, this_scale=scales[i], next_scale=scales[i + 1], aspect_ratios=aspect_ratios[i],
+                    two_boxes_for_ar1=two_boxes_for_ar1, this_steps=steps[i], this_offsets=offsets[i],
+                    clip_boxes=clip_boxes, variances=variances, coords=coords, normalize_coords=normalize_coords,
+                    name=names[i])
+        for i in range(len(names))])

@@ -1,0 +1,121 @@
+"""`ssd_300` -- drop-in for the reference builder models/keras_ssd300.py:31-457, as a torch module.
+
+VGG-16 (atrous fc6/fc7) + extra feature layers + 6 pairs of 3x3 predictor heads; 8732 anchors at
+300x300.  The convolutions are PyTorch-ROCm calls (MIOpen -> MFMA); keep the model in
+channels_last and bf16 for throughput, fp32 for numerics checks.  Layer names follow the
+reference so ported weights can be loaded by name.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from ..keras_layers.keras_layer_L2Normalization import L2Normalization
+from ._common import SSDModel, conv_out, he_normal_, make_priorboxes, pool_out, resolve_anchor_config
+
+
+class _VGGBase(SSDModel):
+    """conv1_1 .. fc7 shared by SSD300 and SSD512 (keras_ssd300.py:274-300)."""
+
+    def _build_vgg(self, in_ch):
+        def c(i, o, k=3, **kw):
+            return nn.Conv2d(i, o, k, padding=kw.pop('padding', k // 2), **kw)
+        self.conv1_1, self.conv1_2 = c(in_ch, 64), c(64, 64)
+        self.conv2_1, self.conv2_2 = c(64, 128), c(128, 128)
+        self.conv3_1, self.conv3_2, self.conv3_3 = c(128, 256), c(256, 256), c(256, 256)
+        self.conv4_1, self.conv4_2, self.conv4_3 = c(256, 512), c(512, 512), c(512, 512)
+        self.conv5_1, self.conv5_2, self.conv5_3 = c(512, 512), c(512, 512), c(512, 512)
+        self.fc6 = nn.Conv2d(512, 1024, 3, padding=6, dilation=6)
+        self.fc7 = nn.Conv2d(1024, 1024, 1)
+        self.conv4_3_norm = L2Normalization(gamma_init=20, n_channels=512, name='conv4_3_norm')
+
+    def _vgg(self, x):
+        r = F.relu
+        x = r(self.conv1_2(r(self.conv1_1(x))))
+        x = F.max_pool2d(x, 2, 2, ceil_mode=True)                      # 'same' pooling pads bottom/right
+        x = r(self.conv2_2(r(self.conv2_1(x))))
+        x = F.max_pool2d(x, 2, 2, ceil_mode=True)
+        x = r(self.conv3_3(r(self.conv3_2(r(self.conv3_1(x))))))
+        x = F.max_pool2d(x, 2, 2, ceil_mode=True)
+        conv4_3 = r(self.conv4_3(r(self.conv4_2(r(self.conv4_1(x))))))
+        x = F.max_pool2d(conv4_3, 2, 2, ceil_mode=True)
+        x = r(self.conv5_3(r(self.conv5_2(r(self.conv5_1(x))))))
+        x = F.max_pool2d(x, 3, 1, padding=1)
+        fc7 = r(self.fc7(r(self.fc6(x))))
+        return conv4_3, fc7
+
+    @staticmethod
+    def _vgg_sizes(n):
+        for _ in range(3):
+            n = pool_out(n, 2, 2, ceil_mode=True)
+        c43 = n
+        n = pool_out(n, 2, 2, ceil_mode=True)
+        return c43, n                                                   # conv4_3, fc7
+
+
+class SSD300(_VGGBase):
+    SOURCE_CHANNELS = (512, 1024, 512, 256, 256, 256)
+    NAMES = ('conv4_3_norm', 'fc7', 'conv6_2', 'conv7_2', 'conv8_2', 'conv9_2')
+
+    def __init__(self, image_size, n_classes, mode, l2_regularization, scales, aspect_ratios, n_boxes, steps, offsets,
+                 two_boxes_for_ar1, clip_boxes, variances, coords, normalize_coords, subtract_mean, divide_by_stddev,
+                 swap_channels, confidence_thresh, iou_threshold, top_k, nms_max_output_size):
+        super().__init__(image_size, n_classes, mode, l2_regularization, subtract_mean, divide_by_stddev, swap_channels,
+                         confidence_thresh, iou_threshold, top_k, nms_max_output_size, coords, normalize_coords)
+        self._build_vgg(self.img_channels)
+        self.conv6_1, self.conv6_2 = nn.Conv2d(1024, 256, 1), nn.Conv2d(256, 512, 3, stride=2, padding=1)
+        self.conv7_1, self.conv7_2 = nn.Conv2d(512, 128, 1), nn.Conv2d(128, 256, 3, stride=2, padding=1)
+        self.conv8_1, self.conv8_2 = nn.Conv2d(256, 128, 1), nn.Conv2d(128, 256, 3)
+        self.conv9_1, self.conv9_2 = nn.Conv2d(256, 128, 1), nn.Conv2d(128, 256, 3)
+        self.conf_heads = nn.ModuleList([nn.Conv2d(ch, nb * self.n_classes, 3, padding=1)
+                                         for ch, nb in zip(self.SOURCE_CHANNELS, n_boxes)])
+        self.loc_heads = nn.ModuleList([nn.Conv2d(ch, nb * 4, 3, padding=1) for ch, nb in zip(self.SOURCE_CHANNELS, n_boxes)])
+        self.priorboxes = make_priorboxes(self.img_height, self.img_width, scales, aspect_ratios, two_boxes_for_ar1, steps,
+                                          offsets, clip_boxes, variances, coords, normalize_coords,
+                                          [n + '_mbox_priorbox' for n in self.NAMES])
+        he_normal_(self)
+
+    def features(self, x):
+        r = F.relu
+        conv4_3, fc7 = self._vgg(x)
+        conv6_2 = r(self.conv6_2(r(self.conv6_1(fc7))))
+        conv7_2 = r(self.conv7_2(r(self.conv7_1(conv6_2))))
+        conv8_2 = r(self.conv8_2(r(self.conv8_1(conv7_2))))
+        conv9_2 = r(self.conv9_2(r(self.conv9_1(conv8_2))))
+        return [self.conv4_3_norm(conv4_3), fc7, conv6_2, conv7_2, conv8_2, conv9_2]
+
+    def predictor_sizes(self):
+        out = []
+        for n in (self.img_height, self.img_width):
+            c43, f7 = self._vgg_sizes(n)
+            c6 = conv_out(f7, 3, 2, 1)
+            c7 = conv_out(c6, 3, 2, 1)
+            c8 = conv_out(c7, 3)
+            c9 = conv_out(c8, 3)
+            out.append([c43, f7, c6, c7, c8, c9])
+        return np.array(list(zip(*out)))
+
+
+def ssd_300(image_size, n_classes, mode='training', l2_regularization=0.0005, min_scale=None, max_scale=None, scales=None,
+            aspect_ratios_global=None,
+            aspect_ratios_per_layer=[[1.0, 2.0, 0.5], [1.0, 2.0, 0.5, 3.0, 1.0/3.0], [1.0, 2.0, 0.5, 3.0, 1.0/3.0],
+                                     [1.0, 2.0, 0.5, 3.0, 1.0/3.0], [1.0, 2.0, 0.5], [1.0, 2.0, 0.5]],
+            two_boxes_for_ar1=True, steps=[8, 16, 32, 64, 100, 300], offsets=None, clip_boxes=False,
+            variances=[0.1, 0.1, 0.2, 0.2], coords='centroids', normalize_coords=True, subtract_mean=[123, 117, 104],
+            divide_by_stddev=None, swap_channels=[2, 1, 0], confidence_thresh=0.01, iou_threshold=0.45, top_k=200,
+            nms_max_output_size=400, return_predictor_sizes=False):
+    '''Build an SSD300 (reference keras_ssd300.py:31-59 for the arguments).  Returns a torch module whose
+    forward takes `(batch, height, width, channels)` images (0..255, RGB) and returns the
+    `(batch, 8732, n_classes+1+12)` prediction tensor (`mode='training'`) or the decoded
+    `(batch, top_k, 6)` detections (`'inference'`, `'inference_fast'`); optionally also `predictor_sizes`.'''
+    scales, ars, n_boxes, steps, offsets = resolve_anchor_config(6, min_scale, max_scale, scales, aspect_ratios_global,
+                                                                 aspect_ratios_per_layer, two_boxes_for_ar1, steps,
+                                                                 offsets, variances)
+    model = SSD300(image_size, n_classes, mode, l2_regularization, scales, ars, n_boxes, steps, offsets, two_boxes_for_ar1,
+                   clip_boxes, variances, coords, normalize_coords, subtract_mean, divide_by_stddev, swap_channels,
+                   confidence_thresh, iou_threshold, top_k, nms_max_output_size)
+    if return_predictor_sizes:
+        return model, model.predictor_sizes()
+    return model
