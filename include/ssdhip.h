@@ -112,6 +112,7 @@ int ssdhip_decode_stages(int stages, const void* y_pred, int in_dtype, int B, in
  *   variances     [4] float64
  *   gt            [G_total,5] float64 rows class,xmin,ymin,xmax,ymax in absolute pixels ('corners'),
  *                 images concatenated; gt_offsets [B+1] int32 CSR offsets (an image may have 0 rows)
+ *   max_gt_per_image  largest row count of any image (the host built the CSR, so it knows); <= 1024
  *   matching_type 0 'bipartite', 1 'multi'
  *   y_encoded_f32 / y_encoded_f64  [B,N,C+12] outputs, either may be NULL
  *   match_gt      [B,N] int32: >=0 index (within the image) of the matched GT, -1 background,
@@ -120,7 +121,7 @@ int ssdhip_decode_stages(int stages, const void* y_pred, int in_dtype, int B, in
  */
 size_t ssdhip_encode_workspace_bytes(int B, int N, int C, int G_total);
 int ssdhip_encode(const double* anchors, const double* variances, const double* gt, const int* gt_offsets,
-                  int G_total, int B, int N, int C, double img_height, double img_width,
+                  int G_total, int max_gt_per_image, int B, int N, int C, double img_height, double img_width,
                   int matching_type, double pos_iou_threshold, double neg_iou_limit,
                   int coords, int normalize_coords, int border_pixels, int background_id,
                   float* y_encoded_f32, double* y_encoded_f64, int* match_gt,

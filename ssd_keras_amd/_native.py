@@ -60,7 +60,7 @@ def load():
             lib.ssdhip_encode_workspace_bytes.restype = c_sz
             lib.ssdhip_encode_workspace_bytes.argtypes = [c_int] * 4
             lib.ssdhip_encode.restype = c_int
-            lib.ssdhip_encode.argtypes = ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_dbl, c_dbl,
+            lib.ssdhip_encode.argtypes = ([c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_dbl, c_dbl,
                                            c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
                                            c_vp, c_vp, c_vp, c_vp, c_sz, c_vp])
         if hasattr(lib, "ssdhip_loss_forward"):
