@@ -133,8 +133,8 @@ int ssdhip_encode(const double* anchors, const double* variances, const double* 
  *
  *   loss_per_item [B] float32
  *   stats         [4] float32: n_positive, n_neg_losses, k (negatives kept), k-th largest negative loss
- *   keep_mask     [B,N] uint8: 1 where the anchor's classification loss enters the sum
- *                 (positive, or a kept hard negative) -- saved for backward
+ *   keep_mask     [B,N] uint8: 1 where the anchor is a kept hard negative (its classification loss
+ *                 enters the sum besides the positives') -- saved for backward
  *   backward: grad_y_pred [B,N,C+12] = d(sum_b grad_out[b]*loss[b]) / d y_pred (last 8 columns zero)
  */
 size_t ssdhip_loss_workspace_bytes(int B, int N, int C);

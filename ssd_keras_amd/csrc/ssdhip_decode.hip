@@ -213,27 +213,7 @@ __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, i
             atomicAdd(&hist[(u32)(key >> shift) & (NBINS - 1)], 1u);
         }
         __syncthreads();
-        // thread t owns bins [t*32, t*32+32); suffix sums over threads locate the digit
-        constexpr int PER = NBINS / NMS_THREADS;
-        u32 local = 0;
-        for (int j = 0; j < PER; ++j) local += hist[tid * PER + j];
-        red[tid] = (int)local;
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, t = NMS_THREADS - 1;
-            for (; t > 0; --t) {                    // counts of bins strictly above thread t's range
-                if (acc + red[t] >= k) break;
-                acc += red[t];
-            }
-            int d = t * PER + PER - 1;
-            for (; d > t * PER; --d) {
-                if (acc + (int)hist[d] >= k) break;
-                acc += (int)hist[d];
-            }
-            red[256] = d;
-            red[257] = acc;                        // number of keys with a larger digit
-        }
-        __syncthreads();
+        block_find_digit<NBINS / NMS_THREADS>(hist, k, red, red + 256);
         const int d = red[256];
         k -= red[257];
         prefix |= (u64)d << shift;

@@ -1,0 +1,337 @@
+// ssdhip_loss.hip -- the SSD multibox loss (forward + backward) on gfx950 (MI355X).
+//
+// Replaces SSDLoss.compute_loss (reference keras_loss_function/keras_ssd_loss.py:98-211, with smooth_L1_loss
+// :53-75 and log_loss :77-96), float32 like the TensorFlow graph.  Hard-negative mining is global over the
+// batch the call is given (:179-183): the k = min(max(ratio*n_pos, n_neg_min), #non-zero negative losses)
+// largest negative classification losses of the flattened (B*N) array are kept; among equal losses at the
+// k-th place the lowest flat index wins (tf.nn.top_k).
+//
+// Forward = four kernels on the caller's stream:
+//   L1 anchor_kernel  grid (anchor tiles, B): tiles of y_true / y_pred rows copied coalesced into LDS; per anchor the
+//                     log loss (only where y_true != 0), smooth L1, positive / negative weights; writes cls_loss[B,N]
+//                     and neg_all[B,N], accumulates per-image sums (float64 atomics) and the two global counts.
+//   L2 select_kernel  one workgroup: k, then a 3-pass radix select (11+11+10 bits of the order-preserving float key)
+//                     for the k-th largest negative loss and, only if ties straddle the cut, the flat-index limit.
+//   L3 keep_kernel    grid-stride over B*N: keep mask + per-image sum of the kept negative losses.
+//   L4 total_kernel   B threads: (pos_cls + neg_cls + alpha*loc) / max(1, n_pos) * B.
+// Backward = one kernel with the same LDS tiling writing d loss / d y_pred coalesced.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+#include "ssdhip_tile.h"
+
+namespace ssdhip {
+
+constexpr int LOSS_THREADS = 256;
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_BINS = 2048;
+
+struct LossWs {
+    size_t sums, counts, sel, cls, neg, total;   // sums: 3*B doubles + n_pos double; counts: ints; sel: select result
+};
+
+struct SelectResult {
+    int k;
+    unsigned int thresh_key;      // float_key of the k-th largest negative loss
+    int tie_limit;                // elements == thresh are kept iff flat index < tie_limit
+    int n_neg_losses;
+    float n_pos;
+    float thresh;
+};
+
+static inline size_t lalign(size_t v) { return (v + 255) / 256 * 256; }
+
+static LossWs loss_ws_layout(int B, int N) {
+    LossWs w;
+    size_t o = 0;
+    w.sums = o;   o = lalign(o + (size_t)(3 * B + 1) * sizeof(double));
+    w.counts = o; o = lalign(o + 4 * sizeof(int));
+    w.sel = o;    o = lalign(o + sizeof(SelectResult));
+    w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
+    w.neg = o;    o = lalign(o + (size_t)B * N * sizeof(float));
+    w.total = o;
+    return w;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ======================================================================================
+// L1
+// ======================================================================================
+__global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
+                                                              int B, int N, int C, float* __restrict__ cls_out,
+                                                              float* __restrict__ neg_out, double* __restrict__ sums,
+                                                              int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[4][LOSS_THREADS / 64];
+    const int TA = blockDim.x, L = C + 12;
+    const int b = blockIdx.y, a0 = blockIdx.x * TA, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = min(TA, N - a0);
+    const size_t off = ((size_t)b * N + a0) * (size_t)L;
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const size_t half = ((size_t)TA * L + 4 + 3) / 4 * 4;
+    const float* yt = tile_copy_f32(lds, y_true + off, na * L, tid, TA);
+    const float* yp = tile_copy_f32(lds + half, y_pred + off, na * L, tid, TA);
+    __syncthreads();
+    double s_poscls = 0.0, s_loc = 0.0, s_npos = 0.0;
+    int nonzero = 0;
+    if (tid < na) {
+        const float* t = yt + (size_t)tid * L;
+        const float* q = yp + (size_t)tid * L;
+        float cls = 0.f, pos = t[1];
+        for (int c = 0; c < C; ++c) {                                  // log_loss (:93-95)
+            const float tc = t[c];
+            if (c >= 1) pos = fmaxf(pos, tc);                           // positives = max(y_true[1:C]) (:140)
+            if (tc != 0.f) cls += tc * logf(fmaxf(q[c], 1e-15f));
+        }
+        cls = -cls;
+        float loc = 0.f;
+        for (int k = 0; k < 4; ++k) {                                   // smooth_L1_loss (:72-75)
+            const float d = t[C + k] - q[C + k];
+            const float ad = fabsf(d);
+            loc += ad < 1.0f ? 0.5f * (d * d) : ad - 0.5f;
+        }
+        const float neg = cls * t[0];                                   // neg_class_loss_all (:150)
+        cls_out[(size_t)b * N + a0 + tid] = cls;
+        neg_out[(size_t)b * N + a0 + tid] = neg;
+        s_poscls = (double)(cls * pos);
+        s_loc = (double)(loc * pos);
+        s_npos = (double)pos;
+        nonzero = neg != 0.f;
+    }
+    s_poscls = wave_sum(s_poscls); s_loc = wave_sum(s_loc); s_npos = wave_sum(s_npos);
+    const double s_nz = wave_sum((double)nonzero);
+    if (lane == 0) { red[0][wave] = s_poscls; red[1][wave] = s_loc; red[2][wave] = s_npos; red[3][wave] = s_nz; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0, l = 0, n = 0, z = 0;
+        for (int w = 0; w < TA / 64; ++w) { a += red[0][w]; l += red[1][w]; n += red[2][w]; z += red[3][w]; }
+        if (a != 0.0) atomicAdd(&sums[b], a);
+        if (l != 0.0) atomicAdd(&sums[B + b], l);
+        if (n != 0.0) atomicAdd(&sums[3 * B], n);
+        if (z != 0.0) atomicAdd(&counts[0], (int)z);
+    }
+}
+
+// ======================================================================================
+// L2
+// ======================================================================================
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ neg_all, int total, int neg_pos_ratio,
+                                                             int n_neg_min, const double* __restrict__ sums, int B,
+                                                             const int* __restrict__ counts, SelectResult* __restrict__ res,
+                                                             float* __restrict__ stats) {
+    __shared__ u32 hist[SEL_BINS];
+    __shared__ int sh_out[2];
+    __shared__ int sh_digit;
+    __shared__ int wave_cnt[SEL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float n_pos = (float)sums[3 * B];
+    const int n_neg_losses = counts[0];
+    int k = neg_pos_ratio * (int)n_pos;                                  // tf.to_int32(n_positive) truncates (:166)
+    k = k > n_neg_min ? k : n_neg_min;
+    k = k < n_neg_losses ? k : n_neg_losses;
+    u32 prefix = 0, pmask = 0;
+    int tie_limit = 0x7fffffff;
+    if (k > 0) {
+        int want = k;
+        const int shifts[3] = {21, 10, 0};
+        const u32 masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < total; i += SEL_THREADS) {
+                const u32 key = float_key(neg_all[i]);
+                if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & masks[pass]], 1u);
+            }
+            __syncthreads();
+            block_find_digit<SEL_BINS / SEL_THREADS>(hist, want, wave_cnt, sh_out);
+            want -= sh_out[1];
+            prefix |= (u32)sh_out[0] << shifts[pass];
+            pmask |= masks[pass] << shifts[pass];
+            __syncthreads();
+        }
+        // `want` of the elements equal to the threshold are kept; if that is not all of them, the lowest flat indices win
+        int eq_local = 0;
+        for (int i = tid; i < total; i += SEL_THREADS) eq_local += float_key(neg_all[i]) == prefix;
+        eq_local = (int)wave_sum((double)eq_local);
+        if (lane == 0) wave_cnt[wave] = eq_local;
+        __syncthreads();
+        int eq_total = 0;
+        for (int w = 0; w < SEL_THREADS / 64; ++w) eq_total += wave_cnt[w];
+        __syncthreads();
+        if (eq_total != want) {
+            int seen = 0;                                               // ordered scan, 1024 elements per step
+            for (int base = 0; base < total && tie_limit == 0x7fffffff; base += SEL_THREADS) {
+                const int i = base + tid;
+                const bool is = i < total && float_key(neg_all[i]) == prefix;
+                const u64 m = __ballot(is);
+                if (lane == 0) wave_cnt[wave] = __popcll(m);
+                __syncthreads();
+                int before = seen;
+                for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+                int step = 0;
+                for (int w = 0; w < SEL_THREADS / 64; ++w) step += wave_cnt[w];
+                const int rank = before + __popcll(m & lanemask_lt());   // ties before this one
+                if (is && rank == want - 1) sh_digit = i + 1;            // the want-th tie: limit is one past it
+                __syncthreads();
+                if (seen + step >= want) tie_limit = sh_digit;
+                seen += step;
+                __syncthreads();
+            }
+        }
+    }
+    if (tid == 0) {
+        res->k = k; res->thresh_key = prefix; res->tie_limit = tie_limit; res->n_neg_losses = n_neg_losses;
+        res->n_pos = n_pos; res->thresh = k > 0 ? key_float(prefix) : 0.f;
+        stats[0] = n_pos; stats[1] = (float)n_neg_losses; stats[2] = (float)k; stats[3] = res->thresh;
+    }
+}
+
+// ======================================================================================
+// L3 / L4
+// ======================================================================================
+__global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restrict__ cls, const float* __restrict__ neg_all,
+                                                            int B, int N, const SelectResult* __restrict__ res,
+                                                            unsigned char* __restrict__ keep, double* __restrict__ sums) {
+    __shared__ double red[LOSS_THREADS / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = res->k, tie_limit = res->tie_limit;
+    const u32 tk = res->thresh_key;
+    double s = 0.0;
+    for (int n = blockIdx.x * LOSS_THREADS + tid; n < N; n += gridDim.x * LOSS_THREADS) {
+        const int flat = b * N + n;
+        bool kp = false;
+        if (k > 0) {
+            const u32 key = float_key(neg_all[flat]);
+            kp = key > tk || (key == tk && flat < tie_limit);
+        }
+        keep[flat] = kp ? 1 : 0;
+        if (kp) s += (double)cls[flat];                                 // classification_loss * negatives_keep (:190)
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0;
+        for (int w = 0; w < LOSS_THREADS / 64; ++w) a += red[w];
+        if (a != 0.0) atomicAdd(&sums[2 * B + b], a);
+    }
+}
+
+__global__ void total_kernel(const double* __restrict__ sums, int B, float alpha, float* __restrict__ loss) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float n_pos = (float)sums[3 * B];
+    const float cls = (float)sums[b] + (float)sums[2 * B + b];            // class_loss = pos + neg (:200)
+    const float tot = (cls + alpha * (float)sums[B + b]) / fmaxf(1.0f, n_pos);
+    loss[b] = tot * (float)B;                                             // :208-209
+}
+
+// ======================================================================================
+// backward
+// ======================================================================================
+__global__ __launch_bounds__(LOSS_THREADS) void backward_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
+                                                                const unsigned char* __restrict__ keep,
+                                                                const float* __restrict__ stats, const float* __restrict__ grad_out,
+                                                                int B, int N, int C, float alpha, float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int TA = blockDim.x, L = C + 12;
+    const int b = blockIdx.y, a0 = blockIdx.x * TA, tid = threadIdx.x;
+    const int na = min(TA, N - a0);
+    const size_t off = ((size_t)b * N + a0) * (size_t)L;
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const size_t half = ((size_t)TA * L + 4 + 3) / 4 * 4;
+    const float* yt = tile_copy_f32(lds, y_true + off, na * L, tid, TA);
+    float* yp = tile_copy_f32(lds + half, y_pred + off, na * L, tid, TA);
+    __syncthreads();
+    const float scale = grad_out[b] * (float)B / fmaxf(1.0f, stats[0]);
+    if (tid < na) {
+        const float* t = yt + (size_t)tid * L;
+        float* q = yp + (size_t)tid * L;                                  // overwritten with the gradient row
+        float pos = t[1];
+        for (int c = 2; c < C; ++c) pos = fmaxf(pos, t[c]);
+        const float w_cls = (pos + (keep[(size_t)b * N + a0 + tid] ? 1.0f : 0.0f)) * scale;
+        for (int c = 0; c < C; ++c) {
+            const float pc = q[c];
+            q[c] = (pc >= 1e-15f && t[c] != 0.f) ? -(t[c] / pc) * w_cls : 0.f;
+        }
+        const float w_loc = alpha * pos * scale;
+        for (int k = 0; k < 4; ++k) {
+            const float d = t[C + k] - q[C + k];
+            const float dl = fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f);
+            q[C + k] = -dl * w_loc;
+        }
+        for (int k = 4; k < 12; ++k) q[C + k] = 0.f;
+    }
+    __syncthreads();
+    const int total = na * L;
+    for (int i = tid; i < total; i += TA) grad[off + i] = yp[i];
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+static int loss_tile(int L) {
+    int TA = 256;
+    while (TA > 64 && 2 * ((size_t)TA * L + 8) * sizeof(float) > 64 * 1024) TA >>= 1;
+    return TA;
+}
+
+extern "C" size_t ssdhip_loss_workspace_bytes(int B, int N, int C) {
+    if (B <= 0 || N <= 0 || C < 2) return 0;
+    return loss_ws_layout(B, N).total;
+}
+
+extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int B, int N, int C,
+                                   int neg_pos_ratio, int n_neg_min, float alpha,
+                                   float* loss_per_item, float* stats, unsigned char* keep_mask,
+                                   void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!y_true || !y_pred || !loss_per_item || !stats || !keep_mask || B <= 0 || N <= 0 || C < 2) return SSDHIP_E_BADARG;
+    if ((long long)B * N > 0x7ffffff0LL) return SSDHIP_E_BADARG;
+    const LossWs lay = loss_ws_layout(B, N);
+    if (!ws || ws_bytes < lay.total) return SSDHIP_E_WORKSPACE;
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    double* sums = reinterpret_cast<double*>(base + lay.sums);
+    int* counts = reinterpret_cast<int*>(base + lay.counts);
+    SelectResult* sel = reinterpret_cast<SelectResult*>(base + lay.sel);
+    float* cls = reinterpret_cast<float*>(base + lay.cls);
+    float* neg = reinterpret_cast<float*>(base + lay.neg);
+    if (hipMemsetAsync(base, 0, lay.sel, stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // sums + counts
+
+    const int L = C + 12;
+    const int TA = loss_tile(L);
+    const size_t lds = 2 * (((size_t)TA * L + 4 + 3) / 4 * 4) * sizeof(float) + 16;
+    if (lds > 150 * 1024) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(anchor_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, sums, counts);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, neg, B * N, neg_pos_ratio, n_neg_min, sums, B, counts, sel, stats);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    const int gx = (N + LOSS_THREADS - 1) / LOSS_THREADS;
+    hipLaunchKernelGGL(keep_kernel, dim3(gx < 64 ? gx : 64, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, sel, keep_mask, sums);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(total_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sums, B, alpha, loss_per_item);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    return SSDHIP_OK;
+}
+
+extern "C" int ssdhip_loss_backward(const float* y_true, const float* y_pred, const unsigned char* keep_mask,
+                                    const float* stats, const float* grad_out, int B, int N, int C, float alpha,
+                                    float* grad_y_pred, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!y_true || !y_pred || !keep_mask || !stats || !grad_out || !grad_y_pred || B <= 0 || N <= 0 || C < 2) return SSDHIP_E_BADARG;
+    const int L = C + 12;
+    const int TA = loss_tile(L);
+    const size_t lds = 2 * (((size_t)TA * L + 4 + 3) / 4 * 4) * sizeof(float) + 16;
+    if (lds > 150 * 1024) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(backward_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), lds, stream, y_true, y_pred, keep_mask, stats, grad_out,
+                       B, N, C, alpha, grad_y_pred);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    return SSDHIP_OK;
+}

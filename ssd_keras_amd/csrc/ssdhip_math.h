@@ -89,4 +89,34 @@ __device__ __forceinline__ u64 lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64u - lane));
 }
 
+// ---------------------------------------------------------------------------------------
+// Radix-select helper: hist[] holds per-digit counts (blockDim.x * PER bins); find the digit d with
+//   #(digit > d) < want <= #(digit >= d)      (want >= 1, want <= total count)
+// All threads call it; result in out[0] = d, out[1] = #(digit > d).  wave_tot: LDS, blockDim.x/64 ints.
+// Parallel suffix scan: per-thread bin sums, shuffle scan inside each wave, wave totals through LDS.
+// ---------------------------------------------------------------------------------------
+template <int PER>
+__device__ __forceinline__ void block_find_digit(const u32* hist, int want, int* wave_tot, int* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    u32 local[PER];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { local[j] = hist[tid * PER + j]; s += (int)local[j]; }
+    int suf = s;                                   // inclusive suffix sum over the lanes of this wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(suf, off);
+        if (lane + off < 64) suf += o;
+    }
+    if (lane == 0) wave_tot[wave] = suf;
+    __syncthreads();
+    int above = suf - s;
+    for (int w = wave + 1; w < nw; ++w) above += wave_tot[w];
+#pragma unroll
+    for (int j = PER - 1; j >= 0; --j) {
+        if (above < want && want <= above + (int)local[j]) { out[0] = tid * PER + j; out[1] = above; }
+        above += (int)local[j];
+    }
+    __syncthreads();
+}
+
 }  // namespace ssdhip
