@@ -1,0 +1,72 @@
+"""The N > 1 path on CPU: two gloo ranks on 127.0.0.1.  Checks the sharding arithmetic, the max-over-ranks
+timing reduction bench.py uses, and that the bucketed gradient all-reduce of two half-batches reproduces the
+single-process gradient of the full batch (the data-parallel training step of BASELINE configs[3])."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from ssd_keras_amd import distributed as dp
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [dp.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build():
+    from ssd_keras_amd.models.keras_ssd7 import build_model
+    torch.manual_seed(0)
+    m = build_model((64, 64, 3), 3, scales=[0.1, 0.3, 0.5, 0.7, 0.9], normalize_coords=True)
+    return m.eval()                       # BatchNorm on running statistics: shards and full batch see the same function
+
+
+def _loss(pred):
+    c = pred.shape[2] - 12
+    return (pred[:, :, :c + 4] ** 2).mean()
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    model = dp.data_parallel(_build(), bucket_cap_mb=1)
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(4, 64, 64, 3)).astype(np.float32))
+    lo, hi = dp.shard_range(4, rank, world)
+    _loss(model(x[lo:hi])).backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    t = dp.max_over_ranks(1.0 + rank)
+    s = dp.sum_over_ranks(1.0)
+    torch.save({"grads": grads, "t": t, "s": s}, os.path.join(tmp, "r%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(2)]
+    assert torch.equal(outs[0]["grads"], outs[1]["grads"])              # both ranks hold the averaged gradient
+    assert outs[0]["t"] == 2.0 and outs[1]["t"] == 2.0 and outs[0]["s"] == 2.0
+    model = _build()
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(4, 64, 64, 3)).astype(np.float32))
+    _loss(model(x)).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    torch.testing.assert_close(outs[0]["grads"], ref, rtol=1e-4, atol=1e-6)

@@ -1,0 +1,130 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/ssdhip.h declares; host-side
+logic of the drop-in surface (argument validation, anchors, containers, model graphs) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ssd_keras_amd import synthetic as syn
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ssd_keras_amd import build
+    path = build.build()
+    return ctypes.CDLL(path)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "ssdhip.h")).read()
+    names = sorted(set(re.findall(r"\b(ssdhip_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.ssdhip_abi_version.restype = ctypes.c_int
+    assert lib.ssdhip_abi_version() == 1
+    lib.ssdhip_strerror.restype = ctypes.c_char_p
+    assert b"workspace" in lib.ssdhip_strerror(-2)
+
+
+def test_workspace_sizes(lib):
+    for fn in (lib.ssdhip_decode_workspace_bytes, lib.ssdhip_encode_workspace_bytes, lib.ssdhip_loss_workspace_bytes):
+        fn.restype = ctypes.c_size_t
+    d = lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 0)
+    assert 32 * 8732 * (16 + 20 * 8) <= d < 2 * 32 * 8732 * (16 + 20 * 8)
+    assert lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 1) == 0        # float64 input not built
+    assert lib.ssdhip_decode_workspace_bytes(0, 8732, 21, 200, 400, 0, 0) == 0
+    assert lib.ssdhip_encode_workspace_bytes(32, 8732, 21, 256) >= 256 * 8732 * 8
+    assert lib.ssdhip_loss_workspace_bytes(32, 8732, 21) >= 2 * 32 * 8732 * 4
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "ssd_keras_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "np_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ssd_keras_amd import _native as nat
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_output_decoder import decode_detections
+    y = np.zeros((1, 10, 18), np.float32)
+    with pytest.raises(Exception):
+        decode_detections(y, img_height=10, img_width=10)           # no CPU fallback
+    with pytest.raises(nat.SsdHipError):
+        nat.require_cuda(torch.zeros(3), "x")
+
+
+def test_encoder_host_logic_matches_reference_anchors():
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_input_encoder import DegenerateBoxError, SSDInputEncoder
+    z = util.load("anchors")
+    for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
+        enc = SSDInputEncoder(**cfg)
+        assert np.array_equal(np.concatenate([b.reshape(-1, 4) for b in enc.boxes_list]), z[name + "_centroids_clip0"])
+        assert enc.n_classes == cfg["n_classes"] + 1
+    enc = SSDInputEncoder(**syn.TINY)
+    assert len(enc.boxes_list) == 4 and enc.boxes_list[0].shape == (8, 8, 4, 4) and enc.n_boxes == 4
+    t = enc.generate_encoding_template(2)
+    assert t.shape == (2, 340, 18) and np.all(t[:, :, :6] == 0) and np.array_equal(t[0, :, 6:10], t[0, :, 10:14])
+    with pytest.raises(DegenerateBoxError):
+        enc._pack_ground_truth([np.array([[1, 5, 5, 5, 9.]])])
+    gt, off, mx = enc._pack_ground_truth([np.zeros((0, 5)), np.array([[1, 1, 1, 5, 9.], [2, 0, 0, 3, 3]])])
+    assert list(off) == [0, 0, 2] and mx == 2 and gt.shape == (2, 5)
+    for bad in (dict(scales=[0.1, 0.2]), dict(variances=[1, 1, 1]), dict(variances=[1, 1, 1, 0]), dict(coords="polar"),
+                dict(steps=[1, 2]), dict(offsets=[0.5]), dict(aspect_ratios_per_layer=[[1.0]]),
+                dict(min_scale=None, max_scale=None), dict(aspect_ratios_global=[0.0, 1.0])):
+        kw = dict(syn.TINY)
+        kw.update(bad)
+        with pytest.raises(ValueError):
+            SSDInputEncoder(**kw)
+
+
+def test_layers_and_models_on_cpu():
+    import torch
+    from ssd_keras_amd.keras_layers.keras_layer_AnchorBoxes import AnchorBoxes
+    from ssd_keras_amd.keras_layers.keras_layer_DecodeDetections import DecodeDetections
+    from ssd_keras_amd.keras_layers.keras_layer_L2Normalization import L2Normalization
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.models.keras_ssd7 import build_model
+    from oracle import np_oracle as orc
+    ab = AnchorBoxes(300, 300, 0.2, 0.37, aspect_ratios=[1.0, 2.0, 0.5, 3.0, 1.0 / 3.0], this_steps=16, this_offsets=0.5,
+                     normalize_coords=True)
+    out = ab(torch.zeros(2, 24, 19, 19))
+    want = orc.anchor_boxes_layer(2, 300, 300, (19, 19), 0.2, 0.37, [1.0, 2.0, 0.5, 3.0, 1.0 / 3.0], True, 16, 0.5, False,
+                                  [0.1, 0.1, 0.2, 0.2], "centroids", True)
+    assert out.shape == (2, 19, 19, 6, 8) and np.array_equal(out.numpy(), want)
+    assert ab.compute_output_shape((2, 24, 19, 19)) == (2, 19, 19, 6, 8) and ab.get_config()["this_scale"] == 0.2
+    l2 = L2Normalization(gamma_init=20, n_channels=8)
+    x = torch.randn(2, 8, 5, 5)
+    ref = orc.l2_normalization(x.permute(0, 2, 3, 1).numpy(), np.full(8, 20, np.float32))
+    np.testing.assert_allclose(l2(x).permute(0, 2, 3, 1).detach().numpy(), ref, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        DecodeDetections(normalize_coords=True)
+    with pytest.raises(ValueError):
+        DecodeDetections(coords="corners", img_height=1, img_width=1)
+    m, ps = build_model((300, 300, 3), 5, scales=syn.SSD7_300["scales"], normalize_coords=True, return_predictor_sizes=True)
+    assert ps.tolist() == [[37, 37], [18, 18], [9, 9], [4, 4]]
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.zeros(1, 300, 300, 3))
+    enc = orc.EncoderOracle(**syn.SSD7_300)
+    assert y.shape == (1, 7160, 18)
+    assert np.array_equal(y[0, :, -8:].numpy(), enc.generate_encoding_template(1)[0, :, -8:].astype(np.float32))
+    np.testing.assert_allclose(y[0, :, :6].sum(-1).numpy(), 1.0, rtol=1e-5)
+    m3, ps3 = ssd_300((300, 300, 3), 20, scales=syn.SSD300_VOC["scales"], return_predictor_sizes=True)
+    assert ps3.tolist() == [[38, 38], [19, 19], [10, 10], [5, 5], [3, 3], [1, 1]]
+    assert sum(p.numel() for p in m3.parameters()) == 26285486
+    with pytest.raises(ValueError):
+        ssd_300((300, 300, 3), 20, mode="bogus", scales=syn.SSD300_VOC["scales"])
+    with pytest.raises(ValueError):
+        ssd_300((300, 300, 3), 20)                                   # neither scales nor min/max scale
