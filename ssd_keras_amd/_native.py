@@ -12,7 +12,8 @@ import threading
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libssdhip.so")
+# SSDHIP_LIB lets tools/ load the instrumented build of the same sources (tools/prof_build.sh); never a CPU fallback.
+_LIB_PATH = os.environ.get("SSDHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libssdhip.so")
 _lib = None
 _lock = threading.Lock()
 

@@ -26,26 +26,55 @@
 
 #include "ssdhip.h"
 #include "ssdhip_math.h"
+#include "ssdhip_tile.h"
+
+// In-kernel phase timers, compiled only into the profiling build (tools/prof_build.sh, -DSSDHIP_PROFILE).
+#ifdef SSDHIP_PROFILE
+__device__ unsigned long long g_prof[64];
+#define PROF_DECL long long _pt = clock64(); long long _pa[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_MARK(i) { const long long _t = clock64(); _pa[i] += _t - _pt; _pt = _t; }
+#define PROF_FLUSH(base) if (threadIdx.x == 0) { for (int _i = 0; _i < 12; ++_i) if (_pa[_i]) atomicAdd(&g_prof[(base) + _i], (unsigned long long)_pa[_i]); }
+extern "C" int ssdhip_profile_read(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH(base)
+#endif
 
 namespace ssdhip {
 
 constexpr int IDX_BITS = 20;                 // anchor index field of a candidate key: N <= 2^20
 constexpr u32 IDX_MASK = (1u << IDX_BITS) - 1u;
-constexpr int DIGIT_BITS = 13;               // radix-select digit
+constexpr int DIGIT_BITS = 13;               // histogram resolution of the chunk selection
 constexpr int NBINS = 1 << DIGIT_BITS;       // 8192 LDS counters = 32 KiB
 constexpr int NMS_THREADS = 256;
-constexpr int MAX_CHUNK = 2048;              // keys sorted per round in K4
-constexpr int KEPT_LDS = 512;                // survivors whose pixel boxes are cached in LDS
+constexpr int MAX_CHUNK = 1024;              // candidates sorted + staged per round in K4
+constexpr int KEPT_LDS = 512;                // survivors whose boxes are cached in LDS
 constexpr int TOPK_SORT_MAX = 4096;          // rows K5 can return sorted
 
 struct DecodeParams {
     int B, N, C, L, G;          // L = C + 12, G = groups per image (C-1, or 1 when class-agnostic)
     int class_agnostic, semantics, coords, border;
-    int thr_f32, thr_inclusive; // threshold compare: in float32?  '>=' instead of '>'?
+    int thr_inclusive;          // '>=' instead of '>'
+    float thr_eff;              // float32 threshold with the same outcome as the reference's compare (see host code)
+    u32 bin_base;               // float_key(thr_eff) >> 13: origin of the score histogram
     int iou_f32;                // NMS arithmetic in float32 (reference: float32 input + 'corners')
-    double conf_thresh, iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
+    int fast_ok;                // float32 pre-test of IoU > thr usable (image size exactly representable, |thr| <= 1)
+    double iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
     int top_k, cap, cap_store, out_rows, sorted;
 };
+
+// monotone score-key -> histogram bin: 2^13 float32 ulps per bin starting at the threshold (8 binades), clamped
+__device__ __forceinline__ int bin_of(u32 skey, u32 bin_base) {
+    const u32 v = skey >> 13;
+    if (v <= bin_base) return 0;
+    const u32 d = v - bin_base;
+    return d > (u32)(NBINS - 1) ? NBINS - 1 : (int)d;
+}
 
 // ======================================================================================
 // K3
@@ -55,15 +84,6 @@ __device__ __forceinline__ float decode_center(float off, float var, float a_wh,
     if (SEM == SSDHIP_SEM_KERAS) return (off * var) * a_wh + a_c;      // keras_layer_DecodeDetections.py:124-125
     if (SEM == SSDHIP_SEM_DEBUG) return (off * a_wh) * var + a_c;      // ssd_output_decoder.py:400
     return off * (var * a_wh) + a_c;                                   // ssd_output_decoder.py:177-178
-}
-
-__device__ __forceinline__ bool over_threshold(float s, const DecodeParams& p) {
-    if (p.thr_f32) {
-        const float t = (float)p.conf_thresh;
-        return p.thr_inclusive ? (s >= t) : (s > t);
-    }
-    const double t = p.conf_thresh;
-    return p.thr_inclusive ? ((double)s >= t) : ((double)s > t);
 }
 
 __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, DecodeParams p,
@@ -79,22 +99,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
     const int lane = tid & 63, wave = tid >> 6, nwaves = TA >> 6;
 
     // ---- coalesced tile copy: rows [a0, a0+na) are one contiguous run of na*L floats ----
-    const float* src = y + ((size_t)b * p.N + a0) * (size_t)L;
-    const int total = na * L;
-    const int phase = (int)(((uintptr_t)src & 15u) >> 2);         // keep the 16-byte phase of global memory in LDS
-    float* tile = reinterpret_cast<float*>(smem_raw) + phase;      // tile[i] <-> src[i]
+    const float* tile = tile_copy_f32(reinterpret_cast<float*>(smem_raw), y + ((size_t)b * p.N + a0) * (size_t)L, na * L, tid, TA);
     int* wave_cnt = reinterpret_cast<int*>(smem_raw + (((size_t)TA * L + 4) * sizeof(float) + 15) / 16 * 16);
-    {
-        const int head = min(total, (4 - phase) & 3);
-        if (tid < head) tile[tid] = src[tid];
-        const int nvec = (total - head) >> 2;
-        const float4* vsrc = reinterpret_cast<const float4*>(src + head);
-        float4* vdst = reinterpret_cast<float4*>(tile + head);
-        for (int i = tid; i < nvec; i += TA) vdst[i] = vsrc[i];
-        const int done = head + (nvec << 2);
-        if (tid < total - done) tile[done + tid] = src[done + tid];
-    }
+    PROF_DECL
     __syncthreads();
+    PROF_MARK(0)
 
     const bool active = tid < na;
     const float* row = tile + (size_t)tid * L;
@@ -139,28 +148,46 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
             int bi = 0;
             for (int c = 1; c < C; ++c) {
                 const float s = row[c];
-                if (s > best || (best != best && s == s)) { best = s; bi = c; }
+                if (s > best) { best = s; bi = c; }
             }
-            // np.argmax/np.amax propagate NaN (first NaN wins); mirror that
-            for (int c = 0; c < C; ++c) if (row[c] != row[c]) { best = row[c]; bi = c; break; }
+            for (int c = 0; c < C; ++c) if (row[c] != row[c]) { best = row[c]; bi = c; break; }   // np.argmax: first NaN wins
             fast_cls = bi;
             fast_conf = best;
             cls_out[(size_t)b * p.N + a0 + tid] = (unsigned short)bi;
         }
     }
+    PROF_MARK(1)
 
-    // ---- pass 1: how many candidates does each wave hold per group ----
+    // ---- candidate bit masks, 64 groups at a time; pass 1 counts per (wave, group) ----
     const int G = p.G;
-    for (int g = 0; g < G; ++g) {
-        bool pred = false;
-        if (active) {
-            if (p.class_agnostic) pred = (fast_cls != 0) && over_threshold(fast_conf, p);
-            else pred = over_threshold(row[g + 1], p);
+    const float t = p.thr_eff;
+    const bool incl = p.thr_inclusive != 0;
+    auto group_mask = [&](int gb, int ng) -> u64 {
+        u64 mask = 0;
+        if (!active) return mask;
+        if (p.class_agnostic) {
+            const bool c = (fast_cls != 0) && (incl ? (fast_conf >= t) : (fast_conf > t));
+            return c ? 1ull : 0ull;
         }
-        const u64 m = __ballot(pred);
-        if (lane == 0) wave_cnt[wave * G + g] = __popcll(m);
+        const float* sc = row + gb + 1;
+#pragma unroll 4
+        for (int j = 0; j < ng; ++j) {
+            const float s = sc[j];
+            const bool c = incl ? (s >= t) : (s > t);
+            mask |= (u64)c << j;
+        }
+        return mask;
+    };
+    for (int gb = 0; gb < G; gb += 64) {
+        const int ng = min(64, G - gb);
+        const u64 mask = group_mask(gb, ng);
+        for (int j = 0; j < ng; ++j) {
+            const u64 m = __ballot((mask >> j) & 1ull);
+            if (lane == 0) wave_cnt[wave * G + gb + j] = __popcll(m);
+        }
     }
     __syncthreads();
+    PROF_MARK(2)
     // ---- one global atomic per (workgroup, group) reserves the slots ----
     for (int g = tid; g < G; g += TA) {
         int tot = 0;
@@ -174,29 +201,34 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
         }
     }
     __syncthreads();
+    PROF_MARK(3)
     // ---- pass 2: write the keys ----
     const u64 lt = lanemask_lt();
     const u32 inv_idx = IDX_MASK - (u32)(a0 + tid);
-    for (int g = 0; g < G; ++g) {
-        bool pred = false;
-        float s = 0.f;
-        if (active) {
-            if (p.class_agnostic) { s = fast_conf; pred = (fast_cls != 0) && over_threshold(s, p); }
-            else { s = row[g + 1]; pred = over_threshold(s, p); }
-        }
-        const u64 m = __ballot(pred);
-        if (pred) {
-            const int slot = wave_cnt[wave * G + g] + __popcll(m & lt);
-            cand[((size_t)b * G + g) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
+    for (int gb = 0; gb < G; gb += 64) {
+        const int ng = min(64, G - gb);
+        const u64 mask = group_mask(gb, ng);
+        for (int j = 0; j < ng; ++j) {
+            const bool pred = (mask >> j) & 1ull;
+            const u64 m = __ballot(pred);
+            if (m == 0) continue;
+            if (pred) {
+                const int g = gb + j;
+                const float s = p.class_agnostic ? fast_conf : row[g + 1];
+                const int slot = wave_cnt[wave * G + g] + __popcll(m & lt);
+                cand[((size_t)b * G + g) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
+            }
         }
     }
+    PROF_MARK(4)
+    PROF_FLUSH(16)
 }
 
 // ======================================================================================
 // block-wide helpers (256 threads)
 // ======================================================================================
-// k-th largest (k >= 1) of {key : key < upper (if has_upper)} over a list in global memory.
-// `hist` = NBINS LDS counters, `red` = 260 LDS ints.  Keys are unique, so exactly k keys are >= result.
+// Exact k-th largest (k >= 1) of {key : key < upper (if has_upper)}: radix select, one pass per 13-bit digit.
+// Only the fallback when a histogram bin overflows the chunk.  `hist` = NBINS LDS counters, `red` = 260 LDS ints.
 template <int KEY_BITS, typename KeyF>
 __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, int k, u32* hist, int* red) {
     const int tid = threadIdx.x;
@@ -223,20 +255,38 @@ __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, i
     return prefix;
 }
 
-// in-LDS bitonic sort, descending, P a power of two >= 2 (P/2 compare-exchanges per step spread over the block)
-__device__ void block_bitonic_desc(u64* buf, int P) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += NMS_THREADS) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int ixj = i | j;
-                const u64 a = buf[i], b = buf[ixj];
-                const bool desc = (i & k) == 0;
-                if (desc ? (a < b) : (a > b)) { buf[i] = b; buf[ixj] = a; }
-            }
-            __syncthreads();
-        }
+// Rank sort, descending, out of place: out[#{j : in[j] > in[i]}] = in[i].  Keys are unique; in[m] must be readable.
+// Every thread streams the whole list through LDS broadcast reads and ranks PER of its own keys in registers.
+template <int PER>
+__device__ __forceinline__ void rank_sort_desc_impl(u64* in, u64* out, int m) {
+    const int tid = threadIdx.x;
+    u64 mine[PER];
+    int rank[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = tid + t * NMS_THREADS;
+        mine[t] = i < m ? in[i] : ~0ull;
+        rank[t] = 0;
     }
+    for (int j = 0; j < m; j += 2) {
+        const u64 a = in[j], b2 = in[j + 1];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) rank[t] += (int)(a > mine[t]) + (int)(b2 > mine[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = tid + t * NMS_THREADS;
+        if (i < m) out[rank[t]] = mine[t];
+    }
+}
+
+__device__ void block_rank_sort_desc(u64* in, u64* out, int m) {   // m <= 4 * NMS_THREADS; in has m+1 slots
+    if (threadIdx.x == 0) in[m] = 0;
+    __syncthreads();
+    if (m <= NMS_THREADS) rank_sort_desc_impl<1>(in, out, m);
+    else if (m <= 2 * NMS_THREADS) rank_sort_desc_impl<2>(in, out, m);
+    else rank_sort_desc_impl<4>(in, out, m);
+    __syncthreads();
 }
 
 // ======================================================================================
@@ -245,7 +295,7 @@ __device__ void block_bitonic_desc(u64* buf, int P) {
 template <typename F>
 __device__ __forceinline__ PxBox<F> px_box(const float4 bx, F W, F H, F d) {
     PxBox<F> r;
-    r.x0 = (F)bx.x * W;                 // exact in double; the float32 product when F = float (corners flow)
+    r.x0 = (F)bx.x * W;                 // exact in double
     r.y0 = (F)bx.y * H;
     r.x1 = (F)bx.z * W;
     r.y1 = (F)bx.w * H;
@@ -253,7 +303,58 @@ __device__ __forceinline__ PxBox<F> px_box(const float4 bx, F W, F H, F d) {
     return r;
 }
 
-template <typename F>
+// A box as the NMS loop holds it in LDS: float32 pixel corners + what the conservative pre-test needs.
+struct NBox {
+    float x0, y0, x1, y1, area;   // area = (x1-x0+d)*(y1-y0+d): exactly the reference's float32 flow
+    float P;                      // |w| + |h| + 2  (bounds the side lengths entering any product)
+    float A;                      // |x0|+|y0|+|x1|+|y1| (bounds every coordinate; NaN/inf propagate)
+    u32 idx;                      // anchor index, to fetch the float32 box for the exact float64 evaluation
+};
+
+__device__ __forceinline__ NBox make_nbox(const float4 bx, u32 idx, float W, float H, float d) {
+    NBox r;
+    r.x0 = bx.x * W; r.y0 = bx.y * H; r.x1 = bx.z * W; r.y1 = bx.w * H;
+    const float w = r.x1 - r.x0, h = r.y1 - r.y0;
+    r.area = (w + d) * (h + d);
+    r.P = fabsf(w) + fabsf(h) + 2.0f;
+    r.A = (fabsf(r.x0) + fabsf(r.y0)) + (fabsf(r.x1) + fabsf(r.y1));
+    r.idx = idx;
+    return r;
+}
+
+// "IoU(a,b) is NOT <= thr" (the reference's suppression test, ssd_output_decoder.py:91).
+//  * float32 flow (F32FLOW): the reference itself works in float32 -> evaluate it directly, IEEE division.
+//  * float64 flow: first a float32 evaluation of inter - thr*union with a rigorous error bound T
+//    (every length is off by <= 3u*A, products by that times the other side, u = 2^-24; constants doubled);
+//    only pairs within T of the threshold, non-finite boxes or non-positive unions take the exact float64 path
+//    (IEEE division, the reference's operation order) on the original float32 boxes.
+template <bool F32FLOW>
+__device__ __forceinline__ bool suppresses(const NBox& a, const NBox& b, const float4* __restrict__ img_boxes,
+                                           const DecodeParams& p, float thr32, float d32) {
+    const float iw = fmaxf(fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), 0.f);
+    const float ih = fmaxf(fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0), 0.f);
+    if (F32FLOW) {
+        PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
+        const float v = iou_px<float>(pa, pb);
+        return !(v <= thr32);
+    }
+    if (p.fast_ok) {
+        const float inter = iw * ih;
+        const float uni = (a.area + b.area) - inter;
+        const float num = inter - thr32 * uni;
+        const float T = (0x1p-20f * (a.A + b.A)) * (a.P + b.P) + 0x1p-20f * (fabsf(a.area) + fabsf(b.area));
+        if (uni > T) {
+            if (num > T) return true;
+            if (num < -T) return false;
+        }
+    }
+    const double W = p.img_w, H = p.img_h, d = (double)d32;
+    const PxBox<double> pa = px_box<double>(img_boxes[a.idx], W, H, d), pb = px_box<double>(img_boxes[b.idx], W, H, d);
+    const double v = iou_px<double>(pa, pb);
+    return !(v <= p.iou_thresh);
+}
+
+template <bool F32FLOW>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
                                                           const u64* __restrict__ cand, const int* __restrict__ cand_count,
                                                           u64* __restrict__ kept, int* __restrict__ kept_count) {
@@ -265,88 +366,128 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
     if ((int)(blockIdx.x >> 3) >= per_xcd || work >= total_work) return;
     const int b = work / p.G;
 
-    __shared__ __attribute__((aligned(16))) u64 sortbuf[NBINS * sizeof(u32) / sizeof(u64)];   // 32 KiB, aliased with hist
-    __shared__ PxBox<F> kcache[KEPT_LDS];
-    __shared__ PxBox<F> cbox[64];
+    __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 2];     // unsorted chunk
+    __shared__ __attribute__((aligned(16))) u64 sorted[MAX_CHUNK + 2];     // sorted chunk
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[NBINS * sizeof(u32)];   // hist, then the chunk's NBoxes
+    __shared__ NBox kcache[KEPT_LDS];
     __shared__ u64 maskrow[64];
     __shared__ u64 supp_a[NMS_THREADS / 64];
     __shared__ int red[260];
     __shared__ int fill;
-    u32* hist = reinterpret_cast<u32*>(sortbuf);
+    u32* hist = reinterpret_cast<u32*>(scratch);
+    NBox* cbox = reinterpret_cast<NBox*>(scratch);
+    static_assert(sizeof(NBox) * MAX_CHUNK <= NBINS * sizeof(u32), "chunk boxes alias the histogram");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cand_count[work];
     const u64* keys = cand + (size_t)work * p.N;
     u64* kept_out = kept + (size_t)work * p.cap_store;
     const float4* img_boxes = boxes + (size_t)b * p.N;
-    const F W = (F)p.img_w, H = (F)p.img_h;
-    const F d = p.border == SSDHIP_BORDER_INCLUDE ? (F)1 : (p.border == SSDHIP_BORDER_EXCLUDE ? (F)-1 : (F)0);
-    const F thr = (F)p.iou_thresh;
+    const float W32 = (float)p.img_w, H32 = (float)p.img_h;
+    const float d32 = p.border == SSDHIP_BORDER_INCLUDE ? 1.f : (p.border == SSDHIP_BORDER_EXCLUDE ? -1.f : 0.f);
+    const float thr32 = (float)p.iou_thresh;
     const int cap_eff = min(p.cap_store, n);
 
     int K = 0, consumed = 0;
-    u64 upper = 0;
-    bool has_upper = false;
+    u64 upper = ~0ull;                       // keys >= upper are consumed; a real key is never all ones (its score field is a
+    bool has_upper = false;                  // float key, whose all-ones value is a NaN that cannot pass the threshold)
+    PROF_DECL
     while (consumed < n && K < cap_eff) {
         const int remaining = n - consumed;
-        // chunk size: enough for the survivors still wanted (x2 headroom for suppressed ones), a power of two
-        int want = 2 * (cap_eff - K);
+        int want = 2 * (cap_eff - K);        // survivors still wanted, x2 headroom for suppressed candidates
         int M = 256;
         while (M < want && M < MAX_CHUNK) M <<= 1;
         int m;
         u64 cutoff = 0;
-        if (remaining <= M) {
-            m = remaining;
+        bool by_bin = false;
+        int bin_cut = 0;
+        if (remaining <= MAX_CHUNK) {
+            m = remaining;                   // take everything that is left
         } else {
-            m = M;
-            cutoff = block_select_kth<32 + IDX_BITS>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
+            // histogram of the remaining keys by score bin -> lowest bin such that >= M keys lie at or above it
+            for (int i = tid; i < NBINS; i += NMS_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (int i0 = tid; i0 < n; i0 += 4 * NMS_THREADS) {
+                u64 k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * NMS_THREADS; k4[u] = i < n ? keys[i] : ~0ull; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (k4[u] < upper) atomicAdd(&hist[bin_of((u32)(k4[u] >> IDX_BITS), p.bin_base)], 1u);
+            }
+            __syncthreads();
+            block_find_digit<NBINS / NMS_THREADS>(hist, M, red, red + 256);
+            bin_cut = red[256];
+            m = red[257] + (int)hist[bin_cut];
+            __syncthreads();
+            if (m <= MAX_CHUNK) {
+                by_bin = true;
+            } else {                         // one bin holds too many equal-ish scores: exact selection of the M best
+                m = M;
+                cutoff = block_select_kth<32 + IDX_BITS>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
+            }
         }
+        PROF_MARK(0)
         if (tid == 0) fill = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += NMS_THREADS) {
-            const u64 key = keys[i];
-            if (key >= cutoff && (!has_upper || key < upper)) sortbuf[atomicAdd(&fill, 1)] = key;
+        for (int i0 = tid; i0 < n; i0 += 4 * NMS_THREADS) {
+            u64 k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * NMS_THREADS; k4[u] = i < n ? keys[i] : ~0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u64 key = k4[u];
+                if (!(key < upper)) continue;
+                const bool take = by_bin ? (bin_of((u32)(key >> IDX_BITS), p.bin_base) >= bin_cut) : (key >= cutoff);
+                if (take) keybuf[atomicAdd(&fill, 1)] = key;
+            }
         }
-        int P = 2;
-        while (P < m) P <<= 1;
         __syncthreads();
-        for (int i = m + tid; i < P; i += NMS_THREADS) sortbuf[i] = 0;
-        __syncthreads();
-        block_bitonic_desc(sortbuf, P);
-        upper = sortbuf[m - 1];
+        PROF_MARK(1)
+        block_rank_sort_desc(keybuf, sorted, m);
+        PROF_MARK(2)
+        upper = sorted[m - 1];
         has_upper = true;
         consumed += m;
+        // stage the chunk's boxes (independent gathers, one latency exposure per round)
+        for (int i = tid; i < m; i += NMS_THREADS) {
+            const u32 idx = IDX_MASK - (u32)(sorted[i] & IDX_MASK);
+            cbox[i] = make_nbox(img_boxes[idx], idx, W32, H32, d32);
+        }
+        __syncthreads();
+        PROF_MARK(3)
 
         for (int base = 0; base < m && K < cap_eff; base += 64) {
             const int nb = min(64, m - base);
             const bool valid = lane < nb;
-            const u64 key = valid ? sortbuf[base + lane] : 0;
-            PxBox<F> me = {};
-            if (valid) me = px_box<F>(img_boxes[IDX_MASK - (u32)(key & IDX_MASK)], W, H, d);
-            if (wave == 0) cbox[lane] = me;
+            const NBox me = cbox[base + (valid ? lane : 0)];
             // phase A: against survivors of earlier batches, kept list striped over the waves
             bool supp = false;
             for (int j = wave; j < K; j += NMS_THREADS / 64) {
-                PxBox<F> kb;
+                NBox kb;
                 if (j < KEPT_LDS) kb = kcache[j];
-                else kb = px_box<F>(img_boxes[IDX_MASK - (u32)(kept_out[j] & IDX_MASK)], W, H, d);
-                const F v = iou_px<F>(me, kb);
-                supp = supp || !(v <= thr);
+                else { const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK); kb = make_nbox(img_boxes[idx], idx, W32, H32, d32); }
+                supp = supp || suppresses<F32FLOW>(me, kb, img_boxes, p, thr32, d32);
             }
             const u64 sa = __ballot(supp && valid);
             if (lane == 0) supp_a[wave] = sa;
-            __syncthreads();
+            PROF_MARK(4)
             // phase B: in-batch suppression rows, 16 per wave: bit i of maskrow[j] = "j suppresses i" (i > j)
             for (int jj = 0; jj < 16; ++jj) {
                 const int j = wave * 16 + jj;
                 if (j >= nb) break;
-                const F v = iou_px<F>(me, cbox[j]);
-                const u64 mrow = __ballot(valid && lane > j && !(v <= thr));
+                const NBox cj = cbox[base + j];
+                const bool sj = suppresses<F32FLOW>(me, cj, img_boxes, p, thr32, d32);
+                const u64 mrow = __ballot(valid && lane > j && sj);
                 if (lane == 0) maskrow[j] = mrow;
             }
             __syncthreads();
-            // resolve (every wave computes the same scalars)
-            u64 alive = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) & ~(supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3]);
+            PROF_MARK(5)
+            // resolve: scalar loop over the surviving bits; the 64 mask rows sit one per lane and are fetched by readlane
+            const u64 myrow = maskrow[lane];
+            const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
+            const u64 sall = supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3];
+            u64 alive = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) & ~sall;
+            alive = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(alive >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)alive);
             u64 keptmask = 0;
             int cnt = 0;
             while (alive) {
@@ -354,18 +495,24 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
                 keptmask |= 1ull << j;
                 ++cnt;
                 if (K + cnt >= cap_eff) break;
-                alive &= ~maskrow[j];
+                const u64 mj = ((u64)(u32)__builtin_amdgcn_readlane((int)row_hi, j) << 32) | (u32)__builtin_amdgcn_readlane((int)row_lo, j);
+                alive &= ~mj;
                 alive &= ~(1ull << j);
             }
             if (wave == 0 && ((keptmask >> lane) & 1ull)) {
                 const int pos = K + __popcll(keptmask & lanemask_lt());
-                kept_out[pos] = key;
+                kept_out[pos] = sorted[base + lane];
                 if (pos < KEPT_LDS) kcache[pos] = me;
             }
             K += cnt;
             __syncthreads();
+            PROF_MARK(6)
         }
     }
+    PROF_FLUSH(0)
+#ifdef SSDHIP_PROFILE
+    if (tid == 0) { atomicAdd(&g_prof[12], 1ull); atomicAdd(&g_prof[13], (unsigned long long)consumed); atomicAdd(&g_prof[14], (unsigned long long)K); }
+#endif
     if (tid == 0) kept_count[work] = K;
 }
 
@@ -395,9 +542,9 @@ __device__ __forceinline__ void write_row(OutT* out, int* out_idx, int row, int 
     if (out_idx) out_idx[row] = (int)idx;
 }
 
-// entry e of the class-major concatenation of an image's survivor lists -> (group, rank)
+// entry e of the class-major concatenation of an image's survivor lists -> group (offs[g] <= e < offs[g+1])
 __device__ __forceinline__ int find_group(const int* offs, int G, int e) {
-    int lo = 0, hi = G;                  // offs[g] <= e < offs[g+1]
+    int lo = 0, hi = G;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (offs[mid] <= e) lo = mid; else hi = mid;
@@ -412,12 +559,14 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
                                                            OutT* __restrict__ out, int* __restrict__ out_count,
                                                            int* __restrict__ out_idx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64* sortbuf = reinterpret_cast<u64*>(smem_raw);                       // 32 KiB (aliased with hist)
+    u64* bufa = reinterpret_cast<u64*>(smem_raw);                                         // 32 KiB: hist, then collected keys
     u32* hist = reinterpret_cast<u32*>(smem_raw);
-    int* offs = reinterpret_cast<int*>(smem_raw + NBINS * sizeof(u32));    // G+1 ints
+    u64* bufb = reinterpret_cast<u64*>(smem_raw + NBINS * sizeof(u32));                   // 32 KiB + 16: sorted keys
+    int* offs = reinterpret_cast<int*>(smem_raw + 2 * NBINS * sizeof(u32) + 16);          // G+1 ints
     __shared__ int red[260];
     __shared__ int fill;
     __shared__ int wave_tot[NMS_THREADS / 64];
+    __shared__ u64 sh_cut;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
@@ -427,23 +576,41 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
     int* img_idx = out_idx ? out_idx + (size_t)b * p.out_rows : nullptr;
     const unsigned short* img_cls = p.class_agnostic ? cls_map + (size_t)b * p.N : nullptr;
 
-    if (tid == 0) {
-        int acc = 0;
-        for (int g = 0; g < G; ++g) { offs[g] = acc; acc += kept_count[b * G + g]; }
-        offs[G] = acc;
+    // class-major offsets: block scan of the survivor counts
+    {
+        int run = 0;
+        for (int g0 = 0; g0 < G; g0 += NMS_THREADS) {
+            const int g = g0 + tid;
+            const int c = g < G ? kept_count[b * G + g] : 0;
+            int inc = c;                                         // inclusive scan inside the wave
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+            if (lane == 63) wave_tot[wave] = inc;
+            __syncthreads();
+            int before = run;
+            for (int w = 0; w < wave; ++w) before += wave_tot[w];
+            if (g < G) offs[g] = before + inc - c;
+            for (int w = 0; w < NMS_THREADS / 64; ++w) run += wave_tot[w];
+            __syncthreads();
+        }
+        if (tid == 0) offs[G] = run;
     }
+    PROF_DECL
     __syncthreads();
+    PROF_MARK(0)
     const int T = offs[G];
     int rows = p.top_k > 0 ? min(T, p.top_k) : T;
     rows = min(rows, p.out_rows);
 
-    // composite key of entry e: [score key (32) | inverted class-major position (32)] -> score desc, then class asc,
+    // composite key of a survivor: [score key (32) | inverted class-major position (32)] -> score desc, then class asc,
     // then NMS rank asc -- tf.nn.top_k's tie order on the layer's class-major padded array.
+    auto comp_of = [&](int g, int r) -> u64 {
+        const u64 key = img_kept[(size_t)g * p.cap_store + r];
+        const u32 pos = (u32)g * (u32)p.cap_store + (u32)r;
+        return ((key >> IDX_BITS) << 32) | (u64)(0xffffffffu - pos);
+    };
     auto comp_at = [&](int e) -> u64 {
         const int g = find_group(offs, G, e);
-        const u64 key = img_kept[(size_t)g * p.cap_store + (e - offs[g])];
-        const u32 pos = (u32)g * (u32)p.cap_store + (u32)(e - offs[g]);
-        return ((key >> IDX_BITS) << 32) | (u64)(0xffffffffu - pos);
+        return comp_of(g, e - offs[g]);
     };
     auto emit = [&](int row, u64 comp) {
         const u32 pos = 0xffffffffu - (u32)comp;
@@ -453,25 +620,71 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
         write_row<OutT>(img_out, img_idx, row, cls, key, img_boxes, p);
     };
 
+    // ---- the rows-th largest composite key (only when something has to be cut) ----
     u64 cutoff = 0;
-    if (T > rows && rows > 0) cutoff = block_select_kth<64>(comp_at, T, 0, false, rows, hist, red);
+    if (T > rows && rows > 0) {
+        for (int i = tid; i < NBINS; i += NMS_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int g = 0; g < G; ++g) {
+            const int kc = offs[g + 1] - offs[g];
+            for (int r = tid; r < kc; r += NMS_THREADS)
+                atomicAdd(&hist[bin_of((u32)(img_kept[(size_t)g * p.cap_store + r] >> IDX_BITS), p.bin_base)], 1u);
+        }
+        __syncthreads();
+        block_find_digit<NBINS / NMS_THREADS>(hist, rows, red, red + 256);
+        const int bin_cut = red[256];
+        const int need = rows - red[257];                      // how many of bin_cut's entries make the cut
+        const int in_bin = (int)hist[bin_cut];
+        __syncthreads();
+        if (in_bin <= TOPK_SORT_MAX) {
+            if (tid == 0) fill = 0;
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int kc = offs[g + 1] - offs[g];
+                for (int r = tid; r < kc; r += NMS_THREADS) {
+                    const u64 key = img_kept[(size_t)g * p.cap_store + r];
+                    if (bin_of((u32)(key >> IDX_BITS), p.bin_base) == bin_cut) bufa[atomicAdd(&fill, 1)] = comp_of(g, r);
+                }
+            }
+            __syncthreads();
+            // the need-th largest of the bin's entries: rank each one against the others
+            for (int i = tid; i < in_bin; i += NMS_THREADS) {
+                const u64 mine = bufa[i];
+                int rank = 0;
+                for (int j = 0; j < in_bin; ++j) rank += (int)(bufa[j] > mine);
+                if (rank == need - 1) sh_cut = mine;
+            }
+            __syncthreads();
+            cutoff = sh_cut;
+        } else {
+            cutoff = block_select_kth<64>(comp_at, T, 0, false, rows, hist, red);
+        }
+    }
     __syncthreads();
+    PROF_MARK(1)
 
     if (rows > 0 && p.sorted) {
-        // collect the selected entries, sort them, write in order
+        // collect the selected entries, rank-sort them, write in order
         if (tid == 0) fill = 0;
         __syncthreads();
-        for (int e = tid; e < T; e += NMS_THREADS) {
-            const u64 c = comp_at(e);
-            if (c >= cutoff) sortbuf[atomicAdd(&fill, 1)] = c;
+        for (int g = 0; g < G; ++g) {
+            const int kc = offs[g + 1] - offs[g];
+            for (int r = tid; r < kc; r += NMS_THREADS) {
+                const u64 c = comp_of(g, r);
+                if (c >= cutoff) bufa[atomicAdd(&fill, 1)] = c;
+            }
         }
-        int P = 2;
-        while (P < rows) P <<= 1;
         __syncthreads();
-        for (int i = rows + tid; i < P; i += NMS_THREADS) sortbuf[i] = 0;
+        PROF_MARK(2)
+        for (int i = tid; i < rows; i += NMS_THREADS) {
+            const u64 mine = bufa[i];
+            int rank = 0;
+            for (int j = 0; j < rows; ++j) rank += (int)(bufa[j] > mine);
+            bufb[rank] = mine;
+        }
         __syncthreads();
-        block_bitonic_desc(sortbuf, P);
-        for (int r = tid; r < rows; r += NMS_THREADS) emit(r, sortbuf[r]);
+        PROF_MARK(3)
+        for (int r = tid; r < rows; r += NMS_THREADS) emit(r, bufb[r]);
     } else if (rows > 0) {
         // class-major order (the reference's order when nothing is cut); selected entries compacted by a block scan
         int base = 0;
@@ -490,10 +703,13 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
             __syncthreads();
         }
     }
+    PROF_MARK(4)
     // zero padding
     for (int i = rows * 6 + tid; i < p.out_rows * 6; i += NMS_THREADS) img_out[i] = (OutT)0;
     if (img_idx) for (int i = rows + tid; i < p.out_rows; i += NMS_THREADS) img_idx[i] = -1;
     if (tid == 0) out_count[b] = rows;
+    PROF_MARK(5)
+    PROF_FLUSH(32)
 }
 
 // ======================================================================================
@@ -508,7 +724,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static int cap_store_for(int N, int top_k, int nms_cap) {
     int cap = N;                                   // uncapped: every candidate may survive
     if (nms_cap > 0) cap = nms_cap < cap ? nms_cap : cap;
-    else if (top_k > 0) cap = top_k < cap ? top_k : cap;   // members of the global top-k are within a class's first top_k survivors
+    if (top_k > 0) cap = top_k < cap ? top_k : cap;        // members of the global top-k are within a class's first top_k survivors
     return cap < 1 ? 1 : cap;
 }
 
@@ -562,11 +778,27 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
     p.semantics = semantics; p.coords = coords; p.border = border_pixels;
     // dtype flow of the reference: float32 predictions stay float32 only on the 'corners' path (no convert_coordinates)
     p.iou_f32 = (semantics != SSDHIP_SEM_KERAS && coords == SSDHIP_CORNERS) ? 1 : 0;
-    p.thr_f32 = (semantics == SSDHIP_SEM_KERAS || p.iou_f32) ? 1 : 0;
     p.thr_inclusive = (class_agnostic && semantics != SSDHIP_SEM_KERAS) ? 1 : 0;   // ssd_output_decoder.py:325 vs layer :180
-    p.conf_thresh = conf_thresh; p.iou_thresh = iou_thresh;
+    {
+        // The reference compares float32 scores with the python-float threshold either in float32 (Keras layer,
+        // 'corners' flow) or after widening the score to float64.  Both are reproduced by ONE float32 compare
+        // against thr_eff:  (double)s >  t  <=>  s >  largest float <= t ;  (double)s >= t  <=>  s >= smallest float >= t.
+        const bool cmp_f32 = (semantics == SSDHIP_SEM_KERAS) || p.iou_f32;
+        float te = (float)conf_thresh;
+        if (!cmp_f32 && conf_thresh == conf_thresh && te - te == 0.f) {
+            if (!p.thr_inclusive && (double)te > conf_thresh) te = nextafterf(te, -INFINITY);
+            if (p.thr_inclusive && (double)te < conf_thresh) te = nextafterf(te, INFINITY);
+        }
+        p.thr_eff = te;
+        union { float f; unsigned u; } cv;
+        cv.f = te;
+        const unsigned key = (cv.u & 0x80000000u) ? ~cv.u : (cv.u | 0x80000000u);
+        p.bin_base = key >> 13;
+    }
+    p.iou_thresh = iou_thresh;
     p.img_w = normalize_coords ? img_width : 1.0;
     p.img_h = normalize_coords ? img_height : 1.0;
+    p.fast_ok = ((double)(float)p.img_w == p.img_w && (double)(float)p.img_h == p.img_h && iou_thresh >= -1.0 && iou_thresh <= 1.0) ? 1 : 0;
     p.top_k = top_k; p.cap = nms_cap; p.cap_store = cap_store_for(N, top_k, nms_cap);
     p.out_rows = out_rows; p.sorted = sorted;
 
@@ -581,9 +813,9 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
     if (stages & 1) {
     if (hipMemsetAsync(cand_count, 0, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
 
-    // K3: tile = as many anchors as fit 64 KiB of LDS, 64..256 threads
+    // K3: small tiles (<= 24 KiB of LDS) keep many workgroups in flight per CU to hide the load -> atomic -> store chain
     int TA = 256;
-    while (TA > 64 && (size_t)TA * p.L * sizeof(float) > 64 * 1024) TA >>= 1;
+    while (TA > 64 && (size_t)TA * p.L * sizeof(float) > 24 * 1024) TA >>= 1;
     const size_t k3_lds = align_up(((size_t)TA * p.L + 4) * sizeof(float), 16) + (size_t)(TA / 64) * p.G * sizeof(int);
     if (k3_lds > 160 * 1024) return SSDHIP_E_BADARG;
     dim3 g3((N + TA - 1) / TA, B);
@@ -595,13 +827,13 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
     if (stages & 2) {
     const int work = B * p.G;
     const int g4 = ((work + 7) / 8) * 8;
-    if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<float>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
-    else hipLaunchKernelGGL(nms_kernel<double>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<true>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    else hipLaunchKernelGGL(nms_kernel<false>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
 
     if (stages & 4) {
-    const size_t k5_lds = NBINS * sizeof(u32) + align_up((size_t)(p.G + 1) * sizeof(int), 16);
+    const size_t k5_lds = 2 * NBINS * sizeof(u32) + 16 + align_up((size_t)(p.G + 1) * sizeof(int), 16);
     if (out_dtype == SSDHIP_F32)
         hipLaunchKernelGGL(topk_kernel<float>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
                            static_cast<float*>(out), out_count, out_anchor_idx);
