@@ -49,11 +49,13 @@ namespace ssdhip {
 
 constexpr int IDX_BITS = 20;                 // anchor index field of a candidate key: N <= 2^20
 constexpr u32 IDX_MASK = (1u << IDX_BITS) - 1u;
-constexpr int DIGIT_BITS = 13;               // histogram resolution of the chunk selection
+constexpr int DIGIT_BITS = 13;               // radix-select digit / K5 histogram resolution
 constexpr int NBINS = 1 << DIGIT_BITS;       // 8192 LDS counters = 32 KiB
+constexpr int NMS_BIN_SHIFT = 14;            // K4 score histogram: 2^14 float32 ulps per bin ...
+constexpr int NMS_NBINS = 4096;              // ... 4096 bins = 16 KiB (9 binades above the threshold)
 constexpr int NMS_THREADS = 256;
-constexpr int MAX_CHUNK = 1024;              // candidates sorted + staged per round in K4
-constexpr int KEPT_LDS = 512;                // survivors whose boxes are cached in LDS
+constexpr int MAX_CHUNK = 512;               // candidates sorted + staged per round in K4
+constexpr int KEPT_LDS = 256;                // survivors whose boxes are cached in LDS
 constexpr int TOPK_SORT_MAX = 4096;          // rows K5 can return sorted
 
 struct DecodeParams {
@@ -61,19 +63,20 @@ struct DecodeParams {
     int class_agnostic, semantics, coords, border;
     int thr_inclusive;          // '>=' instead of '>'
     float thr_eff;              // float32 threshold with the same outcome as the reference's compare (see host code)
-    u32 bin_base;               // float_key(thr_eff) >> 13: origin of the score histogram
+    u32 thr_key;                // float_key(thr_eff): origin of the score histograms
     int iou_f32;                // NMS arithmetic in float32 (reference: float32 input + 'corners')
     int fast_ok;                // float32 pre-test of IoU > thr usable (image size exactly representable, |thr| <= 1)
     double iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
     int top_k, cap, cap_store, out_rows, sorted;
 };
 
-// monotone score-key -> histogram bin: 2^13 float32 ulps per bin starting at the threshold (8 binades), clamped
-__device__ __forceinline__ int bin_of(u32 skey, u32 bin_base) {
-    const u32 v = skey >> 13;
-    if (v <= bin_base) return 0;
-    const u32 d = v - bin_base;
-    return d > (u32)(NBINS - 1) ? NBINS - 1 : (int)d;
+// monotone score-key -> histogram bin: 2^SHIFT float32 ulps per bin starting at the threshold, clamped to NB-1
+template <int SHIFT, int NB>
+__device__ __forceinline__ int bin_of(u32 skey, u32 thr_key) {
+    const u32 v = skey >> SHIFT, base = thr_key >> SHIFT;
+    if (v <= base) return 0;
+    const u32 d = v - base;
+    return d > (u32)(NB - 1) ? NB - 1 : (int)d;
 }
 
 // ======================================================================================
@@ -158,33 +161,26 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
     }
     PROF_MARK(1)
 
-    // ---- candidate bit masks, 64 groups at a time; pass 1 counts per (wave, group) ----
+    // ---- pass 1: candidates per (wave, group).  One LDS read + one v_cmp (its SGPR result IS the ballot) + one
+    //      s_bcnt1 per class; the count is parked in lane j of a VGPR, one LDS store per 64 classes ----
     const int G = p.G;
     const float t = p.thr_eff;
     const bool incl = p.thr_inclusive != 0;
-    auto group_mask = [&](int gb, int ng) -> u64 {
-        u64 mask = 0;
-        if (!active) return mask;
-        if (p.class_agnostic) {
-            const bool c = (fast_cls != 0) && (incl ? (fast_conf >= t) : (fast_conf > t));
-            return c ? 1ull : 0ull;
-        }
-        const float* sc = row + gb + 1;
-#pragma unroll 4
-        for (int j = 0; j < ng; ++j) {
-            const float s = sc[j];
-            const bool c = incl ? (s >= t) : (s > t);
-            mask |= (u64)c << j;
-        }
-        return mask;
-    };
+    const bool fast_pred = active && (fast_cls != 0) && (incl ? (fast_conf >= t) : (fast_conf > t));
     for (int gb = 0; gb < G; gb += 64) {
         const int ng = min(64, G - gb);
-        const u64 mask = group_mask(gb, ng);
-        for (int j = 0; j < ng; ++j) {
-            const u64 m = __ballot((mask >> j) & 1ull);
-            if (lane == 0) wave_cnt[wave * G + gb + j] = __popcll(m);
+        int mycnt = 0;
+        if (p.class_agnostic) {
+            mycnt = __popcll(__ballot(fast_pred));
+        } else {
+            const float* sc = row + gb + 1;
+            for (int j = 0; j < ng; ++j) {
+                const float s = sc[j];
+                const bool pr = active && (incl ? (s >= t) : (s > t));
+                { const int cnt = __popcll(__ballot(pr)); mycnt = lane == j ? cnt : mycnt; }
+            }
         }
+        if (lane < ng) wave_cnt[wave * G + gb + lane] = mycnt;
     }
     __syncthreads();
     PROF_MARK(2)
@@ -202,21 +198,21 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
     }
     __syncthreads();
     PROF_MARK(3)
-    // ---- pass 2: write the keys ----
-    const u64 lt = lanemask_lt();
+    // ---- pass 2: write the keys (slot = wave base of the class + rank of the lane among the class's candidates) ----
     const u32 inv_idx = IDX_MASK - (u32)(a0 + tid);
     for (int gb = 0; gb < G; gb += 64) {
         const int ng = min(64, G - gb);
-        const u64 mask = group_mask(gb, ng);
+        const int mybase = lane < ng ? wave_cnt[wave * G + gb + lane] : 0;
+        const float* sc = row + gb + 1;
         for (int j = 0; j < ng; ++j) {
-            const bool pred = (mask >> j) & 1ull;
-            const u64 m = __ballot(pred);
+            const float s = p.class_agnostic ? fast_conf : sc[j];
+            const bool pr = p.class_agnostic ? fast_pred : (active && (incl ? (s >= t) : (s > t)));
+            const u64 m = __ballot(pr);
             if (m == 0) continue;
-            if (pred) {
-                const int g = gb + j;
-                const float s = p.class_agnostic ? fast_conf : row[g + 1];
-                const int slot = wave_cnt[wave * G + g] + __popcll(m & lt);
-                cand[((size_t)b * G + g) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
+            const int base_j = __builtin_amdgcn_readlane(mybase, j);
+            if (pr) {
+                const int slot = base_j + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                cand[((size_t)b * G + gb + j) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
             }
         }
     }
@@ -227,38 +223,40 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
 // ======================================================================================
 // block-wide helpers (256 threads)
 // ======================================================================================
-// Exact k-th largest (k >= 1) of {key : key < upper (if has_upper)}: radix select, one pass per 13-bit digit.
-// Only the fallback when a histogram bin overflows the chunk.  `hist` = NBINS LDS counters, `red` = 260 LDS ints.
-template <int KEY_BITS, typename KeyF>
+// Exact k-th largest (k >= 1) of {key : key < upper (if has_upper)}: radix select, one pass per DB-bit digit.
+// Only the fallback when a histogram bin overflows the chunk.  `hist` = 2^DB LDS counters, `red` = 260 LDS ints.
+template <int KEY_BITS, int DB, typename KeyF>
 __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, int k, u32* hist, int* red) {
     const int tid = threadIdx.x;
+    constexpr int NB = 1 << DB;
     u64 prefix = 0, pmask = 0;
-    constexpr int NPASS = (KEY_BITS + DIGIT_BITS - 1) / DIGIT_BITS;
+    constexpr int NPASS = (KEY_BITS + DB - 1) / DB;
     for (int pass = 0; pass < NPASS; ++pass) {
-        const int shift = (NPASS - 1 - pass) * DIGIT_BITS;
-        for (int i = tid; i < NBINS; i += NMS_THREADS) hist[i] = 0;
+        const int shift = (NPASS - 1 - pass) * DB;
+        for (int i = tid; i < NB; i += NMS_THREADS) hist[i] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += NMS_THREADS) {
             const u64 key = key_at(i);
             if (has_upper && !(key < upper)) continue;
             if ((key & pmask) != prefix) continue;
-            atomicAdd(&hist[(u32)(key >> shift) & (NBINS - 1)], 1u);
+            atomicAdd(&hist[(u32)(key >> shift) & (NB - 1)], 1u);
         }
         __syncthreads();
-        block_find_digit<NBINS / NMS_THREADS>(hist, k, red, red + 256);
+        block_find_digit<NB / NMS_THREADS>(hist, k, red, red + 256);
         const int d = red[256];
         k -= red[257];
         prefix |= (u64)d << shift;
-        pmask |= (u64)(NBINS - 1) << shift;
+        pmask |= (u64)(NB - 1) << shift;
         __syncthreads();
     }
     return prefix;
 }
 
-// Rank sort, descending, out of place: out[#{j : in[j] > in[i]}] = in[i].  Keys are unique; in[m] must be readable.
-// Every thread streams the whole list through LDS broadcast reads and ranks PER of its own keys in registers.
+// Rank sort, descending, out of place: out[#{j : in[j] > in[i]}] = in[i].  Keys are unique and non-zero; `in` needs
+// m + 8 slots.  Every thread streams the whole list through LDS broadcast reads (8 keys per step, so the loads
+// overlap the compares) and ranks PER of its own keys in registers.
 template <int PER>
-__device__ __forceinline__ void rank_sort_desc_impl(u64* in, u64* out, int m) {
+__device__ __forceinline__ void rank_sort_desc_impl(const u64* in, u64* out, int m) {
     const int tid = threadIdx.x;
     u64 mine[PER];
     int rank[PER];
@@ -268,10 +266,14 @@ __device__ __forceinline__ void rank_sort_desc_impl(u64* in, u64* out, int m) {
         mine[t] = i < m ? in[i] : ~0ull;
         rank[t] = 0;
     }
-    for (int j = 0; j < m; j += 2) {
-        const u64 a = in[j], b2 = in[j + 1];
+    for (int j = 0; j < m; j += 8) {
+        u64 k8[8];
 #pragma unroll
-        for (int t = 0; t < PER; ++t) rank[t] += (int)(a > mine[t]) + (int)(b2 > mine[t]);
+        for (int u = 0; u < 8; ++u) k8[u] = in[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < PER; ++t) rank[t] += (int)(k8[u] > mine[t]);
     }
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
@@ -280,12 +282,11 @@ __device__ __forceinline__ void rank_sort_desc_impl(u64* in, u64* out, int m) {
     }
 }
 
-__device__ void block_rank_sort_desc(u64* in, u64* out, int m) {   // m <= 4 * NMS_THREADS; in has m+1 slots
-    if (threadIdx.x == 0) in[m] = 0;
+__device__ void block_rank_sort_desc(u64* in, u64* out, int m) {   // m <= 2 * NMS_THREADS
+    if (threadIdx.x < 8) in[m + threadIdx.x] = 0;
     __syncthreads();
     if (m <= NMS_THREADS) rank_sort_desc_impl<1>(in, out, m);
-    else if (m <= 2 * NMS_THREADS) rank_sort_desc_impl<2>(in, out, m);
-    else rank_sort_desc_impl<4>(in, out, m);
+    else rank_sort_desc_impl<2>(in, out, m);
     __syncthreads();
 }
 
@@ -322,36 +323,33 @@ __device__ __forceinline__ NBox make_nbox(const float4 bx, u32 idx, float W, flo
     return r;
 }
 
-// "IoU(a,b) is NOT <= thr" (the reference's suppression test, ssd_output_decoder.py:91).
-//  * float32 flow (F32FLOW): the reference itself works in float32 -> evaluate it directly, IEEE division.
-//  * float64 flow: first a float32 evaluation of inter - thr*union with a rigorous error bound T
-//    (every length is off by <= 3u*A, products by that times the other side, u = 2^-24; constants doubled);
-//    only pairs within T of the threshold, non-finite boxes or non-positive unions take the exact float64 path
-//    (IEEE division, the reference's operation order) on the original float32 boxes.
+// "IoU(a,b) is NOT <= thr" (the reference's suppression test, ssd_output_decoder.py:91), in two steps.
+//  pretest(): branch-free float32 classification -> 1 suppressed, 0 kept, 2 undecided.
+//    * float32 flow (F32FLOW): the reference itself works in float32 -> evaluate it directly (IEEE division), never 2.
+//    * float64 flow: sign of inter - thr*union in float32 with a rigorous error bound T (every length is off by
+//      <= 3u*A, products by that times the other side, u = 2^-24; constants doubled).  Pairs within T of the
+//      threshold, non-finite boxes (T = NaN/inf) and non-positive unions come back undecided.
+//  exact(): the reference's float64 operation order with IEEE division on the original float32 boxes.
 template <bool F32FLOW>
-__device__ __forceinline__ bool suppresses(const NBox& a, const NBox& b, const float4* __restrict__ img_boxes,
-                                           const DecodeParams& p, float thr32, float d32) {
+__device__ __forceinline__ int pretest(const NBox& a, const NBox& b, float thr32, int fast_ok) {
     const float iw = fmaxf(fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), 0.f);
     const float ih = fmaxf(fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0), 0.f);
     if (F32FLOW) {
-        PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
-        const float v = iou_px<float>(pa, pb);
-        return !(v <= thr32);
+        const PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
+        return (iou_px<float>(pa, pb) <= thr32) ? 0 : 1;
     }
-    if (p.fast_ok) {
-        const float inter = iw * ih;
-        const float uni = (a.area + b.area) - inter;
-        const float num = inter - thr32 * uni;
-        const float T = (0x1p-20f * (a.A + b.A)) * (a.P + b.P) + 0x1p-20f * (fabsf(a.area) + fabsf(b.area));
-        if (uni > T) {
-            if (num > T) return true;
-            if (num < -T) return false;
-        }
-    }
+    const float inter = iw * ih;
+    const float uni = (a.area + b.area) - inter;
+    const float num = inter - thr32 * uni;
+    const float T = (0x1p-20f * (a.A + b.A)) * (a.P + b.P) + 0x1p-20f * (fabsf(a.area) + fabsf(b.area));
+    const bool ok = fast_ok && (uni > T);
+    return (ok && num > T) ? 1 : ((ok && num < -T) ? 0 : 2);
+}
+
+__device__ __forceinline__ bool exact_suppresses(u32 ia, u32 ib, const float4* __restrict__ img_boxes, const DecodeParams& p, float d32) {
     const double W = p.img_w, H = p.img_h, d = (double)d32;
-    const PxBox<double> pa = px_box<double>(img_boxes[a.idx], W, H, d), pb = px_box<double>(img_boxes[b.idx], W, H, d);
-    const double v = iou_px<double>(pa, pb);
-    return !(v <= p.iou_thresh);
+    const PxBox<double> pa = px_box<double>(img_boxes[ia], W, H, d), pb = px_box<double>(img_boxes[ib], W, H, d);
+    return !(iou_px<double>(pa, pb) <= p.iou_thresh);
 }
 
 template <bool F32FLOW>
@@ -366,9 +364,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
     if ((int)(blockIdx.x >> 3) >= per_xcd || work >= total_work) return;
     const int b = work / p.G;
 
-    __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 2];     // unsorted chunk
-    __shared__ __attribute__((aligned(16))) u64 sorted[MAX_CHUNK + 2];     // sorted chunk
-    __shared__ __attribute__((aligned(16))) unsigned char scratch[NBINS * sizeof(u32)];   // hist, then the chunk's NBoxes
+    __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 8];     // unsorted chunk
+    __shared__ __attribute__((aligned(16))) u64 sorted[MAX_CHUNK + 8];     // sorted chunk
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[NMS_NBINS * sizeof(u32)];   // hist, then the chunk's NBoxes
     __shared__ NBox kcache[KEPT_LDS];
     __shared__ u64 maskrow[64];
     __shared__ u64 supp_a[NMS_THREADS / 64];
@@ -376,7 +374,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
     __shared__ int fill;
     u32* hist = reinterpret_cast<u32*>(scratch);
     NBox* cbox = reinterpret_cast<NBox*>(scratch);
-    static_assert(sizeof(NBox) * MAX_CHUNK <= NBINS * sizeof(u32), "chunk boxes alias the histogram");
+    static_assert(sizeof(NBox) * MAX_CHUNK <= NMS_NBINS * sizeof(u32), "chunk boxes alias the histogram");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cand_count[work];
@@ -387,6 +385,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
     const float d32 = p.border == SSDHIP_BORDER_INCLUDE ? 1.f : (p.border == SSDHIP_BORDER_EXCLUDE ? -1.f : 0.f);
     const float thr32 = (float)p.iou_thresh;
     const int cap_eff = min(p.cap_store, n);
+    const int fast_ok = p.fast_ok;
+
+    auto load_kept = [&](int j) -> NBox {
+        if (j < KEPT_LDS) return kcache[j];
+        const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK);
+        return make_nbox(img_boxes[idx], idx, W32, H32, d32);
+    };
 
     int K = 0, consumed = 0;
     u64 upper = ~0ull;                       // keys >= upper are consumed; a real key is never all ones (its score field is a
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
     while (consumed < n && K < cap_eff) {
         const int remaining = n - consumed;
         int want = 2 * (cap_eff - K);        // survivors still wanted, x2 headroom for suppressed candidates
-        int M = 256;
+        int M = 128;
         while (M < want && M < MAX_CHUNK) M <<= 1;
         int m;
         u64 cutoff = 0;
@@ -405,39 +410,40 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
             m = remaining;                   // take everything that is left
         } else {
             // histogram of the remaining keys by score bin -> lowest bin such that >= M keys lie at or above it
-            for (int i = tid; i < NBINS; i += NMS_THREADS) hist[i] = 0;
+            for (int i = tid; i < NMS_NBINS; i += NMS_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i0 = tid; i0 < n; i0 += 4 * NMS_THREADS) {
-                u64 k4[4];
+            for (int i0 = tid; i0 < n; i0 += 8 * NMS_THREADS) {
+                u64 k8[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + u * NMS_THREADS; k4[u] = i < n ? keys[i] : ~0ull; }
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * NMS_THREADS; k8[u] = i < n ? keys[i] : ~0ull; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (k4[u] < upper) atomicAdd(&hist[bin_of((u32)(k4[u] >> IDX_BITS), p.bin_base)], 1u);
+                for (int u = 0; u < 8; ++u)
+                    if (k8[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(k8[u] >> IDX_BITS), p.thr_key)], 1u);
             }
             __syncthreads();
-            block_find_digit<NBINS / NMS_THREADS>(hist, M, red, red + 256);
+            block_find_digit<NMS_NBINS / NMS_THREADS>(hist, M, red, red + 256);
             bin_cut = red[256];
             m = red[257] + (int)hist[bin_cut];
             __syncthreads();
             if (m <= MAX_CHUNK) {
                 by_bin = true;
-            } else {                         // one bin holds too many equal-ish scores: exact selection of the M best
+            } else {                         // one bin holds too many near-equal scores: exact selection of the M best
                 m = M;
-                cutoff = block_select_kth<32 + IDX_BITS>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
+                cutoff = block_select_kth<32 + IDX_BITS, 12>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
             }
         }
         PROF_MARK(0)
         if (tid == 0) fill = 0;
         __syncthreads();
-        for (int i0 = tid; i0 < n; i0 += 4 * NMS_THREADS) {
-            u64 k4[4];
+        for (int i0 = tid; i0 < n; i0 += 8 * NMS_THREADS) {
+            u64 k8[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * NMS_THREADS; k4[u] = i < n ? keys[i] : ~0ull; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NMS_THREADS; k8[u] = i < n ? keys[i] : ~0ull; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const u64 key = k4[u];
+            for (int u = 0; u < 8; ++u) {
+                const u64 key = k8[u];
                 if (!(key < upper)) continue;
-                const bool take = by_bin ? (bin_of((u32)(key >> IDX_BITS), p.bin_base) >= bin_cut) : (key >= cutoff);
+                const bool take = by_bin ? (bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key) >= bin_cut) : (key >= cutoff);
                 if (take) keybuf[atomicAdd(&fill, 1)] = key;
             }
         }
@@ -460,47 +466,77 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
             const int nb = min(64, m - base);
             const bool valid = lane < nb;
             const NBox me = cbox[base + (valid ? lane : 0)];
-            // phase A: against survivors of earlier batches, kept list striped over the waves
+            // phase A: against survivors of earlier batches; the kept list is striped over the waves, four boxes per
+            // step so that four independent dependency chains are in flight
             bool supp = false;
-            for (int j = wave; j < K; j += NMS_THREADS / 64) {
-                NBox kb;
-                if (j < KEPT_LDS) kb = kcache[j];
-                else { const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK); kb = make_nbox(img_boxes[idx], idx, W32, H32, d32); }
-                supp = supp || suppresses<F32FLOW>(me, kb, img_boxes, p, thr32, d32);
+            for (int j = wave; j < K; j += 4 * (NMS_THREADS / 64)) {
+                int code[4];
+                u32 kidx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u * (NMS_THREADS / 64);
+                    code[u] = 0;
+                    kidx[u] = 0;
+                    if (jj < K) {
+                        const NBox kb = load_kept(jj);
+                        code[u] = pretest<F32FLOW>(me, kb, thr32, fast_ok);
+                        kidx[u] = kb.idx;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (code[u] == 1) supp = true;
+                    else if (!F32FLOW && code[u] == 2 && !supp) supp = exact_suppresses(me.idx, kidx[u], img_boxes, p, d32);
+                }
+                if (__ballot(valid && !supp) == 0) break;          // the whole batch is already suppressed
             }
             const u64 sa = __ballot(supp && valid);
             if (lane == 0) supp_a[wave] = sa;
             PROF_MARK(4)
             // phase B: in-batch suppression rows, 16 per wave: bit i of maskrow[j] = "j suppresses i" (i > j)
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = wave * 16 + jj;
-                if (j >= nb) break;
-                const NBox cj = cbox[base + j];
-                const bool sj = suppresses<F32FLOW>(me, cj, img_boxes, p, thr32, d32);
-                const u64 mrow = __ballot(valid && lane > j && sj);
-                if (lane == 0) maskrow[j] = mrow;
+            for (int jj = 0; jj < 16; jj += 4) {
+                int code[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = wave * 16 + jj + u;
+                    code[u] = 0;
+                    if (j < nb) code[u] = pretest<F32FLOW>(me, cbox[base + j], thr32, fast_ok);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = wave * 16 + jj + u;
+                    if (j >= nb) break;
+                    bool sj = code[u] == 1;
+                    if (!F32FLOW && code[u] == 2 && lane > j) sj = exact_suppresses(me.idx, cbox[base + j].idx, img_boxes, p, d32);
+                    const u64 mrow = __ballot(valid && lane > j && sj);
+                    if (lane == 0) maskrow[j] = mrow;
+                }
             }
             __syncthreads();
             PROF_MARK(5)
-            // resolve: scalar loop over the surviving bits; the 64 mask rows sit one per lane and are fetched by readlane
-            const u64 myrow = maskrow[lane];
+            // resolve.  Candidates are taken in order; a candidate is kept iff no earlier KEPT candidate suppresses it.
+            // Only lanes whose row is non-zero can change anything, so the scalar loop visits just those ("conflict
+            // lanes"); everything still alive at the end is kept.  Rows sit one per lane and are fetched by readlane.
+            const u64 myrow = valid ? maskrow[lane] : 0ull;
             const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
             const u64 sall = supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3];
             u64 alive = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) & ~sall;
             alive = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(alive >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)alive);
-            u64 keptmask = 0;
-            int cnt = 0;
-            while (alive) {
-                const int j = __ffsll((long long)alive) - 1;
-                keptmask |= 1ull << j;
-                ++cnt;
-                if (K + cnt >= cap_eff) break;
-                const u64 mj = ((u64)(u32)__builtin_amdgcn_readlane((int)row_hi, j) << 32) | (u32)__builtin_amdgcn_readlane((int)row_lo, j);
+            const u64 cmask = __ballot(myrow != 0ull);
+            u64 pending = alive & cmask;
+            while (pending) {
+                const int j = __ffsll((long long)pending) - 1;
+                const u64 mj = ((u64)(u32)__builtin_amdgcn_readlane((int)row_hi, j) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)row_lo, j);
                 alive &= ~mj;
-                alive &= ~(1ull << j);
+                pending = alive & cmask & ~((2ull << j) - 1ull);
             }
-            if (wave == 0 && ((keptmask >> lane) & 1ull)) {
-                const int pos = K + __popcll(keptmask & lanemask_lt());
+            int cnt = __popcll(alive);
+            while (K + cnt > cap_eff) {                     // cap reached inside this batch: drop the lowest-scored extras
+                alive &= ~(1ull << (63 - __clzll((long long)alive)));
+                --cnt;
+            }
+            if (wave == 0 && ((alive >> lane) & 1ull)) {
+                const int pos = K + __popcll(alive & lanemask_lt());
                 kept_out[pos] = sorted[base + lane];
                 if (pos < KEPT_LDS) kcache[pos] = me;
             }
@@ -628,7 +664,7 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
         for (int g = 0; g < G; ++g) {
             const int kc = offs[g + 1] - offs[g];
             for (int r = tid; r < kc; r += NMS_THREADS)
-                atomicAdd(&hist[bin_of((u32)(img_kept[(size_t)g * p.cap_store + r] >> IDX_BITS), p.bin_base)], 1u);
+                atomicAdd(&hist[bin_of<DIGIT_BITS, NBINS>((u32)(img_kept[(size_t)g * p.cap_store + r] >> IDX_BITS), p.thr_key)], 1u);
         }
         __syncthreads();
         block_find_digit<NBINS / NMS_THREADS>(hist, rows, red, red + 256);
@@ -643,7 +679,7 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
                 const int kc = offs[g + 1] - offs[g];
                 for (int r = tid; r < kc; r += NMS_THREADS) {
                     const u64 key = img_kept[(size_t)g * p.cap_store + r];
-                    if (bin_of((u32)(key >> IDX_BITS), p.bin_base) == bin_cut) bufa[atomicAdd(&fill, 1)] = comp_of(g, r);
+                    if (bin_of<DIGIT_BITS, NBINS>((u32)(key >> IDX_BITS), p.thr_key) == bin_cut) bufa[atomicAdd(&fill, 1)] = comp_of(g, r);
                 }
             }
             __syncthreads();
@@ -657,7 +693,7 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
             __syncthreads();
             cutoff = sh_cut;
         } else {
-            cutoff = block_select_kth<64>(comp_at, T, 0, false, rows, hist, red);
+            cutoff = block_select_kth<64, DIGIT_BITS>(comp_at, T, 0, false, rows, hist, red);
         }
     }
     __syncthreads();
@@ -793,7 +829,7 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
         union { float f; unsigned u; } cv;
         cv.f = te;
         const unsigned key = (cv.u & 0x80000000u) ? ~cv.u : (cv.u | 0x80000000u);
-        p.bin_base = key >> 13;
+        p.thr_key = key;
     }
     p.iou_thresh = iou_thresh;
     p.img_w = normalize_coords ? img_width : 1.0;

@@ -60,6 +60,17 @@ if __name__ == "__main__":
     results.append(run("ssd300_dense_bias0_numpy_sem", syn.make_y_pred(av, B, 21, bias=0.0), keras=False))
     wild = syn.make_y_pred(av, B, 21, bias=0.0, loc_sigma=300.0)       # random-init-weights-like: exploding offsets
     results.append(run("ssd300_dense_wild_offsets", wild))
+    if os.environ.get("MODEL", "1") == "1":
+        from ssd_keras_amd.models.keras_ssd300 import ssd_300
+        torch.manual_seed(1234)
+        cfg = syn.SSD300_VOC
+        model = ssd_300((300, 300, 3), 20, mode="training", scales=cfg["scales"], aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"],
+                        steps=cfg["steps"], offsets=cfg["offsets"]).cuda().to(memory_format=torch.channels_last).to(torch.bfloat16).eval()
+        imgs = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).cuda()
+        with torch.no_grad():
+            yp = model(imgs).float().cpu().numpy()
+        np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pred_rand_b0.npy"), yp[:2, :, :25])
+        results.append(run("ssd300_random_init_bf16_model", yp))
     if os.environ.get("S512", "1") == "1":
         av5 = anchors_var(syn.SSD512_COCO)
         results.append(run("ssd512_sparse_bias7", syn.make_y_pred(av5, 16, 81, bias=7.0), img=512))
