@@ -54,7 +54,13 @@ constexpr int NBINS = 1 << DIGIT_BITS;       // 8192 LDS counters = 32 KiB
 constexpr int NMS_BIN_SHIFT = 14;            // K4 score histogram: 2^14 float32 ulps per bin ...
 constexpr int NMS_NBINS = 4096;              // ... 4096 bins = 16 KiB (9 binades above the threshold)
 constexpr int NMS_THREADS = 256;
-constexpr int MAX_CHUNK = 512;               // candidates sorted + staged per round in K4
+#ifndef SSDHIP_MAX_CHUNK
+#define SSDHIP_MAX_CHUNK 512
+#endif
+#ifndef SSDHIP_NMS_MINWAVES
+#define SSDHIP_NMS_MINWAVES 3
+#endif
+constexpr int MAX_CHUNK = SSDHIP_MAX_CHUNK;   // candidates sorted + staged per round in K4
 constexpr int KEPT_LDS = 256;                // survivors whose boxes are cached in LDS
 constexpr int TOPK_SORT_MAX = 4096;          // rows K5 can return sorted
 
@@ -65,7 +71,8 @@ struct DecodeParams {
     float thr_eff;              // float32 threshold with the same outcome as the reference's compare (see host code)
     u32 thr_key;                // float_key(thr_eff): origin of the score histograms
     int iou_f32;                // NMS arithmetic in float32 (reference: float32 input + 'corners')
-    int fast_ok;                // float32 pre-test of IoU > thr usable (image size exactly representable, |thr| <= 1)
+    int fast_ok;                // division-free IoU test usable (0 < iou_thresh < inf)
+    int px_f32;                 // pixel boxes rounded to float32 before NMS (the Keras layer's float32 scaling)
     double iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
     int top_k, cap, cap_store, out_rows, sorted;
 };
@@ -293,67 +300,71 @@ __device__ void block_rank_sort_desc(u64* in, u64* out, int m) {   // m <= 2 * N
 // ======================================================================================
 // K4
 // ======================================================================================
+// A box as the NMS loop holds it in LDS: pixel corners + area in the dtype the reference's IoU works in (float64,
+// or float32 on the 'corners' flow), computed once per box with the reference's operations.
 template <typename F>
-__device__ __forceinline__ PxBox<F> px_box(const float4 bx, F W, F H, F d) {
-    PxBox<F> r;
-    r.x0 = (F)bx.x * W;                 // exact in double
-    r.y0 = (F)bx.y * H;
-    r.x1 = (F)bx.z * W;
-    r.y1 = (F)bx.w * H;
-    r.area = box_area<F>(r.x0, r.y0, r.x1, r.y1, d);
-    return r;
-}
-
-// A box as the NMS loop holds it in LDS: float32 pixel corners + what the conservative pre-test needs.
-struct NBox {
-    float x0, y0, x1, y1, area;   // area = (x1-x0+d)*(y1-y0+d): exactly the reference's float32 flow
-    float P;                      // |w| + |h| + 2  (bounds the side lengths entering any product)
-    float A;                      // |x0|+|y0|+|x1|+|y1| (bounds every coordinate; NaN/inf propagate)
-    u32 idx;                      // anchor index, to fetch the float32 box for the exact float64 evaluation
+struct __attribute__((aligned(16))) NBox {
+    F x0, y0, x1, y1, area;
+    u32 idx;                      // anchor index
+    u32 ok;                       // all five values finite -> the division-free test below is valid for this box
 };
 
-__device__ __forceinline__ NBox make_nbox(const float4 bx, u32 idx, float W, float H, float d) {
-    NBox r;
-    r.x0 = bx.x * W; r.y0 = bx.y * H; r.x1 = bx.z * W; r.y1 = bx.w * H;
-    const float w = r.x1 - r.x0, h = r.y1 - r.y0;
-    r.area = (w + d) * (h + d);
-    r.P = fabsf(w) + fabsf(h) + 2.0f;
-    r.A = (fabsf(r.x0) + fabsf(r.y0)) + (fabsf(r.x1) + fabsf(r.y1));
+template <typename F>
+__device__ __forceinline__ bool is_finite(F v) { return v - v == (F)0; }
+
+// px_f32: the Keras layer scales the box by the image size in float32 (keras_layer_DecodeDetections.py:140-149)
+// before NMS sees it; the NumPy decoder multiplies the float64 copy (ssd_output_decoder.py:196-198).
+template <typename F>
+__device__ __forceinline__ NBox<F> make_nbox(const float4 bx, u32 idx, F W, F H, F d, bool px_f32) {
+    NBox<F> r;
+    if (px_f32) {                 // float32 product == correctly rounded exact product (W, H exact in float32: host checks)
+        r.x0 = (F)(float)((double)bx.x * (double)W); r.y0 = (F)(float)((double)bx.y * (double)H);
+        r.x1 = (F)(float)((double)bx.z * (double)W); r.y1 = (F)(float)((double)bx.w * (double)H);
+    } else {
+        r.x0 = (F)bx.x * W; r.y0 = (F)bx.y * H; r.x1 = (F)bx.z * W; r.y1 = (F)bx.w * H;   // exact in double
+    }
+    r.area = box_area<F>(r.x0, r.y0, r.x1, r.y1, d);
     r.idx = idx;
+    r.ok = (is_finite(r.x0) && is_finite(r.y0) && is_finite(r.x1) && is_finite(r.y1) && is_finite(r.area)) ? 1u : 0u;
     return r;
 }
 
-// "IoU(a,b) is NOT <= thr" (the reference's suppression test, ssd_output_decoder.py:91), in two steps.
-//  pretest(): branch-free float32 classification -> 1 suppressed, 0 kept, 2 undecided.
-//    * float32 flow (F32FLOW): the reference itself works in float32 -> evaluate it directly (IEEE division), never 2.
-//    * float64 flow: sign of inter - thr*union in float32 with a rigorous error bound T (every length is off by
-//      <= 3u*A, products by that times the other side, u = 2^-24; constants doubled).  Pairs within T of the
-//      threshold, non-finite boxes (T = NaN/inf) and non-positive unions come back undecided.
-//  exact(): the reference's float64 operation order with IEEE division on the original float32 boxes.
-template <bool F32FLOW>
-__device__ __forceinline__ int pretest(const NBox& a, const NBox& b, float thr32, int fast_ok) {
-    const float iw = fmaxf(fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), 0.f);
-    const float ih = fmaxf(fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0), 0.f);
-    if (F32FLOW) {
-        const PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
-        return (iou_px<float>(pa, pb) <= thr32) ? 0 : 1;
-    }
-    const float inter = iw * ih;
-    const float uni = (a.area + b.area) - inter;
-    const float num = inter - thr32 * uni;
-    const float T = (0x1p-20f * (a.A + b.A)) * (a.P + b.P) + 0x1p-20f * (fabsf(a.area) + fabsf(b.area));
-    const bool ok = fast_ok && (uni > T);
-    return (ok && num > T) ? 1 : ((ok && num < -T) ? 0 : 2);
+// "IoU(a,b) is NOT <= thr" (the reference's suppression test, ssd_output_decoder.py:91) -> 1 suppressed, 0 kept,
+// 2 undecided (caller evaluates exact_suppresses()).
+//  * float64 flow: inter and uni are computed exactly as the reference computes them; instead of dividing, the sign
+//    of R = inter - thr*uni (one fma, correctly rounded, so sign(r) == sign(R)) decides, which is the same answer as
+//    fl(inter/uni) <= thr whenever |R| > 2^-51 * thr*uni, i.e. the exact ratio is more than 2 ulp away from thr
+//    (rounding is monotone).  Needs finite boxes, uni > 0 (not tiny) and 0 < thr < inf (fast_ok); two zero-area boxes
+//    (0/0) are decided directly; everything else -- non-finite boxes, knife edges -- takes the IEEE division.
+//    float64 add/mul/max/fma issue at the float32 (non-packed) rate on CDNA4, so this costs ~16 full-rate VALU ops
+//    per pair and no division.
+//  * float32 flow ('corners' + float32 input): the reference itself works in float32 -> evaluate it directly.
+__device__ __forceinline__ int nms_test(const NBox<double>& a, const NBox<double>& b, double thr, int fast_ok) {
+    const double ix0 = fmax(a.x0, b.x0), iy0 = fmax(a.y0, b.y0);
+    const double ix1 = fmin(a.x1, b.x1), iy1 = fmin(a.y1, b.y1);
+    const double iw = fmax(ix1 - ix0, 0.0), ih = fmax(iy1 - iy0, 0.0);
+    const double inter = iw * ih;
+    const double uni = (a.area + b.area) - inter;
+    const double tu = thr * uni;
+    const double r = fma(-thr, uni, inter);
+    const bool fin = (a.ok & b.ok & (u32)fast_ok) != 0u;
+    const bool zero = uni == 0.0 && inter == 0.0;            // 0/0 = NaN: "not <= thr" (two zero-area boxes)
+    const bool dec = uni > 0x1p-900 && fabs(r) > 0x1p-50 * tu;
+    return fin ? (zero ? 1 : (dec ? (r > 0.0 ? 1 : 0) : 2)) : 2;
+}
+__device__ __forceinline__ int nms_test(const NBox<float>& a, const NBox<float>& b, float thr, int) {
+    const PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
+    return (iou_px<float>(pa, pb) <= thr) ? 0 : 1;
 }
 
-__device__ __forceinline__ bool exact_suppresses(u32 ia, u32 ib, const float4* __restrict__ img_boxes, const DecodeParams& p, float d32) {
-    const double W = p.img_w, H = p.img_h, d = (double)d32;
-    const PxBox<double> pa = px_box<double>(img_boxes[ia], W, H, d), pb = px_box<double>(img_boxes[ib], W, H, d);
-    return !(iou_px<double>(pa, pb) <= p.iou_thresh);
+template <typename F>
+__device__ __forceinline__ bool exact_suppresses(const NBox<F>& a, const NBox<F>& b, F thr) {
+    const PxBox<F> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
+    return !(iou_px<F>(pa, pb) <= thr);
 }
 
-template <bool F32FLOW>
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
+template <typename F>
+__global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
                                                           const u64* __restrict__ cand, const int* __restrict__ cand_count,
                                                           u64* __restrict__ kept, int* __restrict__ kept_count) {
     // XCD-aware work mapping: hardware places block x on XCD x%8; give every XCD a contiguous range of
@@ -366,38 +377,40 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
 
     __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 8];     // unsorted chunk
     __shared__ __attribute__((aligned(16))) u64 sorted[MAX_CHUNK + 8];     // sorted chunk
-    __shared__ __attribute__((aligned(16))) unsigned char scratch[NMS_NBINS * sizeof(u32)];   // hist, then the chunk's NBoxes
-    __shared__ NBox kcache[KEPT_LDS];
+    constexpr size_t SCRATCH = sizeof(NBox<F>) * MAX_CHUNK > NMS_NBINS * sizeof(u32) ? sizeof(NBox<F>) * MAX_CHUNK : NMS_NBINS * sizeof(u32);
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[SCRATCH];   // score histogram, then the chunk's boxes
+    __shared__ NBox<F> kcache[KEPT_LDS];
     __shared__ u64 maskrow[64];
     __shared__ u64 supp_a[NMS_THREADS / 64];
     __shared__ int red[260];
     __shared__ int fill;
     u32* hist = reinterpret_cast<u32*>(scratch);
-    NBox* cbox = reinterpret_cast<NBox*>(scratch);
-    static_assert(sizeof(NBox) * MAX_CHUNK <= NMS_NBINS * sizeof(u32), "chunk boxes alias the histogram");
+    NBox<F>* cbox = reinterpret_cast<NBox<F>*>(scratch);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cand_count[work];
     const u64* keys = cand + (size_t)work * p.N;
     u64* kept_out = kept + (size_t)work * p.cap_store;
     const float4* img_boxes = boxes + (size_t)b * p.N;
-    const float W32 = (float)p.img_w, H32 = (float)p.img_h;
-    const float d32 = p.border == SSDHIP_BORDER_INCLUDE ? 1.f : (p.border == SSDHIP_BORDER_EXCLUDE ? -1.f : 0.f);
-    const float thr32 = (float)p.iou_thresh;
+    const F Wpx = (F)p.img_w, Hpx = (F)p.img_h;
+    const F dpx = p.border == SSDHIP_BORDER_INCLUDE ? (F)1 : (p.border == SSDHIP_BORDER_EXCLUDE ? (F)-1 : (F)0);
+    const F thr = (F)p.iou_thresh;
+    const bool px_f32 = p.px_f32 != 0;
     const int cap_eff = min(p.cap_store, n);
     const int fast_ok = p.fast_ok;
 
-    auto load_kept = [&](int j) -> NBox {
+    auto load_kept = [&](int j) -> NBox<F> {
         if (j < KEPT_LDS) return kcache[j];
         const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK);
-        return make_nbox(img_boxes[idx], idx, W32, H32, d32);
+        return make_nbox<F>(img_boxes[idx], idx, Wpx, Hpx, dpx, px_f32);
     };
 
     int K = 0, consumed = 0;
     u64 upper = ~0ull;                       // keys >= upper are consumed; a real key is never all ones (its score field is a
     bool has_upper = false;                  // float key, whose all-ones value is a NaN that cannot pass the threshold)
     PROF_DECL
-    while (consumed < n && K < cap_eff) {
+    bool finished = false;
+    while (consumed < n && K < cap_eff && !finished) {
         const int remaining = n - consumed;
         int want = 2 * (cap_eff - K);        // survivors still wanted, x2 headroom for suppressed candidates
         int M = 128;
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
         if (remaining <= MAX_CHUNK) {
             m = remaining;                   // take everything that is left
         } else {
-            // histogram of the remaining keys by score bin -> lowest bin such that >= M keys lie at or above it
+            // histogram of the remaining keys by score bin
             for (int i = tid; i < NMS_NBINS; i += NMS_THREADS) hist[i] = 0;
             __syncthreads();
             for (int i0 = tid; i0 < n; i0 += 8 * NMS_THREADS) {
@@ -421,11 +434,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
                     if (k8[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(k8[u] >> IDX_BITS), p.thr_key)], 1u);
             }
             __syncthreads();
-            block_find_digit<NMS_NBINS / NMS_THREADS>(hist, M, red, red + 256);
-            bin_cut = red[256];
-            m = red[257] + (int)hist[bin_cut];
+            // highest bin d such that the bins above it hold <= MAX_CHUNK keys (and d included would not fit)
+            block_find_digit<NMS_NBINS / NMS_THREADS>(hist, MAX_CHUNK + 1, red, red + 256);
+            bin_cut = red[256] + 1;
+            m = red[257];
             __syncthreads();
-            if (m <= MAX_CHUNK) {
+            if (m >= (M >> 2)) {
                 by_bin = true;
             } else {                         // one bin holds too many near-equal scores: exact selection of the M best
                 m = M;
@@ -457,36 +471,34 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
         // stage the chunk's boxes (independent gathers, one latency exposure per round)
         for (int i = tid; i < m; i += NMS_THREADS) {
             const u32 idx = IDX_MASK - (u32)(sorted[i] & IDX_MASK);
-            cbox[i] = make_nbox(img_boxes[idx], idx, W32, H32, d32);
+            cbox[i] = make_nbox<F>(img_boxes[idx], idx, Wpx, Hpx, dpx, px_f32);
         }
         __syncthreads();
         PROF_MARK(3)
 
-        for (int base = 0; base < m && K < cap_eff; base += 64) {
+        for (int base = 0; base < m && K < cap_eff && !finished; base += 64) {
             const int nb = min(64, m - base);
             const bool valid = lane < nb;
-            const NBox me = cbox[base + (valid ? lane : 0)];
+            const NBox<F> me = cbox[base + (valid ? lane : 0)];
             // phase A: against survivors of earlier batches; the kept list is striped over the waves, four boxes per
             // step so that four independent dependency chains are in flight
             bool supp = false;
             for (int j = wave; j < K; j += 4 * (NMS_THREADS / 64)) {
                 int code[4];
-                u32 kidx[4];
+                NBox<F> kb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int jj = j + u * (NMS_THREADS / 64);
                     code[u] = 0;
-                    kidx[u] = 0;
                     if (jj < K) {
-                        const NBox kb = load_kept(jj);
-                        code[u] = pretest<F32FLOW>(me, kb, thr32, fast_ok);
-                        kidx[u] = kb.idx;
+                        kb[u] = load_kept(jj);
+                        code[u] = nms_test(me, kb[u], thr, fast_ok);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (code[u] == 1) supp = true;
-                    else if (!F32FLOW && code[u] == 2 && !supp) supp = exact_suppresses(me.idx, kidx[u], img_boxes, p, d32);
+                    else if (code[u] == 2 && !supp) supp = exact_suppresses<F>(me, kb[u], thr);
                 }
                 if (__ballot(valid && !supp) == 0) break;          // the whole batch is already suppressed
             }
@@ -500,14 +512,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
                 for (int u = 0; u < 4; ++u) {
                     const int j = wave * 16 + jj + u;
                     code[u] = 0;
-                    if (j < nb) code[u] = pretest<F32FLOW>(me, cbox[base + j], thr32, fast_ok);
+                    if (j < nb) code[u] = nms_test(me, cbox[base + j], thr, fast_ok);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = wave * 16 + jj + u;
                     if (j >= nb) break;
                     bool sj = code[u] == 1;
-                    if (!F32FLOW && code[u] == 2 && lane > j) sj = exact_suppresses(me.idx, cbox[base + j].idx, img_boxes, p, d32);
+                    if (code[u] == 2 && lane > j) sj = exact_suppresses<F>(me, cbox[base + j], thr);
                     const u64 mrow = __ballot(valid && lane > j && sj);
                     if (lane == 0) maskrow[j] = mrow;
                 }
@@ -541,6 +553,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(DecodeParams p, const 
                 if (pos < KEPT_LDS) kcache[pos] = me;
             }
             K += cnt;
+            // a kept box whose area is NaN makes every later IoU NaN ("not <= thr"): nothing after it can survive
+            if (alive & __ballot(valid && me.area != me.area)) finished = true;
             __syncthreads();
             PROF_MARK(6)
         }
@@ -834,7 +848,9 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
     p.iou_thresh = iou_thresh;
     p.img_w = normalize_coords ? img_width : 1.0;
     p.img_h = normalize_coords ? img_height : 1.0;
-    p.fast_ok = ((double)(float)p.img_w == p.img_w && (double)(float)p.img_h == p.img_h && iou_thresh >= -1.0 && iou_thresh <= 1.0) ? 1 : 0;
+    p.fast_ok = (iou_thresh > 0.0 && iou_thresh < 1e300) ? 1 : 0;
+    p.px_f32 = (semantics == SSDHIP_SEM_KERAS) ? 1 : 0;
+    if (p.px_f32 && ((double)(float)p.img_w != p.img_w || (double)(float)p.img_h != p.img_h)) return SSDHIP_E_BADARG;
     p.top_k = top_k; p.cap = nms_cap; p.cap_store = cap_store_for(N, top_k, nms_cap);
     p.out_rows = out_rows; p.sorted = sorted;
 
@@ -863,8 +879,8 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
     if (stages & 2) {
     const int work = B * p.G;
     const int g4 = ((work + 7) / 8) * 8;
-    if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<true>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
-    else hipLaunchKernelGGL(nms_kernel<false>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<float>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    else hipLaunchKernelGGL(nms_kernel<double>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
 

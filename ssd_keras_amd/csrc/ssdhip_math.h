@@ -61,12 +61,18 @@ __device__ __forceinline__ F clamp0(F v) { return v < (F)0 ? (F)0 : v; }   // np
 template <typename F>
 __device__ __forceinline__ F box_area(F x0, F y0, F x1, F y1, F d) { return (x1 - x0 + d) * (y1 - y0 + d); }
 
+// np.maximum / np.minimum: a NaN operand wins (unlike fmax/fmin and unlike a bare `a > b ? a : b`)
+template <typename F>
+__device__ __forceinline__ F np_maximum(F a, F b) { return (a > b || a != a) ? a : b; }
+template <typename F>
+__device__ __forceinline__ F np_minimum(F a, F b) { return (a < b || a != a) ? a : b; }
+
 template <typename F>
 __device__ __forceinline__ F iou_px(const PxBox<F>& a, const PxBox<F>& b) {
-    const F ix0 = a.x0 > b.x0 ? a.x0 : b.x0;
-    const F iy0 = a.y0 > b.y0 ? a.y0 : b.y0;
-    const F ix1 = a.x1 < b.x1 ? a.x1 : b.x1;
-    const F iy1 = a.y1 < b.y1 ? a.y1 : b.y1;
+    const F ix0 = np_maximum<F>(a.x0, b.x0);
+    const F iy0 = np_maximum<F>(a.y0, b.y0);
+    const F ix1 = np_minimum<F>(a.x1, b.x1);
+    const F iy1 = np_minimum<F>(a.y1, b.y1);
     const F iw = clamp0<F>(ix1 - ix0);
     const F ih = clamp0<F>(iy1 - iy0);
     const F inter = iw * ih;

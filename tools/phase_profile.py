@@ -52,3 +52,13 @@ if __name__ == "__main__":
     run("sparse_bias7", syn.make_y_pred(av, 32, 21, bias=7.0))
     run("dense_bias0", syn.make_y_pred(av, 32, 21, bias=0.0))
     run("dense_wild", syn.make_y_pred(av, 32, 21, bias=0.0, loc_sigma=300.0))
+    if os.environ.get("MODEL", "1") == "1":          # what bench.py decodes: a random-init SSD300's own predictions
+        from ssd_keras_amd.models.keras_ssd300 import ssd_300
+        torch.manual_seed(1234)
+        cfg = syn.SSD300_VOC
+        model = ssd_300((300, 300, 3), 20, mode="training", scales=cfg["scales"], aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"],
+                        steps=cfg["steps"], offsets=cfg["offsets"]).cuda().to(memory_format=torch.channels_last).to(torch.bfloat16).eval()
+        imgs = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(32, 300, 300, 3)).astype(np.float32)).cuda()
+        with torch.no_grad():
+            yp = model(imgs).float().cpu().numpy()
+        run("random_init_model", yp)
