@@ -146,6 +146,36 @@ int ssdhip_loss_backward(const float* y_true, const float* y_pred, const unsigne
                          const float* stats, const float* grad_out, int B, int N, int C, float alpha,
                          float* grad_y_pred, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Graph glue between the convolutions (bf16 activations, NHWC = torch channels_last; C % 8 == 0; pointers
+ * 16-byte aligned).  Each call is ONE pass over the tensor where the framework path runs 2-7 elementwise kernels.
+ *
+ * ssdhip_bias_act_nhwc_bf16        y = act(x + bias[c]) (x, y may alias): Conv2D(..., activation='relu')'s epilogue,
+ *                                  models/keras_ssd300.py:274-313.  bias may be NULL; relu 0/1.
+ * ssdhip_bias_act_maxpool_nhwc_bf16  the same followed by MaxPooling2D (kernel, stride, pad; window clipped to the map --
+ *                                  Keras 'same' pooling == pad 0 + Ho = ceil(H/stride)); y [B,Ho,Wo,C].
+ * ssdhip_l2_normalize_nhwc_bf16    keras_layers/keras_layer_L2Normalization.py:61-63: x * rsqrt(max(sum_c x^2, 1e-12)) * gamma[c],
+ *                                  gamma float32 [C].
+ * ssdhip_preprocess_nhwc_f32_to_bf16  the Lambda input layers, models/keras_ssd300.py:247-272: subtract mean, divide by
+ *                                  stddev, reorder channels; mean_h / divide_h / swap_h are HOST arrays of `channels`
+ *                                  entries (NULL = identity); out[...,c] = bf16((img[...,swap[c]] - mean[swap[c]]) / divide[swap[c]]).
+ * ssdhip_assemble_predictions_bf16  Reshape + Concatenate + softmax + AnchorBoxes + Concatenate, models/keras_ssd300.py:363-419
+ *                                  and keras_layers/keras_layer_AnchorBoxes.py:245-255: per predictor layer l the NHWC conv outputs
+ *                                  conf_h[l] [B, n_anchors_h[l], C] and loc_h[l] [B, n_anchors_h[l], 4] (bf16 DEVICE pointers held
+ *                                  in HOST arrays, as are the optional per-layer biases [n_boxes*C], [n_boxes*4]) become
+ *                                  y_pred [B, N, C+12] float32 = [softmax(conf) | loc | anchors_var[N,8]]; N = sum n_anchors_h.
+ */
+int ssdhip_bias_act_nhwc_bf16(const void* x, const void* bias, void* y, long long n_pixels, int C, int relu, void* stream);
+int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias, void* y, int B, int H, int W, int C,
+                                      int kernel, int stride, int pad, int Ho, int Wo, int relu, void* stream);
+int ssdhip_l2_normalize_nhwc_bf16(const void* x, const float* gamma, void* y, long long n_pixels, int C, void* stream);
+int ssdhip_preprocess_nhwc_f32_to_bf16(const float* images, void* out, long long n_pixels, int channels,
+                                       const float* mean_h, const float* divide_h, const int* swap_h, void* stream);
+int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                     const void* const* conf_bias_h, const void* const* loc_bias_h,
+                                     const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
+                                     int B, int N, int C, float* y_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,3 +167,152 @@ def to_device(a, device=None, dtype=None):
     if dtype is not None and a.dtype != dtype:
         a = a.to(dtype)
     return a.to(device, non_blocking=False).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# graph glue (csrc/ssdhip_layers.hip): bf16 NHWC activations
+# ------------------------------------------------------------------------------------------------
+def _bind_layers(lib):
+    if getattr(lib, "_layers_bound", False):
+        return
+    c_int, c_vp, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+    lib.ssdhip_bias_act_nhwc_bf16.restype = c_int
+    lib.ssdhip_bias_act_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_vp]
+    lib.ssdhip_bias_act_maxpool_nhwc_bf16.restype = c_int
+    lib.ssdhip_bias_act_maxpool_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 10 + [c_vp]
+    lib.ssdhip_l2_normalize_nhwc_bf16.restype = c_int
+    lib.ssdhip_l2_normalize_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_ll, c_int, c_vp]
+    lib.ssdhip_preprocess_nhwc_f32_to_bf16.restype = c_int
+    lib.ssdhip_preprocess_nhwc_f32_to_bf16.argtypes = [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp]
+    lib.ssdhip_assemble_predictions_bf16.restype = c_int
+    lib.ssdhip_assemble_predictions_bf16.argtypes = [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]
+    lib._layers_bound = True
+
+
+def _layers_lib():
+    lib = load()
+    _bind_layers(lib)
+    return lib
+
+
+def _nhwc_bf16(t, name):
+    """(B, C, H, W) bf16 CUDA tensor whose memory is NHWC; returns it (made so if needed) and (B, H, W, C)."""
+    torch = _torch()
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4:
+        raise SsdHipError("%s must be a 4-D bfloat16 CUDA tensor" % name)
+    if not t.permute(0, 2, 3, 1).is_contiguous():
+        t = t.contiguous(memory_format=torch.channels_last)
+        if not t.permute(0, 2, 3, 1).is_contiguous():          # size-1 dims can leave odd strides behind
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    b, c, h, w = t.shape
+    if c % 8:
+        raise SsdHipError("%s: channel count %d is not a multiple of 8" % (name, c))
+    return t, (b, h, w, c)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def bias_act(x, bias, relu=True, inplace=True):
+    """act(x + bias[c]) on an NHWC-memory bf16 feature map (B, C, H, W); in place by default."""
+    torch = _torch()
+    lib = _layers_lib()
+    x, (b, h, w, c) = _nhwc_bf16(x, "x")
+    y = x if inplace else torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_bias_act_nhwc_bf16(_ptr(x), _ptr(bias), _ptr(y), b * h * w, c, int(bool(relu)), current_stream_ptr(x.device))
+    check(rc, "ssdhip_bias_act_nhwc_bf16")
+    return y
+
+
+def pool_out_size(n, k, s, p, ceil_mode):
+    if ceil_mode:
+        o = -(-(n + 2 * p - k) // s) + 1
+        if (o - 1) * s >= n + p:
+            o -= 1
+        return o
+    return (n + 2 * p - k) // s + 1
+
+
+def bias_act_maxpool(x, bias, kernel, stride, pad=0, ceil_mode=False, relu=True):
+    """max_pool2d(act(x + bias)) in one pass; x (B, C, H, W) bf16 with NHWC memory -> (B, C, Ho, Wo) likewise."""
+    torch = _torch()
+    lib = _layers_lib()
+    x, (b, h, w, c) = _nhwc_bf16(x, "x")
+    ho, wo = pool_out_size(h, kernel, stride, pad, ceil_mode), pool_out_size(w, kernel, stride, pad, ceil_mode)
+    y = torch.empty((b, ho, wo, c), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_bias_act_maxpool_nhwc_bf16(_ptr(x), _ptr(bias), _ptr(y), b, h, w, c, int(kernel), int(stride), int(pad),
+                                                   ho, wo, int(bool(relu)), current_stream_ptr(x.device))
+    check(rc, "ssdhip_bias_act_maxpool_nhwc_bf16")
+    return y
+
+
+def l2_normalize(x, gamma):
+    torch = _torch()
+    lib = _layers_lib()
+    x, (b, h, w, c) = _nhwc_bf16(x, "x")
+    g = gamma.detach().float().contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_l2_normalize_nhwc_bf16(_ptr(x), _ptr(g), _ptr(y), b * h * w, c, current_stream_ptr(x.device))
+    check(rc, "ssdhip_l2_normalize_nhwc_bf16")
+    return y
+
+
+def preprocess(images, mean=None, divide=None, swap=None):
+    """(B, H, W, C<=4) float32 CUDA images -> (B, C, H, W) bf16 with NHWC memory: (img[..., swap] - mean[swap]) / divide[swap]."""
+    torch = _torch()
+    lib = _layers_lib()
+    require_cuda(images, "images")
+    if images.dtype != torch.float32 or images.dim() != 4 or images.shape[3] > 4:
+        raise SsdHipError("images must be float32 (B, H, W, C<=4)")
+    b, h, w, c = images.shape
+    out = torch.empty((b, h, w, c), dtype=torch.bfloat16, device=images.device)
+    def fa(v):
+        if v is None:
+            return None
+        v = [float(v)] * c if np.isscalar(v) else [float(t) for t in v]
+        if len(v) != c:
+            raise SsdHipError("per-channel constant has %d entries for %d channels" % (len(v), c))
+        return (ctypes.c_float * c)(*v)
+    ia = (ctypes.c_int * c)(*[int(t) for t in swap]) if swap else None
+    with torch.cuda.device(images.device):
+        rc = lib.ssdhip_preprocess_nhwc_f32_to_bf16(_ptr(images), _ptr(out), b * h * w, c, fa(mean), fa(divide), ia,
+                                                    current_stream_ptr(images.device))
+    check(rc, "ssdhip_preprocess_nhwc_f32_to_bf16")
+    return out.permute(0, 3, 1, 2)
+
+
+def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
+    """Per-layer NHWC conv outputs (B, n_boxes*C, h, w) / (B, n_boxes*4, h, w) bf16 -> y_pred (B, N, C+12) float32."""
+    torch = _torch()
+    lib = _layers_lib()
+    nl = len(confs)
+    keep = []
+    cp, lp, cbp, lbp, na = [], [], [], [], []
+    for i in range(nl):
+        cf = confs[i] if confs[i].permute(0, 2, 3, 1).is_contiguous() else confs[i].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        lc = locs[i] if locs[i].permute(0, 2, 3, 1).is_contiguous() else locs[i].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        if cf.dtype != torch.bfloat16 or lc.dtype != torch.bfloat16 or not cf.is_cuda:
+            raise SsdHipError("assemble_predictions needs bfloat16 CUDA head outputs")
+        keep += [cf, lc]
+        b, ch, h, w = cf.shape
+        if ch != n_boxes[i] * n_classes or lc.shape[1] != n_boxes[i] * 4:
+            raise SsdHipError("head %d has %d / %d channels, expected %d / %d" % (i, ch, lc.shape[1], n_boxes[i] * n_classes, n_boxes[i] * 4))
+        cp.append(cf.data_ptr()); lp.append(lc.data_ptr()); na.append(h * w * n_boxes[i])
+        cbp.append(conf_biases[i].data_ptr() if conf_biases[i] is not None else 0)
+        lbp.append(loc_biases[i].data_ptr() if loc_biases[i] is not None else 0)
+    B = confs[0].shape[0]
+    N = int(sum(na))
+    if anchors_var.shape != (N, 8) or anchors_var.dtype != torch.float32:
+        raise SsdHipError("anchors_var must be float32 (%d, 8)" % N)
+    y = torch.empty((B, N, n_classes + 12), dtype=torch.float32, device=confs[0].device)
+    arr = lambda v: (ctypes.c_void_p * nl)(*v)
+    iarr = lambda v: (ctypes.c_int * nl)(*[int(t) for t in v])
+    with torch.cuda.device(y.device):
+        rc = lib.ssdhip_assemble_predictions_bf16(nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes),
+                                                  _ptr(anchors_var), B, N, int(n_classes), _ptr(y), current_stream_ptr(y.device))
+    check(rc, "ssdhip_assemble_predictions_bf16")
+    return y

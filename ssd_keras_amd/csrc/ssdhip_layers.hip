@@ -1,0 +1,302 @@
+// ssdhip_layers.hip -- the memory-bound glue of the SSD graph between the convolutions, on gfx950 (MI355X).
+//
+// The reference expresses these as separate Keras layers / TF ops (file:line relative to the reference root):
+//   * conv bias + ReLU (+ MaxPooling2D)   models/keras_ssd300.py:274-313 (Conv2D(activation='relu') + MaxPooling2D)
+//   * L2Normalization                     keras_layers/keras_layer_L2Normalization.py:61-63
+//   * input mean/scale/channel swap       models/keras_ssd300.py:247-272 (Lambda layers)
+//   * Reshape + Concatenate + softmax + AnchorBoxes tiling + final Concatenate -> (B, N, C+12)
+//                                         models/keras_ssd300.py:363-419, keras_layers/keras_layer_AnchorBoxes.py:245-255
+// PyTorch-ROCm runs each of them as 2-7 elementwise kernels (bias add, clamp, pool, copies, cat); here each is ONE pass:
+// HBM bytes = read the conv output once + write the result once.  All tensors are NHWC (torch channels_last), bf16
+// activations, 16-byte (8 x bf16) vector accesses; arithmetic in float32 with one rounding to bf16, which makes
+// bias+ReLU(+pool) bit-identical to the PyTorch sequence conv -> add(bf16) -> clamp_min(0) -> max_pool2d.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(u32 h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ u32 f2bf(float f) {            // round to nearest even, NaN stays NaN (as c10::BFloat16)
+    const u32 u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// two bf16 lanes of one dword: out = act(x + b)
+__device__ __forceinline__ u32 bias_act2(u32 x, u32 b, bool relu) {
+    u32 lo = f2bf(bf2f(x & 0xffffu) + bf2f(b & 0xffffu));
+    u32 hi = f2bf(bf2f(x >> 16) + bf2f(b >> 16));
+    if (relu) {                                            // clamp_min(0) on the rounded value; NaN passes through
+        if ((lo & 0x8000u) && (lo & 0x7fffu) <= 0x7f80u) lo = 0;
+        if ((hi & 0x8000u) && (hi & 0x7fffu) <= 0x7f80u) hi = 0;
+    }
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ uint4 bias_act8(uint4 x, uint4 b, bool relu) {
+    return make_uint4(bias_act2(x.x, b.x, relu), bias_act2(x.y, b.y, relu), bias_act2(x.z, b.z, relu), bias_act2(x.w, b.w, relu));
+}
+// max of two bf16 as torch's max_pool2d takes it (NaN propagates)
+__device__ __forceinline__ u32 bfmax1(u32 a, u32 b) {
+    const float fa = bf2f(a), fb = bf2f(b);
+    return (fa > fb || fa != fa) ? a : b;
+}
+__device__ __forceinline__ u32 bfmax2(u32 a, u32 b) { return bfmax1(a & 0xffffu, b & 0xffffu) | (bfmax1(a >> 16, b >> 16) << 16); }
+__device__ __forceinline__ uint4 bfmax8(uint4 a, uint4 b) { return make_uint4(bfmax2(a.x, b.x), bfmax2(a.y, b.y), bfmax2(a.z, b.z), bfmax2(a.w, b.w)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// y = act(x + bias[c]); x, y: [n_pixels, C] bf16 (may alias), C % 8 == 0.  4 independent 16-byte loads per thread.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_act_kernel(const uint4* __restrict__ x, const uint4* __restrict__ bias,
+                                                       uint4* __restrict__ y, u32 nvec, u32 cvec, int relu) {
+    const u32 stride = gridDim.x * 256u;
+    for (u32 i0 = blockIdx.x * 256u + threadIdx.x; i0 < nvec; i0 += 4u * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * stride; if (i < nvec) v[u] = x[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 i = i0 + u * stride;
+            if (i < nvec) y[i] = bias_act8(v[u], bias ? bias[i % cvec] : make_uint4(0, 0, 0, 0), relu != 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// y[b,ho,wo,c] = max over the k x k window (stride s, padding p, clipped to the map) of act(x[b,hi,wi,c] + bias[c]).
+// One thread per (output pixel, 8 channels); consecutive threads walk the channel vectors of a pixel, then wo.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint4* __restrict__ x, const uint4* __restrict__ bias,
+                                                               uint4* __restrict__ y, int B, int H, int W, u32 cvec, int k, int s,
+                                                               int p, int Ho, int Wo, int relu) {
+    const u32 total = (u32)B * Ho * Wo * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 cg = i % cvec;
+        u32 t = i / cvec;
+        const int wo = t % Wo; t /= Wo;
+        const int ho = t % Ho;
+        const int b = t / Ho;
+        const int h0 = max(ho * s - p, 0), h1 = min(ho * s - p + k, H);
+        const int w0 = max(wo * s - p, 0), w1 = min(wo * s - p + k, W);
+        const uint4 bv = bias ? bias[cg] : make_uint4(0, 0, 0, 0);
+        uint4 best = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);      // -inf
+        for (int hi = h0; hi < h1; ++hi)
+            for (int wi = w0; wi < w1; ++wi)
+                best = bfmax8(bias_act8(x[((size_t)(b * H + hi) * W + wi) * cvec + cg], bv, relu != 0), best);
+        y[i] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// L2Normalization: y = x * rsqrt(max(sum_c x^2, 1e-12)) * gamma[c]; one wave per pixel, float32 math.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma,
+                                                     uint4* __restrict__ y, u32 n_pixels, u32 cvec) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256u) >> 6;
+    for (u32 px = wave; px < n_pixels; px += nwaves) {
+        const uint4* row = x + (size_t)px * cvec;
+        float ss = 0.f;
+        for (u32 j = lane; j < cvec; j += 64u) {
+            const uint4 v = row[j];
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float a = bf2f(w[q] & 0xffffu), c = bf2f(w[q] >> 16); ss += a * a; ss += c * c; }
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        for (u32 j = lane; j < cvec; j += 64u) {
+            const uint4 v = row[j];
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+            u32 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g0 = gamma[j * 8 + q * 2], g1 = gamma[j * 8 + q * 2 + 1];
+                o[q] = f2bf((bf2f(w[q] & 0xffffu) * inv) * g0) | (f2bf((bf2f(w[q] >> 16) * inv) * g1) << 16);
+            }
+            y[(size_t)px * cvec + j] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input pipeline: out[b,h,w,c'] = bf16((img[b,h,w,swap[c']] - mean[swap[c']]) * scale[swap[c']]), img float32 NHWC.
+// ---------------------------------------------------------------------------------------------------------------
+struct PreParams { float mean[4]; float scale[4]; int swap[4]; int has_scale; };
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, u32 n_pixels,
+                                                         int Cin, PreParams pp) {
+    for (u32 px = blockIdx.x * 256u + threadIdx.x; px < n_pixels; px += gridDim.x * 256u) {
+        float v[4];
+        for (int c = 0; c < Cin; ++c) v[c] = img[(size_t)px * Cin + c];
+        for (int c = 0; c < Cin; ++c) {
+            const int sc = pp.swap[c];
+            float t = v[sc] - pp.mean[sc];
+            if (pp.has_scale) t = t / pp.scale[sc];
+            out[(size_t)px * Cin + c] = (bf16_t)f2bf(t);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Prediction assembly.  For predictor layer l with n_l anchors (= h*w*n_boxes, anchor a <-> (y, x, box) row-major):
+//   conf_l [B, n_l, C] bf16 logits (the NHWC conv output read as Keras' Reshape((-1, C)) reads it), loc_l [B, n_l, 4]
+//   y_pred[b, off_l + a, :] = [softmax(conf + bias) (C) | loc + bias (4) | anchor (4) | variances (4)]  float32
+// grid (tiles over all layers, B); a tile = TA anchors of one layer; rows are built in LDS and stored coalesced.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MAX_PRED_LAYERS = 8;
+struct HeadParams {
+    const bf16_t* conf[MAX_PRED_LAYERS];
+    const bf16_t* loc[MAX_PRED_LAYERS];
+    const bf16_t* conf_bias[MAX_PRED_LAYERS];     // [n_boxes*C] or null
+    const bf16_t* loc_bias[MAX_PRED_LAYERS];      // [n_boxes*4] or null
+    int n_anchors[MAX_PRED_LAYERS];
+    int n_boxes[MAX_PRED_LAYERS];
+    int tile_start[MAX_PRED_LAYERS + 1];          // first tile of layer l
+    int anchor_off[MAX_PRED_LAYERS];
+    int n_layers, N, C, TA;
+};
+
+__global__ __launch_bounds__(256) void head_kernel(HeadParams hp, const float* __restrict__ anchors_var, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, b = blockIdx.y, TA = hp.TA, C = hp.C, L = C + 12;
+    int l = 0;
+    while (l + 1 < hp.n_layers && (int)blockIdx.x >= hp.tile_start[l + 1]) ++l;
+    const int a0 = ((int)blockIdx.x - hp.tile_start[l]) * TA;
+    const int na = min(TA, hp.n_anchors[l] - a0);
+    float* rows = reinterpret_cast<float*>(smem_raw);                                   // [TA][L]
+    bf16_t* cl = reinterpret_cast<bf16_t*>(smem_raw + (size_t)TA * L * sizeof(float));  // [TA][C] logits, then [TA][4]
+    bf16_t* ll = cl + (size_t)TA * C;
+    const bf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
+    const bf16_t* lsrc = hp.loc[l] + ((size_t)b * hp.n_anchors[l] + a0) * 4;
+    for (int i = tid; i < na * C; i += 256) cl[i] = csrc[i];
+    for (int i = tid; i < na * 4; i += 256) ll[i] = lsrc[i];
+    __syncthreads();
+    const int nb = hp.n_boxes[l];
+    for (int a = tid; a < na; a += 256) {
+        const int box = (a0 + a) % nb;
+        float* r = rows + (size_t)a * L;
+        const bf16_t* cb = hp.conf_bias[l] ? hp.conf_bias[l] + box * C : nullptr;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            // the PyTorch path rounds conv + bias to bf16 before the float32 softmax: keep that rounding
+            const float v = cb ? bf2f(f2bf(bf2f(cl[a * C + c]) + bf2f(cb[c]))) : bf2f(cl[a * C + c]);
+            r[c] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) { const float e = expf(r[c] - mx); r[c] = e; sum += e; }
+        for (int c = 0; c < C; ++c) r[c] = r[c] / sum;
+        const bf16_t* lb = hp.loc_bias[l] ? hp.loc_bias[l] + box * 4 : nullptr;
+        for (int k = 0; k < 4; ++k) r[C + k] = lb ? bf2f(f2bf(bf2f(ll[a * 4 + k]) + bf2f(lb[k]))) : bf2f(ll[a * 4 + k]);
+        const float* av = anchors_var + (size_t)(hp.anchor_off[l] + a0 + a) * 8;
+        for (int k = 0; k < 8; ++k) r[C + 4 + k] = av[k];
+    }
+    __syncthreads();
+    float* dst = y + ((size_t)b * hp.N + hp.anchor_off[l] + a0) * L;
+    for (int i = tid; i < na * L; i += 256) dst[i] = rows[i];
+}
+
+static inline int grid_for(size_t work_items, int per_block) {
+    size_t g = (work_items + per_block - 1) / per_block;
+    const size_t cap = 256 * 16;                 // 16 workgroups per CU: enough loads in flight, few tail blocks
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+extern "C" int ssdhip_bias_act_nhwc_bf16(const void* x, const void* bias, void* y, long long n_pixels, int C, int relu,
+                                         void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || n_pixels <= 0 || C <= 0 || (C & 7)) return SSDHIP_E_BADARG;
+    const long long nvec = n_pixels * (C / 8);
+    if (nvec > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for((size_t)nvec, 1024)), dim3(256), 0, stream, static_cast<const uint4*>(x),
+                       static_cast<const uint4*>(bias), static_cast<uint4*>(y), (u32)nvec, (u32)(C / 8), relu);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias, void* y, int B, int H, int W, int C,
+                                                 int kernel, int stride, int pad, int Ho, int Wo, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || kernel <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0)
+        return SSDHIP_E_BADARG;
+    if (pad >= kernel || (Ho - 1) * stride - pad >= H || (Wo - 1) * stride - pad >= W) return SSDHIP_E_BADARG;   // empty window
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    if (total > 0x7fffffffLL || (long long)B * H * W * (C / 8) > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(bias_act_maxpool_kernel, dim3(grid_for((size_t)total, 256)), dim3(256), 0, stream,
+                       static_cast<const uint4*>(x), static_cast<const uint4*>(bias), static_cast<uint4*>(y), B, H, W, (u32)(C / 8),
+                       kernel, stride, pad, Ho, Wo, relu);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_l2_normalize_nhwc_bf16(const void* x, const float* gamma, void* y, long long n_pixels, int C, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !gamma || !y || n_pixels <= 0 || C <= 0 || (C & 7) || n_pixels > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(grid_for((size_t)n_pixels, 4)), dim3(256), 0, stream, static_cast<const uint4*>(x), gamma,
+                       static_cast<uint4*>(y), (u32)n_pixels, (u32)(C / 8));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_preprocess_nhwc_f32_to_bf16(const float* images, void* out, long long n_pixels, int channels,
+                                                  const float* mean_h, const float* divide_h, const int* swap_h, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!images || !out || n_pixels <= 0 || n_pixels > 0x7fffffffLL || channels < 1 || channels > 4) return SSDHIP_E_BADARG;
+    PreParams pp;
+    for (int c = 0; c < 4; ++c) {
+        pp.mean[c] = (mean_h && c < channels) ? mean_h[c] : 0.f;
+        pp.scale[c] = (divide_h && c < channels) ? divide_h[c] : 1.f;
+        pp.swap[c] = (swap_h && c < channels) ? swap_h[c] : c;
+        if (pp.swap[c] < 0 || pp.swap[c] >= 4) return SSDHIP_E_BADARG;
+    }
+    pp.has_scale = divide_h ? 1 : 0;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((size_t)n_pixels, 256)), dim3(256), 0, stream, images,
+                       static_cast<bf16_t*>(out), (u32)n_pixels, channels, pp);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                                const void* const* conf_bias_h, const void* const* loc_bias_h,
+                                                const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
+                                                int B, int N, int C, float* y_pred, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !conf_h || !loc_h || !n_anchors_h || !n_boxes_h || !anchors_var || !y_pred ||
+        B <= 0 || N <= 0 || C < 2 || C > 1024)
+        return SSDHIP_E_BADARG;
+    HeadParams hp;
+    const int L = C + 12;
+    int TA = 256;
+    while (TA > 32 && (size_t)TA * (L * sizeof(float) + (C + 4) * sizeof(bf16_t)) > 60 * 1024) TA >>= 1;
+    hp.n_layers = n_layers; hp.N = N; hp.C = C; hp.TA = TA;
+    int off = 0, tiles = 0;
+    for (int l = 0; l < MAX_PRED_LAYERS; ++l) {
+        const bool on = l < n_layers;
+        hp.conf[l] = on ? static_cast<const bf16_t*>(conf_h[l]) : nullptr;
+        hp.loc[l] = on ? static_cast<const bf16_t*>(loc_h[l]) : nullptr;
+        hp.conf_bias[l] = (on && conf_bias_h) ? static_cast<const bf16_t*>(conf_bias_h[l]) : nullptr;
+        hp.loc_bias[l] = (on && loc_bias_h) ? static_cast<const bf16_t*>(loc_bias_h[l]) : nullptr;
+        hp.n_anchors[l] = on ? n_anchors_h[l] : 0;
+        hp.n_boxes[l] = on ? n_boxes_h[l] : 1;
+        hp.tile_start[l] = tiles;
+        hp.anchor_off[l] = off;
+        if (on) {
+            if (!hp.conf[l] || !hp.loc[l] || hp.n_anchors[l] <= 0 || hp.n_boxes[l] <= 0 || hp.n_anchors[l] % hp.n_boxes[l]) return SSDHIP_E_BADARG;
+            off += hp.n_anchors[l];
+            tiles += (hp.n_anchors[l] + TA - 1) / TA;
+        }
+    }
+    hp.tile_start[MAX_PRED_LAYERS] = tiles;
+    if (off != N) return SSDHIP_E_BADARG;
+    const size_t lds = (size_t)TA * (L * sizeof(float) + (C + 4) * sizeof(bf16_t));
+    hipLaunchKernelGGL(head_kernel, dim3(tiles, B), dim3(256), lds, stream, hp, anchors_var, y_pred);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

@@ -14,6 +14,7 @@ class L2Normalization(nn.Module):
     def __init__(self, gamma_init=20, n_channels=None, **kwargs):
         super().__init__()
         self.gamma_init = gamma_init
+        self.fused_inference = True
         self.name = kwargs.get('name')
         self.gamma = nn.Parameter(torch.full((n_channels,), float(gamma_init))) if n_channels else None
 
@@ -23,6 +24,10 @@ class L2Normalization(nn.Module):
     def forward(self, x):
         if self.gamma is None:
             self.build(x.shape[1], x.device)
+        if (self.fused_inference and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and x.shape[1] % 8 == 0):
+            from .. import _native as nat          # one pass in libssdhip (csrc/ssdhip_layers.hip) instead of seven kernels
+            return nat.l2_normalize(x, self.gamma)
         xf = x.float()
         inv = torch.rsqrt(torch.clamp_min((xf * xf).sum(dim=1, keepdim=True), 1e-12))
         return (xf * inv * self.gamma.view(1, -1, 1, 1)).to(x.dtype)

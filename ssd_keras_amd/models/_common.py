@@ -10,7 +10,9 @@ from __future__ import annotations
 import numpy as np
 import torch
 from torch import nn
+import torch.nn.functional as F
 
+from .. import _native as nat
 from ..anchor_math import n_boxes_for
 from ..keras_layers.keras_layer_AnchorBoxes import AnchorBoxes
 from ..keras_layers.keras_layer_DecodeDetections import DecodeDetections
@@ -86,6 +88,7 @@ class SSDModel(nn.Module):
         self.subtract_mean = subtract_mean
         self.divide_by_stddev = divide_by_stddev
         self.swap_channels = swap_channels
+        self.fused_inference = True         # bf16 + no_grad on a GPU: graph glue runs in libssdhip (csrc/ssdhip_layers.hip)
         self.decoder = None
         if mode != 'training':
             layer = DecodeDetections if mode == 'inference' else DecodeDetectionsFast
@@ -95,12 +98,44 @@ class SSDModel(nn.Module):
                                  img_width=self.img_width, name='decoded_predictions')
         self._anchor_cache = {}
 
+    # -- fused inference path: every conv is followed by ONE libssdhip pass (bias + ReLU [+ max-pool]) instead of the
+    #    2-3 elementwise kernels PyTorch launches; bit-identical results (see csrc/ssdhip_layers.hip) ----------------
+    def _fused(self, x, conv=None):
+        return (self.fused_inference and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and (conv is None or (conv.weight.dtype == torch.bfloat16 and conv.out_channels % 8 == 0)))
+
+    @staticmethod
+    def _conv_nobias(conv, x):
+        return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+    def conv_act(self, conv, x, relu=True):
+        if self._fused(x, conv):
+            return nat.bias_act(self._conv_nobias(conv, x), conv.bias, relu=relu)
+        y = conv(x)
+        return F.relu(y) if relu else y
+
+    def conv_act_pool(self, conv, x, kernel, stride, pad=0, ceil_mode=False):
+        if self._fused(x, conv):
+            return nat.bias_act_maxpool(self._conv_nobias(conv, x), conv.bias, kernel, stride, pad, ceil_mode, relu=True)
+        return F.max_pool2d(F.relu(conv(x)), kernel, stride, pad, ceil_mode=ceil_mode)
+
+    def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):
+        if self._fused(x) and x.shape[1] % 8 == 0:
+            return nat.bias_act_maxpool(x, None, kernel, stride, pad, ceil_mode, relu=False)
+        return F.max_pool2d(x, kernel, stride, pad, ceil_mode=ceil_mode)
+
     # -- in-graph input pipeline (keras_ssd300.py:247-272): NHWC 0..255 -> normalised NCHW (channels_last memory) --
     def preprocess(self, images):
         x = images
         if x.dim() != 4:
             raise ValueError("expected images of shape (batch, height, width, channels)")
-        if x.shape[-1] == self.img_channels and x.shape[1] != self.img_channels:
+        nhwc = x.shape[-1] == self.img_channels and x.shape[1] != self.img_channels
+        if (nhwc and self.fused_inference and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                and not torch.is_grad_enabled() and self.img_channels <= 4
+                and next(self.parameters()).dtype == torch.bfloat16):
+            return nat.preprocess(x, self.subtract_mean, self.divide_by_stddev,
+                                  list(self.swap_channels) if self.swap_channels else None)
+        if nhwc:
             x = x.permute(0, 3, 1, 2)                # NHWC storage == channels_last NCHW: no copy
         x = x.float()
         if self.subtract_mean is not None:
@@ -128,16 +163,27 @@ class SSDModel(nn.Module):
         dtype = next(self.parameters()).dtype
         feats = self.features(x.to(dtype) if not torch.is_autocast_enabled() else x)
         b = x.shape[0]
-        confs, locs, sizes = [], [], []
+        sizes = [(f.shape[2], f.shape[3]) for f in feats]
+        if all(self._fused_head_ok(f, ch) for f, ch in zip(feats, self.conf_heads)):
+            # heads without bias; bias, Reshape, softmax, anchors and the concatenations are one libssdhip pass (:363-419)
+            confs = [self._conv_nobias(ch, f) for f, ch in zip(feats, self.conf_heads)]
+            locs = [self._conv_nobias(lh, f) for f, lh in zip(feats, self.loc_heads)]
+            anchors = self.anchors_and_variances(sizes, x.device)
+            return nat.assemble_predictions(confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
+                                            [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
+        confs, locs = [], []
         for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads):
             # NCHW -> NHWC before the reshape so the channel axis splits as (box, class) like Keras (:363-383)
             confs.append(ch(f).permute(0, 2, 3, 1).reshape(b, -1, self.n_classes))
             locs.append(lh(f).permute(0, 2, 3, 1).reshape(b, -1, 4))
-            sizes.append((f.shape[2], f.shape[3]))
         conf = torch.softmax(torch.cat(confs, dim=1).float(), dim=-1)          # 'mbox_conf_softmax' (:415)
         loc = torch.cat(locs, dim=1).float()
         anchors = self.anchors_and_variances(sizes, conf.device)
         return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+
+    def _fused_head_ok(self, f, conv):
+        return (self.fused_inference and f.is_cuda and f.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and conv.weight.dtype == torch.bfloat16)
 
     def forward(self, images):
         pred = self.raw_predictions(images)

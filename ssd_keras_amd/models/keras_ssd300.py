@@ -32,18 +32,14 @@ class _VGGBase(SSDModel):
         self.conv4_3_norm = L2Normalization(gamma_init=20, n_channels=512, name='conv4_3_norm')
 
     def _vgg(self, x):
-        r = F.relu
-        x = r(self.conv1_2(r(self.conv1_1(x))))
-        x = F.max_pool2d(x, 2, 2, ceil_mode=True)                      # 'same' pooling pads bottom/right
-        x = r(self.conv2_2(r(self.conv2_1(x))))
-        x = F.max_pool2d(x, 2, 2, ceil_mode=True)
-        x = r(self.conv3_3(r(self.conv3_2(r(self.conv3_1(x))))))
-        x = F.max_pool2d(x, 2, 2, ceil_mode=True)
-        conv4_3 = r(self.conv4_3(r(self.conv4_2(r(self.conv4_1(x))))))
-        x = F.max_pool2d(conv4_3, 2, 2, ceil_mode=True)
-        x = r(self.conv5_3(r(self.conv5_2(r(self.conv5_1(x))))))
-        x = F.max_pool2d(x, 3, 1, padding=1)
-        fc7 = r(self.fc7(r(self.fc6(x))))
+        ca, cap = self.conv_act, self.conv_act_pool
+        x = cap(self.conv1_2, ca(self.conv1_1, x), 2, 2, ceil_mode=True)          # 'same' pooling pads bottom/right
+        x = cap(self.conv2_2, ca(self.conv2_1, x), 2, 2, ceil_mode=True)
+        x = cap(self.conv3_3, ca(self.conv3_2, ca(self.conv3_1, x)), 2, 2, ceil_mode=True)
+        conv4_3 = ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x)))
+        x = self.max_pool(conv4_3, 2, 2, ceil_mode=True)
+        x = cap(self.conv5_3, ca(self.conv5_2, ca(self.conv5_1, x)), 3, 1, pad=1)
+        fc7 = ca(self.fc7, ca(self.fc6, x))
         return conv4_3, fc7
 
     @staticmethod
@@ -78,12 +74,12 @@ class SSD300(_VGGBase):
         he_normal_(self)
 
     def features(self, x):
-        r = F.relu
+        ca = self.conv_act
         conv4_3, fc7 = self._vgg(x)
-        conv6_2 = r(self.conv6_2(r(self.conv6_1(fc7))))
-        conv7_2 = r(self.conv7_2(r(self.conv7_1(conv6_2))))
-        conv8_2 = r(self.conv8_2(r(self.conv8_1(conv7_2))))
-        conv9_2 = r(self.conv9_2(r(self.conv9_1(conv8_2))))
+        conv6_2 = ca(self.conv6_2, ca(self.conv6_1, fc7))
+        conv7_2 = ca(self.conv7_2, ca(self.conv7_1, conv6_2))
+        conv8_2 = ca(self.conv8_2, ca(self.conv8_1, conv7_2))
+        conv9_2 = ca(self.conv9_2, ca(self.conv9_1, conv8_2))
         return [self.conv4_3_norm(conv4_3), fc7, conv6_2, conv7_2, conv8_2, conv9_2]
 
     def predictor_sizes(self):

@@ -37,13 +37,13 @@ class SSD512(_VGGBase):
         he_normal_(self)
 
     def features(self, x):
-        r = F.relu
+        ca = self.conv_act
         conv4_3, fc7 = self._vgg(x)
-        conv6_2 = r(self.conv6_2(r(self.conv6_1(fc7))))
-        conv7_2 = r(self.conv7_2(r(self.conv7_1(conv6_2))))
-        conv8_2 = r(self.conv8_2(r(self.conv8_1(conv7_2))))
-        conv9_2 = r(self.conv9_2(r(self.conv9_1(conv8_2))))
-        conv10_2 = r(self.conv10_2(r(self.conv10_1(conv9_2))))
+        conv6_2 = ca(self.conv6_2, ca(self.conv6_1, fc7))
+        conv7_2 = ca(self.conv7_2, ca(self.conv7_1, conv6_2))
+        conv8_2 = ca(self.conv8_2, ca(self.conv8_1, conv7_2))
+        conv9_2 = ca(self.conv9_2, ca(self.conv9_1, conv8_2))
+        conv10_2 = ca(self.conv10_2, ca(self.conv10_1, conv9_2))
         return [self.conv4_3_norm(conv4_3), fc7, conv6_2, conv7_2, conv8_2, conv9_2, conv10_2]
 
     def predictor_sizes(self):

@@ -39,7 +39,7 @@ class SSD7(SSDModel):
             if i >= 3:
                 feats.append(x)
             if i < 6:
-                x = F.max_pool2d(x, 2, 2)
+                x = self.max_pool(x, 2, 2)
         return feats
 
     def predictor_sizes(self):

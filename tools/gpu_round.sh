@@ -15,6 +15,7 @@ tail -c 3000 $OUT/bench.json
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -o bench -- \
     python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/trace_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trace_err.log )
 # PMC passes (own runs, --kernel-trace only)
+if [ "${3:-}" = "skip_pmc" ]; then exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && REPS=5 timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o dec -- \
       python $GRAFT_REPO_ROOT/tools/pmc_decode.py > $GRAFT_REPO_ROOT/$OUT/pmc_$C.log 2>&1 )
