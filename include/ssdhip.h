@@ -176,6 +176,16 @@ int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, co
                                      const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
                                      int B, int N, int C, float* y_pred, void* stream);
 
+/* 'same' convolution (kernel 1 or 3, stride 1, any dilation, zero padding) + bias + ReLU as one implicit-GEMM MFMA kernel:
+ * Conv2D(filters, (k,k), padding='same', activation='relu'[, dilation_rate]) of models/keras_ssd300.py:274-300.
+ *   x [B,H,W,Cin] bf16 NHWC, weight [Cout,k,k,Cin] bf16 (torch OIHW weight in channels_last memory), bias [Cout] bf16 or NULL,
+ *   y [B,H,W,Cout] bf16.  Cin % 64 == 0, Cout % 64 == 0; float32 accumulation, one rounding to bf16 after bias + activation. */
+int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                 int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
+/* Profiling aid: the same with an explicit kernel variant (1: 128-pixel tile, two-stage pipeline; 3: the shipped kernel). */
+int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
+                                         int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

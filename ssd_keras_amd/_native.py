@@ -316,3 +316,28 @@ def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_
                                                   _ptr(anchors_var), B, N, int(n_classes), _ptr(y), current_stream_ptr(y.device))
     check(rc, "ssdhip_assemble_predictions_bf16")
     return y
+
+
+def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
+    """'same' convolution (kernel 1 or 3, stride 1) + bias + ReLU in ONE libssdhip MFMA kernel (csrc/ssdhip_conv.hip).
+    x (B, Cin, H, W) bf16 with NHWC memory; weight (Cout, Cin, k, k) bf16 with channels_last memory; Cin, Cout % 64 == 0."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_conv_bound", False):
+        lib.ssdhip_conv2d_same_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv2d_same_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+        lib.ssdhip_conv2d_same_nhwc_bf16_variant.restype = ctypes.c_int
+        lib.ssdhip_conv2d_same_nhwc_bf16_variant.argtypes = [ctypes.c_int] + lib.ssdhip_conv2d_same_nhwc_bf16.argtypes
+        lib._conv_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or kh != kw:
+        raise SsdHipError("weight must be bfloat16 (Cout, %d, k, k)" % cin)
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        args = (_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(kh), int(dilation), int(bool(relu)),
+                current_stream_ptr(x.device))
+        rc = lib.ssdhip_conv2d_same_nhwc_bf16(*args) if variant is None else lib.ssdhip_conv2d_same_nhwc_bf16_variant(int(variant), *args)
+    check(rc, "ssdhip_conv2d_same_nhwc_bf16")
+    return y

@@ -1,0 +1,415 @@
+// ssdhip_conv.hip -- 'same' convolution (3x3 or 1x1, stride 1, any dilation) + bias + ReLU as ONE implicit-GEMM MFMA kernel
+// for gfx950 (MI355X), bf16 NHWC activations, float32 accumulation.
+//
+// Reference: every Conv2D(..., padding='same', activation='relu') of the VGG-16 trunk and fc6/fc7,
+// models/keras_ssd300.py:274-300 (keras_ssd512.py twin).  The framework path runs conv (MIOpen) + bias add + clamp as
+// three kernels; here the bias/activation lives in the epilogue of the GEMM, so the activation tensor is written once.
+//
+// GEMM view:  D[co][m] = sum_{tap, ci} Wt[co][tap][ci] * X[m + off(tap)][ci]     m = flattened (b, h, w) pixel index
+//   * MFMA 'A' operand = weights (rows = output channels), 'B' operand = pixels: each lane then owns 4 consecutive
+//     channels of one pixel per accumulator quad -> 8-byte NHWC stores straight from registers.
+//   * workgroup tile: BC (64|128) channels x 128 pixels x 64 input channels of one tap per K-step; 4 waves as 2x2,
+//     v_mfma_f32_32x32x16_bf16, 16 (BC=128) MFMAs per wave per K-step.
+//   * global -> LDS with global_load_lds_dwordx4 (no VGPR staging): LDS image is lane-linear, so the 16-byte chunks of
+//     a 128-byte row are permuted on the SOURCE side (chunk j of row r sits at position j ^ ((r >> 1) & 7)) and the
+//     same involution is applied when reading fragments -> ds_read_b128 free of bank conflicts.
+//   * padding: a pixel whose tap falls outside the image reads from a 64-byte zero block instead (per-lane source
+//     pointer select; validity of the 9 taps is a bit mask computed once per thread).
+//   * two LDS buffers, one barrier per K-step: loads of step s+1 are in flight while step s is multiplied.
+//   * blockIdx -> tile map keeps the channel tiles of one pixel tile on the same XCD (shared L2 for X).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __attribute__((aligned(64))) const unsigned int g_zero_block[16] = {0};
+
+constexpr int CONV_BP = 128;     // pixels per workgroup tile
+constexpr int CONV_BK = 64;      // input channels per K-step (128 bytes per row)
+constexpr int CONV_THREADS = 256;
+
+struct ConvParams {
+    const bf16_t* x;             // [M, Cin]
+    const bf16_t* w;             // [Cout, KS*KS, Cin]  (torch OIHW weight in channels_last memory)
+    const bf16_t* bias;          // [Cout] or null
+    bf16_t* y;                   // [M, Cout]
+    int H, W, Cin, Cout, KS, dil, relu;
+    int M, m_tiles, n_tiles;
+};
+
+__device__ __forceinline__ u32 f2bf_rn(float f) {
+    const u32 u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BC>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvParams p) {
+    constexpr int CI = BC / 64;                       // 32-channel MFMA tiles per wave
+    constexpr int WROWS = BC;                         // weight rows per tile
+    constexpr int XBYTES = CONV_BP * 128, WBYTES = WROWS * 128, BUF = XBYTES + WBYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
+
+    // XCD-aware tile map: workgroup id -> (pixel tile, channel tile); all channel tiles of a pixel tile on one XCD
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
+    if (mt >= p.m_tiles) return;
+    const int m0 = mt * CONV_BP, co0 = nt * BC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wp = wave & 1;
+    const int Cin = p.Cin, KK = p.KS * p.KS, half = p.KS >> 1;
+    const int csteps = Cin / CONV_BK, T = KK * csteps;
+
+    // ---- per-thread load descriptors: 4 X rows (+ tap validity) and CI*2 weight rows --------------------------
+    const bf16_t* xsrc[4];
+    u32 xok[4];
+    const int pos = lane & 7;
+    {
+        // rows of this thread: m0 + wave*8 + (lane>>3) + 32*i; (h, w) of the first by division, the others by stepping
+        int m = m0 + wave * 8 + (lane >> 3);
+        int wq = m % p.W, hq = (m / p.W) % p.H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            const int j = pos ^ ((row >> 1) & 7);
+            u32 rmask = 0, cmask = 0;                  // taps valid along h / along w; tap (kh, kw) valid iff both
+            for (int k = 0; k < p.KS; ++k) {
+                const int d = (k - half) * p.dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (m < p.M)
+                for (int kh = 0; kh < p.KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * p.KS);
+            xok[i] = ok;
+            xsrc[i] = p.x + (size_t)m * Cin + j * 8;
+            m += 32;
+            wq += 32;
+            while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
+        }
+    }
+    const bf16_t* wsrc[CI * 2];
+#pragma unroll
+    for (int i = 0; i < CI * 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const int j = pos ^ ((row >> 1) & 7);
+        wsrc[i] = p.w + (size_t)(co0 + row) * KK * Cin + j * 8;
+    }
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_block);               // 16 readable zero bytes
+
+    auto issue = [&](int s, int buf) {
+        const int t = s / csteps, c0 = (s - t * csteps) * CONV_BK;
+        const int dh = (t / p.KS - half) * p.dil, dw = (t % p.KS - half) * p.dil;
+        const long xoff = ((long)dh * p.W + dw) * Cin + c0;
+        const long woff = (long)t * Cin + c0;
+        unsigned char* xb = lds + buf * BUF;
+        unsigned char* wb = xb + XBYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* src = ((xok[i] >> t) & 1u) ? xsrc[i] + xoff : zsrc;
+            glds16(src, xb + (i * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < CI * 2; ++i) glds16(wsrc[i] + woff, wb + (i * 4 + wave) * 1024);
+    };
+
+    f32x16 acc[CI][2];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int swz = (r31 >> 1) & 7;                   // tile-row bases are multiples of 32, so (row >> 1) & 7 == this
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        if (s + 1 < T) issue(s + 1, (s + 1) & 1);
+        const unsigned char* xb = lds + (s & 1) * BUF;
+        const unsigned char* wb = xb + XBYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int choff = ((2 * kk + khalf) ^ swz) << 4;
+            bf16x8 a[CI], b[2];
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+                a[ci] = *reinterpret_cast<const bf16x8*>(wb + (wc * (BC / 2) + ci * 32 + r31) * 128 + choff);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+                b[pi] = *reinterpret_cast<const bf16x8*>(xb + (wp * 64 + pi * 32 + r31) * 128 + choff);
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ci], b[pi], acc[ci][pi], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step's tile has landed (this wave's part) ...
+        __syncthreads();                                         // ... and everybody's; nobody still reads this step's buffer
+    }
+
+    // ---- epilogue: D row = channel (v&3) + 8*(v>>2) + 4*(lane>>5), column = pixel lane&31 ------------------------
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int m = m0 + wp * 64 + pi * 32 + r31;
+        if (m >= p.M) continue;
+        bf16_t* yrow = p.y + (size_t)m * p.Cout;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][pi][4 * g + q] + bv[q];
+                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                *reinterpret_cast<uint2*>(yrow + ch) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+    }
+}
+
+
+// =================================================================================================================
+// v3: 256-pixel tile, 8 waves, three-stage weight pipeline, kw-reuse of the activation strip.
+//   * tile = BC channels x 256 consecutive pixels; 8 waves as 2 (channels) x 4 (pixels), each 32*CI x 64.
+//   * a GROUP is (kh, 64-channel slice): the strip of 256 + 2*dil pixel rows [m0 - dil, m0 + 256 + dil) shifted by
+//     (kh-1)*dil image rows is loaded ONCE and serves the three taps kw = 0,1,2 (tap kw reads strip row p + kw*dil);
+//     pixels whose tap leaves the image are zeroed in registers (v_cndmask on the B fragment) -- X traffic / 3.
+//   * weights: one [BC][64] tile per tap, three LDS buffers; loads of step s+2 are issued before step s is multiplied
+//     and only a COUNTED s_waitcnt vmcnt(n) + raw s_barrier closes the step, so two tiles stay in flight across the
+//     barrier (__syncthreads() would drain them).  LDS: 2 x 40 KB strips + 3 x BC*128 B = 128 KB at BC = 128, one
+//     workgroup (8 waves) per CU.
+// =================================================================================================================
+constexpr int C3_BP = 256, C3_THREADS = 512, C3_STRIP_ROWS = 320;     // 5 wave-instructions of 8 rows per wave
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int BC>
+__global__ __launch_bounds__(C3_THREADS) void conv_igemm3_kernel(ConvParams p) {
+    constexpr int CI = BC / 64, NW = BC / 64;         // 32-channel MFMA tiles per wave; weight glds per thread per step
+    constexpr int XBYTES = C3_STRIP_ROWS * 128, WBYTES = BC * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * XBYTES + 3 * WBYTES];
+
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
+    if (mt >= p.m_tiles) return;
+    const int m0 = mt * C3_BP, co0 = nt * BC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 2, wp = wave & 3;
+    const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
+    const int hdil = half * dil;                      // halo rows on each side of the strip (0 for 1x1)
+    const int csteps = Cin / CONV_BK, G = KS * csteps, T = G * KS;
+
+    // ---- load descriptors -------------------------------------------------------------------------------------
+    const int pos = tid & 7;
+    const int jch = (pos ^ ((tid >> 4) & 7)) * 8;     // source chunk (in elements) for LDS slot (row, pos): j = pos ^ ((row>>1)&7)
+    const long gq0 = (long)m0 - hdil + (tid >> 3);    // flattened pixel of strip row q_i = i*64 + (tid>>3), before the kh shift
+    const bf16_t* wsrc[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wsrc[i] = p.w + (size_t)(co0 + i * 64 + (tid >> 3)) * KK * Cin + jch;
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_block);
+    unsigned char* const xlds = lds;
+    unsigned char* const wlds = lds + 2 * XBYTES;
+
+    auto issue_x = [&](int g) {
+        const int kh = g / csteps, c0 = (g - kh * csteps) * CONV_BK;
+        const long vshift = (long)(kh - half) * dil * p.W;
+        unsigned char* dst = xlds + (g & 1) * XBYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const long gp = gq0 + i * 64 + vshift;
+            const bool in = gp >= 0 && gp < (long)p.M && (i < 4 || (tid >> 3) < 2 * hdil);
+            glds16(in ? p.x + gp * Cin + c0 + jch : zsrc, dst + i * 8192);
+        }
+    };
+    auto issue_w = [&](int s) {
+        const int g = s / KS, kw = s - g * KS;
+        const int kh = g / csteps, c0 = (g - kh * csteps) * CONV_BK;
+        const long woff = (long)(kh * KS + kw) * Cin + c0;
+        unsigned char* dst = wlds + (s % 3) * WBYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) glds16(wsrc[i] + woff, dst + i * 8192);
+    };
+
+    // ---- which taps are inside the image for the two pixels whose B fragments this lane reads -----------------------
+    const int r31 = lane & 31, khalf = lane >> 5;
+    u32 okb[2];
+    {
+        int m = m0 + wp * 64 + r31;
+        int wq = m % p.W, hq = (m / p.W) % p.H;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            u32 rmask = 0, cmask = 0;
+            for (int k = 0; k < KS; ++k) {
+                const int d = (k - half) * dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (m < p.M)
+                for (int kh = 0; kh < KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+            okb[pi] = ok;
+            m += 32;
+            wq += 32;
+            while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
+        }
+    }
+
+    f32x16 acc[CI][2];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    const int aswz = (r31 >> 1) & 7;                  // weight rows: tile-row bases are multiples of 32
+
+    issue_x(0);
+    issue_w(0);
+    if (T > 1) { issue_w(1); wait_vmcnt<NW>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < T; ++s) {
+        const int g = s / KS, kw = s - g * KS;
+        const bool do_x = (kw == 0) && (g + 1 < G);
+        const bool do_w = s + 2 < T;
+        if (do_x) issue_x(g + 1);
+        if (do_w) issue_w(s + 2);
+
+        const unsigned char* xb = xlds + (g & 1) * XBYTES;
+        const unsigned char* wb = wlds + (s % 3) * WBYTES;
+        const int tap = (g / csteps) * KS + kw;
+        const int q0 = wp * 64 + r31 + kw * dil;      // strip row of this lane's first pixel for this tap
+        const int q1 = q0 + 32;
+        const int bswz0 = (q0 >> 1) & 7, bswz1 = (q1 >> 1) & 7;
+        const bool ok0 = (okb[0] >> tap) & 1u, ok1 = (okb[1] >> tap) & 1u;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = 2 * kk + khalf;
+            bf16x8 a[CI], b[2];
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+                a[ci] = *reinterpret_cast<const bf16x8*>(wb + (wc * (BC / 2) + ci * 32 + r31) * 128 + ((ch ^ aswz) << 4));
+            uint4 b0 = *reinterpret_cast<const uint4*>(xb + q0 * 128 + ((ch ^ bswz0) << 4));
+            uint4 b1 = *reinterpret_cast<const uint4*>(xb + q1 * 128 + ((ch ^ bswz1) << 4));
+            if (!ok0) b0 = make_uint4(0, 0, 0, 0);
+            if (!ok1) b1 = make_uint4(0, 0, 0, 0);
+            b[0] = __builtin_bit_cast(bf16x8, b0);
+            b[1] = __builtin_bit_cast(bf16x8, b1);
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ci], b[pi], acc[ci][pi], 0, 0, 0);
+        }
+        // everything older than what this iteration issued has landed: W(s+1) and, after kw = 1, the next strip
+        const bool x_flies = do_x && KS > 1;          // 1x1: the strip issued now is needed by the very next step
+        if (x_flies && do_w) wait_vmcnt<5 + NW>();
+        else if (x_flies) wait_vmcnt<5>();
+        else if (do_w) wait_vmcnt<NW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: D row = channel (v&3) + 8*(v>>2) + 4*(lane>>5), column = pixel lane&31 ------------------------
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int m = m0 + wp * 64 + pi * 32 + r31;
+        if (m >= p.M) continue;
+        bf16_t* yrow = p.y + (size_t)m * p.Cout;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * gq + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][pi][4 * gq + q] + bv[q];
+                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                *reinterpret_cast<uint2*>(yrow + ch) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+    }
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+static int conv_run(int variant, const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                    int Cin, int Cout, int kernel, int dilation, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || dilation <= 0 || dilation > 8) return SSDHIP_E_BADARG;
+    if (kernel != 1 && kernel != 3) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % CONV_BK) || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 7)) return SSDHIP_E_BADARG;
+    const long long M = (long long)B * H * W;
+    if (M * (long long)(Cin > Cout ? Cin : Cout) > 0x7fffffff0LL || M > 0x7fffff00LL) return SSDHIP_E_BADARG;
+    ConvParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
+    p.M = (int)M;
+    const bool wide = (Cout % 128) == 0;
+    p.n_tiles = Cout / (wide ? 128 : 64);
+    if (variant == 1) {                       // 128-pixel tile, two-stage pipeline (kept for A/B timing)
+        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (wide) hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    } else {
+        p.m_tiles = (int)((M + C3_BP - 1) / C3_BP);
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (wide) hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(grid), dim3(C3_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL(conv_igemm3_kernel<64>, dim3(grid), dim3(C3_THREADS), 0, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// y[b,h,w,co] = act(bias[co] + sum_{kh,kw,ci} x[b, h + (kh-k/2)*dil, w + (kw-k/2)*dil, ci] * w[co,kh,kw,ci]), zero padding.
+extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                            int Cin, int Cout, int kernel, int dilation, int relu, void* stream) {
+    return conv_run(3, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
+}
+
+// Profiling aid: the same with an explicit kernel variant (1: 128-pixel tile / two stages, 3: the shipped kernel).
+extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
+                                                    int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
+                                                    void* stream) {
+    if (variant != 1 && variant != 3) return SSDHIP_E_BADARG;
+    return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
+}

@@ -1,0 +1,54 @@
+"""Implicit-GEMM MFMA convolution (csrc/ssdhip_conv.hip, through the C ABI) vs a plain PyTorch float32 reference of the
+same op on the same bf16-valued inputs.  Needs an MI355X.  Bar: |got - want| <= 2^-7 |want| + 1e-2 * rms (one bf16
+rounding of a float32-accumulated sum; the reference accumulates in a different order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, H, W, Cin, Cout, k, dil, bias, relu
+    (2, 19, 19, 64, 64, 3, 1, True, True),        # BC=64 path, M = 722 (partial last tile)
+    (1, 38, 38, 128, 128, 3, 1, True, True),      # BC=128 path
+    (2, 10, 7, 64, 256, 3, 1, True, False),       # W < 32: several image rows inside one row group, no ReLU
+    (1, 19, 19, 128, 128, 3, 6, True, True),      # fc6-style dilation 6
+    (3, 5, 5, 256, 128, 1, 1, False, True),       # 1x1, no bias
+    (1, 1, 1, 64, 64, 3, 1, True, True),          # single pixel: only the centre tap is inside the image
+    (1, 75, 75, 256, 256, 3, 1, True, True),      # conv3_2 shape, K = 2304
+    (2, 300, 300, 64, 64, 3, 1, True, True),      # conv1_2 shape
+    (2, 19, 19, 128, 128, 1, 1, True, True),      # 1x1 with two channel slices (strip needed by the very next step)
+    (1, 19, 19, 192, 64, 3, 6, True, True),       # dilation 6, three channel slices, BC = 64
+    (4, 3, 3, 64, 128, 3, 2, True, True),         # map smaller than the dilated kernel reach
+]
+
+
+@pytest.mark.parametrize("variant", [None, 1])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_vs_float32_reference(case, variant):
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, k, dil, has_bias, relu = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    # asymmetric weights (a transposed operand or tap order would not survive this)
+    wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
+    got = nat.conv2d_same(x, wt, bias, dilation=dil, relu=relu, variant=variant).float()
+    want = F.conv2d(x.float(), wt.float(), bias.float() if has_bias else None, 1, dil * (k // 2), dil)
+    if relu:
+        want = torch.relu(want)
+    assert got.shape == want.shape
+    rms = want.pow(2).mean().sqrt().item()
+    err = (got - want).abs()
+    tol = want.abs() * 2.0 ** -7 + 1e-2 * rms
+    bad = int((err > tol).sum().item())
+    assert bad == 0, "%d of %d outputs off; max err %g (rms %g)" % (bad, err.numel(), err.max().item(), rms)
+
+
+def test_conv_rejects_unsupported_shapes():
+    import torch
+    from ssd_keras_amd import _native as nat
+    x = torch.zeros((1, 8, 8, 3), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
+    w = torch.zeros((64, 3, 3, 3), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d_same(x, w, None)
