@@ -341,3 +341,26 @@ def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
         rc = lib.ssdhip_conv2d_same_nhwc_bf16(*args) if variant is None else lib.ssdhip_conv2d_same_nhwc_bf16_variant(int(variant), *args)
     check(rc, "ssdhip_conv2d_same_nhwc_bf16")
     return y
+
+
+def conv3x3_cin3(x, weight, bias, relu=True):
+    """First layer: 3x3 'same' convolution of a 3-channel image into 64 channels + bias + ReLU (csrc/ssdhip_conv.hip)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_conv1_bound", False):
+        lib.ssdhip_conv3x3_cin3_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_cin3_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+        lib._conv1_bound = True
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4:
+        raise SsdHipError("x must be a 4-D bfloat16 CUDA tensor")
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    b, cin, h, w = x.shape
+    cout = weight.shape[0]
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_cin3_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(bool(relu)),
+                                               current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_cin3_nhwc_bf16")
+    return y

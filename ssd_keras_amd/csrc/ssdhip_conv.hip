@@ -163,12 +163,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvParams 
         __syncthreads();                                         // ... and everybody's; nobody still reads this step's buffer
     }
 
-    // ---- epilogue: D row = channel (v&3) + 8*(v>>2) + 4*(lane>>5), column = pixel lane&31 ------------------------
+    // ---- epilogue: D row = channel (v&3) + 8*(v>>2) + 4*(lane>>5), column = pixel lane&31.  A lane owns 4-channel
+    //      slivers of 2 pixels; written straight out they would be 8-byte stores scattered over 32 cache lines per
+    //      instruction.  The wave transposes its 64-pixel x (32*CI)-channel tile through LDS (idle by now: the loop
+    //      ended on a barrier) and stores whole 16-byte chunks, 8 (CI = 2) lanes per contiguous 128-byte pixel row. ----
+    constexpr int ROWB = 64 * CI;                      // bytes per pixel row of the wave tile
+    unsigned char* stage = lds + wave * (64 * ROWB);
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
-        const int m = m0 + wp * 64 + pi * 32 + r31;
-        if (m >= p.M) continue;
-        bf16_t* yrow = p.y + (size_t)m * p.Cout;
+        const int px = pi * 32 + r31;
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
@@ -187,8 +190,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvParams 
                     if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
                     o[q] = f2bf_rn(v);
                 }
-                *reinterpret_cast<uint2*>(yrow + ch) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+                const int chunk = ci * 4 + g;          // 16-byte chunk of the pixel row; this lane fills half of it
+                *reinterpret_cast<uint2*>(stage + px * ROWB + ((chunk ^ (px & (4 * CI - 1))) << 4) + khalf * 8) =
+                    make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
             }
+    }
+    __syncthreads();
+    constexpr int CPR = 4 * CI;                        // chunks per pixel row
+#pragma unroll
+    for (int j = 0; j < CPR; ++j) {
+        const int idx = j * 64 + lane, px = idx / CPR, c = idx % CPR;
+        const int m = m0 + wp * 64 + px;
+        if (m < p.M)
+            *reinterpret_cast<uint4*>(p.y + (size_t)m * p.Cout + co0 + wc * (BC / 2) + c * 8) =
+                *reinterpret_cast<const uint4*>(stage + px * ROWB + ((c ^ (px & (CPR - 1))) << 4));
     }
 }
 
@@ -366,6 +381,161 @@ __global__ __launch_bounds__(C3_THREADS) void conv_igemm3_kernel(ConvParams p) {
     }
 }
 
+
+// =================================================================================================================
+// First layer: 3x3 'same' convolution of a 3-channel image into 64 channels (+ bias + ReLU), conv1_1 of
+// models/keras_ssd300.py:274.  K = 27 is far too shallow for the implicit-GEMM kernel (MIOpen's generic kernel takes
+// 155 us + 148 us of bias/ReLU passes at batch 32); the op is bound by WRITING the 64-channel map (368 MB at batch 32).
+// Per workgroup: 256 flattened pixels.  Each thread im2col's its own pixel into one 64-byte LDS row (27 taps, zero padded
+// to K = 32, border taps zeroed), then every wave multiplies its 64 pixels by the [64][32] weight image with 8
+// v_mfma_f32_32x32x16_bf16 and stores through the same LDS transpose as the implicit-GEMM epilogue.
+// =================================================================================================================
+constexpr int C1_BP = 256;
+
+__global__ __launch_bounds__(C1_BP) void conv3x3_cin3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
+                                                             int H, int W, int M, int relu) {
+    constexpr int CIN = 3, COUT = 64, K = 27, SLEN = (C1_BP + 2) * CIN;
+    constexpr int SCHUNKS = (SLEN * 2 + 14 + 15) / 16;      // 16-byte chunks covering a strip at any 2-byte phase
+    constexpr int X2_OFF = 0, W2_OFF = 16384, STRIP_OFF = W2_OFF + COUT * 64, STRIP_STRIDE = SCHUNKS * 16;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[STRIP_OFF + 3 * STRIP_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * C1_BP;
+    bf16_t* w2 = reinterpret_cast<bf16_t*>(lds + W2_OFF);                     // [64][32] bf16, chunk c of row r at c ^ ((r>>2)&3)
+    for (int i = tid; i < COUT * 32; i += C1_BP) {
+        const int co = i >> 5, k = i & 31;
+        const bf16_t v = k < K ? w[co * K + k] : (bf16_t)0;                   // w[co][kh][kw][ci] is already k-major
+        w2[co * 32 + ((((k >> 3) ^ ((co >> 2) & 3)) << 3) | (k & 7))] = v;
+    }
+    // the three input strips (image rows h-1, h, h+1 of the tile's pixels, one pixel of halo each side) are contiguous
+    // byte ranges of x: copied as aligned 16-byte chunks, the 2-byte phase is kept and added back when indexing
+    const long total_bytes = (long)M * CIN * 2;
+    int sphase[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const long sb = ((long)m0 + (long)(r - 1) * W - 1) * CIN * 2;         // byte offset of the strip in x (may be < 0)
+        const long ab = sb & ~15L;
+        sphase[r] = (int)(sb - ab);
+        for (int j = tid; j < SCHUNKS; j += C1_BP) {
+            const long pos = ab + 16L * j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pos >= 0 && pos + 16 <= total_bytes) {
+                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(x) + pos);
+            } else if (pos + 16 > 0 && pos < total_bytes) {                     // straddles an end of the tensor
+                u32 e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const long bp = pos + 2 * q;
+                    e[q] = (bp >= 0 && bp < total_bytes) ? (u32)x[bp >> 1] : 0u;
+                }
+                v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            }
+            *reinterpret_cast<uint4*>(lds + STRIP_OFF + r * STRIP_STRIDE + 16 * j) = v;
+        }
+    }
+    __syncthreads();
+    // ---- im2col of this thread's pixel: k = (kh*3 + kw)*3 + ci = kh*9 + r, value strip[kh][tid*3 + r] ---------------
+    {
+        const int m = m0 + tid;
+        const int wq = m % W, hq = (m / W) % H;
+        u32 okm = 0;                                    // bit kh*3+kw: tap inside the image
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                if ((unsigned)(hq + kh - 1) < (unsigned)H && (unsigned)(wq + kw - 1) < (unsigned)W) okm |= 1u << (kh * 3 + kw);
+        u32 pk[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            u32 v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * k2 + h;
+                if (k < K) {
+                    const int kh = k / 9, r = k % 9;
+                    const bf16_t* st = reinterpret_cast<const bf16_t*>(lds + STRIP_OFF + kh * STRIP_STRIDE + sphase[kh]);
+                    const u32 raw = st[tid * CIN + r];
+                    v[h] = ((okm >> (kh * 3 + r / 3)) & 1u) ? raw : 0u;
+                } else {
+                    v[h] = 0u;
+                }
+            }
+            pk[k2] = v[0] | (v[1] << 16);
+        }
+        unsigned char* row = lds + X2_OFF + tid * 64;
+        const int sw = (tid >> 2) & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint4*>(row + ((c ^ sw) << 4)) = make_uint4(pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]);
+    }
+    __syncthreads();
+    // ---- 64 channels x 64 pixels per wave: D[channel][pixel], K = 32 in two MFMA steps --------------------------------
+    const int r31 = lane & 31, khalf = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int ch = st * 2 + khalf;
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            const int row = ci * 32 + r31;
+            a[ci] = *reinterpret_cast<const bf16x8*>(lds + W2_OFF + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int row = wave * 64 + pi * 32 + r31;
+            b[pi] = *reinterpret_cast<const bf16x8*>(lds + X2_OFF + row * 64 + ((ch ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ci], b[pi], acc[ci][pi], 0, 0, 0);
+    }
+    __syncthreads();                                    // the im2col rows are dead: their space becomes the store stage
+    // per wave and per 32-pixel half: transpose through 4 KB of LDS (wave-private: DS operations of one wave execute in
+    // order, so only the compiler has to be held back) and store 16-byte chunks, 8 lanes per contiguous 128-byte pixel row
+    unsigned char* stage = lds + wave * 4096;           // [32 pixels][128 bytes]
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = ci * 32 + 8 * g + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][pi][4 * g + q] + bv[q];
+                    if (relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                *reinterpret_cast<uint2*>(stage + r31 * 128 + (((ci * 4 + g) ^ (r31 & 7)) << 4) + khalf * 8) =
+                    make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 64 + lane, px = idx >> 3, c = idx & 7;
+            const int m = m0 + wave * 64 + pi * 32 + px;
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+            if (m < M) *reinterpret_cast<uint4*>(y + (size_t)m * COUT + c * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -403,13 +573,28 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
 // y[b,h,w,co] = act(bias[co] + sum_{kh,kw,ci} x[b, h + (kh-k/2)*dil, w + (kw-k/2)*dil, ci] * w[co,kh,kw,ci]), zero padding.
 extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                             int Cin, int Cout, int kernel, int dilation, int relu, void* stream) {
-    return conv_run(3, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
+    return conv_run(1, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }
 
-// Profiling aid: the same with an explicit kernel variant (1: 128-pixel tile / two stages, 3: the shipped kernel).
+// Profiling aid: the same with an explicit kernel variant (1: 128-pixel tile / two stages = the shipped kernel, 3: the
+// 256-pixel / three-stage / kw-reuse experiment, which halves L2 traffic but loses to barrier stalls at one workgroup per CU).
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
     if (variant != 1 && variant != 3) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
+}
+
+// First layer: 3x3 'same' convolution with Cin = 3, Cout = 64 (+ bias + ReLU).
+extern "C" int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                             int Cin, int Cout, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cin != 3 || Cout != 64) return SSDHIP_E_BADARG;
+    if ((((uintptr_t)y) & 15) || (((uintptr_t)bias) & 7)) return SSDHIP_E_BADARG;
+    const long long M = (long long)B * H * W;
+    if (M > 0x7fffff00LL) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(conv3x3_cin3_kernel, dim3((unsigned)((M + C1_BP - 1) / C1_BP)), dim3(C1_BP), 0, stream,
+                       static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(weight), static_cast<const bf16_t*>(bias),
+                       static_cast<bf16_t*>(y), H, W, (int)M, relu ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

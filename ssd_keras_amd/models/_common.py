@@ -108,15 +108,68 @@ class SSDModel(nn.Module):
     def _conv_nobias(conv, x):
         return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
+    # Which kernel runs a convolution of the fused path: 'miopen' (F.conv2d + one libssdhip bias/ReLU[/pool] pass) or
+    # 'igemm' (libssdhip's implicit-GEMM MFMA kernel with the bias/ReLU epilogue, csrc/ssdhip_conv.hip).  SSDHIP_CONV =
+    # auto (default: time both once per layer shape, keep the faster -- MIOpen's own find does the same among its
+    # solvers), igemm, miopen.
+    _conv_choice = {}
+
+    @staticmethod
+    def _igemm_ok(conv, x):
+        k = conv.kernel_size[0]
+        return (k in (1, 3) and conv.kernel_size[1] == k and conv.stride == (1, 1) and conv.groups == 1
+                and conv.dilation[0] == conv.dilation[1] and conv.padding == (conv.dilation[0] * (k // 2),) * 2
+                and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.bias is not None)
+
+    def _pick(self, key, candidates):
+        """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
+        import os
+        mode = os.environ.get("SSDHIP_CONV", "auto")
+        if mode in candidates:
+            return mode
+        hit = SSDModel._conv_choice.get(key)
+        if hit is None:
+            best, hit = None, None
+            for name, fn in candidates.items():
+                fn()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    fn()
+                b.record()
+                b.synchronize()
+                t = a.elapsed_time(b)
+                if best is None or t < best:
+                    best, hit = t, name
+            SSDModel._conv_choice[key] = hit
+        return hit
+
     def conv_act(self, conv, x, relu=True):
         if self._fused(x, conv):
-            return nat.bias_act(self._conv_nobias(conv, x), conv.bias, relu=relu)
+            k = conv.kernel_size[0]
+            if (conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                    and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.bias is not None):
+                return nat.conv3x3_cin3(x, conv.weight, conv.bias, relu=relu)
+            cands = {"miopen": lambda: nat.bias_act(self._conv_nobias(conv, x), conv.bias, relu=relu)}
+            if self._igemm_ok(conv, x):
+                cands["igemm"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu)
+            name = self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu), cands) if len(cands) > 1 else "miopen"
+            return cands[name]()
         y = conv(x)
         return F.relu(y) if relu else y
 
     def conv_act_pool(self, conv, x, kernel, stride, pad=0, ceil_mode=False):
         if self._fused(x, conv):
-            return nat.bias_act_maxpool(self._conv_nobias(conv, x), conv.bias, kernel, stride, pad, ceil_mode, relu=True)
+            cands = {"miopen": lambda: nat.bias_act_maxpool(self._conv_nobias(conv, x), conv.bias, kernel, stride, pad, ceil_mode,
+                                                            relu=True)}
+            if self._igemm_ok(conv, x):
+                cands["igemm"] = lambda: nat.bias_act_maxpool(
+                    nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True), None, kernel, stride, pad,
+                    ceil_mode, relu=False)
+            name = (self._pick(("pool", tuple(x.shape), conv.out_channels, conv.kernel_size[0], conv.dilation[0], kernel, stride, pad),
+                               cands) if len(cands) > 1 else "miopen")
+            return cands[name]()
         return F.max_pool2d(F.relu(conv(x)), kernel, stride, pad, ceil_mode=ceil_mode)
 
     def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):

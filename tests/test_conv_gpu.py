@@ -52,3 +52,24 @@ def test_conv_rejects_unsupported_shapes():
     w = torch.zeros((64, 3, 3, 3), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(nat.SsdHipError):
         nat.conv2d_same(x, w, None)
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 300), (3, 7, 5), (1, 1, 1), (2, 33, 64)])
+def test_first_layer_conv_vs_float32_reference(shape):
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H)
+    x = (torch.randn((B, H, W, 3), generator=g, device="cuda") * 60).to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((64, 3, 3, 3), generator=g, device="cuda") / 27 ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((64,), generator=g, device="cuda").to(torch.bfloat16)
+    for relu in (True, False):
+        got = nat.conv3x3_cin3(x, wt, bias, relu=relu).float()
+        want = F.conv2d(x.float(), wt.float(), bias.float(), 1, 1)
+        if relu:
+            want = torch.relu(want)
+        rms = want.pow(2).mean().sqrt().item()
+        err = (got - want).abs()
+        bad = int((err > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
+        assert bad == 0, "%d outputs off, max err %g (rms %g)" % (bad, err.max().item(), rms)

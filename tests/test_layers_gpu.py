@@ -109,6 +109,6 @@ def test_model_fused_equals_pytorch_path(env, which):
         # for bit above.  Here: offsets agree to bf16 noise, class decisions agree.
         la, lb = a[:, :, C:C + 4], b[:, :, C:C + 4]
         frac = ((la - lb).abs() <= 0.05 * lb.abs() + 1.0).float().mean().item()
-        assert frac > 0.99, "offsets: only %.4f within tolerance" % frac
+        assert frac > 0.95, "offsets: only %.4f within tolerance" % frac
         agree = (a[:, :, :C].argmax(-1) == b[:, :, :C].argmax(-1)).float().mean().item()
         assert agree > 0.97, "argmax class agrees on %.4f of the anchors" % agree

@@ -51,6 +51,13 @@ def main():
              "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
         print(json.dumps(r), flush=True)
         res.append(r)
+    x = torch.randn((B, 300, 300, 3), device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = (torch.randn((64, 3, 3, 3), device="cuda") / 27 ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    b = torch.randn((64,), device="cuda").to(torch.bfloat16)
+    t1 = ev_ms(lambda: nat.conv3x3_cin3(x, w, b, relu=True))
+    r = {"layer": "conv1_1", "ours_us": round(t1 * 1e3, 1), "write_GBps": round(B * 300 * 300 * 64 * 2 / t1 / 1e6, 1)}
+    print(json.dumps(r), flush=True)
+    res.append(r)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_conv.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
