@@ -150,11 +150,14 @@ def main():
         fwd_ms = event_ms(lambda: model.raw_predictions(images), 10)
     dom = max(("scan_kernel", "nms_kernel<double>", "topk_kernel<float>"), key=lambda k: stage_ms[k])
     achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "decode_pmc_traffic.json")
-    if os.path.exists(prof):
+    traffic = None                                   # HBM bytes per launch of the dominant kernel from the committed PMC passes
+    import glob
+    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*decode_pmc_traffic.json")))
+    if profs:
         try:
-            traffic = json.load(open(prof)).get(dom)
+            rec = json.load(open(profs[-1])).get(dom)
+            traffic = {"hbm_bytes_per_launch": round(rec["hbm_bytes"]), "read": round(rec["hbm_read_bytes"]),
+                       "write": round(rec["hbm_write_bytes"]), "source": "profiles/" + os.path.basename(profs[-1])}
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
