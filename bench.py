@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=1, help="1: decode on a second stream beside the next forward; 0: one stream")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images for the CPU baseline (0: auto, ~10-30 s)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (encoder / loss / sparse decode / training step)")
+    ap.add_argument("--train-steps", type=int, default=6, help="timed steps of the training-step leg (0: skip it)")
     return ap.parse_args()
 
 
@@ -193,6 +195,23 @@ def main():
                "speedup_decode": round((cpu_s / n_img) / (stage_ms["decode_path"] * 1e-3 / B), 1),
                "host_cpus": os.cpu_count()}
 
+    # ---- secondary legs (bench_extra.py): encoder / loss / sparse decode vs the CPU port on rank 0 at N=1; the
+    #      data-parallel training step (configs[2], configs[3]) on every rank.  None of them touches `value`. ------------
+    extra = {}
+    if not args.no_extra:
+        import bench_extra as bx
+        del model, out
+        torch.cuda.empty_cache()
+        with_cpu = world == 1 and not args.no_cpu_baseline
+        if rank == 0:
+            extra["encoder"] = bx.encoder_leg(dev, B, with_cpu)
+            extra["loss"] = bx.loss_leg(dev, B, with_cpu)
+            extra["decode_sparse"] = bx.sparse_decode_leg(dev, B, with_cpu)
+        if args.train_steps > 0:
+            tr = bx.train_leg(dev, rank, world, B, steps=args.train_steps, warmup=3)
+            if rank == 0:
+                extra["train_step"] = tr
+
     if rank == 0:
         ips = world * B * args.steps / elapsed
         line = {"metric": "images/sec SSD300 fwd+decode @batch32", "value": round(ips, 2), "unit": "images/sec",
@@ -206,6 +225,7 @@ def main():
                            "conv_dtype": args.dtype, "decode_dtype": "f32 decode, f64 IoU", "parallelism": "replicas x%d" % world,
                            "decode_stream": "second HIP stream, overlapped with the next forward" if args.overlap else "same stream"},
                 "roofline": roofline, "conv_roofline": conv, "cpu_baseline": cpu}
+        line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,0 +1,234 @@
+"""Secondary measurements printed on bench.py's JSON line beside the headline (BASELINE.json `metric`, second half:
+"encoder+NMS ms/img vs CPU ref"; configs[2] training-step kernels; configs[3] data-parallel training step).
+
+Every function returns a JSON-able dict and never raises (an exception becomes {"error": ...}) so the headline
+number cannot be lost to a secondary leg.  The CPU legs call `oracle/np_oracle.py` (the checker) as the reference's
+CPU path -- measured beside the product, never used by it.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _events_ms(fn, reps, stream=None):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def _guard(fn):
+    def run(*a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:                       # noqa: BLE001 -- a secondary leg must not sink the headline
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    return run
+
+
+def _encoder_pair(cfg, **over):
+    from oracle import np_oracle as orc
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder
+    kw = dict(cfg)
+    kw.update(over)
+    return SSDInputEncoder(**kw), orc.EncoderOracle(**kw)
+
+
+@_guard
+def encoder_leg(dev, B, with_cpu=True):
+    """SSDInputEncoder.__call__ on B images (BASELINE configs[2]: SSD300, 21 classes, multi matching, pos 0.5 / neg 0.5,
+    1-8 ground truth boxes per image, seed 7): HIP kernels (E1 iou, E2 bipartite, E3 finalize) vs the NumPy port."""
+    from ssd_keras_amd import synthetic as syn
+    cfg = syn.SSD300_VOC
+    enc, ora = _encoder_pair(cfg, matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5)
+    gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=7)
+    with torch.cuda.device(dev):
+        enc.encode_to_device(gt, device=dev)                                  # warm-up (uploads the anchors once)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            y32, _, _ = enc.encode_to_device(gt, device=dev)
+        torch.cuda.synchronize()
+        wall_ms = 1e3 * (time.perf_counter() - t) / reps                      # host CSR packing + H2D of the labels + kernels
+        ev_ms = _events_ms(lambda: enc.encode_to_device(gt, device=dev), reps)
+    N, L = y32.shape[1], y32.shape[2]
+    algo = B * N * L * 4 + sum(g.shape[0] for g in gt) * 5 * 8                # f32 targets written + labels read
+    out = {"workload": "SSD300/VOC targets, batch %d, 1-8 GT boxes/img, multi matching, f32 output" % B,
+           "gpu_ms_per_batch_wall": round(wall_ms, 4), "gpu_ms_per_batch_stream": round(ev_ms, 4),
+           "gpu_ms_per_img": round(wall_ms / B, 5),
+           "roofline": {"kernel": "finalize_kernel (E3) + iou_kernel (E1)", "bound": "hbm",
+                        "algorithmic_bytes": algo, "achieved": round(algo / (ev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(algo / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    if with_cpu:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ora(gt[:2])
+            t = time.perf_counter()
+            ora(gt)
+            cpu_ms = 1e3 * (time.perf_counter() - t)
+        out["cpu"] = {"ms_per_img": round(cpu_ms / B, 4), "cores": 1, "kind": "port",
+                      "sample": "oracle EncoderOracle.__call__ (NumPy port of ssd_input_encoder.py:277-418) on the same %d label "
+                                "arrays, one pass" % B,
+                      "speedup": round(cpu_ms / wall_ms, 1)}
+    return out
+
+
+@_guard
+def loss_leg(dev, B, with_cpu=True):
+    """SSDLoss.compute_loss forward + backward (BASELINE configs[2]): y_true = the encoder's targets, y_pred = the
+    trained-model-like sparse prediction tensor."""
+    from oracle import np_oracle as orc
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
+    cfg = syn.SSD300_VOC
+    enc, ora = _encoder_pair(cfg, matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5)
+    gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=7)
+    with torch.cuda.device(dev):
+        y_true, _, _ = enc.encode_to_device(gt, device=dev)
+        av = ora.generate_encoding_template(1)[0, :, -8:]
+        y_host = syn.make_y_pred(av, B, enc.n_classes, bias=7.0, seed=1234)
+        y_pred = torch.from_numpy(y_host).to(dev).requires_grad_(True)
+        lf = SSDLoss(neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+        loss = lf.compute_loss(y_true, y_pred)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            fwd_ms = _events_ms(lambda: lf.compute_loss(y_true, y_pred.detach()), 30)
+
+        def fb():
+            y_pred.grad = None
+            lf.compute_loss(y_true, y_pred).sum().backward()
+        both_ms = _events_ms(fb, 30)
+    N, L = y_pred.shape[1], y_pred.shape[2]
+    fwd_bytes, bwd_bytes = 2 * B * N * L * 4, 3 * B * N * L * 4
+    out = {"workload": "SSDLoss(3, 0, 1.0) on (%d, %d, %d) f32" % (B, N, L),
+           "fwd_ms": round(fwd_ms, 4), "fwd_bwd_ms": round(both_ms, 4),
+           "roofline_fwd": {"bound": "hbm", "algorithmic_bytes": fwd_bytes, "achieved": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+           "roofline_fwd_bwd": {"bound": "hbm", "algorithmic_bytes": fwd_bytes + bwd_bytes,
+                                "achieved": round((fwd_bytes + bwd_bytes) / (both_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round((fwd_bytes + bwd_bytes) / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                "note": "includes the autograd glue (sum, grad buffers) around the two kernels"}}
+    if with_cpu:
+        yt = y_true.cpu().numpy()
+        t = time.perf_counter()
+        orc.ssd_loss(yt, y_host)
+        orc.ssd_loss_grad(yt, y_host, np.ones((B,), dtype=np.float32))
+        cpu_ms = 1e3 * (time.perf_counter() - t)
+        out["cpu"] = {"fwd_bwd_ms": round(cpu_ms, 2), "cores": 1, "kind": "port",
+                      "sample": "oracle ssd_loss + ssd_loss_grad (NumPy restatement of keras_ssd_loss.py:98-211; TensorFlow absent) "
+                                "on the same tensors, one pass", "speedup": round(cpu_ms / both_ms, 1)}
+    return out
+
+
+@_guard
+def sparse_decode_leg(dev, B, with_cpu=True):
+    """decode_detections on the trained-model-like SPARSE tensor (background logit +7, ~6.5k candidates/img at 0.01;
+    SURVEY 8d config 2) -- the regime a trained detector is in; the headline step decodes random-init (dense) output."""
+    from oracle import np_oracle as orc
+    from ssd_keras_amd import _native as nat
+    from ssd_keras_amd import synthetic as syn
+    cfg = syn.SSD300_VOC
+    _, ora = _encoder_pair(cfg)
+    av = ora.generate_encoding_template(1)[0, :, -8:]
+    y_host = syn.make_y_pred(av, B, ora.n_classes, bias=7.0, seed=1234)
+    with torch.cuda.device(dev):
+        y = torch.from_numpy(y_host).to(dev)
+        N, C = y.shape[1], y.shape[2] - 12
+        dkw = dict(conf_thresh=0.01, iou_thresh=0.45, top_k=200, nms_cap=0, class_agnostic=False, semantics=nat.SEM_NUMPY,
+                   coords="centroids", normalize_coords=True, img_height=300, img_width=300, border_pixels="half",
+                   out_dtype=nat.F64, out_rows=200)
+        outs = nat.decode(y, **dkw)
+        torch.cuda.synchronize()
+        stage = {}
+        for name, mask in (("scan_kernel", 1), ("nms_kernel<double>", 2), ("topk_kernel<double>", 4), ("decode_path", 7)):
+            nat.decode(y, stages=mask, outputs=outs, **dkw)
+            torch.cuda.synchronize()
+            stage[name] = _events_ms(lambda m=mask: nat.decode(y, stages=m, outputs=outs, **dkw), 50)
+    algo = B * (N * (C + 12) * 4 + 200 * 6 * 8)
+    out = {"workload": "decode_detections (NumPy semantics, f64 rows) on the sparse SSD300 tensor, batch %d, conf 0.01 / "
+                       "NMS 0.45 / top-200" % B,
+           "kernel_ms": {k: round(v, 5) for k, v in stage.items()}, "gpu_ms_per_img": round(stage["decode_path"] / B, 5),
+           "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": round(algo / (stage["decode_path"] * 1e-3) / 1e9, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (stage["decode_path"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "scan_kernel_GBps": round(B * N * (C + 12) * 4 / (stage["scan_kernel"] * 1e-3) / 1e9, 1)}}
+    if with_cpu:
+        kw = dict(confidence_thresh=0.01, iou_threshold=0.45, top_k=200, normalize_coords=True, img_height=300, img_width=300)
+        t = time.perf_counter()
+        orc.decode_detections(y_host[:2], **kw)
+        per = (time.perf_counter() - t) / 2
+        n_img = int(max(2, min(B, round(10.0 / max(per, 1e-3)))))
+        t = time.perf_counter()
+        orc.decode_detections(y_host[:n_img], **kw)
+        cpu_ms = 1e3 * (time.perf_counter() - t) / n_img
+        out["cpu"] = {"ms_per_img": round(cpu_ms, 3), "cores": 1, "kind": "port",
+                      "sample": "oracle decode_detections on the first %d of %d images" % (n_img, B),
+                      "speedup": round(cpu_ms / (stage["decode_path"] / B), 1)}
+    return out
+
+
+@_guard
+def train_leg(dev, rank, world, B, steps=6, warmup=3):
+    """BASELINE configs[2]/[3]: one SSD300 training step per rank = SSDInputEncoder (HIP) -> forward (bf16 autocast,
+    fp32 master weights) -> SSDLoss (HIP, local hard-negative mining) -> backward -> RCCL gradient all-reduce (DDP,
+    25 MB buckets overlapped with backward) -> SGD(momentum 0.9).  Weak scaling: B images per rank."""
+    from ssd_keras_amd import distributed as dp
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(4321)                                                   # same initial weights on every rank
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", l2_regularization=0.0005, scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"]).to(dev)
+    model = model.to(memory_format=torch.channels_last).train()
+    n_params = sum(p.numel() for p in model.parameters())
+    ddp = dp.data_parallel(model, dev)
+    # Keras adds l2(5e-4) * sum(W^2) over the conv kernels to the loss (keras_ssd300.py:274): gradient 2 * l2 * W == SGD weight
+    # decay 1e-3 on the kernels only
+    decay = [p for p in model.parameters() if p.dim() > 1]
+    plain = [p for p in model.parameters() if p.dim() <= 1]
+    opt = torch.optim.SGD([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-4, momentum=0.9)
+    enc = SSDInputEncoder(matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5, **cfg)
+    gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=7 + rank)
+    images = torch.from_numpy(np.random.RandomState(100 + rank).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
+    lf = SSDLoss(neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+    last = {}
+
+    def step():
+        y_true, _, _ = enc.encode_to_device(gt, device=dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y_pred = ddp(images)
+        loss = lf.compute_loss(y_true, y_pred.float()).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        last["loss"] = loss.detach()
+
+    with torch.cuda.device(dev):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = dp.max_over_ranks(time.perf_counter() - t, device=dev)
+    return {"workload": "SSD300 VGG-16 training step, 21 classes, batch %d per GPU (global %d), bf16 autocast + fp32 master "
+                        "weights, SGD momentum 0.9; HIP encoder + HIP SSDLoss; %s" % (
+                            B, B * world, "DDP/RCCL gradient all-reduce (25 MB buckets)" if world > 1 else "single GPU, no collective"),
+            "images_per_sec": round(world * B * steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "steps": steps, "warmup": warmup, "n_gpus": world, "scaling": "weak", "parameters": n_params,
+            "allreduce_bytes_per_step": 4 * n_params if world > 1 else 0, "final_loss": float(last["loss"].item())}

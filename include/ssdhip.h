@@ -147,6 +147,49 @@ int ssdhip_loss_backward(const float* y_true, const float* y_pred, const unsigne
                          float* grad_y_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Public box utilities (stand-alone; the encoder / decoder above fuse the same arithmetic into their kernels).
+ * dtypes are SSDHIP_F32 / SSDHIP_F64 and follow NumPy's rules, because those decide where the reference rounds.
+ */
+/* conversion codes of convert_coordinates (bounding_box_utils/bounding_box_utils.py:24-87) */
+enum {
+    SSDHIP_MINMAX2CENTROIDS = 0, SSDHIP_CENTROIDS2MINMAX = 1, SSDHIP_CORNERS2CENTROIDS = 2, SSDHIP_CENTROIDS2CORNERS = 3,
+    SSDHIP_SWAP_MINMAX_CORNERS = 4    /* 'minmax2corners' and 'corners2minmax' are the same permutation */
+};
+/* convert_coordinates(tensor, start_index, conversion, border_pixels) (:24-87; convert_coordinates2 :89-117 is the same
+ * arithmetic for a float64 input): `in` is the tensor flattened to [n_rows, row_len] of in_dtype; `out` is its float64 copy
+ * with columns start_index..start_index+3 converted.  Right-hand sides are evaluated in in_dtype (as NumPy does), then widened. */
+int ssdhip_convert_coordinates(const void* in, int in_dtype, double* out, long long n_rows, int row_len,
+                               int start_index, int conversion, int border_pixels, void* stream);
+/* iou() :283-383 (op 0) and intersection_area() / intersection_area_() :119-280 (op 1).
+ *   boxes1 [m,4] of dtype1, boxes2 [n,4] of dtype2, both in `coords` format
+ *   mode 0 'outer_product' -> out [m,n];  mode 1 'element-wise' -> out [max(m,n)], m == n or one of them 1 (broadcast)
+ *   out dtype = ssdhip_iou_result_dtype(dtype1, dtype2, coords): F32 only for two F32 inputs in 'corners'/'minmax'
+ *   (the 'centroids' conversion yields float64), else F64.
+ * op 0 keeps the reference's quirk (:345): the intersection ignores border_pixels, the two areas do not. */
+int ssdhip_iou_result_dtype(int dtype1, int dtype2, int coords);
+int ssdhip_box_overlap(int op, const void* boxes1, int dtype1, int m, const void* boxes2, int dtype2, int n,
+                       int coords, int mode, int border_pixels, void* out, void* stream);
+/* match_bipartite_greedy(weight_matrix) (ssd_encoder_decoder/matching_utils.py:22-79): weight_matrix [m,n] float64 (not
+ * modified), matches [m] int32 = the column matched to each row.  m <= 4096.  Ties -> lowest row, then lowest column;
+ * removed rows/columns count as zeros exactly like the reference's in-place zeroing. */
+int ssdhip_match_bipartite_greedy(const double* weight_matrix, int m, int n, int* matches, void* stream);
+/* match_multi(weight_matrix, threshold) (:81-116): per column the first arg-max row, kept where the value >= threshold.
+ * gt_idx / anchor_idx [n] int32 receive the `*count` kept (row, column) pairs in ascending column order. */
+size_t ssdhip_match_multi_workspace_bytes(int m, int n);
+int ssdhip_match_multi(const double* weight_matrix, int m, int n, double threshold, int* gt_idx, int* anchor_idx,
+                       int* count, void* ws, size_t ws_bytes, void* stream);
+/* greedy_nms / _greedy_nms / _greedy_nms2 / _greedy_nms_debug (ssd_encoder_decoder/ssd_output_decoder.py:27-109, 469-486)
+ * on a float64 table rows [n_rows_total, row_len]: segments (batch items) given by seg_offsets [n_segments+1]; the score
+ * is column score_col, the box columns box_col..box_col+3 in `coords` format.  Per segment: repeatedly keep the first
+ * maximum-score row and drop every row whose IoU with it is not <= iou_threshold.
+ * kept_idx [n_rows_total]: for segment s, kept_idx[seg_offsets[s] + k] = row (within the segment) of the k-th kept box,
+ * k < kept_count[s] (selection order = score descending). */
+size_t ssdhip_greedy_nms_workspace_bytes(int n_rows_total);
+int ssdhip_greedy_nms(const double* rows, int n_rows_total, int row_len, int score_col, int box_col,
+                      const int* seg_offsets, int n_segments, double iou_threshold, int coords, int border_pixels,
+                      int* kept_idx, int* kept_count, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Graph glue between the convolutions (bf16 activations, NHWC = torch channels_last; C % 8 == 0; pointers
  * 16-byte aligned).  Each call is ONE pass over the tensor where the framework path runs 2-7 elementwise kernels.
  *

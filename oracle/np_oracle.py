@@ -152,6 +152,45 @@ def iou(boxes1, boxes2, coords="centroids", mode="outer_product", border_pixels=
         return inter / (area_p + area_q - inter)
 
 
+def convert_coordinates2(tensor, start_index, conversion):
+    """bounding_box_utils.py:89-117: float64 copy times a constant 4x4 matrix with entries 0, +-0.5, +-1.  Each output is
+    a two-term sum of exact products (plus exact zeros), i.e. one rounding -- the same value `convert_coordinates` gives
+    for a float64 input with border_pixels='half'."""
+    if conversion not in ("minmax2centroids", "centroids2minmax"):
+        raise ValueError("Unexpected conversion value.")
+    return convert_coordinates(np.array(tensor, dtype=np.float64), start_index, conversion, "half")
+
+
+def intersection_area(boxes1, boxes2, coords="centroids", mode="outer_product", border_pixels="half"):
+    """bounding_box_utils.py:119-224 (the public function: side lengths DO see border_pixels)."""
+    boxes1, boxes2 = np.asarray(boxes1), np.asarray(boxes2)
+    if boxes1.ndim > 2 or boxes2.ndim > 2:
+        raise ValueError("boxes must have rank 1 or 2")
+    if boxes1.ndim == 1:
+        boxes1 = boxes1[None]
+    if boxes2.ndim == 1:
+        boxes2 = boxes2[None]
+    if not (boxes1.shape[1] == boxes2.shape[1] == 4):
+        raise ValueError("All boxes must consist of 4 coordinates")
+    if mode not in ("outer_product", "element-wise"):
+        raise ValueError("`mode` must be one of 'outer_product' and 'element-wise'")
+    if coords == "centroids":
+        boxes1 = convert_coordinates(boxes1, 0, "centroids2corners")
+        boxes2 = convert_coordinates(boxes2, 0, "centroids2corners")
+        coords = "corners"
+    elif coords not in ("minmax", "corners"):
+        raise ValueError("Unexpected value for `coords`.")
+    x0, y0, x1, y1 = _corner_cols(coords)
+    d = _BORDER[border_pixels]
+    if mode == "outer_product":
+        p, q = boxes1[:, None, :], boxes2[None, :, :]
+    else:
+        p, q = boxes1, boxes2
+    iw = np.maximum(0, np.minimum(p[..., x1], q[..., x1]) - np.maximum(p[..., x0], q[..., x0]) + d)
+    ih = np.maximum(0, np.minimum(p[..., y1], q[..., y1]) - np.maximum(p[..., y0], q[..., y0]) + d)
+    return iw * ih
+
+
 # --------------------------------------------------------------------------------------
 # matching_utils
 # --------------------------------------------------------------------------------------
@@ -365,7 +404,7 @@ class DegenerateBoxError(Exception):
 # --------------------------------------------------------------------------------------
 # decoder
 # --------------------------------------------------------------------------------------
-def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels):
+def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels, coords="corners"):
     """The loop shared by greedy_nms / _greedy_nms / _greedy_nms2 / _greedy_nms_debug
     (ssd_output_decoder.py:27-109, 469-486): repeatedly take the first maximum of the
     remaining scores, drop it from the pool, drop everything whose IoU with it is
@@ -382,16 +421,25 @@ def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels):
         alive = alive[alive != j]
         if not alive.size:
             break
-        sim = iou(boxes[alive], boxes[j], coords="corners", mode="element-wise", border_pixels=border_pixels)
+        sim = iou(boxes[alive], boxes[j], coords=coords, mode="element-wise", border_pixels=border_pixels)
         alive = alive[sim <= iou_threshold]
     return rows[kept]
 
 
 def greedy_nms(y_pred_decoded, iou_threshold=0.45, coords="corners", border_pixels="half"):
     """ssd_output_decoder.py:27-75 (rows `[class_id, score, 4 coords]`)."""
-    if coords != "corners":
-        raise NotImplementedError("oracle restates the 'corners' call pattern only")
-    return [_greedy_nms_rows(np.copy(item), 1, 2, iou_threshold, border_pixels) for item in y_pred_decoded]
+    res = [_greedy_nms_rows(np.copy(item), 1, 2, iou_threshold, border_pixels, coords) for item in y_pred_decoded]
+    return [r if r.shape[0] else np.array([]) for r in res]          # `np.array(maxima)` of an empty list
+
+
+def greedy_nms_single(predictions, iou_threshold=0.45, coords="corners", border_pixels="half"):
+    """`_greedy_nms` (:77-92): rows `[score, 4 coords]`."""
+    return _greedy_nms_rows(np.copy(predictions), 0, 1, iou_threshold, border_pixels, coords)
+
+
+def greedy_nms_single2(predictions, iou_threshold=0.45, coords="corners", border_pixels="half"):
+    """`_greedy_nms2` (:94-109) / `_greedy_nms_debug` (:469-486): rows `[id, score, 4 coords]`."""
+    return _greedy_nms_rows(np.copy(predictions), 1, 2, iou_threshold, border_pixels, coords)
 
 
 def _decode_boxes(y_pred, n_lead, input_coords, normalize_coords, img_height, img_width, exp_mode, order="numpy"):

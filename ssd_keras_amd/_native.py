@@ -364,3 +364,147 @@ def conv3x3_cin3(x, weight, bias, relu=True):
                                                current_stream_ptr(x.device))
     check(rc, "ssdhip_conv3x3_cin3_nhwc_bf16")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# public box utilities (csrc/ssdhip_boxes.hip)
+# ------------------------------------------------------------------------------------------------
+CONVERSIONS = {"minmax2centroids": 0, "centroids2minmax": 1, "corners2centroids": 2, "centroids2corners": 3,
+               "minmax2corners": 4, "corners2minmax": 4}
+
+
+def _bind_boxes(lib):
+    if getattr(lib, "_boxes_bound", False):
+        return
+    c_int, c_vp, c_ll, c_dbl, c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_double, ctypes.c_size_t
+    lib.ssdhip_convert_coordinates.restype = c_int
+    lib.ssdhip_convert_coordinates.argtypes = [c_vp, c_int, c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp]
+    lib.ssdhip_iou_result_dtype.restype = c_int
+    lib.ssdhip_iou_result_dtype.argtypes = [c_int, c_int, c_int]
+    lib.ssdhip_box_overlap.restype = c_int
+    lib.ssdhip_box_overlap.argtypes = [c_int, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
+    lib.ssdhip_match_bipartite_greedy.restype = c_int
+    lib.ssdhip_match_bipartite_greedy.argtypes = [c_vp, c_int, c_int, c_vp, c_vp]
+    lib.ssdhip_match_multi_workspace_bytes.restype = c_sz
+    lib.ssdhip_match_multi_workspace_bytes.argtypes = [c_int, c_int]
+    lib.ssdhip_match_multi.restype = c_int
+    lib.ssdhip_match_multi.argtypes = [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]
+    lib.ssdhip_greedy_nms_workspace_bytes.restype = c_sz
+    lib.ssdhip_greedy_nms_workspace_bytes.argtypes = [c_int]
+    lib.ssdhip_greedy_nms.restype = c_int
+    lib.ssdhip_greedy_nms.argtypes = [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_dbl, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]
+    lib._boxes_bound = True
+
+
+def _boxes_lib():
+    lib = load()
+    _bind_boxes(lib)
+    return lib
+
+
+def _float_device(a, name):
+    """NumPy array / torch tensor -> contiguous CUDA tensor of float32 or float64 (other dtypes -> float64, which is
+    what NumPy's arithmetic would promote integer boxes to in every formula of the box utilities)."""
+    torch = _torch()
+    if isinstance(a, np.ndarray):
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        return to_device(a)
+    if not torch.is_tensor(a):
+        return to_device(np.asarray(a, dtype=np.float64))
+    if a.dtype not in (torch.float32, torch.float64):
+        a = a.to(torch.float64)
+    return to_device(a)
+
+
+def _dt(t):
+    torch = _torch()
+    return F32 if t.dtype == torch.float32 else F64
+
+
+def convert_coordinates(t, start_index, conversion, border_pixels):
+    """t: CUDA float32/float64 tensor, last axis holds the 4 coordinates from start_index.  Returns a float64 tensor."""
+    torch = _torch()
+    lib = _boxes_lib()
+    require_cuda(t, "tensor")
+    L = int(t.shape[-1])
+    rows = t.numel() // L if L else 0
+    out = torch.empty(t.shape, dtype=torch.float64, device=t.device)
+    if t.numel() == 0:
+        return out
+    with torch.cuda.device(t.device):
+        rc = lib.ssdhip_convert_coordinates(_ptr(t), _dt(t), _ptr(out), rows, L, int(start_index), CONVERSIONS[conversion],
+                                            BORDER[border_pixels], current_stream_ptr(t.device))
+    check(rc, "ssdhip_convert_coordinates")
+    return out
+
+
+def box_overlap(op, b1, b2, coords, mode, border_pixels):
+    """op 0 iou / 1 intersection_area; b1 (m,4), b2 (n,4) CUDA tensors; mode 'outer_product' | 'element-wise'."""
+    torch = _torch()
+    lib = _boxes_lib()
+    require_cuda(b1, "boxes1")
+    require_cuda(b2, "boxes2")
+    m, n = int(b1.shape[0]), int(b2.shape[0])
+    rdt = torch.float32 if lib.ssdhip_iou_result_dtype(_dt(b1), _dt(b2), COORDS[coords]) == F32 else torch.float64
+    outer = mode == "outer_product"
+    out = torch.empty((m, n) if outer else (max(m, n) if min(m, n) > 0 else 0,), dtype=rdt, device=b1.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(b1.device):
+        rc = lib.ssdhip_box_overlap(int(op), _ptr(b1), _dt(b1), m, _ptr(b2), _dt(b2), n, COORDS[coords], 0 if outer else 1,
+                                    BORDER[border_pixels], _ptr(out), current_stream_ptr(b1.device))
+    check(rc, "ssdhip_box_overlap")
+    return out
+
+
+def match_bipartite_greedy(w):
+    torch = _torch()
+    lib = _boxes_lib()
+    require_cuda(w, "weight_matrix")
+    m, n = int(w.shape[0]), int(w.shape[1])
+    out = torch.zeros((m,), dtype=torch.int32, device=w.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(w.device):
+        rc = lib.ssdhip_match_bipartite_greedy(_ptr(w), m, n, _ptr(out), current_stream_ptr(w.device))
+    check(rc, "ssdhip_match_bipartite_greedy")
+    return out
+
+
+def match_multi(w, threshold):
+    torch = _torch()
+    lib = _boxes_lib()
+    require_cuda(w, "weight_matrix")
+    m, n = int(w.shape[0]), int(w.shape[1])
+    gt = torch.empty((max(n, 1),), dtype=torch.int32, device=w.device)
+    col = torch.empty((max(n, 1),), dtype=torch.int32, device=w.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=w.device)
+    ws = workspaces.get(w.device, "match_multi", lib.ssdhip_match_multi_workspace_bytes(m, n))
+    with torch.cuda.device(w.device):
+        rc = lib.ssdhip_match_multi(_ptr(w), m, n, float(threshold), _ptr(gt), _ptr(col), _ptr(cnt), _ptr(ws), ws.numel(),
+                                    current_stream_ptr(w.device))
+    check(rc, "ssdhip_match_multi")
+    k = int(cnt.item())
+    return gt[:k], col[:k]
+
+
+def greedy_nms_rows(rows, seg_offsets, score_col, box_col, iou_threshold, coords, border_pixels):
+    """rows: CUDA float64 (n_total, L); seg_offsets: host int array (S+1,).  Returns (kept_idx (n_total,), kept_count (S,))
+    as CUDA int32 tensors (see include/ssdhip.h)."""
+    torch = _torch()
+    lib = _boxes_lib()
+    require_cuda(rows, "rows")
+    n_total, L = int(rows.shape[0]), int(rows.shape[1])
+    S = len(seg_offsets) - 1
+    dev = rows.device
+    off = torch.from_numpy(np.asarray(seg_offsets, dtype=np.int32)).to(dev)
+    kept = torch.empty((max(n_total, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((max(S, 1),), dtype=torch.int32, device=dev)
+    ws = workspaces.get(dev, "greedy_nms", lib.ssdhip_greedy_nms_workspace_bytes(n_total))
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_greedy_nms(_ptr(rows), n_total, L, int(score_col), int(box_col), _ptr(off), S, float(iou_threshold),
+                                   COORDS[coords], BORDER[border_pixels], _ptr(kept), _ptr(cnt), _ptr(ws), ws.numel(),
+                                   current_stream_ptr(dev))
+    check(rc, "ssdhip_greedy_nms")
+    return kept, cnt

@@ -58,6 +58,59 @@ def _to_list(out, count, aidx=None, empty_1d=True):
     return res
 
 
+def _nms_tables(tables, score_col, box_col, iou_threshold, coords, border_pixels):
+    """Greedy NMS of several row tables in one launch (`ssdhip_greedy_nms`, one workgroup per table).  Returns, per
+    table, the kept rows in selection order as float64 NumPy arrays (what `np.array(maxima)` is in the reference)."""
+    import torch
+    if coords not in nat.COORDS:
+        raise ValueError("Unexpected value for `coords`. Supported values are 'minmax', 'corners' and 'centroids'.")
+    tabs = []
+    for t in tables:
+        t = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+        tabs.append(np.ascontiguousarray(t, dtype=np.float64))
+    widths = {t.shape[1] for t in tabs if t.ndim == 2 and t.shape[0]}
+    if len(widths) > 1:
+        raise ValueError("all batch items must have the same number of columns")
+    if not widths:
+        return [np.array([]) for _ in tabs]                     # `np.array(maxima)` of an empty list
+    L = widths.pop()
+    if L < box_col + 4 or L <= score_col:
+        raise ValueError("rows need at least {} columns".format(max(box_col + 4, score_col + 1)))
+    nonempty = [t if (t.ndim == 2 and t.shape[0]) else np.zeros((0, L)) for t in tabs]
+    off = np.cumsum([0] + [t.shape[0] for t in nonempty]).astype(np.int32)
+    cat = np.concatenate(nonempty, axis=0)
+    rows_d = nat.to_device(cat)
+    kept, cnt = nat.greedy_nms_rows(rows_d, off, score_col, box_col, iou_threshold, coords, border_pixels)
+    kept, cnt = kept.cpu().numpy(), cnt.cpu().numpy()
+    res = []
+    for i, t in enumerate(nonempty):
+        k = int(cnt[i])
+        res.append(t[kept[off[i]:off[i] + k]] if k else np.array([]))
+    return res
+
+
+def greedy_nms(y_pred_decoded, iou_threshold=0.45, coords='corners', border_pixels='half'):
+    '''Reference: ssd_output_decoder.py:27-75.  `y_pred_decoded`: list of `(k, 6)` arrays `[class_id, score, 4 box
+    coordinates]`; per batch item, repeatedly keep the highest-scoring box and drop every box whose IoU with it is
+    `> iou_threshold`.  Returns the list of kept rows (score descending).'''
+    return _nms_tables(list(y_pred_decoded), 1, 2, iou_threshold, coords, border_pixels)
+
+
+def _greedy_nms(predictions, iou_threshold=0.45, coords='corners', border_pixels='half'):
+    '''Reference :77-92: rows `[score, 4 box coordinates]` of one class of one image.'''
+    return _nms_tables([predictions], 0, 1, iou_threshold, coords, border_pixels)[0]
+
+
+def _greedy_nms2(predictions, iou_threshold=0.45, coords='corners', border_pixels='half'):
+    '''Reference :94-109: rows `[class_id, score, 4 box coordinates]` of one image.'''
+    return _nms_tables([predictions], 1, 2, iou_threshold, coords, border_pixels)[0]
+
+
+def _greedy_nms_debug(predictions, iou_threshold=0.45, coords='corners', border_pixels='half'):
+    '''Reference :469-486: rows `[box_id, score, 4 box coordinates]`.'''
+    return _nms_tables([predictions], 1, 2, iou_threshold, coords, border_pixels)[0]
+
+
 def decode_detections(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=200, input_coords='centroids',
                       normalize_coords=True, img_height=None, img_width=None, border_pixels='half'):
     '''Reference: ssd_output_decoder.py:111-226.  Per image and per non-background class: strict `>`

@@ -26,11 +26,12 @@ np.float = float   # noqa: aliases removed in NumPy >= 1.24, used by the referen
 np.int = int       # noqa
 np.bool = bool     # noqa
 
-from bounding_box_utils.bounding_box_utils import convert_coordinates, iou            # noqa: E402
+from bounding_box_utils.bounding_box_utils import (convert_coordinates, convert_coordinates2, intersection_area,  # noqa: E402
+                                                    iou)
 from ssd_encoder_decoder.matching_utils import match_bipartite_greedy, match_multi     # noqa: E402
 from ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder                      # noqa: E402
 from ssd_encoder_decoder.ssd_output_decoder import (decode_detections, decode_detections_debug,  # noqa: E402
-                                                    decode_detections_fast, greedy_nms)
+                                                    decode_detections_fast, greedy_nms, _greedy_nms, _greedy_nms2)
 
 from ssd_keras_amd import synthetic as syn                                             # noqa: E402
 
@@ -96,6 +97,83 @@ def gen_box_utils():
         g, a_ = match_multi(m, 0.5)
         out["match_multi_gt_%d" % i], out["match_multi_anchor_%d" % i] = g, a_
     save("box_utils", **out)
+
+
+def gen_box_utils2():
+    """Second box-utilities fixture: the public callables the first one does not cover (intersection_area, float32 /
+    mixed-dtype iou, nD convert_coordinates, convert_coordinates2, the greedy_nms family in every coords format,
+    larger / tie-heavy / signed matching problems)."""
+    rng = np.random.RandomState(23)
+    out = {}
+
+    def boxes(n, lo=0.0, hi=60.0):
+        a = rng.uniform(lo, hi, size=(n, 2))
+        return np.concatenate([a, a + rng.uniform(1, 35, size=(n, 2))], axis=1)        # corners
+
+    c1, c2 = boxes(13), boxes(17)
+    out["corners1"], out["corners2"] = c1, c2
+    views = {"corners": (c1, c2), "minmax": (c1[:, [0, 2, 1, 3]], c2[:, [0, 2, 1, 3]]),
+             "centroids": (convert_coordinates(c1, 0, "corners2centroids"), convert_coordinates(c2, 0, "corners2centroids"))}
+    for coords, (p, q) in views.items():
+        for bp in ("half", "include", "exclude"):
+            out["ia_outer_%s_%s" % (coords, bp)] = intersection_area(p, q, coords, "outer_product", bp)
+            out["ia_elem_%s_%s" % (coords, bp)] = intersection_area(p, q[:13], coords, "element-wise", bp)
+            # dtype rules: float32 x float32, float32 x float64
+            p32, q32 = p.astype(np.float32), q.astype(np.float32)
+            r = iou(p32, q32, coords, "outer_product", bp)
+            out["iou32_outer_%s_%s" % (coords, bp)] = r
+            out["iou32_outer_%s_%s_dtype" % (coords, bp)] = np.array(r.dtype.name)
+            r = iou(p32, q, coords, "outer_product", bp)
+            out["iou3264_outer_%s_%s" % (coords, bp)] = r
+            r = iou(p, q32[:13], coords, "element-wise", bp)
+            out["iou6432_elem_%s_%s" % (coords, bp)] = r
+            r = intersection_area(p32, q32, coords, "outer_product", bp)
+            out["ia32_outer_%s_%s" % (coords, bp)] = r
+    # nD tensor, coordinates in the middle of the last axis
+    t = rng.uniform(0, 40, size=(2, 5, 9))
+    out["nd_in"] = t
+    for conv in ("minmax2centroids", "centroids2minmax", "corners2centroids", "centroids2corners", "minmax2corners",
+                 "corners2minmax"):
+        out["nd_%s" % conv] = convert_coordinates(t, 3, conv, "include")
+        out["nd32_%s" % conv] = convert_coordinates(t.astype(np.float32), 3, conv, "exclude")
+    for conv in ("minmax2centroids", "centroids2minmax"):
+        out["cc2_%s" % conv] = convert_coordinates2(t, 3, conv)
+        out["cc2_32_%s" % conv] = convert_coordinates2(t.astype(np.float32), 3, conv)
+    # greedy NMS family
+    def table(n, lead, coords):
+        b = boxes(n, 0, 40)
+        if coords == "minmax":
+            b = b[:, [0, 2, 1, 3]]
+        elif coords == "centroids":
+            b = convert_coordinates(b, 0, "corners2centroids")
+        score = np.round(rng.uniform(0, 1, size=(n, 1)), 2)            # two decimals: plenty of ties
+        cols = [rng.randint(1, 4, size=(n, 1)).astype(np.float64)] * (lead - 1) + [score, b]
+        return np.concatenate(cols, axis=1)
+    for coords in ("corners", "minmax", "centroids"):
+        for bp in ("half", "include", "exclude"):
+            items = [table(60, 2, coords), np.zeros((0, 6)), table(1, 2, coords), table(150, 2, coords)]
+            cat, off = ragged(items, 6)
+            res = greedy_nms(items, iou_threshold=0.45, coords=coords, border_pixels=bp)
+            rcat, roff = ragged(res, 6)
+            pre = "nms_%s_%s_" % (coords, bp)
+            out[pre + "in"], out[pre + "in_off"], out[pre + "out"], out[pre + "out_off"] = cat, off, rcat, roff
+    t5 = table(90, 1, "corners")
+    out["nms1_in"], out["nms1_out"] = t5, _greedy_nms(t5, iou_threshold=0.3, coords="corners", border_pixels="half")
+    t6 = table(90, 2, "corners")
+    out["nms2_in"], out["nms2_out"] = t6, _greedy_nms2(t6, iou_threshold=0.6, coords="corners", border_pixels="include")
+    # matching: larger, tie-heavy (quantised), sparse, and signed matrices
+    mats = [np.round(rng.uniform(0, 1, size=(12, 300)), 1),
+            rng.uniform(0, 1, size=(20, 700)) * (rng.uniform(0, 1, size=(20, 700)) > 0.97),
+            rng.uniform(-1, 1, size=(6, 30)),
+            -rng.uniform(0, 1, size=(4, 9)),
+            np.zeros((3, 5)),
+            rng.uniform(0, 1, size=(1, 1))]
+    for i, m in enumerate(mats):
+        out["match_in_%d" % i] = m
+        out["match_bip_%d" % i] = match_bipartite_greedy(m)
+        g, a_ = match_multi(m, 0.5)
+        out["match_multi_gt_%d" % i], out["match_multi_anchor_%d" % i] = g, a_
+    save("box_utils2", **out)
 
 
 def gen_anchors():
@@ -253,6 +331,7 @@ def gen_decoder():
 
 if __name__ == "__main__":
     gen_box_utils()
+    gen_box_utils2()
     gen_anchors()
     gen_encoder()
     gen_decoder()

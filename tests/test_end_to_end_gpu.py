@@ -1,0 +1,75 @@
+"""BASELINE.json configs[0]: SSD7 300x300, 5 classes, batch 4, random weights, end to end on the GPU --
+encode (HIP) -> forward (PyTorch-ROCm) -> SSDLoss (HIP) -> backward -> SGD -> decode (HIP) -- with every
+per-anchor stage checked against the oracle on the tensors the step actually produced.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+from ssd_keras_amd import synthetic as syn
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ssd7_encode_forward_loss_backward_decode():
+    import torch
+    from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
+    from ssd_keras_amd.models.keras_ssd7 import build_model
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_output_decoder import decode_detections
+    cfg = syn.SSD7_300
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model, psizes = build_model((300, 300, 3), cfg["n_classes"], mode="training", l2_regularization=0.0005, scales=cfg["scales"],
+                                aspect_ratios_global=cfg["aspect_ratios_global"], variances=cfg["variances"],
+                                normalize_coords=True, subtract_mean=127.5, divide_by_stddev=127.5, return_predictor_sizes=True)
+    assert [tuple(p) for p in psizes] == [tuple(p) for p in cfg["predictor_sizes"]]
+    model = model.to(dev).train()
+    enc = SSDInputEncoder(matching_type="multi", pos_iou_threshold=0.5, neg_iou_limit=0.3, **cfg)
+    ora = orc.EncoderOracle(matching_type="multi", pos_iou_threshold=0.5, neg_iou_limit=0.3, **cfg)
+    B = 4
+    gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=0)
+    images = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
+
+    # encode: HIP targets == oracle targets (class columns / anchors exactly, offsets to 1e-6 in f32)
+    y_true, _, _ = enc.encode_to_device(gt, device=dev)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want_true = ora(gt)
+    C = enc.n_classes
+    assert y_true.shape == (B, 7160, C + 12)
+    assert np.array_equal(y_true.cpu().numpy()[:, :, :C], want_true[:, :, :C].astype(np.float32))
+    np.testing.assert_allclose(y_true.cpu().numpy(), want_true.astype(np.float32), rtol=1e-6, atol=1e-7)
+
+    lf = SSDLoss(neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    losses = []
+    for it in range(8):
+        y_pred = model(images)
+        assert y_pred.shape == (B, 7160, C + 12)
+        per_item = lf.compute_loss(y_true, y_pred)
+        if it == 0:
+            # loss and gradient of the step == oracle on the same tensors (north_star tolerance 1e-4)
+            yp = y_pred.detach().cpu().numpy()
+            want = orc.ssd_loss(y_true.cpu().numpy(), yp)
+            np.testing.assert_allclose(per_item.detach().cpu().numpy(), want, rtol=1e-4)
+            g = torch.autograd.grad(per_item.sum(), y_pred, retain_graph=True)[0].cpu().numpy()
+            want_g = orc.ssd_loss_grad(y_true.cpu().numpy(), yp, np.ones((B,), dtype=np.float32))
+            np.testing.assert_allclose(g, want_g, rtol=1e-4, atol=1e-6)
+        loss = per_item.mean() + model.l2_regularization_loss()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses                                     # the step trains
+
+    # decode what the trained-for-8-steps model predicts: HIP == oracle on the same prediction tensor
+    model.eval()
+    with torch.no_grad():
+        y_pred = model(images)
+    yp = y_pred.cpu().numpy()
+    for thr in (0.01, 0.5):
+        kw = dict(confidence_thresh=thr, iou_threshold=0.45, top_k=200, normalize_coords=True, img_height=300, img_width=300)
+        got = decode_detections(y_pred, **kw)
+        want = orc.decode_detections(yp, exp_mode="det", **kw)
+        util.dets_equal(got, want, exact=True)

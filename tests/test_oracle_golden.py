@@ -196,3 +196,62 @@ def test_greedy_nms_public():
         want = util.unragged(z["gnms_out_" + bp], z["gnms_out_off_" + bp])
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
+
+
+def _views(c1, c2):
+    return {"corners": (c1, c2), "minmax": (c1[:, [0, 2, 1, 3]], c2[:, [0, 2, 1, 3]]),
+            "centroids": (orc.convert_coordinates(c1, 0, "corners2centroids"), orc.convert_coordinates(c2, 0, "corners2centroids"))}
+
+
+def test_box_utils2_overlap_and_dtypes():
+    z = util.load("box_utils2")
+    for coords, (p, q) in _views(z["corners1"], z["corners2"]).items():
+        p32, q32 = p.astype(np.float32), q.astype(np.float32)
+        for bp in ("half", "include", "exclude"):
+            tag = "%s_%s" % (coords, bp)
+            assert np.array_equal(orc.intersection_area(p, q, coords, "outer_product", bp), z["ia_outer_" + tag])
+            assert np.array_equal(orc.intersection_area(p, q[:13], coords, "element-wise", bp), z["ia_elem_" + tag])
+            r = orc.iou(p32, q32, coords, "outer_product", bp)
+            assert r.dtype.name == str(z["iou32_outer_%s_dtype" % tag]) and np.array_equal(r, z["iou32_outer_" + tag])
+            assert np.array_equal(orc.iou(p32, q, coords, "outer_product", bp), z["iou3264_outer_" + tag])
+            assert np.array_equal(orc.iou(p, q32[:13], coords, "element-wise", bp), z["iou6432_elem_" + tag])
+            r = orc.intersection_area(p32, q32, coords, "outer_product", bp)
+            assert r.dtype == z["ia32_outer_" + tag].dtype and np.array_equal(r, z["ia32_outer_" + tag])
+
+
+def test_box_utils2_convert_nd():
+    z = util.load("box_utils2")
+    t = z["nd_in"]
+    for conv in ("minmax2centroids", "centroids2minmax", "corners2centroids", "centroids2corners", "minmax2corners", "corners2minmax"):
+        assert np.array_equal(orc.convert_coordinates(t, 3, conv, "include"), z["nd_" + conv])
+        assert np.array_equal(orc.convert_coordinates(t.astype(np.float32), 3, conv, "exclude"), z["nd32_" + conv])
+    for conv in ("minmax2centroids", "centroids2minmax"):
+        assert np.array_equal(orc.convert_coordinates2(t, 3, conv), z["cc2_" + conv])
+        assert np.array_equal(orc.convert_coordinates2(t.astype(np.float32), 3, conv), z["cc2_32_" + conv])
+
+
+def test_box_utils2_greedy_nms_family():
+    z = util.load("box_utils2")
+    for coords in ("corners", "minmax", "centroids"):
+        for bp in ("half", "include", "exclude"):
+            pre = "nms_%s_%s_" % (coords, bp)
+            items = util.unragged(z[pre + "in"], z[pre + "in_off"])
+            want = util.unragged(z[pre + "out"], z[pre + "out_off"])
+            got = orc.greedy_nms(items, 0.45, coords, bp)
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert np.array_equal(g.reshape(-1, 6), w.reshape(-1, 6))
+    assert np.array_equal(orc.greedy_nms_single(z["nms1_in"], 0.3, "corners", "half"), z["nms1_out"])
+    assert np.array_equal(orc.greedy_nms_single2(z["nms2_in"], 0.6, "corners", "include"), z["nms2_out"])
+
+
+def test_box_utils2_matching():
+    z = util.load("box_utils2")
+    i = 0
+    while "match_in_%d" % i in z:
+        m = z["match_in_%d" % i]
+        assert np.array_equal(orc.match_bipartite_greedy(m), z["match_bip_%d" % i]), i
+        g, a = orc.match_multi(m, 0.5)
+        assert np.array_equal(g, z["match_multi_gt_%d" % i]) and np.array_equal(a, z["match_multi_anchor_%d" % i])
+        i += 1
+    assert i == 6

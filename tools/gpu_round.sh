@@ -13,7 +13,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/benc
 tail -c 3000 $OUT/bench.json
 # kernel trace of the same command (MIOpen's find results are cached by the run above)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -o bench -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/trace_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trace_err.log )
+    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $GRAFT_REPO_ROOT/$OUT/trace_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trace_err.log )
 # PMC passes (own runs, --kernel-trace only)
 if [ "${3:-}" = "skip_pmc" ]; then exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE; do
