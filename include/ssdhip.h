@@ -225,8 +225,9 @@ int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, co
  *   y [B,H,W,Cout] bf16.  Cin % 64 == 0, Cout % 64 == 0; float32 accumulation, one rounding to bf16 after bias + activation. */
 int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                  int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
-/* Profiling aid: the same with an explicit kernel variant (1: 128-pixel tile, two-stage pipeline = the shipped kernel;
- * 3: 256-pixel tile, three-stage weight pipeline, kw-reuse of the activation strip -- an experiment kept for A/B timing). */
+/* Profiling aid: the same with an explicit kernel variant (4: the shipped kernel -- 128-pixel tile, two LDS stages, buffer-addressed
+ * LDS-DMA loads, batched fragment reads; 1: its predecessor with per-lane pointers; 3: 256-pixel tile, three-stage weight pipeline,
+ * kw-reuse of the activation strip -- kept for A/B timing). */
 int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                          int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 

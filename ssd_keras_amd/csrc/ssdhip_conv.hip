@@ -208,6 +208,195 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvParams 
 }
 
 
+
+// =================================================================================================================
+// v4: the v1 tile (BC channels x 128 pixels x 64 input channels per K-step, 4 waves as 2x2, two LDS buffers) with the
+// per-step instruction overhead taken out -- rocprofv3 PMC of v1 on conv4_2 showed each wave ISSUING for ~840 cycles per
+// K-step against 512 cycles of MFMA work (SQ_ACTIVE_INST_ANY), and the ISA showed why:
+//   * two scalar integer divisions per step to turn the step number into (tap, channel slice)  -> the (kh, kw, slice)
+//     counters are advanced incrementally;
+//   * per LDS-DMA load two 64-bit pointer adds, a mask test and a two-register pointer select against the zero block,
+//     and a v_readfirstlane for M0                                                               -> buffer addressing:
+//     the row's byte offset is ONE 32-bit VGPR, the step's (tap, slice) displacement rides in the scalar soffset (not
+//     range checked), a tap that falls outside the image becomes an out-of-range voffset (0x80000000 >= num_records:
+//     the buffer unit returns zeros into LDS), and the wave number is made scalar once so the LDS destination is SALU;
+//   * the compiler read one kk-slice of fragments, waited lgkmcnt(0), issued 4 MFMAs, four times per step (LDS latency
+//     exposed four times)                                 -> all 16 fragment reads of the step are issued back to back
+//     into four register sets and the MFMAs start as each set lands (counted lgkmcnt).
+// The descriptor base is x minus the largest negative tap displacement `neg`, so every soffset is non-negative, and
+// num_records = bytes(x) + 2 * neg because on gfx950 the range check covers voffset + soffset (measured: with
+// num_records = bytes(x) the last 2W+2 pixels of the batch lost their positive-displacement taps); valid lanes still
+// address only bytes inside x.  Needs x and w below 2 GiB each (checked on the host; v1 otherwise).
+// =================================================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// (the body is a __device__ function: the host pass never sees the buffer-resource type, which only exists for amdgcn)
+template <int BC>
+__device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned char* lds) {
+    constexpr int CI = BC / 64;
+    constexpr int XBYTES = CONV_BP * 128, WBYTES = BC * 128, BUF = XBYTES + WBYTES;
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
+    if (mt >= p.m_tiles) return;
+    const int m0 = mt * CONV_BP, co0 = nt * BC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wp = wave & 1;
+    const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
+    const int csteps = Cin / CONV_BK, T = KK * csteps;
+
+    const int neg = (half * dil * p.W + half * dil) * Cin * 2;            // bytes; largest negative tap displacement
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.M * Cin * 2 + 2 * neg, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.w)), 0, p.Cout * KK * Cin * 2, 0x00020000);
+
+    // ---- per-thread load descriptors: byte offsets of 4 X rows (+ tap validity) and CI*2 weight rows ---------------
+    u32 xoff[4], xok[4], woff[CI * 2];
+    const int pos = lane & 7;
+    {
+        int m = m0 + wave * 8 + (lane >> 3);
+        int wq = m % p.W, hq = (m / p.W) % p.H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            const int j = pos ^ ((row >> 1) & 7);
+            u32 rmask = 0, cmask = 0;
+            for (int k = 0; k < KS; ++k) {
+                const int d = (k - half) * dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (m < p.M)
+                for (int kh = 0; kh < KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+            xok[i] = ok;
+            xoff[i] = (u32)m * (u32)(Cin * 2) + (u32)(j * 16);
+            m += 32;
+            wq += 32;
+            while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CI * 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const int j = pos ^ ((row >> 1) & 7);
+        woff[i] = (u32)(co0 + row) * (u32)(KK * Cin * 2) + (u32)(j * 16);
+    }
+
+    int n_kh = 0, n_kw = 0, n_cs = 0;                  // the step the next issue() loads
+    auto issue = [&](int buf) {
+        const int t = n_kh * KS + n_kw;
+        const int soff_x = neg + (((n_kh - half) * dil * p.W + (n_kw - half) * dil) * Cin + n_cs * CONV_BK) * 2;
+        const int soff_w = (t * Cin + n_cs * CONV_BK) * 2;
+        const u32 tapbit = 1u << t;
+        unsigned char* xb = lds + buf * BUF + wave * 1024;
+        unsigned char* wb = xb + XBYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xb + i * 4096), 16, (xok[i] & tapbit) ? xoff[i] : OOB,
+                                                     soff_x, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CI * 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wb + i * 4096), 16, woff[i], soff_w, 0, 0);
+        if (++n_cs == csteps) { n_cs = 0; if (++n_kw == KS) { n_kw = 0; ++n_kh; } }
+    };
+
+    f32x16 acc[CI][2];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int swz = (r31 >> 1) & 7;
+    const int arow = (wc * (BC / 2) + r31) * 128, brow = (wp * 64 + r31) * 128;
+    int choff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) choff[kk] = ((2 * kk + khalf) ^ swz) << 4;
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const unsigned char* xb = lds + (s & 1) * BUF;
+        const unsigned char* wb = xb + XBYTES;
+        bf16x8 a[4][CI], b[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) a[kk][ci] = *reinterpret_cast<const bf16x8*>(wb + arow + ci * 4096 + choff[kk]);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) b[kk][pi] = *reinterpret_cast<const bf16x8*>(xb + brow + pi * 4096 + choff[kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);             // the step's 16 fragment reads go out first ...
+        if (s + 1 < T) issue((s + 1) & 1);             // ... their latency hides behind issuing the next step's LDS-DMA loads
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][ci], b[kk][pi], acc[ci][pi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);             // all MFMAs are queued before the wave parks on the loads / the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: identical to v1 (LDS transpose, 16-byte stores) --------------------------------------------------
+    constexpr int ROWB = 64 * CI;
+    unsigned char* stage = lds + wave * (64 * ROWB);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int px = pi * 32 + r31;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][pi][4 * g + q] + bv[q];
+                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                const int chunk = ci * 4 + g;
+                *reinterpret_cast<uint2*>(stage + px * ROWB + ((chunk ^ (px & (4 * CI - 1))) << 4) + khalf * 8) =
+                    make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = 4 * CI;
+#pragma unroll
+    for (int j = 0; j < CPR; ++j) {
+        const int idx = j * 64 + lane, px = idx / CPR, c = idx % CPR;
+        const int m = m0 + wp * 64 + px;
+        if (m < p.M)
+            *reinterpret_cast<uint4*>(p.y + (size_t)m * p.Cout + co0 + wc * (BC / 2) + c * 8) =
+                *reinterpret_cast<const uint4*>(stage + px * ROWB + ((c ^ (px & (CPR - 1))) << 4));
+    }
+}
+
+template <int BC>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
+    conv_igemm4_body<BC>(p, lds);
+}
+
 // =================================================================================================================
 // v3: 256-pixel tile, 8 waves, three-stage weight pipeline, kw-reuse of the activation strip.
 //   * tile = BC channels x 256 consecutive pixels; 8 waves as 2 (channels) x 4 (pixels), each 32*CI x 64.
@@ -556,7 +745,14 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
     p.M = (int)M;
     const bool wide = (Cout % 128) == 0;
     p.n_tiles = Cout / (wide ? 128 : 64);
-    if (variant == 1) {                       // 128-pixel tile, two-stage pipeline (kept for A/B timing)
+    const bool small = M * Cin * 2 + 4LL * (dilation * W + dilation) * Cin < 0x7ffff000LL && (long long)Cout * kernel * kernel * Cin * 2 < 0x7ffff000LL;
+    if (variant == 4 && !small) variant = 1;  // buffer addressing needs 31-bit byte offsets
+    if (variant == 4) {                       // v1's tile with buffer-addressed LDS-DMA and batched fragment reads
+        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL(conv_igemm4_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    } else if (variant == 1) {                // 128-pixel tile, two-stage pipeline (kept for A/B timing)
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
         if (wide) hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
@@ -573,15 +769,16 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
 // y[b,h,w,co] = act(bias[co] + sum_{kh,kw,ci} x[b, h + (kh-k/2)*dil, w + (kw-k/2)*dil, ci] * w[co,kh,kw,ci]), zero padding.
 extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                             int Cin, int Cout, int kernel, int dilation, int relu, void* stream) {
-    return conv_run(1, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
+    return conv_run(4, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }
 
-// Profiling aid: the same with an explicit kernel variant (1: 128-pixel tile / two stages = the shipped kernel, 3: the
+// Profiling aid: the same with an explicit kernel variant (4: the shipped kernel; 1: its predecessor with per-lane
+// pointers, per-step divisions and per-kk fragment waits -- 10-27 % slower on the VGG shapes; 3: the
 // 256-pixel / three-stage / kw-reuse experiment, which halves L2 traffic but loses to barrier stalls at one workgroup per CU).
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
-    if (variant != 1 && variant != 3) return SSDHIP_E_BADARG;
+    if (variant != 1 && variant != 3 && variant != 4) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }
 

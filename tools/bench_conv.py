@@ -41,12 +41,13 @@ def main():
         flop = 2.0 * B * hw * hw * cin * cout * k * k
         t_ours = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True))
         t_v1 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=1)) if os.environ.get("V1", "1") == "1" else float("nan")
+        t_v4 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=4))
         if os.environ.get("MIOPEN", "1") == "1":
             t_mi = ev_ms(lambda: F.conv2d(x, w, None, 1, dil * (k // 2), dil))
             t_mi_full = ev_ms(lambda: nat.bias_act(F.conv2d(x, w, None, 1, dil * (k // 2), dil), b, relu=True))
         else:
             t_mi = t_mi_full = float("nan")
-        r = {"layer": name, "ours_us": round(t_ours * 1e3, 1), "ours_TFs": round(flop / t_ours / 1e9, 1), "v1_us": round(t_v1 * 1e3, 1),
+        r = {"layer": name, "ours_us": round(t_ours * 1e3, 1), "ours_TFs": round(flop / t_ours / 1e9, 1), "v1_us": round(t_v1 * 1e3, 1), "v4_us": round(t_v4 * 1e3, 1), "v4_TFs": round(flop / t_v4 / 1e9, 1),
              "miopen_conv_us": round(t_mi * 1e3, 1), "miopen_TFs": round(flop / t_mi / 1e9, 1),
              "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
         print(json.dumps(r), flush=True)
