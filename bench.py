@@ -169,9 +169,18 @@ def main():
                 "decode_ms_in_step": round(decode_ms_in_step, 5),
                 "decode_path_GBps": round(algo_bytes / (stage_ms["decode_path"] * 1e-3) / 1e9, 2)}
     conv_tflops = B * SSD300_FWD_GFLOP_PER_IMG / 1e3 / (fwd_ms * 1e-3)
+    from ssd_keras_amd.models._common import SSDModel
+    choices = {}
+    for key, name in SSDModel._conv_choice.items():          # which kernel the per-shape autotune kept for each convolution
+        kind, shape = key[0], key[1] if kind != "head" else key[2]
+        label = "%s %s->%s k%s" % (kind, "x".join(str(v) for v in shape), key[2] if kind != "head" else "%s+%s" % (key[3], key[4]),
+                                   key[3] if kind != "head" else 3)
+        choices[label] = name
     conv = {"bound": "mfma", "forward_ms": round(fwd_ms, 4), "achieved": round(conv_tflops, 2),
             "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(conv_tflops / MFMA_PEAK_TFLOPS[args.dtype], 5),
-            "note": "PyTorch-ROCm (MIOpen) convolutions + libssdhip fused bias/ReLU/pool/L2Norm/head passes, %s" % args.dtype}
+            "note": "per layer the faster of libssdhip's implicit-GEMM MFMA kernel (fused bias/ReLU epilogue; packed conf+loc heads) "
+                    "and MIOpen + one libssdhip bias/ReLU[/pool] pass, %s; 62.747 GFLOP/img (SURVEY App. B)" % args.dtype,
+            "kernel_per_layer": choices}
 
     # ---- CPU baseline: NumPy port of the reference decoder on a bounded sample (rank 0, N=1) -----
     cpu = None

@@ -218,6 +218,15 @@ int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, co
                                      const void* const* conf_bias_h, const void* const* loc_bias_h,
                                      const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
                                      int B, int N, int C, float* y_pred, void* stream);
+/* The same when a layer's two heads were computed by ONE wider convolution (conf and loc filters concatenated along Cout,
+ * padded to the MFMA kernel's 64-channel granularity): conf_h[l] / loc_h[l] point at the first conf / loc channel of pixel 0 and
+ * conf_stride_h[l] / loc_stride_h[l] give the number of bf16 elements between consecutive pixels (>= n_boxes*C / n_boxes*4;
+ * NULL arrays = dense heads as above). */
+int ssdhip_assemble_predictions_strided_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                             const void* const* conf_bias_h, const void* const* loc_bias_h,
+                                             const int* n_anchors_h, const int* n_boxes_h,
+                                             const int* conf_stride_h, const int* loc_stride_h,
+                                             const float* anchors_var, int B, int N, int C, float* y_pred, void* stream);
 
 /* 'same' convolution (kernel 1 or 3, stride 1, any dilation, zero padding) + bias + ReLU as one implicit-GEMM MFMA kernel:
  * Conv2D(filters, (k,k), padding='same', activation='relu'[, dilation_rate]) of models/keras_ssd300.py:274-300.

@@ -186,6 +186,8 @@ def _bind_layers(lib):
     lib.ssdhip_preprocess_nhwc_f32_to_bf16.argtypes = [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.ssdhip_assemble_predictions_bf16.restype = c_int
     lib.ssdhip_assemble_predictions_bf16.argtypes = [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]
+    lib.ssdhip_assemble_predictions_strided_bf16.restype = c_int
+    lib.ssdhip_assemble_predictions_strided_bf16.argtypes = [c_int] + [c_vp] * 9 + [c_int, c_int, c_int, c_vp, c_vp]
     lib._layers_bound = True
 
 
@@ -286,22 +288,33 @@ def preprocess(images, mean=None, divide=None, swap=None):
 
 
 def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
-    """Per-layer NHWC conv outputs (B, n_boxes*C, h, w) / (B, n_boxes*4, h, w) bf16 -> y_pred (B, N, C+12) float32."""
+    """Per-layer NHWC conv outputs -> y_pred (B, N, C+12) float32 in one pass (softmax, biases, anchors, concatenation).
+    Layer i is given either as two dense head outputs confs[i] (B, n_boxes*C, h, w), locs[i] (B, n_boxes*4, h, w), or --
+    locs[i] is None -- as ONE wider output confs[i] (B, >= n_boxes*(C+4), h, w) whose channels are [conf | loc | padding]."""
     torch = _torch()
     lib = _layers_lib()
     nl = len(confs)
     keep = []
-    cp, lp, cbp, lbp, na = [], [], [], [], []
+    cp, lp, cbp, lbp, na, cs, ls = [], [], [], [], [], [], []
+    nhwc = lambda t: t if t.permute(0, 2, 3, 1).is_contiguous() else t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     for i in range(nl):
-        cf = confs[i] if confs[i].permute(0, 2, 3, 1).is_contiguous() else confs[i].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-        lc = locs[i] if locs[i].permute(0, 2, 3, 1).is_contiguous() else locs[i].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-        if cf.dtype != torch.bfloat16 or lc.dtype != torch.bfloat16 or not cf.is_cuda:
+        cf = nhwc(confs[i])
+        if cf.dtype != torch.bfloat16 or not cf.is_cuda:
             raise SsdHipError("assemble_predictions needs bfloat16 CUDA head outputs")
-        keep += [cf, lc]
         b, ch, h, w = cf.shape
-        if ch != n_boxes[i] * n_classes or lc.shape[1] != n_boxes[i] * 4:
-            raise SsdHipError("head %d has %d / %d channels, expected %d / %d" % (i, ch, lc.shape[1], n_boxes[i] * n_classes, n_boxes[i] * 4))
-        cp.append(cf.data_ptr()); lp.append(lc.data_ptr()); na.append(h * w * n_boxes[i])
+        nc, nloc = n_boxes[i] * n_classes, n_boxes[i] * 4
+        if locs[i] is None:                                  # packed heads
+            if ch < nc + nloc:
+                raise SsdHipError("packed head %d has %d channels, expected >= %d" % (i, ch, nc + nloc))
+            keep.append(cf)
+            cp.append(cf.data_ptr()); lp.append(cf.data_ptr() + 2 * nc); cs.append(ch); ls.append(ch)
+        else:
+            lc = nhwc(locs[i])
+            if lc.dtype != torch.bfloat16 or ch != nc or lc.shape[1] != nloc:
+                raise SsdHipError("head %d has %d / %d channels, expected %d / %d" % (i, ch, lc.shape[1], nc, nloc))
+            keep += [cf, lc]
+            cp.append(cf.data_ptr()); lp.append(lc.data_ptr()); cs.append(nc); ls.append(nloc)
+        na.append(h * w * n_boxes[i])
         cbp.append(conf_biases[i].data_ptr() if conf_biases[i] is not None else 0)
         lbp.append(loc_biases[i].data_ptr() if loc_biases[i] is not None else 0)
     B = confs[0].shape[0]
@@ -312,9 +325,10 @@ def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_
     arr = lambda v: (ctypes.c_void_p * nl)(*v)
     iarr = lambda v: (ctypes.c_int * nl)(*[int(t) for t in v])
     with torch.cuda.device(y.device):
-        rc = lib.ssdhip_assemble_predictions_bf16(nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes),
-                                                  _ptr(anchors_var), B, N, int(n_classes), _ptr(y), current_stream_ptr(y.device))
-    check(rc, "ssdhip_assemble_predictions_bf16")
+        rc = lib.ssdhip_assemble_predictions_strided_bf16(nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes),
+                                                          iarr(cs), iarr(ls), _ptr(anchors_var), B, N, int(n_classes), _ptr(y),
+                                                          current_stream_ptr(y.device))
+    check(rc, "ssdhip_assemble_predictions_strided_bf16")
     return y
 
 

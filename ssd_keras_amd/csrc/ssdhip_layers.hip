@@ -156,6 +156,8 @@ struct HeadParams {
     const bf16_t* loc_bias[MAX_PRED_LAYERS];      // [n_boxes*4] or null
     int n_anchors[MAX_PRED_LAYERS];
     int n_boxes[MAX_PRED_LAYERS];
+    int conf_stride[MAX_PRED_LAYERS];             // elements between consecutive pixels of the conf / loc source
+    int loc_stride[MAX_PRED_LAYERS];              // (n_boxes*C and n_boxes*4 when the heads are separate, dense tensors)
     int tile_start[MAX_PRED_LAYERS + 1];          // first tile of layer l
     int anchor_off[MAX_PRED_LAYERS];
     int n_layers, N, C, TA;
@@ -171,12 +173,24 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams hp, const float* _
     float* rows = reinterpret_cast<float*>(smem_raw);                                   // [TA][L]
     bf16_t* cl = reinterpret_cast<bf16_t*>(smem_raw + (size_t)TA * L * sizeof(float));  // [TA][C] logits, then [TA][4]
     bf16_t* ll = cl + (size_t)TA * C;
-    const bf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
-    const bf16_t* lsrc = hp.loc[l] + ((size_t)b * hp.n_anchors[l] + a0) * 4;
-    for (int i = tid; i < na * C; i += 256) cl[i] = csrc[i];
-    for (int i = tid; i < na * 4; i += 256) ll[i] = lsrc[i];
-    __syncthreads();
     const int nb = hp.n_boxes[l];
+    if (hp.conf_stride[l] == nb * C && hp.loc_stride[l] == nb * 4) {                    // dense heads: contiguous spans
+        const bf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
+        const bf16_t* lsrc = hp.loc[l] + ((size_t)b * hp.n_anchors[l] + a0) * 4;
+        for (int i = tid; i < na * C; i += 256) cl[i] = csrc[i];
+        for (int i = tid; i < na * 4; i += 256) ll[i] = lsrc[i];
+    } else {                                                                            // heads packed into one wider conv output
+        const size_t px0 = (size_t)b * (hp.n_anchors[l] / nb);
+        for (int i = tid; i < na * C; i += 256) {
+            const int ga = a0 + i / C, c = i % C;
+            cl[i] = hp.conf[l][(px0 + ga / nb) * hp.conf_stride[l] + (ga % nb) * C + c];
+        }
+        for (int i = tid; i < na * 4; i += 256) {
+            const int ga = a0 + (i >> 2), k = i & 3;
+            ll[i] = hp.loc[l][(px0 + ga / nb) * hp.loc_stride[l] + (ga % nb) * 4 + k];
+        }
+    }
+    __syncthreads();
     for (int a = tid; a < na; a += 256) {
         const int box = (a0 + a) % nb;
         float* r = rows + (size_t)a * L;
@@ -264,10 +278,12 @@ extern "C" int ssdhip_preprocess_nhwc_f32_to_bf16(const float* images, void* out
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
-extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
-                                                const void* const* conf_bias_h, const void* const* loc_bias_h,
-                                                const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
-                                                int B, int N, int C, float* y_pred, void* stream_) {
+extern "C" int ssdhip_assemble_predictions_strided_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                                        const void* const* conf_bias_h, const void* const* loc_bias_h,
+                                                        const int* n_anchors_h, const int* n_boxes_h,
+                                                        const int* conf_stride_h, const int* loc_stride_h,
+                                                        const float* anchors_var, int B, int N, int C, float* y_pred,
+                                                        void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !conf_h || !loc_h || !n_anchors_h || !n_boxes_h || !anchors_var || !y_pred ||
         B <= 0 || N <= 0 || C < 2 || C > 1024)
@@ -286,10 +302,13 @@ extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const*
         hp.loc_bias[l] = (on && loc_bias_h) ? static_cast<const bf16_t*>(loc_bias_h[l]) : nullptr;
         hp.n_anchors[l] = on ? n_anchors_h[l] : 0;
         hp.n_boxes[l] = on ? n_boxes_h[l] : 1;
+        hp.conf_stride[l] = on ? (conf_stride_h ? conf_stride_h[l] : n_boxes_h[l] * C) : 0;
+        hp.loc_stride[l] = on ? (loc_stride_h ? loc_stride_h[l] : n_boxes_h[l] * 4) : 0;
         hp.tile_start[l] = tiles;
         hp.anchor_off[l] = off;
         if (on) {
             if (!hp.conf[l] || !hp.loc[l] || hp.n_anchors[l] <= 0 || hp.n_boxes[l] <= 0 || hp.n_anchors[l] % hp.n_boxes[l]) return SSDHIP_E_BADARG;
+            if (hp.conf_stride[l] < hp.n_boxes[l] * C || hp.loc_stride[l] < hp.n_boxes[l] * 4) return SSDHIP_E_BADARG;
             off += hp.n_anchors[l];
             tiles += (hp.n_anchors[l] + TA - 1) / TA;
         }
@@ -299,4 +318,12 @@ extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const*
     const size_t lds = (size_t)TA * (L * sizeof(float) + (C + 4) * sizeof(bf16_t));
     hipLaunchKernelGGL(head_kernel, dim3(tiles, B), dim3(256), lds, stream, hp, anchors_var, y_pred);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                                const void* const* conf_bias_h, const void* const* loc_bias_h,
+                                                const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
+                                                int B, int N, int C, float* y_pred, void* stream) {
+    return ssdhip_assemble_predictions_strided_bf16(n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h,
+                                                    nullptr, nullptr, anchors_var, B, N, C, y_pred, stream);
 }

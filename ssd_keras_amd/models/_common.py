@@ -97,6 +97,7 @@ class SSDModel(nn.Module):
                                  normalize_coords=normalize_coords, img_height=self.img_height,
                                  img_width=self.img_width, name='decoded_predictions')
         self._anchor_cache = {}
+        self._packed_heads = {}
 
     # -- fused inference path: every conv is followed by ONE libssdhip pass (bias + ReLU [+ max-pool]) instead of the
     #    2-3 elementwise kernels PyTorch launches; bit-identical results (see csrc/ssdhip_layers.hip) ----------------
@@ -218,9 +219,18 @@ class SSDModel(nn.Module):
         b = x.shape[0]
         sizes = [(f.shape[2], f.shape[3]) for f in feats]
         if all(self._fused_head_ok(f, ch) for f, ch in zip(feats, self.conf_heads)):
-            # heads without bias; bias, Reshape, softmax, anchors and the concatenations are one libssdhip pass (:363-419)
-            confs = [self._conv_nobias(ch, f) for f, ch in zip(feats, self.conf_heads)]
-            locs = [self._conv_nobias(lh, f) for f, lh in zip(feats, self.loc_heads)]
+            # heads without bias; bias, Reshape, softmax, anchors and the concatenations are one libssdhip pass (:363-419).
+            # Per layer the two heads run either as two MIOpen convolutions or PACKED into one libssdhip implicit-GEMM launch
+            # (conf and loc filters concatenated along Cout, zero-padded to 64 channels): timed once per shape, faster kept.
+            confs, locs = [], []
+            for l, (f, ch, lh) in enumerate(zip(feats, self.conf_heads, self.loc_heads)):
+                cands = {"miopen": lambda f=f, ch=ch, lh=lh: (self._conv_nobias(ch, f), self._conv_nobias(lh, f))}
+                if self._packed_head_ok(ch, lh, f):
+                    cands["igemm"] = lambda f=f, l=l: (nat.conv2d_same(f, self._packed_head_weight(l), None, dilation=1, relu=False), None)
+                name = self._pick(("head", l, tuple(f.shape), ch.out_channels, lh.out_channels), cands) if len(cands) > 1 else "miopen"
+                c, lo = cands[name]()
+                confs.append(c)
+                locs.append(lo)
             anchors = self.anchors_and_variances(sizes, x.device)
             return nat.assemble_predictions(confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
                                             [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
@@ -233,6 +243,27 @@ class SSDModel(nn.Module):
         loc = torch.cat(locs, dim=1).float()
         anchors = self.anchors_and_variances(sizes, conf.device)
         return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+
+    @staticmethod
+    def _packed_head_ok(ch, lh, f):
+        same = lambda c: (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1)
+        return same(ch) and same(lh) and ch.in_channels % 64 == 0 and ch.in_channels == lh.in_channels
+
+    def _packed_head_weight(self, l):
+        """[conf filters | loc filters | zero rows up to a multiple of 64] of predictor layer l as one (Cout, Cin, 3, 3) bf16
+        weight in channels_last memory; rebuilt when either head's weight tensor changes (in-place updates bump `_version`)."""
+        ch, lh = self.conf_heads[l], self.loc_heads[l]
+        key = (ch.weight._version, lh.weight._version, ch.weight.data_ptr(), lh.weight.data_ptr())
+        hit = self._packed_heads.get(l)
+        if hit is None or hit[0] != key:
+            n = ch.out_channels + lh.out_channels
+            pad = (-n) % 64
+            with torch.no_grad():
+                w = torch.cat([ch.weight, lh.weight] + ([ch.weight.new_zeros((pad,) + tuple(ch.weight.shape[1:]))] if pad else []), dim=0)
+                w = w.contiguous(memory_format=torch.channels_last)
+            hit = (key, w)
+            self._packed_heads[l] = hit
+        return hit[1]
 
     def _fused_head_ok(self, f, conv):
         return (self.fused_inference and f.is_cuda and f.dtype == torch.bfloat16 and not torch.is_grad_enabled()

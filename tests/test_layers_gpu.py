@@ -71,11 +71,17 @@ def test_preprocess(env):
     assert torch.equal(nat.preprocess(img, [127.5] * 3, [127.5] * 3, None), want2)
 
 
-@pytest.mark.parametrize("which", ["ssd300", "ssd7"])
-def test_model_fused_equals_pytorch_path(env, which):
+@pytest.mark.parametrize("which", ["ssd300", "ssd7", "ssd300-igemm"])
+def test_model_fused_equals_pytorch_path(env, which, monkeypatch):
     torch, F, nat = env
     from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models._common import SSDModel
     torch.manual_seed(5)
+    # which kernel runs each convolution of the fused path: the bit-exact SSD7 comparison needs MIOpen on both sides; the
+    # "-igemm" case forces libssdhip's implicit-GEMM kernel everywhere it applies (trunk layers and the packed heads)
+    monkeypatch.setenv("SSDHIP_CONV", {"ssd7": "miopen", "ssd300-igemm": "igemm"}.get(which, "auto"))
+    monkeypatch.setattr(SSDModel, "_conv_choice", {})
+    which = which.split("-")[0]
     if which == "ssd300":
         from ssd_keras_amd.models.keras_ssd300 import ssd_300
         cfg = syn.SSD300_VOC
@@ -112,3 +118,36 @@ def test_model_fused_equals_pytorch_path(env, which):
         assert frac > 0.95, "offsets: only %.4f within tolerance" % frac
         agree = (a[:, :, :C].argmax(-1) == b[:, :, :C].argmax(-1)).float().mean().item()
         assert agree > 0.97, "argmax class agrees on %.4f of the anchors" % agree
+
+
+def test_prediction_assembly_dense_vs_packed_vs_torch(env):
+    """ssdhip_assemble_predictions_strided_bf16: dense head tensors and the same logits packed into one wider, padded
+    conv output give identical bytes; both match the PyTorch formulation (bias add rounded to bf16, float32 softmax)."""
+    torch, F, nat = env
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, C = 3, 21
+    layers = [(5, 7, 4), (3, 3, 6), (1, 1, 4)]                          # (h, w, n_boxes)
+    confs, locs, packed, cb, lb = [], [], [], [], []
+    for h, w, nb in layers:
+        c = torch.randn((B, h, w, nb * C), generator=g, device="cuda").to(torch.bfloat16)
+        lo = torch.randn((B, h, w, nb * 4), generator=g, device="cuda").to(torch.bfloat16)
+        pad = (-(nb * (C + 4))) % 64
+        junk = torch.randn((B, h, w, pad), generator=g, device="cuda").to(torch.bfloat16)       # padding channels are never read
+        confs.append(c.permute(0, 3, 1, 2))
+        locs.append(lo.permute(0, 3, 1, 2))
+        packed.append(torch.cat([c, lo, junk], dim=-1).contiguous().permute(0, 3, 1, 2))
+        cb.append(torch.randn((nb * C,), generator=g, device="cuda").to(torch.bfloat16))
+        lb.append(torch.randn((nb * 4,), generator=g, device="cuda").to(torch.bfloat16))
+    N = sum(h * w * nb for h, w, nb in layers)
+    av = torch.rand((N, 8), generator=g, device="cuda")
+    nbs = [nb for _, _, nb in layers]
+    dense = nat.assemble_predictions(confs, locs, cb, lb, nbs, av, C)
+    pack = nat.assemble_predictions(packed, [None] * 3, cb, lb, nbs, av, C)
+    mixed = nat.assemble_predictions([packed[0], confs[1], packed[2]], [None, locs[1], None], cb, lb, nbs, av, C)
+    assert dense.shape == (B, N, C + 12)
+    assert torch.equal(dense, pack) and torch.equal(dense, mixed)
+    want_c = torch.cat([(c.permute(0, 2, 3, 1) + b_).reshape(B, -1, C) for c, b_ in zip(confs, cb)], dim=1)
+    want_l = torch.cat([(lo.permute(0, 2, 3, 1) + b_).reshape(B, -1, 4) for lo, b_ in zip(locs, lb)], dim=1)
+    want = torch.cat([torch.softmax(want_c.float(), dim=-1), want_l.float(), av.unsqueeze(0).expand(B, -1, -1)], dim=2)
+    assert torch.equal(dense[:, :, C:], want[:, :, C:])
+    assert (dense[:, :, :C] - want[:, :, :C]).abs().max().item() <= 2e-6
