@@ -303,7 +303,10 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
 #pragma unroll
         for (int i = 0; i < CI * 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wb + i * 4096), 16, woff[i], soff_w, 0, 0);
-        if (++n_cs == csteps) { n_cs = 0; if (++n_kw == KS) { n_kw = 0; ++n_kh; } }
+        // taps innermost: the nine taps of one 64-channel slice touch the SAME cache lines (shifted by one pixel / one image
+        // row), so consecutive steps re-read lines that are still in L2; with the slice innermost (v1) a line's reuse distance is
+        // Cin/64 steps x every workgroup of the XCD -- beyond the 4 MB L2, and each tap's tile came back from MALL/HBM again
+        if (++n_kw == KS) { n_kw = 0; if (++n_kh == KS) { n_kh = 0; ++n_cs; } }
     };
 
     f32x16 acc[CI][2];
