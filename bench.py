@@ -46,6 +46,14 @@ def parse():
     return ap.parse_args()
 
 
+def conv_choice_label(key):
+    """Readable name of an autotune key of ssd_keras_amd.models._common.SSDModel._pick."""
+    kind = key[0]
+    if kind == "head":                                       # ("head", layer, x shape, conf Cout, loc Cout)
+        return "head%d %s -> %d+%d k3" % (key[1], "x".join(str(v) for v in key[2]), key[3], key[4])
+    return "%s %s -> %s k%s d%s" % (kind, "x".join(str(v) for v in key[1]), key[2], key[3], key[4])
+
+
 def event_ms(fn, reps):
     """Average milliseconds of `fn()` over `reps` back-to-back launches, events on the current stream."""
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -172,10 +180,7 @@ def main():
     from ssd_keras_amd.models._common import SSDModel
     choices = {}
     for key, name in SSDModel._conv_choice.items():          # which kernel the per-shape autotune kept for each convolution
-        kind, shape = key[0], key[1] if kind != "head" else key[2]
-        label = "%s %s->%s k%s" % (kind, "x".join(str(v) for v in shape), key[2] if kind != "head" else "%s+%s" % (key[3], key[4]),
-                                   key[3] if kind != "head" else 3)
-        choices[label] = name
+        choices[conv_choice_label(key)] = name
     conv = {"bound": "mfma", "forward_ms": round(fwd_ms, 4), "achieved": round(conv_tflops, 2),
             "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(conv_tflops / MFMA_PEAK_TFLOPS[args.dtype], 5),
             "note": "per layer the faster of libssdhip's implicit-GEMM MFMA kernel (fused bias/ReLU epilogue; packed conf+loc heads) "

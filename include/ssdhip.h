@@ -240,6 +240,13 @@ int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* 
 int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                          int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 
+/* The same convolution followed by MaxPooling2D(pool_size 2, strides 2, padding 'same') in ONE kernel (conv1_2 -> pool1,
+ * conv2_2 -> pool2, conv3_3 -> pool3 of models/keras_ssd300.py:274-290): the 2x2 maximum is taken on the float32 accumulators,
+ * then bias, ReLU and one bf16 rounding -- equal to pooling the rounded activations because all three are monotonic.
+ *   y [B, ceil(H/2), ceil(W/2), Cout] bf16; windows are clipped to the map (odd H or W). */
+int ssdhip_conv2d_same_pool2_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                       int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
+
 /* First layer (conv1_1, models/keras_ssd300.py:274): 3x3 'same' convolution of a 3-channel NHWC bf16 image into 64 channels
  * + bias + ReLU, one thread per pixel (the op is bound by writing the 64-channel map).  Cin must be 3, Cout 64. */
 int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,

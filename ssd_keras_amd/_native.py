@@ -357,6 +357,28 @@ def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
     return y
 
 
+def conv2d_same_pool2(x, weight, bias, dilation=1, relu=True):
+    """'same' convolution + bias + ReLU + 2x2 / stride-2 max-pool ('same' = windows clipped to the map) in ONE libssdhip
+    MFMA kernel.  x (B, Cin, H, W) bf16 NHWC memory -> (B, Cout, ceil(H/2), ceil(W/2))."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_convpool_bound", False):
+        lib.ssdhip_conv2d_same_pool2_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv2d_same_pool2_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+        lib._convpool_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or kh != kw:
+        raise SsdHipError("weight must be bfloat16 (Cout, %d, k, k)" % cin)
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, (h + 1) // 2, (w + 1) // 2, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv2d_same_pool2_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(kh), int(dilation),
+                                                    int(bool(relu)), current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv2d_same_pool2_nhwc_bf16")
+    return y
+
+
 def conv3x3_cin3(x, weight, bias, relu=True):
     """First layer: 3x3 'same' convolution of a 3-channel image into 64 channels + bias + ReLU (csrc/ssdhip_conv.hip)."""
     torch = _torch()

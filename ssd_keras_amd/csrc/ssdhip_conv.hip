@@ -42,6 +42,8 @@ struct ConvParams {
     bf16_t* y;                   // [M, Cout]
     int H, W, Cin, Cout, KS, dil, relu;
     int M, m_tiles, n_tiles;
+    int Ho, Wo, WT, HT, cshift;  // fused 2x2/2 max-pool: pooled map size; a tile is (64 >> cshift) row pairs x (1 << cshift)
+                                 // columns, WT x HT tiles per image
 };
 
 __device__ __forceinline__ u32 f2bf_rn(float f) {
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvParams 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // (the body is a __device__ function: the host pass never sees the buffer-resource type, which only exists for amdgcn)
-template <int BC>
+template <int BC, bool POOL>
 __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned char* lds) {
     constexpr int CI = BC / 64;
     constexpr int XBYTES = CONV_BP * 128, WBYTES = BC * 128, BUF = XBYTES + WBYTES;
@@ -240,7 +242,9 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
     if (mt >= p.m_tiles) return;
-    const int m0 = mt * CONV_BP, co0 = nt * BC;
+    const int m0 = mt * CONV_BP, co0 = nt * BC;       // POOL: mt = ((b * HT + ht) * WT + wt), see below
+    int pb = 0, php = 0, pwt = 0;                      // POOL: image, first row pair, column tile of this workgroup
+    if constexpr (POOL) { pwt = mt % p.WT; const int r = mt / p.WT; php = (r % p.HT) * (64 >> p.cshift); pb = r / p.HT; }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,7 +261,7 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     // ---- per-thread load descriptors: byte offsets of 4 X rows (+ tap validity) and CI*2 weight rows ---------------
     u32 xoff[4], xok[4], woff[CI * 2];
     const int pos = lane & 7;
-    {
+    if constexpr (!POOL) {
         int m = m0 + wave * 8 + (lane >> 3);
         int wq = m % p.W, hq = (m / p.W) % p.H;
 #pragma unroll
@@ -279,6 +283,30 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
             m += 32;
             wq += 32;
             while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
+        }
+    } else {
+        // tile = RP = 64 >> cshift row pairs x CC = 1 << cshift columns (shape picked on the host to waste the fewest
+        // padded pixels).  Tile-local pixel i (= LDS row = MFMA column wp*64 + pi*32 + r31) has q = (i >> 6) * 32 + (i & 31):
+        // image row 2 * (php + q / CC) + ((i >> 5) & 1), column CC * pwt + q % CC -- a lane's two accumulator blocks (pi = 0, 1)
+        // are the SAME column of the two rows of a pair, and lane ^ 1 is the neighbouring column of the same pair.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            const int j = pos ^ ((row >> 1) & 7);
+            const int q = (row >> 6) * 32 + (row & 31);
+            const int hq = 2 * (php + (q >> p.cshift)) + ((row >> 5) & 1), wq = (pwt << p.cshift) + (q & ((1 << p.cshift) - 1));
+            u32 rmask = 0, cmask = 0;
+            for (int k = 0; k < KS; ++k) {
+                const int d = (k - half) * dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (hq < p.H && wq < p.W)
+                for (int kh = 0; kh < KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+            xok[i] = ok;
+            xoff[i] = (u32)((pb * p.H + hq) * p.W + wq) * (u32)(Cin * 2) + (u32)(j * 16);
         }
     }
 #pragma unroll
@@ -353,6 +381,58 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
         __syncthreads();
     }
 
+    if constexpr (POOL) {
+        // ---- pooled epilogue: max over the 2x2 window in registers (vertical: the lane's two accumulator blocks; horizontal:
+        //      lane ^ 1 by DPP quad_perm), THEN bias + ReLU + one bf16 rounding -- all three are monotonic, so this equals
+        //      pooling the rounded activations (what Conv2D(activation='relu') -> MaxPooling2D computes).  Even lanes hold the
+        //      16 pooled columns of the wave; they go through the LDS transpose and leave as 16-byte stores. ----------------
+        constexpr int ROWB = 64 * CI;
+        unsigned char* stage = lds + wave * (16 * ROWB);
+        const int q = wp * 32 + r31;
+        const int hq = 2 * (php + (q >> p.cshift)), wq = (pwt << p.cshift) + (q & ((1 << p.cshift) - 1));
+        const bool has_below = hq + 1 < p.H, has_right = wq + 1 < p.W;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][0][4 * g + q];
+                    const float below = acc[ci][1][4 * g + q];
+                    if (has_below) v = below > v ? below : v;
+                    const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+                    if (has_right) v = right > v ? right : v;
+                    v += bv[q];
+                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                if (!(r31 & 1)) {
+                    const int px = r31 >> 1, chunk = ci * 4 + g;
+                    *reinterpret_cast<uint2*>(stage + px * ROWB + ((chunk ^ (px & (4 * CI - 1))) << 4) + khalf * 8) =
+                        make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+                }
+            }
+        __syncthreads();
+        constexpr int CPR = 4 * CI;
+#pragma unroll
+        for (int j = 0; j < CPR / 4; ++j) {
+            const int idx = j * 64 + lane, px = idx / CPR, c = idx % CPR;
+            const int qe = wp * 32 + 2 * px;
+            const int ho = php + (qe >> p.cshift), wo = ((pwt << p.cshift) + (qe & ((1 << p.cshift) - 1))) >> 1;
+            if (ho < p.Ho && wo < p.Wo)
+                *reinterpret_cast<uint4*>(p.y + ((size_t)(pb * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + wc * (BC / 2) + c * 8) =
+                    *reinterpret_cast<const uint4*>(stage + px * ROWB + ((c ^ (px & (CPR - 1))) << 4));
+        }
+        return;
+    }
     // ---- epilogue: identical to v1 (LDS transpose, 16-byte stores) --------------------------------------------------
     constexpr int ROWB = 64 * CI;
     unsigned char* stage = lds + wave * (64 * ROWB);
@@ -397,8 +477,220 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
 template <int BC>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
-    conv_igemm4_body<BC>(p, lds);
+    conv_igemm4_body<BC, false>(p, lds);
 }
+
+template <int BC>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_pool_kernel(ConvParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
+    conv_igemm4_body<BC, true>(p, lds);
+}
+
+// =================================================================================================================
+// v5: multi-stage LDS ring.  The trace of v4 showed ~1 us per K-step on EVERY layer, big or small, busy CU or idle: a step
+// cannot finish before the loads issued at its start have come back from L2 / MALL (prefetch distance = one step), so the
+// kernel is bound by load latency x bytes in flight (64 KB per CU), not by MFMA or L2 bandwidth.  v5 keeps v4's tile
+// (BC channels x 128 pixels, 4 waves as 2x2) but steps through K in 32-channel slices (16 KB per stage at BC = 128) and
+// keeps NS stages in LDS: loads run NS-1 steps ahead of the MFMAs.
+//   * NS = 4: 64 KB per workgroup, 2 workgroups per CU, 96 KB in flight per CU; NS = 3: 48 KB, 3 workgroups per CU.
+//   * One s_barrier per step, none of them draining the loads: the LDS-DMA loads are issued from inline asm (a
+//     __builtin load makes hipcc put s_waitcnt vmcnt(0) in front of every ds_read that might alias an in-flight
+//     LDS-DMA -- that is what serialised v3 -- and __syncthreads() waits vmcnt(0) as well), completion is counted by
+//     hand: before step s a wave waits until all but its newest (NS-2) x LPW loads have landed, then the barrier makes
+//     that true for every wave and also says everybody is done reading the stage that the next loads overwrite.
+//   * LDS rows are 64 bytes (32 channels); 16-byte chunk c of row r sits at position c ^ ((r >> 2) & 3), which keeps
+//     both the lane-linear LDS-DMA image and the ds_read_b128 fragment reads free of bank conflicts.
+// =================================================================================================================
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// one wave-wide 1 KiB LDS-DMA load: lane L writes 16 bytes at lds_dst + 16 L from base(rsrc) + soff + voff (zeros if voff is
+// out of range).  M0 is saved and restored inside the statement (hipcc does not model it around asm).
+__device__ __forceinline__ void bload_lds16(u32 voff, i32x4 rsrc, u32 lds_dst, u32 soff) {
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, long offset_bytes, int num_records) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base + (unsigned long long)offset_bytes;
+    i32x4 r;
+    r.x = (int)(u32)a;
+    r.y = (int)((u32)(a >> 32) & 0xffffu);             // stride 0, no swizzle
+    r.z = num_records;
+    r.w = 0x00020000;
+    return r;
+}
+
+template <int BC, int NS>
+__device__ __forceinline__ void conv_igemm5_body(const ConvParams& p, unsigned char* lds) {
+    constexpr int CI = BC / 64;
+    constexpr int BK = 32, ROW = 64;                   // bytes per LDS row
+    constexpr int XBYTES = CONV_BP * ROW, WBYTES = BC * ROW, STG = XBYTES + WBYTES;
+    constexpr int XP = 2, WP = BC / 64, LPW = XP + WP; // 1 KiB pieces per wave per step
+    constexpr int D = NS - 1;                          // prefetch distance in steps
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
+    if (mt >= p.m_tiles) return;
+    const int m0 = mt * CONV_BP, co0 = nt * BC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wp = wave & 1;
+    const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
+    const int csteps = Cin / BK, T = KK * csteps;
+
+    const int neg = (half * dil * p.W + half * dil) * Cin * 2;
+    const i32x4 rx = make_rsrc(p.x, -(long)neg, p.M * Cin * 2 + 2 * neg);
+    const i32x4 rw = make_rsrc(p.w, 0, p.Cout * KK * Cin * 2);
+    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    // ---- per-thread load descriptors: a 1 KiB piece = 16 rows x 64 bytes; lane L -> row L >> 2, position L & 3 ------
+    u32 xoff[XP], xok[XP], woff[WP];
+    const int pos = lane & 3;
+    {
+        int m = m0 + wave * 16 + (lane >> 2);
+        int wq = m % p.W, hq = (m / p.W) % p.H;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int row = (i * 4 + wave) * 16 + (lane >> 2);
+            const int j = pos ^ ((row >> 2) & 3);
+            u32 rmask = 0, cmask = 0;
+            for (int k = 0; k < KS; ++k) {
+                const int d = (k - half) * dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (m < p.M)
+                for (int kh = 0; kh < KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+            xok[i] = ok;
+            xoff[i] = (u32)m * (u32)(Cin * 2) + (u32)(j * 16);
+            m += 64;
+            wq += 64;
+            while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        const int j = pos ^ ((row >> 2) & 3);
+        woff[i] = (u32)(co0 + row) * (u32)(KK * Cin * 2) + (u32)(j * 16);
+    }
+
+    int n_kh = 0, n_kw = 0, n_cs = 0;                  // the step the next issue() loads (taps innermost, see v4)
+    auto issue = [&](int stage) {
+        const int t = n_kh * KS + n_kw;
+        const u32 soff_x = (u32)(neg + (((n_kh - half) * dil * p.W + (n_kw - half) * dil) * Cin + n_cs * BK) * 2);
+        const u32 soff_w = (u32)((t * Cin + n_cs * BK) * 2);
+        const u32 tapbit = 1u << t;
+        const u32 xb = lds0 + stage * STG + wave * 1024, wb = xb + XBYTES;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) bload_lds16((xok[i] & tapbit) ? xoff[i] : OOB, rx, xb + i * 4096, soff_x);
+#pragma unroll
+        for (int i = 0; i < WP; ++i) bload_lds16(woff[i], rw, wb + i * 4096, soff_w);
+        if (++n_kw == KS) { n_kw = 0; if (++n_kh == KS) { n_kh = 0; ++n_cs; } }
+    };
+
+    f32x16 acc[CI][2];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int swz = (r31 >> 2) & 3;                    // tile-row bases are multiples of 32
+    const int arow = XBYTES + (wc * (BC / 2) + r31) * ROW, brow = (wp * 64 + r31) * ROW;
+    int choff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) choff[kk] = ((2 * kk + khalf) ^ swz) << 4;
+
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < T) issue(d);
+
+    for (int s = 0; s < T; ++s) {
+        // step s's tile has landed (this wave's pieces) once at most min(D-1, T-1-s) newer steps are still in flight
+        const int ahead = (T - 1 - s) < (D - 1) ? (T - 1 - s) : (D - 1);
+        if (ahead >= 2) wait_vmcnt<2 * LPW>();
+        else if (ahead == 1) wait_vmcnt<LPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                  // ... everybody's pieces; and nobody still reads stage (s-1) % NS
+        const unsigned char* sb = lds + (s % NS) * STG;
+        bf16x8 a[2][CI], b[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) a[kk][ci] = *reinterpret_cast<const bf16x8*>(sb + arow + ci * 32 * ROW + choff[kk]);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) b[kk][pi] = *reinterpret_cast<const bf16x8*>(sb + brow + pi * 32 * ROW + choff[kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + D < T) issue((s + D) % NS);            // overwrites the stage read during step s-1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][ci], b[kk][pi], acc[ci][pi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                   // all fragment reads done: the ring becomes the store stage
+
+    // ---- epilogue: identical to v1 / v4 (LDS transpose, 16-byte stores) ------------------------------------------------
+    constexpr int ROWB = 64 * CI;
+    unsigned char* stage = lds + wave * (64 * ROWB);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int px = pi * 32 + r31;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][pi][4 * g + q] + bv[q];
+                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                const int chunk = ci * 4 + g;
+                *reinterpret_cast<uint2*>(stage + px * ROWB + ((chunk ^ (px & (4 * CI - 1))) << 4) + khalf * 8) =
+                    make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = 4 * CI;
+#pragma unroll
+    for (int j = 0; j < CPR; ++j) {
+        const int idx = j * 64 + lane, px = idx / CPR, c = idx % CPR;
+        const int m = m0 + wp * 64 + px;
+        if (m < p.M)
+            *reinterpret_cast<uint4*>(p.y + (size_t)m * p.Cout + co0 + wc * (BC / 2) + c * 8) =
+                *reinterpret_cast<const uint4*>(stage + px * ROWB + ((c ^ (px & (CPR - 1))) << 4));
+    }
+}
+
+template <int BC, int NS>
+__global__ __launch_bounds__(CONV_THREADS, (NS >= 4 ? 2 : 3)) void conv_igemm5_kernel(ConvParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * (CONV_BP * 64 + BC * 64)];
+    conv_igemm5_body<BC, NS>(p, lds);
+}
+
 
 // =================================================================================================================
 // v3: 256-pixel tile, 8 waves, three-stage weight pipeline, kw-reuse of the activation strip.
@@ -413,7 +705,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams
 // =================================================================================================================
 constexpr int C3_BP = 256, C3_THREADS = 512, C3_STRIP_ROWS = 320;     // 5 wave-instructions of 8 rows per wave
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int BC>
 __global__ __launch_bounds__(C3_THREADS) void conv_igemm3_kernel(ConvParams p) {
@@ -746,11 +1037,23 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
     p.y = static_cast<bf16_t*>(y);
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
     p.M = (int)M;
+    p.Ho = p.Wo = p.WT = p.HT = p.cshift = 0;
     const bool wide = (Cout % 128) == 0;
     p.n_tiles = Cout / (wide ? 128 : 64);
     const bool small = M * Cin * 2 + 4LL * (dilation * W + dilation) * Cin < 0x7ffff000LL && (long long)Cout * kernel * kernel * Cin * 2 < 0x7ffff000LL;
     if (variant == 4 && !small) variant = 1;  // buffer addressing needs 31-bit byte offsets
-    if (variant == 4) {                       // v1's tile with buffer-addressed LDS-DMA and batched fragment reads
+    if ((variant == 5 || variant == 6) && !small) variant = 1;
+    if (variant == 5 || variant == 6) {       // multi-stage LDS ring: 5 = four 16 KB stages (2 WG/CU), 6 = three (3 WG/CU)
+        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (variant == 5) {
+            if (wide) hipLaunchKernelGGL((conv_igemm5_kernel<128, 4>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm5_kernel<64, 4>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        } else {
+            if (wide) hipLaunchKernelGGL((conv_igemm5_kernel<128, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm5_kernel<64, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        }
+    } else if (variant == 4) {                // v1's tile with buffer-addressed LDS-DMA and batched fragment reads
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
         if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
@@ -781,8 +1084,42 @@ extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, c
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
-    if (variant != 1 && variant != 3 && variant != 4) return SSDHIP_E_BADARG;
+    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 6) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
+}
+
+// Conv2D(k x k, padding='same', activation='relu') followed by MaxPooling2D(2, 2, padding='same') as ONE kernel
+// (models/keras_ssd300.py:274-283 conv1_2 -> pool1 and twins): y [B, ceil(H/2), ceil(W/2), Cout].
+extern "C" int ssdhip_conv2d_same_pool2_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                                  int Cin, int Cout, int kernel, int dilation, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || dilation <= 0 || dilation > 8) return SSDHIP_E_BADARG;
+    if (kernel != 1 && kernel != 3) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % CONV_BK) || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 7)) return SSDHIP_E_BADARG;
+    const long long M = (long long)B * H * W;
+    if (M * Cin * 2 + 4LL * (dilation * W + dilation) * Cin >= 0x7ffff000LL || (long long)Cout * kernel * kernel * Cin * 2 >= 0x7ffff000LL)
+        return SSDHIP_E_BADARG;
+    ConvParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
+    p.M = (int)M;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    long long best = -1;                      // tile shape (64 >> cs row pairs x 1 << cs columns) with the smallest padded area
+    for (int cs = 6; cs >= 1; --cs) {
+        const long long wt = (W + (1 << cs) - 1) >> cs, ht = (p.Ho + (64 >> cs) - 1) / (64 >> cs);
+        if (best < 0 || wt * ht < best) { best = wt * ht; p.cshift = cs; p.WT = (int)wt; p.HT = (int)ht; }
+    }
+    const bool wide = (Cout % 128) == 0;
+    p.n_tiles = Cout / (wide ? 128 : 64);
+    const long long mt = (long long)B * p.HT * p.WT;
+    if (mt > 0x3fffffffLL / p.n_tiles) return SSDHIP_E_BADARG;
+    p.m_tiles = (int)mt;
+    const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+    if (wide) hipLaunchKernelGGL(conv_igemm4_pool_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_igemm4_pool_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
 // First layer: 3x3 'same' convolution with Cin = 3, Cout = 64 (+ bias + ReLU).

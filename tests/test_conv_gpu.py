@@ -21,7 +21,7 @@ CASES = [  # B, H, W, Cin, Cout, k, dil, bias, relu
 ]
 
 
-@pytest.mark.parametrize("variant", [None, 1, 4])
+@pytest.mark.parametrize("variant", [None, 1, 4, 5, 6])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_vs_float32_reference(case, variant):
     import torch
@@ -73,3 +73,41 @@ def test_first_layer_conv_vs_float32_reference(shape):
         err = (got - want).abs()
         bad = int((err > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
         assert bad == 0, "%d outputs off, max err %g (rms %g)" % (bad, err.max().item(), rms)
+
+
+POOL_CASES = [  # B, H, W, Cin, Cout, k, dil
+    (2, 300, 300, 64, 64, 3, 1),      # conv1_2 -> pool1
+    (1, 150, 150, 128, 128, 3, 1),    # conv2_2 -> pool2
+    (2, 75, 75, 256, 256, 3, 1),      # conv3_3 -> pool3: odd size, clipped last row / column
+    (3, 5, 7, 64, 64, 3, 1),          # tiny odd map, one partial column tile
+    (1, 1, 1, 64, 128, 3, 1),         # single pixel
+    (2, 8, 130, 64, 64, 1, 1),        # 1x1 kernel, three column tiles (the last with 2 columns)
+    (1, 19, 19, 128, 64, 3, 2),       # dilation 2
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_conv_pool_fused(case):
+    """Convolution with the 2x2 max-pool in its epilogue == the unfused libssdhip path bit for bit (same accumulation order;
+    max commutes with bias / ReLU / rounding), and matches the float32 reference within the convolution tolerance."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, k, dil = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+    for relu in (True, False):
+        got = nat.conv2d_same_pool2(x, wt, bias, dilation=dil, relu=relu)
+        assert got.shape == (B, Cout, (H + 1) // 2, (W + 1) // 2)
+        unfused = nat.bias_act_maxpool(nat.conv2d_same(x, wt, bias, dilation=dil, relu=relu, variant=4), None, 2, 2, 0, True, relu=False)
+        assert torch.equal(got, unfused), "%d of %d outputs differ from the unfused path" % (int((got != unfused).sum()), got.numel())
+        ref = F.conv2d(x.float(), wt.float(), bias.float(), 1, dil * (k // 2), dil)
+        if relu:
+            ref = torch.relu(ref)
+        want = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+        rms = ref.pow(2).mean().sqrt().item()
+        err = (got.float() - want).abs()
+        bad = int((err > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
+        assert bad == 0, "%d outputs off, max err %g" % (bad, err.max().item())

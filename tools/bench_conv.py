@@ -11,7 +11,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ssd_keras_amd import _native as nat          # noqa: E402
 
-LAYERS = [("conv1_2", 300, 64, 64, 3, 1), ("conv2_1", 150, 64, 128, 3, 1), ("conv2_2", 150, 128, 128, 3, 1),
+LAYERS = [("head1", 19, 1024, 192, 3, 1), ("head3", 5, 256, 192, 3, 1), ("conv1_2", 300, 64, 64, 3, 1), ("conv2_1", 150, 64, 128, 3, 1), ("conv2_2", 150, 128, 128, 3, 1),
           ("conv3_1", 75, 128, 256, 3, 1), ("conv3_2", 75, 256, 256, 3, 1), ("conv4_1", 38, 256, 512, 3, 1),
           ("conv4_2", 38, 512, 512, 3, 1), ("conv5_1", 19, 512, 512, 3, 1), ("fc6", 19, 512, 1024, 3, 6),
           ("fc7", 19, 1024, 1024, 1, 1)]
@@ -42,12 +42,19 @@ def main():
         t_ours = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True))
         t_v1 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=1)) if os.environ.get("V1", "1") == "1" else float("nan")
         t_v4 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=4))
+        t_v5 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=5))
+        t_v6 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=6))
+        t_pool = t_unf = float("nan")
+        if name in ("conv1_2", "conv2_2", "conv3_2"):
+            t_pool = ev_ms(lambda: nat.conv2d_same_pool2(x, w, b, dilation=dil, relu=True))
+            t_unf = ev_ms(lambda: nat.bias_act_maxpool(nat.conv2d_same(x, w, b, dilation=dil, relu=True), None, 2, 2, 0, True, relu=False))
         if os.environ.get("MIOPEN", "1") == "1":
             t_mi = ev_ms(lambda: F.conv2d(x, w, None, 1, dil * (k // 2), dil))
             t_mi_full = ev_ms(lambda: nat.bias_act(F.conv2d(x, w, None, 1, dil * (k // 2), dil), b, relu=True))
         else:
             t_mi = t_mi_full = float("nan")
         r = {"layer": name, "ours_us": round(t_ours * 1e3, 1), "ours_TFs": round(flop / t_ours / 1e9, 1), "v1_us": round(t_v1 * 1e3, 1), "v4_us": round(t_v4 * 1e3, 1), "v4_TFs": round(flop / t_v4 / 1e9, 1),
+             "conv_pool_fused_us": round(t_pool * 1e3, 1), "conv_then_pool_us": round(t_unf * 1e3, 1), "v5_us": round(t_v5 * 1e3, 1), "v5_TFs": round(flop / t_v5 / 1e9, 1), "v6_us": round(t_v6 * 1e3, 1), "v6_TFs": round(flop / t_v6 / 1e9, 1),
              "miopen_conv_us": round(t_mi * 1e3, 1), "miopen_TFs": round(flop / t_mi / 1e9, 1),
              "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
         print(json.dumps(r), flush=True)
