@@ -47,11 +47,16 @@ def parse():
 
 
 def conv_choice_label(key):
-    """Readable name of an autotune key of ssd_keras_amd.models._common.SSDModel._pick."""
-    kind = key[0]
-    if kind == "head":                                       # ("head", layer, x shape, conf Cout, loc Cout)
-        return "head%d %s -> %d+%d k3" % (key[1], "x".join(str(v) for v in key[2]), key[3], key[4])
-    return "%s %s -> %s k%s d%s" % (kind, "x".join(str(v) for v in key[1]), key[2], key[3], key[4])
+    """Readable name of an autotune key of ssd_keras_amd.models._common.SSDModel._pick (never raises)."""
+    try:
+        kind = key[0]
+        if kind == "head":                                   # ("head", layer, x shape, conf Cout, loc Cout)
+            return "head%d %s -> %d+%d k3" % (key[1], "x".join(str(v) for v in key[2]), key[3], key[4])
+        if kind == "heads":                                  # ("heads", shapes of all source maps, classes)
+            return "all heads (%d source maps)" % len(key[1])
+        return "%s %s -> %s k%s d%s" % (kind, "x".join(str(v) for v in key[1]), key[2], key[3], key[4])
+    except Exception:
+        return repr(key)
 
 
 def event_ms(fn, reps):

@@ -247,6 +247,14 @@ int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void*
 int ssdhip_conv2d_same_pool2_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                        int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 
+/* n_problems (<= 8) independent 'same' convolutions of the kind above in ONE launch -- the predictor heads of all source layers
+ * (models/keras_ssd300.py:322-361), whose small members are latency-bound when launched alone.  Every array is a HOST array with one
+ * entry per problem (device pointers inside x_h / weight_h / bias_h / y_h; bias_h or its entries may be NULL). */
+int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* const* x_h, const void* const* weight_h,
+                                       const void* const* bias_h, void* const* y_h, const int* B_h, const int* H_h,
+                                       const int* W_h, const int* Cin_h, const int* Cout_h, const int* kernel_h,
+                                       const int* dilation_h, int relu, void* stream);
+
 /* First layer (conv1_1, models/keras_ssd300.py:274): 3x3 'same' convolution of a 3-channel NHWC bf16 image into 64 channels
  * + bias + ReLU, one thread per pixel (the op is bound by writing the 64-channel map).  Cin must be 3, Cout 64. */
 int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,

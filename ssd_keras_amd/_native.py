@@ -379,6 +379,41 @@ def conv2d_same_pool2(x, weight, bias, dilation=1, relu=True):
     return y
 
 
+def conv2d_same_group(xs, weights, biases=None, relu=False):
+    """Several independent 'same' convolutions (kernel 1 or 3, stride 1, dilation 1) in ONE libssdhip launch.
+    xs[i] (B, Cin_i, H_i, W_i) bf16 NHWC memory, weights[i] (Cout_i, Cin_i, k, k) bf16 channels_last -> list of outputs."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_convgroup_bound", False):
+        lib.ssdhip_conv2d_same_group_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv2d_same_group_nhwc_bf16.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_void_p]
+        lib._convgroup_bound = True
+    n = len(xs)
+    keep, xp, wp, bp, yp, dims, ys = [], [], [], [], [], [], []
+    for i in range(n):
+        x, (b, h, w, cin) = _nhwc_bf16(xs[i], "x")
+        wt = weights[i]
+        cout, cin_w, kh, kw = wt.shape
+        if wt.dtype != torch.bfloat16 or cin_w != cin or kh != kw:
+            raise SsdHipError("weight %d must be bfloat16 (Cout, %d, k, k)" % (i, cin))
+        if not wt.permute(0, 2, 3, 1).is_contiguous():
+            wt = wt.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+        keep += [x, wt]
+        ys.append(y)
+        xp.append(x.data_ptr()); wp.append(wt.data_ptr()); yp.append(y.data_ptr())
+        bp.append(biases[i].data_ptr() if (biases is not None and biases[i] is not None) else 0)
+        dims.append((b, h, w, cin, cout, int(kh), 1))
+    parr = lambda v: (ctypes.c_void_p * n)(*v)
+    iarr = lambda k: (ctypes.c_int * n)(*[d[k] for d in dims])
+    dev = ys[0].device
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_conv2d_same_group_nhwc_bf16(n, parr(xp), parr(wp), parr(bp), parr(yp), iarr(0), iarr(1), iarr(2), iarr(3),
+                                                    iarr(4), iarr(5), iarr(6), int(bool(relu)), current_stream_ptr(dev))
+    check(rc, "ssdhip_conv2d_same_group_nhwc_bf16")
+    return ys
+
+
 def conv3x3_cin3(x, weight, bias, relu=True):
     """First layer: 3x3 'same' convolution of a 3-channel image into 64 channels + bias + ReLU (csrc/ssdhip_conv.hip)."""
     torch = _torch()

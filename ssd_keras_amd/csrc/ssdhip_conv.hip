@@ -232,14 +232,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvParams 
 // =================================================================================================================
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// The bodies below use amdgcn-only types and builtins (buffer resources, DPP, inline ISA): they exist in the device pass only;
+// the host pass sees just the kernel stubs.
+#if defined(__HIP_DEVICE_COMPILE__)
 // (the body is a __device__ function: the host pass never sees the buffer-resource type, which only exists for amdgcn)
 template <int BC, bool POOL>
-__device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned char* lds) {
+__device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned char* lds, const int id) {
     constexpr int CI = BC / 64;
     constexpr int XBYTES = CONV_BP * 128, WBYTES = BC * 128, BUF = XBYTES + WBYTES;
     constexpr unsigned OOB = 0x80000000u;
 
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int xcd = id & 7, slot = id >> 3;
     const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
     if (mt >= p.m_tiles) return;
     const int m0 = mt * CONV_BP, co0 = nt * BC;       // POOL: mt = ((b * HT + ht) * WT + wt), see below
@@ -474,16 +477,40 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     }
 }
 
+#endif  // __HIP_DEVICE_COMPILE__
+
 template <int BC>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
-    conv_igemm4_body<BC, false>(p, lds);
+    conv_igemm4_body<BC, false>(p, lds, (int)blockIdx.x);
+#endif
 }
 
 template <int BC>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_pool_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
-    conv_igemm4_body<BC, true>(p, lds);
+    conv_igemm4_body<BC, true>(p, lds, (int)blockIdx.x);
+#endif
+}
+
+// Several independent convolutions in ONE launch (the six predictor heads of an SSD: a 1x1-pixel head is a single workgroup
+// walking 36 K-steps, ~40 us of pure latency when launched alone; side by side the small problems hide behind the big ones).
+constexpr int CONV_MAX_GROUP = 8;
+struct ConvGroup {
+    ConvParams p[CONV_MAX_GROUP];
+    int first_block[CONV_MAX_GROUP + 1];     // workgroups of problem k: [first_block[k], first_block[k+1]), each a multiple of 8
+    int n;
+};
+
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_group_kernel(ConvGroup g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + 64 * 128)];
+    int k = 0;
+    while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
+    conv_igemm4_body<64, false>(g.p[k], lds, (int)blockIdx.x - g.first_block[k]);
+#endif
 }
 
 // =================================================================================================================
@@ -504,6 +531,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_pool_kernel(ConvP
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+#if defined(__HIP_DEVICE_COMPILE__)
 // one wave-wide 1 KiB LDS-DMA load: lane L writes 16 bytes at lds_dst + 16 L from base(rsrc) + soff + voff (zeros if voff is
 // out of range).  M0 is saved and restored inside the statement (hipcc does not model it around asm).
 __device__ __forceinline__ void bload_lds16(u32 voff, i32x4 rsrc, u32 lds_dst, u32 soff) {
@@ -685,10 +713,14 @@ __device__ __forceinline__ void conv_igemm5_body(const ConvParams& p, unsigned c
     }
 }
 
+#endif  // __HIP_DEVICE_COMPILE__
+
 template <int BC, int NS>
 __global__ __launch_bounds__(CONV_THREADS, (NS >= 4 ? 2 : 3)) void conv_igemm5_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * (CONV_BP * 64 + BC * 64)];
     conv_igemm5_body<BC, NS>(p, lds);
+#endif
 }
 
 
@@ -1119,6 +1151,48 @@ extern "C" int ssdhip_conv2d_same_pool2_nhwc_bf16(const void* x, const void* wei
     const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
     if (wide) hipLaunchKernelGGL(conv_igemm4_pool_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
     else hipLaunchKernelGGL(conv_igemm4_pool_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// n_problems independent 'same' convolutions (no pooling) in one launch; arrays are HOST arrays of per-problem arguments.
+extern "C" int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* const* x_h, const void* const* weight_h,
+                                                  const void* const* bias_h, void* const* y_h, const int* B_h, const int* H_h,
+                                                  const int* W_h, const int* Cin_h, const int* Cout_h, const int* kernel_h,
+                                                  const int* dilation_h, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_problems <= 0 || n_problems > CONV_MAX_GROUP || !x_h || !weight_h || !y_h || !B_h || !H_h || !W_h || !Cin_h || !Cout_h ||
+        !kernel_h || !dilation_h)
+        return SSDHIP_E_BADARG;
+    ConvGroup g;
+    g.n = n_problems;
+    long long blocks = 0;
+    for (int k = 0; k < CONV_MAX_GROUP; ++k) {
+        g.first_block[k] = (int)blocks;
+        if (k >= n_problems) { g.p[k] = g.p[0]; continue; }
+        const int B = B_h[k], H = H_h[k], W = W_h[k], Cin = Cin_h[k], Cout = Cout_h[k], ks = kernel_h[k], dil = dilation_h[k];
+        const void* bias = bias_h ? bias_h[k] : nullptr;
+        if (!x_h[k] || !weight_h[k] || !y_h[k] || B <= 0 || H <= 0 || W <= 0 || dil <= 0 || dil > 8 || (ks != 1 && ks != 3))
+            return SSDHIP_E_BADARG;
+        if (Cin <= 0 || (Cin % CONV_BK) || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
+        if (((uintptr_t)x_h[k] | (uintptr_t)weight_h[k] | (uintptr_t)y_h[k]) & 15 || ((uintptr_t)bias & 7)) return SSDHIP_E_BADARG;
+        const long long M = (long long)B * H * W;
+        if (M * Cin * 2 + 4LL * (dil * W + dil) * Cin >= 0x7ffff000LL || (long long)Cout * ks * ks * Cin * 2 >= 0x7ffff000LL ||
+            M * Cout > 0x7fffffff0LL)
+            return SSDHIP_E_BADARG;
+        ConvParams& p = g.p[k];
+        p.x = static_cast<const bf16_t*>(x_h[k]); p.w = static_cast<const bf16_t*>(weight_h[k]); p.bias = static_cast<const bf16_t*>(bias);
+        p.y = static_cast<bf16_t*>(y_h[k]);
+        p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ks; p.dil = dil; p.relu = relu ? 1 : 0;
+        p.M = (int)M;
+        p.Ho = p.Wo = p.WT = p.HT = p.cshift = 0;
+        p.n_tiles = Cout / 64;
+        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+        blocks += (long long)((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (blocks > 0x3fffffffLL) return SSDHIP_E_BADARG;
+    }
+    g.first_block[CONV_MAX_GROUP] = (int)blocks;
+    for (int k = n_problems; k < CONV_MAX_GROUP; ++k) g.first_block[k] = (int)blocks;
+    hipLaunchKernelGGL(conv_igemm4_group_kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), 0, stream, g);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -231,18 +231,15 @@ class SSDModel(nn.Module):
         b = x.shape[0]
         sizes = [(f.shape[2], f.shape[3]) for f in feats]
         if all(self._fused_head_ok(f, ch) for f, ch in zip(feats, self.conf_heads)):
-            # heads without bias; bias, Reshape, softmax, anchors and the concatenations are one libssdhip pass (:363-419).
-            # Per layer the two heads run either as two MIOpen convolutions or PACKED into one libssdhip implicit-GEMM launch
-            # (conf and loc filters concatenated along Cout, zero-padded to 64 channels): timed once per shape, faster kept.
-            confs, locs = [], []
-            for l, (f, ch, lh) in enumerate(zip(feats, self.conf_heads, self.loc_heads)):
-                cands = {"miopen": lambda f=f, ch=ch, lh=lh: (self._conv_nobias(ch, f), self._conv_nobias(lh, f))}
-                if self._packed_head_ok(ch, lh, f):
-                    cands["igemm"] = lambda f=f, l=l: (nat.conv2d_same(f, self._packed_head_weight(l), None, dilation=1, relu=False), None)
-                name = self._pick(("head", l, tuple(f.shape), ch.out_channels, lh.out_channels), cands) if len(cands) > 1 else "miopen"
-                c, lo = cands[name]()
-                confs.append(c)
-                locs.append(lo)
+            # heads without bias; bias, Reshape, softmax, anchors and the concatenations are one libssdhip pass (:363-419)
+            packable = all(self._packed_head_ok(ch, lh, f) for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads))
+            how = "per_layer"
+            if packable and len(feats) <= 8:
+                # all packed heads as ONE grouped launch vs one launch per layer: the 1x1..5x5 heads are single workgroups
+                # walking long K loops (pure latency); side by side they hide behind the 38x38 / 19x19 heads
+                how = self._pick(("heads", tuple(tuple(f.shape) for f in feats), self.n_classes),
+                                 {"per_layer": lambda: self._heads_per_layer(feats), "grouped": lambda: self._heads_grouped(feats)})
+            confs, locs = self._heads_grouped(feats) if how == "grouped" else self._heads_per_layer(feats)
             anchors = self.anchors_and_variances(sizes, x.device)
             return nat.assemble_predictions(confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
                                             [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
@@ -255,6 +252,24 @@ class SSDModel(nn.Module):
         loc = torch.cat(locs, dim=1).float()
         anchors = self.anchors_and_variances(sizes, conf.device)
         return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+
+    def _heads_grouped(self, feats):
+        outs = nat.conv2d_same_group(list(feats), [self._packed_head_weight(l) for l in range(len(feats))], None, relu=False)
+        return outs, [None] * len(outs)
+
+    def _heads_per_layer(self, feats):
+        """Per layer the two heads run either as two MIOpen convolutions or PACKED into one libssdhip implicit-GEMM launch
+        (conf and loc filters concatenated along Cout, zero-padded to 64 channels): timed once per shape, faster kept."""
+        confs, locs = [], []
+        for l, (f, ch, lh) in enumerate(zip(feats, self.conf_heads, self.loc_heads)):
+            cands = {"miopen": lambda f=f, ch=ch, lh=lh: (self._conv_nobias(ch, f), self._conv_nobias(lh, f))}
+            if self._packed_head_ok(ch, lh, f):
+                cands["igemm"] = lambda f=f, l=l: (nat.conv2d_same(f, self._packed_head_weight(l), None, dilation=1, relu=False), None)
+            name = self._pick(("head", l, tuple(f.shape), ch.out_channels, lh.out_channels), cands) if len(cands) > 1 else "miopen"
+            c, lo = cands[name]()
+            confs.append(c)
+            locs.append(lo)
+        return confs, locs
 
     @staticmethod
     def _packed_head_ok(ch, lh, f):

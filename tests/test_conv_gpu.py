@@ -111,3 +111,28 @@ def test_conv_pool_fused(case):
         err = (got.float() - want).abs()
         bad = int((err > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
         assert bad == 0, "%d outputs off, max err %g" % (bad, err.max().item())
+
+
+def test_grouped_launch_equals_single_launches():
+    """ssdhip_conv2d_same_group_nhwc_bf16: six head-shaped problems in one launch == the same problems launched one by one
+    (identical K order per output element -> identical bytes)."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(2, 38, 38, 512, 128), (2, 19, 19, 1024, 192), (2, 10, 10, 512, 192), (2, 5, 5, 256, 192), (2, 3, 3, 256, 128),
+              (2, 1, 1, 256, 128)]
+    xs, ws = [], []
+    for B, H, W, Cin, Cout in shapes:
+        xs.append(torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2))
+        ws.append((torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2))
+    got = nat.conv2d_same_group(xs, ws, None, relu=False)
+    for x, w, y in zip(xs, ws, got):
+        want = nat.conv2d_same(x, w, None, dilation=1, relu=False, variant=4)
+        assert y.shape == want.shape and torch.equal(y, want)
+    # with biases and ReLU, and a 1x1 member
+    bs = [torch.randn((w.shape[0],), generator=g, device="cuda").to(torch.bfloat16) for w in ws[:2]]
+    w11 = (torch.randn((64, 1, 1, 512), generator=g, device="cuda") / 512 ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    got = nat.conv2d_same_group([xs[0], xs[1], xs[2]], [ws[0], ws[1], w11], [bs[0], bs[1], None], relu=True)
+    assert torch.equal(got[0], nat.conv2d_same(xs[0], ws[0], bs[0], relu=True, variant=4))
+    assert torch.equal(got[1], nat.conv2d_same(xs[1], ws[1], bs[1], relu=True, variant=4))
+    assert torch.equal(got[2], nat.conv2d_same(xs[2], w11, None, relu=True, variant=4))
