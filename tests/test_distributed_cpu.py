@@ -70,3 +70,42 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     _loss(model(x)).backward()
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     torch.testing.assert_close(outs[0]["grads"], ref, rtol=1e-4, atol=1e-6)
+
+
+def _worker_ssd300(rank, world, port, tmp):
+    """The model bench.py's training leg wraps in DDP (SSD300/VOC, mode='training'), two steps on two gloo ranks: every
+    parameter must take part in the reduction (an unused one makes DDP raise on the second forward)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dp.init_from_env("gloo")
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(4321)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", l2_regularization=0.0005, scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"]).train()
+    ddp = dp.data_parallel(model)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-9, momentum=0.9)
+    x = torch.from_numpy(np.random.RandomState(10 + rank).randint(0, 256, size=(1, 300, 300, 3)).astype(np.float32))
+    for _ in range(2):
+        pred = ddp(x)
+        assert pred.shape == (1, 8732, 33)
+        loss = _loss(pred)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    missing = [n for n, p in model.named_parameters() if p.grad is None]
+    grads = torch.cat([p.grad.reshape(-1)[:64] for p in model.parameters()])
+    torch.save({"missing": missing, "grads": grads, "n": sum(p.numel() for p in model.parameters())}, os.path.join(tmp, "s%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_ddp_over_the_ssd300_training_model(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_ssd300, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "s%d.pt" % r)) for r in range(2)]
+    assert outs[0]["missing"] == [] and outs[1]["missing"] == []
+    assert outs[0]["n"] == 26285486                                      # SSD300 / 21 classes (SURVEY App. B)
+    assert torch.equal(outs[0]["grads"], outs[1]["grads"])              # averaged gradients are identical on both ranks
