@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=1, help="1: decode on a second stream beside the next forward; 0: one stream")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="0 (default): decode on the forward's stream; 1: on a second stream beside the next forward -- measured 3 %% "
+                         "SLOWER since the convolutions fill the CUs (the persistent conv64 kernel owns every CU's LDS)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images for the CPU baseline (0: auto, ~10-30 s)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (encoder / loss / sparse decode / training step)")
     ap.add_argument("--train-steps", type=int, default=6, help="timed steps of the training-step leg (0: skip it)")
@@ -114,9 +116,9 @@ def main():
             torch.distributed.barrier()
 
     # ---- timed region: exactly K steps ---------------------------------------------------------
-    # A step = forward (current stream) + DecodeDetections of ITS predictions.  With --overlap (default) the decode is
-    # enqueued on a second HIP stream behind an event, so the latency-bound NMS of step i runs beside the convolutions
-    # of step i+1 (a serving loop's natural shape); every step's decode finishes inside the timed region.
+    # A step = forward + DecodeDetections of ITS predictions, on one stream (default).  With --overlap 1 the decode is
+    # enqueued on a second HIP stream behind an event so that the NMS of step i runs beside the convolutions of step i+1;
+    # every step's decode finishes inside the timed region either way.
     dec_stream = torch.cuda.Stream(device=dev) if args.overlap else torch.cuda.current_stream(dev)
     dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()

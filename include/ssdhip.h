@@ -255,6 +255,14 @@ int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* const* x_h, c
                                        const int* W_h, const int* Cin_h, const int* Cout_h, const int* kernel_h,
                                        const int* dilation_h, int relu, void* stream);
 
+/* 3x3 'same' convolution for the Cin = 64 layers (conv1_2, conv2_1: models/keras_ssd300.py:275-279) + bias + ReLU, optionally with
+ * MaxPooling2D(2, 2, 'same') fused (pool != 0; y then [B, ceil(H/2), ceil(W/2), Cout]).  Persistent workgroups keep the whole
+ * 72 KB filter bank of a 64-channel output slice resident in LDS and stream one activation halo per 128-pixel tile
+ * (csrc/ssdhip_conv64.hip).  Cin must be 64, Cout % 64 == 0; n_workgroups = persistent workgroups to launch (the CU count; 0 = 256).
+ * Same numerics as ssdhip_conv2d_same[_pool2]_nhwc_bf16 (bit-identical results). */
+int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                 int Cin, int Cout, int relu, int pool, int n_workgroups, void* stream);
+
 /* First layer (conv1_1, models/keras_ssd300.py:274): 3x3 'same' convolution of a 3-channel NHWC bf16 image into 64 channels
  * + bias + ReLU, one thread per pixel (the op is bound by writing the 64-channel map).  Cin must be 3, Cout 64. */
 int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,

@@ -414,6 +414,35 @@ def conv2d_same_group(xs, weights, biases=None, relu=False):
     return ys
 
 
+_CU_COUNT = {}
+
+
+def conv3x3_c64(x, weight, bias, relu=True, pool=False):
+    """3x3 'same' convolution of a 64-channel map + bias + ReLU [+ 2x2/2 'same' max-pool]: the resident-weight, halo-tile kernel of
+    csrc/ssdhip_conv64.hip.  x (B, 64, H, W) bf16 NHWC memory, weight (Cout, 64, 3, 3) bf16 channels_last, Cout % 64 == 0."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_c64_bound", False):
+        lib.ssdhip_conv3x3_c64_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_c64_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+        lib._c64_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or cin != 64 or kh != 3 or kw != 3:
+        raise SsdHipError("conv3x3_c64 needs a bfloat16 (Cout, 64, 3, 3) weight and a 64-channel input")
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    y = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    key = str(x.device)
+    if key not in _CU_COUNT:
+        _CU_COUNT[key] = int(torch.cuda.get_device_properties(x.device).multi_processor_count)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_c64_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(bool(relu)), int(bool(pool)),
+                                              _CU_COUNT[key], current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_c64_nhwc_bf16")
+    return y
+
+
 def conv3x3_cin3(x, weight, bias, relu=True):
     """First layer: 3x3 'same' convolution of a 3-channel image into 64 channels + bias + ReLU (csrc/ssdhip_conv.hip)."""
     torch = _torch()

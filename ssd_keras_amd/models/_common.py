@@ -161,6 +161,8 @@ class SSDModel(nn.Module):
                 cands["igemm"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu)
                 # the three-stage / 32-channel-slice / 3-workgroups-per-CU variant wins on the shallow-K layers (Cin = 64)
                 cands["igemm6"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=6)
+                if conv.in_channels == 64 and k == 3 and conv.dilation[0] == 1:
+                    cands["c64"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=relu, pool=False)
             name = self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu), cands) if len(cands) > 1 else "miopen"
             return cands[name]()
         y = conv(x)
@@ -180,6 +182,8 @@ class SSDModel(nn.Module):
                 if (kernel == 2 and stride == 2 and pad == 0 and (ceil_mode or x.shape[2] % 2 == 0) and (ceil_mode or x.shape[3] % 2 == 0)):
                     # pooling fused into the convolution's epilogue: the full-resolution activation is never written
                     cands["igemm_pool"] = lambda: nat.conv2d_same_pool2(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True)
+                    if conv.in_channels == 64 and conv.kernel_size == (3, 3) and conv.dilation[0] == 1:
+                        cands["c64_pool"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=True, pool=True)
             name = (self._pick(("pool", tuple(x.shape), conv.out_channels, conv.kernel_size[0], conv.dilation[0], kernel, stride, pad),
                                cands) if len(cands) > 1 else "miopen")
             return cands[name]()

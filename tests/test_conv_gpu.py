@@ -136,3 +136,43 @@ def test_grouped_launch_equals_single_launches():
     assert torch.equal(got[0], nat.conv2d_same(xs[0], ws[0], bs[0], relu=True, variant=4))
     assert torch.equal(got[1], nat.conv2d_same(xs[1], ws[1], bs[1], relu=True, variant=4))
     assert torch.equal(got[2], nat.conv2d_same(xs[2], w11, None, relu=True, variant=4))
+
+
+C64_CASES = [  # B, H, W, Cout
+    (2, 300, 300, 64),        # conv1_2
+    (2, 150, 150, 128),       # conv2_1: two 64-channel output slices
+    (1, 75, 75, 64),          # odd size
+    (3, 5, 7, 64),            # tiny: a single partial tile per image
+    (1, 1, 1, 128),           # single pixel
+    (2, 9, 130, 64),          # wide and short
+    (40, 16, 16, 64),         # more tiles than one round of persistent workgroups would need per image
+]
+
+
+@pytest.mark.parametrize("case", C64_CASES)
+def test_resident_weight_conv_c64(case):
+    """csrc/ssdhip_conv64.hip (persistent workgroups, resident 72 KB filter bank, activation halos) == the implicit-GEMM kernel
+    bit for bit, with and without the fused pool, and within the convolution tolerance of the float32 reference."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cout = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, 64), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, 64), generator=g, device="cuda") / 24.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+    for relu in (True, False):
+        for b_ in (bias, None):
+            got = nat.conv3x3_c64(x, wt, b_, relu=relu, pool=False)
+            want = nat.conv2d_same(x, wt, b_, dilation=1, relu=relu, variant=4)
+            assert got.shape == want.shape
+            assert torch.equal(got, want), "%d of %d outputs differ from the implicit-GEMM kernel" % (int((got != want).sum()), got.numel())
+            gotp = nat.conv3x3_c64(x, wt, b_, relu=relu, pool=True)
+            wantp = nat.bias_act_maxpool(want, None, 2, 2, 0, True, relu=False)
+            assert gotp.shape == wantp.shape
+            assert torch.equal(gotp, wantp), "%d of %d pooled outputs differ" % (int((gotp != wantp).sum()), gotp.numel())
+    ref = torch.relu(F.conv2d(x.float(), wt.float(), bias.float(), 1, 1))
+    got = nat.conv3x3_c64(x, wt, bias, relu=True, pool=False).float()
+    rms = ref.pow(2).mean().sqrt().item()
+    bad = int(((got - ref).abs() > ref.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
+    assert bad == 0

@@ -48,13 +48,17 @@ def main():
         if name in ("conv1_2", "conv2_2", "conv3_2"):
             t_pool = ev_ms(lambda: nat.conv2d_same_pool2(x, w, b, dilation=dil, relu=True))
             t_unf = ev_ms(lambda: nat.bias_act_maxpool(nat.conv2d_same(x, w, b, dilation=dil, relu=True), None, 2, 2, 0, True, relu=False))
+        t_c64 = t_c64p = float("nan")
+        if cin == 64 and k == 3:
+            t_c64 = ev_ms(lambda: nat.conv3x3_c64(x, w, b, relu=True, pool=False))
+            t_c64p = ev_ms(lambda: nat.conv3x3_c64(x, w, b, relu=True, pool=True))
         if os.environ.get("MIOPEN", "1") == "1":
             t_mi = ev_ms(lambda: F.conv2d(x, w, None, 1, dil * (k // 2), dil))
             t_mi_full = ev_ms(lambda: nat.bias_act(F.conv2d(x, w, None, 1, dil * (k // 2), dil), b, relu=True))
         else:
             t_mi = t_mi_full = float("nan")
         r = {"layer": name, "ours_us": round(t_ours * 1e3, 1), "ours_TFs": round(flop / t_ours / 1e9, 1), "v1_us": round(t_v1 * 1e3, 1), "v4_us": round(t_v4 * 1e3, 1), "v4_TFs": round(flop / t_v4 / 1e9, 1),
-             "conv_pool_fused_us": round(t_pool * 1e3, 1), "conv_then_pool_us": round(t_unf * 1e3, 1), "v5_us": round(t_v5 * 1e3, 1), "v5_TFs": round(flop / t_v5 / 1e9, 1), "v6_us": round(t_v6 * 1e3, 1), "v6_TFs": round(flop / t_v6 / 1e9, 1),
+             "c64_us": round(t_c64 * 1e3, 1), "c64_pool_us": round(t_c64p * 1e3, 1), "conv_pool_fused_us": round(t_pool * 1e3, 1), "conv_then_pool_us": round(t_unf * 1e3, 1), "v5_us": round(t_v5 * 1e3, 1), "v5_TFs": round(flop / t_v5 / 1e9, 1), "v6_us": round(t_v6 * 1e3, 1), "v6_TFs": round(flop / t_v6 / 1e9, 1),
              "miopen_conv_us": round(t_mi * 1e3, 1), "miopen_TFs": round(flop / t_mi / 1e9, 1),
              "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
         print(json.dumps(r), flush=True)

@@ -20,7 +20,12 @@ def main():
         b = torch.randn((cout,), device="cuda").to(torch.bfloat16)
         for variant in [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]:
             for _ in range(3):
-                nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=variant)
+                if variant == 64:
+                    nat.conv3x3_c64(x, w, b, relu=True, pool=True)
+                elif variant == 40:
+                    nat.conv2d_same_pool2(x, w, b, dilation=dil, relu=True)
+                else:
+                    nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=variant)
         torch.cuda.synchronize()
     print("done")
 

@@ -15,6 +15,6 @@ for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WA
   timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pass$i -o conv -- python $GRAFT_REPO_ROOT/tools/pmc_conv.py > $OUT/pass$i.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
-python tools/pmc_fold.py $OUT conv_igemm > $OUT/summary.txt 2>&1
+python tools/pmc_fold.py $OUT conv > $OUT/summary.txt 2>&1
 find $OUT -name "*.csv" -size +5M -delete
 cat $OUT/summary.txt | head -120
