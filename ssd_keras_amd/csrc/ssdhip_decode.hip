@@ -504,6 +504,12 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
             }
             const u64 sa = __ballot(supp && valid);
             if (lane == 0) supp_a[wave] = sa;
+            __syncthreads();
+            // candidates already suppressed by an earlier survivor are dead: their rows of the in-batch matrix are never read
+            // by the resolve loop, so phase B skips them (on densely overlapping boxes most of a batch dies in phase A)
+            const u64 sall_v = supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3];
+            const u64 sall = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(sall_v >> 32)) << 32) |
+                             (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)sall_v);      // scalar: the skips below are s_cbranch
             PROF_MARK(4)
             // phase B: in-batch suppression rows, 16 per wave: bit i of maskrow[j] = "j suppresses i" (i > j)
             for (int jj = 0; jj < 16; jj += 4) {
@@ -512,12 +518,16 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
                 for (int u = 0; u < 4; ++u) {
                     const int j = wave * 16 + jj + u;
                     code[u] = 0;
-                    if (j < nb) code[u] = nms_test(me, cbox[base + j], thr, fast_ok);
+                    if (j < nb && !((sall >> j) & 1ull)) code[u] = nms_test(me, cbox[base + j], thr, fast_ok);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = wave * 16 + jj + u;
                     if (j >= nb) break;
+                    if ((sall >> j) & 1ull) {                                  // wave-uniform
+                        if (lane == 0) maskrow[j] = 0ull;
+                        continue;
+                    }
                     bool sj = code[u] == 1;
                     if (code[u] == 2 && lane > j) sj = exact_suppresses<F>(me, cbox[base + j], thr);
                     const u64 mrow = __ballot(valid && lane > j && sj);
@@ -531,7 +541,6 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
             // lanes"); everything still alive at the end is kept.  Rows sit one per lane and are fetched by readlane.
             const u64 myrow = valid ? maskrow[lane] : 0ull;
             const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
-            const u64 sall = supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3];
             u64 alive = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) & ~sall;
             alive = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(alive >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)alive);
             const u64 cmask = __ballot(myrow != 0ull);
