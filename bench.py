@@ -228,6 +228,7 @@ def main():
             extra["encoder"] = bx.encoder_leg(dev, B, with_cpu)
             extra["loss"] = bx.loss_leg(dev, B, with_cpu)
             extra["decode_sparse"] = bx.sparse_decode_leg(dev, B, with_cpu)
+            extra["evaluator"] = bx.evaluator_leg(dev, with_cpu)
         if args.train_steps > 0:
             tr = bx.train_leg(dev, rank, world, B, steps=args.train_steps, warmup=3)
             if rank == 0:

@@ -234,3 +234,62 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3):
             "steps": steps, "warmup": warmup, "n_gpus": world, "scaling": "weak", "parameters": n_params,
             "allreduce_bytes_per_step": 4 * n_params if world > 1 else 0, "first_loss": float(last["first"].item()), "final_loss": float(last["loss"].item()),
             "note": "random He-normal init on 0..255 inputs (no pretrained VGG here): lr 1e-7 keeps the few timed steps finite"}
+
+
+@_guard
+def evaluator_leg(dev, with_cpu=True):
+    """Evaluator.match_predictions (the reference's Python loop over every prediction of every class) with the
+    matching on the GPU vs the NumPy port, on a VOC2007-test-sized synthetic problem (4952 images, 20 classes)."""
+    from oracle import np_oracle as orc
+    from ssd_keras_amd.eval_utils.average_precision_evaluator import Evaluator
+    rng = np.random.RandomState(0)
+    n_images, n_classes = 4952, 20
+    labels, neutral, image_ids = [], [], []
+    preds = [[] for _ in range(n_classes + 1)]
+    for i in range(n_images):
+        image_ids.append("%06d" % i)
+        g = int(rng.randint(1, 6))
+        cls = rng.randint(1, n_classes + 1, size=g)
+        x0, y0 = rng.randint(0, 400, size=g), rng.randint(0, 300, size=g)
+        lab = np.stack([cls, x0, y0, x0 + rng.randint(8, 120, size=g), y0 + rng.randint(8, 120, size=g)], axis=1).astype(np.int64)
+        labels.append(lab)
+        neutral.append(rng.uniform(size=g) < 0.15)
+        for b in lab:
+            for _ in range(int(rng.randint(0, 4))):
+                j = rng.normal(0, 5, size=4)
+                preds[int(b[0])].append((image_ids[-1], float(rng.uniform(0.01, 1)), float(b[1] + j[0]), float(b[2] + j[1]),
+                                         float(b[3] + j[2]), float(b[4] + j[3])))
+        for _ in range(int(rng.randint(0, 30))):
+            c = int(rng.randint(1, n_classes + 1))
+            x, y = rng.uniform(0, 450, size=2)
+            preds[c].append((image_ids[-1], float(rng.uniform(0.01, 0.5)), float(x), float(y), float(x + rng.uniform(4, 90)), float(y + rng.uniform(4, 90))))
+    gen = type("Gen", (), {})()
+    gen.labels, gen.eval_neutral, gen.image_ids = labels, neutral, image_ids
+    ev = Evaluator(model=None, n_classes=n_classes, data_generator=gen)
+    ev.prediction_results = preds
+    n_pred = sum(len(q) for q in preds)
+    with torch.cuda.device(dev):
+        ev.match_predictions(verbose=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        tp, fp, _, _ = ev.match_predictions(verbose=False, ret=True)
+        torch.cuda.synchronize()
+        gpu_ms = 1e3 * (time.perf_counter() - t)
+    ev.get_num_gt_per_class(verbose=False)
+    ev.compute_precision_recall(verbose=False)
+    ev.compute_average_precisions(verbose=False)
+    out = {"workload": "Evaluator.match_predictions, %d images, %d classes, %d predictions (synthetic, VOC2007-test sized)" % (n_images, n_classes, n_pred),
+           "gpu_ms_total": round(gpu_ms, 2), "note": "wall time incl. the host-side per-class CSR packing of labels and predictions",
+           "mAP_of_the_synthetic_problem": round(float(ev.compute_mean_average_precision()), 4)}
+    if with_cpu:
+        sub = [[]] + [preds[c] if c <= 2 else [] for c in range(1, n_classes + 1)]      # two classes, scaled up
+        t = time.perf_counter()
+        wtp, _, _, _ = orc.evaluator_match_predictions(sub, labels, image_ids, neutral, n_classes)
+        cpu_s = time.perf_counter() - t
+        frac = (len(preds[1]) + len(preds[2])) / max(n_pred, 1)
+        same = all(np.array_equal(tp[c], wtp[c]) for c in (1, 2))
+        out["cpu"] = {"ms_total_extrapolated": round(1e3 * cpu_s / max(frac, 1e-9), 1), "cores": 1, "kind": "port",
+                      "sample": "oracle evaluator_match_predictions (NumPy port of average_precision_evaluator.py:538-736) on classes 1-2 "
+                                "(%.1f %% of the predictions), scaled to all classes" % (100 * frac),
+                      "identical_flags_on_the_sample": bool(same), "speedup": round((cpu_s / max(frac, 1e-9)) / (gpu_ms * 1e-3), 1)}
+    return out

@@ -190,6 +190,22 @@ int ssdhip_greedy_nms(const double* rows, int n_rows_total, int row_len, int sco
                       int* kept_idx, int* kept_count, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Evaluator.match_predictions, one class (eval_utils/average_precision_evaluator.py:604-725).
+ *   pred        [P,5] float32 rows confidence, xmin, ymin, xmax, ymax (the reference keeps predictions as 'f4')
+ *   pred_image  [P] int32 index of each prediction's image
+ *   gt_boxes    [G,4] float64 'corners' boxes of THIS class, images concatenated; gt_offsets [n_images+1] int32 CSR
+ *   gt_neutral  [G] uint8, non-zero = evaluation-neutral ('difficult') box, or NULL
+ * Outputs, all [P] int32 and in the reference's order (confidence descending, equal confidences in input order, i.e.
+ * np.argsort(-confidence, kind='mergesort')): `order` (index into pred), true_pos, false_pos and their cumulative sums.
+ * A prediction whose best-IoU box (first maximum) is below the threshold, or whose image has no box of the class, is a false
+ * positive; a neutral best match is neither; otherwise it is a true positive iff no earlier prediction claimed that box. */
+size_t ssdhip_match_predictions_workspace_bytes(int P, int G);
+int ssdhip_match_predictions(const float* pred, const int* pred_image, int P, const double* gt_boxes, const int* gt_offsets,
+                             const unsigned char* gt_neutral, int n_images, int G, double matching_iou_threshold,
+                             int border_pixels, int* order, int* true_pos, int* false_pos, int* cum_true_pos,
+                             int* cum_false_pos, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Graph glue between the convolutions (bf16 activations, NHWC = torch channels_last; C % 8 == 0; pointers
  * 16-byte aligned).  Each call is ONE pass over the tensor where the framework path runs 2-7 elementwise kernels.
  *

@@ -680,3 +680,103 @@ def anchor_boxes_layer(batch_size, img_height, img_width, feature_map_size, this
     v = np.zeros_like(a) + np.asarray(variances, dtype=np.float64)
     t = np.concatenate([a, v], axis=-1)[None].astype(np.float32)
     return np.tile(t, (batch_size, 1, 1, 1, 1))
+
+
+# --------------------------------------------------------------------------------------
+# eval_utils/average_precision_evaluator.py
+# --------------------------------------------------------------------------------------
+def evaluator_num_gt_per_class(labels, eval_neutral, n_classes, class_id_index=0, ignore_neutral_boxes=True):
+    """average_precision_evaluator.py:477-536."""
+    num = np.zeros(n_classes + 1, dtype=np.int64)
+    for i, boxes in enumerate(labels):
+        boxes = np.asarray(boxes)
+        for j in range(boxes.shape[0]):
+            if ignore_neutral_boxes and eval_neutral is not None and eval_neutral[i][j]:
+                continue
+            num[int(boxes[j, class_id_index])] += 1
+    return num
+
+
+def evaluator_match_predictions(prediction_results, labels, image_ids, eval_neutral, n_classes,
+                                gt_format={"class_id": 0, "xmin": 1, "ymin": 2, "xmax": 3, "ymax": 4},
+                                ignore_neutral_boxes=True, matching_iou_threshold=0.5, border_pixels="include"):
+    """average_precision_evaluator.py:538-736 as it behaves with verbose=True and a stable sort (`kind='mergesort'`): with
+    verbose=False the reference iterates `range(len(predictions.shape))`, i.e. over the first prediction only (:650), and
+    'quicksort' leaves the order of equal confidences unspecified.  Returns (tp, fp, cum_tp, cum_fp): lists indexed by class id;
+    classes without predictions get empty arrays for all four (the reference appends nothing to the cumulative lists, :616-620)."""
+    cols = [gt_format[k] for k in ("xmin", "ymin", "xmax", "ymax")]
+    neutral_on = ignore_neutral_boxes and eval_neutral is not None
+    gt_by_image = {str(image_ids[i]): i for i in range(len(image_ids))}
+    tps, fps, ctps, cfps = [[]], [[]], [[]], [[]]
+    for class_id in range(1, n_classes + 1):
+        preds = prediction_results[class_id]
+        n = len(preds)
+        tp, fp = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        if n:
+            conf = np.array([p[1] for p in preds], dtype=np.float32)
+            order = np.argsort(-conf, kind="mergesort")
+            matched = {}
+            for s, pi in enumerate(order):
+                image_id = str(preds[pi][0])
+                box = np.array(preds[pi][2:6], dtype=np.float32)          # the structured array stores 'f4' (:629-634)
+                i = gt_by_image[image_id]
+                gt = np.asarray(labels[i])
+                mask = gt[:, gt_format["class_id"]] == class_id if gt.size else np.zeros((0,), dtype=bool)
+                gt = gt[mask] if gt.size else gt
+                if gt.size == 0:
+                    fp[s] = 1
+                    continue
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    overlaps = iou(gt[:, cols], box, coords="corners", mode="element-wise", border_pixels=border_pixels)
+                j = int(np.argmax(overlaps))
+                if overlaps[j] < matching_iou_threshold:
+                    fp[s] = 1
+                    continue
+                if neutral_on and np.asarray(eval_neutral[i])[mask][j]:
+                    continue
+                flags = matched.setdefault(image_id, np.zeros(gt.shape[0], dtype=bool))
+                if not flags[j]:
+                    tp[s] = 1
+                    flags[j] = True
+                else:
+                    fp[s] = 1
+        tps.append(tp)
+        fps.append(fp)
+        ctps.append(np.cumsum(tp))
+        cfps.append(np.cumsum(fp))
+    return tps, fps, ctps, cfps
+
+
+def evaluator_precision_recall(cum_tp, cum_fp, num_gt_per_class):
+    """average_precision_evaluator.py:738-781."""
+    precisions, recalls = [[]], [[]]
+    for c in range(1, len(cum_tp)):
+        tp, fp = np.asarray(cum_tp[c]), np.asarray(cum_fp[c])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            precisions.append(np.where(tp + fp > 0, tp / (tp + fp), 0))
+            recalls.append(tp / num_gt_per_class[c])
+    return precisions, recalls
+
+
+def evaluator_average_precisions(precisions, recalls, mode="sample", num_recall_points=11):
+    """average_precision_evaluator.py:783-884 ('sample': Pascal VOC pre-2010 k-point sampling; 'integrate': post-2010)."""
+    aps = [0.0]
+    for c in range(1, len(precisions)):
+        prec, rec = np.asarray(precisions[c]), np.asarray(recalls[c])
+        ap = 0.0
+        if mode == "sample":
+            for t in np.linspace(0, 1, num_recall_points, endpoint=True):
+                sel = prec[rec >= t]
+                ap += 0.0 if sel.size == 0 else np.amax(sel)
+            ap /= num_recall_points
+        elif mode == "integrate":
+            ur, ui, _ = np.unique(rec, return_index=True, return_counts=True)
+            maxp, dr = np.zeros_like(ur), np.zeros_like(ur)
+            for i in range(len(ur) - 2, -1, -1):
+                maxp[i] = np.maximum(np.amax(prec[ui[i]:ui[i + 1]]), maxp[i + 1])
+                dr[i] = ur[i + 1] - ur[i]
+            ap = np.sum(maxp * dr)
+        else:
+            raise ValueError("`mode` can be either 'sample' or 'integrate'")
+        aps.append(ap)
+    return aps

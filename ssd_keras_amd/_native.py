@@ -608,3 +608,39 @@ def greedy_nms_rows(rows, seg_offsets, score_col, box_col, iou_threshold, coords
                                    current_stream_ptr(dev))
     check(rc, "ssdhip_greedy_nms")
     return kept, cnt
+
+
+# ------------------------------------------------------------------------------------------------
+# Evaluator matching (csrc/ssdhip_eval.hip)
+# ------------------------------------------------------------------------------------------------
+def match_predictions_class(pred, pred_image, gt_boxes, gt_offsets, gt_neutral, matching_iou_threshold, border_pixels):
+    """One class of Evaluator.match_predictions.  pred (P,5) float32 [conf, xmin, ymin, xmax, ymax], pred_image (P,) int32,
+    gt_boxes (G,4) float64, gt_offsets (n_images+1,) int32, gt_neutral (G,) uint8 or None -- NumPy arrays or CUDA tensors.
+    Returns CUDA int32 tensors (order, true_pos, false_pos, cum_true_pos, cum_false_pos), each (P,)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_eval_bound", False):
+        c_int, c_vp, c_dbl, c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t
+        lib.ssdhip_match_predictions_workspace_bytes.restype = c_sz
+        lib.ssdhip_match_predictions_workspace_bytes.argtypes = [c_int, c_int]
+        lib.ssdhip_match_predictions.restype = c_int
+        lib.ssdhip_match_predictions.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_int,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]
+        lib._eval_bound = True
+    pred = to_device(pred, dtype=torch.float32)
+    dev = pred.device
+    pred_image = to_device(pred_image, device=dev, dtype=torch.int32)
+    gt_boxes = to_device(gt_boxes, device=dev, dtype=torch.float64)
+    gt_offsets = to_device(gt_offsets, device=dev, dtype=torch.int32)
+    neutral = to_device(gt_neutral, device=dev, dtype=torch.uint8) if gt_neutral is not None else None
+    P, G, n_images = int(pred.shape[0]), int(gt_boxes.shape[0]), int(gt_offsets.shape[0]) - 1
+    outs = [torch.zeros((P,), dtype=torch.int32, device=dev) for _ in range(5)]
+    if P == 0:
+        return tuple(outs)
+    ws = workspaces.get(dev, "match_predictions", lib.ssdhip_match_predictions_workspace_bytes(P, G))
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_match_predictions(_ptr(pred), _ptr(pred_image), P, _ptr(gt_boxes) if G else None, _ptr(gt_offsets), _ptr(neutral),
+                                          n_images, G, float(matching_iou_threshold), BORDER[border_pixels],
+                                          *[_ptr(o) for o in outs], _ptr(ws), ws.numel(), current_stream_ptr(dev))
+    check(rc, "ssdhip_match_predictions")
+    return tuple(outs)

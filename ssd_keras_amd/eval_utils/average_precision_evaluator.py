@@ -1,0 +1,304 @@
+"""`Evaluator` -- drop-in for the reference's eval_utils/average_precision_evaluator.py:36-899.
+
+Pascal-VOC-style mean average precision (pre-2010 k-point sampling and post-2010 integration).  The step that
+dominates the reference's run time -- `match_predictions`, a Python loop over up to ~184 k predictions per class
+(:604-725) -- runs on the GPU (`ssdhip_match_predictions`, csrc/ssdhip_eval.hip: IoU with the reference's mixed
+float64 / float32 arithmetic, arg-max, claim resolution by atomic max of the sort key, radix sort, prefix sums).  The
+per-class bookkeeping around it (ground truth counts, precision / recall arrays, the 11-point / integrated average) is
+the same few NumPy lines as in the reference.
+
+Same constructor, method names, keyword arguments and attributes as the reference.  Deliberate differences:
+  * predictions of equal confidence keep their input order (`np.argsort(-conf, kind='mergesort')`); the reference's default
+    'quicksort' leaves that order unspecified, so `sorting_algorithm` is accepted and ignored;
+  * `verbose=False` matches ALL predictions (the reference then iterates `range(len(predictions.shape))`, i.e. over the
+    first prediction of each class only, :650);
+  * a class without predictions gets empty cumulative arrays and average precision 0.0 (the reference leaves its
+    cumulative lists one entry short, :616-620, and `compute_precision_recall` raises IndexError or mis-assigns classes);
+  * `data_generator` is any object with `labels`, `image_ids`, `eval_neutral` (and, for `predict_on_dataset`, a
+    `generate(...)` / `get_dataset_size()` pair with the reference generator's contract) -- the reference's own image
+    pipeline is outside this package.
+"""
+from __future__ import annotations
+
+import sys
+from math import ceil
+
+import numpy as np
+
+from .. import _native as nat
+
+
+class Evaluator:
+    '''Computes the mean average precision of an SSD model on a dataset (reference class :36-93).'''
+
+    def __init__(self, model, n_classes, data_generator, model_mode='inference',
+                 pred_format={'class_id': 0, 'conf': 1, 'xmin': 2, 'ymin': 3, 'xmax': 4, 'ymax': 5},
+                 gt_format={'class_id': 0, 'xmin': 1, 'ymin': 2, 'xmax': 3, 'ymax': 4}):
+        self.model = model
+        self.data_generator = data_generator
+        self.n_classes = n_classes
+        self.model_mode = model_mode
+        self.pred_format = pred_format
+        self.gt_format = gt_format
+        # per-class lists of length n_classes + 1 (entry 0 is a dummy for the background class), as in the reference
+        self.prediction_results = None
+        self.num_gt_per_class = None
+        self.true_positives = None
+        self.false_positives = None
+        self.cumulative_true_positives = None
+        self.cumulative_false_positives = None
+        self.cumulative_precisions = None
+        self.cumulative_recalls = None
+        self.average_precisions = None
+        self.mean_average_precision = None
+
+    def __call__(self, img_height, img_width, batch_size, data_generator_mode='resize', round_confidences=False,
+                 matching_iou_threshold=0.5, border_pixels='include', sorting_algorithm='quicksort',
+                 average_precision_mode='sample', num_recall_points=11, ignore_neutral_boxes=True, return_precisions=False,
+                 return_recalls=False, return_average_precisions=False, verbose=True, decoding_confidence_thresh=0.01,
+                 decoding_iou_threshold=0.45, decoding_top_k=200, decoding_pred_coords='centroids',
+                 decoding_normalize_coords=True):
+        '''Reference :94-256: the whole evaluation in one call.  Returns the mean average precision and, optionally, the
+        average precisions, precisions and recalls (in that order, as the reference does).'''
+        self.predict_on_dataset(img_height=img_height, img_width=img_width, batch_size=batch_size,
+                                data_generator_mode=data_generator_mode, decoding_confidence_thresh=decoding_confidence_thresh,
+                                decoding_iou_threshold=decoding_iou_threshold, decoding_top_k=decoding_top_k,
+                                decoding_pred_coords=decoding_pred_coords, decoding_normalize_coords=decoding_normalize_coords,
+                                decoding_border_pixels=border_pixels, round_confidences=round_confidences, verbose=verbose, ret=False)
+        self.get_num_gt_per_class(ignore_neutral_boxes=ignore_neutral_boxes, verbose=False, ret=False)
+        self.match_predictions(ignore_neutral_boxes=ignore_neutral_boxes, matching_iou_threshold=matching_iou_threshold,
+                               border_pixels=border_pixels, sorting_algorithm=sorting_algorithm, verbose=verbose, ret=False)
+        self.compute_precision_recall(verbose=verbose, ret=False)
+        self.compute_average_precisions(mode=average_precision_mode, num_recall_points=num_recall_points, verbose=verbose, ret=False)
+        mean_average_precision = self.compute_mean_average_precision(ret=True)
+        if return_precisions or return_recalls or return_average_precisions:
+            ret = [mean_average_precision]
+            if return_average_precisions:
+                ret.append(self.average_precisions)
+            if return_precisions:
+                ret.append(self.cumulative_precisions)
+            if return_recalls:
+                ret.append(self.cumulative_recalls)
+            return ret
+        return mean_average_precision
+
+    def predict_on_dataset(self, img_height, img_width, batch_size, data_generator_mode='resize',
+                           decoding_confidence_thresh=0.01, decoding_iou_threshold=0.45, decoding_top_k=200,
+                           decoding_pred_coords='centroids', decoding_normalize_coords=True, decoding_border_pixels='include',
+                           round_confidences=False, verbose=True, ret=False):
+        '''Reference :258-424: run the model over `data_generator` and collect, per class, the tuples
+        `(image_id, confidence, xmin, ymin, xmax, ymax)`.  The generator must honour the reference's `generate(batch_size,
+        shuffle=False, transformations=..., label_encoder=None, returns={...}, keep_images_without_gt=True,
+        degenerate_box_handling='remove')` contract; `transformations` is passed as the mode string ('resize' / 'pad') because
+        the reference's image transformation classes are not part of this package.'''
+        if data_generator_mode not in ('resize', 'pad'):
+            raise ValueError("`data_generator_mode` can be either of 'resize' or 'pad', but received '{}'.".format(data_generator_mode))
+        import torch
+        from ..ssd_encoder_decoder.ssd_output_decoder import decode_detections
+        pf = self.pred_format
+        generator = self.data_generator.generate(batch_size=batch_size, shuffle=False, transformations=data_generator_mode,
+                                                 label_encoder=None,
+                                                 returns={'processed_images', 'image_ids', 'evaluation-neutral', 'inverse_transform',
+                                                          'original_labels'},
+                                                 keep_images_without_gt=True, degenerate_box_handling='remove')
+        if self.data_generator.image_ids is None:
+            self.data_generator.image_ids = list(range(self.data_generator.get_dataset_size()))
+        results = [list() for _ in range(self.n_classes + 1)]
+        n_images = self.data_generator.get_dataset_size()
+        n_batches = int(ceil(n_images / batch_size))
+        if verbose:
+            print("Number of images in the evaluation dataset: {}".format(n_images))
+        for _ in range(n_batches):
+            batch_X, batch_image_ids, _neutral, batch_inverse_transforms, _orig = next(generator)
+            predict = getattr(self.model, 'predict', self.model)
+            with torch.no_grad():
+                y_pred = predict(batch_X if torch.is_tensor(batch_X) else torch.as_tensor(np.asarray(batch_X), dtype=torch.float32).cuda())
+            if self.model_mode == 'training':
+                y_pred = decode_detections(y_pred, confidence_thresh=decoding_confidence_thresh, iou_threshold=decoding_iou_threshold,
+                                           top_k=decoding_top_k, input_coords=decoding_pred_coords,
+                                           normalize_coords=decoding_normalize_coords, img_height=img_height, img_width=img_width,
+                                           border_pixels=decoding_border_pixels)
+            else:
+                y_pred = y_pred.float().cpu().numpy()
+                y_pred = [y_pred[i][y_pred[i, :, 0] != 0] for i in range(len(y_pred))]       # drop the zero padding (:395-398)
+            if batch_inverse_transforms is not None:                                          # apply_inverse_transforms (:401)
+                y_pred = [self._invert(np.copy(y_pred[i]), batch_inverse_transforms[i]) for i in range(len(y_pred))]
+            for k, batch_item in enumerate(y_pred):
+                image_id = batch_image_ids[k]
+                for box in batch_item:
+                    class_id = int(box[pf['class_id']])
+                    confidence = round(box[pf['conf']], round_confidences) if round_confidences else box[pf['conf']]
+                    results[class_id].append((image_id, confidence, round(box[pf['xmin']], 1), round(box[pf['ymin']], 1),
+                                              round(box[pf['xmax']], 1), round(box[pf['ymax']], 1)))
+        self.prediction_results = results
+        if ret:
+            return results
+
+    @staticmethod
+    def _invert(boxes, inverters):
+        for inverter in (inverters or []):
+            if inverter is not None and boxes.size:
+                boxes = inverter(boxes)
+        return boxes
+
+    def write_predictions_to_txt(self, classes=None, out_file_prefix='comp3_det_test_', verbose=True):
+        '''Reference :426-475: one Pascal VOC results file per class.'''
+        if self.prediction_results is None:
+            raise ValueError("There are no prediction results. You must run `predict_on_dataset()` before calling this method.")
+        for class_id in range(1, self.n_classes + 1):
+            if verbose:
+                print("Writing results file for class {}/{}.".format(class_id, self.n_classes))
+            suffix = '{:04d}'.format(class_id) if classes is None else classes[class_id]
+            with open('{}{}.txt'.format(out_file_prefix, suffix), 'w') as results_file:
+                for prediction in self.prediction_results[class_id]:
+                    prediction_list = list(prediction)
+                    prediction_list[0] = '{:06d}'.format(int(prediction_list[0]))
+                    prediction_list[1] = round(prediction_list[1], 4)
+                    results_file.write(' '.join(map(str, prediction_list)) + '\n')
+        if verbose:
+            print("All results files saved.")
+
+    def get_num_gt_per_class(self, ignore_neutral_boxes=True, verbose=True, ret=False):
+        '''Reference :477-536: number of (non-neutral) ground truth boxes per class over the dataset.'''
+        if self.data_generator.labels is None:
+            raise ValueError("Computing the number of ground truth boxes per class not possible, no ground truth given.")
+        num_gt_per_class = np.zeros(shape=(self.n_classes + 1), dtype=np.int64)
+        ci = self.gt_format['class_id']
+        neutral = self.data_generator.eval_neutral
+        for i, boxes in enumerate(self.data_generator.labels):
+            boxes = np.asarray(boxes)
+            if boxes.size == 0:
+                continue
+            cls = boxes[:, ci].astype(np.int64)
+            if ignore_neutral_boxes and neutral is not None:
+                cls = cls[~np.asarray(neutral[i], dtype=bool)]
+            np.add.at(num_gt_per_class, cls, 1)
+        self.num_gt_per_class = num_gt_per_class
+        if ret:
+            return num_gt_per_class
+
+    def match_predictions(self, ignore_neutral_boxes=True, matching_iou_threshold=0.5, border_pixels='include',
+                          sorting_algorithm='quicksort', verbose=True, ret=False):
+        '''Reference :538-736: match every prediction to the ground truth.  Per class the result arrays are ordered by
+        descending confidence: `true_positives[c][i]` / `false_positives[c][i]` flag the i-th most confident prediction,
+        `cumulative_*` are their running sums.'''
+        if self.data_generator.labels is None:
+            raise ValueError("Matching predictions to ground truth boxes not possible, no ground truth given.")
+        if self.prediction_results is None:
+            raise ValueError("There are no prediction results. You must run `predict_on_dataset()` before calling this method.")
+        if border_pixels not in nat.BORDER:
+            raise ValueError("`border_pixels` must be one of 'half', 'include' and 'exclude'")
+        gf = self.gt_format
+        cols = [gf['xmin'], gf['ymin'], gf['xmax'], gf['ymax']]
+        image_ids = [str(v) for v in self.data_generator.image_ids]
+        index_of = {image_id: i for i, image_id in enumerate(image_ids)}
+        labels = [np.asarray(lab) for lab in self.data_generator.labels]
+        neutral = self.data_generator.eval_neutral if (ignore_neutral_boxes and self.data_generator.eval_neutral is not None) else None
+
+        true_positives, false_positives = [[]], [[]]
+        cumulative_true_positives, cumulative_false_positives = [[]], [[]]
+        for class_id in range(1, self.n_classes + 1):
+            predictions = self.prediction_results[class_id]
+            P = len(predictions)
+            if P == 0:
+                if verbose:
+                    print("No predictions for class {}/{}".format(class_id, self.n_classes))
+                empty = np.zeros(0, dtype=np.int64)
+                for lst in (true_positives, false_positives, cumulative_true_positives, cumulative_false_positives):
+                    lst.append(empty.copy())
+                continue
+            # this class's ground truth as CSR over the images (boxes float64: integer labels convert exactly)
+            boxes, offsets, flags = [], [0], []
+            for i, lab in enumerate(labels):
+                if lab.size:
+                    mask = lab[:, gf['class_id']] == class_id
+                    boxes.append(lab[mask][:, cols].astype(np.float64))
+                    if neutral is not None:
+                        flags.append(np.asarray(neutral[i], dtype=bool)[mask])
+                    offsets.append(offsets[-1] + int(mask.sum()))
+                else:
+                    offsets.append(offsets[-1])
+            gt_boxes = np.concatenate(boxes, axis=0) if boxes else np.zeros((0, 4))
+            gt_neutral = (np.concatenate(flags).astype(np.uint8) if flags else np.zeros((0,), np.uint8)) if neutral is not None else None
+            pred = np.array([p[1:6] for p in predictions], dtype=np.float32).reshape(P, 5)      # 'f4' like the reference (:629-634)
+            pred_image = np.array([index_of[str(p[0])] for p in predictions], dtype=np.int32)
+            if verbose:
+                print("Matching predictions to ground truth, class {}/{}.".format(class_id, self.n_classes))
+                sys.stdout.flush()
+            _order, tp, fp, ctp, cfp = nat.match_predictions_class(pred, pred_image, gt_boxes, np.asarray(offsets, dtype=np.int32),
+                                                                   gt_neutral, matching_iou_threshold, border_pixels)
+            true_positives.append(tp.cpu().numpy().astype(np.int64))
+            false_positives.append(fp.cpu().numpy().astype(np.int64))
+            cumulative_true_positives.append(ctp.cpu().numpy().astype(np.int64))
+            cumulative_false_positives.append(cfp.cpu().numpy().astype(np.int64))
+        self.true_positives = true_positives
+        self.false_positives = false_positives
+        self.cumulative_true_positives = cumulative_true_positives
+        self.cumulative_false_positives = cumulative_false_positives
+        if ret:
+            return true_positives, false_positives, cumulative_true_positives, cumulative_false_positives
+
+    def compute_precision_recall(self, verbose=True, ret=False):
+        '''Reference :738-781.'''
+        if (self.cumulative_true_positives is None) or (self.cumulative_false_positives is None):
+            raise ValueError("True and false positives not available. You must run `match_predictions()` before you call this method.")
+        if self.num_gt_per_class is None:
+            raise ValueError("Number of ground truth boxes per class not available. You must run `get_num_gt_per_class()` before "
+                             "you call this method.")
+        cumulative_precisions, cumulative_recalls = [[]], [[]]
+        for class_id in range(1, self.n_classes + 1):
+            if verbose:
+                print("Computing precisions and recalls, class {}/{}".format(class_id, self.n_classes))
+            tp = self.cumulative_true_positives[class_id]
+            fp = self.cumulative_false_positives[class_id]
+            with np.errstate(divide='ignore', invalid='ignore'):
+                cumulative_precisions.append(np.where(tp + fp > 0, tp / (tp + fp), 0))
+                cumulative_recalls.append(tp / self.num_gt_per_class[class_id])
+        self.cumulative_precisions = cumulative_precisions
+        self.cumulative_recalls = cumulative_recalls
+        if ret:
+            return cumulative_precisions, cumulative_recalls
+
+    def compute_average_precisions(self, mode='sample', num_recall_points=11, verbose=True, ret=False):
+        '''Reference :783-884: 'sample' = Pascal VOC pre-2010 k-point sampling, 'integrate' = post-2010 integration.'''
+        if (self.cumulative_precisions is None) or (self.cumulative_recalls is None):
+            raise ValueError("Precisions and recalls not available. You must run `compute_precision_recall()` before you call this method.")
+        if mode not in {'sample', 'integrate'}:
+            raise ValueError("`mode` can be either 'sample' or 'integrate', but received '{}'".format(mode))
+        average_precisions = [0.0]
+        for class_id in range(1, self.n_classes + 1):
+            if verbose:
+                print("Computing average precision, class {}/{}".format(class_id, self.n_classes))
+            cumulative_precision = self.cumulative_precisions[class_id]
+            cumulative_recall = self.cumulative_recalls[class_id]
+            average_precision = 0.0
+            if len(cumulative_precision) == 0:
+                average_precisions.append(average_precision)
+                continue
+            if mode == 'sample':
+                for t in np.linspace(start=0, stop=1, num=num_recall_points, endpoint=True):
+                    cum_prec_recall_greater_t = cumulative_precision[cumulative_recall >= t]
+                    average_precision += 0.0 if cum_prec_recall_greater_t.size == 0 else np.amax(cum_prec_recall_greater_t)
+                average_precision /= num_recall_points
+            else:
+                unique_recalls, unique_recall_indices, _ = np.unique(cumulative_recall, return_index=True, return_counts=True)
+                maximal_precisions = np.zeros_like(unique_recalls)
+                recall_deltas = np.zeros_like(unique_recalls)
+                for i in range(len(unique_recalls) - 2, -1, -1):
+                    begin, end = unique_recall_indices[i], unique_recall_indices[i + 1]
+                    maximal_precisions[i] = np.maximum(np.amax(cumulative_precision[begin:end]), maximal_precisions[i + 1])
+                    recall_deltas[i] = unique_recalls[i + 1] - unique_recalls[i]
+                average_precision = np.sum(maximal_precisions * recall_deltas)
+            average_precisions.append(average_precision)
+        self.average_precisions = average_precisions
+        if ret:
+            return average_precisions
+
+    def compute_mean_average_precision(self, ret=True):
+        '''Reference :886-899: the mean over the positive classes.'''
+        if self.average_precisions is None:
+            raise ValueError("Average precisions not available. You must run `compute_average_precisions()` before you call this method.")
+        mean_average_precision = np.average(self.average_precisions[1:])
+        self.mean_average_precision = mean_average_precision
+        if ret:
+            return mean_average_precision

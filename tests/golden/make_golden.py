@@ -176,6 +176,115 @@ def gen_box_utils2():
     save("box_utils2", **out)
 
 
+def _import_reference_evaluator():
+    """The reference Evaluator imports its data generator (cv2 / h5py / PIL are absent here); stub those modules -- none of
+    the methods pinned below touches them -- and import the real class."""
+    import types
+    for name, attrs in {"data_generator": [], "data_generator.object_detection_2d_data_generator": ["DataGenerator"],
+                        "data_generator.object_detection_2d_geometric_ops": ["Resize"],
+                        "data_generator.object_detection_2d_patch_sampling_ops": ["RandomPadFixedAR"],
+                        "data_generator.object_detection_2d_photometric_ops": ["ConvertTo3Channels"],
+                        "data_generator.object_detection_2d_misc_utils": ["apply_inverse_transforms"]}.items():
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, type(a, (), {}))
+            sys.modules[name] = m
+    from eval_utils.average_precision_evaluator import Evaluator
+    return Evaluator
+
+
+def make_eval_case(seed, n_images=40, n_classes=4, neutral=True, int_labels=True, empty_last_class=False):
+    """Synthetic detection results + ground truth: jittered copies of the boxes (duplicates), random false positives,
+    two-decimal confidences (plenty of ties), images without boxes, optional 'difficult' flags.  Labels are integer arrays, as
+    the reference's dataset parsers produce them (get_num_gt_per_class indexes an array with the class id, :525)."""
+    rng = np.random.RandomState(seed)
+    labels, neutrals, image_ids = [], [], []
+    preds = [[] for _ in range(n_classes + 1)]
+    for i in range(n_images):
+        image_ids.append("%06d" % (i * 7 + 3))
+        g = int(rng.randint(0, 7)) if i % 9 else 0
+        cls = rng.randint(1, n_classes + 1, size=g)
+        x0 = rng.uniform(0, 200, size=g); y0 = rng.uniform(0, 200, size=g)
+        w = rng.uniform(10, 90, size=g); h = rng.uniform(10, 90, size=g)
+        lab = np.stack([cls.astype(np.float64), x0, y0, x0 + w, y0 + h], axis=1) if g else np.zeros((0, 5))
+        if int_labels:
+            lab = np.round(lab).astype(np.int64)
+        labels.append(lab)
+        neutrals.append(rng.uniform(size=g) < 0.25)
+        for b in lab:
+            for _ in range(int(rng.randint(0, 4))):                      # 0-3 detections per object -> duplicates
+                jit = rng.normal(0, 6, size=4)
+                c = int(b[0]) if rng.uniform() < 0.85 else int(rng.randint(1, n_classes + 1))
+                preds[c].append((image_ids[-1], float(np.round(rng.uniform(0.02, 1.0), 2)), float(b[1] + jit[0]), float(b[2] + jit[1]),
+                                 float(b[3] + jit[2]), float(b[4] + jit[3])))
+        for _ in range(int(rng.randint(0, 5))):                          # background detections
+            c = int(rng.randint(1, n_classes + 1))
+            x, y = rng.uniform(0, 250, size=2)
+            preds[c].append((image_ids[-1], float(np.round(rng.uniform(0.02, 0.6), 2)), float(x), float(y), float(x + rng.uniform(5, 60)),
+                             float(y + rng.uniform(5, 60))))
+    if empty_last_class:
+        preds[n_classes] = []
+    return labels, (neutrals if neutral else None), image_ids, preds
+
+
+def gen_evaluator():
+    import contextlib
+    import io
+    Evaluator = _import_reference_evaluator()
+    out = {}
+    cases = [dict(seed=1, neutral=True, ignore=True, thr=0.5, bp="include"), dict(seed=2, neutral=True, ignore=False, thr=0.5, bp="half"),
+             dict(seed=3, neutral=False, ignore=True, thr=0.3, bp="exclude"), dict(seed=4, neutral=True, ignore=True, thr=0.75, bp="include"),
+             # a class without predictions: the reference then leaves its cumulative lists one entry short (:616-620) and
+             # compute_precision_recall raises IndexError -- only match_predictions is pinned for this case
+             dict(seed=5, neutral=True, ignore=True, thr=0.5, bp="include", empty_last_class=True)]
+    for ci, case in enumerate(cases):
+        labels, neutrals, image_ids, preds = make_eval_case(case["seed"], neutral=case["neutral"], empty_last_class=case.get("empty_last_class", False))
+        gen = type("Gen", (), {})()
+        gen.labels, gen.eval_neutral, gen.image_ids = labels, neutrals, image_ids
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev = Evaluator(model=None, n_classes=4, data_generator=gen)
+        ev.prediction_results = preds
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink), np.errstate(divide="ignore", invalid="ignore"):
+            num_gt = ev.get_num_gt_per_class(ignore_neutral_boxes=case["ignore"], verbose=False, ret=True)
+            tp, fp, ctp, cfp = ev.match_predictions(ignore_neutral_boxes=case["ignore"], matching_iou_threshold=case["thr"],
+                                                    border_pixels=case["bp"], sorting_algorithm="mergesort", verbose=True, ret=True)
+            if case.get("empty_last_class"):
+                prec, rec, ap_s, ap_i, map_s, map_i = [[]], [[]], [0.0], [0.0], 0.0, 0.0
+            else:
+                prec, rec = ev.compute_precision_recall(verbose=False, ret=True)
+                ap_s = ev.compute_average_precisions(mode="sample", num_recall_points=11, verbose=False, ret=True)
+                map_s = ev.compute_mean_average_precision(ret=True)
+                ap_i = ev.compute_average_precisions(mode="integrate", verbose=False, ret=True)
+                map_i = ev.compute_mean_average_precision(ret=True)
+        pre = "e%d_" % ci
+        lab_cat, lab_off = ragged(labels, 5)
+        out[pre + "labels"], out[pre + "labels_off"] = lab_cat, lab_off
+        out[pre + "neutral"] = np.concatenate([np.asarray(n, dtype=np.uint8) for n in neutrals]) if neutrals is not None else np.zeros((0,), np.uint8)
+        out[pre + "has_neutral"] = np.array(int(neutrals is not None))
+        out[pre + "image_ids"] = np.array(image_ids)
+        out[pre + "params"] = np.array(repr(case))
+        out[pre + "num_gt"] = np.asarray(num_gt)
+        for c in range(1, 5):
+            pc = preds[c]
+            out[pre + "c%d_pred_img" % c] = np.array([q[0] for q in pc]) if pc else np.zeros((0,), dtype="U6")
+            out[pre + "c%d_pred" % c] = np.array([q[1:] for q in pc], dtype=np.float64).reshape(-1, 5)
+            out[pre + "c%d_tp" % c], out[pre + "c%d_fp" % c] = np.asarray(tp[c]), np.asarray(fp[c])
+            # classes without predictions get no cumulative / precision entries in the reference (:616-620 `continue`)
+            if len(pc):
+                out[pre + "c%d_ctp" % c], out[pre + "c%d_cfp" % c] = np.asarray(ctp[c]), np.asarray(cfp[c])
+        out[pre + "ap_sample"], out[pre + "ap_integrate"] = np.asarray(ap_s, dtype=np.float64), np.asarray(ap_i, dtype=np.float64)
+        out[pre + "map_sample"], out[pre + "map_integrate"] = np.array(map_s), np.array(map_i)
+        out[pre + "n_prec"] = np.array(len(prec))
+        for c in range(1, len(prec)):
+            out[pre + "c%d_prec" % c], out[pre + "c%d_rec" % c] = np.asarray(prec[c], dtype=np.float64), np.asarray(rec[c], dtype=np.float64)
+    out["n_cases"] = np.array(len(cases))
+    save("evaluator", **out)
+
+
 def gen_anchors():
     out = {}
     for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
@@ -332,6 +441,7 @@ def gen_decoder():
 if __name__ == "__main__":
     gen_box_utils()
     gen_box_utils2()
+    gen_evaluator()
     gen_anchors()
     gen_encoder()
     gen_decoder()

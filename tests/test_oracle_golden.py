@@ -255,3 +255,41 @@ def test_box_utils2_matching():
         assert np.array_equal(g, z["match_multi_gt_%d" % i]) and np.array_equal(a, z["match_multi_anchor_%d" % i])
         i += 1
     assert i == 6
+
+
+def _eval_case(z, ci):
+    pre = "e%d_" % ci
+    labels = [a.astype(np.int64) for a in util.unragged(z[pre + "labels"], z[pre + "labels_off"])]
+    neutral = None
+    if int(z[pre + "has_neutral"]):
+        flat, off = z[pre + "neutral"].astype(bool), z[pre + "labels_off"]
+        neutral = [flat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    image_ids = [str(s) for s in z[pre + "image_ids"]]
+    preds = [[]]
+    for c in range(1, 5):
+        img, rows = z[pre + "c%d_pred_img" % c], z[pre + "c%d_pred" % c]
+        preds.append([(str(img[k]),) + tuple(float(v) for v in rows[k]) for k in range(rows.shape[0])])
+    return pre, labels, neutral, image_ids, preds, ast.literal_eval(str(z[pre + "params"]))
+
+
+def test_evaluator_matching_and_average_precision():
+    z = util.load("evaluator")
+    for ci in range(int(z["n_cases"])):
+        pre, labels, neutral, image_ids, preds, case = _eval_case(z, ci)
+        num_gt = orc.evaluator_num_gt_per_class(labels, neutral, 4, 0, case["ignore"])
+        assert np.array_equal(num_gt, z[pre + "num_gt"])
+        tp, fp, ctp, cfp = orc.evaluator_match_predictions(preds, labels, image_ids, neutral, 4, ignore_neutral_boxes=case["ignore"],
+                                                           matching_iou_threshold=case["thr"], border_pixels=case["bp"])
+        for c in range(1, 5):
+            assert np.array_equal(tp[c], z[pre + "c%d_tp" % c]) and np.array_equal(fp[c], z[pre + "c%d_fp" % c]), (ci, c)
+            if len(preds[c]):
+                assert np.array_equal(ctp[c], z[pre + "c%d_ctp" % c]) and np.array_equal(cfp[c], z[pre + "c%d_cfp" % c])
+        if case.get("empty_last_class"):
+            continue
+        prec, rec = orc.evaluator_precision_recall(ctp, cfp, num_gt)
+        for c in range(1, 5):
+            assert np.array_equal(prec[c], z[pre + "c%d_prec" % c]) and np.array_equal(rec[c], z[pre + "c%d_rec" % c])
+        for mode in ("sample", "integrate"):
+            ap = np.asarray(orc.evaluator_average_precisions(prec, rec, mode=mode), dtype=np.float64)
+            assert np.array_equal(ap, z[pre + "ap_" + mode]), (ci, mode)
+            assert np.mean(ap[1:]) == float(z[pre + "map_" + mode])
