@@ -1,0 +1,102 @@
+"""Keras-layout weights <-> the PyTorch SSD modules.
+
+The reference ships weights as Keras HDF5 files (`model.load_weights(path, by_name=True)`, ssd300_training.ipynb:120-140)
+whose layers are named exactly like the layers in models/keras_ssd300.py:274-361 (`conv1_1` ... `conv9_2`, `fc6`, `fc7`,
+`conv4_3_norm`, `<source>_mbox_conf`, `<source>_mbox_loc`; keras_ssd512.py adds `conv10_1/2`; keras_ssd7.py uses
+`conv1..7`, `bn1..7`, `classes4..7`, `boxes4..7`).  Layouts differ: a Keras Conv2D kernel is HWIO `(kh, kw, in, out)`,
+torch's is OIHW; BatchNormalization stores `gamma, beta, moving_mean, moving_variance`.
+
+`keras_layer_map(model)` gives name -> list of (parameter/buffer, to_torch, to_keras) in Keras' `weight_names` order;
+`load_keras_weights(model, source)` takes either a `{layer_name: [arrays in Keras order]}` dict or the path of a Keras
+`.h5` weight file (needs h5py, which is not installed in every environment: ImportError says so);
+`export_keras_weights(model)` is the inverse (dict).  `by_name` semantics as in Keras: layers missing from the source keep
+their initialisation, layers whose shapes do not match raise ValueError.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def _conv(c):
+    items = [(c.weight, lambda a: np.transpose(a, (3, 2, 0, 1)), lambda t: np.transpose(t, (2, 3, 1, 0)))]
+    if c.bias is not None:
+        items.append((c.bias, lambda a: a, lambda t: t))
+    return items
+
+
+def _bn(b):
+    ident = (lambda a: a, lambda t: t)
+    return [(b.weight,) + ident, (b.bias,) + ident, (b.running_mean,) + ident, (b.running_var,) + ident]
+
+
+def keras_layer_map(model):
+    """Keras layer name -> [(tensor, keras->torch, torch->keras), ...] for every weighted layer of an SSD300 / SSD512 / SSD7."""
+    from .keras_ssd7 import SSD7
+    m = {}
+    if isinstance(model, SSD7):
+        for i in range(7):
+            m["conv%d" % (i + 1)] = _conv(model.convs[i])
+            m["bn%d" % (i + 1)] = _bn(model.bns[i])
+        for i in range(4):
+            m["classes%d" % (i + 4)] = _conv(model.conf_heads[i])
+            m["boxes%d" % (i + 4)] = _conv(model.loc_heads[i])
+        return m
+    for name, mod in model.named_children():
+        if isinstance(mod, torch.nn.Conv2d):
+            m[name] = _conv(mod)                               # conv1_1 ... conv10_2, fc6, fc7: attribute names == Keras names
+    m["conv4_3_norm"] = [(model.conv4_3_norm.gamma, lambda a: a, lambda t: t)]
+    for i, src in enumerate(model.NAMES):
+        m[src + "_mbox_conf"] = _conv(model.conf_heads[i])
+        m[src + "_mbox_loc"] = _conv(model.loc_heads[i])
+    return m
+
+
+def _read_h5(path):
+    try:
+        import h5py
+    except ImportError as e:                                     # pragma: no cover - depends on the environment
+        raise ImportError("reading Keras .h5 weight files needs h5py, which is not installed here; pass a "
+                          "{layer_name: [arrays]} dict instead (e.g. from np.load of a converted file)") from e
+    out = {}
+    with h5py.File(path, "r") as f:
+        g = f["model_weights"] if "model_weights" in f else f
+        names = [n.decode() if isinstance(n, bytes) else n for n in g.attrs["layer_names"]]
+        for name in names:
+            wn = [n.decode() if isinstance(n, bytes) else n for n in g[name].attrs["weight_names"]]
+            if wn:
+                out[name] = [np.asarray(g[name][w]) for w in wn]
+    return out
+
+
+def load_keras_weights(model, source, by_name=True, strict_shapes=True):
+    """Load Keras-layout weights into `model` (in place).  Returns (loaded layer names, model layers absent from the source)."""
+    weights = _read_h5(source) if isinstance(source, str) else source
+    lm = keras_layer_map(model)
+    if not by_name and set(weights) != set(lm):
+        raise ValueError("by_name=False needs exactly the model's layers; differing: {}".format(sorted(set(weights) ^ set(lm))))
+    loaded, missing = [], []
+    with torch.no_grad():
+        for name, items in lm.items():
+            if name not in weights:
+                missing.append(name)
+                continue
+            arrays = weights[name]
+            if len(arrays) != len(items):
+                raise ValueError("layer '{}' expects {} weight arrays, the source has {}".format(name, len(items), len(arrays)))
+            for (tensor, to_torch, _), a in zip(items, arrays):
+                v = np.ascontiguousarray(to_torch(np.asarray(a)))
+                if tuple(v.shape) != tuple(tensor.shape):
+                    if strict_shapes:
+                        raise ValueError("layer '{}': source shape {} does not fit parameter shape {}".format(
+                            name, tuple(np.asarray(a).shape), tuple(tensor.shape)))
+                    continue
+                tensor.copy_(torch.from_numpy(v).to(tensor.dtype))
+            loaded.append(name)
+    return loaded, missing
+
+
+def export_keras_weights(model):
+    """{Keras layer name: [arrays in Keras layout and order]} (float32 NumPy)."""
+    return {name: [np.ascontiguousarray(to_keras(t.detach().float().cpu().numpy())) for t, _, to_keras in items]
+            for name, items in keras_layer_map(model).items()}

@@ -128,3 +128,48 @@ def test_layers_and_models_on_cpu():
         ssd_300((300, 300, 3), 20, mode="bogus", scales=syn.SSD300_VOC["scales"])
     with pytest.raises(ValueError):
         ssd_300((300, 300, 3), 20)                                   # neither scales nor min/max scale
+
+
+def test_keras_weight_layout_round_trip():
+    """models/keras_weights.py: Keras layer names + HWIO kernels <-> the torch modules (SSD300 and SSD7), by_name semantics."""
+    import numpy as np
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.models.keras_ssd7 import build_model
+    from ssd_keras_amd.models.keras_weights import export_keras_weights, keras_layer_map, load_keras_weights
+    torch.manual_seed(0)
+    sc = [0.1, 0.2, 0.37, 0.54, 0.71, 0.88, 1.05]
+    a = ssd_300((300, 300, 3), 20, mode="training", scales=sc)
+    names = set(keras_layer_map(a))
+    expect = {"conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1",
+              "conv5_2", "conv5_3", "fc6", "fc7", "conv6_1", "conv6_2", "conv7_1", "conv7_2", "conv8_1", "conv8_2", "conv9_1", "conv9_2",
+              "conv4_3_norm"} | {s + t for s in ("conv4_3_norm", "fc7", "conv6_2", "conv7_2", "conv8_2", "conv9_2") for t in ("_mbox_conf", "_mbox_loc")}
+    assert names == expect                                     # the layer names of models/keras_ssd300.py:274-361
+    w = export_keras_weights(a)
+    assert w["conv1_1"][0].shape == (3, 3, 3, 64) and w["fc6"][0].shape == (3, 3, 512, 1024) and w["conv4_3_norm"][0].shape == (512,)
+    assert w["conv4_3_norm_mbox_conf"][0].shape == (3, 3, 512, 4 * 21)
+    # a Keras kernel element [kh, kw, ci, co] is the torch weight [co, ci, kh, kw]
+    assert w["conv2_1"][0][1, 2, 5, 7] == a.conv2_1.weight[7, 5, 1, 2].item()
+    torch.manual_seed(1)
+    b = ssd_300((300, 300, 3), 20, mode="training", scales=sc)
+    part = {k: v for k, v in w.items() if not k.startswith("conv9")}          # by_name: missing layers keep their init
+    keep = b.conv9_1.weight.clone()
+    loaded, missing = load_keras_weights(b, part)
+    assert sorted(missing) == ["conv9_1", "conv9_2", "conv9_2_mbox_conf", "conv9_2_mbox_loc"] and torch.equal(b.conv9_1.weight, keep)
+    assert torch.equal(a.conv3_2.weight, b.conv3_2.weight) and torch.equal(a.conv4_3_norm.gamma, b.conv4_3_norm.gamma)
+    assert torch.equal(a.loc_heads[1].bias, b.loc_heads[1].bias)
+    bad = dict(w)
+    bad["fc7"] = [w["fc7"][0][:, :, :, :10], w["fc7"][1][:10]]
+    with pytest.raises(ValueError):
+        load_keras_weights(b, bad)
+    # SSD7 incl. BatchNormalization statistics; loaded model computes the same function
+    s1 = build_model((64, 64, 3), 3, scales=[0.1, 0.3, 0.5, 0.7, 0.9]).eval()
+    for bn in s1.bns:
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    s2 = build_model((64, 64, 3), 3, scales=[0.1, 0.3, 0.5, 0.7, 0.9]).eval()
+    loaded, missing = load_keras_weights(s2, export_keras_weights(s1), by_name=False)
+    assert not missing and "bn3" in loaded and "classes5" in loaded
+    x = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(2, 64, 64, 3)).astype(np.float32))
+    with torch.no_grad():
+        assert torch.equal(s1(x), s2(x))
