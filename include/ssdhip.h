@@ -256,6 +256,18 @@ int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* 
 int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                          int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 
+/* DecodeDetections straight from the predictor heads: the arguments of ssdhip_assemble_predictions_strided_bf16
+ * followed by those of ssdhip_decode_detections.  The [C+12]-float prediction rows are built in LDS (bias, softmax, anchors) and
+ * decoded / thresholded at once; y_pred is never written.  Results are identical to assembling and then decoding. */
+int ssdhip_decode_from_heads(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                             const void* const* conf_bias_h, const void* const* loc_bias_h,
+                             const int* n_anchors_h, const int* n_boxes_h, const int* conf_stride_h,
+                             const int* loc_stride_h, const float* anchors_var, int B, int N, int C,
+                             double conf_thresh, double iou_thresh, int top_k, int nms_cap, int class_agnostic,
+                             int semantics, int coords, int normalize_coords, double img_height, double img_width,
+                             int border_pixels, void* out, int out_dtype, int out_rows, int* out_count,
+                             int* out_anchor_idx, void* ws, size_t ws_bytes, void* stream);
+
 /* The same convolution followed by MaxPooling2D(pool_size 2, strides 2, padding 'same') in ONE kernel (conv1_2 -> pool1,
  * conv2_2 -> pool2, conv3_3 -> pool3 of models/keras_ssd300.py:274-290): the 2x2 maximum is taken on the float32 accumulators,
  * then bias, ReLU and one bf16 rounding -- equal to pooling the rounded activations because all three are monotonic.

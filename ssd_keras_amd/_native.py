@@ -287,12 +287,11 @@ def preprocess(images, mean=None, divide=None, swap=None):
     return out.permute(0, 3, 1, 2)
 
 
-def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
-    """Per-layer NHWC conv outputs -> y_pred (B, N, C+12) float32 in one pass (softmax, biases, anchors, concatenation).
-    Layer i is given either as two dense head outputs confs[i] (B, n_boxes*C, h, w), locs[i] (B, n_boxes*4, h, w), or --
-    locs[i] is None -- as ONE wider output confs[i] (B, >= n_boxes*(C+4), h, w) whose channels are [conf | loc | padding]."""
+def _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
+    """Validate the per-layer head outputs and pack them for the C ABI.  Layer i is given either as two dense head outputs
+    confs[i] (B, n_boxes*C, h, w), locs[i] (B, n_boxes*4, h, w), or -- locs[i] is None -- as ONE wider output confs[i]
+    (B, >= n_boxes*(C+4), h, w) whose channels are [conf | loc | padding].  Returns (ctypes argument tuple, keep-alive list, B, N)."""
     torch = _torch()
-    lib = _layers_lib()
     nl = len(confs)
     keep = []
     cp, lp, cbp, lbp, na, cs, ls = [], [], [], [], [], [], []
@@ -300,7 +299,7 @@ def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_
     for i in range(nl):
         cf = nhwc(confs[i])
         if cf.dtype != torch.bfloat16 or not cf.is_cuda:
-            raise SsdHipError("assemble_predictions needs bfloat16 CUDA head outputs")
+            raise SsdHipError("the predictor head outputs must be bfloat16 CUDA tensors")
         b, ch, h, w = cf.shape
         nc, nloc = n_boxes[i] * n_classes, n_boxes[i] * 4
         if locs[i] is None:                                  # packed heads
@@ -321,15 +320,59 @@ def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_
     N = int(sum(na))
     if anchors_var.shape != (N, 8) or anchors_var.dtype != torch.float32:
         raise SsdHipError("anchors_var must be float32 (%d, 8)" % N)
-    y = torch.empty((B, N, n_classes + 12), dtype=torch.float32, device=confs[0].device)
     arr = lambda v: (ctypes.c_void_p * nl)(*v)
     iarr = lambda v: (ctypes.c_int * nl)(*[int(t) for t in v])
+    args = (nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes), iarr(cs), iarr(ls), _ptr(anchors_var))
+    return args, keep, int(B), N
+
+
+def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
+    """Per-layer NHWC conv outputs -> y_pred (B, N, C+12) float32 in one pass (softmax, biases, anchors, concatenation);
+    see `_head_sources` for the accepted layer formats."""
+    torch = _torch()
+    lib = _layers_lib()
+    args, keep, B, N = _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes)
+    y = torch.empty((B, N, n_classes + 12), dtype=torch.float32, device=confs[0].device)
     with torch.cuda.device(y.device):
-        rc = lib.ssdhip_assemble_predictions_strided_bf16(nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes),
-                                                          iarr(cs), iarr(ls), _ptr(anchors_var), B, N, int(n_classes), _ptr(y),
-                                                          current_stream_ptr(y.device))
+        rc = lib.ssdhip_assemble_predictions_strided_bf16(*args, B, N, int(n_classes), _ptr(y), current_stream_ptr(y.device))
     check(rc, "ssdhip_assemble_predictions_strided_bf16")
     return y
+
+
+def decode_from_heads(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes, conf_thresh, iou_thresh, top_k,
+                      nms_cap, class_agnostic, semantics, coords, normalize_coords, img_height, img_width, border_pixels, out_dtype,
+                      out_rows, want_anchor_idx=False):
+    """DecodeDetections straight from the predictor heads' outputs (no y_pred in HBM): `ssdhip_decode_from_heads`.
+    Returns (out (B,out_rows,6), count (B,) int32, anchor_idx or None) exactly as `decode` does for the assembled tensor."""
+    torch = _torch()
+    lib = _layers_lib()
+    if not getattr(lib, "_dfh_bound", False):
+        c_int, c_vp, c_dbl, c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t
+        lib.ssdhip_decode_from_heads.restype = c_int
+        lib.ssdhip_decode_from_heads.argtypes = ([c_int] + [c_vp] * 9 + [c_int, c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
+                                                                       c_int, c_int, c_dbl, c_dbl, c_int, c_vp, c_int, c_int, c_vp, c_vp,
+                                                                       c_vp, c_sz, c_vp])
+        lib._dfh_bound = True
+    args, keep, B, N = _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes)
+    dev = confs[0].device
+    k = int(top_k) if top_k else 0
+    cap = int(nms_cap) if nms_cap else 0
+    need = lib.ssdhip_decode_workspace_bytes(B, N, int(n_classes), k, cap, int(bool(class_agnostic)), F32)
+    if need == 0:
+        raise SsdHipError("unsupported decode shape B=%d N=%d C=%d" % (B, N, n_classes))
+    ws = workspaces.get(dev, "decode", need)
+    out = torch.empty((B, out_rows, 6), dtype=torch.float64 if out_dtype == F64 else torch.float32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    aidx = torch.empty((B, out_rows), dtype=torch.int32, device=dev) if want_anchor_idx else None
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_decode_from_heads(*args, B, N, int(n_classes), float(conf_thresh), float(iou_thresh), k, cap,
+                                          int(bool(class_agnostic)), int(semantics), COORDS[coords], int(bool(normalize_coords)),
+                                          float(img_height if img_height is not None else 1.0),
+                                          float(img_width if img_width is not None else 1.0), BORDER[border_pixels], _ptr(out),
+                                          out_dtype, int(out_rows), _ptr(count), _ptr(aidx), _ptr(ws), ws.numel(),
+                                          current_stream_ptr(dev))
+    check(rc, "ssdhip_decode_from_heads")
+    return out, count, aidx
 
 
 def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):

@@ -27,6 +27,7 @@
 #include "ssdhip.h"
 #include "ssdhip_math.h"
 #include "ssdhip_tile.h"
+#include "ssdhip_heads.h"
 
 // In-kernel phase timers, compiled only into the profiling build (tools/prof_build.sh, -DSSDHIP_PROFILE).
 #ifdef SSDHIP_PROFILE
@@ -96,23 +97,16 @@ __device__ __forceinline__ float decode_center(float off, float var, float a_wh,
     return off * (var * a_wh) + a_c;                                   // ssd_output_decoder.py:177-178
 }
 
-__global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, DecodeParams p,
-                                                   float4* __restrict__ boxes, u64* __restrict__ cand,
-                                                   int* __restrict__ cand_count, unsigned short* __restrict__ cls_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int TA = blockDim.x;                       // anchors per tile = threads per block
-    const int b = blockIdx.y;
-    const int a0 = blockIdx.x * TA;
-    const int na = min(TA, p.N - a0);
+// The body shared by scan_kernel (tile copied from y_pred) and scan_heads_kernel (tile built from the head outputs): `tile`
+// holds rows [a0, a0 + na) of image b as [C+12] floats in LDS, one thread per row; wave_cnt: LDS, (blockDim.x / 64) * G ints.
+__device__ __forceinline__ void scan_tile_body(const float* tile, int* wave_cnt, const DecodeParams& p, const int b, const int a0,
+                                               const int na, float4* __restrict__ boxes, u64* __restrict__ cand,
+                                               int* __restrict__ cand_count, unsigned short* __restrict__ cls_out) {
+    const int TA = blockDim.x;
     const int L = p.L;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = TA >> 6;
-
-    // ---- coalesced tile copy: rows [a0, a0+na) are one contiguous run of na*L floats ----
-    const float* tile = tile_copy_f32(reinterpret_cast<float*>(smem_raw), y + ((size_t)b * p.N + a0) * (size_t)L, na * L, tid, TA);
-    int* wave_cnt = reinterpret_cast<int*>(smem_raw + (((size_t)TA * L + 4) * sizeof(float) + 15) / 16 * 16);
     PROF_DECL
-    __syncthreads();
     PROF_MARK(0)
 
     const bool active = tid < na;
@@ -225,6 +219,38 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
     }
     PROF_MARK(4)
     PROF_FLUSH(16)
+}
+
+__global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, DecodeParams p,
+                                                   float4* __restrict__ boxes, u64* __restrict__ cand,
+                                                   int* __restrict__ cand_count, unsigned short* __restrict__ cls_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int TA = blockDim.x;                       // anchors per tile = threads per block
+    const int b = blockIdx.y;
+    const int a0 = blockIdx.x * TA;
+    const int na = min(TA, p.N - a0);
+    // ---- coalesced tile copy: rows [a0, a0+na) are one contiguous run of na*L floats ----
+    const float* tile = tile_copy_f32(reinterpret_cast<float*>(smem_raw), y + ((size_t)b * p.N + a0) * (size_t)p.L, na * p.L, threadIdx.x, TA);
+    int* wave_cnt = reinterpret_cast<int*>(smem_raw + (((size_t)TA * p.L + 4) * sizeof(float) + 15) / 16 * 16);
+    __syncthreads();
+    scan_tile_body(tile, wave_cnt, p, b, a0, na, boxes, cand, cand_count, cls_out);
+}
+
+// K3 fused with the prediction assembly: the [C+12]-float rows are built in LDS straight from the predictor
+// heads' bf16 outputs (bias, softmax, anchors: head_build_rows) and decoded / thresholded at once -- y_pred (36.9 MB at
+// SSD300 / batch 32, a quarter of it the constant anchor + variance columns) is neither written nor read back.
+__global__ __launch_bounds__(256) void scan_heads_kernel(HeadParams hp, const float* __restrict__ anchors_var, DecodeParams p,
+                                                         float4* __restrict__ boxes, u64* __restrict__ cand,
+                                                         int* __restrict__ cand_count, unsigned short* __restrict__ cls_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int b = blockIdx.y;
+    int l, a0, na;
+    head_tile_of(hp, (int)blockIdx.x, l, a0, na);
+    float* rows = reinterpret_cast<float*>(smem_raw);
+    hbf16_t* cl = reinterpret_cast<hbf16_t*>(smem_raw + (size_t)hp.TA * p.L * sizeof(float));
+    int* wave_cnt = reinterpret_cast<int*>(smem_raw + (head_tile_lds(hp.TA, p.C) + 15) / 16 * 16);
+    head_build_rows(hp, anchors_var, l, b, a0, na, rows, cl, threadIdx.x, blockDim.x);
+    scan_tile_body(rows, wave_cnt, p, b, hp.anchor_off[l] + a0, na, boxes, cand, cand_count, cls_out);
 }
 
 // ======================================================================================
@@ -811,7 +837,13 @@ extern "C" size_t ssdhip_decode_workspace_bytes(int B, int N, int C, int top_k, 
     return decode_ws_layout(B, N, C, top_k, nms_cap, class_agnostic).total;
 }
 
-static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N, int C,
+struct HeadSource {              // non-null: K3 reads the predictor heads instead of y_pred
+    const HeadParams* hp;
+    const float* anchors_var;
+    int tiles;
+};
+
+static int decode_run(const HeadSource* heads, int stages, const void* y_pred, int in_dtype, int B, int N, int C,
                       double conf_thresh, double iou_thresh, int top_k, int nms_cap,
                       int class_agnostic, int semantics,
                       int coords, int normalize_coords, double img_height, double img_width,
@@ -819,7 +851,7 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
                       void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
                       void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!y_pred || !out || !out_count || B <= 0 || N <= 0 || C < 2 || out_rows <= 0) return SSDHIP_E_BADARG;
+    if ((!y_pred && !heads) || !out || !out_count || B <= 0 || N <= 0 || C < 2 || out_rows <= 0) return SSDHIP_E_BADARG;
     if (in_dtype != SSDHIP_F32) return SSDHIP_E_BADARG;           // float64 predictions: not built yet
     if (out_dtype != SSDHIP_F32 && out_dtype != SSDHIP_F64) return SSDHIP_E_BADARG;
     if (N > (1 << IDX_BITS) || C > 1025) return SSDHIP_E_BADARG;
@@ -879,9 +911,17 @@ static int decode_run(int stages, const void* y_pred, int in_dtype, int B, int N
     while (TA > 64 && (size_t)TA * p.L * sizeof(float) > 24 * 1024) TA >>= 1;
     const size_t k3_lds = align_up(((size_t)TA * p.L + 4) * sizeof(float), 16) + (size_t)(TA / 64) * p.G * sizeof(int);
     if (k3_lds > 160 * 1024) return SSDHIP_E_BADARG;
-    dim3 g3((N + TA - 1) / TA, B);
-    hipLaunchKernelGGL(scan_kernel, g3, dim3(TA), k3_lds, stream, static_cast<const float*>(y_pred), p, boxes, cand,
-                       cand_count, cls_map);
+    if (heads) {
+        const int HT = heads->hp->TA;                 // one thread per row of the head tile
+        const size_t lds = (head_tile_lds(HT, C) + 15) / 16 * 16 + (size_t)((HT + 63) / 64) * p.G * sizeof(int);
+        if (lds > 160 * 1024) return SSDHIP_E_BADARG;
+        hipLaunchKernelGGL(scan_heads_kernel, dim3(heads->tiles, B), dim3(HT < 64 ? 64 : HT), lds, stream, *heads->hp,
+                           heads->anchors_var, p, boxes, cand, cand_count, cls_map);
+    } else {
+        dim3 g3((N + TA - 1) / TA, B);
+        hipLaunchKernelGGL(scan_kernel, g3, dim3(TA), k3_lds, stream, static_cast<const float*>(y_pred), p, boxes, cand,
+                           cand_count, cls_map);
+    }
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
 
@@ -913,7 +953,7 @@ extern "C" int ssdhip_decode_detections(const void* y_pred, int in_dtype, int B,
                                         int border_pixels,
                                         void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
                                         void* ws, size_t ws_bytes, void* stream) {
-    return decode_run(7, y_pred, in_dtype, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords,
+    return decode_run(nullptr, 7, y_pred, in_dtype, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords,
                       normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
                       out_anchor_idx, ws, ws_bytes, stream);
 }
@@ -926,7 +966,30 @@ extern "C" int ssdhip_decode_stages(int stages, const void* y_pred, int in_dtype
                                     void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx,
                                     void* ws, size_t ws_bytes, void* stream) {
     if (stages <= 0 || stages > 7) return SSDHIP_E_BADARG;
-    return decode_run(stages, y_pred, in_dtype, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,
+    return decode_run(nullptr, stages, y_pred, in_dtype, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,
+                      coords, normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
+                      out_anchor_idx, ws, ws_bytes, stream);
+}
+
+// DecodeDetections straight from the predictor heads (no y_pred): the arguments of ssdhip_assemble_predictions_strided_bf16
+// followed by those of ssdhip_decode_detections (in_dtype is implied: the rows are built in float32).
+extern "C" int ssdhip_decode_from_heads(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                        const void* const* conf_bias_h, const void* const* loc_bias_h,
+                                        const int* n_anchors_h, const int* n_boxes_h, const int* conf_stride_h,
+                                        const int* loc_stride_h, const float* anchors_var, int B, int N, int C,
+                                        double conf_thresh, double iou_thresh, int top_k, int nms_cap, int class_agnostic,
+                                        int semantics, int coords, int normalize_coords, double img_height, double img_width,
+                                        int border_pixels, void* out, int out_dtype, int out_rows, int* out_count,
+                                        int* out_anchor_idx, void* ws, size_t ws_bytes, void* stream) {
+    if (!anchors_var) return SSDHIP_E_BADARG;
+    HeadParams hp;
+    HeadSource src;
+    src.hp = &hp; src.anchors_var = anchors_var; src.tiles = 0;
+    const int rc = head_fill_params(hp, n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h, conf_stride_h,
+                                    loc_stride_h, N, C, 60 * 1024, &src.tiles);
+    if (rc != SSDHIP_OK) return rc;
+    if (hp.TA < 64) return SSDHIP_E_BADARG;          // C too large for a one-thread-per-row tile
+    return decode_run(&src, 7, nullptr, SSDHIP_F32, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,
                       coords, normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
                       out_anchor_idx, ws, ws_bytes, stream);
 }

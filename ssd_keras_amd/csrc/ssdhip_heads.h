@@ -1,0 +1,131 @@
+// Prediction assembly shared by head_kernel (csrc/ssdhip_layers.hip: rows -> y_pred in HBM) and scan_heads_kernel
+// (csrc/ssdhip_decode.hip: rows stay in LDS and are decoded at once).  Reference: Reshape + Concatenate + softmax + AnchorBoxes
+// + Concatenate, models/keras_ssd300.py:363-419 and keras_layers/keras_layer_AnchorBoxes.py:245-255.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short hbf16_t;
+
+__device__ __forceinline__ float h_bf2f(u32 h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ u32 h_f2bf(float f) {          // round to nearest even, NaN stays NaN (as c10::BFloat16)
+    const u32 u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+constexpr int MAX_PRED_LAYERS = 8;
+struct HeadParams {
+    const hbf16_t* conf[MAX_PRED_LAYERS];
+    const hbf16_t* loc[MAX_PRED_LAYERS];
+    const hbf16_t* conf_bias[MAX_PRED_LAYERS];    // [n_boxes*C] or null
+    const hbf16_t* loc_bias[MAX_PRED_LAYERS];     // [n_boxes*4] or null
+    int n_anchors[MAX_PRED_LAYERS];
+    int n_boxes[MAX_PRED_LAYERS];
+    int conf_stride[MAX_PRED_LAYERS];             // elements between consecutive pixels of the conf / loc source
+    int loc_stride[MAX_PRED_LAYERS];              // (n_boxes*C and n_boxes*4 when the heads are separate, dense tensors)
+    int tile_start[MAX_PRED_LAYERS + 1];          // first tile of layer l
+    int anchor_off[MAX_PRED_LAYERS];
+    int n_layers, N, C, TA;
+};
+
+// LDS bytes of one tile: [TA][C+12] float rows + [TA][C] + [TA][4] bf16 logits
+__host__ __device__ inline size_t head_tile_lds(int TA, int C) { return (size_t)TA * ((C + 12) * sizeof(float) + (C + 4) * sizeof(hbf16_t)); }
+
+// Which layer / anchors the tile `tile_id` of the launch covers.
+__device__ __forceinline__ void head_tile_of(const HeadParams& hp, int tile_id, int& l, int& a0, int& na) {
+    l = 0;
+    while (l + 1 < hp.n_layers && tile_id >= hp.tile_start[l + 1]) ++l;
+    a0 = (tile_id - hp.tile_start[l]) * hp.TA;
+    na = min(hp.TA, hp.n_anchors[l] - a0);
+}
+
+// Builds rows[a][0..C+11] = [softmax(conf + bias) | loc + bias | anchor | variances] for anchors a0..a0+na-1 of layer l, image b.
+// `rows`: [TA][C+12] float in LDS, `cl`: [TA][C] + [TA][4] bf16 staging in LDS.  Ends with a __syncthreads().
+__device__ __forceinline__ void head_build_rows(const HeadParams& hp, const float* __restrict__ anchors_var, int l, int b, int a0, int na,
+                                                float* rows, hbf16_t* cl, int tid, int nthreads) {
+    const int TA = hp.TA, C = hp.C, L = C + 12;
+    hbf16_t* ll = cl + (size_t)TA * C;
+    const int nb = hp.n_boxes[l];
+    if (hp.conf_stride[l] == nb * C && hp.loc_stride[l] == nb * 4) {                    // dense heads: contiguous spans
+        const hbf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
+        const hbf16_t* lsrc = hp.loc[l] + ((size_t)b * hp.n_anchors[l] + a0) * 4;
+        for (int i = tid; i < na * C; i += nthreads) cl[i] = csrc[i];
+        for (int i = tid; i < na * 4; i += nthreads) ll[i] = lsrc[i];
+    } else {                                                                            // heads packed into one wider conv output
+        const size_t px0 = (size_t)b * (hp.n_anchors[l] / nb);
+        for (int i = tid; i < na * C; i += nthreads) {
+            const int ga = a0 + i / C, c = i % C;
+            cl[i] = hp.conf[l][(px0 + ga / nb) * hp.conf_stride[l] + (ga % nb) * C + c];
+        }
+        for (int i = tid; i < na * 4; i += nthreads) {
+            const int ga = a0 + (i >> 2), k = i & 3;
+            ll[i] = hp.loc[l][(px0 + ga / nb) * hp.loc_stride[l] + (ga % nb) * 4 + k];
+        }
+    }
+    __syncthreads();
+    for (int a = tid; a < na; a += nthreads) {
+        const int box = (a0 + a) % nb;
+        float* r = rows + (size_t)a * L;
+        const hbf16_t* cb = hp.conf_bias[l] ? hp.conf_bias[l] + box * C : nullptr;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            // the PyTorch path rounds conv + bias to bf16 before the float32 softmax: keep that rounding
+            const float v = cb ? h_bf2f(h_f2bf(h_bf2f(cl[a * C + c]) + h_bf2f(cb[c]))) : h_bf2f(cl[a * C + c]);
+            r[c] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) { const float e = expf(r[c] - mx); r[c] = e; sum += e; }
+        for (int c = 0; c < C; ++c) r[c] = r[c] / sum;
+        const hbf16_t* lb = hp.loc_bias[l] ? hp.loc_bias[l] + box * 4 : nullptr;
+        for (int k = 0; k < 4; ++k) r[C + k] = lb ? h_bf2f(h_f2bf(h_bf2f(ll[a * 4 + k]) + h_bf2f(lb[k]))) : h_bf2f(ll[a * 4 + k]);
+        const float* av = anchors_var + (size_t)(hp.anchor_off[l] + a0 + a) * 8;
+        for (int k = 0; k < 8; ++k) r[C + 4 + k] = av[k];
+    }
+    __syncthreads();
+}
+
+// Host side: validate the per-layer arrays of the C ABI and fill HeadParams.  Returns SSDHIP_OK or SSDHIP_E_BADARG; *tiles_out =
+// number of tiles (grid.x), hp.TA = anchors per tile such that head_tile_lds(TA, C) + extra_lds_per_tile fits max_lds bytes.
+static inline int head_fill_params(HeadParams& hp, int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                   const void* const* conf_bias_h, const void* const* loc_bias_h, const int* n_anchors_h,
+                                   const int* n_boxes_h, const int* conf_stride_h, const int* loc_stride_h, int N, int C,
+                                   size_t max_lds, int* tiles_out) {
+    if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !conf_h || !loc_h || !n_anchors_h || !n_boxes_h || N <= 0 || C < 2 || C > 1024)
+        return SSDHIP_E_BADARG;
+    int TA = 256;
+    while (TA > 32 && head_tile_lds(TA, C) > max_lds) TA >>= 1;
+    hp.n_layers = n_layers; hp.N = N; hp.C = C; hp.TA = TA;
+    int off = 0, tiles = 0;
+    for (int l = 0; l < MAX_PRED_LAYERS; ++l) {
+        const bool on = l < n_layers;
+        hp.conf[l] = on ? static_cast<const hbf16_t*>(conf_h[l]) : nullptr;
+        hp.loc[l] = on ? static_cast<const hbf16_t*>(loc_h[l]) : nullptr;
+        hp.conf_bias[l] = (on && conf_bias_h) ? static_cast<const hbf16_t*>(conf_bias_h[l]) : nullptr;
+        hp.loc_bias[l] = (on && loc_bias_h) ? static_cast<const hbf16_t*>(loc_bias_h[l]) : nullptr;
+        hp.n_anchors[l] = on ? n_anchors_h[l] : 0;
+        hp.n_boxes[l] = on ? n_boxes_h[l] : 1;
+        hp.conf_stride[l] = on ? (conf_stride_h ? conf_stride_h[l] : n_boxes_h[l] * C) : 0;
+        hp.loc_stride[l] = on ? (loc_stride_h ? loc_stride_h[l] : n_boxes_h[l] * 4) : 0;
+        hp.tile_start[l] = tiles;
+        hp.anchor_off[l] = off;
+        if (on) {
+            if (!hp.conf[l] || !hp.loc[l] || hp.n_anchors[l] <= 0 || hp.n_boxes[l] <= 0 || hp.n_anchors[l] % hp.n_boxes[l]) return SSDHIP_E_BADARG;
+            if (hp.conf_stride[l] < hp.n_boxes[l] * C || hp.loc_stride[l] < hp.n_boxes[l] * 4) return SSDHIP_E_BADARG;
+            off += hp.n_anchors[l];
+            tiles += (hp.n_anchors[l] + TA - 1) / TA;
+        }
+    }
+    hp.tile_start[MAX_PRED_LAYERS] = tiles;
+    if (off != N) return SSDHIP_E_BADARG;
+    *tiles_out = tiles;
+    return SSDHIP_OK;
+}
+
+}  // namespace ssdhip

@@ -15,6 +15,7 @@
 
 #include "ssdhip.h"
 #include "ssdhip_math.h"
+#include "ssdhip_heads.h"
 
 namespace ssdhip {
 
@@ -148,69 +149,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
 //   y_pred[b, off_l + a, :] = [softmax(conf + bias) (C) | loc + bias (4) | anchor (4) | variances (4)]  float32
 // grid (tiles over all layers, B); a tile = TA anchors of one layer; rows are built in LDS and stored coalesced.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int MAX_PRED_LAYERS = 8;
-struct HeadParams {
-    const bf16_t* conf[MAX_PRED_LAYERS];
-    const bf16_t* loc[MAX_PRED_LAYERS];
-    const bf16_t* conf_bias[MAX_PRED_LAYERS];     // [n_boxes*C] or null
-    const bf16_t* loc_bias[MAX_PRED_LAYERS];      // [n_boxes*4] or null
-    int n_anchors[MAX_PRED_LAYERS];
-    int n_boxes[MAX_PRED_LAYERS];
-    int conf_stride[MAX_PRED_LAYERS];             // elements between consecutive pixels of the conf / loc source
-    int loc_stride[MAX_PRED_LAYERS];              // (n_boxes*C and n_boxes*4 when the heads are separate, dense tensors)
-    int tile_start[MAX_PRED_LAYERS + 1];          // first tile of layer l
-    int anchor_off[MAX_PRED_LAYERS];
-    int n_layers, N, C, TA;
-};
-
 __global__ __launch_bounds__(256) void head_kernel(HeadParams hp, const float* __restrict__ anchors_var, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, b = blockIdx.y, TA = hp.TA, C = hp.C, L = C + 12;
-    int l = 0;
-    while (l + 1 < hp.n_layers && (int)blockIdx.x >= hp.tile_start[l + 1]) ++l;
-    const int a0 = ((int)blockIdx.x - hp.tile_start[l]) * TA;
-    const int na = min(TA, hp.n_anchors[l] - a0);
+    const int tid = threadIdx.x, b = blockIdx.y, L = hp.C + 12;
+    int l, a0, na;
+    head_tile_of(hp, (int)blockIdx.x, l, a0, na);
     float* rows = reinterpret_cast<float*>(smem_raw);                                   // [TA][L]
-    bf16_t* cl = reinterpret_cast<bf16_t*>(smem_raw + (size_t)TA * L * sizeof(float));  // [TA][C] logits, then [TA][4]
-    bf16_t* ll = cl + (size_t)TA * C;
-    const int nb = hp.n_boxes[l];
-    if (hp.conf_stride[l] == nb * C && hp.loc_stride[l] == nb * 4) {                    // dense heads: contiguous spans
-        const bf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
-        const bf16_t* lsrc = hp.loc[l] + ((size_t)b * hp.n_anchors[l] + a0) * 4;
-        for (int i = tid; i < na * C; i += 256) cl[i] = csrc[i];
-        for (int i = tid; i < na * 4; i += 256) ll[i] = lsrc[i];
-    } else {                                                                            // heads packed into one wider conv output
-        const size_t px0 = (size_t)b * (hp.n_anchors[l] / nb);
-        for (int i = tid; i < na * C; i += 256) {
-            const int ga = a0 + i / C, c = i % C;
-            cl[i] = hp.conf[l][(px0 + ga / nb) * hp.conf_stride[l] + (ga % nb) * C + c];
-        }
-        for (int i = tid; i < na * 4; i += 256) {
-            const int ga = a0 + (i >> 2), k = i & 3;
-            ll[i] = hp.loc[l][(px0 + ga / nb) * hp.loc_stride[l] + (ga % nb) * 4 + k];
-        }
-    }
-    __syncthreads();
-    for (int a = tid; a < na; a += 256) {
-        const int box = (a0 + a) % nb;
-        float* r = rows + (size_t)a * L;
-        const bf16_t* cb = hp.conf_bias[l] ? hp.conf_bias[l] + box * C : nullptr;
-        float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) {
-            // the PyTorch path rounds conv + bias to bf16 before the float32 softmax: keep that rounding
-            const float v = cb ? bf2f(f2bf(bf2f(cl[a * C + c]) + bf2f(cb[c]))) : bf2f(cl[a * C + c]);
-            r[c] = v;
-            mx = fmaxf(mx, v);
-        }
-        float sum = 0.f;
-        for (int c = 0; c < C; ++c) { const float e = expf(r[c] - mx); r[c] = e; sum += e; }
-        for (int c = 0; c < C; ++c) r[c] = r[c] / sum;
-        const bf16_t* lb = hp.loc_bias[l] ? hp.loc_bias[l] + box * 4 : nullptr;
-        for (int k = 0; k < 4; ++k) r[C + k] = lb ? bf2f(f2bf(bf2f(ll[a * 4 + k]) + bf2f(lb[k]))) : bf2f(ll[a * 4 + k]);
-        const float* av = anchors_var + (size_t)(hp.anchor_off[l] + a0 + a) * 8;
-        for (int k = 0; k < 8; ++k) r[C + 4 + k] = av[k];
-    }
-    __syncthreads();
+    hbf16_t* cl = reinterpret_cast<hbf16_t*>(smem_raw + (size_t)hp.TA * L * sizeof(float));
+    head_build_rows(hp, anchors_var, l, b, a0, na, rows, cl, tid, 256);
     float* dst = y + ((size_t)b * hp.N + hp.anchor_off[l] + a0) * L;
     for (int i = tid; i < na * L; i += 256) dst[i] = rows[i];
 }
@@ -285,38 +231,13 @@ extern "C" int ssdhip_assemble_predictions_strided_bf16(int n_layers, const void
                                                         const float* anchors_var, int B, int N, int C, float* y_pred,
                                                         void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !conf_h || !loc_h || !n_anchors_h || !n_boxes_h || !anchors_var || !y_pred ||
-        B <= 0 || N <= 0 || C < 2 || C > 1024)
-        return SSDHIP_E_BADARG;
+    if (!anchors_var || !y_pred || B <= 0) return SSDHIP_E_BADARG;
     HeadParams hp;
-    const int L = C + 12;
-    int TA = 256;
-    while (TA > 32 && (size_t)TA * (L * sizeof(float) + (C + 4) * sizeof(bf16_t)) > 60 * 1024) TA >>= 1;
-    hp.n_layers = n_layers; hp.N = N; hp.C = C; hp.TA = TA;
-    int off = 0, tiles = 0;
-    for (int l = 0; l < MAX_PRED_LAYERS; ++l) {
-        const bool on = l < n_layers;
-        hp.conf[l] = on ? static_cast<const bf16_t*>(conf_h[l]) : nullptr;
-        hp.loc[l] = on ? static_cast<const bf16_t*>(loc_h[l]) : nullptr;
-        hp.conf_bias[l] = (on && conf_bias_h) ? static_cast<const bf16_t*>(conf_bias_h[l]) : nullptr;
-        hp.loc_bias[l] = (on && loc_bias_h) ? static_cast<const bf16_t*>(loc_bias_h[l]) : nullptr;
-        hp.n_anchors[l] = on ? n_anchors_h[l] : 0;
-        hp.n_boxes[l] = on ? n_boxes_h[l] : 1;
-        hp.conf_stride[l] = on ? (conf_stride_h ? conf_stride_h[l] : n_boxes_h[l] * C) : 0;
-        hp.loc_stride[l] = on ? (loc_stride_h ? loc_stride_h[l] : n_boxes_h[l] * 4) : 0;
-        hp.tile_start[l] = tiles;
-        hp.anchor_off[l] = off;
-        if (on) {
-            if (!hp.conf[l] || !hp.loc[l] || hp.n_anchors[l] <= 0 || hp.n_boxes[l] <= 0 || hp.n_anchors[l] % hp.n_boxes[l]) return SSDHIP_E_BADARG;
-            if (hp.conf_stride[l] < hp.n_boxes[l] * C || hp.loc_stride[l] < hp.n_boxes[l] * 4) return SSDHIP_E_BADARG;
-            off += hp.n_anchors[l];
-            tiles += (hp.n_anchors[l] + TA - 1) / TA;
-        }
-    }
-    hp.tile_start[MAX_PRED_LAYERS] = tiles;
-    if (off != N) return SSDHIP_E_BADARG;
-    const size_t lds = (size_t)TA * (L * sizeof(float) + (C + 4) * sizeof(bf16_t));
-    hipLaunchKernelGGL(head_kernel, dim3(tiles, B), dim3(256), lds, stream, hp, anchors_var, y_pred);
+    int tiles = 0;
+    const int rc = head_fill_params(hp, n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h, conf_stride_h,
+                                    loc_stride_h, N, C, 60 * 1024, &tiles);
+    if (rc != SSDHIP_OK) return rc;
+    hipLaunchKernelGGL(head_kernel, dim3(tiles, B), dim3(256), head_tile_lds(hp.TA, C), stream, hp, anchors_var, y_pred);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -49,6 +49,17 @@ class DecodeDetections(nn.Module):
 
     call = forward
 
+    @torch.no_grad()
+    def forward_from_heads(self, confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
+        """The same layer fed by the predictor heads' bf16 outputs instead of the assembled `(batch, #boxes, #classes + 12)`
+        tensor: bias, softmax, anchors and the decode happen in one kernel (`scan_heads_kernel`), the
+        prediction tensor never exists in HBM.  Same result, bit for bit, as `forward(assembled tensor)`."""
+        out, _, _ = nat.decode_from_heads(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes,
+                                          self.confidence_thresh, self.iou_threshold, self.top_k, self.nms_max_output_size,
+                                          self._class_agnostic, nat.SEM_KERAS, 'centroids', self.normalize_coords, self.img_height,
+                                          self.img_width, 'half', nat.F32, self.top_k)
+        return out
+
     def compute_output_shape(self, input_shape):
         batch_size, n_boxes, last_axis = input_shape
         return (batch_size, self.top_k, 6)

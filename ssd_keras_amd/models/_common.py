@@ -228,7 +228,9 @@ class SSDModel(nn.Module):
     def predictor_sizes(self):
         raise NotImplementedError
 
-    def raw_predictions(self, images):
+    def raw_predictions(self, images, decode=False):
+        """The `(batch, #boxes, #classes + 12)` prediction tensor; with `decode=True` (used by `forward` in the inference modes) the
+        decoded detections, which on the fused bf16 path come straight from the head outputs."""
         x = self.preprocess(images)
         dtype = next(self.parameters()).dtype
         feats = self.features(x.to(dtype) if not torch.is_autocast_enabled() else x)
@@ -245,8 +247,12 @@ class SSDModel(nn.Module):
                                  {"per_layer": lambda: self._heads_per_layer(feats), "grouped": lambda: self._heads_grouped(feats)})
             confs, locs = self._heads_grouped(feats) if how == "grouped" else self._heads_per_layer(feats)
             anchors = self.anchors_and_variances(sizes, x.device)
-            return nat.assemble_predictions(confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
-                                            [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
+            head_args = (confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
+                         [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
+            if decode and self.decoder is not None and self.n_classes <= 81:
+                return self.decoder.forward_from_heads(*head_args)          # y_pred is never materialised
+            pred = nat.assemble_predictions(*head_args)
+            return self.decoder(pred) if (decode and self.decoder is not None) else pred
         confs, locs = [], []
         for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads):
             # NCHW -> NHWC before the reshape so the channel axis splits as (box, class) like Keras (:363-383)
@@ -255,7 +261,8 @@ class SSDModel(nn.Module):
         conf = torch.softmax(torch.cat(confs, dim=1).float(), dim=-1)          # 'mbox_conf_softmax' (:415)
         loc = torch.cat(locs, dim=1).float()
         anchors = self.anchors_and_variances(sizes, conf.device)
-        return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+        pred = torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+        return self.decoder(pred) if (decode and self.decoder is not None) else pred
 
     def _heads_grouped(self, feats):
         outs = nat.conv2d_same_group(list(feats), [self._packed_head_weight(l) for l in range(len(feats))], None, relu=False)
@@ -301,10 +308,7 @@ class SSDModel(nn.Module):
                 and conv.weight.dtype == torch.bfloat16)
 
     def forward(self, images):
-        pred = self.raw_predictions(images)
-        if self.decoder is None:
-            return pred
-        return self.decoder(pred)
+        return self.raw_predictions(images, decode=self.decoder is not None)
 
     predict = forward
 
