@@ -189,6 +189,14 @@ int ssdhip_greedy_nms(const double* rows, int n_rows_total, int row_len, int sco
                       const int* seg_offsets, int n_segments, double iou_threshold, int coords, int border_pixels,
                       int* kept_idx, int* kept_count, void* ws, size_t ws_bytes, void* stream);
 
+/* BoxFilter.__call__ (data_generator/object_detection_2d_image_boxes_validation_utils.py:147-232) for a whole batch: boxes [G,4]
+ * float64 'corners' of all images concatenated, box_image [G] int32 image index of each box, image_hw [n_images,2] float64
+ * (height, width) of the image / patch each box is validated against.  overlap_criterion 0 'center_point', 1 'iou', 2 'area';
+ * keep [G] uint8 = 1 where the box passes every enabled check (degenerate, min_area, overlap within (lower, upper]). */
+int ssdhip_box_filter(const double* boxes, const int* box_image, const double* image_hw, int G, int n_images,
+                      int check_overlap, int check_min_area, int check_degenerate, int overlap_criterion,
+                      double lower, double upper, double min_area, int border_pixels, unsigned char* keep, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Evaluator.match_predictions, one class (eval_utils/average_precision_evaluator.py:604-725).
  *   pred        [P,5] float32 rows confidence, xmin, ymin, xmax, ymax (the reference keeps predictions as 'f4')

@@ -780,3 +780,40 @@ def evaluator_average_precisions(precisions, recalls, mode="sample", num_recall_
             raise ValueError("`mode` can be either 'sample' or 'integrate'")
         aps.append(ap)
     return aps
+
+
+# --------------------------------------------------------------------------------------
+# data_generator/object_detection_2d_image_boxes_validation_utils.py
+# --------------------------------------------------------------------------------------
+def box_filter_mask(labels, image_height, image_width, check_overlap=True, check_min_area=True, check_degenerate=True,
+                    overlap_criterion="center_point", overlap_bounds=(0.3, 1.0), min_area=16, border_pixels="half",
+                    labels_format={"class_id": 0, "xmin": 1, "ymin": 2, "xmax": 3, "ymax": 4}):
+    """BoxFilter.__call__ (:147-232) as a boolean mask over the rows of `labels`."""
+    labels = np.asarray(labels)
+    xmin, ymin, xmax, ymax = (labels_format[k] for k in ("xmin", "ymin", "xmax", "ymax"))
+    ok = np.ones(labels.shape[0], dtype=bool)
+    if labels.shape[0] == 0:
+        return ok
+    if check_degenerate:
+        ok &= (labels[:, xmax] > labels[:, xmin]) & (labels[:, ymax] > labels[:, ymin])
+    if check_min_area:
+        ok &= (labels[:, xmax] - labels[:, xmin]) * (labels[:, ymax] - labels[:, ymin]) >= min_area
+    if check_overlap:
+        lower, upper = overlap_bounds
+        if overlap_criterion == "iou":
+            with np.errstate(divide="ignore", invalid="ignore"):
+                v = iou(np.array([0, 0, image_width, image_height]), labels[:, [xmin, ymin, xmax, ymax]], coords="corners",
+                        mode="element-wise", border_pixels=border_pixels)
+            ok &= (v > lower) & (v <= upper)
+        elif overlap_criterion == "area":
+            d = _BORDER[border_pixels]
+            box_areas = (labels[:, xmax] - labels[:, xmin] + d) * (labels[:, ymax] - labels[:, ymin] + d)
+            cy = np.clip(labels[:, [ymin, ymax]], 0, image_height - 1)
+            cx = np.clip(labels[:, [xmin, xmax]], 0, image_width - 1)
+            inter = (cx[:, 1] - cx[:, 0] + d) * (cy[:, 1] - cy[:, 0] + d)
+            ok &= ((inter > lower * box_areas) if lower == 0.0 else (inter >= lower * box_areas)) & (inter <= upper * box_areas)
+        else:
+            cy = (labels[:, ymin] + labels[:, ymax]) / 2
+            cx = (labels[:, xmin] + labels[:, xmax]) / 2
+            ok &= (cy >= 0.0) & (cy <= image_height - 1) & (cx >= 0.0) & (cx <= image_width - 1)
+    return ok

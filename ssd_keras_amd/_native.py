@@ -687,3 +687,29 @@ def match_predictions_class(pred, pred_image, gt_boxes, gt_offsets, gt_neutral, 
                                           *[_ptr(o) for o in outs], _ptr(ws), ws.numel(), current_stream_ptr(dev))
     check(rc, "ssdhip_match_predictions")
     return tuple(outs)
+
+
+def box_filter(boxes, box_image, image_hw, check_overlap, check_min_area, check_degenerate, criterion, lower, upper, min_area,
+               border_pixels):
+    """Batched BoxFilter: boxes (G,4) float64 corners, box_image (G,) int32, image_hw (n_images,2) float64 -> CUDA uint8 keep mask."""
+    torch = _torch()
+    lib = _boxes_lib()
+    if not getattr(lib, "_bf_bound", False):
+        c_int, c_vp, c_dbl = ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+        lib.ssdhip_box_filter.restype = c_int
+        lib.ssdhip_box_filter.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp]
+        lib._bf_bound = True
+    boxes = to_device(boxes, dtype=torch.float64)
+    dev = boxes.device
+    box_image = to_device(box_image, device=dev, dtype=torch.int32)
+    image_hw = to_device(image_hw, device=dev, dtype=torch.float64)
+    G = int(boxes.shape[0])
+    keep = torch.zeros((G,), dtype=torch.uint8, device=dev)
+    if G == 0:
+        return keep
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_box_filter(_ptr(boxes), _ptr(box_image), _ptr(image_hw), G, int(image_hw.shape[0]), int(bool(check_overlap)),
+                                   int(bool(check_min_area)), int(bool(check_degenerate)), {"center_point": 0, "iou": 1, "area": 2}[criterion],
+                                   float(lower), float(upper), float(min_area), BORDER[border_pixels], _ptr(keep), current_stream_ptr(dev))
+    check(rc, "ssdhip_box_filter")
+    return keep

@@ -343,6 +343,49 @@ __global__ __launch_bounds__(BX_THREADS) void nms_rows_kernel(NmsRowsParams p, c
     if (tid == 0) kept_count[seg] = kept;
 }
 
+// ======================================================================================
+// BoxFilter (data_generator/object_detection_2d_image_boxes_validation_utils.py:147-232), batched: one thread per box
+// ======================================================================================
+struct BoxFilterParams {
+    int check_overlap, check_min_area, check_degenerate, criterion, border;   // criterion 0 'center_point', 1 'iou', 2 'area'
+    double min_area, lower, upper;
+};
+
+__global__ __launch_bounds__(BX_THREADS) void box_filter_kernel(BoxFilterParams q, const double* __restrict__ boxes,
+                                                                const int* __restrict__ box_image, const double* __restrict__ image_hw,
+                                                                int G, unsigned char* __restrict__ keep) {
+    const int g = blockIdx.x * BX_THREADS + threadIdx.x;
+    if (g >= G) return;
+    const double xmin = boxes[(size_t)g * 4], ymin = boxes[(size_t)g * 4 + 1], xmax = boxes[(size_t)g * 4 + 2], ymax = boxes[(size_t)g * 4 + 3];
+    const double H = image_hw[(size_t)box_image[g] * 2], W = image_hw[(size_t)box_image[g] * 2 + 1];
+    bool ok = true;
+    if (q.check_degenerate) ok = ok && (xmax > xmin) && (ymax > ymin);                          // :170-172
+    if (q.check_min_area) ok = ok && ((xmax - xmin) * (ymax - ymin) >= q.min_area);             // :174-176
+    if (q.check_overlap) {
+        const double d = bx_border(q.border);
+        if (q.criterion == 1) {                                                                 // 'iou' :187-192: iou(image, box)
+            PxBox<double> im, bb;
+            im.x0 = 0.0; im.y0 = 0.0; im.x1 = W; im.y1 = H;
+            im.area = box_area<double>(im.x0, im.y0, im.x1, im.y1, d);
+            bb.x0 = xmin; bb.y0 = ymin; bb.x1 = xmax; bb.y1 = ymax;
+            bb.area = box_area<double>(xmin, ymin, xmax, ymax, d);
+            const double v = iou_px<double>(im, bb);
+            ok = ok && (v > q.lower) && (v <= q.upper);
+        } else if (q.criterion == 2) {                                                          // 'area' :193-214
+            const double box_area_ = ((xmax - xmin) + d) * ((ymax - ymin) + d);
+            const double cy0 = np_minimum<double>(np_maximum<double>(ymin, 0.0), H - 1.0), cy1 = np_minimum<double>(np_maximum<double>(ymax, 0.0), H - 1.0);
+            const double cx0 = np_minimum<double>(np_maximum<double>(xmin, 0.0), W - 1.0), cx1 = np_minimum<double>(np_maximum<double>(xmax, 0.0), W - 1.0);
+            const double inter = ((cx1 - cx0) + d) * ((cy1 - cy0) + d);
+            const bool lo = q.lower == 0.0 ? (inter > q.lower * box_area_) : (inter >= q.lower * box_area_);
+            ok = ok && lo && (inter <= q.upper * box_area_);
+        } else {                                                                                // 'center_point' :215-220
+            const double cy = (ymin + ymax) / 2.0, cx = (xmin + xmax) / 2.0;
+            ok = ok && (cy >= 0.0) && (cy <= H - 1.0) && (cx >= 0.0) && (cx <= W - 1.0);
+        }
+    }
+    keep[g] = ok ? 1 : 0;
+}
+
 static inline size_t bx_align(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace ssdhip
@@ -453,5 +496,20 @@ extern "C" int ssdhip_greedy_nms(const double* rows, int n_rows_total, int row_l
     p.n_segments = n_segments; p.iou_threshold = iou_threshold;
     hipLaunchKernelGGL(nms_rows_kernel, dim3(n_segments), dim3(BX_THREADS), 0, stream, p, rows, seg_offsets, box_ws, score_ws, alive,
                        kept_idx, kept_count);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_box_filter(const double* boxes, const int* box_image, const double* image_hw, int G, int n_images,
+                                 int check_overlap, int check_min_area, int check_degenerate, int overlap_criterion,
+                                 double lower, double upper, double min_area, int border_pixels, unsigned char* keep, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (G < 0 || n_images < 0 || overlap_criterion < 0 || overlap_criterion > 2 || border_pixels < 0 || border_pixels > 2) return SSDHIP_E_BADARG;
+    if (G == 0) return SSDHIP_OK;
+    if (!boxes || !box_image || !image_hw || !keep) return SSDHIP_E_BADARG;
+    BoxFilterParams q;
+    q.check_overlap = check_overlap ? 1 : 0; q.check_min_area = check_min_area ? 1 : 0; q.check_degenerate = check_degenerate ? 1 : 0;
+    q.criterion = overlap_criterion; q.border = border_pixels; q.min_area = min_area; q.lower = lower; q.upper = upper;
+    hipLaunchKernelGGL(box_filter_kernel, dim3((G + BX_THREADS - 1) / BX_THREADS), dim3(BX_THREADS), 0, stream, q, boxes, box_image,
+                       image_hw, G, keep);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

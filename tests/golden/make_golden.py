@@ -285,6 +285,53 @@ def gen_evaluator():
     save("evaluator", **out)
 
 
+def gen_box_filter():
+    """BoxFilter / ImageValidator of the real reference (data_generator/object_detection_2d_image_boxes_validation_utils.py).
+    Stored compactly: the label sets once, per case the configuration, the indices of the rows the reference kept (its output
+    preserves row order, so they are recovered by a sequential match) and the two ImageValidator verdicts."""
+    from data_generator.object_detection_2d_image_boxes_validation_utils import BoxFilter, ImageValidator
+    rng = np.random.RandomState(31)
+    out = {}
+    cfgs, kept_idx, kept_off, valid = [], [], [0], []
+    sets = 0
+    for dtype in (np.int64, np.float64):
+        for trial in range(3):
+            n = int(rng.randint(0, 14)) if trial else 12
+            x0 = rng.uniform(-40, 260, size=n); y0 = rng.uniform(-40, 200, size=n)
+            w = rng.uniform(-5, 120, size=n); h = rng.uniform(-5, 120, size=n)          # some degenerate / tiny boxes
+            lab = np.stack([rng.randint(1, 21, size=n).astype(np.float64), x0, y0, x0 + w, y0 + h], axis=1)
+            lab = np.round(lab).astype(np.int64) if dtype is np.int64 else lab
+            H, W = int(rng.randint(100, 240)), int(rng.randint(120, 300))
+            out["L%d" % sets], out["L%d_hw" % sets] = lab, np.array([H, W])
+            for crit in ("center_point", "iou", "area"):
+                for bp in ("half", "include", "exclude"):
+                    for bounds in ((0.3, 1.0), (0.0, 1.0), (0.1, 0.6), (1.0, 1.0)):
+                        for flags in ((True, True, True), (True, False, False), (False, True, True)):
+                            f = BoxFilter(check_overlap=flags[0], check_min_area=flags[1], check_degenerate=flags[2], overlap_criterion=crit,
+                                          overlap_bounds=bounds, min_area=16, border_pixels=bp)
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                kept = f(lab, H, W)
+                            idx, j = [], 0
+                            for row in kept:                                   # order-preserving subset -> indices
+                                while not np.array_equal(lab[j], row):
+                                    j += 1
+                                idx.append(j)
+                                j += 1
+                            v = ImageValidator(overlap_criterion=crit, bounds=bounds, n_boxes_min=2, border_pixels=bp)
+                            va = ImageValidator(overlap_criterion=crit, bounds=bounds, n_boxes_min="all", border_pixels=bp)
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                valid.append([bool(v(lab, H, W)), bool(va(lab, H, W))])
+                            cfgs.append(repr(dict(set=sets, crit=crit, bp=bp, bounds=bounds, flags=flags)))
+                            kept_idx += idx
+                            kept_off.append(len(kept_idx))
+            sets += 1
+    out["cfgs"] = np.array(cfgs)
+    out["kept_idx"], out["kept_off"] = np.array(kept_idx, dtype=np.int32), np.array(kept_off, dtype=np.int32)
+    out["valid"] = np.array(valid, dtype=bool)
+    out["n_sets"] = np.array(sets)
+    save("box_filter", **out)
+
+
 def gen_anchors():
     out = {}
     for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
@@ -442,6 +489,7 @@ if __name__ == "__main__":
     gen_box_utils()
     gen_box_utils2()
     gen_evaluator()
+    gen_box_filter()
     gen_anchors()
     gen_encoder()
     gen_decoder()

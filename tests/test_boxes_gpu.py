@@ -187,3 +187,40 @@ def test_greedy_nms_at_decoder_scale_vs_oracle():
     again = dec.greedy_nms(got, iou_threshold=0.45, coords="corners", border_pixels="half")
     for g, w in zip(again, got):
         _same(g, w)                                                            # NMS of an NMS result changes nothing
+
+
+def test_golden_box_filter_and_image_validator():
+    """BoxFilter / ImageValidator (ssdhip_box_filter) vs the real reference's outputs: 648 configurations (criteria x border modes x
+    bounds x check flags, integer and float64 labels, degenerate and out-of-image boxes), single calls and one batched launch."""
+    from ssd_keras_amd.data_generator.object_detection_2d_image_boxes_validation_utils import BoundGenerator, BoxFilter, ImageValidator
+    from tests.test_oracle_golden import box_filter_cases
+    cases = list(box_filter_cases())
+    for cfg, lab, H, W, want, valid in cases[::7]:                            # every 7th configuration through the per-image API
+        f = BoxFilter(check_overlap=cfg["flags"][0], check_min_area=cfg["flags"][1], check_degenerate=cfg["flags"][2],
+                      overlap_criterion=cfg["crit"], overlap_bounds=cfg["bounds"], min_area=16, border_pixels=cfg["bp"])
+        got = f(lab, H, W)
+        assert got.dtype == lab.dtype and np.array_equal(got, lab[want]), cfg
+        v = ImageValidator(overlap_criterion=cfg["crit"], bounds=cfg["bounds"], n_boxes_min=2, border_pixels=cfg["bp"])
+        va = ImageValidator(overlap_criterion=cfg["crit"], bounds=cfg["bounds"], n_boxes_min="all", border_pixels=cfg["bp"])
+        assert v(lab, H, W) == bool(valid[0]) and va(lab, H, W) == bool(valid[1]), cfg
+    # all configurations: group by filter settings, one batched launch per group over the six label sets
+    groups = {}
+    for cfg, lab, H, W, want, valid in cases:
+        groups.setdefault((cfg["crit"], cfg["bp"], cfg["bounds"], cfg["flags"]), []).append((lab, H, W, want))
+    assert len(groups) == 108
+    for (crit, bp, bounds, flags), items in groups.items():
+        f = BoxFilter(check_overlap=flags[0], check_min_area=flags[1], check_degenerate=flags[2], overlap_criterion=crit,
+                      overlap_bounds=bounds, min_area=16, border_pixels=bp)
+        got = f.filter_batch([it[0].astype(np.float64) for it in items], [it[1] for it in items], [it[2] for it in items])
+        for g, it in zip(got, items):
+            assert np.array_equal(g, it[0].astype(np.float64)[it[3]]), (crit, bp, bounds, flags)
+    with pytest.raises(ValueError):
+        BoxFilter(overlap_criterion="corner")
+    with pytest.raises(ValueError):
+        BoxFilter(overlap_bounds=(0.8, 0.2))
+    with pytest.raises(ValueError):
+        ImageValidator(n_boxes_min=0)
+    bg = BoundGenerator(sample_space=((0.1, None), (None, 0.9)), weights=[0.5, 0.5])
+    assert bg() in ([0.1, 1.0], [0.0, 0.9])
+    f = BoxFilter(overlap_criterion="iou", overlap_bounds=bg)                # bounds drawn per call
+    assert f(cases[0][1], cases[0][2], cases[0][3]).shape[1] == 5

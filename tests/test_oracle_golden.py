@@ -293,3 +293,24 @@ def test_evaluator_matching_and_average_precision():
             ap = np.asarray(orc.evaluator_average_precisions(prec, rec, mode=mode), dtype=np.float64)
             assert np.array_equal(ap, z[pre + "ap_" + mode]), (ci, mode)
             assert np.mean(ap[1:]) == float(z[pre + "map_" + mode])
+
+
+def box_filter_cases():
+    z = util.load("box_filter")
+    for i, c in enumerate(z["cfgs"]):
+        cfg = ast.literal_eval(str(c))
+        lab, hw = z["L%d" % cfg["set"]], z["L%d_hw" % cfg["set"]]
+        want = z["kept_idx"][z["kept_off"][i]:z["kept_off"][i + 1]]
+        yield cfg, lab, int(hw[0]), int(hw[1]), want, z["valid"][i]
+
+
+def test_box_filter_oracle_vs_reference():
+    n = 0
+    for cfg, lab, H, W, want, valid in box_filter_cases():
+        m = orc.box_filter_mask(lab, H, W, check_overlap=cfg["flags"][0], check_min_area=cfg["flags"][1], check_degenerate=cfg["flags"][2],
+                                overlap_criterion=cfg["crit"], overlap_bounds=cfg["bounds"], min_area=16, border_pixels=cfg["bp"])
+        assert np.array_equal(np.nonzero(m)[0], want), cfg
+        mv = orc.box_filter_mask(lab, H, W, True, False, False, cfg["crit"], cfg["bounds"], 16, cfg["bp"])
+        assert bool(mv.sum() >= 2) == bool(valid[0]) and bool(mv.sum() == len(mv)) == bool(valid[1])
+        n += 1
+    assert n == 648
