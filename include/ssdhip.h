@@ -260,7 +260,8 @@ int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* 
                                  int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 /* Profiling aid: the same with an explicit kernel variant (4: the shipped kernel -- 128-pixel tile, two LDS stages, buffer-addressed
  * LDS-DMA loads, batched fragment reads; 1: its predecessor with per-lane pointers; 3: 256-pixel tile, three-stage weight pipeline,
- * kw-reuse of the activation strip -- kept for A/B timing). */
+ * kw-reuse of the activation strip; 5 / 6: four / three-stage LDS ring of 32-channel slices; 9: eight waves per workgroup with the
+ * step's MFMAs split over two wave groups -- all kept for A/B timing, all covered by the parity tests). */
 int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                          int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 

@@ -371,7 +371,7 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
         }
         __builtin_amdgcn_sched_barrier(0);             // the step's 16 fragment reads go out first ...
         if (s + 1 < T) issue((s + 1) & 1);             // ... their latency hides behind issuing the next step's LDS-DMA loads
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);             // (measured: loads before the reads, or s_setprio around the MFMAs, change nothing)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -477,6 +477,192 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v9: the v4 tile and pipeline with EIGHT waves per workgroup: waves 0-3 multiply k16 slices 0-1 of every K-step, waves 4-7
+// slices 2-3 (each still a 64-channel x 64-pixel tile; the two partial accumulators are added through LDS once, after the
+// K loop).  Why: every counter of v4 sits at ~40 % (MFMA busy, L2 -> LDS bytes, LDS cycles) and reordering its phases moves
+// nothing -- it is short of waves to overlap, and LDS (64 KB per workgroup) caps it at two workgroups = 8 waves per CU.  Splitting a
+// step's 16 MFMAs over two waves doubles the waves per CU (16, four per SIMD) on the SAME LDS footprint and halves each
+// wave's loads, fragment reads and fragment registers.  RESULT (MI355X): 3-4 % SLOWER than v4 on every VGG shape -- occupancy is
+// not what v4 lacks either.  A timing-only diagnostic that skipped two of every three activation-tile loads (-33 % of the
+// global -> LDS bytes) ran 6-11 % faster: the LDS-DMA byte rate is one contributor among several balanced ones (MFMA busy,
+// L2 -> LDS bytes and LDS cycles all sit near 40 %).  Kept as variant 9 for A/B timing.
+// ---------------------------------------------------------------------------------------------------------------------
+
+template <int BC>
+__device__ __forceinline__ void conv_igemm9_body(const ConvParams& p, unsigned char* lds, const int id) {
+    constexpr int CI = BC / 64;
+    constexpr int XBYTES = CONV_BP * 128, WBYTES = BC * 128, BUF = XBYTES + WBYTES;
+    constexpr int XP = 2, WP = BC / 64;               // 1 KiB pieces per wave per step: 16 X pieces + BC/8 W pieces over 8 waves
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
+    if (mt >= p.m_tiles) return;
+    const int m0 = mt * CONV_BP, co0 = nt * BC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
+    const int grp = wave >> 2, w4 = wave & 3;                          // K half, tile quadrant
+    const int wc = w4 >> 1, wp = w4 & 1;
+    const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
+    const int csteps = Cin / CONV_BK, T = KK * csteps;
+
+    const int neg = (half * dil * p.W + half * dil) * Cin * 2;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.M * Cin * 2 + 2 * neg, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.w)), 0, p.Cout * KK * Cin * 2, 0x00020000);
+
+    u32 xoff[XP], xok[XP], woff[WP];
+    const int pos = lane & 7;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int j = pos ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const int wq = m % p.W, hq = (m / p.W) % p.H;
+        u32 rmask = 0, cmask = 0;
+        for (int k = 0; k < KS; ++k) {
+            const int d = (k - half) * dil;
+            if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+            if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+        }
+        u32 ok = 0;
+        if (m < p.M)
+            for (int kh = 0; kh < KS; ++kh)
+                if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+        xok[i] = ok;
+        xoff[i] = (u32)m * (u32)(Cin * 2) + (u32)(j * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int j = pos ^ ((row >> 1) & 7);
+        woff[i] = (u32)(co0 + row) * (u32)(KK * Cin * 2) + (u32)(j * 16);
+    }
+
+    int n_kh = 0, n_kw = 0, n_cs = 0;
+    auto issue = [&](int buf) {
+        const int t = n_kh * KS + n_kw;
+        const int soff_x = neg + (((n_kh - half) * dil * p.W + (n_kw - half) * dil) * Cin + n_cs * CONV_BK) * 2;
+        const int soff_w = (t * Cin + n_cs * CONV_BK) * 2;
+        const u32 tapbit = 1u << t;
+        unsigned char* xb = lds + buf * BUF + wave * 1024;
+        unsigned char* wb = xb + XBYTES;
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xb + i * 8192), 16, (xok[i] & tapbit) ? xoff[i] : OOB, soff_x, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wb + i * 8192), 16, woff[i], soff_w, 0, 0);
+        if (++n_kw == KS) { n_kw = 0; if (++n_kh == KS) { n_kh = 0; ++n_cs; } }
+    };
+
+    f32x16 acc[CI][2];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int swz = (r31 >> 1) & 7;
+    const int arow = (wc * (BC / 2) + r31) * 128, brow = (wp * 64 + r31) * 128;
+    int choff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) choff[kk] = ((2 * (2 * grp + kk) + khalf) ^ swz) << 4;
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const unsigned char* xb = lds + (s & 1) * BUF;
+        const unsigned char* wb = xb + XBYTES;
+        bf16x8 a[2][CI], b[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) a[kk][ci] = *reinterpret_cast<const bf16x8*>(wb + arow + ci * 4096 + choff[kk]);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) b[kk][pi] = *reinterpret_cast<const bf16x8*>(xb + brow + pi * 4096 + choff[kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < T) issue((s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][ci], b[kk][pi], acc[ci][pi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- add the two K halves: waves 4-7 park their accumulators in LDS (lane-major: conflict-free), waves 0-3 add them ------
+    float* red = reinterpret_cast<float*>(lds) + (size_t)w4 * (CI * 2 * 16 * 64);
+    if (grp == 1) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) red[((ci * 2 + pi) * 16 + v) * 64 + lane] = acc[ci][pi][v];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] += red[((ci * 2 + pi) * 16 + v) * 64 + lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of `red` are done before its region becomes the stage
+
+    // ---- epilogue of v4; the stage (= this wave's own `red` region) is wave-private, so no block barrier is needed ------------
+    constexpr int ROWB = 64 * CI;
+    unsigned char* stage = reinterpret_cast<unsigned char*>(red);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int px = pi * 32 + r31;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
+                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+                }
+                u32 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[ci][pi][4 * g + q] + bv[q];
+                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+                    o[q] = f2bf_rn(v);
+                }
+                const int chunk = ci * 4 + g;
+                *reinterpret_cast<uint2*>(stage + px * ROWB + ((chunk ^ (px & (4 * CI - 1))) << 4) + khalf * 8) =
+                    make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int CPR = 4 * CI;
+#pragma unroll
+    for (int j = 0; j < CPR; ++j) {
+        const int idx = j * 64 + lane, px = idx / CPR, c = idx % CPR;
+        const int m = m0 + wp * 64 + px;
+        if (m < p.M)
+            *reinterpret_cast<uint4*>(p.y + (size_t)m * p.Cout + co0 + wc * (BC / 2) + c * 8) =
+                *reinterpret_cast<const uint4*>(stage + px * ROWB + ((c ^ (px & (CPR - 1))) << 4));
+    }
+}
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <int BC>
@@ -484,6 +670,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
     conv_igemm4_body<BC, false>(p, lds, (int)blockIdx.x);
+#endif
+}
+
+template <int BC>
+__global__ __launch_bounds__(512, 4) void conv_igemm9_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
+    conv_igemm9_body<BC>(p, lds, (int)blockIdx.x);
 #endif
 }
 
@@ -1085,6 +1279,11 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
             if (wide) hipLaunchKernelGGL((conv_igemm5_kernel<128, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
             else hipLaunchKernelGGL((conv_igemm5_kernel<64, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
         }
+    } else if (variant == 9 && small) {       // 8 waves per workgroup, the step's MFMAs split over two wave groups
+        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (wide) hipLaunchKernelGGL(conv_igemm9_kernel<128>, dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(conv_igemm9_kernel<64>, dim3(grid), dim3(512), 0, stream, p);
     } else if (variant == 4) {                // v1's tile with buffer-addressed LDS-DMA and batched fragment reads
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
@@ -1116,7 +1315,7 @@ extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, c
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
-    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 6) return SSDHIP_E_BADARG;
+    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 9) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }
 

@@ -44,6 +44,7 @@ def main():
         t_v4 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=4))
         t_v5 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=5))
         t_v6 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=6))
+        t_v7 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=9))
         t_pool = t_unf = float("nan")
         if name in ("conv1_2", "conv2_2", "conv3_2"):
             t_pool = ev_ms(lambda: nat.conv2d_same_pool2(x, w, b, dilation=dil, relu=True))
@@ -58,7 +59,7 @@ def main():
         else:
             t_mi = t_mi_full = float("nan")
         r = {"layer": name, "ours_us": round(t_ours * 1e3, 1), "ours_TFs": round(flop / t_ours / 1e9, 1), "v1_us": round(t_v1 * 1e3, 1), "v4_us": round(t_v4 * 1e3, 1), "v4_TFs": round(flop / t_v4 / 1e9, 1),
-             "c64_us": round(t_c64 * 1e3, 1), "c64_pool_us": round(t_c64p * 1e3, 1), "conv_pool_fused_us": round(t_pool * 1e3, 1), "conv_then_pool_us": round(t_unf * 1e3, 1), "v5_us": round(t_v5 * 1e3, 1), "v5_TFs": round(flop / t_v5 / 1e9, 1), "v6_us": round(t_v6 * 1e3, 1), "v6_TFs": round(flop / t_v6 / 1e9, 1),
+             "c64_us": round(t_c64 * 1e3, 1), "c64_pool_us": round(t_c64p * 1e3, 1), "conv_pool_fused_us": round(t_pool * 1e3, 1), "conv_then_pool_us": round(t_unf * 1e3, 1), "v5_us": round(t_v5 * 1e3, 1), "v5_TFs": round(flop / t_v5 / 1e9, 1), "v6_us": round(t_v6 * 1e3, 1), "v9_8waves_us": round(t_v7 * 1e3, 1), "v6_TFs": round(flop / t_v6 / 1e9, 1),
              "miopen_conv_us": round(t_mi * 1e3, 1), "miopen_TFs": round(flop / t_mi / 1e9, 1),
              "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
         print(json.dumps(r), flush=True)
