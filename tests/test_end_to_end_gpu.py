@@ -73,3 +73,34 @@ def test_ssd7_encode_forward_loss_backward_decode():
         got = decode_detections(y_pred, **kw)
         want = orc.decode_detections(yp, exp_mode="det", **kw)
         util.dets_equal(got, want, exact=True)
+
+
+def test_ssd512_coco_shape_inference_config4():
+    """BASELINE.json configs[4]: SSD512, 81 classes (COCO shape), 24564 anchors -- the bf16 inference path end to end (conv64 /
+    implicit-GEMM / grouped heads at the 512 x 512 shapes), the DecodeDetections layer on the model's own predictions checked
+    against the oracle, and the fused decode-from-heads path exercised at this shape."""
+    import torch
+    from ssd_keras_amd.models.keras_ssd512 import ssd_512
+    cfg = syn.SSD512_COCO
+    torch.manual_seed(3)
+    model, psizes = ssd_512((512, 512, 3), cfg["n_classes"], mode="inference", scales=cfg["scales"],
+                            aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"],
+                            confidence_thresh=0.5, iou_threshold=0.45, top_k=200, nms_max_output_size=400, return_predictor_sizes=True)
+    assert [tuple(p) for p in psizes] == [tuple(p) for p in cfg["predictor_sizes"]]
+    model = model.cuda().to(memory_format=torch.channels_last).to(torch.bfloat16).eval()
+    B = 2
+    images = torch.from_numpy(np.random.RandomState(5).randint(0, 256, size=(B, 512, 512, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        pred = model.raw_predictions(images)
+        assert pred.shape == (B, 24564, 81 + 12) and pred.dtype == torch.float32
+        probs = pred[:, :, :81]
+        assert torch.isfinite(probs).all() and (probs.sum(-1) - 1).abs().max().item() < 1e-4
+        got = model.decoder(pred).cpu().numpy()
+        fused = model(images)                                              # forward + decode straight from the head outputs
+    want = orc.decode_detections_layer(pred.cpu().numpy(), confidence_thresh=0.5, iou_threshold=0.45, top_k=200, nms_max_output_size=400,
+                                       normalize_coords=True, img_height=512, img_width=512)
+    assert got.shape == (B, 200, 6) and np.array_equal(got, want, equal_nan=True)
+    assert fused.shape == (B, 200, 6)
+    # the two forward passes agree up to MIOpen's non-deterministic split-K extras: same number of detections within a few rows
+    n_a, n_b = int((got[:, :, 1] > 0).sum()), int((fused[:, :, 1] > 0).sum().item())
+    assert n_a > 0 and abs(n_a - n_b) <= max(4, n_a // 20)
