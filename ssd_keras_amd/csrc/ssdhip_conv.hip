@@ -700,10 +700,13 @@ struct ConvGroup {
 
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_group_kernel(ConvGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + 64 * 128)];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + 128 * 128)];
     int k = 0;
     while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
-    conv_igemm4_body<64, false>(g.p[k], lds, (int)blockIdx.x - g.first_block[k]);
+    // problems whose channel count is a multiple of 128 take the 128-channel tile (same pixels, half the activation re-reads);
+    // the host sized n_tiles accordingly
+    if (g.p[k].Cout % 128 == 0) conv_igemm4_body<128, false>(g.p[k], lds, (int)blockIdx.x - g.first_block[k]);
+    else conv_igemm4_body<64, false>(g.p[k], lds, (int)blockIdx.x - g.first_block[k]);
 #endif
 }
 
@@ -1384,7 +1387,7 @@ extern "C" int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* co
         p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ks; p.dil = dil; p.relu = relu ? 1 : 0;
         p.M = (int)M;
         p.Ho = p.Wo = p.WT = p.HT = p.cshift = 0;
-        p.n_tiles = Cout / 64;
+        p.n_tiles = (Cout % 128 == 0) ? Cout / 128 : Cout / 64;
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         blocks += (long long)((p.m_tiles + 7) / 8) * p.n_tiles * 8;
         if (blocks > 0x3fffffffLL) return SSDHIP_E_BADARG;
