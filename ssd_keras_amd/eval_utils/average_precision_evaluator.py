@@ -192,8 +192,9 @@ class Evaluator:
         cols = [gf['xmin'], gf['ymin'], gf['xmax'], gf['ymax']]
         image_ids = [str(v) for v in self.data_generator.image_ids]
         index_of = {image_id: i for i, image_id in enumerate(image_ids)}
-        labels = [np.asarray(lab) for lab in self.data_generator.labels]
         neutral = self.data_generator.eval_neutral if (ignore_neutral_boxes and self.data_generator.eval_neutral is not None) else None
+        gt_cat, gt_img, neutral_cat = self._concat_ground_truth(self.data_generator.labels, neutral)
+        n_images = len(image_ids)
 
         true_positives, false_positives = [[]], [[]]
         cumulative_true_positives, cumulative_false_positives = [[]], [[]]
@@ -207,26 +208,15 @@ class Evaluator:
                 for lst in (true_positives, false_positives, cumulative_true_positives, cumulative_false_positives):
                     lst.append(empty.copy())
                 continue
-            # this class's ground truth as CSR over the images (boxes float64: integer labels convert exactly)
-            boxes, offsets, flags = [], [0], []
-            for i, lab in enumerate(labels):
-                if lab.size:
-                    mask = lab[:, gf['class_id']] == class_id
-                    boxes.append(lab[mask][:, cols].astype(np.float64))
-                    if neutral is not None:
-                        flags.append(np.asarray(neutral[i], dtype=bool)[mask])
-                    offsets.append(offsets[-1] + int(mask.sum()))
-                else:
-                    offsets.append(offsets[-1])
-            gt_boxes = np.concatenate(boxes, axis=0) if boxes else np.zeros((0, 4))
-            gt_neutral = (np.concatenate(flags).astype(np.uint8) if flags else np.zeros((0,), np.uint8)) if neutral is not None else None
-            pred = np.array([p[1:6] for p in predictions], dtype=np.float32).reshape(P, 5)      # 'f4' like the reference (:629-634)
-            pred_image = np.array([index_of[str(p[0])] for p in predictions], dtype=np.int32)
+            gt_boxes, offsets, gt_neutral = self._class_ground_truth(gt_cat, gt_img, neutral_cat, n_images, class_id, gf['class_id'], cols)
+            columns = list(zip(*predictions))                                 # (image ids, conf, xmin, ymin, xmax, ymax)
+            pred = np.stack([np.asarray(col, dtype=np.float32) for col in columns[1:6]], axis=1)   # 'f4' like the reference (:629-634)
+            pred_image = np.fromiter((index_of[str(v)] for v in columns[0]), dtype=np.int32, count=P)
             if verbose:
                 print("Matching predictions to ground truth, class {}/{}.".format(class_id, self.n_classes))
                 sys.stdout.flush()
-            _order, tp, fp, ctp, cfp = nat.match_predictions_class(pred, pred_image, gt_boxes, np.asarray(offsets, dtype=np.int32),
-                                                                   gt_neutral, matching_iou_threshold, border_pixels)
+            _order, tp, fp, ctp, cfp = nat.match_predictions_class(pred, pred_image, gt_boxes, offsets, gt_neutral, matching_iou_threshold,
+                                                                   border_pixels)
             true_positives.append(tp.cpu().numpy().astype(np.int64))
             false_positives.append(fp.cpu().numpy().astype(np.int64))
             cumulative_true_positives.append(ctp.cpu().numpy().astype(np.int64))
@@ -237,6 +227,31 @@ class Evaluator:
         self.cumulative_false_positives = cumulative_false_positives
         if ret:
             return true_positives, false_positives, cumulative_true_positives, cumulative_false_positives
+
+    @staticmethod
+    def _concat_ground_truth(labels, neutral):
+        """All label arrays stacked once: (G_all, n_cols) rows in image order, the image index of each row, neutral flags or None."""
+        arrs = [np.asarray(lab) for lab in labels]
+        counts = np.array([a.shape[0] if a.ndim == 2 else 0 for a in arrs], dtype=np.int64)
+        keep = [a for a, c in zip(arrs, counts) if c]
+        cat = np.concatenate(keep, axis=0) if keep else np.zeros((0, 5))
+        img = np.repeat(np.arange(len(arrs), dtype=np.int64), counts)
+        ncat = None
+        if neutral is not None:
+            flags = [np.asarray(neutral[i], dtype=bool).reshape(-1) for i, c in enumerate(counts) if c]
+            ncat = np.concatenate(flags) if flags else np.zeros((0,), dtype=bool)
+        return cat, img, ncat
+
+    @staticmethod
+    def _class_ground_truth(gt_cat, gt_img, neutral_cat, n_images, class_id, class_col, cols):
+        """One class's ground truth as CSR over the images: boxes (G,4) float64 (integer labels convert exactly), offsets
+        (n_images + 1,) int32, neutral flags (G,) uint8 or None.  Rows stay in image order, as the reference's per-image masks."""
+        mask = gt_cat[:, class_col] == class_id if gt_cat.shape[0] else np.zeros((0,), dtype=bool)
+        boxes = gt_cat[mask][:, cols].astype(np.float64) if gt_cat.shape[0] else np.zeros((0, 4))
+        per_image = np.bincount(gt_img[mask], minlength=n_images) if gt_cat.shape[0] else np.zeros(n_images, dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(per_image)]).astype(np.int32)
+        flags = neutral_cat[mask].astype(np.uint8) if neutral_cat is not None else None
+        return boxes, offsets, flags
 
     def compute_precision_recall(self, verbose=True, ret=False):
         '''Reference :738-781.'''

@@ -173,3 +173,29 @@ def test_keras_weight_layout_round_trip():
     x = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(2, 64, 64, 3)).astype(np.float32))
     with torch.no_grad():
         assert torch.equal(s1(x), s2(x))
+
+
+def test_evaluator_ground_truth_packing():
+    """The vectorised per-class CSR packing of Evaluator.match_predictions == a per-image loop with the reference's masks."""
+    import numpy as np
+    from ssd_keras_amd.eval_utils.average_precision_evaluator import Evaluator
+    rng = np.random.RandomState(4)
+    labels, neutral = [], []
+    for i in range(57):
+        g = int(rng.randint(0, 6)) if i % 5 else 0
+        labels.append(np.stack([rng.randint(1, 5, size=g), rng.randint(0, 50, size=g), rng.randint(0, 50, size=g),
+                                rng.randint(50, 99, size=g), rng.randint(50, 99, size=g)], axis=1).astype(np.int64).reshape(-1, 5))
+        neutral.append(rng.uniform(size=g) < 0.3)
+    labels[3] = []                                                   # an image given as an empty list
+    neutral[3] = []
+    cat, img, ncat = Evaluator._concat_ground_truth(labels, neutral)
+    for c in range(1, 5):
+        boxes, off, flags = Evaluator._class_ground_truth(cat, img, ncat, len(labels), c, 0, [1, 2, 3, 4])
+        assert off.dtype == np.int32 and off.shape == (58,) and boxes.dtype == np.float64 and flags.dtype == np.uint8
+        for i, lab in enumerate(labels):
+            lab = np.asarray(lab).reshape(-1, 5)
+            m = lab[:, 0] == c
+            assert np.array_equal(boxes[off[i]:off[i + 1]], lab[m][:, 1:5].astype(np.float64))
+            assert np.array_equal(flags[off[i]:off[i + 1]].astype(bool), np.asarray(neutral[i], dtype=bool).reshape(-1)[m])
+    cat, img, ncat = Evaluator._concat_ground_truth(labels, None)
+    assert ncat is None and Evaluator._class_ground_truth(cat, img, None, len(labels), 2, 0, [1, 2, 3, 4])[2] is None
