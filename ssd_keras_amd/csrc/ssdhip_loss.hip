@@ -6,12 +6,14 @@
 // largest negative classification losses of the flattened (B*N) array are kept; among equal losses at the
 // k-th place the lowest flat index wins (tf.nn.top_k).
 //
-// Forward = four kernels on the caller's stream:
+// Forward on the caller's stream:
 //   L1 anchor_kernel  grid (anchor tiles, B): tiles of y_true / y_pred rows copied coalesced into LDS; per anchor the
 //                     log loss (only where y_true != 0), smooth L1, positive / negative weights; writes cls_loss[B,N]
 //                     and neg_all[B,N], accumulates per-image sums (float64 atomics) and the two global counts.
-//   L2 select_kernel  one workgroup: k, then a 3-pass radix select (11+11+10 bits of the order-preserving float key)
-//                     for the k-th largest negative loss and, only if ties straddle the cut, the flat-index limit.
+//   L2 sel_*_kernel   k, then a radix select (11+11+10 bits of the order-preserving float key) for the k-th largest negative
+//                     loss: a chip-wide histogram of the top 11 bits (L2a), the pivot digit (L2b), a chip-wide compaction
+//                     of that digit's [key | index] pairs (L2c), and one workgroup finishing on the short list (L2d) --
+//                     including, only if ties straddle the cut, the flat-index limit.
 //   L3 keep_kernel    grid-stride over B*N: keep mask + per-image sum of the kept negative losses.
 //   L4 total_kernel   B threads: (pos_cls + neg_cls + alpha*loc) / max(1, n_pos) * B.
 // Backward = one kernel with the same LDS tiling writing d loss / d y_pred coalesced.
@@ -26,10 +28,13 @@ namespace ssdhip {
 
 constexpr int LOSS_THREADS = 256;
 constexpr int SEL_THREADS = 1024;
+constexpr int SELG_THREADS = 256;
+constexpr int SELG_MAX_BLOCKS = 256;
 constexpr int SEL_BINS = 2048;
 
 struct LossWs {
-    size_t sums, counts, sel, cls, neg, total;   // sums: 3*B doubles + n_pos double; counts: ints; sel: select result
+    size_t sums, counts, hist, sel, cls, neg, list, total;   // sums: 3*B doubles + n_pos double; counts: [non-zero negative losses,
+                                                             // list length]; hist: L2a bins; sel: select state; list: L2c pairs
 };
 
 struct SelectResult {
@@ -39,6 +44,8 @@ struct SelectResult {
     int n_neg_losses;
     float n_pos;
     float thresh;
+    int digit;                    // L2b -> L2c/L2d: top 11 key bits of the threshold
+    int want;                     //                 how many of that digit's values are kept
 };
 
 static inline size_t lalign(size_t v) { return (v + 255) / 256 * 256; }
@@ -48,9 +55,11 @@ static LossWs loss_ws_layout(int B, int N) {
     size_t o = 0;
     w.sums = o;   o = lalign(o + (size_t)(3 * B + 1) * sizeof(double));
     w.counts = o; o = lalign(o + 4 * sizeof(int));
+    w.hist = o;   o = lalign(o + SEL_BINS * sizeof(u32));
     w.sel = o;    o = lalign(o + sizeof(SelectResult));
     w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.neg = o;    o = lalign(o + (size_t)B * N * sizeof(float));
+    w.list = o;   o = lalign(o + (size_t)B * N * sizeof(u64));
     w.total = o;
     return w;
 }
@@ -119,33 +128,92 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
 }
 
 // ======================================================================================
-// L2
+// L2: k and the k-th largest negative loss.  Four short launches; only the two streaming passes use the whole chip.
 // ======================================================================================
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ neg_all, int total, int neg_pos_ratio,
-                                                             int n_neg_min, const double* __restrict__ sums, int B,
-                                                             const int* __restrict__ counts, SelectResult* __restrict__ res,
-                                                             float* __restrict__ stats) {
+// L2a: histogram of the top 11 key bits over all B*N values, privatised in LDS per workgroup
+__global__ __launch_bounds__(SELG_THREADS) void sel_hist_kernel(const float* __restrict__ neg_all, int total, u32* __restrict__ ghist) {
+    __shared__ u32 hist[SEL_BINS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SEL_BINS; i += SELG_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * SELG_THREADS + tid; i < total; i += gridDim.x * SELG_THREADS)
+        atomicAdd(&hist[float_key(neg_all[i]) >> 21], 1u);
+    __syncthreads();
+    for (int i = tid; i < SEL_BINS; i += SELG_THREADS) {
+        const u32 c = hist[i];
+        if (c) atomicAdd(&ghist[i], c);
+    }
+}
+
+// L2b: k (:166-177) and the top-11-bit digit the k-th largest value falls in
+__global__ __launch_bounds__(SEL_THREADS) void sel_pivot_kernel(const u32* __restrict__ ghist, int neg_pos_ratio, int n_neg_min,
+                                                                const double* __restrict__ sums, int B, const int* __restrict__ counts,
+                                                                SelectResult* __restrict__ res, float* __restrict__ stats) {
     __shared__ u32 hist[SEL_BINS];
     __shared__ int sh_out[2];
-    __shared__ int sh_digit;
     __shared__ int wave_cnt[SEL_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const float n_pos = (float)sums[3 * B];
     const int n_neg_losses = counts[0];
     int k = neg_pos_ratio * (int)n_pos;                                  // tf.to_int32(n_positive) truncates (:166)
     k = k > n_neg_min ? k : n_neg_min;
     k = k < n_neg_losses ? k : n_neg_losses;
-    u32 prefix = 0, pmask = 0;
-    int tie_limit = 0x7fffffff;
     if (k > 0) {
-        int want = k;
-        const int shifts[3] = {21, 10, 0};
-        const u32 masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
-        for (int pass = 0; pass < 3; ++pass) {
+        for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = ghist[i];
+        __syncthreads();
+        block_find_digit<SEL_BINS / SEL_THREADS>(hist, k, wave_cnt, sh_out);
+    }
+    if (tid == 0) {
+        res->k = k; res->thresh_key = 0; res->tie_limit = 0x7fffffff; res->n_neg_losses = n_neg_losses;
+        res->n_pos = n_pos; res->thresh = 0.f;
+        res->digit = k > 0 ? sh_out[0] : 0;
+        res->want = k > 0 ? k - sh_out[1] : 0;
+        stats[0] = n_pos; stats[1] = (float)n_neg_losses; stats[2] = (float)k; stats[3] = 0.f;
+    }
+}
+
+// L2c: the values of that digit, as [key | flat index] pairs, appended to a list (order does not matter)
+__global__ __launch_bounds__(SELG_THREADS) void sel_compact_kernel(const float* __restrict__ neg_all, int total,
+                                                                   const SelectResult* __restrict__ res, int* __restrict__ list_count,
+                                                                   u64* __restrict__ list) {
+    if (res->k <= 0) return;
+    const u32 digit = (u32)res->digit;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * SELG_THREADS; base < total; base += gridDim.x * SELG_THREADS) {
+        const int i = base + threadIdx.x;
+        u32 key = 0;
+        bool is = false;
+        if (i < total) { key = float_key(neg_all[i]); is = (key >> 21) == digit; }
+        const u64 m = __ballot(is);
+        if (m) {                                                        // wave-uniform
+            int start = 0;
+            if (lane == 0) start = atomicAdd(list_count, __popcll(m));
+            start = __shfl(start, 0);
+            if (is) list[start + __popcll(m & lanemask_lt())] = ((u64)key << 32) | (u64)(u32)i;
+        }
+    }
+}
+
+// L2d: one workgroup finishes on the list: the remaining 21 key bits, then -- only if ties straddle the cut -- the flat
+// index limit: the want-th smallest index among the ties, found by the same radix select on the inverted index.
+__global__ __launch_bounds__(SEL_THREADS) void sel_finish_kernel(const u64* __restrict__ list, const int* __restrict__ list_count,
+                                                                 SelectResult* __restrict__ res, float* __restrict__ stats) {
+    __shared__ u32 hist[SEL_BINS];
+    __shared__ int sh_out[2];
+    __shared__ int wave_cnt[SEL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (res->k <= 0) return;
+    const int n = *list_count;
+    int want = res->want;
+    u32 prefix = (u32)res->digit << 21, pmask = 0x7ffu << 21;
+    {
+        const int shifts[2] = {10, 0};
+        const u32 masks[2] = {0x7ffu, 0x3ffu};
+        for (int pass = 0; pass < 2; ++pass) {
             for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < total; i += SEL_THREADS) {
-                const u32 key = float_key(neg_all[i]);
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const u32 key = (u32)(list[i] >> 32);
                 if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & masks[pass]], 1u);
             }
             __syncthreads();
@@ -155,40 +223,42 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
             pmask |= masks[pass] << shifts[pass];
             __syncthreads();
         }
-        // `want` of the elements equal to the threshold are kept; if that is not all of them, the lowest flat indices win
-        int eq_local = 0;
-        for (int i = tid; i < total; i += SEL_THREADS) eq_local += float_key(neg_all[i]) == prefix;
-        eq_local = (int)wave_sum((double)eq_local);
-        if (lane == 0) wave_cnt[wave] = eq_local;
-        __syncthreads();
-        int eq_total = 0;
-        for (int w = 0; w < SEL_THREADS / 64; ++w) eq_total += wave_cnt[w];
-        __syncthreads();
-        if (eq_total != want) {
-            int seen = 0;                                               // ordered scan, 1024 elements per step
-            for (int base = 0; base < total && tie_limit == 0x7fffffff; base += SEL_THREADS) {
-                const int i = base + tid;
-                const bool is = i < total && float_key(neg_all[i]) == prefix;
-                const u64 m = __ballot(is);
-                if (lane == 0) wave_cnt[wave] = __popcll(m);
-                __syncthreads();
-                int before = seen;
-                for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-                int step = 0;
-                for (int w = 0; w < SEL_THREADS / 64; ++w) step += wave_cnt[w];
-                const int rank = before + __popcll(m & lanemask_lt());   // ties before this one
-                if (is && rank == want - 1) sh_digit = i + 1;            // the want-th tie: limit is one past it
-                __syncthreads();
-                if (seen + step >= want) tie_limit = sh_digit;
-                seen += step;
-                __syncthreads();
+    }
+    // `want` of the elements equal to the threshold are kept; if that is not all of them, the lowest flat indices win
+    int eq_local = 0;
+    for (int i = tid; i < n; i += SEL_THREADS) eq_local += (u32)(list[i] >> 32) == prefix;
+    eq_local = (int)wave_sum((double)eq_local);
+    if (lane == 0) wave_cnt[wave] = eq_local;
+    __syncthreads();
+    int eq_total = 0;
+    for (int w = 0; w < SEL_THREADS / 64; ++w) eq_total += wave_cnt[w];
+    __syncthreads();
+    int tie_limit = 0x7fffffff;
+    if (eq_total != want) {
+        u32 ip = 0, im = 0;
+        int w2 = want;
+        const int shifts[3] = {21, 10, 0};
+        const u32 masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const u64 e = list[i];
+                const u32 inv = ~(u32)e;
+                if ((u32)(e >> 32) == prefix && (inv & im) == ip) atomicAdd(&hist[(inv >> shifts[pass]) & masks[pass]], 1u);
             }
+            __syncthreads();
+            block_find_digit<SEL_BINS / SEL_THREADS>(hist, w2, wave_cnt, sh_out);
+            w2 -= sh_out[1];
+            ip |= (u32)sh_out[0] << shifts[pass];
+            im |= masks[pass] << shifts[pass];
+            __syncthreads();
         }
+        tie_limit = (int)(~ip) + 1;                                     // one past the want-th tie
     }
     if (tid == 0) {
-        res->k = k; res->thresh_key = prefix; res->tie_limit = tie_limit; res->n_neg_losses = n_neg_losses;
-        res->n_pos = n_pos; res->thresh = k > 0 ? key_float(prefix) : 0.f;
-        stats[0] = n_pos; stats[1] = (float)n_neg_losses; stats[2] = (float)k; stats[3] = res->thresh;
+        res->thresh_key = prefix; res->tie_limit = tie_limit; res->thresh = key_float(prefix);
+        stats[3] = res->thresh;
     }
 }
 
@@ -303,7 +373,9 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     SelectResult* sel = reinterpret_cast<SelectResult*>(base + lay.sel);
     float* cls = reinterpret_cast<float*>(base + lay.cls);
     float* neg = reinterpret_cast<float*>(base + lay.neg);
-    if (hipMemsetAsync(base, 0, lay.sel, stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // sums + counts
+    u32* ghist = reinterpret_cast<u32*>(base + lay.hist);
+    u64* list = reinterpret_cast<u64*>(base + lay.list);
+    if (hipMemsetAsync(base, 0, lay.sel, stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // sums + counts + L2a bins
 
     const int L = C + 12;
     const int TA = loss_tile(L);
@@ -311,7 +383,16 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     if (lds > 150 * 1024) return SSDHIP_E_BADARG;
     hipLaunchKernelGGL(anchor_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, sums, counts);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, neg, B * N, neg_pos_ratio, n_neg_min, sums, B, counts, sel, stats);
+    const int total = B * N;
+    int sel_blocks = (total + SELG_THREADS - 1) / SELG_THREADS;
+    if (sel_blocks > SELG_MAX_BLOCKS) sel_blocks = SELG_MAX_BLOCKS;
+    hipLaunchKernelGGL(sel_hist_kernel, dim3(sel_blocks), dim3(SELG_THREADS), 0, stream, neg, total, ghist);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(sel_pivot_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, ghist, neg_pos_ratio, n_neg_min, sums, B, counts, sel, stats);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(sel_compact_kernel, dim3(sel_blocks), dim3(SELG_THREADS), 0, stream, neg, total, sel, counts + 1, list);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(sel_finish_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, list, counts + 1, sel, stats);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     const int gx = (N + LOSS_THREADS - 1) / LOSS_THREADS;
     hipLaunchKernelGGL(keep_kernel, dim3(gx < 64 ? gx : 64, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, sel, keep_mask, sums);

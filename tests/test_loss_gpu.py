@@ -84,6 +84,26 @@ def test_ties_resolved_by_lowest_flat_index():
     np.testing.assert_allclose(loss, want, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cfg,B", [("ssd7", 4), ("ssd300", 8)])
+def test_ties_at_scale(cfg, B):
+    """The compacted list of the pivot digit holds every value (all equal) or a few distinct levels whose ties straddle
+    the cut: the index-limit select runs over tens of thousands of ties."""
+    y_true, y_pred = _inputs(cfg, B, 35, bias=0.0)
+    C = y_true.shape[2] - 12
+    same = y_pred.copy()
+    same[:, :, :C] = 1.0 / C
+    levels = y_pred.copy()
+    levels[:, :, :C] = np.maximum(np.round(levels[:, :, :C] * 8.0) / 8.0, 1.0 / 64.0)
+    for yp in (same, levels):
+        for ratio in (3, 40):
+            kw = dict(neg_pos_ratio=ratio, n_neg_min=0, alpha=1.0)
+            loss, stats, keep, grad, w = _run(y_true, yp, **kw)
+            want, parts = orc.ssd_loss(y_true, yp, return_parts=True, **kw)
+            assert stats[2] == parts["k"]
+            assert np.array_equal(keep.astype(bool), parts["keep"].astype(bool))
+            np.testing.assert_allclose(loss, want, rtol=1e-4)
+
+
 def test_gradient_against_finite_differences():
     import torch
     from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
