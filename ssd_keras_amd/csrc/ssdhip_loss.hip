@@ -8,8 +8,9 @@
 //
 // Forward on the caller's stream:
 //   L1 anchor_kernel  grid (anchor tiles, B): tiles of y_true / y_pred rows copied coalesced into LDS; per anchor the
-//                     log loss (only where y_true != 0), smooth L1, positive / negative weights; writes cls_loss[B,N]
-//                     and neg_all[B,N], accumulates per-image sums (float64 atomics) and the two global counts.
+//                     log loss (only where y_true != 0), smooth L1, positive / negative weights; writes cls_loss[B,N], neg_all[B,N] and the tile's four partial sums (float64).
+//                     No atomics anywhere in the sums: L2b and L4 add the partials in a fixed order, so the loss is
+//                     bit-reproducible from run to run.
 //   L2 sel_*_kernel   k, then a radix select (11+11+10 bits of the order-preserving float key) for the k-th largest negative
 //                     loss: a chip-wide histogram of the top 11 bits (L2a), the pivot digit (L2b), a chip-wide compaction
 //                     of that digit's [key | index] pairs (L2c), and one workgroup finishing on the short list (L2d) --
@@ -30,11 +31,15 @@ constexpr int LOSS_THREADS = 256;
 constexpr int SEL_THREADS = 1024;
 constexpr int SELG_THREADS = 256;
 constexpr int SELG_MAX_BLOCKS = 256;
+constexpr int SELC_ITEMS = 8;
+constexpr int KEEP_BLOCKS = 64;
 constexpr int SEL_BINS = 2048;
 
 struct LossWs {
-    size_t sums, counts, hist, sel, cls, neg, list, total;   // sums: 3*B doubles + n_pos double; counts: [non-zero negative losses,
-                                                             // list length]; hist: L2a bins; sel: select state; list: L2c pairs
+    size_t sums, counts, hist, sel, cls, neg, list, part, keep_part, total;
+    // sums: per-image positive class loss [B] | loc loss [B] | (unused [B]) | n_pos; counts[1]: list length; hist: L2a bins;
+    // sel: select state; list: L2c pairs; part: L1's per-tile partial sums [4][B][tiles]; keep_part: L3's [B][KEEP_BLOCKS]
+    int tiles;
 };
 
 struct SelectResult {
@@ -50,8 +55,17 @@ struct SelectResult {
 
 static inline size_t lalign(size_t v) { return (v + 255) / 256 * 256; }
 
-static LossWs loss_ws_layout(int B, int N) {
+// anchors per L1 / backward tile: both row tiles ([TA][C+12] of y_true and y_pred) within 64 KB of LDS
+static int loss_tile(int L) {
+    int TA = 256;
+    while (TA > 64 && 2 * ((size_t)TA * L + 8) * sizeof(float) > 64 * 1024) TA >>= 1;
+    return TA;
+}
+
+static LossWs loss_ws_layout(int B, int N, int C) {
     LossWs w;
+    const int TA = loss_tile(C + 12);
+    w.tiles = (N + TA - 1) / TA;
     size_t o = 0;
     w.sums = o;   o = lalign(o + (size_t)(3 * B + 1) * sizeof(double));
     w.counts = o; o = lalign(o + 4 * sizeof(int));
@@ -60,6 +74,8 @@ static LossWs loss_ws_layout(int B, int N) {
     w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.neg = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.list = o;   o = lalign(o + (size_t)B * N * sizeof(u64));
+    w.part = o;   o = lalign(o + (size_t)4 * B * w.tiles * sizeof(double));
+    w.keep_part = o; o = lalign(o + (size_t)B * KEEP_BLOCKS * sizeof(double));
     w.total = o;
     return w;
 }
@@ -74,8 +90,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ======================================================================================
 __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
                                                               int B, int N, int C, float* __restrict__ cls_out,
-                                                              float* __restrict__ neg_out, double* __restrict__ sums,
-                                                              int* __restrict__ counts) {
+                                                              float* __restrict__ neg_out, double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4][LOSS_THREADS / 64];
     const int TA = blockDim.x, L = C + 12;
@@ -117,13 +132,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
     const double s_nz = wave_sum((double)nonzero);
     if (lane == 0) { red[0][wave] = s_poscls; red[1][wave] = s_loc; red[2][wave] = s_npos; red[3][wave] = s_nz; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {                                                     // per-tile partial sums, reduced in a fixed order by L2b
         double a = 0, l = 0, n = 0, z = 0;
         for (int w = 0; w < TA / 64; ++w) { a += red[0][w]; l += red[1][w]; n += red[2][w]; z += red[3][w]; }
-        if (a != 0.0) atomicAdd(&sums[b], a);
-        if (l != 0.0) atomicAdd(&sums[B + b], l);
-        if (n != 0.0) atomicAdd(&sums[3 * B], n);
-        if (z != 0.0) atomicAdd(&counts[0], (int)z);
+        const size_t tiles = gridDim.x, slot = (size_t)b * tiles + blockIdx.x, plane = (size_t)B * tiles;
+        part[slot] = a; part[plane + slot] = l; part[2 * plane + slot] = n; part[3 * plane + slot] = z;
     }
 }
 
@@ -147,14 +160,30 @@ __global__ __launch_bounds__(SELG_THREADS) void sel_hist_kernel(const float* __r
 
 // L2b: k (:166-177) and the top-11-bit digit the k-th largest value falls in
 __global__ __launch_bounds__(SEL_THREADS) void sel_pivot_kernel(const u32* __restrict__ ghist, int neg_pos_ratio, int n_neg_min,
-                                                                const double* __restrict__ sums, int B, const int* __restrict__ counts,
-                                                                SelectResult* __restrict__ res, float* __restrict__ stats) {
+                                                                const double* __restrict__ part, int tiles, double* __restrict__ sums,
+                                                                int B, SelectResult* __restrict__ res, float* __restrict__ stats) {
     __shared__ u32 hist[SEL_BINS];
     __shared__ int sh_out[2];
     __shared__ int wave_cnt[SEL_THREADS / 64];
-    const int tid = threadIdx.x;
-    const float n_pos = (float)sums[3 * B];
-    const int n_neg_losses = counts[0];
+    __shared__ double tot[2][SEL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // L1's per-tile partial sums -> per-image sums (one wave each) and the two batch totals: fixed order, no atomics
+    const size_t plane = (size_t)B * tiles;
+    for (int job = wave; job < 2 * B; job += SEL_THREADS / 64) {         // job = q * B + b, q = 0 positive class loss, 1 loc loss
+        double v = 0.0;
+        for (int t = lane; t < tiles; t += 64) v += part[(size_t)job * tiles + t];
+        v = wave_sum(v);
+        if (lane == 0) sums[job] = v;
+    }
+    double np_ = 0.0, nz_ = 0.0;
+    for (size_t i = tid; i < plane; i += SEL_THREADS) { np_ += part[2 * plane + i]; nz_ += part[3 * plane + i]; }
+    np_ = wave_sum(np_); nz_ = wave_sum(nz_);
+    if (lane == 0) { tot[0][wave] = np_; tot[1][wave] = nz_; }
+    __syncthreads();
+    np_ = 0.0; nz_ = 0.0;
+    for (int w = 0; w < SEL_THREADS / 64; ++w) { np_ += tot[0][w]; nz_ += tot[1][w]; }
+    const float n_pos = (float)np_;
+    const int n_neg_losses = (int)nz_;
     int k = neg_pos_ratio * (int)n_pos;                                  // tf.to_int32(n_positive) truncates (:166)
     k = k > n_neg_min ? k : n_neg_min;
     k = k < n_neg_losses ? k : n_neg_losses;
@@ -164,6 +193,7 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_pivot_kernel(const u32* __res
         block_find_digit<SEL_BINS / SEL_THREADS>(hist, k, wave_cnt, sh_out);
     }
     if (tid == 0) {
+        sums[3 * B] = np_;
         res->k = k; res->thresh_key = 0; res->tie_limit = 0x7fffffff; res->n_neg_losses = n_neg_losses;
         res->n_pos = n_pos; res->thresh = 0.f;
         res->digit = k > 0 ? sh_out[0] : 0;
@@ -172,26 +202,44 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_pivot_kernel(const u32* __res
     }
 }
 
-// L2c: the values of that digit, as [key | flat index] pairs, appended to a list (order does not matter)
+// L2c: the values of that digit, as [key | flat index] pairs, appended to a list (order does not matter): each workgroup
+// takes SELC_ITEMS * 256 values, counts its matches, reserves its slice of the list with one atomic
 __global__ __launch_bounds__(SELG_THREADS) void sel_compact_kernel(const float* __restrict__ neg_all, int total,
                                                                    const SelectResult* __restrict__ res, int* __restrict__ list_count,
                                                                    u64* __restrict__ list) {
+    __shared__ int wave_tot[SELG_THREADS / 64];
+    __shared__ int base_sh;
     if (res->k <= 0) return;
     const u32 digit = (u32)res->digit;
-    const int lane = threadIdx.x & 63;
-    for (int base = blockIdx.x * SELG_THREADS; base < total; base += gridDim.x * SELG_THREADS) {
-        const int i = base + threadIdx.x;
-        u32 key = 0;
-        bool is = false;
-        if (i < total) { key = float_key(neg_all[i]); is = (key >> 21) == digit; }
-        const u64 m = __ballot(is);
-        if (m) {                                                        // wave-uniform
-            int start = 0;
-            if (lane == 0) start = atomicAdd(list_count, __popcll(m));
-            start = __shfl(start, 0);
-            if (is) list[start + __popcll(m & lanemask_lt())] = ((u64)key << 32) | (u64)(u32)i;
-        }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * (SELG_THREADS * SELC_ITEMS) + tid;
+    u32 keys[SELC_ITEMS];
+    u32 hit = 0;
+#pragma unroll
+    for (int j = 0; j < SELC_ITEMS; ++j) {
+        const int i = i0 + j * SELG_THREADS;
+        keys[j] = i < total ? float_key(neg_all[i]) : 0u;
+        if (i < total && (keys[j] >> 21) == digit) hit |= 1u << j;
     }
+    const int cnt = __popc(hit);
+    int incl = cnt;                                                     // inclusive prefix over the lanes of this wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < SELG_THREADS / 64; ++w) t += wave_tot[w];
+        base_sh = t ? atomicAdd(list_count, t) : 0;
+    }
+    __syncthreads();
+    int pos = base_sh + incl - cnt;
+    for (int w = 0; w < wave; ++w) pos += wave_tot[w];
+#pragma unroll
+    for (int j = 0; j < SELC_ITEMS; ++j)
+        if (hit & (1u << j)) list[pos++] = ((u64)keys[j] << 32) | (u64)(u32)(i0 + j * SELG_THREADS);
 }
 
 // L2d: one workgroup finishes on the list: the remaining 21 key bits, then -- only if ties straddle the cut -- the flat
@@ -267,7 +315,7 @@ __global__ __launch_bounds__(SEL_THREADS) void sel_finish_kernel(const u64* __re
 // ======================================================================================
 __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restrict__ cls, const float* __restrict__ neg_all,
                                                             int B, int N, const SelectResult* __restrict__ res,
-                                                            unsigned char* __restrict__ keep, double* __restrict__ sums) {
+                                                            unsigned char* __restrict__ keep, double* __restrict__ keep_part) {
     __shared__ double red[LOSS_THREADS / 64];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = res->k, tie_limit = res->tie_limit;
@@ -289,15 +337,18 @@ __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restr
     if (tid == 0) {
         double a = 0;
         for (int w = 0; w < LOSS_THREADS / 64; ++w) a += red[w];
-        if (a != 0.0) atomicAdd(&sums[2 * B + b], a);
+        keep_part[(size_t)b * KEEP_BLOCKS + blockIdx.x] = a;              // summed in a fixed order by L4
     }
 }
 
-__global__ void total_kernel(const double* __restrict__ sums, int B, float alpha, float* __restrict__ loss) {
+__global__ void total_kernel(const double* __restrict__ sums, const double* __restrict__ keep_part, int keep_blocks, int B, float alpha,
+                             float* __restrict__ loss) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float n_pos = (float)sums[3 * B];
-    const float cls = (float)sums[b] + (float)sums[2 * B + b];            // class_loss = pos + neg (:200)
+    double neg = 0.0;
+    for (int i = 0; i < keep_blocks; ++i) neg += keep_part[(size_t)b * KEEP_BLOCKS + i];
+    const float cls = (float)sums[b] + (float)neg;                        // class_loss = pos + neg (:200)
     const float tot = (cls + alpha * (float)sums[B + b]) / fmaxf(1.0f, n_pos);
     loss[b] = tot * (float)B;                                             // :208-209
 }
@@ -347,15 +398,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void backward_kernel(const float* __r
 
 using namespace ssdhip;
 
-static int loss_tile(int L) {
-    int TA = 256;
-    while (TA > 64 && 2 * ((size_t)TA * L + 8) * sizeof(float) > 64 * 1024) TA >>= 1;
-    return TA;
-}
-
 extern "C" size_t ssdhip_loss_workspace_bytes(int B, int N, int C) {
     if (B <= 0 || N <= 0 || C < 2) return 0;
-    return loss_ws_layout(B, N).total;
+    return loss_ws_layout(B, N, C).total;
 }
 
 extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int B, int N, int C,
@@ -365,7 +410,7 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!y_true || !y_pred || !loss_per_item || !stats || !keep_mask || B <= 0 || N <= 0 || C < 2) return SSDHIP_E_BADARG;
     if ((long long)B * N > 0x7ffffff0LL) return SSDHIP_E_BADARG;
-    const LossWs lay = loss_ws_layout(B, N);
+    const LossWs lay = loss_ws_layout(B, N, C);
     if (!ws || ws_bytes < lay.total) return SSDHIP_E_WORKSPACE;
     unsigned char* base = static_cast<unsigned char*>(ws);
     double* sums = reinterpret_cast<double*>(base + lay.sums);
@@ -375,29 +420,34 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     float* neg = reinterpret_cast<float*>(base + lay.neg);
     u32* ghist = reinterpret_cast<u32*>(base + lay.hist);
     u64* list = reinterpret_cast<u64*>(base + lay.list);
-    if (hipMemsetAsync(base, 0, lay.sel, stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // sums + counts + L2a bins
+    double* part = reinterpret_cast<double*>(base + lay.part);
+    double* keep_part = reinterpret_cast<double*>(base + lay.keep_part);
+    if (hipMemsetAsync(base, 0, lay.sel, stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // list length + L2a bins (the sums are plain stores)
 
     const int L = C + 12;
     const int TA = loss_tile(L);
     const size_t lds = 2 * (((size_t)TA * L + 4 + 3) / 4 * 4) * sizeof(float) + 16;
     if (lds > 150 * 1024) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(anchor_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, sums, counts);
+    hipLaunchKernelGGL(anchor_kernel, dim3(lay.tiles, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, part);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     const int total = B * N;
     int sel_blocks = (total + SELG_THREADS - 1) / SELG_THREADS;
     if (sel_blocks > SELG_MAX_BLOCKS) sel_blocks = SELG_MAX_BLOCKS;
+    const int compact_blocks = (total + SELG_THREADS * SELC_ITEMS - 1) / (SELG_THREADS * SELC_ITEMS);
     hipLaunchKernelGGL(sel_hist_kernel, dim3(sel_blocks), dim3(SELG_THREADS), 0, stream, neg, total, ghist);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(sel_pivot_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, ghist, neg_pos_ratio, n_neg_min, sums, B, counts, sel, stats);
+    hipLaunchKernelGGL(sel_pivot_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, ghist, neg_pos_ratio, n_neg_min, part, lay.tiles, sums, B, sel,
+                       stats);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(sel_compact_kernel, dim3(sel_blocks), dim3(SELG_THREADS), 0, stream, neg, total, sel, counts + 1, list);
+    hipLaunchKernelGGL(sel_compact_kernel, dim3(compact_blocks), dim3(SELG_THREADS), 0, stream, neg, total, sel, counts + 1, list);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     hipLaunchKernelGGL(sel_finish_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, list, counts + 1, sel, stats);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    const int gx = (N + LOSS_THREADS - 1) / LOSS_THREADS;
-    hipLaunchKernelGGL(keep_kernel, dim3(gx < 64 ? gx : 64, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, sel, keep_mask, sums);
+    int gx = (N + LOSS_THREADS - 1) / LOSS_THREADS;
+    if (gx > KEEP_BLOCKS) gx = KEEP_BLOCKS;
+    hipLaunchKernelGGL(keep_kernel, dim3(gx, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, sel, keep_mask, keep_part);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(total_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sums, B, alpha, loss_per_item);
+    hipLaunchKernelGGL(total_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sums, keep_part, gx, B, alpha, loss_per_item);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     return SSDHIP_OK;
 }

@@ -134,27 +134,31 @@ class SSDInputEncoder:
         return self._dev[key]
 
     def _pack_ground_truth(self, ground_truth_labels):
-        '''Host-side checks of :327-336 (labels originate on the host) + CSR packing.'''
-        rows, offsets, max_g = [], [0], 0
+        '''Host-side checks of :327-336 (labels originate on the host) + CSR packing.  One concatenation and vectorised
+        checks over the whole batch: the per-image Python work is an `asarray` and a `reshape`.'''
+        rows, counts = [], np.zeros(len(ground_truth_labels) + 1, dtype=np.int64)
         for i, lab in enumerate(ground_truth_labels):
             lab = np.asarray(lab)
-            if lab.size == 0:
-                offsets.append(offsets[-1])
-                continue
-            lab = lab.astype(np.float64).reshape(-1, 5)
-            if np.any(lab[:, 3] - lab[:, 1] <= 0) or np.any(lab[:, 4] - lab[:, 2] <= 0):
-                raise DegenerateBoxError("SSDInputEncoder detected degenerate ground truth bounding boxes for batch item {} with "
-                                         "bounding boxes {}, ".format(i, lab) + "i.e. bounding boxes where xmax <= xmin and/or "
-                                         "ymax <= ymin. Degenerate ground truth bounding boxes will lead to NaN errors during "
-                                         "the training.")
-            cls = lab[:, 0].astype(np.int64)
-            if np.any(cls < 0) or np.any(cls >= self.n_classes):
-                raise IndexError("class id out of range for {} classes (incl. background)".format(self.n_classes))
-            rows.append(lab)
-            offsets.append(offsets[-1] + lab.shape[0])
-            max_g = max(max_g, lab.shape[0])
-        gt = np.concatenate(rows, axis=0) if rows else np.zeros((0, 5))
-        return np.ascontiguousarray(gt), np.asarray(offsets, dtype=np.int32), max_g
+            if lab.size:
+                lab = lab.reshape(-1, 5)
+                rows.append(lab)
+                counts[i + 1] = lab.shape[0]
+        offsets = np.cumsum(counts)
+        if not rows:
+            return np.zeros((0, 5)), offsets.astype(np.int32), 0
+        gt = np.ascontiguousarray(np.concatenate(rows, axis=0), dtype=np.float64)
+        bad = (gt[:, 3] - gt[:, 1] <= 0) | (gt[:, 4] - gt[:, 2] <= 0)
+        if bad.any():
+            i = int(np.searchsorted(offsets, int(np.argmax(bad)), side='right')) - 1
+            lab = gt[offsets[i]:offsets[i + 1]]
+            raise DegenerateBoxError("SSDInputEncoder detected degenerate ground truth bounding boxes for batch item {} with "
+                                     "bounding boxes {}, ".format(i, lab) + "i.e. bounding boxes where xmax <= xmin and/or "
+                                     "ymax <= ymin. Degenerate ground truth bounding boxes will lead to NaN errors during "
+                                     "the training.")
+        cls = gt[:, 0].astype(np.int64)
+        if cls.min() < 0 or cls.max() >= self.n_classes:
+            raise IndexError("class id out of range for {} classes (incl. background)".format(self.n_classes))
+        return gt, offsets.astype(np.int32), int(counts.max())
 
     def encode_to_device(self, ground_truth_labels, device=None, want_f32=True, want_f64=False, want_matches=False):
         '''Run the encoder kernels; outputs stay in HBM.  Returns (y_f32 | None, y_f64 | None, match_gt | None).'''
@@ -169,8 +173,14 @@ class SSDInputEncoder:
             raise ValueError("at most 1024 ground truth boxes per image are supported, got {}".format(max_g))
         B, N, C = len(ground_truth_labels), self.n_anchors, self.n_classes
         anchors, variances = self._device_constants(device)
-        gt_d = torch.from_numpy(gt).to(device) if gt.shape[0] else torch.zeros((1, 5), dtype=torch.float64, device=device)
-        off_d = torch.from_numpy(offsets).to(device)
+        # one upload: [offsets int32 (B+1), padded to 8 bytes | ground truth rows float64]
+        n_off = (offsets.shape[0] + 1) // 2
+        packed = np.empty(n_off + max(int(gt.shape[0]), 1) * 5, dtype=np.float64)
+        packed[:n_off].view(np.int32)[:offsets.shape[0]] = offsets
+        packed[n_off:n_off + gt.size] = gt.ravel()
+        packed_d = torch.from_numpy(packed).to(device)
+        off_d = packed_d[:n_off].view(torch.int32)
+        gt_d = packed_d[n_off:]
         y32 = torch.empty((B, N, C + 12), dtype=torch.float32, device=device) if want_f32 else None
         y64 = torch.empty((B, N, C + 12), dtype=torch.float64, device=device) if want_f64 else None
         mm = torch.empty((B, N), dtype=torch.int32, device=device) if want_matches else None

@@ -104,6 +104,15 @@ def test_ties_at_scale(cfg, B):
             np.testing.assert_allclose(loss, want, rtol=1e-4)
 
 
+def test_loss_is_bit_reproducible():
+    """No atomics in the sums: the per-tile partials are added in a fixed order, so two runs agree to the last bit."""
+    y_true, y_pred = _inputs("ssd300", 8, 41)
+    a = _run(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+    b = _run(y_true, y_pred, neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
 def test_gradient_against_finite_differences():
     import torch
     from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
