@@ -56,7 +56,10 @@ def conv_choice_label(key):
             return "head%d %s -> %d+%d k3" % (key[1], "x".join(str(v) for v in key[2]), key[3], key[4])
         if kind == "heads":                                  # ("heads", shapes of all source maps, classes)
             return "all heads (%d source maps)" % len(key[1])
-        return "%s %s -> %s k%s d%s" % (kind, "x".join(str(v) for v in key[1]), key[2], key[3], key[4])
+        label = "%s %s -> %s k%s d%s" % (kind, "x".join(str(v) for v in key[1]), key[2], key[3], key[4])
+        if kind == "act" and len(key) >= 8 and (key[6] != 1 or key[7] != key[4] * (key[3] // 2)):
+            label += " s%s p%s" % (key[6], key[7])              # strided / partially padded extra layers
+        return label
     except Exception:
         return repr(key)
 

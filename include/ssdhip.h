@@ -258,6 +258,12 @@ int ssdhip_assemble_predictions_strided_bf16(int n_layers, const void* const* co
  *   y [B,H,W,Cout] bf16.  Cin % 64 == 0, Cout % 64 == 0; float32 accumulation, one rounding to bf16 after bias + activation. */
 int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                  int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
+/* General form of the above (same kernel, only the tile prologue's pixel -> address map differs): stride 1..4 and zero padding
+ * 0 <= pad <= (kernel/2)*dilation on every side, torch.nn.Conv2d semantics -- the SSD extra layers conv6_2 / conv7_2
+ * (ZeroPadding2D(1) + 3x3 stride 2, models/keras_ssd300.py:302-307) and conv8_2 / conv9_2 (3x3 'valid', :310-313).
+ *   y [B,Ho,Wo,Cout], Ho = (H + 2*pad - dilation*(kernel-1) - 1) / stride + 1.  Tensors below 2 GiB (31-bit buffer offsets). */
+int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                            int kernel, int stride, int pad, int dilation, int relu, void* stream);
 /* Profiling aid: the same with an explicit kernel variant (4: the shipped kernel -- 128-pixel tile, two LDS stages, buffer-addressed
  * LDS-DMA loads, batched fragment reads; 1: its predecessor with per-lane pointers; 3: 256-pixel tile, three-stage weight pipeline,
  * kw-reuse of the activation strip; 5 / 6: four / three-stage LDS ring of 32-channel slices; 9: eight waves per workgroup with the

@@ -400,6 +400,32 @@ def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
     return y
 
 
+def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True):
+    """Convolution (kernel 1 or 3, stride 1..4, zero padding <= (k//2)*dilation: torch.nn.Conv2d semantics) + bias + ReLU in
+    ONE libssdhip MFMA kernel -- the strided / 'valid' extra layers of the SSD trunk.  Layouts as conv2d_same."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_convgen_bound", False):
+        lib.ssdhip_conv2d_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv2d_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 10 + [ctypes.c_void_p]
+        lib._convgen_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or kh != kw:
+        raise SsdHipError("weight must be bfloat16 (Cout, %d, k, k)" % cin)
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    span = int(dilation) * (int(kh) - 1) + 1
+    ho, wo = (h + 2 * int(padding) - span) // int(stride) + 1, (w + 2 * int(padding) - span) // int(stride) + 1
+    if ho < 1 or wo < 1:
+        raise SsdHipError("convolution output would be empty")
+    y = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv2d_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(kh), int(stride), int(padding),
+                                         int(dilation), int(bool(relu)), current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv2d_nhwc_bf16")
+    return y
+
+
 def conv2d_same_pool2(x, weight, bias, dilation=1, relu=True):
     """'same' convolution + bias + ReLU + 2x2 / stride-2 max-pool ('same' = windows clipped to the map) in ONE libssdhip
     MFMA kernel.  x (B, Cin, H, W) bf16 NHWC memory -> (B, Cout, ceil(H/2), ceil(W/2))."""

@@ -44,6 +44,9 @@ struct ConvParams {
     int M, m_tiles, n_tiles;
     int Ho, Wo, WT, HT, cshift;  // fused 2x2/2 max-pool: pooled map size; a tile is (64 >> cshift) row pairs x (1 << cshift)
                                  // columns, WT x HT tiles per image
+    int stride, coff, Min;       // v4 only: output pixel (ho, wo) is centred on input pixel (ho*stride + coff, wo*stride + coff),
+                                 // coff = (KS/2)*dil - pad >= 0; then Ho x Wo is the output map, M = B*Ho*Wo and Min = B*H*W.
+                                 // stride 1, coff 0 is the 'same' convolution (Min == M)
 };
 
 __device__ __forceinline__ u32 f2bf_rn(float f) {
@@ -257,14 +260,37 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
 
     const int neg = (half * dil * p.W + half * dil) * Cin * 2;            // bytes; largest negative tap displacement
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.M * Cin * 2 + 2 * neg, 0x00020000);
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.Min * Cin * 2 + 2 * neg, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.w)), 0, p.Cout * KK * Cin * 2, 0x00020000);
 
     // ---- per-thread load descriptors: byte offsets of 4 X rows (+ tap validity) and CI*2 weight rows ---------------
     u32 xoff[4], xok[4], woff[CI * 2];
     const int pos = lane & 7;
-    if constexpr (!POOL) {
+    if (!POOL && (p.stride != 1 || p.coff != 0)) {
+        // strided and / or partially padded: the tile's 128 OUTPUT pixels, each centred on its own input pixel; the taps
+        // are the same displacements around that centre, so everything after this prologue is unchanged
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            const int j = pos ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+            const int hq = ho * p.stride + p.coff, wq = wo * p.stride + p.coff;
+            u32 rmask = 0, cmask = 0;
+            for (int k = 0; k < KS; ++k) {
+                const int d = (k - half) * dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (m < p.M)
+                for (int kh = 0; kh < KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+            xok[i] = ok;
+            xoff[i] = (u32)((b * p.H + hq) * p.W + wq) * (u32)(Cin * 2) + (u32)(j * 16);
+        }
+    } else if constexpr (!POOL) {
         int m = m0 + wave * 8 + (lane >> 3);
         int wq = m % p.W, hq = (m / p.W) % p.H;
 #pragma unroll
@@ -1267,6 +1293,7 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
     p.M = (int)M;
     p.Ho = p.Wo = p.WT = p.HT = p.cshift = 0;
+    p.stride = 1; p.coff = 0; p.Min = (int)M;
     const bool wide = (Cout % 128) == 0;
     p.n_tiles = Cout / (wide ? 128 : 64);
     const bool small = M * Cin * 2 + 4LL * (dilation * W + dilation) * Cin < 0x7ffff000LL && (long long)Cout * kernel * kernel * Cin * 2 < 0x7ffff000LL;
@@ -1312,6 +1339,42 @@ extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, c
     return conv_run(4, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }
 
+// General form: stride >= 1 and zero padding 0 <= pad <= (kernel/2)*dilation on every side (torch.nn.Conv2d semantics):
+//   y[b,ho,wo,co] = act(bias[co] + sum x[b, ho*stride - pad + kh*dil, wo*stride - pad + kw*dil, ci] * w[co,kh,kw,ci]),
+//   Ho = (H + 2*pad - dil*(kernel-1) - 1) / stride + 1 (same for Wo).
+// The SSD extra layers: conv6_2 / conv7_2 (ZeroPadding2D(1) + 3x3 stride 2, models/keras_ssd300.py:302-307) and conv8_2 /
+// conv9_2 (3x3 'valid', :310-313).  Same kernel as the 'same' convolution: only the tile prologue's pixel -> address map differs.
+extern "C" int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                                       int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || dilation <= 0 || dilation > 8) return SSDHIP_E_BADARG;
+    if ((kernel != 1 && kernel != 3) || stride < 1 || stride > 4) return SSDHIP_E_BADARG;
+    const int reach = (kernel / 2) * dilation;
+    if (pad < 0 || pad > reach) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % CONV_BK) || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 7)) return SSDHIP_E_BADARG;
+    const int Ho = (H + 2 * pad - 2 * reach - 1) / stride + 1, Wo = (W + 2 * pad - 2 * reach - 1) / stride + 1;
+    if (H + 2 * pad - 2 * reach < 1 || W + 2 * pad - 2 * reach < 1) return SSDHIP_E_BADARG;
+    const long long Min = (long long)B * H * W, M = (long long)B * Ho * Wo;
+    if (Min * Cin * 2 + 4LL * (dilation * W + dilation) * Cin >= 0x7ffff000LL || (long long)Cout * kernel * kernel * Cin * 2 >= 0x7ffff000LL ||
+        M * Cout > 0x7fffffff0LL)
+        return SSDHIP_E_BADARG;                // buffer addressing: 31-bit byte offsets
+    ConvParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
+    p.M = (int)M; p.Min = (int)Min;
+    p.Ho = Ho; p.Wo = Wo; p.WT = p.HT = p.cshift = 0;
+    p.stride = stride; p.coff = reach - pad;
+    const bool wide = (Cout % 128) == 0;
+    p.n_tiles = Cout / (wide ? 128 : 64);
+    p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+    const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+    if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_igemm4_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 // Profiling aid: the same with an explicit kernel variant (4: the shipped kernel; 1: its predecessor with per-lane
 // pointers, per-step divisions and per-kk fragment waits -- 10-27 % slower on the VGG shapes; 3: the
 // 256-pixel / three-stage / kw-reuse experiment, which halves L2 traffic but loses to barrier stalls at one workgroup per CU).
@@ -1340,6 +1403,7 @@ extern "C" int ssdhip_conv2d_same_pool2_nhwc_bf16(const void* x, const void* wei
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
     p.M = (int)M;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.stride = 1; p.coff = 0; p.Min = (int)M;
     long long best = -1;                      // tile shape (64 >> cs row pairs x 1 << cs columns) with the smallest padded area
     for (int cs = 6; cs >= 1; --cs) {
         const long long wt = (W + (1 << cs) - 1) >> cs, ht = (p.Ho + (64 >> cs) - 1) / (64 >> cs);
@@ -1387,6 +1451,7 @@ extern "C" int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* co
         p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = ks; p.dil = dil; p.relu = relu ? 1 : 0;
         p.M = (int)M;
         p.Ho = p.Wo = p.WT = p.HT = p.cshift = 0;
+        p.stride = 1; p.coff = 0; p.Min = (int)M;
         p.n_tiles = (Cout % 128 == 0) ? Cout / 128 : Cout / 64;
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         blocks += (long long)((p.m_tiles + 7) / 8) * p.n_tiles * 8;

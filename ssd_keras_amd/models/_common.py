@@ -122,6 +122,16 @@ class SSDModel(nn.Module):
                 and conv.dilation[0] == conv.dilation[1] and conv.padding == (conv.dilation[0] * (k // 2),) * 2
                 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.bias is not None)
 
+    @staticmethod
+    def _igemm_general_ok(conv, x):
+        """Strided / partially padded 3x3 and 1x1 layers (conv6_2 ... conv9_2) for nat.conv2d."""
+        k = conv.kernel_size[0]
+        return (k in (1, 3) and conv.kernel_size[1] == k and conv.stride[0] == conv.stride[1] and 1 <= conv.stride[0] <= 4
+                and conv.groups == 1 and conv.dilation[0] == conv.dilation[1] and isinstance(conv.padding, tuple)
+                and conv.padding[0] == conv.padding[1] and 0 <= conv.padding[0] <= conv.dilation[0] * (k // 2)
+                and conv.padding_mode == 'zeros' and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+                and conv.bias is not None)
+
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
         import os
@@ -173,7 +183,11 @@ class SSDModel(nn.Module):
                 cands["igemm6"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=6)
                 if conv.in_channels == 64 and k == 3 and conv.dilation[0] == 1:
                     cands["c64"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=relu, pool=False)
-            name = self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu), cands) if len(cands) > 1 else "miopen"
+            elif self._igemm_general_ok(conv, x):
+                cands["igemm"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
+                                                    dilation=conv.dilation[0], relu=relu)
+            name = (self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu, conv.stride[0], conv.padding[0]), cands)
+                    if len(cands) > 1 else "miopen")
             return cands[name]()
         y = conv(x)
         return F.relu(y) if relu else y

@@ -45,6 +45,56 @@ def test_conv_vs_float32_reference(case, variant):
     assert bad == 0, "%d of %d outputs off; max err %g (rms %g)" % (bad, err.numel(), err.max().item(), rms)
 
 
+GENERAL_CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil, bias, relu
+    (32, 19, 19, 256, 512, 3, 2, 1, 1, True, True),   # conv6_2 (ZeroPadding2D(1) + stride 2): 19 -> 10
+    (32, 10, 10, 128, 256, 3, 2, 1, 1, True, True),   # conv7_2: 10 -> 5
+    (32, 5, 5, 128, 256, 3, 1, 0, 1, True, True),     # conv8_2 ('valid'): 5 -> 3
+    (32, 3, 3, 128, 256, 3, 1, 0, 1, True, True),     # conv9_2: 3 -> 1
+    (2, 32, 32, 128, 256, 3, 2, 1, 1, True, True),    # SSD512 conv7_2-like, even size: 32 -> 16
+    (3, 11, 7, 64, 64, 3, 3, 0, 1, False, False),     # stride 3, no padding, rectangular, no bias / ReLU, BC = 64
+    (1, 20, 20, 64, 128, 3, 2, 2, 2, True, True),     # dilation 2 with full padding and stride 2
+    (2, 9, 9, 64, 64, 1, 2, 0, 1, True, True),        # 1x1 stride 2 (sub-sampling)
+    (1, 16, 16, 64, 64, 3, 1, 1, 1, True, True),      # the 'same' special case through the general entry
+    (1, 13, 13, 64, 64, 3, 1, 0, 2, True, True),      # 'valid' with dilation 2: 13 -> 9
+]
+
+
+@pytest.mark.parametrize("case", GENERAL_CASES)
+def test_general_conv_vs_float32_reference(case):
+    """Strided / partially padded convolutions (the SSD extra layers) through ssdhip_conv2d_nhwc_bf16."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, k, stride, pad, dil, has_bias, relu = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
+    got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=dil, relu=relu).float()
+    want = F.conv2d(x.float(), wt.float(), bias.float() if has_bias else None, stride, pad, dil)
+    if relu:
+        want = torch.relu(want)
+    assert got.shape == want.shape
+    rms = want.pow(2).mean().sqrt().item()
+    err = (got - want).abs()
+    tol = want.abs() * 2.0 ** -7 + 1e-2 * rms
+    bad = int((err > tol).sum().item())
+    assert bad == 0, "%d of %d outputs off; max err %g (rms %g)" % (bad, err.numel(), err.max().item(), rms)
+
+
+def test_general_conv_rejects_unsupported_arguments():
+    import torch
+    from ssd_keras_amd import _native as nat
+    x = torch.zeros((1, 8, 8, 64), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
+    w = torch.zeros((64, 64, 3, 3), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d(x, w, None, stride=1, padding=2)          # more padding than the kernel reaches
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d(x, w, None, stride=5, padding=0)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d(x[:, :, :2, :2].contiguous(memory_format=torch.channels_last), w, None, stride=1, padding=0)   # empty output
+
+
 def test_conv_rejects_unsupported_shapes():
     import torch
     from ssd_keras_amd import _native as nat
