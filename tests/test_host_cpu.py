@@ -199,3 +199,81 @@ def test_evaluator_ground_truth_packing():
             assert np.array_equal(flags[off[i]:off[i + 1]].astype(bool), np.asarray(neutral[i], dtype=bool).reshape(-1)[m])
     cat, img, ncat = Evaluator._concat_ground_truth(labels, None)
     assert ncat is None and Evaluator._class_ground_truth(cat, img, None, len(labels), 2, 0, [1, 2, 3, 4])[2] is None
+
+
+def test_entry_points_reject_bad_arguments_before_launching(lib):
+    """Argument validation happens on the host, ahead of any launch: callable without a GPU."""
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    conv = lib.ssdhip_conv2d_nhwc_bf16
+    conv.restype = ci
+    conv.argtypes = [vp] * 4 + [ci] * 10 + [vp]
+    dummy = ctypes.create_string_buffer(64)
+    a = ctypes.addressof(dummy)
+    a += (-a) % 16                                                    # a 16-byte aligned, non-null fake pointer (never dereferenced)
+    ok_dims = dict(B=1, H=8, W=8, Cin=64, Cout=64, k=3, stride=2, pad=1, dil=1)
+
+    def call(**kw):
+        d = dict(ok_dims)
+        d.update(kw)
+        return conv(a, a, None, a, d["B"], d["H"], d["W"], d["Cin"], d["Cout"], d["k"], d["stride"], d["pad"], d["dil"], 1, None)
+
+    assert conv(None, None, None, None, 1, 8, 8, 64, 64, 3, 2, 1, 1, 1, None) == -1       # SSDHIP_E_BADARG
+    for bad in (dict(Cin=48), dict(Cout=32), dict(k=5), dict(stride=0), dict(stride=5), dict(pad=2), dict(pad=-1), dict(dil=0),
+                dict(H=2, W=2, pad=0)):
+        assert call(**bad) == -1, bad
+    same = lib.ssdhip_conv2d_same_nhwc_bf16
+    same.restype = ci
+    same.argtypes = [vp] * 4 + [ci] * 8 + [vp]
+    assert same(a, a, None, a, 1, 8, 8, 64, 48, 3, 1, 1, None) == -1
+    loss = lib.ssdhip_loss_forward
+    loss.restype = ci
+    loss.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.c_float, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    assert loss(a, a, 2, 10, 6, 3, 0, 1.0, a, a, a, a, 16, None) == -2                      # SSDHIP_E_WORKSPACE: too small
+    assert loss(a, a, 2, 10, 1, 3, 0, 1.0, a, a, a, a, 1 << 20, None) == -1                 # C < 2
+
+
+def test_autotune_keeps_the_fastest_candidate_and_probes_slow_ones_once(monkeypatch):
+    """SSDModel._pick (models/_common.py): best of two bursts per candidate; the library candidate goes last and is dropped
+    after one probe call when that alone is slower than three calls of the best so far."""
+    import time
+    import torch
+    from ssd_keras_amd.models._common import SSDModel
+
+    class FakeEvent:
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.delenv("SSDHIP_CONV", raising=False)
+    saved = dict(SSDModel._conv_choice)
+    SSDModel._conv_choice.clear()
+    try:
+        calls = {}
+
+        def cand(name, seconds):
+            def fn():
+                calls[name] = calls.get(name, 0) + 1
+                time.sleep(seconds)
+            return fn
+
+        m = SSDModel.__new__(SSDModel)
+        got = m._pick(("t", 1), {"miopen": cand("miopen", 0.02), "igemm": cand("igemm", 0.002), "igemm6": cand("igemm6", 0.001)})
+        assert got == "igemm6" and calls["miopen"] == 2 and calls["igemm"] >= 9 and calls["igemm6"] >= 9
+        calls.clear()
+        assert m._pick(("t", 2), {"miopen": cand("miopen", 0.001), "igemm": cand("igemm", 0.003)}) == "miopen"
+        assert m._pick(("t", 2), {}) == "miopen"                         # cached per key
+        monkeypatch.setenv("SSDHIP_CONV", "igemm")
+        assert m._pick(("t", 3), {"miopen": None, "igemm": None}) == "igemm" and m._pick(("t", 4), {"miopen": None}) == "miopen"
+    finally:
+        SSDModel._conv_choice.clear()
+        SSDModel._conv_choice.update(saved)
