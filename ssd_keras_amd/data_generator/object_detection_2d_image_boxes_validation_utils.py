@@ -83,6 +83,28 @@ class BoxFilter:
         off = np.cumsum([0] + counts)
         return [keep[off[i]:off[i + 1]] for i in range(len(arrs))]
 
+    def masks_patches(self, labels, patch_ymin, patch_xmin, patch_heights, patch_widths):
+        '''Keep masks (T, g) of ONE image's boxes against T candidate patches in one launch: patch t sees the boxes translated into
+        its own coordinate system (minus (patch_xmin[t], patch_ymin[t]), evaluated in the dtype of `labels` like the reference's in-place
+        `labels[:, [xmin, xmax]] -= patch_xmin`) and tests them against (patch_heights[t], patch_widths[t]).  This is the shape of a
+        random-crop step: every trial of a sampling round validated at once.'''
+        lf = self.labels_format
+        cols = [lf['xmin'], lf['ymin'], lf['xmax'], lf['ymax']]
+        labels = np.asarray(labels)
+        T = len(patch_ymin)
+        g = labels.shape[0] if labels.ndim == 2 else 0
+        if g == 0 or T == 0:
+            return np.zeros((T, g), dtype=bool)
+        px, py = np.asarray(patch_xmin), np.asarray(patch_ymin)
+        shift = np.stack([px, py, px, py], axis=1).astype(labels.dtype)
+        boxes = (labels[:, cols][None, :, :] - shift[:, None, :]).astype(np.float64).reshape(T * g, 4)
+        box_image = np.repeat(np.arange(T, dtype=np.int32), g)
+        hw = np.stack([np.asarray(patch_heights, dtype=np.float64), np.asarray(patch_widths, dtype=np.float64)], axis=1)
+        lower, upper = self._bounds() if self.check_overlap else (0.0, 1.0)
+        keep = nat.box_filter(boxes, box_image, hw, self.check_overlap, self.check_min_area, self.check_degenerate,
+                              self.overlap_criterion, lower, upper, self.min_area, self.border_pixels).cpu().numpy().astype(bool)
+        return keep.reshape(T, g)
+
     def filter_batch(self, labels_list, image_heights, image_widths):
         '''`[labels[mask] for each image]` in one launch.'''
         masks = self.masks_batch(labels_list, image_heights, image_widths)
@@ -120,6 +142,16 @@ class ImageValidator:
         if self.n_boxes_min == 'all':
             return [bool(m.sum() == len(m)) for m in masks]
         return [bool(m.sum() >= self.n_boxes_min) for m in masks]
+
+    def validate_patches(self, labels, patch_ymin, patch_xmin, patch_heights, patch_widths):
+        '''One boolean per candidate patch of ONE image (see `BoxFilter.masks_patches`), one launch for all of them.'''
+        self.box_filter.overlap_bounds = self.bounds
+        self.box_filter.labels_format = self.labels_format
+        masks = self.box_filter.masks_patches(labels, patch_ymin, patch_xmin, patch_heights, patch_widths)
+        n_valid = masks.sum(axis=1)
+        if self.n_boxes_min == 'all':
+            return n_valid == masks.shape[1]
+        return n_valid >= self.n_boxes_min
 
     def __call__(self, labels, image_height, image_width):
         '''Reference :286-322.'''

@@ -332,6 +332,34 @@ def gen_box_filter():
     save("box_filter", **out)
 
 
+def gen_patch_sampling():
+    """The reference's patch sampling ops (data_generator/object_detection_2d_patch_sampling_ops.py, NumPy only) and the box-level
+    half of its original-SSD chain (SSDRandomCrop / SSDExpand of data_augmentation_chain_original_ssd.py; that module imports cv2
+    for its photometric half, which is stubbed -- nothing pinned here calls it) on the seeded cases of tests/patch_cases.py."""
+    import types
+    if "cv2" not in sys.modules:
+        class _Cv2Stub(types.ModuleType):
+            def __getattr__(self, name):
+                return 0
+        sys.modules["cv2"] = _Cv2Stub("cv2")
+    import data_generator.object_detection_2d_patch_sampling_ops as ops
+    import data_generator.object_detection_2d_image_boxes_validation_utils as val
+    import data_generator.data_augmentation_chain_original_ssd as chain
+    from tests import patch_cases as pc
+    ns = types.SimpleNamespace(SSDRandomCrop=chain.SSDRandomCrop, SSDExpand=chain.SSDExpand, BoundGenerator=val.BoundGenerator,
+                               BoxFilter=val.BoxFilter, ImageValidator=val.ImageValidator)
+    for name in ("PatchCoordinateGenerator", "CropPad", "Crop", "Pad", "RandomPatch", "RandomPatchInf", "RandomMaxCropFixedAR",
+                 "RandomPadFixedAR"):
+        setattr(ns, name, getattr(ops, name))
+    out = {"n_cases": np.array(len(pc.CASES))}
+    for i, case in enumerate(pc.CASES):
+        res = pc.run(ns, case)
+        for k, v in res.items():
+            out["p%03d_%s" % (i, k)] = v
+        out["p%03d_case" % i] = np.array(repr(case))
+    save("patch_sampling", **out)
+
+
 def gen_anchors():
     out = {}
     for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
@@ -486,10 +514,9 @@ def gen_decoder():
 
 
 if __name__ == "__main__":
-    gen_box_utils()
-    gen_box_utils2()
-    gen_evaluator()
-    gen_box_filter()
-    gen_anchors()
-    gen_encoder()
-    gen_decoder()
+    # box_filter / patch_sampling import the reference's real data_generator package; gen_evaluator stubs what is left of it
+    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
+    wanted = set(sys.argv[1:])
+    for g in gens:
+        if not wanted or g.__name__[4:] in wanted:
+            g()
