@@ -5,7 +5,6 @@ Every function returns a JSON-able dict and never raises (an exception becomes {
 number cannot be lost to a secondary leg.  The CPU legs call `oracle/np_oracle.py` (the checker) as the reference's
 CPU path -- measured beside the product, never used by it.
 """
-import os
 import time
 
 import numpy as np

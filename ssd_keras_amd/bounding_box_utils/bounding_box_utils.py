@@ -10,7 +10,6 @@ torch tensors (used in place; the result stays on the GPU).  There is no CPU pat
 """
 from __future__ import annotations
 
-import numpy as np
 
 from .. import _native as nat
 

@@ -8,9 +8,7 @@ reference so ported weights can be loaded by name.
 from __future__ import annotations
 
 import numpy as np
-import torch
 from torch import nn
-import torch.nn.functional as F
 
 from ..keras_layers.keras_layer_L2Normalization import L2Normalization
 from ._common import SSDModel, conv_out, he_normal_, make_priorboxes, pool_out, resolve_anchor_config

@@ -7,7 +7,6 @@ from __future__ import annotations
 
 import numpy as np
 from torch import nn
-import torch.nn.functional as F
 
 from ._common import conv_out, he_normal_, make_priorboxes, resolve_anchor_config
 from .keras_ssd300 import _VGGBase

@@ -6,7 +6,6 @@
 """
 from __future__ import annotations
 
-import numpy as np
 
 from .. import _native as nat
 

@@ -1,7 +1,6 @@
 """Implicit-GEMM MFMA convolution (csrc/ssdhip_conv.hip, through the C ABI) vs a plain PyTorch float32 reference of the
 same op on the same bf16-valued inputs.  Needs an MI355X.  Bar: |got - want| <= 2^-7 |want| + 1e-2 * rms (one bf16
 rounding of a float32-accumulated sum; the reference accumulates in a different order)."""
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

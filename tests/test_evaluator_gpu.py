@@ -1,7 +1,6 @@
 """Evaluator (eval_utils/average_precision_evaluator.py) with the matching step on the GPU (ssdhip_match_predictions, through
 the C ABI) vs the golden outputs of the REAL reference class and, at VOC scale, vs the oracle.  Needs an MI355X.
 Bar: true / false positive flags, their cumulative sums, precisions, recalls, average precisions and mAP bit exact."""
-import ast
 
 import numpy as np
 import pytest
