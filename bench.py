@@ -218,6 +218,9 @@ def main():
                "gpu_decode_ms_per_img": round(stage_ms["decode_path"] / B, 5),
                "speedup_decode": round((cpu_s / n_img) / (stage_ms["decode_path"] * 1e-3 / B), 1),
                "host_cpus": os.cpu_count()}
+        # the all-core figure beside the single-core one (own process, one batch item per task)
+        import bench_extra as bx_cpu
+        cpu["all_cores"] = bx_cpu.cpu_decode_all_cores(y_host, kw)
 
     # ---- secondary legs (bench_extra.py): encoder / loss / sparse decode vs the CPU port on rank 0 at N=1; the
     #      data-parallel training step (configs[2], configs[3]) on every rank.  None of them touches `value`. ------------

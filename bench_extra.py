@@ -5,6 +5,7 @@ Every function returns a JSON-able dict and never raises (an exception becomes {
 number cannot be lost to a secondary leg.  The CPU legs call `oracle/np_oracle.py` (the checker) as the reference's
 CPU path -- measured beside the product, never used by it.
 """
+import os
 import time
 
 import numpy as np
@@ -292,3 +293,25 @@ def evaluator_leg(dev, with_cpu=True):
                                 "(%.1f %% of the predictions), scaled to all classes" % (100 * frac),
                       "identical_flags_on_the_sample": bool(same), "speedup": round((cpu_s / max(frac, 1e-9)) / (gpu_ms * 1e-3), 1)}
     return out
+
+
+def cpu_decode_all_cores(y_host, kw, timeout_s=150):
+    """The all-core CPU figure beside cpu_baseline's single-core one: tools/cpu_decode_all_cores.py in its own process (this
+    one holds the HIP runtime and must not fork).  Never raises: a bench leg, not the metric."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    try:
+        root = os.path.dirname(os.path.abspath(__file__))
+        with tempfile.TemporaryDirectory() as d:
+            np.save(os.path.join(d, "y.npy"), np.ascontiguousarray(y_host))
+            with open(os.path.join(d, "kw.json"), "w") as f:
+                json.dump(kw, f)
+            run = subprocess.run([sys.executable, os.path.join(root, "tools", "cpu_decode_all_cores.py"), d], capture_output=True,
+                                 text=True, timeout=timeout_s)
+        if run.returncode != 0:
+            return {"error": run.stderr.strip()[-300:]}
+        return json.loads(run.stdout.strip().splitlines()[-1])
+    except Exception as exc:                                                       # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
