@@ -442,7 +442,8 @@ def greedy_nms_single2(predictions, iou_threshold=0.45, coords="corners", border
     return _greedy_nms_rows(np.copy(predictions), 1, 2, iou_threshold, border_pixels, coords)
 
 
-def _decode_boxes(y_pred, n_lead, input_coords, normalize_coords, img_height, img_width, exp_mode, order="numpy"):
+def _decode_boxes(y_pred, n_lead, input_coords, normalize_coords, img_height, img_width, exp_mode, order="numpy",
+                  variance_encoded_in_target=False):
     """Steps 1-2 of decode_detections (:172-198) / decode_detections_fast (:295-321).
 
     Returns the (B, N, 4) corner boxes.  dtype: float64 when the reference routes the
@@ -452,7 +453,12 @@ def _decode_boxes(y_pred, n_lead, input_coords, normalize_coords, img_height, im
     """
     off = np.copy(y_pred[:, :, -12:-8])
     anc, var = y_pred[:, :, -8:-4], y_pred[:, :, -4:]
-    if input_coords == "centroids":
+    if input_coords == "centroids" and variance_encoded_in_target:
+        # decode_detections_debug only (:405-409): the targets were not divided by the variances
+        wh = _exp_like_input(off[:, :, 2:4], exp_mode) * anc[:, :, 2:4]
+        cxy = off[:, :, 0:2] * anc[:, :, 2:4] + anc[:, :, 0:2]
+        box = convert_coordinates(np.concatenate([cxy, wh], axis=-1), 0, "centroids2corners")
+    elif input_coords == "centroids":
         wh = _exp_like_input(off[:, :, 2:4] * var[:, :, 2:4], exp_mode)
         wh = wh * anc[:, :, 2:4]
         if order == "numpy":
@@ -485,7 +491,7 @@ def _decode_boxes(y_pred, n_lead, input_coords, normalize_coords, img_height, im
 
 def decode_detections(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=200, input_coords="centroids",
                       normalize_coords=True, img_height=None, img_width=None, border_pixels="half",
-                      exp_mode="numpy", with_anchor_index=False, decode_order="numpy"):
+                      exp_mode="numpy", with_anchor_index=False, decode_order="numpy", variance_encoded_in_target=False):
     """ssd_output_decoder.py:111-226 (and decode_detections_debug :342-467 when
     `with_anchor_index`: rows get the anchor index prepended).
 
@@ -495,7 +501,8 @@ def decode_detections(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=
     if normalize_coords and (img_height is None or img_width is None):
         raise ValueError("the decoder needs the image size to convert relative to absolute coordinates")
     y_pred = np.asarray(y_pred)
-    box = _decode_boxes(y_pred, 0, input_coords, normalize_coords, img_height, img_width, exp_mode, decode_order)
+    box = _decode_boxes(y_pred, 0, input_coords, normalize_coords, img_height, img_width, exp_mode, decode_order,
+                        variance_encoded_in_target)
     C = y_pred.shape[2] - 12
     # rows live in one array per image in the reference, so everything is box.dtype
     conf = y_pred[:, :, :C].astype(box.dtype)

@@ -151,10 +151,14 @@ def decode_detections_debug(y_pred, confidence_thresh=0.01, iou_threshold=0.45, 
                             border_pixels='half'):
     '''Reference: ssd_output_decoder.py:342-467.  As `decode_detections`, rows
     `[box_id, class_id, confidence, xmin, ymin, xmax, ymax]`.'''
-    if variance_encoded_in_target:
-        raise NotImplementedError("variance_encoded_in_target=True is not supported")
     y = _as_device_f32(y_pred)
     _check_common(y, normalize_coords, img_height, img_width, input_coords)
+    if variance_encoded_in_target and input_coords == 'centroids':
+        # :405-409: the offsets were not divided by the variances, i.e. decode with variances of one -- x * 1.0 is exact, so the
+        # kernel's (d * a) * var + c and exp(d * var) * a are bit for bit the reference's d * a + c and exp(d) * a.  (The
+        # reference ignores the flag for 'corners' / 'minmax', :416-425.)
+        y = y.clone()                                  # never write into the caller's tensor
+        y[:, :, -4:] = 1.0
     out, count, aidx = nat.decode(y, confidence_thresh, iou_threshold, int(top_k), 0, False, nat.SEM_DEBUG, input_coords,
                                   normalize_coords, img_height, img_width, border_pixels, nat.F64, int(top_k),
                                   want_anchor_idx=True)

@@ -476,6 +476,8 @@ def gen_decoder():
     y = syn.make_y_pred(anchors_var(enc), 2, enc.n_classes, bias=1.0, seed=77)
     add("tiny_debug", decode_detections_debug, y, y, confidence_thresh=0.02, iou_threshold=0.45, top_k=50,
         input_coords="centroids", normalize_coords=True, img_height=96, img_width=128)
+    add("tiny_debug_vit", decode_detections_debug, y, y, confidence_thresh=0.02, iou_threshold=0.45, top_k=50,
+        input_coords="centroids", normalize_coords=True, img_height=96, img_width=128, variance_encoded_in_target=True)
     add("tiny_nothing", decode_detections, y, y, confidence_thresh=0.999, iou_threshold=0.45, top_k=200,
         input_coords="centroids", normalize_coords=True, img_height=96, img_width=128)
 
