@@ -64,6 +64,22 @@ def main():
              "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
         print(json.dumps(r), flush=True)
         res.append(r)
+    # the strided / 'valid' extra layers: libssdhip's general entry vs MIOpen + the bias/ReLU pass
+    for name, hw, cin, cout, stride, pad in (("conv6_2", 19, 256, 512, 2, 1), ("conv7_2", 10, 128, 256, 2, 1),
+                                             ("conv8_2", 5, 128, 256, 1, 0), ("conv9_2", 3, 128, 256, 1, 0)):
+        if only and name not in only.split(","):
+            continue
+        x = torch.randn((B, hw, hw, cin), device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+        w = (torch.randn((cout, 3, 3, cin), device="cuda") / (9 * cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+        b = torch.randn((cout,), device="cuda").to(torch.bfloat16)
+        ho = (hw + 2 * pad - 3) // stride + 1
+        flop = 2.0 * B * ho * ho * cin * cout * 9
+        t_ours = ev_ms(lambda: nat.conv2d(x, w, b, stride=stride, padding=pad, relu=True))
+        t_mi_full = ev_ms(lambda: nat.bias_act(F.conv2d(x, w, None, stride, pad, 1), b, relu=True))
+        r = {"layer": name, "ours_us": round(t_ours * 1e3, 1), "ours_TFs": round(flop / t_ours / 1e9, 1),
+             "miopen_plus_epilogue_us": round(t_mi_full * 1e3, 1)}
+        print(json.dumps(r), flush=True)
+        res.append(r)
     x = torch.randn((B, 300, 300, 3), device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
     w = (torch.randn((64, 3, 3, 3), device="cuda") / 27 ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
     b = torch.randn((64,), device="cuda").to(torch.bfloat16)
