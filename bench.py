@@ -207,9 +207,11 @@ def main():
         orc.decode_detections(y_host[:1], **kw)
         one = time.perf_counter() - t
         n_img = args.cpu_sample or int(max(1, min(B, round(15.0 / max(one, 1e-3)))))
+        orc.NMS_WORK.update(iou_pairs=0, kept=0)
         t = time.perf_counter()
         ref = orc.decode_detections(y_host[:n_img], **kw)
         cpu_s = time.perf_counter() - t
+        pairs_per_img = orc.NMS_WORK["iou_pairs"] / n_img            # box pairs the reference's NMS formulation evaluates
         cpu = {"value": round(n_img / cpu_s, 4), "unit": "images/sec (decode_detections only)", "cores": 1, "kind": "port",
                "ms_per_img": round(1e3 * cpu_s / n_img, 3),
                "sample": "oracle/np_oracle.decode_detections (NumPy port of ssd_output_decoder.py:111-226) on the first %d of "
@@ -217,7 +219,11 @@ def main():
                          "regime); the forward pass has no CPU reference here (TensorFlow absent)" % (n_img, B),
                "gpu_decode_ms_per_img": round(stage_ms["decode_path"] / B, 5),
                "speedup_decode": round((cpu_s / n_img) / (stage_ms["decode_path"] * 1e-3 / B), 1),
-               "host_cpus": os.cpu_count()}
+               "host_cpus": os.cpu_count(),
+               # SURVEY 8d secondary figure (the dense regime is VALU-bound): IoU evaluations of the reference's formulation
+               # (every kept box against everything still alive) per second, CPU port vs the HIP NMS kernel on the same images
+               "nms_iou_pairs_per_img": round(pairs_per_img), "cpu_iou_pairs_per_sec": round(pairs_per_img * n_img / cpu_s),
+               "gpu_iou_pairs_per_sec": round(pairs_per_img * B / (stage_ms["nms_kernel<double>"] * 1e-3))}
         # the all-core figure beside the single-core one (own process, one batch item per task)
         import bench_extra as bx_cpu
         cpu["all_cores"] = bx_cpu.cpu_decode_all_cores(y_host, kw)

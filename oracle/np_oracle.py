@@ -422,8 +422,15 @@ def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels, coo
         if not alive.size:
             break
         sim = iou(boxes[alive], boxes[j], coords=coords, mode="element-wise", border_pixels=border_pixels)
+        NMS_WORK["iou_pairs"] += int(alive.size)
         alive = alive[sim <= iou_threshold]
+    NMS_WORK["kept"] += len(kept)
     return rows[kept]
+
+
+# Work counters of the loop above (bench.py's secondary figure, SURVEY 8d: "report IoUs/s"): how many box pairs the
+# reference's formulation evaluates -- every kept box against everything still alive -- and how many boxes it keeps.
+NMS_WORK = {"iou_pairs": 0, "kept": 0}
 
 
 def greedy_nms(y_pred_decoded, iou_threshold=0.45, coords="corners", border_pixels="half"):
