@@ -63,6 +63,8 @@ class AnchorBoxes(nn.Module):
         b, _, h, w = x.shape
         return self.constant(h, w, x.device).unsqueeze(0).expand(b, -1, -1, -1, -1)
 
+    call = forward                                   # the Keras layer's method name (reference :133)
+
     def compute_output_shape(self, input_shape):
         batch_size, _, h, w = input_shape
         return (batch_size, h, w, self.n_boxes, 8)

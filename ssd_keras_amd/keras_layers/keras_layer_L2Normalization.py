@@ -32,5 +32,7 @@ class L2Normalization(nn.Module):
         inv = torch.rsqrt(torch.clamp_min((xf * xf).sum(dim=1, keepdim=True), 1e-12))
         return (xf * inv * self.gamma.view(1, -1, 1, 1)).to(x.dtype)
 
+    call = forward                                   # the Keras layer's method name (reference :61)
+
     def get_config(self):
         return {'gamma_init': self.gamma_init}
