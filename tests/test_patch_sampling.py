@@ -87,3 +87,23 @@ def test_crop_pad_without_labels_returns_the_image():
     assert np.array_equal(inv(np.zeros((1, 6)))[0], [0, 0, -2, -1, -2, -1])
     with pytest.raises(ValueError):
         CropPad(7, 0, 2, 2)(image)
+
+
+def test_apply_inverse_transforms():
+    """object_detection_2d_misc_utils.apply_inverse_transforms (:22-73) with CropPad's inverters: list and array containers,
+    `None` inverters, batch items without predictions."""
+    from ssd_keras_amd.data_generator.object_detection_2d_misc_utils import apply_inverse_transforms
+    from ssd_keras_amd.data_generator.object_detection_2d_patch_sampling_ops import CropPad, Pad
+    image = np.zeros((20, 30, 3), dtype=np.uint8)
+    _, inv_a = CropPad(2, 3, 10, 12)(image, return_inverter=True)
+    _, inv_b = Pad(4, 0, 5, 0)(image, return_inverter=True)
+    pred = np.array([[1, 0.9, 1.0, 2.0, 5.0, 6.0], [2, 0.8, 0.0, 0.0, 3.0, 3.0]])
+    empty = np.array([])
+    out = apply_inverse_transforms([pred, empty, pred], [[inv_a, None, inv_b], [inv_a], []])
+    assert np.array_equal(out[0][:, 2:], pred[:, 2:] + np.array([3 - 5, 2 - 4, 3 - 5, 2 - 4])) and np.array_equal(out[0][:, :2], pred[:, :2])
+    assert out[1].shape == (0,) and np.array_equal(out[2], pred) and out[2] is not pred
+    arr = np.stack([pred, pred])
+    out = apply_inverse_transforms(arr, [[inv_a], [None]])
+    assert np.array_equal(out[0][:, 2:], pred[:, 2:] + np.array([3, 2, 3, 2])) and np.array_equal(out[1], pred) and out is not arr
+    with pytest.raises(ValueError):
+        apply_inverse_transforms((pred,), [[inv_a]])
