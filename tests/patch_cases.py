@@ -56,6 +56,19 @@ def _cases():
                                              (59, 79, 5, 5)]):
         cases.append(dict(op='crop_pad', seed=430 + i, n_boxes=6, args=(top, left, ph, pw), clip_boxes=i % 2 == 0, box_filter=i % 3 != 2,
                           float_labels=i == 3, background=(1, 2, 3), inverter=i == 1))
+    # no validator at all (any patch of an acceptable shape is cut), a non-default label layout, and validators that draw
+    # their own random bounds on every call (the trials of a round then cannot be validated in one go)
+    for seed in range(4):
+        cases.append(dict(op='patch_inf', seed=500 + seed, n_boxes=3, float_labels=seed == 2, crit='iou', n_boxes_min=1, must_match='h_w',
+                          bound_gen=False, n_trials_max=5, prob=0.8, clip_boxes=True, box_filter=seed % 2 == 0, inverter=seed == 1,
+                          validator=False, fmt='alt' if seed == 3 else 'default'))
+    for seed in range(6):
+        cases.append(dict(op='patch_inf', seed=510 + seed, n_boxes=2 + seed % 3, float_labels=seed == 4, crit=('iou', 'area')[seed % 2],
+                          n_boxes_min=1, must_match='h_w', bound_gen=False, n_trials_max=(4, 9)[seed % 2], prob=0.9, clip_boxes=True,
+                          box_filter=True, inverter=seed == 5, random_bounds=True, fmt='alt' if seed == 2 else 'default'))
+    for seed in range(4):
+        cases.append(dict(op='patch', seed=520 + seed, n_boxes=2, float_labels=False, can_fail=seed % 2 == 0, crit='iou', bounds=None,
+                          n_trials_max=4, prob=1.0, validator=True, inverter=seed == 3, scale=(0.3, 1.0), random_bounds=True))
     return cases
 
 
@@ -73,14 +86,18 @@ def build(ns, case):
         gen = ns.PatchCoordinateGenerator(must_match=case['must_match'], min_scale=0.3, max_scale=1.0, min_aspect_ratio=0.5, max_aspect_ratio=2.0)
         box_filter = ns.BoxFilter(check_overlap=True, check_min_area=True, check_degenerate=True, overlap_criterion='area',
                                   overlap_bounds=(0.4, 1.0), min_area=20, labels_format=fmt) if case['box_filter'] else None
-        validator = ns.ImageValidator(overlap_criterion=case['crit'], bounds=(0.3, 1.0), n_boxes_min=case['n_boxes_min'], labels_format=fmt)
+        vbounds = ns.BoundGenerator(sample_space=((0.05, None), (0.2, None), (0.4, 0.95))) if case.get('random_bounds') else (0.3, 1.0)
+        validator = ns.ImageValidator(overlap_criterion=case['crit'], bounds=vbounds, n_boxes_min=case['n_boxes_min'], labels_format=fmt)
+        if not case.get('validator', True):
+            validator = None
         bounds = ns.BoundGenerator(sample_space=((0.1, None), (0.3, 0.9), (None, None)), weights=(0.5, 0.25, 0.25)) if case['bound_gen'] else None
         return ns.RandomPatchInf(gen, box_filter=box_filter, image_validator=validator, bound_generator=bounds,
                                  n_trials_max=case['n_trials_max'], clip_boxes=case['clip_boxes'], prob=case['prob'], background=(9, 8, 7),
                                  labels_format=fmt)
     if op == 'patch':
         gen = ns.PatchCoordinateGenerator(must_match='h_w', min_scale=case['scale'][0], max_scale=case['scale'][1])
-        validator = ns.ImageValidator(overlap_criterion=case['crit'], bounds=case['bounds'], n_boxes_min=1) if case['validator'] else None
+        vbounds = ns.BoundGenerator(sample_space=((0.05, None), (0.2, None), (0.4, 0.95))) if case.get('random_bounds') else case['bounds']
+        validator = ns.ImageValidator(overlap_criterion=case['crit'], bounds=vbounds, n_boxes_min=1) if case['validator'] else None
         box_filter = ns.BoxFilter(check_overlap=True, check_min_area=False, check_degenerate=True, overlap_criterion='center_point')
         return ns.RandomPatch(gen, box_filter=box_filter, image_validator=validator, n_trials_max=case['n_trials_max'], clip_boxes=True,
                               prob=case['prob'], background=(50, 60, 70), can_fail=case['can_fail'])
