@@ -209,7 +209,7 @@ def main():
         n_img = args.cpu_sample or int(max(1, min(B, round(15.0 / max(one, 1e-3)))))
         orc.NMS_WORK.update(iou_pairs=0, kept=0)
         t = time.perf_counter()
-        ref = orc.decode_detections(y_host[:n_img], **kw)
+        ref = orc.decode_detections(y_host[:n_img], exp_mode="det", **kw)    # "det": the exp shared with the kernel (bit-comparable)
         cpu_s = time.perf_counter() - t
         pairs_per_img = orc.NMS_WORK["iou_pairs"] / n_img            # box pairs the reference's NMS formulation evaluates
         cpu = {"value": round(n_img / cpu_s, 4), "unit": "images/sec (decode_detections only)", "cores": 1, "kind": "port",
@@ -224,6 +224,16 @@ def main():
                # (every kept box against everything still alive) per second, CPU port vs the HIP NMS kernel on the same images
                "nms_iou_pairs_per_img": round(pairs_per_img), "cpu_iou_pairs_per_sec": round(pairs_per_img * n_img / cpu_s),
                "gpu_iou_pairs_per_sec": round(pairs_per_img * B / (stage_ms["nms_kernel<double>"] * 1e-3))}
+        # parity at the bench's own scale: the HIP decoder (NumPy semantics) against the port on the sampled images, row for row
+        try:
+            from ssd_keras_amd.ssd_encoder_decoder.ssd_output_decoder import decode_detections as hip_decode
+            got = hip_decode(pred[:n_img], **kw)
+            canon = lambda a: a[np.lexsort(a.T[::-1])] if a.size else a.reshape(0, 6)
+            same = all(np.array_equal(canon(g), canon(w)) for g, w in zip(got, ref))
+            cpu["hip_equals_port_on_the_sample"] = bool(same)
+            cpu["detections_on_the_sample"] = int(sum(w.shape[0] for w in ref if w.size))
+        except Exception as exc:                                        # noqa: BLE001 -- a reported flag, never the metric
+            cpu["hip_equals_port_on_the_sample"] = "error: %s: %s" % (type(exc).__name__, exc)
         # the all-core figure beside the single-core one (own process, one batch item per task)
         import bench_extra as bx_cpu
         cpu["all_cores"] = bx_cpu.cpu_decode_all_cores(y_host, kw)
