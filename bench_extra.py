@@ -71,12 +71,19 @@ def encoder_leg(dev, B, with_cpu=True):
         with np.errstate(invalid="ignore", divide="ignore"):
             ora(gt[:2])
             t = time.perf_counter()
-            ora(gt)
+            ref = ora(gt)
             cpu_ms = 1e3 * (time.perf_counter() - t)
         out["cpu"] = {"ms_per_img": round(cpu_ms / B, 4), "cores": 1, "kind": "port",
                       "sample": "oracle EncoderOracle.__call__ (NumPy port of ssd_input_encoder.py:277-418) on the same %d label "
                                 "arrays, one pass" % B,
                       "speedup": round(cpu_ms / wall_ms, 1)}
+        try:                                                                  # parity on the same labels (a reported flag)
+            got = y32.float().cpu().numpy()
+            C = got.shape[2] - 12
+            out["cpu"]["hip_matches_port"] = bool(np.array_equal(got[:, :, :C], ref[:, :, :C].astype(np.float32))
+                                                  and np.allclose(got, ref.astype(np.float32), rtol=1e-6, atol=1e-7))
+        except Exception as exc:                                              # noqa: BLE001
+            out["cpu"]["hip_matches_port"] = "error: %s: %s" % (type(exc).__name__, exc)
     return out
 
 
@@ -119,12 +126,23 @@ def loss_leg(dev, B, with_cpu=True):
     if with_cpu:
         yt = y_true.cpu().numpy()
         t = time.perf_counter()
-        orc.ssd_loss(yt, y_host)
-        orc.ssd_loss_grad(yt, y_host, np.ones((B,), dtype=np.float32))
+        ref_loss = orc.ssd_loss(yt, y_host)
+        ref_grad = orc.ssd_loss_grad(yt, y_host, np.ones((B,), dtype=np.float32))
         cpu_ms = 1e3 * (time.perf_counter() - t)
         out["cpu"] = {"fwd_bwd_ms": round(cpu_ms, 2), "cores": 1, "kind": "port",
                       "sample": "oracle ssd_loss + ssd_loss_grad (NumPy restatement of keras_ssd_loss.py:98-211; TensorFlow absent) "
                                 "on the same tensors, one pass", "speedup": round(cpu_ms / both_ms, 1)}
+        try:                                                                  # north_star tolerance 1e-4 (a reported flag)
+            with torch.cuda.device(dev):
+                y_pred.grad = None
+                got_loss = lf.compute_loss(y_true, y_pred)
+                got_loss.sum().backward()
+            out["cpu"]["hip_loss_within_1e-4_of_port"] = bool(np.allclose(got_loss.detach().cpu().numpy(), ref_loss, rtol=1e-4, atol=1e-6))
+            # a hard negative sitting exactly on the k-th loss value may be kept by one side only (device logf vs NumPy log):
+            # its row of the gradient then differs; everything else is within the tolerance
+            out["cpu"]["hip_grad_elements_outside_1e-4"] = int((~np.isclose(y_pred.grad.cpu().numpy(), ref_grad, rtol=1e-4, atol=1e-6)).sum())
+        except Exception as exc:                                              # noqa: BLE001
+            out["cpu"]["hip_loss_within_1e-4_of_port"] = "error: %s: %s" % (type(exc).__name__, exc)
     return out
 
 
@@ -166,11 +184,18 @@ def sparse_decode_leg(dev, B, with_cpu=True):
         per = (time.perf_counter() - t) / 2
         n_img = int(max(2, min(B, round(10.0 / max(per, 1e-3)))))
         t = time.perf_counter()
-        orc.decode_detections(y_host[:n_img], **kw)
+        ref = orc.decode_detections(y_host[:n_img], exp_mode="det", **kw)     # "det": the exp shared with the kernel
         cpu_ms = 1e3 * (time.perf_counter() - t) / n_img
         out["cpu"] = {"ms_per_img": round(cpu_ms, 3), "cores": 1, "kind": "port",
                       "sample": "oracle decode_detections on the first %d of %d images" % (n_img, B),
                       "speedup": round(cpu_ms / (stage["decode_path"] / B), 1)}
+        try:                                                                  # parity on the sample, row for row (a reported flag)
+            rows, count = outs[0].cpu().numpy(), outs[1].cpu().numpy()
+            canon = lambda a: a[np.lexsort(a.T[::-1])] if a.size else a.reshape(0, 6)
+            out["cpu"]["hip_equals_port_on_the_sample"] = bool(all(
+                np.array_equal(canon(rows[b, :int(count[b])]), canon(ref[b])) for b in range(n_img)))
+        except Exception as exc:                                              # noqa: BLE001
+            out["cpu"]["hip_equals_port_on_the_sample"] = "error: %s: %s" % (type(exc).__name__, exc)
     return out
 
 
