@@ -277,3 +277,18 @@ def test_autotune_keeps_the_fastest_candidate_and_probes_slow_ones_once(monkeypa
     finally:
         SSDModel._conv_choice.clear()
         SSDModel._conv_choice.update(saved)
+
+
+def test_all_core_cpu_baseline_helper_runs_and_agrees_with_the_port():
+    """bench.py's cpu_baseline.all_cores leg (tools/cpu_decode_all_cores.py in its own process): same detections as the port in
+    this process; a bad argument comes back as an error entry instead of an exception."""
+    import bench_extra as bx
+    from oracle import np_oracle as orc
+    enc = orc.EncoderOracle(**syn.TINY)
+    y = syn.make_y_pred(enc.generate_encoding_template(1)[0, :, -8:], 3, enc.n_classes, bias=1.0, seed=3)
+    kw = dict(confidence_thresh=0.05, iou_threshold=0.45, top_k=50, normalize_coords=True, img_height=96, img_width=128)
+    res = bx.cpu_decode_all_cores(y, kw, timeout_s=120)
+    assert "error" not in res, res
+    want = sum(r.shape[0] for r in orc.decode_detections(y, **kw) if r.size)
+    assert res["images"] == 3 and res["detections"] == want and res["value"] > 0 and 1 <= res["cores"] <= 3
+    assert "error" in bx.cpu_decode_all_cores(y, dict(kw, no_such_argument=1), timeout_s=120)
