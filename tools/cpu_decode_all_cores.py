@@ -21,7 +21,10 @@ _KW = {}
 
 def _start(y_small):
     """Pool initializer: every worker imports the oracle and decodes a few rows once, outside the timed region."""
-    _decode_one(y_small)
+    try:
+        _decode_one(y_small)
+    except Exception:                                   # noqa: BLE001 -- a worker dying here would make the pool respawn it forever;
+        pass                                            # the same error surfaces from the first real task instead
 
 
 def _decode_one(y):
