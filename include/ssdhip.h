@@ -67,7 +67,9 @@ const char* ssdhip_strerror(int rc);
  * decode_detections_debug :342-467, _greedy_nms* :77-109, and the in-graph
  * keras_layer_DecodeDetections.py:109-265 / keras_layer_DecodeDetectionsFast.py:111-248.
  *
- *   y_pred        [B, N, C+12] of `in_dtype` (SSDHIP_F32 today; F64 -> SSDHIP_E_BADARG)
+ *   y_pred        [B, N, C+12] of `in_dtype`.  SSDHIP_F32 (what the model emits): float32 decode, then the reference's
+ *                 float64 flow from convert_coordinates on.  SSDHIP_F64: the reference's all-float64 flow
+ *                 (ssd_output_decoder.py:172-198 computes in the input's dtype); not with SEM_KERAS (a float32 graph)
  *   C             number of classes INCLUDING background (class 0)
  *   conf_thresh   candidates need score > conf_thresh (class_agnostic + SEM_NUMPY: >=, and class != 0)
  *   iou_thresh    a box is dropped when IoU with an already kept box is NOT <= iou_thresh

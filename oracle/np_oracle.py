@@ -67,9 +67,31 @@ def det_expf(x):
     return np.where(nan, np.float32(np.nan), out).astype(np.float32)
 
 
+def det_exp64(x):
+    """float64 -> float64 exp through the same fixed chain of double operations as `det_expf` (no final narrowing):
+    k = rint(x*log2(e)); r = x - k*ln2 (two-term); p = Horner(sum r^n/n!, n<=13); result = ldexp(p, k) (one rounding,
+    also in the subnormal range).  Truncation error of the polynomial on |r| <= ln2/2 is 4e-18, so the result is within
+    ~1 ulp of exp(x) -- what np.exp(float64) promises too, without being the same on every host.  Inputs are clamped to
+    [-746, 710] (beyond that the float64 result is 0 / inf anyway); NaN propagates."""
+    xd = np.asarray(x, dtype=np.float64)
+    nan = np.isnan(xd)
+    xd = np.where(nan, 0.0, xd)
+    xd = np.minimum(np.maximum(xd, -746.0), 710.0)
+    k = (xd * _LOG2E + _RND) - _RND
+    r = (xd - k * _LN2_HI) - k * _LN2_LO
+    p = np.full_like(r, _EXP_C[13])
+    for n in range(12, -1, -1):
+        p = p * r + _EXP_C[n]
+    with np.errstate(over="ignore", under="ignore"):
+        out = np.ldexp(p, k.astype(np.int64).astype(np.int32))
+    return np.where(nan, np.nan, out)
+
+
 def _exp_like_input(v, exp_mode):
     if v.dtype == np.float32 and exp_mode == "det":
         return det_expf(v)
+    if v.dtype == np.float64 and exp_mode == "det":
+        return det_exp64(v)
     return np.exp(v)
 
 
@@ -404,12 +426,14 @@ class DegenerateBoxError(Exception):
 # --------------------------------------------------------------------------------------
 # decoder
 # --------------------------------------------------------------------------------------
-def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels, coords="corners"):
+def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels, coords="corners", max_keep=None):
     """The loop shared by greedy_nms / _greedy_nms / _greedy_nms2 / _greedy_nms_debug
     (ssd_output_decoder.py:27-109, 469-486): repeatedly take the first maximum of the
     remaining scores, drop it from the pool, drop everything whose IoU with it is
     > threshold (keep `<=`).  Order of the pool is preserved, so among equal scores the
     earliest (lowest anchor index) wins.  IoU runs in the dtype of `rows`.
+    `max_keep`: stop after that many survivors (`tf.image.non_max_suppression(max_output_size=...)`: the first
+    max_keep rows of the uncapped result).
     """
     alive = np.arange(rows.shape[0])
     kept = []
@@ -419,7 +443,7 @@ def _greedy_nms_rows(rows, score_col, box_col, iou_threshold, border_pixels, coo
         j = alive[int(np.argmax(scores[alive]))]
         kept.append(j)
         alive = alive[alive != j]
-        if not alive.size:
+        if not alive.size or (max_keep is not None and len(kept) >= max_keep):
             break
         sim = iou(boxes[alive], boxes[j], coords=coords, mode="element-wise", border_pixels=border_pixels)
         NMS_WORK["iou_pairs"] += int(alive.size)
@@ -567,22 +591,61 @@ def decode_detections_fast(y_pred, confidence_thresh=0.5, iou_threshold=0.45, to
     return out
 
 
+def _tf_iou_f32(box, others):
+    """`IOU()` of tensorflow/core/kernels/non_max_suppression_op.cc (TF 1.x; the dependency is un-vendored and un-pinned:
+    README.md:143-150 only says "TensorFlow 1.x"), float32 throughout: corners normalised with std::min / std::max
+    ((a < b) ? b : a -- NOT NaN-propagating), `area_i <= 0 || area_j <= 0 -> 0`, IEEE division.  box (4,), others (n, 4)."""
+    f = np.float32
+    mx = lambda a, b: np.where(a < b, b, a)          # std::max(a, b)
+    mn = lambda a, b: np.where(b < a, b, a)          # std::min(a, b)
+    with np.errstate(all="ignore"):
+        y0i, x0i, y1i, x1i = mn(box[0], box[2]), mn(box[1], box[3]), mx(box[0], box[2]), mx(box[1], box[3])
+        y0j, x0j = mn(others[:, 0], others[:, 2]), mn(others[:, 1], others[:, 3])
+        y1j, x1j = mx(others[:, 0], others[:, 2]), mx(others[:, 1], others[:, 3])
+        area_i = f((y1i - y0i) * (x1i - x0i))
+        area_j = ((y1j - y0j) * (x1j - x0j)).astype(f)
+        iy0, ix0, iy1, ix1 = mx(y0i, y0j), mx(x0i, x0j), mn(y1i, y1j), mn(x1i, x1j)
+        inter = (mx((iy1 - iy0).astype(f), f(0)) * mx((ix1 - ix0).astype(f), f(0))).astype(f)
+        out = (inter / ((area_i + area_j).astype(f) - inter).astype(f)).astype(f)
+    return np.where((area_i <= 0) | (area_j <= 0), f(0), out)
+
+
+def _tf_nms(boxes32, scores32, iou_threshold, max_keep):
+    """`tf.image.non_max_suppression(boxes, scores, max_output_size, iou_threshold)`: candidates by score descending
+    (equal scores: lower index first), a candidate is dropped when its IoU with an already selected box is `>`
+    float32(iou_threshold); stops at `max_keep` selections.  Returns the selected indices in selection order."""
+    thr = np.float32(iou_threshold)
+    alive = np.argsort(-scores32, kind="stable")
+    kept = []
+    while alive.size and len(kept) < max_keep:
+        j = alive[0]
+        kept.append(j)
+        alive = alive[1:]
+        if not alive.size:
+            break
+        sim = _tf_iou_f32(boxes32[j], boxes32[alive])
+        NMS_WORK["iou_pairs"] += int(alive.size)
+        alive = alive[~(sim > thr)]
+    NMS_WORK["kept"] += len(kept)
+    return np.asarray(kept, dtype=np.int64)
+
+
 def decode_detections_layer(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400,
                             normalize_coords=True, img_height=None, img_width=None, fast=False, exp_mode="det"):
     """Container semantics of the DecodeDetections / DecodeDetectionsFast Keras layers
     (keras_layer_DecodeDetections.py:109-265, keras_layer_DecodeDetectionsFast.py:111-248),
     PARITY UNPINNED (TensorFlow is not installable here):
       * decode in float32 with the layer's association (d*var)*a + c, corners = c -/+ 0.5*wh, *img size in f32;
-      * per class (or once, class-agnostic, `fast`): strict `>` threshold evaluated in float32, greedy NMS
-        capped at `nms_max_output_size` survivors (tf.image.non_max_suppression(max_output_size=...));
+      * per class (or once, class-agnostic, `fast`): strict `>` threshold evaluated in float32, then
+        `tf.image.non_max_suppression(max_output_size=nms_max_output_size)` restated from the TF kernel's source
+        (`_tf_nms`: float32 IoU, `>` float32 threshold, zero for non-positive areas);
       * global top-k by confidence, sorted descending (tf.nn.top_k(sorted=True); ties -> lower position in
         the class-major padded array), zero rows as padding -> (B, top_k, 6) float32.
-    NMS IoU is evaluated in float64 on the float32 pixel boxes (the TF kernel uses float32; only
-    knife-edge pairs can differ).
     """
     y_pred = np.asarray(y_pred, dtype=np.float32)
-    box64 = _decode_boxes(y_pred, 0, "centroids", normalize_coords, img_height, img_width, exp_mode, "keras")
-    box = box64.astype(np.float32).astype(np.float64)     # f32 product == rounded exact product
+    with np.errstate(all="ignore"):
+        box64 = _decode_boxes(y_pred, 0, "centroids", normalize_coords, img_height, img_width, exp_mode, "keras")
+        box = box64.astype(np.float32)                    # f32 product == rounded exact product
     B, N, L = y_pred.shape
     C = L - 12
     thr32 = np.float32(confidence_thresh)
@@ -599,15 +662,15 @@ def decode_detections_layer(y_pred, confidence_thresh=0.01, iou_threshold=0.45, 
         for c, sel, cls, conf in groups:
             if sel.any():
                 idx = np.nonzero(sel)[0]
-                cid = (cls[idx] if c is None else np.full(idx.size, c)).astype(np.float64)
-                rows = np.concatenate([cid[:, None], conf[idx, None].astype(np.float64), box[b, idx]], axis=1)
-                kept = _greedy_nms_rows(rows, 1, 2, iou_threshold, "half")[:nms_max_output_size]
-                for r, row in enumerate(kept):
+                keep = idx[_tf_nms(box[b, idx], conf[idx], iou_threshold, nms_max_output_size)]
+                cid = (cls[keep] if c is None else np.full(keep.size, c)).astype(np.float32)
+                rows = np.concatenate([cid[:, None], conf[keep, None], box[b, keep]], axis=1)
+                for r, row in enumerate(rows):
                     cand.append((row, pos + r))
             pos += nms_max_output_size
         cand.sort(key=lambda t: (-t[0][1], t[1]))
         for r, (row, _) in enumerate(cand[:top_k]):
-            out[b, r] = row.astype(np.float32)
+            out[b, r] = row
     return out
 
 

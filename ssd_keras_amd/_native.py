@@ -124,18 +124,22 @@ def decode(y_pred, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, sema
            img_height, img_width, border_pixels, out_dtype, out_rows, want_anchor_idx=False, workspace=None,
            stages=7, outputs=None):
     """Enqueue ssdhip_decode_detections on the current stream.
-    y_pred: CUDA float32 (B, N, C+12).  Returns (out (B,out_rows,6), count (B,) int32, anchor_idx or None)."""
+    y_pred: CUDA float32 or float64 (B, N, C+12) -- float64 predictions take the reference's all-float64 flow
+    (csrc/ssdhip_decode64.hip).  Returns (out (B,out_rows,6), count (B,) int32, anchor_idx or None)."""
     torch = _torch()
     lib = load()
     require_cuda(y_pred, "y_pred")
-    if y_pred.dtype != torch.float32:
-        raise SsdHipError("y_pred must be float32 (float64 predictions are not built yet)")
+    if y_pred.dtype not in (torch.float32, torch.float64):
+        raise SsdHipError("y_pred must be float32 or float64")
+    in_dt = F32 if y_pred.dtype == torch.float32 else F64
+    if in_dt == F64 and semantics == SEM_KERAS:
+        raise SsdHipError("the DecodeDetections layers are float32 graphs: float64 predictions are not accepted there")
     B, N, L = y_pred.shape
     C = L - 12
     dev = y_pred.device
     k = int(top_k) if top_k else 0
     cap = int(nms_cap) if nms_cap else 0
-    need = lib.ssdhip_decode_workspace_bytes(B, N, C, k, cap, int(bool(class_agnostic)), F32)
+    need = lib.ssdhip_decode_workspace_bytes(B, N, C, k, cap, int(bool(class_agnostic)), in_dt)
     if need == 0:
         raise SsdHipError("unsupported decode shape B=%d N=%d C=%d" % (B, N, C))
     ws = workspace if workspace is not None else workspaces.get(dev, "decode", need)
@@ -147,7 +151,7 @@ def decode(y_pred, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, sema
         aidx = torch.empty((B, out_rows), dtype=torch.int32, device=dev) if want_anchor_idx else None
     with torch.cuda.device(dev):
         rc = lib.ssdhip_decode_stages(
-            int(stages), ctypes.c_void_p(y_pred.data_ptr()), F32, B, N, C, float(conf_thresh), float(iou_thresh), k, cap,
+            int(stages), ctypes.c_void_p(y_pred.data_ptr()), in_dt, B, N, C, float(conf_thresh), float(iou_thresh), k, cap,
             int(bool(class_agnostic)), int(semantics), COORDS[coords], int(bool(normalize_coords)),
             float(img_height if img_height is not None else 1.0), float(img_width if img_width is not None else 1.0),
             BORDER[border_pixels], ctypes.c_void_p(out.data_ptr()), out_dtype, int(out_rows),

@@ -1,11 +1,14 @@
 """Build libssdhip.so (the hand-written gfx950 kernels + C ABI) in-tree with hipcc.
 
-    python -m ssd_keras_amd.build            # build if sources are newer than the library
+    python -m ssd_keras_amd.build            # rebuild what is older than its sources
     python -m ssd_keras_amd.build --force
 
 hipcc cross-compiles for gfx950 without a GPU.  `-ffp-contract=off` is part of the
 contract: the kernels promise the reference's operation order, one IEEE rounding per
 operation, so the compiler must not fuse a*b+c.
+
+Every `csrc/*.hip` is compiled to its own object under `build/` (in parallel, only when it or a header changed) and the
+objects are linked into `ssd_keras_amd/libssdhip.so`.
 """
 from __future__ import annotations
 
@@ -13,35 +16,60 @@ import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(PKG, "libssdhip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-Wall",
+          "-Wno-unused-function"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+
+
+def _obj_of(src):
+    return os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+
+def _newer(deps, target):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True):
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + sources()
-    if verbose:
-        print("[ssd_keras_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers() + [os.path.abspath(__file__)]
+    todo = [s for s in sources() if force or _newer([s] + hdrs, _obj_of(s))]
+
+    def compile_one(src):
+        cmd = [hipcc] + CFLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", _obj_of(src)]
+        if verbose:
+            print("[ssd_keras_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as pool:
+            list(pool.map(compile_one, todo))
+    objs = [_obj_of(s) for s in sources()]
+    stale_objs = [o for o in glob.glob(os.path.join(OBJ, "*.o")) if o not in objs]
+    for o in stale_objs:                                  # a deleted source must not stay linked in
+        os.remove(o)
+    if todo or stale_objs or _newer(objs, LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs
+        if verbose:
+            print("[ssd_keras_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

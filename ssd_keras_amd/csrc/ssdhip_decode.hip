@@ -28,6 +28,7 @@
 #include "ssdhip_math.h"
 #include "ssdhip_tile.h"
 #include "ssdhip_heads.h"
+#include "ssdhip_decode64.h"
 
 // In-kernel phase timers, compiled only into the profiling build (tools/prof_build.sh, -DSSDHIP_PROFILE).
 #ifdef SSDHIP_PROFILE
@@ -54,7 +55,10 @@ constexpr int DIGIT_BITS = 13;               // radix-select digit / K5 histogra
 constexpr int NBINS = 1 << DIGIT_BITS;       // 8192 LDS counters = 32 KiB
 constexpr int NMS_BIN_SHIFT = 14;            // K4 score histogram: 2^14 float32 ulps per bin ...
 constexpr int NMS_NBINS = 4096;              // ... 4096 bins = 16 KiB (9 binades above the threshold)
-constexpr int NMS_THREADS = 256;
+#ifndef SSDHIP_NMS_THREADS
+#define SSDHIP_NMS_THREADS 256
+#endif
+constexpr int NMS_THREADS = SSDHIP_NMS_THREADS;    // K4 workgroup (K5 and the block helpers use the same size)
 #ifndef SSDHIP_MAX_CHUNK
 #define SSDHIP_MAX_CHUNK 512
 #endif
@@ -74,6 +78,8 @@ struct DecodeParams {
     int iou_f32;                // NMS arithmetic in float32 (reference: float32 input + 'corners')
     int fast_ok;                // division-free IoU test usable (0 < iou_thresh < inf)
     int px_f32;                 // pixel boxes rounded to float32 before NMS (the Keras layer's float32 scaling)
+    int no_nms;                 // iou_thresh == +inf: the reference skipped NMS (decode_detections_fast with a falsy threshold)
+    float filter_kE;            // POL_NUMPY64: |R32| > filter_kE * S decides a pair in float32 (inf: never)
     double iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
     int top_k, cap, cap_store, out_rows, sorted;
 };
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void scan_heads_kernel(HeadParams hp, const fl
 // ======================================================================================
 // Exact k-th largest (k >= 1) of {key : key < upper (if has_upper)}: radix select, one pass per DB-bit digit.
 // Only the fallback when a histogram bin overflows the chunk.  `hist` = 2^DB LDS counters, `red` = 260 LDS ints.
-template <int KEY_BITS, int DB, typename KeyF>
+template <int KEY_BITS, int DB, int T, typename KeyF>
 __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, int k, u32* hist, int* red) {
     const int tid = threadIdx.x;
     constexpr int NB = 1 << DB;
@@ -266,16 +272,16 @@ __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, i
     constexpr int NPASS = (KEY_BITS + DB - 1) / DB;
     for (int pass = 0; pass < NPASS; ++pass) {
         const int shift = (NPASS - 1 - pass) * DB;
-        for (int i = tid; i < NB; i += NMS_THREADS) hist[i] = 0;
+        for (int i = tid; i < NB; i += T) hist[i] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += NMS_THREADS) {
+        for (int i = tid; i < n; i += T) {
             const u64 key = key_at(i);
             if (has_upper && !(key < upper)) continue;
             if ((key & pmask) != prefix) continue;
             atomicAdd(&hist[(u32)(key >> shift) & (NB - 1)], 1u);
         }
         __syncthreads();
-        block_find_digit<NB / NMS_THREADS>(hist, k, red, red + 256);
+        block_find_digit<NB / T>(hist, k, red, red + 256);
         const int d = red[256];
         k -= red[257];
         prefix |= (u64)d << shift;
@@ -389,47 +395,186 @@ __device__ __forceinline__ bool exact_suppresses(const NBox<F>& a, const NBox<F>
     return !(iou_px<F>(pa, pb) <= thr);
 }
 
-template <typename F>
-__global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
-                                                          const u64* __restrict__ cand, const int* __restrict__ cand_count,
-                                                          u64* __restrict__ kept, int* __restrict__ kept_count) {
+// ---------------------------------------------------------------------------------------------------------------
+// K4 (second generation).  One workgroup of T threads (W = T/64 waves) per (image, class).  Per round: histogram-select
+// the next <= MAX_CHUNK best keys -> bitonic sort in LDS -> stage the chunk's boxes as 32-byte FBox records -> greedy
+// NMS in batches of 64 (lane = candidate):
+//   phase A  the batch against the survivors so far; the kept list is striped over the waves, each kept box is ONE
+//            broadcast LDS read (b128 + b64) and ~15 float32 VALU instructions per 64 pairs;
+//   phase B  the batch against itself: only the 2016 pairs i > j, row j folded with row 63-j into one 64-lane step;
+//   resolve  scalar walk over the lanes whose row is non-zero (rows fetched by readlane).
+// Three pair-test policies, one per arithmetic the reference family uses:
+//   POL_NUMPY64  ssd_output_decoder.py:77-92 with float64 boxes (float32 input routed through convert_coordinates, SURVEY
+//                A.3): the test "IoU <= thr" is decided by a float32 evaluation of R = inter - thr*union with a rigorous
+//                error bound E = kE * S (S >= max(4 max|coord|^2, |area|) of the pair; derivation in DESIGN.md 4.1);
+//                |R32| <= E -- knife edges, non-finite boxes -- falls through to the float64 sign test / IEEE division
+//                of the first generation (nms_test / exact_suppresses), so results stay bit-identical to the reference;
+//   POL_NUMPY32  the same loop in float32 ('corners' input stays float32 in the reference): exact float32 IoU;
+//   POL_TF32     tf.image.non_max_suppression as the Keras layers call it (keras_layer_DecodeDetections.py:195-199):
+//                float32 IoU of min/max-normalised corners, 0 when either area is <= 0, suppressed when IoU > float32(thr)
+//                (tensorflow/core/kernels/non_max_suppression_op.cc; un-pinned dependency, restated from its source).
+// ---------------------------------------------------------------------------------------------------------------
+enum { POL_NUMPY64 = 0, POL_NUMPY32 = 1, POL_TF32 = 2 };
+
+struct __attribute__((aligned(16))) FBox {
+    float x0, y0, x1, y1;        // pixel corners, float32
+    float area;                  // POL_TF32: +inf marks a box that neither suppresses nor is suppressed (area <= 0 or NaN)
+    float sc;                    // POL_NUMPY64: error scale S of the float32 filter, rounded up (inf: never decided in float32)
+    u32 idx;                     // anchor index
+    u32 pad;
+};
+
+struct NmsK {                    // wave-uniform constants of a launch
+    double W, H, d, thr;
+    float Wf, Hf, df, thr32, kE;
+    int fast_ok, no_nms;
+};
+
+// v_max_f32 / v_min_f32 without the canonicalising self-max hipcc adds to fmaxf() on loaded values (IEEE mode).  NaN
+// operands never reach a decision through them: POL_NUMPY64 gives such boxes S = inf, POL_TF32 stores them as inert boxes.
+__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <int POL>
+__device__ __forceinline__ FBox make_fbox(const float4 bx, u32 idx, const NmsK& k) {
+    FBox r;
+    r.idx = idx; r.pad = 0u; r.sc = 0.f;
+    if (POL == POL_NUMPY64) {
+        const double x0 = (double)bx.x * k.W, y0 = (double)bx.y * k.H, x1 = (double)bx.z * k.W, y1 = (double)bx.w * k.H;   // exact
+        const double area = box_area<double>(x0, y0, x1, y1, k.d);
+        const double m = fmax(fmax(fabs(x0), fabs(y0)), fmax(fabs(x1), fabs(y1)));
+        const double S = fmax(fmax(4.0 * m * m, fabs(area)), 0x1p-60) * (1.0 + 0x1p-20);
+        // finite everywhere and far from float32 overflow (2 S must stay finite), else the float32 filter never decides
+        const bool fin = is_finite(x0) && is_finite(y0) && is_finite(x1) && is_finite(y1) && is_finite(area) && S < 0x1p120;
+        r.x0 = (float)x0; r.y0 = (float)y0; r.x1 = (float)x1; r.y1 = (float)y1; r.area = (float)area;
+        r.sc = fin ? (float)S : __builtin_inff();
+    } else if (POL == POL_NUMPY32) {
+        r.x0 = bx.x * k.Wf; r.y0 = bx.y * k.Hf; r.x1 = bx.z * k.Wf; r.y1 = bx.w * k.Hf;         // ssd_output_decoder.py:196-198 in float32
+        r.area = box_area<float>(r.x0, r.y0, r.x1, r.y1, k.df);
+    } else {
+        // the layer scales in float32 (keras_layer_DecodeDetections.py:140-149): rounded exact product (W, H exact in float32)
+        const float ax = (float)((double)bx.x * k.W), ay = (float)((double)bx.y * k.H);
+        const float bxx = (float)((double)bx.z * k.W), by = (float)((double)bx.w * k.H);
+        const float x0 = bxx < ax ? bxx : ax, x1 = ax < bxx ? bxx : ax;      // std::min / std::max of the TF kernel
+        const float y0 = by < ay ? by : ay, y1 = ay < by ? by : ay;
+        const float area = (y1 - y0) * (x1 - x0);
+        if (area > 0.f) { r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.area = area; }
+        else { r.x0 = 0.f; r.y0 = 0.f; r.x1 = 0.f; r.y1 = 0.f; r.area = __builtin_inff(); }   // IoU 0 or NaN with everything: inert
+    }
+    return r;
+}
+
+// supp: the pair is decided "b suppresses a"; und (POL_NUMPY64 only): the float32 filter cannot decide
+template <int POL>
+__device__ __forceinline__ void pair_test(const FBox& a, const FBox& b, const NmsK& k, bool& supp, bool& und) {
+    if (POL == POL_NUMPY32) {
+        const PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
+        supp = !(iou_px<float>(pa, pb) <= k.thr32);
+        und = false;
+        return;
+    }
+    const float ix0 = vmaxf(a.x0, b.x0), iy0 = vmaxf(a.y0, b.y0);
+    const float ix1 = vminf(a.x1, b.x1), iy1 = vminf(a.y1, b.y1);
+    const float iw = vmaxf(ix1 - ix0, 0.f), ih = vmaxf(iy1 - iy0, 0.f);
+    const float inter = iw * ih;
+    const float uni = (a.area + b.area) - inter;
+    if (POL == POL_NUMPY64) {
+        const float r = __builtin_fmaf(-k.thr32, uni, inter);
+        const float E = k.kE * vmaxf(a.sc, b.sc);
+        const bool dec = __builtin_fabsf(r) > E;
+        supp = dec && r > 0.f;
+        und = !dec;
+    } else {
+        // fl(inter / uni) > thr  <=  inter >= fl(thr*uni) (1 + 2^-21);   fl(inter / uni) <= thr  <=  inter <= fl(thr*uni) (1 - 2^-21)
+        // (thr > 0, uni > 0 or +inf: the rounding of the product and of the quotient are each below 2^-23 relative); what lies in
+        // between -- and every NaN -- takes the division
+        const float hi = k.thr32 * uni;
+        const bool yes = inter >= hi * 1.00000048f, no = inter <= hi * 0.99999952f;
+        supp = k.fast_ok && yes;
+        und = !k.fast_ok || !(yes || no);
+    }
+}
+
+// the exact evaluation of a pair the fast test left undecided
+template <int POL>
+__device__ __forceinline__ bool exact_pair(const FBox& a, const FBox& b, const float4 a4, const float4 b4, const NmsK& k) {
+    if (POL == POL_TF32) {
+        const float ix0 = a.x0 < b.x0 ? b.x0 : a.x0, iy0 = a.y0 < b.y0 ? b.y0 : a.y0;        // std::max / std::min as the TF kernel
+        const float ix1 = b.x1 < a.x1 ? b.x1 : a.x1, iy1 = b.y1 < a.y1 ? b.y1 : a.y1;
+        const float dw = ix1 - ix0, dh = iy1 - iy0;
+        const float inter = (dw < 0.f ? 0.f : dw) * (dh < 0.f ? 0.f : dh);
+        return inter / ((a.area + b.area) - inter) > k.thr32;
+    }
+    // POL_NUMPY64: the first generation's float64 evaluation (sign test, then IEEE division for what is left)
+    const NBox<double> A = make_nbox<double>(a4, 0u, k.W, k.H, k.d, false), B = make_nbox<double>(b4, 0u, k.W, k.H, k.d, false);
+    const int c = nms_test(A, B, k.thr, k.fast_ok);
+    return c == 1 || (c == 2 && exact_suppresses<double>(A, B, k.thr));
+}
+
+// Bitonic sort, descending, in place, of P (a power of two, >= 2) u64 keys in LDS by T threads.  Compare-exchange steps at
+// distance <= 64 stay inside the 128-key segment the wave owns, so only the few long-distance steps need a block barrier.
+template <int T>
+__device__ void block_bitonic_desc(u64* a, int P) {
+    const int tid = threadIdx.x;
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const u64 x = a[i], y = a[l];
+                const bool desc = (i & kk) == 0;
+                if ((x < y) == desc) { a[i] = y; a[l] = x; }
+            }
+            const int nj = j > 1 ? (j >> 1) : kk;             // distance of the next step (the next stage opens at kk)
+            if (j > 64 || nj > 64) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        }
+    }
+    __syncthreads();
+}
+
+template <int POL, int T>
+__global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
+                                               const u64* __restrict__ cand, const int* __restrict__ cand_count,
+                                               const int* __restrict__ work_order,
+                                               u64* __restrict__ kept, int* __restrict__ kept_count) {
+    constexpr int W = T / 64;
     // XCD-aware work mapping: hardware places block x on XCD x%8; give every XCD a contiguous range of
     // (image, class) work items so that all classes of an image share one L2.
     const int total_work = p.B * p.G;
     const int per_xcd = (total_work + 7) >> 3;
-    const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || work >= total_work) return;
+    if (work_order) work = work_order[work];
     const int b = work / p.G;
 
-    __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 8];     // unsorted chunk
-    __shared__ __attribute__((aligned(16))) u64 sorted[MAX_CHUNK + 8];     // sorted chunk
-    constexpr size_t SCRATCH = sizeof(NBox<F>) * MAX_CHUNK > NMS_NBINS * sizeof(u32) ? sizeof(NBox<F>) * MAX_CHUNK : NMS_NBINS * sizeof(u32);
+    __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 8];     // chunk keys, sorted in place
+    constexpr size_t SCRATCH = sizeof(FBox) * MAX_CHUNK > NMS_NBINS * sizeof(u32) ? sizeof(FBox) * MAX_CHUNK : NMS_NBINS * sizeof(u32);
     __shared__ __attribute__((aligned(16))) unsigned char scratch[SCRATCH];   // score histogram, then the chunk's boxes
-    __shared__ NBox<F> kcache[KEPT_LDS];
+    __shared__ __attribute__((aligned(16))) float4 cf4[POL == POL_NUMPY64 ? MAX_CHUNK : 1];    // normalised corners (exact fallback)
+    __shared__ FBox kb[KEPT_LDS + 4 * W];                                    // survivors (reads may run 4W past K: masked)
+    __shared__ __attribute__((aligned(16))) float4 kf4[POL == POL_NUMPY64 ? KEPT_LDS : 1];
     __shared__ u64 maskrow[64];
-    __shared__ u64 supp_a[NMS_THREADS / 64];
+    __shared__ u64 supp_a[W];
     __shared__ int red[260];
     __shared__ int fill;
     u32* hist = reinterpret_cast<u32*>(scratch);
-    NBox<F>* cbox = reinterpret_cast<NBox<F>*>(scratch);
+    FBox* cb = reinterpret_cast<FBox*>(scratch);
+    u64* sorted = keybuf;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cand_count[work];
     const u64* keys = cand + (size_t)work * p.N;
     u64* kept_out = kept + (size_t)work * p.cap_store;
     const float4* img_boxes = boxes + (size_t)b * p.N;
-    const F Wpx = (F)p.img_w, Hpx = (F)p.img_h;
-    const F dpx = p.border == SSDHIP_BORDER_INCLUDE ? (F)1 : (p.border == SSDHIP_BORDER_EXCLUDE ? (F)-1 : (F)0);
-    const F thr = (F)p.iou_thresh;
-    const bool px_f32 = p.px_f32 != 0;
+    NmsK k;
+    k.W = p.img_w; k.H = p.img_h;
+    k.d = p.border == SSDHIP_BORDER_INCLUDE ? 1.0 : (p.border == SSDHIP_BORDER_EXCLUDE ? -1.0 : 0.0);
+    k.thr = p.iou_thresh;
+    k.Wf = (float)p.img_w; k.Hf = (float)p.img_h; k.df = (float)k.d; k.thr32 = (float)p.iou_thresh;
+    k.kE = p.filter_kE;
+    k.fast_ok = p.fast_ok; k.no_nms = p.no_nms;
     const int cap_eff = min(p.cap_store, n);
-    const int fast_ok = p.fast_ok;
-
-    auto load_kept = [&](int j) -> NBox<F> {
-        if (j < KEPT_LDS) return kcache[j];
-        const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK);
-        return make_nbox<F>(img_boxes[idx], idx, Wpx, Hpx, dpx, px_f32);
-    };
 
     int K = 0, consumed = 0;
     u64 upper = ~0ull;                       // keys >= upper are consumed; a real key is never all ones (its score field is a
@@ -449,19 +594,19 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
             m = remaining;                   // take everything that is left
         } else {
             // histogram of the remaining keys by score bin
-            for (int i = tid; i < NMS_NBINS; i += NMS_THREADS) hist[i] = 0;
+            for (int i = tid; i < NMS_NBINS; i += T) hist[i] = 0;
             __syncthreads();
-            for (int i0 = tid; i0 < n; i0 += 8 * NMS_THREADS) {
+            for (int i0 = tid; i0 < n; i0 += 8 * T) {
                 u64 k8[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = i0 + u * NMS_THREADS; k8[u] = i < n ? keys[i] : ~0ull; }
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * T; k8[u] = i < n ? keys[i] : ~0ull; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (k8[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(k8[u] >> IDX_BITS), p.thr_key)], 1u);
             }
             __syncthreads();
             // highest bin d such that the bins above it hold <= MAX_CHUNK keys (and d included would not fit)
-            block_find_digit<NMS_NBINS / NMS_THREADS>(hist, MAX_CHUNK + 1, red, red + 256);
+            block_find_digit<NMS_NBINS / T>(hist, MAX_CHUNK + 1, red, red + 256);
             bin_cut = red[256] + 1;
             m = red[257];
             __syncthreads();
@@ -469,16 +614,19 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
                 by_bin = true;
             } else {                         // one bin holds too many near-equal scores: exact selection of the M best
                 m = M;
-                cutoff = block_select_kth<32 + IDX_BITS, 12>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
+                cutoff = block_select_kth<32 + IDX_BITS, 12, T>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
             }
         }
         PROF_MARK(0)
+        int P = 2;                           // sort size: the power of two >= m, unused slots hold 0 (below every key)
+        while (P < m) P <<= 1;
+        for (int i = tid; i < P + 8; i += T) keybuf[i] = 0ull;
         if (tid == 0) fill = 0;
         __syncthreads();
-        for (int i0 = tid; i0 < n; i0 += 8 * NMS_THREADS) {
+        for (int i0 = tid; i0 < n; i0 += 8 * T) {
             u64 k8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NMS_THREADS; k8[u] = i < n ? keys[i] : ~0ull; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * T; k8[u] = i < n ? keys[i] : ~0ull; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const u64 key = k8[u];
@@ -489,15 +637,17 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
         }
         __syncthreads();
         PROF_MARK(1)
-        block_rank_sort_desc(keybuf, sorted, m);
+        block_bitonic_desc<T>(keybuf, P);
         PROF_MARK(2)
         upper = sorted[m - 1];
         has_upper = true;
         consumed += m;
         // stage the chunk's boxes (independent gathers, one latency exposure per round)
-        for (int i = tid; i < m; i += NMS_THREADS) {
+        for (int i = tid; i < m; i += T) {
             const u32 idx = IDX_MASK - (u32)(sorted[i] & IDX_MASK);
-            cbox[i] = make_nbox<F>(img_boxes[idx], idx, Wpx, Hpx, dpx, px_f32);
+            const float4 f4 = img_boxes[idx];
+            cb[i] = make_fbox<POL>(f4, idx, k);
+            if (POL == POL_NUMPY64) cf4[i] = f4;
         }
         __syncthreads();
         PROF_MARK(3)
@@ -505,59 +655,83 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
         for (int base = 0; base < m && K < cap_eff && !finished; base += 64) {
             const int nb = min(64, m - base);
             const bool valid = lane < nb;
-            const NBox<F> me = cbox[base + (valid ? lane : 0)];
-            // phase A: against survivors of earlier batches; the kept list is striped over the waves, four boxes per
-            // step so that four independent dependency chains are in flight
+            const FBox me = cb[base + (valid ? lane : 0)];
+            float4 me4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (POL == POL_NUMPY64) me4 = cf4[base + (valid ? lane : 0)];
+            // ---- phase A: against the survivors of earlier batches, striped over the waves, four per step ----
             bool supp = false;
-            for (int j = wave; j < K; j += 4 * (NMS_THREADS / 64)) {
-                int code[4];
-                NBox<F> kb[4];
+            if (!k.no_nms) {
+                const int Kl = min(K, KEPT_LDS);
+                for (int j0 = wave; j0 < Kl; j0 += 4 * W) {
+                    bool s_any = false, u_any = false;
+                    bool uu[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int jj = j + u * (NMS_THREADS / 64);
-                    code[u] = 0;
-                    if (jj < K) {
-                        kb[u] = load_kept(jj);
-                        code[u] = nms_test(me, kb[u], thr, fast_ok);
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u * W;
+                        const FBox o = kb[j];
+                        bool s, un;
+                        pair_test<POL>(me, o, k, s, un);
+                        const bool in = j < Kl;
+                        s_any |= in && s;
+                        uu[u] = in && un;
+                        u_any |= uu[u];
                     }
-                }
+                    supp |= s_any;
+                    if (POL != POL_NUMPY32 && __ballot(u_any && valid && !supp) != 0ull) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (code[u] == 1) supp = true;
-                    else if (code[u] == 2 && !supp) supp = exact_suppresses<F>(me, kb[u], thr);
+                        for (int u = 0; u < 4; ++u)
+                            if (uu[u] && !supp) supp = exact_pair<POL>(me, kb[j0 + u * W], me4, POL == POL_NUMPY64 ? kf4[j0 + u * W] : me4, k);
+                    }
+                    if (__ballot(valid && !supp) == 0ull) break;        // the whole batch is already suppressed
                 }
-                if (__ballot(valid && !supp) == 0) break;          // the whole batch is already suppressed
+                for (int j = KEPT_LDS + wave; j < K; j += W) {          // survivors beyond the LDS cache (uncapped decodes)
+                    const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK);
+                    const float4 o4 = img_boxes[idx];
+                    const FBox o = make_fbox<POL>(o4, idx, k);
+                    bool s, un;
+                    pair_test<POL>(me, o, k, s, un);
+                    if (POL != POL_NUMPY32 && un && !supp) s = exact_pair<POL>(me, o, me4, o4, k);
+                    supp |= s;
+                    if (__ballot(valid && !supp) == 0ull) break;
+                }
             }
             const u64 sa = __ballot(supp && valid);
             if (lane == 0) supp_a[wave] = sa;
             __syncthreads();
             // candidates already suppressed by an earlier survivor are dead: their rows of the in-batch matrix are never read
             // by the resolve loop, so phase B skips them (on densely overlapping boxes most of a batch dies in phase A)
-            const u64 sall_v = supp_a[0] | supp_a[1] | supp_a[2] | supp_a[3];
+            u64 sall_v = 0ull;
+#pragma unroll
+            for (int w = 0; w < W; ++w) sall_v |= supp_a[w];
             const u64 sall = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(sall_v >> 32)) << 32) |
                              (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)sall_v);      // scalar: the skips below are s_cbranch
             PROF_MARK(4)
-            // phase B: in-batch suppression rows, 16 per wave: bit i of maskrow[j] = "j suppresses i" (i > j)
-            for (int jj = 0; jj < 16; jj += 4) {
-                int code[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = wave * 16 + jj + u;
-                    code[u] = 0;
-                    if (j < nb && !((sall >> j) & 1ull)) code[u] = nms_test(me, cbox[base + j], thr, fast_ok);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = wave * 16 + jj + u;
-                    if (j >= nb) break;
-                    if ((sall >> j) & 1ull) {                                  // wave-uniform
-                        if (lane == 0) maskrow[j] = 0ull;
-                        continue;
+            // ---- phase B: in-batch pairs i > j.  Row j (lanes j+1..nb-1) and row nb-1-j (lanes nb-j..nb-1) together fill
+            //      nb-1 lanes: folded row f handles rows f and nb-1-f in one step.  Bit i of maskrow[j] = "j suppresses i". ----
+            const int nfold = (nb + 1) >> 1;
+            for (int f = wave; f < nfold; f += W) {
+                const int jA = f, jB = nb - 1 - f;
+                const bool deadA = (sall >> jA) & 1ull, deadB = ((sall >> jB) & 1ull) || jB == jA;
+                u64 rowA = 0ull, rowB = 0ull;
+                if (!k.no_nms && !(deadA && deadB)) {
+                    const bool isA = lane > jA && lane < nb;
+                    const bool isB = lane < f;                               // pair (nb - f + lane, jB)
+                    const int ii = isA ? lane : (isB ? nb - f + lane : 0);
+                    const int jj = isA ? jA : jB;
+                    const bool act = (isA && !deadA) || (isB && !deadB);
+                    const FBox bi = cb[base + ii], bj = cb[base + jj];
+                    bool s, un;
+                    pair_test<POL>(bi, bj, k, s, un);
+                    if (POL != POL_NUMPY32 && __ballot(un && act) != 0ull) {
+                        if (un && act) s = exact_pair<POL>(bi, bj, POL == POL_NUMPY64 ? cf4[base + ii] : me4, POL == POL_NUMPY64 ? cf4[base + jj] : me4, k);
                     }
-                    bool sj = code[u] == 1;
-                    if (code[u] == 2 && lane > j) sj = exact_suppresses<F>(me, cbox[base + j], thr);
-                    const u64 mrow = __ballot(valid && lane > j && sj);
-                    if (lane == 0) maskrow[j] = mrow;
+                    const u64 ball = __ballot(act && s);
+                    rowA = deadA ? 0ull : (ball & ~((2ull << jA) - 1ull));
+                    rowB = (deadB || f == 0) ? 0ull : ((ball & ((1ull << f) - 1ull)) << (nb - f));
+                }
+                if (lane == 0) {
+                    maskrow[jA] = rowA;
+                    if (jB != jA) maskrow[jB] = rowB;
                 }
             }
             __syncthreads();
@@ -585,11 +759,14 @@ __global__ __launch_bounds__(NMS_THREADS, SSDHIP_NMS_MINWAVES) void nms_kernel(D
             if (wave == 0 && ((alive >> lane) & 1ull)) {
                 const int pos = K + __popcll(alive & lanemask_lt());
                 kept_out[pos] = sorted[base + lane];
-                if (pos < KEPT_LDS) kcache[pos] = me;
+                if (pos < KEPT_LDS) {
+                    kb[pos] = cb[base + lane];
+                    if (POL == POL_NUMPY64) kf4[pos] = me4;
+                }
             }
             K += cnt;
-            // a kept box whose area is NaN makes every later IoU NaN ("not <= thr"): nothing after it can survive
-            if (alive & __ballot(valid && me.area != me.area)) finished = true;
+            // NumPy flows: a kept box whose area is NaN makes every later IoU NaN ("not <= thr"): nothing after it can survive
+            if (POL != POL_TF32 && !k.no_nms && (alive & __ballot(valid && me.area != me.area))) finished = true;
             __syncthreads();
             PROF_MARK(6)
         }
@@ -742,7 +919,7 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
             __syncthreads();
             cutoff = sh_cut;
         } else {
-            cutoff = block_select_kth<64, DIGIT_BITS>(comp_at, T, 0, false, rows, hist, red);
+            cutoff = block_select_kth<64, DIGIT_BITS, NMS_THREADS>(comp_at, T, 0, false, rows, hist, red);
         }
     }
     __syncthreads();
@@ -833,7 +1010,8 @@ static DecodeWs decode_ws_layout(int B, int N, int C, int top_k, int nms_cap, in
 using namespace ssdhip;
 
 extern "C" size_t ssdhip_decode_workspace_bytes(int B, int N, int C, int top_k, int nms_cap, int class_agnostic, int in_dtype) {
-    if (B <= 0 || N <= 0 || C < 2 || in_dtype != SSDHIP_F32) return 0;
+    if (B <= 0 || N <= 0 || C < 2 || (in_dtype != SSDHIP_F32 && in_dtype != SSDHIP_F64)) return 0;
+    if (in_dtype == SSDHIP_F64) return decode64_workspace_bytes(B, N, C, top_k, nms_cap, class_agnostic);
     return decode_ws_layout(B, N, C, top_k, nms_cap, class_agnostic).total;
 }
 
@@ -852,11 +1030,17 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
                       void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if ((!y_pred && !heads) || !out || !out_count || B <= 0 || N <= 0 || C < 2 || out_rows <= 0) return SSDHIP_E_BADARG;
-    if (in_dtype != SSDHIP_F32) return SSDHIP_E_BADARG;           // float64 predictions: not built yet
+    if (in_dtype != SSDHIP_F32 && in_dtype != SSDHIP_F64) return SSDHIP_E_BADARG;
     if (out_dtype != SSDHIP_F32 && out_dtype != SSDHIP_F64) return SSDHIP_E_BADARG;
     if (N > (1 << IDX_BITS) || C > 1025) return SSDHIP_E_BADARG;
     if (coords < 0 || coords > 2 || border_pixels < 0 || border_pixels > 2) return SSDHIP_E_BADARG;
     if (semantics < 0 || semantics > 2) return SSDHIP_E_BADARG;
+    if (in_dtype == SSDHIP_F64) {                                   // the all-float64 flow: csrc/ssdhip_decode64.hip
+        if (heads || !y_pred) return SSDHIP_E_BADARG;
+        return decode64_run(stages, static_cast<const double*>(y_pred), B, N, C, conf_thresh, iou_thresh, top_k, nms_cap,
+                            class_agnostic, semantics, coords, normalize_coords, img_height, img_width, border_pixels, out, out_dtype,
+                            out_rows, out_count, out_anchor_idx, ws, ws_bytes, stream);
+    }
     if (semantics == SSDHIP_SEM_KERAS && coords != SSDHIP_CENTROIDS) return SSDHIP_E_BADARG;  // as the layer (:81-82)
     const int sorted = semantics == SSDHIP_SEM_KERAS;
     if (sorted && (top_k <= 0 || top_k > TOPK_SORT_MAX)) return SSDHIP_E_BADARG;
@@ -890,7 +1074,11 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     p.img_w = normalize_coords ? img_width : 1.0;
     p.img_h = normalize_coords ? img_height : 1.0;
     p.fast_ok = (iou_thresh > 0.0 && iou_thresh < 1e300) ? 1 : 0;
+    if (semantics == SSDHIP_SEM_KERAS) p.fast_ok = ((float)iou_thresh >= 1e-30f && (float)iou_thresh < 1e30f) ? 1 : 0;
     p.px_f32 = (semantics == SSDHIP_SEM_KERAS) ? 1 : 0;
+    p.no_nms = (iou_thresh == (double)INFINITY) ? 1 : 0;
+    // error bound of the float32 evaluation of R = inter - thr*union: <= (6.25 + 18.4 thr) 2^-24 S; twice that
+    p.filter_kE = (iou_thresh > 0.0 && iou_thresh <= 16.0) ? (float)((16.0 + 40.0 * iou_thresh) * 0x1p-24 * 1.001) : INFINITY;
     if (p.px_f32 && ((double)(float)p.img_w != p.img_w || (double)(float)p.img_h != p.img_h)) return SSDHIP_E_BADARG;
     p.top_k = top_k; p.cap = nms_cap; p.cap_store = cap_store_for(N, top_k, nms_cap);
     p.out_rows = out_rows; p.sorted = sorted;
@@ -928,8 +1116,13 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     if (stages & 2) {
     const int work = B * p.G;
     const int g4 = ((work + 7) / 8) * 8;
-    if (p.iou_f32) hipLaunchKernelGGL(nms_kernel<float>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
-    else hipLaunchKernelGGL(nms_kernel<double>, dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, kept, kept_count);
+    const int* order = nullptr;
+    if (semantics == SSDHIP_SEM_KERAS)
+        hipLaunchKernelGGL((nms_kernel<POL_TF32, NMS_THREADS>), dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count);
+    else if (p.iou_f32)
+        hipLaunchKernelGGL((nms_kernel<POL_NUMPY32, NMS_THREADS>), dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count);
+    else
+        hipLaunchKernelGGL((nms_kernel<POL_NUMPY64, NMS_THREADS>), dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
 

@@ -45,6 +45,32 @@ __device__ __forceinline__ float det_expf(float xf) {
     return (float)(p * scale);
 }
 
+// float64 exp for the decoders' float64 flow (float64 predictions): the same chain without the final narrowing,
+// scaled by ldexp (one rounding, also for subnormal results).  <= 1 ulp; the CPU checker repeats the chain verbatim.
+__device__ __forceinline__ double det_exp64(double x) {
+    if (x != x) return x;
+    x = x < -746.0 ? -746.0 : x;
+    x = x > 710.0 ? 710.0 : x;
+    const double t = x * 0x1.71547652b82fep+0 + 0x1.8p52;
+    const double k = t - 0x1.8p52;
+    const double r = (x - k * 0x1.62e42fee00000p-1) - k * 0x1.a39ef35793c76p-33;
+    double p = 0x1.6124613a86d09p-33;
+    p = p * r + 0x1.1eed8eff8d898p-29;
+    p = p * r + 0x1.ae64567f544e4p-26;
+    p = p * r + 0x1.27e4fb7789f5cp-22;
+    p = p * r + 0x1.71de3a556c734p-19;
+    p = p * r + 0x1.a01a01a01a01ap-16;
+    p = p * r + 0x1.a01a01a01a01ap-13;
+    p = p * r + 0x1.6c16c16c16c17p-10;
+    p = p * r + 0x1.1111111111111p-7;
+    p = p * r + 0x1.5555555555555p-5;
+    p = p * r + 0x1.5555555555555p-3;
+    p = p * r + 0x1.0000000000000p-1;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    return ldexp(p, (int)k);
+}
+
 // ---------------------------------------------------------------------------------------
 // IoU of two 'corners' boxes exactly as bounding_box_utils.py:283-383 evaluates it in
 // 'element-wise' mode: intersection with d = 0 (the reference forgets to forward

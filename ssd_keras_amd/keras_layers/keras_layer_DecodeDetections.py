@@ -36,6 +36,7 @@ class DecodeDetections(nn.Module):
         self.coords = coords
         self.nms_max_output_size = nms_max_output_size
         self.name = kwargs.get('name')
+        self.timing_events = None          # a list: every call appends its (start, end) torch.cuda.Event pair (bench.py)
 
     @torch.no_grad()
     def forward(self, y_pred):
@@ -54,10 +55,17 @@ class DecodeDetections(nn.Module):
         """The same layer fed by the predictor heads' bf16 outputs instead of the assembled `(batch, #boxes, #classes + 12)`
         tensor: bias, softmax, anchors and the decode happen in one kernel (`scan_heads_kernel`), the
         prediction tensor never exists in HBM.  Same result, bit for bit, as `forward(assembled tensor)`."""
+        ev = None
+        if self.timing_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         out, _, _ = nat.decode_from_heads(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes,
                                           self.confidence_thresh, self.iou_threshold, self.top_k, self.nms_max_output_size,
                                           self._class_agnostic, nat.SEM_KERAS, 'centroids', self.normalize_coords, self.img_height,
                                           self.img_width, 'half', nat.F32, self.top_k)
+        if ev is not None:
+            ev[1].record()
+            self.timing_events.append(ev)
         return out
 
     def compute_output_shape(self, input_shape):

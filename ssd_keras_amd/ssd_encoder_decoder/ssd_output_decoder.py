@@ -15,17 +15,19 @@ import numpy as np
 from .. import _native as nat
 
 
-def _as_device_f32(y_pred):
+def _as_device(y_pred):
+    """NumPy array / torch tensor -> CUDA tensor of float32 (the model's output: float32 decode, then the reference's float64
+    flow) or float64 (the reference computes in the input's dtype, ssd_output_decoder.py:172-198: everything float64).
+    Other dtypes are widened to float64, which is where NumPy's arithmetic with the Python-float thresholds would take them."""
     import torch
     if isinstance(y_pred, np.ndarray):
-        if y_pred.dtype != np.float32:
-            raise TypeError("ssd_keras_amd decodes float32 predictions (what the model emits); got %s. "
-                            "float64 predictions are not supported yet." % y_pred.dtype)
+        if y_pred.dtype not in (np.float32, np.float64):
+            y_pred = y_pred.astype(np.float64)
         return nat.to_device(y_pred)
     if not torch.is_tensor(y_pred):
         raise TypeError("y_pred must be a NumPy array or a torch tensor")
-    if y_pred.dtype != torch.float32:
-        raise TypeError("ssd_keras_amd decodes float32 predictions; got %s" % y_pred.dtype)
+    if y_pred.dtype not in (torch.float32, torch.float64):
+        y_pred = y_pred.to(torch.float64)
     return nat.to_device(y_pred)
 
 
@@ -117,7 +119,7 @@ def decode_detections(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=
     confidence threshold, greedy NMS (float64 IoU, keep `<= iou_threshold`), then the `top_k` most
     confident rows.  Returns a list of `batch_size` float64 arrays `(k, 6)`
     `[class_id, confidence, xmin, ymin, xmax, ymax]`; `np.array([])` for an image with nothing left.'''
-    y = _as_device_f32(y_pred)
+    y = _as_device(y_pred)
     _check_common(y, normalize_coords, img_height, img_width, input_coords)
     B, N, L = y.shape
     k = 0 if top_k == 'all' else int(top_k)
@@ -131,7 +133,7 @@ def decode_detections_fast(y_pred, confidence_thresh=0.5, iou_threshold=0.45, to
                            normalize_coords=True, img_height=None, img_width=None, border_pixels='half'):
     '''Reference: ssd_output_decoder.py:228-333.  Class = first argmax over all scores, background
     dropped, `>=` confidence threshold, one class-agnostic NMS (skipped when `iou_threshold` is falsy).'''
-    y = _as_device_f32(y_pred)
+    y = _as_device(y_pred)
     _check_common(y, normalize_coords, img_height, img_width, input_coords)
     B, N, L = y.shape
     k = 0 if top_k == 'all' else int(top_k)
@@ -151,7 +153,7 @@ def decode_detections_debug(y_pred, confidence_thresh=0.01, iou_threshold=0.45, 
                             border_pixels='half'):
     '''Reference: ssd_output_decoder.py:342-467.  As `decode_detections`, rows
     `[box_id, class_id, confidence, xmin, ymin, xmax, ymax]`.'''
-    y = _as_device_f32(y_pred)
+    y = _as_device(y_pred)
     _check_common(y, normalize_coords, img_height, img_width, input_coords)
     if variance_encoded_in_target and input_coords == 'centroids':
         # :405-409: the offsets were not divided by the variances, i.e. decode with variances of one -- x * 1.0 is exact, so the

@@ -30,13 +30,10 @@ def _golden_cases(z):
 
 def test_golden_cases_vs_oracle_and_reference(dec):
     z = util.load("decoder")
-    n = 0
+    n = n64 = 0
     for name, fn_name, kw in _golden_cases(z):
         y = _y_pred_for(z, name)
-        if y.dtype != np.float32:
-            with pytest.raises(TypeError):
-                dec.decode_detections(y, **kw) if fn_name != "decode_detections_fast" else dec.decode_detections_fast(y, **kw)
-            continue
+        n64 += int(y.dtype == np.float64)            # float64 predictions: the reference's all-float64 flow (ssdhip_decode64.hip)
         want_ref = util.unragged(z[name + "_out"], z[name + "_off"])
         if fn_name == "decode_detections":
             got = dec.decode_detections(y, **kw)
@@ -57,7 +54,7 @@ def test_golden_cases_vs_oracle_and_reference(dec):
                 if w.shape[0] == 0:
                     assert g.shape == (0,)
         n += 1
-    assert n >= 50
+    assert n >= 100 and n64 >= 40
 
 
 def test_row_order_matches_reference_when_nothing_is_cut(dec):

@@ -37,7 +37,9 @@ def test_workspace_sizes(lib):
         fn.restype = ctypes.c_size_t
     d = lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 0)
     assert 32 * 8732 * (16 + 20 * 8) <= d < 2 * 32 * 8732 * (16 + 20 * 8)
-    assert lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 1) == 0        # float64 input not built
+    d64 = lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 1)              # float64 predictions: its own, larger layout
+    assert 32 * 8732 * (40 + 20 * 13) <= d64 < 2 * 32 * 8732 * (40 + 20 * 13)
+    assert lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 2) == 0        # unknown element type
     assert lib.ssdhip_decode_workspace_bytes(0, 8732, 21, 200, 400, 0, 0) == 0
     assert lib.ssdhip_encode_workspace_bytes(32, 8732, 21, 256) >= 256 * 8732 * 8
     assert lib.ssdhip_loss_workspace_bytes(32, 8732, 21) >= 2 * 32 * 8732 * 4

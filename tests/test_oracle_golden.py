@@ -188,6 +188,30 @@ def test_det_expf_accuracy():
     assert orc.det_expf(np.array([-200.0], np.float32))[0] == 0.0
 
 
+def test_det_exp64_accuracy_and_float64_flow():
+    """The float64 flow's exp: <= 1 ulp of exp(x) (np.exp(float64) is not correctly rounded either), exact at the ends; with it
+    the oracle's float64 decodes keep the reference's selection on every float64 golden case, boxes within 1e-9 px."""
+    x = np.concatenate([np.linspace(-745, 709, 400001), np.linspace(-2, 2, 200001)])
+    got, ref = orc.det_exp64(x), np.exp(x)
+    ok = np.isfinite(ref) & (ref > 1e-300)
+    assert np.max(np.abs(got[ok] - ref[ok]) / np.spacing(ref[ok])) <= 1.0
+    assert orc.det_exp64(0.0) == 1.0 and np.isnan(orc.det_exp64(np.nan))
+    assert orc.det_exp64(800.0) == np.inf and orc.det_exp64(-800.0) == 0.0
+    z = util.load("decoder")
+    n = 0
+    for name in [str(s) for s in z["cases"]]:
+        kw = util.kw_of(z, name)
+        y = _y_pred_for(z, name)
+        if y.dtype != np.float64:
+            continue
+        fn = orc.decode_detections_fast if str(z[name + "_fn"]) == "decode_detections_fast" else orc.decode_detections
+        got = fn(y, exp_mode="det", **kw)
+        want = util.unragged(z[name + "_out"], z[name + "_off"])
+        util.dets_equal(got, want, exact=False, rtol=1e-12, atol=1e-9)
+        n += 1
+    assert n >= 40
+
+
 def test_greedy_nms_public():
     z = util.load("decoder")
     items = [it for it in util.unragged(z["gnms_in"], z["gnms_in_off"]) if it.shape[0] > 0]
