@@ -291,44 +291,6 @@ __device__ u64 block_select_kth(KeyF key_at, int n, u64 upper, bool has_upper, i
     return prefix;
 }
 
-// Rank sort, descending, out of place: out[#{j : in[j] > in[i]}] = in[i].  Keys are unique and non-zero; `in` needs
-// m + 8 slots.  Every thread streams the whole list through LDS broadcast reads (8 keys per step, so the loads
-// overlap the compares) and ranks PER of its own keys in registers.
-template <int PER>
-__device__ __forceinline__ void rank_sort_desc_impl(const u64* in, u64* out, int m) {
-    const int tid = threadIdx.x;
-    u64 mine[PER];
-    int rank[PER];
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int i = tid + t * NMS_THREADS;
-        mine[t] = i < m ? in[i] : ~0ull;
-        rank[t] = 0;
-    }
-    for (int j = 0; j < m; j += 8) {
-        u64 k8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) k8[u] = in[j + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int t = 0; t < PER; ++t) rank[t] += (int)(k8[u] > mine[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int i = tid + t * NMS_THREADS;
-        if (i < m) out[rank[t]] = mine[t];
-    }
-}
-
-__device__ void block_rank_sort_desc(u64* in, u64* out, int m) {   // m <= 2 * NMS_THREADS
-    if (threadIdx.x < 8) in[m + threadIdx.x] = 0;
-    __syncthreads();
-    if (m <= NMS_THREADS) rank_sort_desc_impl<1>(in, out, m);
-    else rank_sort_desc_impl<2>(in, out, m);
-    __syncthreads();
-}
-
 // ======================================================================================
 // K4
 // ======================================================================================
@@ -481,7 +443,8 @@ __device__ __forceinline__ void pair_test(const FBox& a, const FBox& b, const Nm
     if (POL == POL_NUMPY64) {
         const float r = __builtin_fmaf(-k.thr32, uni, inter);
         const float E = k.kE * vmaxf(a.sc, b.sc);
-        const bool dec = __builtin_fabsf(r) > E;
+        // the sign of R answers "IoU <= thr" only for a positive union (negative areas: border_pixels 'exclude', inverted boxes)
+        const bool dec = __builtin_fabsf(r) > E && uni > E;
         supp = dec && r > 0.f;
         und = !dec;
     } else {
@@ -814,21 +777,29 @@ __device__ __forceinline__ int find_group(const int* offs, int G, int e) {
     return lo;
 }
 
+// K5 (second generation): one workgroup of TOPK_THREADS per image.  The survivors' composite keys [score (32) | inverted class-major
+// position (32)] order them by (score desc, class asc, NMS rank asc) -- tf.nn.top_k's order on the layer's class-major padded array.
+//   nothing to cut and no order asked (NumPy semantics, T <= top_k): rows leave in class-major order, the reference's own;
+//   otherwise: 8192-bin score histogram -> the bin holding the rows-th best -> collect every key of that bin and above (>= rows
+//   keys; more only when scores tie or crowd inside the boundary bin) -> bitonic sort in LDS -> the first `rows` keys, in order.
+//   Exact however the scores tie: the keys are unique.  Only when the collected set outgrows the LDS sort buffer (`sort_cap` keys)
+//   the first generation's exact radix select over the 64-bit keys runs instead.
+constexpr int TOPK_THREADS = 1024;
+
 template <typename OutT>
-__global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const float4* __restrict__ boxes,
-                                                           const u64* __restrict__ kept, const int* __restrict__ kept_count,
-                                                           const unsigned short* __restrict__ cls_map,
-                                                           OutT* __restrict__ out, int* __restrict__ out_count,
-                                                           int* __restrict__ out_idx) {
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(DecodeParams p, const float4* __restrict__ boxes,
+                                                            const u64* __restrict__ kept, const int* __restrict__ kept_count,
+                                                            const unsigned short* __restrict__ cls_map,
+                                                            OutT* __restrict__ out, int* __restrict__ out_count,
+                                                            int* __restrict__ out_idx, int sort_cap) {
+    constexpr int T5 = TOPK_THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64* bufa = reinterpret_cast<u64*>(smem_raw);                                         // 32 KiB: hist, then collected keys
+    u64* buf = reinterpret_cast<u64*>(smem_raw);                                          // >= 32 KiB: histogram, then keys
     u32* hist = reinterpret_cast<u32*>(smem_raw);
-    u64* bufb = reinterpret_cast<u64*>(smem_raw + NBINS * sizeof(u32));                   // 32 KiB + 16: sorted keys
-    int* offs = reinterpret_cast<int*>(smem_raw + 2 * NBINS * sizeof(u32) + 16);          // G+1 ints
+    int* offs = reinterpret_cast<int*>(smem_raw + (size_t)sort_cap * sizeof(u64));        // G+1 ints
     __shared__ int red[260];
     __shared__ int fill;
-    __shared__ int wave_tot[NMS_THREADS / 64];
-    __shared__ u64 sh_cut;
+    __shared__ int wave_tot[T5 / 64];
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
@@ -841,7 +812,7 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
     // class-major offsets: block scan of the survivor counts
     {
         int run = 0;
-        for (int g0 = 0; g0 < G; g0 += NMS_THREADS) {
+        for (int g0 = 0; g0 < G; g0 += T5) {
             const int g = g0 + tid;
             const int c = g < G ? kept_count[b * G + g] : 0;
             int inc = c;                                         // inclusive scan inside the wave
@@ -851,7 +822,7 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
             int before = run;
             for (int w = 0; w < wave; ++w) before += wave_tot[w];
             if (g < G) offs[g] = before + inc - c;
-            for (int w = 0; w < NMS_THREADS / 64; ++w) run += wave_tot[w];
+            for (int w = 0; w < T5 / 64; ++w) run += wave_tot[w];
             __syncthreads();
         }
         if (tid == 0) offs[G] = run;
@@ -863,8 +834,6 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
     int rows = p.top_k > 0 ? min(T, p.top_k) : T;
     rows = min(rows, p.out_rows);
 
-    // composite key of a survivor: [score key (32) | inverted class-major position (32)] -> score desc, then class asc,
-    // then NMS rank asc -- tf.nn.top_k's tie order on the layer's class-major padded array.
     auto comp_of = [&](int g, int r) -> u64 {
         const u64 key = img_kept[(size_t)g * p.cap_store + r];
         const u32 pos = (u32)g * (u32)p.cap_store + (u32)r;
@@ -882,93 +851,72 @@ __global__ __launch_bounds__(NMS_THREADS) void topk_kernel(DecodeParams p, const
         write_row<OutT>(img_out, img_idx, row, cls, key, img_boxes, p);
     };
 
-    // ---- the rows-th largest composite key (only when something has to be cut) ----
-    u64 cutoff = 0;
-    if (T > rows && rows > 0) {
-        for (int i = tid; i < NBINS; i += NMS_THREADS) hist[i] = 0;
-        __syncthreads();
-        for (int g = 0; g < G; ++g) {
-            const int kc = offs[g + 1] - offs[g];
-            for (int r = tid; r < kc; r += NMS_THREADS)
-                atomicAdd(&hist[bin_of<DIGIT_BITS, NBINS>((u32)(img_kept[(size_t)g * p.cap_store + r] >> IDX_BITS), p.thr_key)], 1u);
+    const bool need_cut = T > rows;
+    if (rows > 0 && !need_cut && !p.sorted) {
+        // the reference's order when nothing is cut: class ascending, NMS order inside a class
+        for (int e = tid; e < T; e += T5) emit(e, comp_at(e));
+    } else if (rows > 0) {
+        int bin_cut = 0, c = T;
+        if (need_cut) {
+            for (int i = tid; i < NBINS; i += T5) hist[i] = 0;
+            __syncthreads();
+            for (int e = tid; e < T; e += T5)
+                atomicAdd(&hist[bin_of<DIGIT_BITS, NBINS>((u32)(comp_at(e) >> 32), p.thr_key)], 1u);
+            __syncthreads();
+            block_find_digit<NBINS / T5>(hist, rows, red, red + 256);
+            bin_cut = red[256];
+            c = red[257] + (int)hist[bin_cut];                    // keys in the boundary bin and above
+            __syncthreads();
         }
-        __syncthreads();
-        block_find_digit<NBINS / NMS_THREADS>(hist, rows, red, red + 256);
-        const int bin_cut = red[256];
-        const int need = rows - red[257];                      // how many of bin_cut's entries make the cut
-        const int in_bin = (int)hist[bin_cut];
-        __syncthreads();
-        if (in_bin <= TOPK_SORT_MAX) {
+        PROF_MARK(1)
+        u64 cutoff = 0;
+        bool by_bin = true;
+        if (c > sort_cap) {
+            // the boundary bin is too crowded for the sort buffer: exact selection of the rows-th largest key instead
+            cutoff = block_select_kth<64, DIGIT_BITS, T5>(comp_at, T, 0, false, rows, hist, red);
+            by_bin = false;
+            c = rows;
+        }
+        if (c <= sort_cap) {
+            int P = 2;
+            while (P < c) P <<= 1;
+            for (int i = tid; i < P; i += T5) buf[i] = 0ull;
             if (tid == 0) fill = 0;
             __syncthreads();
-            for (int g = 0; g < G; ++g) {
-                const int kc = offs[g + 1] - offs[g];
-                for (int r = tid; r < kc; r += NMS_THREADS) {
-                    const u64 key = img_kept[(size_t)g * p.cap_store + r];
-                    if (bin_of<DIGIT_BITS, NBINS>((u32)(key >> IDX_BITS), p.thr_key) == bin_cut) bufa[atomicAdd(&fill, 1)] = comp_of(g, r);
-                }
+            for (int e = tid; e < T; e += T5) {
+                const u64 cm = comp_at(e);
+                const bool take = by_bin ? (bin_of<DIGIT_BITS, NBINS>((u32)(cm >> 32), p.thr_key) >= bin_cut) : (cm >= cutoff);
+                if (take) buf[atomicAdd(&fill, 1)] = cm;
             }
             __syncthreads();
-            // the need-th largest of the bin's entries: rank each one against the others
-            for (int i = tid; i < in_bin; i += NMS_THREADS) {
-                const u64 mine = bufa[i];
-                int rank = 0;
-                for (int j = 0; j < in_bin; ++j) rank += (int)(bufa[j] > mine);
-                if (rank == need - 1) sh_cut = mine;
-            }
-            __syncthreads();
-            cutoff = sh_cut;
+            PROF_MARK(2)
+            block_bitonic_desc<T5>(buf, P);
+            PROF_MARK(3)
+            for (int r = tid; r < rows; r += T5) emit(r, buf[r]);
         } else {
-            cutoff = block_select_kth<64, DIGIT_BITS, NMS_THREADS>(comp_at, T, 0, false, rows, hist, red);
-        }
-    }
-    __syncthreads();
-    PROF_MARK(1)
-
-    if (rows > 0 && p.sorted) {
-        // collect the selected entries, rank-sort them, write in order
-        if (tid == 0) fill = 0;
-        __syncthreads();
-        for (int g = 0; g < G; ++g) {
-            const int kc = offs[g + 1] - offs[g];
-            for (int r = tid; r < kc; r += NMS_THREADS) {
-                const u64 c = comp_of(g, r);
-                if (c >= cutoff) bufa[atomicAdd(&fill, 1)] = c;
+            // more rows than the sort buffer holds (an uncapped NumPy-semantics decode that still cuts): class-major compaction of
+            // the keys >= cutoff by a block scan
+            int base = 0;
+            for (int e0 = 0; e0 < T; e0 += T5) {
+                const int e = e0 + tid;
+                u64 cm = 0;
+                bool sel = false;
+                if (e < T) { cm = comp_at(e); sel = cm >= cutoff; }
+                const u64 m = __ballot(sel);
+                if (lane == 0) wave_tot[wave] = __popcll(m);
+                __syncthreads();
+                int off = base;
+                for (int w = 0; w < wave; ++w) off += wave_tot[w];
+                if (sel) emit(off + __popcll(m & lanemask_lt()), cm);
+                for (int w = 0; w < T5 / 64; ++w) base += wave_tot[w];
+                __syncthreads();
             }
-        }
-        __syncthreads();
-        PROF_MARK(2)
-        for (int i = tid; i < rows; i += NMS_THREADS) {
-            const u64 mine = bufa[i];
-            int rank = 0;
-            for (int j = 0; j < rows; ++j) rank += (int)(bufa[j] > mine);
-            bufb[rank] = mine;
-        }
-        __syncthreads();
-        PROF_MARK(3)
-        for (int r = tid; r < rows; r += NMS_THREADS) emit(r, bufb[r]);
-    } else if (rows > 0) {
-        // class-major order (the reference's order when nothing is cut); selected entries compacted by a block scan
-        int base = 0;
-        for (int e0 = 0; e0 < T; e0 += NMS_THREADS) {
-            const int e = e0 + tid;
-            u64 c = 0;
-            bool sel = false;
-            if (e < T) { c = comp_at(e); sel = c >= cutoff; }
-            const u64 m = __ballot(sel);
-            if (lane == 0) wave_tot[wave] = __popcll(m);
-            __syncthreads();
-            int off = base;
-            for (int w = 0; w < wave; ++w) off += wave_tot[w];
-            if (sel) emit(off + __popcll(m & lanemask_lt()), c);
-            for (int w = 0; w < NMS_THREADS / 64; ++w) base += wave_tot[w];
-            __syncthreads();
         }
     }
     PROF_MARK(4)
     // zero padding
-    for (int i = rows * 6 + tid; i < p.out_rows * 6; i += NMS_THREADS) img_out[i] = (OutT)0;
-    if (img_idx) for (int i = rows + tid; i < p.out_rows; i += NMS_THREADS) img_idx[i] = -1;
+    for (int i = rows * 6 + tid; i < p.out_rows * 6; i += T5) img_out[i] = (OutT)0;
+    if (img_idx) for (int i = rows + tid; i < p.out_rows; i += T5) img_idx[i] = -1;
     if (tid == 0) out_count[b] = rows;
     PROF_MARK(5)
     PROF_FLUSH(32)
@@ -1127,13 +1075,18 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     }
 
     if (stages & 4) {
-    const size_t k5_lds = 2 * NBINS * sizeof(u32) + 16 + align_up((size_t)(p.G + 1) * sizeof(int), 16);
+    // LDS sort buffer: every survivor of an image when that fits 128 KiB, never less than the 8192-counter histogram it aliases
+    size_t sort_cap = 4096;
+    while (sort_cap < (size_t)p.G * (size_t)p.cap_store && sort_cap < 16384) sort_cap <<= 1;
+    const size_t k5_lds = sort_cap * sizeof(u64) + align_up((size_t)(p.G + 1) * sizeof(int), 16);
+    const void* fn = out_dtype == SSDHIP_F32 ? reinterpret_cast<const void*>(topk_kernel<float>) : reinterpret_cast<const void*>(topk_kernel<double>);
+    if (k5_lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k5_lds) != hipSuccess) return SSDHIP_E_LAUNCH;
     if (out_dtype == SSDHIP_F32)
-        hipLaunchKernelGGL(topk_kernel<float>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
-                           static_cast<float*>(out), out_count, out_anchor_idx);
+        hipLaunchKernelGGL(topk_kernel<float>, dim3(B), dim3(TOPK_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
+                           static_cast<float*>(out), out_count, out_anchor_idx, (int)sort_cap);
     else
-        hipLaunchKernelGGL(topk_kernel<double>, dim3(B), dim3(NMS_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
-                           static_cast<double*>(out), out_count, out_anchor_idx);
+        hipLaunchKernelGGL(topk_kernel<double>, dim3(B), dim3(TOPK_THREADS), k5_lds, stream, p, boxes, kept, kept_count, cls_map,
+                           static_cast<double*>(out), out_count, out_anchor_idx, (int)sort_cap);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
     return SSDHIP_OK;
