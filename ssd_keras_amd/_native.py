@@ -101,15 +101,16 @@ def current_stream_ptr(device):
 
 
 class _Workspaces:
-    """One growable scratch buffer per (device, purpose).  Kernels on one stream serialise, so a
-    buffer is reused across calls on that stream; callers running several streams pass their own."""
+    """One growable scratch buffer per (device, purpose, stream).  Kernels on one stream serialise, so a buffer is reused across
+    calls on that stream; work enqueued on another stream gets its own buffer (two streams decoding at once must not share
+    candidate lists), allocated while that stream is current so the caching allocator orders its reuse on the right stream."""
 
     def __init__(self):
         self._bufs = {}
 
     def get(self, device, purpose, nbytes):
         torch = _torch()
-        key = (str(device), purpose)
+        key = (str(device), purpose, int(torch.cuda.current_stream(device).cuda_stream))
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -23,6 +23,7 @@
 //                    [score | class-major position]), optional sort, zero padding, final rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssdhip.h"
 #include "ssdhip_math.h"
@@ -55,10 +56,6 @@ constexpr int DIGIT_BITS = 13;               // radix-select digit / K5 histogra
 constexpr int NBINS = 1 << DIGIT_BITS;       // 8192 LDS counters = 32 KiB
 constexpr int NMS_BIN_SHIFT = 14;            // K4 score histogram: 2^14 float32 ulps per bin ...
 constexpr int NMS_NBINS = 4096;              // ... 4096 bins = 16 KiB (9 binades above the threshold)
-#ifndef SSDHIP_NMS_THREADS
-#define SSDHIP_NMS_THREADS 256
-#endif
-constexpr int NMS_THREADS = SSDHIP_NMS_THREADS;    // K4 workgroup (K5 and the block helpers use the same size)
 #ifndef SSDHIP_MAX_CHUNK
 #define SSDHIP_MAX_CHUNK 512
 #endif
@@ -67,6 +64,7 @@ constexpr int NMS_THREADS = SSDHIP_NMS_THREADS;    // K4 workgroup (K5 and the b
 #endif
 constexpr int MAX_CHUNK = SSDHIP_MAX_CHUNK;   // candidates sorted + staged per round in K4
 constexpr int KEPT_LDS = 256;                // survivors whose boxes are cached in LDS
+constexpr int KC_KEYS = 9216;                // K4: candidate lists up to this long are read in one trip per pass (KC_KEYS / T loads per thread)
 constexpr int TOPK_SORT_MAX = 4096;          // rows K5 can return sorted
 
 struct DecodeParams {
@@ -181,10 +179,16 @@ __device__ __forceinline__ void scan_tile_body(const float* tile, int* wave_cnt,
             mycnt = __popcll(__ballot(fast_pred));
         } else {
             const float* sc = row + gb + 1;
-            for (int j = 0; j < ng; ++j) {
-                const float s = sc[j];
-                const bool pr = active && (incl ? (s >= t) : (s > t));
-                { const int cnt = __popcll(__ballot(pr)); mycnt = lane == j ? cnt : mycnt; }
+            for (int j0 = 0; j0 < ng; j0 += 8) {                  // eight scores per step: their LDS reads are in flight together
+                float s8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s8[u] = (j0 + u < ng) ? sc[j0 + u] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool pr = active && (j0 + u < ng) && (incl ? (s8[u] >= t) : (s8[u] > t));
+                    const int cnt = __popcll(__ballot(pr));
+                    mycnt = lane == j0 + u ? cnt : mycnt;
+                }
             }
         }
         if (lane < ng) wave_cnt[wave * G + gb + lane] = mycnt;
@@ -211,15 +215,22 @@ __device__ __forceinline__ void scan_tile_body(const float* tile, int* wave_cnt,
         const int ng = min(64, G - gb);
         const int mybase = lane < ng ? wave_cnt[wave * G + gb + lane] : 0;
         const float* sc = row + gb + 1;
-        for (int j = 0; j < ng; ++j) {
-            const float s = p.class_agnostic ? fast_conf : sc[j];
-            const bool pr = p.class_agnostic ? fast_pred : (active && (incl ? (s >= t) : (s > t)));
-            const u64 m = __ballot(pr);
-            if (m == 0) continue;
-            const int base_j = __builtin_amdgcn_readlane(mybase, j);
-            if (pr) {
-                const int slot = base_j + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                cand[((size_t)b * G + gb + j) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
+        for (int j0 = 0; j0 < ng; j0 += 8) {
+            float s8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] = p.class_agnostic ? fast_conf : ((j0 + u < ng) ? sc[j0 + u] : 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const float s = s8[u];
+                const bool pr = (j < ng) && (p.class_agnostic ? fast_pred : (active && (incl ? (s >= t) : (s > t))));
+                const u64 m = __ballot(pr);
+                if (m == 0) continue;
+                const int base_j = __builtin_amdgcn_readlane(mybase, j);
+                if (pr) {
+                    const int slot = base_j + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    cand[((size_t)b * G + gb + j) * p.N + slot] = ((u64)float_key(s) << IDX_BITS) | inv_idx;
+                }
             }
         }
     }
@@ -496,12 +507,89 @@ __device__ void block_bitonic_desc(u64* a, int P) {
     __syncthreads();
 }
 
+// Bitonic sort, descending, of T * PER u64 keys held PER per thread (element e = tid * PER + r): compare-exchange partners
+// at distance < PER sit in the same thread, at distance < 64 * PER in the same wave (two 32-bit lane shuffles per key), and only
+// the last log2(T / 64) distances of the last stages go through LDS (`xch`: T * PER u64, two barriers per such step).
+template <int T, int PER>
+__device__ __forceinline__ void block_bitonic_desc_regs(u64 (&v)[PER], u64* xch) {
+    static_assert(PER == 1 || PER == 2 || PER == 4, "PER");
+    const int tid = threadIdx.x;
+    constexpr int N = T * PER;
+    for (int kk = 2; kk <= N; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j < PER) {                                    // both elements in this thread
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+#pragma unroll
+                    for (int jj = 1; jj < PER; jj <<= 1) {
+                        if (jj == j && (r & jj) == 0) {
+                            const bool desc = (((tid * PER + r) & kk) == 0);
+                            const u64 a = v[r], b = v[r | jj];
+                            if ((a < b) == desc) { v[r] = b; v[r | jj] = a; }
+                        }
+                    }
+                }
+            } else if (j < 64 * PER) {                        // partner lane = lane ^ (j / PER)
+                const int m = j / PER;
+                const bool low = (tid & m) == 0;              // this thread holds the lower-indexed element of each pair
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+                    const bool desc = (((tid * PER + r) & kk) == 0);
+                    const u32 olo = (u32)__shfl_xor((int)(u32)v[r], m), ohi = (u32)__shfl_xor((int)(u32)(v[r] >> 32), m);
+                    const u64 o = ((u64)ohi << 32) | olo;
+                    const bool take_max = low == desc;
+                    v[r] = take_max ? (o > v[r] ? o : v[r]) : (o < v[r] ? o : v[r]);
+                }
+            } else {                                          // another wave: exchange through LDS
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < PER; ++r) xch[tid * PER + r] = v[r];
+                __syncthreads();
+                const bool low = ((tid * PER) & j) == 0;
+#pragma unroll
+                for (int r = 0; r < PER; ++r) {
+                    const int e = tid * PER + r;
+                    const bool desc = ((e & kk) == 0);
+                    const u64 o = xch[e ^ j];
+                    const bool take_max = low == desc;
+                    v[r] = take_max ? (o > v[r] ? o : v[r]) : (o < v[r] ? o : v[r]);
+                }
+            }
+        }
+    }
+}
+
+// K4's one-pass read of a candidate list into registers: KC buffer loads per thread, all in flight together, ONE 32-bit
+// offset register (the step rides in the scalar soffset; past-the-end slots come back as 0 from the buffer unit's range check
+// and are mapped to the "consumed" key ~0).  The record count goes through an opaque scalar so that the loads are not hoisted
+// out of the round loop (the list is loop invariant; hoisting would keep 2 * KC registers alive through the NMS phases).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int T, int KC>
+__device__ __forceinline__ void load_keys_cached(const u64* keys, int n, int tid, u64 (&kc)[KC]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int nn = n;
+    asm volatile("" : "+s"(nn));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(keys), 0, nn * 8, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < KC; ++u) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, tid * 8, u * T * 8, 0);
+        const u64 key = ((u64)v.y << 32) | v.x;
+        kc[u] = key ? key : ~0ull;
+    }
+#endif
+}
+
 template <int POL, int T>
-__global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
+__global__ __launch_bounds__(T, (T >= 512 ? 6 : 3)) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
                                                const u64* __restrict__ cand, const int* __restrict__ cand_count,
                                                const int* __restrict__ work_order,
                                                u64* __restrict__ kept, int* __restrict__ kept_count) {
     constexpr int W = T / 64;
+    // pairs tested per step in phase A / folded rows per step in phase B, and whether phase A prefetches the next step's
+    // survivors: eight-wave workgroups trade unrolling (registers) for waves per SIMD
+    constexpr int KC = KC_KEYS / T;
+    constexpr int UA = T >= 512 ? 2 : 4, UB = T >= 512 ? 2 : 4;
+    constexpr bool PREFETCH = T < 512;
     // XCD-aware work mapping: hardware places block x on XCD x%8; give every XCD a contiguous range of
     // (image, class) work items so that all classes of an image share one L2.
     const int total_work = p.B * p.G;
@@ -515,7 +603,7 @@ __global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __
     constexpr size_t SCRATCH = sizeof(FBox) * MAX_CHUNK > NMS_NBINS * sizeof(u32) ? sizeof(FBox) * MAX_CHUNK : NMS_NBINS * sizeof(u32);
     __shared__ __attribute__((aligned(16))) unsigned char scratch[SCRATCH];   // score histogram, then the chunk's boxes
     __shared__ __attribute__((aligned(16))) float4 cf4[POL == POL_NUMPY64 ? MAX_CHUNK : 1];    // normalised corners (exact fallback)
-    __shared__ FBox kb[KEPT_LDS + 4 * W];                                    // survivors (reads may run 4W past K: masked)
+    __shared__ FBox kb[KEPT_LDS + 8 * W + 8];                                    // survivors (reads may run 8W past K: masked)
     __shared__ __attribute__((aligned(16))) float4 kf4[POL == POL_NUMPY64 ? KEPT_LDS : 1];
     __shared__ u64 maskrow[64];
     __shared__ u64 supp_a[W];
@@ -553,19 +641,31 @@ __global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __
         u64 cutoff = 0;
         bool by_bin = false;
         int bin_cut = 0;
+        // A candidate list of up to KC * T keys (every SSD300 class list) is read in ONE trip per pass (histogram, collection):
+        // all of a thread's loads are in flight together.  Longer lists (SSD512) take eight loads at a time.  (Keeping the keys
+        // in registers from the first pass to the second costs 72 VGPRs across the selection and drops a workgroup per CU.)
+        const bool cached = n <= KC * T;
         if (remaining <= MAX_CHUNK) {
             m = remaining;                   // take everything that is left
         } else {
             // histogram of the remaining keys by score bin
             for (int i = tid; i < NMS_NBINS; i += T) hist[i] = 0;
             __syncthreads();
-            for (int i0 = tid; i0 < n; i0 += 8 * T) {
-                u64 k8[8];
+            if (cached) {
+                u64 kc[KC];
+                load_keys_cached<T, KC>(keys, n, tid, kc);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = i0 + u * T; k8[u] = i < n ? keys[i] : ~0ull; }
+                for (int u = 0; u < KC; ++u)
+                    if (kc[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(kc[u] >> IDX_BITS), p.thr_key)], 1u);
+            } else {
+                for (int i0 = tid; i0 < n; i0 += 8 * T) {
+                    u64 k8[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (k8[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(k8[u] >> IDX_BITS), p.thr_key)], 1u);
+                    for (int u = 0; u < 8; ++u) { const int i = i0 + u * T; k8[u] = i < n ? keys[i] : ~0ull; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (k8[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(k8[u] >> IDX_BITS), p.thr_key)], 1u);
+                }
             }
             __syncthreads();
             // highest bin d such that the bins above it hold <= MAX_CHUNK keys (and d included would not fit)
@@ -581,26 +681,45 @@ __global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __
             }
         }
         PROF_MARK(0)
-        int P = 2;                           // sort size: the power of two >= m, unused slots hold 0 (below every key)
-        while (P < m) P <<= 1;
-        for (int i = tid; i < P + 8; i += T) keybuf[i] = 0ull;
+        for (int i = tid; i < MAX_CHUNK + 8; i += T) keybuf[i] = 0ull;     // unused sort slots hold 0 (below every key)
         if (tid == 0) fill = 0;
         __syncthreads();
-        for (int i0 = tid; i0 < n; i0 += 8 * T) {
-            u64 k8[8];
+        if (cached) {
+            u64 kc[KC];
+            load_keys_cached<T, KC>(keys, n, tid, kc);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * T; k8[u] = i < n ? keys[i] : ~0ull; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const u64 key = k8[u];
+            for (int u = 0; u < KC; ++u) {
+                const u64 key = kc[u];
                 if (!(key < upper)) continue;
                 const bool take = by_bin ? (bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key) >= bin_cut) : (key >= cutoff);
                 if (take) keybuf[atomicAdd(&fill, 1)] = key;
             }
+        } else {
+            for (int i0 = tid; i0 < n; i0 += 8 * T) {
+                u64 k8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * T; k8[u] = i < n ? keys[i] : ~0ull; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u64 key = k8[u];
+                    if (!(key < upper)) continue;
+                    const bool take = by_bin ? (bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key) >= bin_cut) : (key >= cutoff);
+                    if (take) keybuf[atomicAdd(&fill, 1)] = key;
+                }
+            }
         }
         __syncthreads();
         PROF_MARK(1)
-        block_bitonic_desc<T>(keybuf, P);
+        {
+            constexpr int PER = MAX_CHUNK / T;
+            u64 v[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) v[r] = keybuf[tid * PER + r];
+            block_bitonic_desc_regs<T, PER>(v, reinterpret_cast<u64*>(scratch));
+#pragma unroll
+            for (int r = 0; r < PER; ++r) keybuf[tid * PER + r] = v[r];
+            __syncthreads();
+        }
         PROF_MARK(2)
         upper = sorted[m - 1];
         has_upper = true;
@@ -625,15 +744,22 @@ __global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __
             bool supp = false;
             if (!k.no_nms) {
                 const int Kl = min(K, KEPT_LDS);
-                for (int j0 = wave; j0 < Kl; j0 += 4 * W) {
-                    bool s_any = false, u_any = false;
-                    bool uu[4];
+                FBox o[UA];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UA; ++u) o[u] = kb[wave + u * W];
+                for (int j0 = wave; j0 < Kl; j0 += UA * W) {
+                    FBox nx[PREFETCH ? UA : 1];                  // PREFETCH: the next step's survivors are on their way while this
+                    if (PREFETCH) {                              // step's are tested (kb is padded: the reads stay in bounds)
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) nx[u] = kb[j0 + UA * W + u * W];
+                    }
+                    bool s_any = false, u_any = false;
+                    bool uu[UA];
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
                         const int j = j0 + u * W;
-                        const FBox o = kb[j];
                         bool s, un;
-                        pair_test<POL>(me, o, k, s, un);
+                        pair_test<POL>(me, o[u], k, s, un);
                         const bool in = j < Kl;
                         s_any |= in && s;
                         uu[u] = in && un;
@@ -642,10 +768,12 @@ __global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __
                     supp |= s_any;
                     if (POL != POL_NUMPY32 && __ballot(u_any && valid && !supp) != 0ull) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (uu[u] && !supp) supp = exact_pair<POL>(me, kb[j0 + u * W], me4, POL == POL_NUMPY64 ? kf4[j0 + u * W] : me4, k);
+                        for (int u = 0; u < UA; ++u)
+                            if (uu[u] && !supp) supp = exact_pair<POL>(me, o[u], me4, POL == POL_NUMPY64 ? kf4[j0 + u * W] : me4, k);
                     }
                     if (__ballot(valid && !supp) == 0ull) break;        // the whole batch is already suppressed
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) o[u] = PREFETCH ? nx[u] : kb[j0 + UA * W + u * W];
                 }
                 for (int j = KEPT_LDS + wave; j < K; j += W) {          // survivors beyond the LDS cache (uncapped decodes)
                     const u32 idx = IDX_MASK - (u32)(kept_out[j] & IDX_MASK);
@@ -672,29 +800,59 @@ __global__ __launch_bounds__(T) void nms_kernel(DecodeParams p, const float4* __
             // ---- phase B: in-batch pairs i > j.  Row j (lanes j+1..nb-1) and row nb-1-j (lanes nb-j..nb-1) together fill
             //      nb-1 lanes: folded row f handles rows f and nb-1-f in one step.  Bit i of maskrow[j] = "j suppresses i". ----
             const int nfold = (nb + 1) >> 1;
-            for (int f = wave; f < nfold; f += W) {
-                const int jA = f, jB = nb - 1 - f;
-                const bool deadA = (sall >> jA) & 1ull, deadB = ((sall >> jB) & 1ull) || jB == jA;
-                u64 rowA = 0ull, rowB = 0ull;
-                if (!k.no_nms && !(deadA && deadB)) {
+            for (int f0 = wave * UB; f0 < nfold; f0 += UB * W) {     // UB folded rows per step: their LDS reads overlap
+                bool s4[UB], un4[UB], act4[UB];
+                int ii4[UB], jj4[UB];
+                FBox bi[UB], bj[UB];
+                bool any_live = false;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int f = f0 + u;
+                    const int jA = f, jB = nb - 1 - f;
+                    const bool row = f < nfold;
+                    const bool deadA = !row || ((sall >> (jA & 63)) & 1ull), deadB = !row || ((sall >> (jB & 63)) & 1ull) || jB == jA;
                     const bool isA = lane > jA && lane < nb;
                     const bool isB = lane < f;                               // pair (nb - f + lane, jB)
-                    const int ii = isA ? lane : (isB ? nb - f + lane : 0);
-                    const int jj = isA ? jA : jB;
-                    const bool act = (isA && !deadA) || (isB && !deadB);
-                    const FBox bi = cb[base + ii], bj = cb[base + jj];
-                    bool s, un;
-                    pair_test<POL>(bi, bj, k, s, un);
-                    if (POL != POL_NUMPY32 && __ballot(un && act) != 0ull) {
-                        if (un && act) s = exact_pair<POL>(bi, bj, POL == POL_NUMPY64 ? cf4[base + ii] : me4, POL == POL_NUMPY64 ? cf4[base + jj] : me4, k);
-                    }
-                    const u64 ball = __ballot(act && s);
-                    rowA = deadA ? 0ull : (ball & ~((2ull << jA) - 1ull));
-                    rowB = (deadB || f == 0) ? 0ull : ((ball & ((1ull << f) - 1ull)) << (nb - f));
+                    ii4[u] = isA ? lane : (isB ? nb - f + lane : 0);
+                    jj4[u] = row ? (isA ? jA : jB) : 0;
+                    ii4[u] = row ? ii4[u] : 0;
+                    act4[u] = !k.no_nms && ((isA && !deadA) || (isB && !deadB));
+                    any_live |= !(deadA && deadB);
                 }
-                if (lane == 0) {
-                    maskrow[jA] = rowA;
-                    if (jB != jA) maskrow[jB] = rowB;
+                if (any_live && !k.no_nms) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { bi[u] = cb[base + ii4[u]]; bj[u] = cb[base + jj4[u]]; }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) pair_test<POL>(bi[u], bj[u], k, s4[u], un4[u]);
+                    if (POL != POL_NUMPY32) {
+                        bool un_any = false;
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) un_any |= un4[u] && act4[u];
+                        if (__ballot(un_any) != 0ull) {
+#pragma unroll
+                            for (int u = 0; u < UB; ++u)
+                                if (un4[u] && act4[u])
+                                    s4[u] = exact_pair<POL>(bi[u], bj[u], POL == POL_NUMPY64 ? cf4[base + ii4[u]] : me4,
+                                                            POL == POL_NUMPY64 ? cf4[base + jj4[u]] : me4, k);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) s4[u] = false;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int f = f0 + u;
+                    if (f >= nfold) break;
+                    const int jA = f, jB = nb - 1 - f;
+                    const bool deadA = (sall >> jA) & 1ull, deadB = ((sall >> jB) & 1ull) || jB == jA;
+                    const u64 ball = __ballot(act4[u] && s4[u]);
+                    const u64 rowA = deadA ? 0ull : (ball & ~((2ull << jA) - 1ull));
+                    const u64 rowB = (deadB || f == 0) ? 0ull : ((ball & ((1ull << f) - 1ull)) << (nb - f));
+                    if (lane == 0) {
+                        maskrow[jA] = rowA;
+                        if (jB != jA) maskrow[jB] = rowB;
+                    }
                 }
             }
             __syncthreads();
@@ -856,12 +1014,25 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(DecodeParams p, cons
         // the reference's order when nothing is cut: class ascending, NMS order inside a class
         for (int e = tid; e < T; e += T5) emit(e, comp_at(e));
     } else if (rows > 0) {
+        // up to PL * T5 survivors (every SSD300 image: 20 classes x 200) are read ONCE, PL independent loads per thread, and
+        // stay in registers for the histogram and the collection
+        constexpr int PL = 4;
+        const bool in_regs = T <= PL * T5;
+        u64 cm[PL];
+#pragma unroll
+        for (int u = 0; u < PL; ++u) { const int e = tid + u * T5; cm[u] = (in_regs && e < T) ? comp_at(e) : 0ull; }
         int bin_cut = 0, c = T;
         if (need_cut) {
             for (int i = tid; i < NBINS; i += T5) hist[i] = 0;
             __syncthreads();
-            for (int e = tid; e < T; e += T5)
-                atomicAdd(&hist[bin_of<DIGIT_BITS, NBINS>((u32)(comp_at(e) >> 32), p.thr_key)], 1u);
+            if (in_regs) {
+#pragma unroll
+                for (int u = 0; u < PL; ++u)
+                    if (cm[u]) atomicAdd(&hist[bin_of<DIGIT_BITS, NBINS>((u32)(cm[u] >> 32), p.thr_key)], 1u);
+            } else {
+                for (int e = tid; e < T; e += T5)
+                    atomicAdd(&hist[bin_of<DIGIT_BITS, NBINS>((u32)(comp_at(e) >> 32), p.thr_key)], 1u);
+            }
             __syncthreads();
             block_find_digit<NBINS / T5>(hist, rows, red, red + 256);
             bin_cut = red[256];
@@ -880,34 +1051,80 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(DecodeParams p, cons
         if (c <= sort_cap) {
             int P = 2;
             while (P < c) P <<= 1;
+            if (P < T5) P = T5;                                   // the register sorts take T5 or 4 * T5 keys
+            else if (P > T5 && P < 4 * T5) P = 4 * T5;
             for (int i = tid; i < P; i += T5) buf[i] = 0ull;
             if (tid == 0) fill = 0;
             __syncthreads();
-            for (int e = tid; e < T; e += T5) {
-                const u64 cm = comp_at(e);
-                const bool take = by_bin ? (bin_of<DIGIT_BITS, NBINS>((u32)(cm >> 32), p.thr_key) >= bin_cut) : (cm >= cutoff);
-                if (take) buf[atomicAdd(&fill, 1)] = cm;
+            if (in_regs) {
+#pragma unroll
+                for (int u = 0; u < PL; ++u) {
+                    const u64 v = cm[u];
+                    const bool take = v != 0ull && (by_bin ? (bin_of<DIGIT_BITS, NBINS>((u32)(v >> 32), p.thr_key) >= bin_cut) : (v >= cutoff));
+                    if (take) buf[atomicAdd(&fill, 1)] = v;
+                }
+            } else {
+                for (int e = tid; e < T; e += T5) {
+                    const u64 v = comp_at(e);
+                    const bool take = by_bin ? (bin_of<DIGIT_BITS, NBINS>((u32)(v >> 32), p.thr_key) >= bin_cut) : (v >= cutoff);
+                    if (take) buf[atomicAdd(&fill, 1)] = v;
+                }
             }
             __syncthreads();
             PROF_MARK(2)
-            block_bitonic_desc<T5>(buf, P);
-            PROF_MARK(3)
-            for (int r = tid; r < rows; r += T5) emit(r, buf[r]);
+            if (P == T5 && c <= 512) {
+                // the usual case, a few hundred keys around the cut: rank by counting -- T5 / Pc threads share a key, each compares it
+                // with a slice of the list (LDS broadcast reads), the partial ranks meet in an LDS counter; no barrier-per-step sort
+                int Pc = 128;
+                while (Pc < c) Pc <<= 1;
+                const int parts = T5 / Pc, len = Pc / parts;          // Pc in {128..512}: parts in {8..2}, len = Pc^2 / T5 >= 16
+                u32* rank = reinterpret_cast<u32*>(buf + T5);         // buf holds >= 4096 u64: ranks live behind the first T5 keys
+                if (tid < Pc) rank[tid] = 0u;
+                __syncthreads();
+                const int ki = tid & (Pc - 1), part = tid / Pc;
+                const u64 mine = buf[ki];
+                u32 r = 0;
+                for (int j = part * len; j < part * len + len; j += 8) {
+                    u64 o8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o8[u] = buf[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) r += (u32)(o8[u] > mine);
+                }
+                if (mine != 0ull && r) atomicAdd(&rank[ki], r);
+                __syncthreads();
+                PROF_MARK(3)
+                if (tid < Pc && mine != 0ull && (int)rank[tid] < rows) emit((int)rank[tid], mine);
+            } else if (P == T5) {                                 // up to 1024 keys
+            } else if (P == 4 * T5) {                             // many equal scores at the cut (saturated softmax)
+                u64 v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = buf[tid * 4 + r];
+                block_bitonic_desc_regs<T5, 4>(v, buf);
+                PROF_MARK(3)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tid * 4 + r < rows) emit(tid * 4 + r, v[r]);
+            } else {                                              // more than 4096 keys: the sort runs in LDS
+                block_bitonic_desc<T5>(buf, P);
+                PROF_MARK(3)
+                for (int r = tid; r < rows; r += T5) emit(r, buf[r]);
+            }
         } else {
             // more rows than the sort buffer holds (an uncapped NumPy-semantics decode that still cuts): class-major compaction of
             // the keys >= cutoff by a block scan
             int base = 0;
             for (int e0 = 0; e0 < T; e0 += T5) {
                 const int e = e0 + tid;
-                u64 cm = 0;
+                u64 cm2 = 0;
                 bool sel = false;
-                if (e < T) { cm = comp_at(e); sel = cm >= cutoff; }
+                if (e < T) { cm2 = comp_at(e); sel = cm2 >= cutoff; }
                 const u64 m = __ballot(sel);
                 if (lane == 0) wave_tot[wave] = __popcll(m);
                 __syncthreads();
                 int off = base;
                 for (int w = 0; w < wave; ++w) off += wave_tot[w];
-                if (sel) emit(off + __popcll(m & lanemask_lt()), cm);
+                if (sel) emit(off + __popcll(m & lanemask_lt()), cm2);
                 for (int w = 0; w < T5 / 64; ++w) base += wave_tot[w];
                 __syncthreads();
             }
@@ -1065,12 +1282,21 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     const int work = B * p.G;
     const int g4 = ((work + 7) / 8) * 8;
     const int* order = nullptr;
-    if (semantics == SSDHIP_SEM_KERAS)
-        hipLaunchKernelGGL((nms_kernel<POL_TF32, NMS_THREADS>), dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count);
-    else if (p.iou_f32)
-        hipLaunchKernelGGL((nms_kernel<POL_NUMPY32, NMS_THREADS>), dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count);
-    else
-        hipLaunchKernelGGL((nms_kernel<POL_NUMPY64, NMS_THREADS>), dim3(g4), dim3(NMS_THREADS), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count);
+    // workgroup size of K4: 512 threads measured 4-8 % faster than 256 for the layer semantics, equal otherwise (profiles/r02e);
+    // SSDHIP_NMS_T overrides (A/B timing)
+    static const int nms_env = []() { const char* e = getenv("SSDHIP_NMS_T"); return e ? atoi(e) : 0; }();
+    const int nms_t = nms_env ? nms_env : (semantics == SSDHIP_SEM_KERAS ? 512 : 256);
+#define SSDHIP_LAUNCH_NMS(POL)                                                                                                            \
+    do {                                                                                                                                  \
+        if (nms_t >= 512)                                                                                                                 \
+            hipLaunchKernelGGL((nms_kernel<POL, 512>), dim3(g4), dim3(512), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count); \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((nms_kernel<POL, 256>), dim3(g4), dim3(256), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count); \
+    } while (0)
+    if (semantics == SSDHIP_SEM_KERAS) SSDHIP_LAUNCH_NMS(POL_TF32);
+    else if (p.iou_f32) SSDHIP_LAUNCH_NMS(POL_NUMPY32);
+    else SSDHIP_LAUNCH_NMS(POL_NUMPY64);
+#undef SSDHIP_LAUNCH_NMS
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
 

@@ -7,7 +7,10 @@ The reference has no multi-device code at all.  What shards h
   * the training step needs exactly one collective, the gradient all-reduce (26.3 M fp32 parameters = 105 MB
     for SSD300/VOC).  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring is per-link bound:
     buckets of ~25 MB keep 4-5 collectives in flight behind the backward pass instead of one 105 MB tail.
-  * hard-negative mining stays local to the rank's batch -- exactly the reference evaluated on that shard.
+  * hard-negative mining and the 1 / n_positives normalisation stay local to the rank's batch -- exactly the reference
+    evaluated on that shard; DDP then AVERAGES the per-rank gradients, so a step is the mean over ranks of the reference's
+    per-shard losses, not the reference's loss on the concatenated batch (that would need an all-reduce of n_positives and a
+    distributed k-th-value select).  `tests/test_distributed_cpu.py` pins this identity.
 """
 from __future__ import annotations
 
@@ -49,8 +52,11 @@ def data_parallel(model, device=None, bucket_cap_mb=25):
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if (device is not None and device.type == "cuda") else None
+    # A model with buffers (SSD7's BatchNorm running statistics) keeps them identical on every rank: rank 0's are broadcast at
+    # each forward, so a checkpoint written by any rank describes the same model.  SSD300 / SSD512 have no buffers: no traffic.
+    has_buffers = any(True for _ in model.buffers())
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
-               broadcast_buffers=False)
+               broadcast_buffers=has_buffers)
 
 
 def max_over_ranks(value, device="cpu"):

@@ -60,27 +60,19 @@ class Evaluator:
                  decoding_normalize_coords=True):
         '''Reference :94-256: the whole evaluation in one call.  Returns the mean average precision and, optionally, the
         average precisions, precisions and recalls (in that order, as the reference does).'''
-        self.predict_on_dataset(img_height=img_height, img_width=img_width, batch_size=batch_size,
-                                data_generator_mode=data_generator_mode, decoding_confidence_thresh=decoding_confidence_thresh,
-                                decoding_iou_threshold=decoding_iou_threshold, decoding_top_k=decoding_top_k,
-                                decoding_pred_coords=decoding_pred_coords, decoding_normalize_coords=decoding_normalize_coords,
-                                decoding_border_pixels=border_pixels, round_confidences=round_confidences, verbose=verbose, ret=False)
-        self.get_num_gt_per_class(ignore_neutral_boxes=ignore_neutral_boxes, verbose=False, ret=False)
-        self.match_predictions(ignore_neutral_boxes=ignore_neutral_boxes, matching_iou_threshold=matching_iou_threshold,
-                               border_pixels=border_pixels, sorting_algorithm=sorting_algorithm, verbose=verbose, ret=False)
-        self.compute_precision_recall(verbose=verbose, ret=False)
-        self.compute_average_precisions(mode=average_precision_mode, num_recall_points=num_recall_points, verbose=verbose, ret=False)
-        mean_average_precision = self.compute_mean_average_precision(ret=True)
-        if return_precisions or return_recalls or return_average_precisions:
-            ret = [mean_average_precision]
-            if return_average_precisions:
-                ret.append(self.average_precisions)
-            if return_precisions:
-                ret.append(self.cumulative_precisions)
-            if return_recalls:
-                ret.append(self.cumulative_recalls)
-            return ret
-        return mean_average_precision
+        # the five stages, each leaving its result on the instance exactly as the stand-alone methods do
+        self.predict_on_dataset(img_height, img_width, batch_size, data_generator_mode, decoding_confidence_thresh,
+                                decoding_iou_threshold, decoding_top_k, decoding_pred_coords, decoding_normalize_coords,
+                                border_pixels, round_confidences, verbose)
+        self.get_num_gt_per_class(ignore_neutral_boxes, verbose=False)
+        self.match_predictions(ignore_neutral_boxes, matching_iou_threshold, border_pixels, sorting_algorithm, verbose)
+        self.compute_precision_recall(verbose)
+        self.compute_average_precisions(average_precision_mode, num_recall_points, verbose)
+        result = [self.compute_mean_average_precision()]
+        extras = ((return_average_precisions, self.average_precisions), (return_precisions, self.cumulative_precisions),
+                  (return_recalls, self.cumulative_recalls))
+        result += [value for wanted, value in extras if wanted]
+        return result if len(result) > 1 else result[0]
 
     def predict_on_dataset(self, img_height, img_width, batch_size, data_generator_mode='resize',
                            decoding_confidence_thresh=0.01, decoding_iou_threshold=0.45, decoding_top_k=200,
@@ -142,19 +134,19 @@ class Evaluator:
         return boxes
 
     def write_predictions_to_txt(self, classes=None, out_file_prefix='comp3_det_test_', verbose=True):
-        '''Reference :426-475: one Pascal VOC results file per class.'''
+        '''Reference :426-475: one Pascal VOC results file per class, a line `image_id confidence xmin ymin xmax ymax` per
+        prediction (image id zero-padded to six digits, confidence rounded to four decimals).'''
         if self.prediction_results is None:
             raise ValueError("There are no prediction results. You must run `predict_on_dataset()` before calling this method.")
-        for class_id in range(1, self.n_classes + 1):
+        for class_id, rows in enumerate(self.prediction_results):
+            if class_id == 0:
+                continue                                              # entry 0 is the background dummy
             if verbose:
                 print("Writing results file for class {}/{}.".format(class_id, self.n_classes))
-            suffix = '{:04d}'.format(class_id) if classes is None else classes[class_id]
-            with open('{}{}.txt'.format(out_file_prefix, suffix), 'w') as results_file:
-                for prediction in self.prediction_results[class_id]:
-                    prediction_list = list(prediction)
-                    prediction_list[0] = '{:06d}'.format(int(prediction_list[0]))
-                    prediction_list[1] = round(prediction_list[1], 4)
-                    results_file.write(' '.join(map(str, prediction_list)) + '\n')
+            name = classes[class_id] if classes is not None else '{:04d}'.format(class_id)
+            lines = ['{:06d} {} {}\n'.format(int(row[0]), round(row[1], 4), ' '.join(str(v) for v in row[2:])) for row in rows]
+            with open(out_file_prefix + name + '.txt', 'w') as handle:
+                handle.writelines(lines)
         if verbose:
             print("All results files saved.")
 
@@ -254,25 +246,61 @@ class Evaluator:
         return boxes, offsets, flags
 
     def compute_precision_recall(self, verbose=True, ret=False):
-        '''Reference :738-781.'''
+        '''Reference :738-781: per class, precision = TP / (TP + FP) (0 where nothing has been predicted yet) and
+        recall = TP / #ground truth, over the confidence-sorted running counts.'''
         if (self.cumulative_true_positives is None) or (self.cumulative_false_positives is None):
             raise ValueError("True and false positives not available. You must run `match_predictions()` before you call this method.")
         if self.num_gt_per_class is None:
             raise ValueError("Number of ground truth boxes per class not available. You must run `get_num_gt_per_class()` before "
                              "you call this method.")
-        cumulative_precisions, cumulative_recalls = [[]], [[]]
+        precisions, recalls = [[]], [[]]
         for class_id in range(1, self.n_classes + 1):
             if verbose:
                 print("Computing precisions and recalls, class {}/{}".format(class_id, self.n_classes))
-            tp = self.cumulative_true_positives[class_id]
-            fp = self.cumulative_false_positives[class_id]
+            hits = self.cumulative_true_positives[class_id]
+            seen = hits + self.cumulative_false_positives[class_id]
             with np.errstate(divide='ignore', invalid='ignore'):
-                cumulative_precisions.append(np.where(tp + fp > 0, tp / (tp + fp), 0))
-                cumulative_recalls.append(tp / self.num_gt_per_class[class_id])
-        self.cumulative_precisions = cumulative_precisions
-        self.cumulative_recalls = cumulative_recalls
+                ratio = hits / seen
+                recalls.append(hits / self.num_gt_per_class[class_id])
+            ratio[seen <= 0] = 0
+            precisions.append(ratio)
+        self.cumulative_precisions, self.cumulative_recalls = precisions, recalls
         if ret:
-            return cumulative_precisions, cumulative_recalls
+            return precisions, recalls
+
+    @staticmethod
+    def _average_precision(precision, recall, mode, num_recall_points):
+        """Average precision of one class from its precision / recall arrays (recall is non-decreasing).  The best precision
+        at recall >= r is a suffix maximum of `precision`, so both Pascal VOC variants are a reversed running maximum plus a
+        sorted search instead of a loop over thresholds / recall levels:
+          'sample'    (pre-2010, reference :829-842): mean over num_recall_points thresholds t of that maximum at the first
+                      position whose recall reaches t (0 when none does), accumulated in threshold order like the reference;
+          'integrate' (post-2010, reference :844-881): sum over the distinct recall levels but the last of
+                      (next level - level) x (best precision from the level's first position up to the last level's first)."""
+        n = len(precision)
+        if n == 0:
+            return 0.0
+        if mode == 'sample' and np.isnan(recall).any():
+            # a class without ground truth boxes: recall is 0/0 until the first hit, so it is not sorted -- the definition itself
+            total = 0.0
+            for t in np.linspace(0, 1, num_recall_points):
+                reached = precision[recall >= t]
+                total += reached.max() if reached.size else 0.0
+            return total / num_recall_points
+        if mode == 'sample':
+            best_from = np.maximum.accumulate(precision[::-1])[::-1]
+            first = np.searchsorted(recall, np.linspace(0, 1, num_recall_points), side='left')
+            total = 0.0
+            for i in first:
+                total += best_from[i] if i < n else 0.0
+            return total / num_recall_points
+        levels, starts = np.unique(recall, return_index=True)
+        best, width = np.zeros_like(levels), np.zeros_like(levels)
+        if len(levels) > 1:
+            head = precision[:starts[-1]]
+            best[:-1] = np.maximum(np.maximum.accumulate(head[::-1])[::-1][starts[:-1]], 0.0)
+            width[:-1] = levels[1:] - levels[:-1]
+        return np.sum(best * width)
 
     def compute_average_precisions(self, mode='sample', num_recall_points=11, verbose=True, ret=False):
         '''Reference :783-884: 'sample' = Pascal VOC pre-2010 k-point sampling, 'integrate' = post-2010 integration.'''
@@ -280,40 +308,21 @@ class Evaluator:
             raise ValueError("Precisions and recalls not available. You must run `compute_precision_recall()` before you call this method.")
         if mode not in {'sample', 'integrate'}:
             raise ValueError("`mode` can be either 'sample' or 'integrate', but received '{}'".format(mode))
-        average_precisions = [0.0]
+        per_class = [0.0]
         for class_id in range(1, self.n_classes + 1):
             if verbose:
                 print("Computing average precision, class {}/{}".format(class_id, self.n_classes))
-            cumulative_precision = self.cumulative_precisions[class_id]
-            cumulative_recall = self.cumulative_recalls[class_id]
-            average_precision = 0.0
-            if len(cumulative_precision) == 0:
-                average_precisions.append(average_precision)
-                continue
-            if mode == 'sample':
-                for t in np.linspace(start=0, stop=1, num=num_recall_points, endpoint=True):
-                    cum_prec_recall_greater_t = cumulative_precision[cumulative_recall >= t]
-                    average_precision += 0.0 if cum_prec_recall_greater_t.size == 0 else np.amax(cum_prec_recall_greater_t)
-                average_precision /= num_recall_points
-            else:
-                unique_recalls, unique_recall_indices, _ = np.unique(cumulative_recall, return_index=True, return_counts=True)
-                maximal_precisions = np.zeros_like(unique_recalls)
-                recall_deltas = np.zeros_like(unique_recalls)
-                for i in range(len(unique_recalls) - 2, -1, -1):
-                    begin, end = unique_recall_indices[i], unique_recall_indices[i + 1]
-                    maximal_precisions[i] = np.maximum(np.amax(cumulative_precision[begin:end]), maximal_precisions[i + 1])
-                    recall_deltas[i] = unique_recalls[i + 1] - unique_recalls[i]
-                average_precision = np.sum(maximal_precisions * recall_deltas)
-            average_precisions.append(average_precision)
-        self.average_precisions = average_precisions
+            per_class.append(self._average_precision(np.asarray(self.cumulative_precisions[class_id], dtype=np.float64),
+                                                     np.asarray(self.cumulative_recalls[class_id], dtype=np.float64), mode,
+                                                     num_recall_points))
+        self.average_precisions = per_class
         if ret:
-            return average_precisions
+            return per_class
 
     def compute_mean_average_precision(self, ret=True):
-        '''Reference :886-899: the mean over the positive classes.'''
+        '''Reference :886-899: the mean over the positive classes (entry 0 is the background dummy).'''
         if self.average_precisions is None:
             raise ValueError("Average precisions not available. You must run `compute_average_precisions()` before you call this method.")
-        mean_average_precision = np.average(self.average_precisions[1:])
-        self.mean_average_precision = mean_average_precision
+        self.mean_average_precision = np.average(self.average_precisions[1:])
         if ret:
-            return mean_average_precision
+            return self.mean_average_precision

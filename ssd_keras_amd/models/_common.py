@@ -111,8 +111,8 @@ class SSDModel(nn.Module):
 
     # Which kernel runs a convolution of the fused path: 'miopen' (F.conv2d + one libssdhip bias/ReLU[/pool] pass) or
     # 'igemm' (libssdhip's implicit-GEMM MFMA kernel with the bias/ReLU epilogue, csrc/ssdhip_conv.hip).  SSDHIP_CONV =
-    # auto (default: time both once per layer shape, keep the faster -- MIOpen's own find does the same among its
-    # solvers), igemm, miopen.
+    # auto (default: time libssdhip's variants once per layer shape, keep the fastest), auto_miopen (MIOpen competes too),
+    # igemm, miopen.
     _conv_choice = {}
 
     @staticmethod
@@ -142,6 +142,16 @@ class SSDModel(nn.Module):
             return "miopen"
         hit = SSDModel._conv_choice.get(key)
         if hit is None:
+            if mode != "auto_miopen" and len(candidates) > 1 and "miopen" in candidates:
+                # Measured on MI355X (profiles/r01*, r02b_bench.json): libssdhip's kernels beat MIOpen + one bias/ReLU pass on every
+                # SSD300 / SSD512 layer, and on shapes where MIOpen has no tuned solver its find step falls back to a naive kernel
+                # (~20 s of probing per process).  MIOpen is only timed when asked for (SSDHIP_CONV=auto_miopen) or when it is the
+                # only candidate.
+                candidates = {k: v for k, v in candidates.items() if k != "miopen"}
+                if len(candidates) == 1:
+                    hit = next(iter(candidates))
+                    SSDModel._conv_choice[key] = hit
+                    return hit
             best, hit = None, None
             # the library candidate goes last: when MIOpen falls back to its naive solver for a shape (tens of ms per call) the
             # single-call probe below drops it without paying for the bursts

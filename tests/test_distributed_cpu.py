@@ -109,3 +109,33 @@ def test_two_rank_ddp_over_the_ssd300_training_model(tmp_path):
     assert outs[0]["missing"] == [] and outs[1]["missing"] == []
     assert outs[0]["n"] == 26285486                                      # SSD300 / 21 classes
     assert torch.equal(outs[0]["grads"], outs[1]["grads"])              # averaged gradients are identical on both ranks
+
+
+def _worker_bn(rank, world, port, tmp):
+    """SSD7 in train mode: BatchNorm running statistics must stay identical on both ranks (rank 0's are broadcast each forward),
+    and the averaged gradient must be the mean of the two per-shard gradients (the documented data-parallel semantics)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env("gloo")
+    model = _build().train()
+    ddp = dp.data_parallel(model, bucket_cap_mb=1)
+    x = torch.from_numpy(np.random.RandomState(5).randint(0, 256, size=(4, 64, 64, 3)).astype(np.float32))
+    lo, hi = dp.shard_range(4, rank, world)
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        _loss(ddp(x[lo:hi])).backward()
+    model.eval()
+    ddp(x[lo:hi])                                                        # buffers are synchronised at the start of a forward
+    bufs = torch.cat([b.detach().float().reshape(-1) for n, b in model.named_buffers() if "num_batches" not in n])
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    torch.save({"bufs": bufs, "grads": grads}, os.path.join(tmp, "b%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_batchnorm_buffers_stay_in_step(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_bn, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "b%d.pt" % r)) for r in range(2)]
+    assert outs[0]["bufs"].numel() > 0 and torch.equal(outs[0]["bufs"], outs[1]["bufs"])       # rank 0's running statistics everywhere
+    assert torch.equal(outs[0]["grads"], outs[1]["grads"])

@@ -235,8 +235,9 @@ def test_entry_points_reject_bad_arguments_before_launching(lib):
 
 
 def test_autotune_keeps_the_fastest_candidate_and_probes_slow_ones_once(monkeypatch):
-    """SSDModel._pick (models/_common.py): best of two bursts per candidate; the library candidate goes last and is dropped
-    after one probe call when that alone is slower than three calls of the best so far."""
+    """SSDModel._pick (models/_common.py): best of two bursts per candidate.  MIOpen competes only under SSDHIP_CONV=auto_miopen
+    (it goes last and is dropped after one probe call when that alone is slower than three calls of the best so far); by default
+    only libssdhip's variants are timed."""
     import time
     import torch
     from ssd_keras_amd.models._common import SSDModel
@@ -256,7 +257,7 @@ def test_autotune_keeps_the_fastest_candidate_and_probes_slow_ones_once(monkeypa
 
     monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
-    monkeypatch.delenv("SSDHIP_CONV", raising=False)
+    monkeypatch.setenv("SSDHIP_CONV", "auto_miopen")
     saved = dict(SSDModel._conv_choice)
     SSDModel._conv_choice.clear()
     try:
@@ -274,6 +275,11 @@ def test_autotune_keeps_the_fastest_candidate_and_probes_slow_ones_once(monkeypa
         calls.clear()
         assert m._pick(("t", 2), {"miopen": cand("miopen", 0.001), "igemm": cand("igemm", 0.003)}) == "miopen"
         assert m._pick(("t", 2), {}) == "miopen"                         # cached per key
+        monkeypatch.delenv("SSDHIP_CONV", raising=False)                 # default: MIOpen is not probed when the library has a kernel
+        calls.clear()
+        assert m._pick(("t", 5), {"miopen": cand("miopen", 0.0001), "igemm": cand("igemm", 0.003), "igemm6": cand("igemm6", 0.001)}) == "igemm6"
+        assert "miopen" not in calls
+        assert m._pick(("t", 6), {"miopen": cand("miopen", 0.0001), "igemm": cand("igemm", 0.003)}) == "igemm" and "miopen" not in calls
         monkeypatch.setenv("SSDHIP_CONV", "igemm")
         assert m._pick(("t", 3), {"miopen": None, "igemm": None}) == "igemm" and m._pick(("t", 4), {"miopen": None}) == "miopen"
     finally:
