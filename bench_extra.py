@@ -336,16 +336,67 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3):
         last["loss"] = loss.detach()
         last.setdefault("first", loss.detach())
 
+    # One GPU: the step is ~600 launches and the eager host loop cannot issue them as fast as the GPU retires them (measured:
+    # 19.8 ms per step eager with 11 ms of kernels, profiles/r02g_train_timeline.json), so forward + loss + backward + SGD are
+    # captured ONCE into a HIP graph (static buffers for the images and the encoder's targets) and replayed; the encoder stays
+    # outside (its labels arrive from the host every step).  With DDP (N > 1) the step stays eager: RCCL's bucketed all-reduce
+    # hooks inside a capture could not be exercised on this single-GPU box.
+    graph = None
+    how = "eager"
+
+    def capture():
+        nonlocal graph
+        y_static, _, _ = enc.encode_to_device(gt, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                                         # warm the allocator / autotune on the capture stream
+            for _ in range(2):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y_pred = ddp(images)
+                loss = lf.compute_loss(y_static, y_pred.float()).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y_pred = ddp(images)
+            loss_static = lf.compute_loss(y_static, y_pred.float()).mean()
+            loss_static.backward()
+            opt.step()
+        graph = (g, y_static, loss_static)
+
+    def graph_step():
+        g, y_static, loss_static = graph
+        y_true, _, _ = enc.encode_to_device(gt, device=dev)
+        y_static.copy_(y_true)
+        g.replay()
+        last["loss"] = loss_static.detach()
+
     with torch.cuda.device(dev):
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
+        run = step
+        if world == 1 and os.environ.get("SSD_TRAIN_GRAPH", "1") == "1":
+            try:
+                capture()
+                for _ in range(2):
+                    graph_step()
+                torch.cuda.synchronize()
+                run, how = graph_step, "hipGraph replay (forward + loss + backward + SGD captured once)"
+            except Exception as exc:                                          # noqa: BLE001 -- fall back to the eager step
+                how = "eager (graph capture failed: %s: %s)" % (type(exc).__name__, str(exc)[:120])
+                torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(steps):
-            step()
+            run()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -354,7 +405,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3):
                         "weights, SGD momentum 0.9; HIP encoder + HIP SSDLoss; %s" % (
                             B, B * world, "DDP/RCCL gradient all-reduce (25 MB buckets)" if world > 1 else "single GPU, no collective"),
             "images_per_sec": round(world * B * steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / steps, 3),
-            "steps": steps, "warmup": warmup, "n_gpus": world, "scaling": "weak", "parameters": n_params,
+            "steps": steps, "warmup": warmup, "n_gpus": world, "scaling": "weak", "parameters": n_params, "launch": how,
             "allreduce_bytes_per_step": 4 * n_params if world > 1 else 0, "first_loss": float(last["first"].item()), "final_loss": float(last["loss"].item()),
             "note": "random He-normal init on 0..255 inputs (no pretrained VGG here): lr 1e-7 keeps the few timed steps finite"}
 

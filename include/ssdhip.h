@@ -244,6 +244,22 @@ int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, co
                                      const void* const* conf_bias_h, const void* const* loc_bias_h,
                                      const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,
                                      int B, int N, int C, float* y_pred, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Training-step glue (csrc/ssdhip_train.hip): the backward of Conv2D(activation='relu') and MaxPooling2D
+ * (models/keras_ssd300.py:274-313; TF graph ops in the reference, ssd300_training.ipynb), bf16 NHWC.
+ *
+ * ssdhip_relu_bwd_bias_nhwc_bf16   out = gy where y > 0 else 0 (threshold_backward) and per-workgroup float32 partial sums of
+ *                                  `out` per channel: partial [n_blocks, C], n_blocks = ssdhip_relu_bwd_bias_blocks(n_pixels, C)
+ *                                  (0: shape not supported -- C / 8 must divide 256); the bias gradient is their sum over axis 0.
+ * ssdhip_maxpool_bwd_nhwc_bf16     gx [B,H,W,C] = gradient of max-pooling (kernel, stride, pad; windows clipped to the map) given its
+ *                                  input x and the gradient gy [B,Ho,Wo,C] of its output: every window's gradient goes to its first
+ *                                  maximum in row-major order (NaN wins), as max_pool2d's backward. */
+int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
+int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, void* out, float* partial, long long n_pixels, int C,
+                                   int n_blocks, void* stream);
+int ssdhip_maxpool_bwd_nhwc_bf16(const void* x, const void* gy, void* gx, int B, int H, int W, int C, int kernel, int stride,
+                                 int pad, int Ho, int Wo, void* stream);
+
 /* The same when a layer's two heads were computed by ONE wider convolution (conf and loc filters concatenated along Cout,
  * padded to the MFMA kernel's 64-channel granularity): conf_h[l] / loc_h[l] point at the first conf / loc channel of pixel 0 and
  * conf_stride_h[l] / loc_stride_h[l] give the number of bf16 elements between consecutive pixels (>= n_boxes*C / n_boxes*4;

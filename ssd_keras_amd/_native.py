@@ -380,6 +380,52 @@ def decode_from_heads(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var
     return out, count, aidx
 
 
+def _train_lib():
+    lib = load()
+    if not getattr(lib, "_train_bound", False):
+        c_int, c_vp, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+        lib.ssdhip_relu_bwd_bias_blocks.restype = c_int
+        lib.ssdhip_relu_bwd_bias_blocks.argtypes = [c_ll, c_int]
+        lib.ssdhip_relu_bwd_bias_nhwc_bf16.restype = c_int
+        lib.ssdhip_relu_bwd_bias_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_vp]
+        lib.ssdhip_maxpool_bwd_nhwc_bf16.restype = c_int
+        lib.ssdhip_maxpool_bwd_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp]
+        lib._train_bound = True
+    return lib
+
+
+def relu_bwd_bias(gy, y):
+    """Backward of `y = relu(conv + bias)` up to the convolution: returns (gy masked by y > 0, bias gradient float32 [C]) in one
+    pass (csrc/ssdhip_train.hip), or None when the channel count is not supported.  gy, y: (B, C, H, W) bf16 with NHWC memory."""
+    torch = _torch()
+    lib = _train_lib()
+    gy, (b, h, w, c) = _nhwc_bf16(gy, "gy")
+    y, _ = _nhwc_bf16(y, "y")
+    nb = lib.ssdhip_relu_bwd_bias_blocks(b * h * w, c)
+    if nb == 0:
+        return None
+    out = torch.empty_like(gy)
+    partial = torch.empty((nb, c), dtype=torch.float32, device=gy.device)
+    with torch.cuda.device(gy.device):
+        rc = lib.ssdhip_relu_bwd_bias_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(out), _ptr(partial), b * h * w, c, nb, current_stream_ptr(gy.device))
+    check(rc, "ssdhip_relu_bwd_bias_nhwc_bf16")
+    return out, partial.sum(dim=0)
+
+
+def maxpool_bwd(x, gy, kernel, stride, pad=0):
+    """Gradient of max_pool2d (windows clipped to the map) with respect to its input: x (B, C, H, W), gy (B, C, Ho, Wo), bf16 NHWC."""
+    torch = _torch()
+    lib = _train_lib()
+    x, (b, h, w, c) = _nhwc_bf16(x, "x")
+    gy, (_, ho, wo, _) = _nhwc_bf16(gy, "gy")
+    gx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_maxpool_bwd_nhwc_bf16(_ptr(x), _ptr(gy), _ptr(gx), b, h, w, c, int(kernel), int(stride), int(pad), ho, wo,
+                                              current_stream_ptr(x.device))
+    check(rc, "ssdhip_maxpool_bwd_nhwc_bf16")
+    return gx
+
+
 def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
     """'same' convolution (kernel 1 or 3, stride 1) + bias + ReLU in ONE libssdhip MFMA kernel (csrc/ssdhip_conv.hip).
     x (B, Cin, H, W) bf16 with NHWC memory; weight (Cout, Cin, k, k) bf16 with channels_last memory; Cin, Cout % 64 == 0."""

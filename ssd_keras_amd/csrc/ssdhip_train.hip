@@ -1,0 +1,150 @@
+// ssdhip_train.hip -- memory-bound glue of the TRAINING step's backward pass on gfx950 (MI355X), bf16 NHWC.
+//
+// The reference trains through Keras/TensorFlow (ssd300_training.ipynb: model.fit_generator with SSDLoss): the backward of
+// Conv2D(activation='relu') and MaxPooling2D (models/keras_ssd300.py:274-313) are TF graph ops.  PyTorch-ROCm runs them as
+// threshold_backward + a bf16 reduction per layer (bias gradient) and max_pool2d_backward; here
+//   * relu_bwd_bias_kernel   ONE pass over (dL/dy, y): writes dL/dy masked by y > 0 (the tensor both convolution gradients consume)
+//                            and per-workgroup float32 partial sums of it per channel (the bias gradient, summed in a fixed order:
+//                            no atomics, bit-reproducible);
+//   * maxpool_bwd_kernel     dL/dx of max-pooling by GATHER: each input pixel recomputes the arg-max of the windows that cover it
+//                            (first maximum in row-major window order, NaN wins: max_pool2d's rule) and sums their gradients --
+//                            deterministic, no atomics, one write per element.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+__device__ __forceinline__ float tb2f(u32 h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ u32 tf2b(float f) {             // round to nearest even, NaN stays NaN (as c10::BFloat16)
+    const u32 u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// gy, y, out: [n_pixels][C] bf16 as uint4 (8 channels); partial: [gridDim.x][C] float32.  cvec = C / 8 divides 256.
+__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const uint4* __restrict__ gy, const uint4* __restrict__ y,
+                                                            uint4* __restrict__ out, float* __restrict__ partial, u32 n_pixels,
+                                                            u32 cvec) {
+    __shared__ float red[256 * 8];
+    const u32 tid = threadIdx.x;
+    const u32 cg = tid % cvec, pl = tid / cvec, ppb = 256u / cvec;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (u32 px = blockIdx.x * ppb + pl; px < n_pixels; px += gridDim.x * ppb) {
+        const size_t i = (size_t)px * cvec + cg;
+        const uint4 g = gy[i], v = y[i];
+        const u32 gw[4] = {g.x, g.y, g.z, g.w}, vw[4] = {v.x, v.y, v.z, v.w};
+        u32 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // threshold_backward(grad, y, 0): zero where y <= 0 (a NaN activation lets the gradient through)
+            const u32 lo = (tb2f(vw[q] & 0xffffu) <= 0.f) ? 0u : (gw[q] & 0xffffu);
+            const u32 hi = (tb2f(vw[q] >> 16) <= 0.f) ? 0u : (gw[q] >> 16);
+            o[q] = lo | (hi << 16);
+            acc[2 * q] += tb2f(lo);
+            acc[2 * q + 1] += tb2f(hi);
+        }
+        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[tid * 8 + q] = acc[q];
+    __syncthreads();
+    if (pl == 0) {                                              // fixed order over the pixel lanes: reproducible sums
+        for (u32 j = 1; j < ppb; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += red[(j * cvec + cg) * 8 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) partial[(size_t)blockIdx.x * cvec * 8 + cg * 8 + q] = acc[q];
+    }
+}
+
+// x: [B,H,W,C] input of the pooling, gy: [B,Ho,Wo,C] gradient of its output, gx: [B,H,W,C].  One thread per (input pixel, 8 channels).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ gy,
+                                                          uint4* __restrict__ gx, int B, int H, int W, u32 cvec, int k, int s, int p,
+                                                          int Ho, int Wo) {
+    const u32 total = (u32)B * H * W * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 cg = i % cvec;
+        u32 t = i / cvec;
+        const int w = t % W; t /= W;
+        const int h = t % H;
+        const int b = t / H;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // windows (oh, ow) with oh*s - p <= h < oh*s - p + k
+        const int oh0 = max((h + p - k + s) / s, 0), oh1 = min((h + p) / s, Ho - 1);
+        const int ow0 = max((w + p - k + s) / s, 0), ow1 = min((w + p) / s, Wo - 1);
+        for (int oh = oh0; oh <= oh1; ++oh)
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const int h0 = max(oh * s - p, 0), h1 = min(oh * s - p + k, H);
+                const int w0 = max(ow * s - p, 0), w1 = min(ow * s - p + k, W);
+                if (h < h0 || h >= h1 || w < w0 || w >= w1) continue;
+                float best[8];
+                int arg[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { best[q] = -__builtin_inff(); arg[q] = -1; }
+                for (int hi = h0; hi < h1; ++hi)
+                    for (int wi = w0; wi < w1; ++wi) {
+                        const uint4 v = x[((size_t)(b * H + hi) * W + wi) * cvec + cg];
+                        const u32 vw[4] = {v.x, v.y, v.z, v.w};
+                        const int pos = hi * W + wi;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float a = tb2f(vw[q] & 0xffffu), c = tb2f(vw[q] >> 16);
+                            if (a > best[2 * q] || a != a) { best[2 * q] = a; arg[2 * q] = pos; }          // max_pool2d: first maximum, NaN wins
+                            if (c > best[2 * q + 1] || c != c) { best[2 * q + 1] = c; arg[2 * q + 1] = pos; }
+                        }
+                    }
+                const uint4 g = gy[((size_t)(b * Ho + oh) * Wo + ow) * cvec + cg];
+                const u32 gw[4] = {g.x, g.y, g.z, g.w};
+                const int me = h * W + w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (arg[2 * q] == me) acc[2 * q] += tb2f(gw[q] & 0xffffu);
+                    if (arg[2 * q + 1] == me) acc[2 * q + 1] += tb2f(gw[q] >> 16);
+                }
+            }
+        gx[i] = make_uint4(tf2b(acc[0]) | (tf2b(acc[1]) << 16), tf2b(acc[2]) | (tf2b(acc[3]) << 16), tf2b(acc[4]) | (tf2b(acc[5]) << 16),
+                           tf2b(acc[6]) | (tf2b(acc[7]) << 16));
+    }
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+extern "C" int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C) {
+    if (n_pixels <= 0 || C <= 0 || C % 8) return 0;
+    const int cvec = C / 8;
+    if (cvec > 256 || (256 % cvec)) return 0;
+    const long long ppb = 256 / cvec;
+    long long blocks = (n_pixels + ppb * 8 - 1) / (ppb * 8);           // >= 8 pixels per pixel lane
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, void* out, float* partial, long long n_pixels, int C,
+                                              int n_blocks, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!gy || !y || !out || !partial || n_pixels <= 0 || n_pixels > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (n_blocks <= 0 || n_blocks != ssdhip_relu_bwd_bias_blocks(n_pixels, C)) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy), static_cast<const uint4*>(y),
+                       static_cast<uint4*>(out), partial, (u32)n_pixels, (u32)(C / 8));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_maxpool_bwd_nhwc_bf16(const void* x, const void* gy, void* gx, int B, int H, int W, int C, int kernel, int stride,
+                                            int pad, int Ho, int Wo, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !gy || !gx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || kernel < 1 || stride < 1 || pad < 0 || pad >= kernel || Ho <= 0 || Wo <= 0)
+        return SSDHIP_E_BADARG;
+    const long long total = (long long)B * H * W * (C / 8);
+    if (total > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint4*>(x),
+                       static_cast<const uint4*>(gy), static_cast<uint4*>(gx), B, H, W, (u32)(C / 8), kernel, stride, pad, Ho, Wo);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

@@ -72,6 +72,73 @@ def resolve_anchor_config(n_predictor_layers, min_scale, max_scale, scales, aspe
     return list(scales), ars, n_boxes, steps, offsets
 
 
+class _ConvBiasActFn(torch.autograd.Function):
+    """A convolution layer of the TRAINING step with libssdhip's MFMA kernel in the forward pass (convolution + bias + ReLU, one
+    kernel, bf16 NHWC -- the same kernels the inference path runs) and PyTorch-ROCm's convolution backward (MIOpen data / weight
+    gradient kernels) behind it.  `run` is the libssdhip thunk picked for this layer shape: (x_bf16, w_bf16, b_bf16) -> y."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu):
+        xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        bb = bias.detach().to(torch.bfloat16) if bias is not None else None
+        y = run(xb, wb, bb)
+        ctx.save_for_backward(xb, wb, y if relu else None)
+        ctx.conf = (stride, padding, dilation, relu, weight.dtype, None if bias is None else bias.dtype, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb, y = ctx.saved_tensors
+        stride, padding, dilation, relu, wdt, bdt, xdt = ctx.conf
+        gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gb = None
+        want_gb = bdt is not None and ctx.needs_input_grad[2]
+        if relu:
+            # ReLU mask and bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the framework pair is the fallback
+            fused = nat.relu_bwd_bias(gy, y)
+            if fused is not None:
+                gy, gb32 = fused
+                gb = gb32.to(bdt) if want_gb else None
+            else:
+                gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        if gb is None and want_gb:
+            gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32).to(bdt)
+        need_x = ctx.needs_input_grad[0]
+        gx = None
+        k = wb.shape[2]
+        same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
+                and wb.shape[0] % 64 == 0 and wb.shape[1] % 64 == 0 and k in (1, 3))
+        if need_x and same:
+            # the data gradient of a stride-1 'same' convolution IS a 'same' convolution of dL/dy with the filters transposed
+            # (Cin <-> Cout) and their taps flipped: the forward's MFMA kernel runs it, no bias, no activation
+            wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+            gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False)
+        masks = [need_x and gx is None, True, False]
+        gx_m, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
+                                                          masks)
+        if gx is None:
+            gx = gx_m
+        return (gx.to(xdt) if need_x else None), gw.to(wdt), gb, None, None, None, None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """max_pool2d of a bf16 NHWC map in the training step: libssdhip forward (one pass) and backward (gather, deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, stride, pad, ceil_mode):
+        y = nat.bias_act_maxpool(x, None, kernel, stride, pad, ceil_mode, relu=False)
+        ctx.save_for_backward(x)
+        ctx.conf = (kernel, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        kernel, stride, pad = ctx.conf
+        return nat.maxpool_bwd(x, gy.to(torch.bfloat16), kernel, stride, pad), None, None, None, None
+
+
 class SSDModel(nn.Module):
     """Base class: subclasses define `features(x) -> list of predictor feature maps` plus
     `conf_heads`, `loc_heads` (ModuleLists) and `priorboxes` (ModuleList of AnchorBoxes)."""
@@ -89,6 +156,7 @@ class SSDModel(nn.Module):
         self.divide_by_stddev = divide_by_stddev
         self.swap_channels = swap_channels
         self.fused_inference = True         # bf16 + no_grad on a GPU: graph glue runs in libssdhip (csrc/ssdhip_layers.hip)
+        self.fused_training = True          # grad mode on a GPU in bf16 (autocast): convolution forwards run in libssdhip too
         self.decoder = None
         if mode != 'training':
             layer = DecodeDetections if mode == 'inference' else DecodeDetectionsFast
@@ -199,8 +267,49 @@ class SSDModel(nn.Module):
             name = (self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu, conv.stride[0], conv.padding[0]), cands)
                     if len(cands) > 1 else "miopen")
             return cands[name]()
+        if self._fused_train(x, conv):
+            run, _name = self._train_thunk(conv, x, relu)
+            if run is not None:
+                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu)
         y = conv(x)
         return F.relu(y) if relu else y
+
+    # -- training step: the forward of every convolution libssdhip has a kernel for runs there (under autograd, see
+    #    _ConvBiasActFn); pooling stays a separate PyTorch op because its backward needs the pre-pool activation ---------------
+    def _fused_train(self, x, conv):
+        return (self.fused_training and x.is_cuda and torch.is_grad_enabled() and conv.bias is not None and conv.groups == 1
+                and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
+
+    def _train_thunk(self, conv, x, relu):
+        """The libssdhip kernel for this layer as `(x_bf16, w_bf16, b_bf16) -> y`, or (None, None).  The variant is the one the
+        per-shape autotune keeps (same keys as the inference path)."""
+        k = conv.kernel_size[0]
+        d = conv.dilation[0]
+        if (conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                and conv.padding == (1, 1) and conv.dilation == (1, 1)):
+            return (lambda xb, wb, bb: nat.conv3x3_cin3(xb, wb, bb, relu=relu)), "cin3"
+        if self._igemm_ok(conv, x):
+            cands = {"igemm": lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=d, relu=relu),
+                     "igemm6": lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=d, relu=relu, variant=6)}
+            if conv.in_channels == 64 and k == 3 and d == 1:
+                cands["c64"] = lambda xb, wb, bb: nat.conv3x3_c64(xb, wb, bb, relu=relu, pool=False)
+        elif self._igemm_general_ok(conv, x):
+            cands = {"igemm": lambda xb, wb, bb: nat.conv2d(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
+                                                            relu=relu)}
+        else:
+            return None, None
+        if len(cands) == 1:
+            name = "igemm"
+        else:
+            with torch.no_grad():
+                xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                wb = conv.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                bb = conv.bias.detach().to(torch.bfloat16)
+                name = self._pick(("act", tuple(x.shape), conv.out_channels, k, d, relu, conv.stride[0], conv.padding[0]),
+                                  {n: (lambda fn=fn: fn(xb, wb, bb)) for n, fn in cands.items()})
+            if name not in cands:
+                name = "igemm"
+        return cands[name], name
 
     def conv_act_pool(self, conv, x, kernel, stride, pad=0, ceil_mode=False):
         if self._fused(x, conv):
@@ -221,11 +330,14 @@ class SSDModel(nn.Module):
             name = (self._pick(("pool", tuple(x.shape), conv.out_channels, conv.kernel_size[0], conv.dilation[0], kernel, stride, pad),
                                cands) if len(cands) > 1 else "miopen")
             return cands[name]()
-        return F.max_pool2d(F.relu(conv(x)), kernel, stride, pad, ceil_mode=ceil_mode)
+        return self.max_pool(self.conv_act(conv, x, relu=True), kernel, stride, pad, ceil_mode=ceil_mode)
 
     def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):
         if self._fused(x) and x.shape[1] % 8 == 0:
             return nat.bias_act_maxpool(x, None, kernel, stride, pad, ceil_mode, relu=False)
+        if (self.fused_training and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and x.shape[1] % 8 == 0
+                and x.requires_grad):
+            return _MaxPoolFn.apply(x, kernel, stride, pad, ceil_mode)
         return F.max_pool2d(x, kernel, stride, pad, ceil_mode=ceil_mode)
 
     # -- in-graph input pipeline (keras_ssd300.py:247-272): NHWC 0..255 -> normalised NCHW (channels_last memory) --
@@ -242,13 +354,23 @@ class SSDModel(nn.Module):
         if nhwc:
             x = x.permute(0, 3, 1, 2)                # NHWC storage == channels_last NCHW: no copy
         x = x.float()
+        # the per-channel constants live on the device (built once): nothing crosses PCIe per call, and the step can be captured
+        # into a HIP graph (a host -> device copy is not allowed while a stream is capturing)
         if self.subtract_mean is not None:
-            x = x - torch.as_tensor(self.subtract_mean, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+            x = x - self._device_const("mean", x.device, lambda: torch.as_tensor(self.subtract_mean, dtype=torch.float32).view(1, -1, 1, 1))
         if self.divide_by_stddev is not None:
-            x = x / torch.as_tensor(self.divide_by_stddev, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+            x = x / self._device_const("std", x.device, lambda: torch.as_tensor(self.divide_by_stddev, dtype=torch.float32).view(1, -1, 1, 1))
         if self.swap_channels:
-            x = x[:, list(self.swap_channels)]
+            x = x.index_select(1, self._device_const("swap", x.device, lambda: torch.as_tensor(list(self.swap_channels), dtype=torch.long)))
         return x.contiguous(memory_format=torch.channels_last)
+
+    def _device_const(self, name, device, build):
+        key = ("const", name, str(device))
+        t = self._anchor_cache.get(key)
+        if t is None:
+            t = build().to(device)
+            self._anchor_cache[key] = t
+        return t
 
     def anchors_and_variances(self, feature_sizes, device):
         """(N, 8) float32 constant, resident per device."""

@@ -104,3 +104,45 @@ def test_ssd512_coco_shape_inference_config4():
     # the two forward passes agree up to MIOpen's non-deterministic split-K extras: same number of detections within a few rows
     n_a, n_b = int((got[:, :, 1] > 0).sum()), int((fused[:, :, 1] > 0).sum().item())
     assert n_a > 0 and abs(n_a - n_b) <= max(4, n_a // 20)
+
+
+def test_training_forward_through_libssdhip_matches_the_framework_path():
+    """The training step's convolution forwards run in libssdhip under autograd (models/_common.py _ConvBiasActFn: MFMA forward with
+    the bias / ReLU epilogue, MIOpen backward).  Against the same model on the plain PyTorch-ROCm path (bf16 autocast): predictions
+    and every parameter gradient agree within bf16 rounding noise of a 20-layer network."""
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(7)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"]).cuda()
+    model = model.to(memory_format=torch.channels_last).train()
+    with torch.no_grad():                                                # He-init on 0..255 inputs saturates the softmax: tame the heads
+        for head in list(model.conf_heads) + list(model.loc_heads):
+            head.weight.mul_(1e-3)
+    images = torch.from_numpy(np.random.RandomState(3).randint(0, 256, size=(4, 300, 300, 3)).astype(np.float32)).cuda()
+    w = torch.randn(4, 8732, 25, device="cuda")                       # a fixed linear functional of the class + offset columns
+
+    def run(fused, autocast=True):
+        model.fused_training = fused
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            pred = model(images)
+        (pred[:, :, :25].float() * w).sum().backward()
+        return pred.detach().float(), [p.grad.detach().float().clone() for p in model.parameters()]
+
+    p_f32, g_f32 = run(False, autocast=False)                            # the float32 model: what both bf16 paths approximate
+    p_ref, g_ref = run(False)
+    p_new, g_new = run(True)
+    assert p_new.shape == (4, 8732, 33)
+    assert torch.equal(p_new[:, :, -8:], p_ref[:, :, -8:])               # anchors and variances
+    err = lambda g: max(float((a - b).norm() / (b.norm() + 1e-12)) for a, b in zip(g, g_f32))
+    e_ref, e_new = err(g_ref), err(g_new)
+    dp_ref, dp_new = float((p_ref - p_f32)[:, :, :25].abs().max()), float((p_new - p_f32)[:, :, :25].abs().max())
+    print("training forward parity vs float32: predictions %.4g (framework bf16 path %.4g), worst parameter gradient %.4g (%.4g)" % (
+        dp_new, dp_ref, e_new, e_ref))
+    # ReLU masks flip where bf16 rounding moves an activation across zero, so two bf16 runs of a 20-layer network differ by tens of
+    # percent in the early layers' gradients; the bar is the framework's own bf16 path measured against float32
+    assert dp_new <= 1.5 * dp_ref + 1e-3
+    assert e_new <= 1.5 * e_ref + 1e-3
+    assert all(torch.isfinite(g).all() for g in g_new)

@@ -1,0 +1,72 @@
+"""Training-step glue kernels (csrc/ssdhip_train.hip) and the convolution data gradient through the forward's MFMA kernel, against
+PyTorch-ROCm's own backward ops on the same tensors.  Needs an MI355X.
+
+Bars: ReLU mask bit exact, bias gradient within float32 summation-order noise (rtol 1e-5); max-pool gradient bit exact (same arg-max
+rule, bf16 sums of at most nine bf16 terms accumulated in float32); data gradient within one bf16 rounding of a float32-accumulated
+sum (the tests/test_conv_gpu.py bar)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from ssd_keras_amd import _native as nat
+    return torch, nat
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 37, 41), (2, 512, 19, 19), (3, 1024, 5, 5), (1, 128, 1, 1)])
+def test_relu_backward_and_bias_gradient(shape):
+    torch, nat = _t()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    y = torch.randn(shape, device="cuda", generator=g).clamp_min(0).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.permute(0, 2, 3, 1).reshape(-1)[::97] = float("nan")              # (a view: the memory is NHWC)
+    gy = torch.randn(shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out, gb = nat.relu_bwd_bias(gy, y)
+    want = torch.ops.aten.threshold_backward(gy, y, 0)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    torch.testing.assert_close(gb, want.float().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+    out2, gb2 = nat.relu_bwd_bias(gy, y)
+    assert torch.equal(gb, gb2)                                           # fixed summation order: reproducible
+
+
+def test_relu_backward_unsupported_channel_count_falls_back():
+    torch, nat = _t()
+    y = torch.zeros((1, 24, 3, 3), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert nat.relu_bwd_bias(y, y) is None                                # C / 8 = 3 does not divide 256: the caller uses the framework ops
+
+
+@pytest.mark.parametrize("shape,k,s,p,ceil", [((2, 64, 75, 75), 2, 2, 0, True), ((2, 64, 38, 38), 2, 2, 0, True), ((3, 128, 19, 19), 3, 1, 1, False),
+                                              ((1, 8, 7, 5), 3, 2, 1, True), ((2, 16, 300, 300), 2, 2, 0, True)])
+def test_maxpool_backward_matches_pytorch(shape, k, s, p, ceil):
+    torch, nat = _t()
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(shape, device="cuda", generator=g).clamp_min(0)       # post-ReLU map: many exact ties at 0
+    x = (x * 4).round() / 4                                               # and ties among positive values
+    x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+    gy = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    (want,) = torch.autograd.grad(y, x, gy)
+    got = nat.maxpool_bwd(x.detach(), gy, k, s, p)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got.float(), want.float(), rtol=2 ** -7, atol=1e-6)
+    if s == k:                                                            # disjoint windows: one term per element, no rounding at all
+        assert torch.equal(got.view(torch.int16), want.contiguous(memory_format=torch.channels_last).view(torch.int16))
+
+
+@pytest.mark.parametrize("cin,cout,k,d,hw", [(64, 64, 3, 1, 40), (128, 256, 3, 1, 38), (512, 1024, 3, 6, 19), (1024, 256, 1, 1, 19)])
+def test_data_gradient_through_the_forward_kernel(cin, cout, k, d, hw):
+    torch, nat = _t()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = (torch.randn((cout, cin, k, k), device="cuda", generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(torch.bfloat16)
+    w = w.contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((2, cout, hw, hw), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+    got = nat.conv2d_same(gy, wt, None, dilation=d, relu=False).float()
+    want = torch.nn.grad.conv2d_input((2, cin, hw, hw), w.float(), gy.float(), stride=1, padding=d * (k // 2), dilation=d)
+    err = (got - want).abs()
+    bound = 2.0 ** -7 * want.abs() + 1e-2 * want.pow(2).mean().sqrt()
+    assert bool((err <= bound).all()), float((err - bound).max())
