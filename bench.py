@@ -290,6 +290,14 @@ def main():
             extra["evaluator"] = bx.evaluator_leg(dev, with_cpu)
         if args.train_steps > 0:
             tr = bx.train_leg(dev, rank, world, B, steps=args.train_steps, warmup=3)
+            if isinstance(tr, dict) and "miopen" in str(tr.get("error", "")).lower():
+                # MIOpen's benchmark (find) mode intermittently rejects a problem with miopenStatusBadParm on this stack (seen on
+                # the training step's framework convolutions): one retry on its default heuristics
+                torch.backends.cudnn.benchmark = False
+                torch.cuda.synchronize()
+                tr = bx.train_leg(dev, rank, world, B, steps=args.train_steps, warmup=3)
+                if isinstance(tr, dict):
+                    tr["note_miopen"] = "retried with torch.backends.cudnn.benchmark = False after a miopenStatusBadParm in find mode"
             if rank == 0:
                 extra["train_step"] = tr
 

@@ -59,14 +59,22 @@ def encoder_leg(dev, B, with_cpu=True):
         torch.cuda.synchronize()
         wall_ms = 1e3 * (time.perf_counter() - t) / reps                      # host CSR packing + H2D of the labels + kernels
         ev_ms = _events_ms(lambda: enc.encode_to_device(gt, device=dev), reps)
+        # the kernels alone: the same labels already on the device in CSR form (encode_packed: no host packing, no upload)
+        gt_np, off_np, max_g = enc._pack_ground_truth(gt)
+        gt_d, off_d = torch.from_numpy(gt_np).to(dev), torch.from_numpy(off_np).to(dev)
+        enc.encode_packed(gt_d, off_d, gt_np.shape[0], max_g, B)
+        torch.cuda.synchronize()
+        kern_ms = _events_ms(lambda: enc.encode_packed(gt_d, off_d, gt_np.shape[0], max_g, B), 50)
     N, L = y32.shape[1], y32.shape[2]
     algo = B * N * L * 4 + sum(g.shape[0] for g in gt) * 5 * 8                # f32 targets written + labels read
     out = {"workload": "SSD300/VOC targets, batch %d, 1-8 GT boxes/img, multi matching, f32 output" % B,
            "gpu_ms_per_batch_wall": round(wall_ms, 4), "gpu_ms_per_batch_stream": round(ev_ms, 4),
-           "gpu_ms_per_img": round(wall_ms / B, 5),
-           "roofline": {"kernel": "finalize_kernel (E3) + iou_kernel (E1)", "bound": "hbm",
-                        "algorithmic_bytes": algo, "achieved": round(algo / (ev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(algo / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+           "gpu_ms_per_batch_kernels": round(kern_ms, 4), "gpu_ms_per_img": round(wall_ms / B, 5),
+           "note": "wall / stream include the host side of SSDInputEncoder (CSR packing of the label list, checks, one upload), which "
+                   "bounds a call at ~0.09 ms; `kernels` = encode_packed on device-resident labels (match_kernel + finalize_kernel)",
+           "roofline": {"kernel": "match_kernel + finalize_kernel<float>", "bound": "hbm",
+                        "algorithmic_bytes": algo, "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
     if with_cpu:
         with np.errstate(invalid="ignore", divide="ignore"):
             ora(gt[:2])

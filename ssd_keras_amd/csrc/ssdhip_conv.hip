@@ -503,192 +503,6 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// v9: the v4 tile and pipeline with EIGHT waves per workgroup: waves 0-3 multiply k16 slices 0-1 of every K-step, waves 4-7
-// slices 2-3 (each still a 64-channel x 64-pixel tile; the two partial accumulators are added through LDS once, after the
-// K loop).  Why: every counter of v4 sits at ~40 % (MFMA busy, L2 -> LDS bytes, LDS cycles) and reordering its phases moves
-// nothing -- it is short of waves to overlap, and LDS (64 KB per workgroup) caps it at two workgroups = 8 waves per CU.  Splitting a
-// step's 16 MFMAs over two waves doubles the waves per CU (16, four per SIMD) on the SAME LDS footprint and halves each
-// wave's loads, fragment reads and fragment registers.  RESULT (MI355X): 3-4 % SLOWER than v4 on every VGG shape -- occupancy is
-// not what v4 lacks either.  A timing-only diagnostic that skipped two of every three activation-tile loads (-33 % of the
-// global -> LDS bytes) ran 6-11 % faster: the LDS-DMA byte rate is one contributor among several balanced ones (MFMA busy,
-// L2 -> LDS bytes and LDS cycles all sit near 40 %).  Kept as variant 9 for A/B timing.
-// ---------------------------------------------------------------------------------------------------------------------
-
-template <int BC>
-__device__ __forceinline__ void conv_igemm9_body(const ConvParams& p, unsigned char* lds, const int id) {
-    constexpr int CI = BC / 64;
-    constexpr int XBYTES = CONV_BP * 128, WBYTES = BC * 128, BUF = XBYTES + WBYTES;
-    constexpr int XP = 2, WP = BC / 64;               // 1 KiB pieces per wave per step: 16 X pieces + BC/8 W pieces over 8 waves
-    constexpr unsigned OOB = 0x80000000u;
-
-    const int xcd = id & 7, slot = id >> 3;
-    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
-    if (mt >= p.m_tiles) return;
-    const int m0 = mt * CONV_BP, co0 = nt * BC;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
-    const int grp = wave >> 2, w4 = wave & 3;                          // K half, tile quadrant
-    const int wc = w4 >> 1, wp = w4 & 1;
-    const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
-    const int csteps = Cin / CONV_BK, T = KK * csteps;
-
-    const int neg = (half * dil * p.W + half * dil) * Cin * 2;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.M * Cin * 2 + 2 * neg, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.w)), 0, p.Cout * KK * Cin * 2, 0x00020000);
-
-    u32 xoff[XP], xok[XP], woff[WP];
-    const int pos = lane & 7;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3);
-        const int j = pos ^ ((row >> 1) & 7);
-        const int m = m0 + row;
-        const int wq = m % p.W, hq = (m / p.W) % p.H;
-        u32 rmask = 0, cmask = 0;
-        for (int k = 0; k < KS; ++k) {
-            const int d = (k - half) * dil;
-            if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
-            if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
-        }
-        u32 ok = 0;
-        if (m < p.M)
-            for (int kh = 0; kh < KS; ++kh)
-                if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
-        xok[i] = ok;
-        xoff[i] = (u32)m * (u32)(Cin * 2) + (u32)(j * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3);
-        const int j = pos ^ ((row >> 1) & 7);
-        woff[i] = (u32)(co0 + row) * (u32)(KK * Cin * 2) + (u32)(j * 16);
-    }
-
-    int n_kh = 0, n_kw = 0, n_cs = 0;
-    auto issue = [&](int buf) {
-        const int t = n_kh * KS + n_kw;
-        const int soff_x = neg + (((n_kh - half) * dil * p.W + (n_kw - half) * dil) * Cin + n_cs * CONV_BK) * 2;
-        const int soff_w = (t * Cin + n_cs * CONV_BK) * 2;
-        const u32 tapbit = 1u << t;
-        unsigned char* xb = lds + buf * BUF + wave * 1024;
-        unsigned char* wb = xb + XBYTES;
-#pragma unroll
-        for (int i = 0; i < XP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xb + i * 8192), 16, (xok[i] & tapbit) ? xoff[i] : OOB, soff_x, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wb + i * 8192), 16, woff[i], soff_w, 0, 0);
-        if (++n_kw == KS) { n_kw = 0; if (++n_kh == KS) { n_kh = 0; ++n_cs; } }
-    };
-
-    f32x16 acc[CI][2];
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
-
-    const int r31 = lane & 31, khalf = lane >> 5;
-    const int swz = (r31 >> 1) & 7;
-    const int arow = (wc * (BC / 2) + r31) * 128, brow = (wp * 64 + r31) * 128;
-    int choff[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) choff[kk] = ((2 * (2 * grp + kk) + khalf) ^ swz) << 4;
-
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s = 0; s < T; ++s) {
-        const unsigned char* xb = lds + (s & 1) * BUF;
-        const unsigned char* wb = xb + XBYTES;
-        bf16x8 a[2][CI], b[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci) a[kk][ci] = *reinterpret_cast<const bf16x8*>(wb + arow + ci * 4096 + choff[kk]);
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi) b[kk][pi] = *reinterpret_cast<const bf16x8*>(xb + brow + pi * 4096 + choff[kk]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < T) issue((s + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-                for (int pi = 0; pi < 2; ++pi)
-                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][ci], b[kk][pi], acc[ci][pi], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // ---- add the two K halves: waves 4-7 park their accumulators in LDS (lane-major: conflict-free), waves 0-3 add them ------
-    float* red = reinterpret_cast<float*>(lds) + (size_t)w4 * (CI * 2 * 16 * 64);
-    if (grp == 1) {
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) red[((ci * 2 + pi) * 16 + v) * 64 + lane] = acc[ci][pi][v];
-    }
-    __syncthreads();
-    if (grp == 1) return;
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[ci][pi][v] += red[((ci * 2 + pi) * 16 + v) * 64 + lane];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of `red` are done before its region becomes the stage
-
-    // ---- epilogue of v4; the stage (= this wave's own `red` region) is wave-private, so no block barrier is needed ------------
-    constexpr int ROWB = 64 * CI;
-    unsigned char* stage = reinterpret_cast<unsigned char*>(red);
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        const int px = pi * 32 + r31;
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
-                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
-                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
-                }
-                u32 o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[ci][pi][4 * g + q] + bv[q];
-                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
-                    o[q] = f2bf_rn(v);
-                }
-                const int chunk = ci * 4 + g;
-                *reinterpret_cast<uint2*>(stage + px * ROWB + ((chunk ^ (px & (4 * CI - 1))) << 4) + khalf * 8) =
-                    make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    constexpr int CPR = 4 * CI;
-#pragma unroll
-    for (int j = 0; j < CPR; ++j) {
-        const int idx = j * 64 + lane, px = idx / CPR, c = idx % CPR;
-        const int m = m0 + wp * 64 + px;
-        if (m < p.M)
-            *reinterpret_cast<uint4*>(p.y + (size_t)m * p.Cout + co0 + wc * (BC / 2) + c * 8) =
-                *reinterpret_cast<const uint4*>(stage + px * ROWB + ((c ^ (px & (CPR - 1))) << 4));
-    }
-}
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <int BC>
@@ -696,14 +510,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
     conv_igemm4_body<BC, false>(p, lds, (int)blockIdx.x);
-#endif
-}
-
-template <int BC>
-__global__ __launch_bounds__(512, 4) void conv_igemm9_kernel(ConvParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
-    conv_igemm9_body<BC>(p, lds, (int)blockIdx.x);
 #endif
 }
 
@@ -948,179 +754,6 @@ __global__ __launch_bounds__(CONV_THREADS, (NS >= 4 ? 2 : 3)) void conv_igemm5_k
 
 
 // =================================================================================================================
-// v3: 256-pixel tile, 8 waves, three-stage weight pipeline, kw-reuse of the activation strip.
-//   * tile = BC channels x 256 consecutive pixels; 8 waves as 2 (channels) x 4 (pixels), each 32*CI x 64.
-//   * a GROUP is (kh, 64-channel slice): the strip of 256 + 2*dil pixel rows [m0 - dil, m0 + 256 + dil) shifted by
-//     (kh-1)*dil image rows is loaded ONCE and serves the three taps kw = 0,1,2 (tap kw reads strip row p + kw*dil);
-//     pixels whose tap leaves the image are zeroed in registers (v_cndmask on the B fragment) -- X traffic / 3.
-//   * weights: one [BC][64] tile per tap, three LDS buffers; loads of step s+2 are issued before step s is multiplied
-//     and only a COUNTED s_waitcnt vmcnt(n) + raw s_barrier closes the step, so two tiles stay in flight across the
-//     barrier (__syncthreads() would drain them).  LDS: 2 x 40 KB strips + 3 x BC*128 B = 128 KB at BC = 128, one
-//     workgroup (8 waves) per CU.
-// =================================================================================================================
-constexpr int C3_BP = 256, C3_THREADS = 512, C3_STRIP_ROWS = 320;     // 5 wave-instructions of 8 rows per wave
-
-
-template <int BC>
-__global__ __launch_bounds__(C3_THREADS) void conv_igemm3_kernel(ConvParams p) {
-    constexpr int CI = BC / 64, NW = BC / 64;         // 32-channel MFMA tiles per wave; weight glds per thread per step
-    constexpr int XBYTES = C3_STRIP_ROWS * 128, WBYTES = BC * 128;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * XBYTES + 3 * WBYTES];
-
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
-    if (mt >= p.m_tiles) return;
-    const int m0 = mt * C3_BP, co0 = nt * BC;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave >> 2, wp = wave & 3;
-    const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
-    const int hdil = half * dil;                      // halo rows on each side of the strip (0 for 1x1)
-    const int csteps = Cin / CONV_BK, G = KS * csteps, T = G * KS;
-
-    // ---- load descriptors -------------------------------------------------------------------------------------
-    const int pos = tid & 7;
-    const int jch = (pos ^ ((tid >> 4) & 7)) * 8;     // source chunk (in elements) for LDS slot (row, pos): j = pos ^ ((row>>1)&7)
-    const long gq0 = (long)m0 - hdil + (tid >> 3);    // flattened pixel of strip row q_i = i*64 + (tid>>3), before the kh shift
-    const bf16_t* wsrc[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) wsrc[i] = p.w + (size_t)(co0 + i * 64 + (tid >> 3)) * KK * Cin + jch;
-    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_block);
-    unsigned char* const xlds = lds;
-    unsigned char* const wlds = lds + 2 * XBYTES;
-
-    auto issue_x = [&](int g) {
-        const int kh = g / csteps, c0 = (g - kh * csteps) * CONV_BK;
-        const long vshift = (long)(kh - half) * dil * p.W;
-        unsigned char* dst = xlds + (g & 1) * XBYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const long gp = gq0 + i * 64 + vshift;
-            const bool in = gp >= 0 && gp < (long)p.M && (i < 4 || (tid >> 3) < 2 * hdil);
-            glds16(in ? p.x + gp * Cin + c0 + jch : zsrc, dst + i * 8192);
-        }
-    };
-    auto issue_w = [&](int s) {
-        const int g = s / KS, kw = s - g * KS;
-        const int kh = g / csteps, c0 = (g - kh * csteps) * CONV_BK;
-        const long woff = (long)(kh * KS + kw) * Cin + c0;
-        unsigned char* dst = wlds + (s % 3) * WBYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) glds16(wsrc[i] + woff, dst + i * 8192);
-    };
-
-    // ---- which taps are inside the image for the two pixels whose B fragments this lane reads -----------------------
-    const int r31 = lane & 31, khalf = lane >> 5;
-    u32 okb[2];
-    {
-        int m = m0 + wp * 64 + r31;
-        int wq = m % p.W, hq = (m / p.W) % p.H;
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            u32 rmask = 0, cmask = 0;
-            for (int k = 0; k < KS; ++k) {
-                const int d = (k - half) * dil;
-                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
-                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
-            }
-            u32 ok = 0;
-            if (m < p.M)
-                for (int kh = 0; kh < KS; ++kh)
-                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
-            okb[pi] = ok;
-            m += 32;
-            wq += 32;
-            while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
-        }
-    }
-
-    f32x16 acc[CI][2];
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
-
-    const int aswz = (r31 >> 1) & 7;                  // weight rows: tile-row bases are multiples of 32
-
-    issue_x(0);
-    issue_w(0);
-    if (T > 1) { issue_w(1); wait_vmcnt<NW>(); } else { wait_vmcnt<0>(); }
-    __builtin_amdgcn_s_barrier();
-
-    for (int s = 0; s < T; ++s) {
-        const int g = s / KS, kw = s - g * KS;
-        const bool do_x = (kw == 0) && (g + 1 < G);
-        const bool do_w = s + 2 < T;
-        if (do_x) issue_x(g + 1);
-        if (do_w) issue_w(s + 2);
-
-        const unsigned char* xb = xlds + (g & 1) * XBYTES;
-        const unsigned char* wb = wlds + (s % 3) * WBYTES;
-        const int tap = (g / csteps) * KS + kw;
-        const int q0 = wp * 64 + r31 + kw * dil;      // strip row of this lane's first pixel for this tap
-        const int q1 = q0 + 32;
-        const int bswz0 = (q0 >> 1) & 7, bswz1 = (q1 >> 1) & 7;
-        const bool ok0 = (okb[0] >> tap) & 1u, ok1 = (okb[1] >> tap) & 1u;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ch = 2 * kk + khalf;
-            bf16x8 a[CI], b[2];
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci)
-                a[ci] = *reinterpret_cast<const bf16x8*>(wb + (wc * (BC / 2) + ci * 32 + r31) * 128 + ((ch ^ aswz) << 4));
-            uint4 b0 = *reinterpret_cast<const uint4*>(xb + q0 * 128 + ((ch ^ bswz0) << 4));
-            uint4 b1 = *reinterpret_cast<const uint4*>(xb + q1 * 128 + ((ch ^ bswz1) << 4));
-            if (!ok0) b0 = make_uint4(0, 0, 0, 0);
-            if (!ok1) b1 = make_uint4(0, 0, 0, 0);
-            b[0] = __builtin_bit_cast(bf16x8, b0);
-            b[1] = __builtin_bit_cast(bf16x8, b1);
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-                for (int pi = 0; pi < 2; ++pi) acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ci], b[pi], acc[ci][pi], 0, 0, 0);
-        }
-        // everything older than what this iteration issued has landed: W(s+1) and, after kw = 1, the next strip
-        const bool x_flies = do_x && KS > 1;          // 1x1: the strip issued now is needed by the very next step
-        if (x_flies && do_w) wait_vmcnt<5 + NW>();
-        else if (x_flies) wait_vmcnt<5>();
-        else if (do_w) wait_vmcnt<NW>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // ---- epilogue: D row = channel (v&3) + 8*(v>>2) + 4*(lane>>5), column = pixel lane&31 ------------------------
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        const int m = m0 + wp * 64 + pi * 32 + r31;
-        if (m >= p.M) continue;
-        bf16_t* yrow = p.y + (size_t)m * p.Cout;
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * gq + 4 * khalf;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ch);
-                    bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
-                    bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
-                }
-                u32 o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[ci][pi][4 * gq + q] + bv[q];
-                    if (p.relu) v = v > 0.f ? v : (v != v ? v : 0.f);
-                    o[q] = f2bf_rn(v);
-                }
-                *reinterpret_cast<uint2*>(yrow + ch) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-            }
-    }
-}
-
-
-// =================================================================================================================
 // First layer: 3x3 'same' convolution of a 3-channel image into 64 channels (+ bias + ReLU), conv1_1 of
 // models/keras_ssd300.py:274.  K = 27 is far too shallow for the implicit-GEMM kernel (MIOpen's generic kernel takes
 // 155 us + 148 us of bias/ReLU passes at batch 32); the op is bound by WRITING the 64-channel map (368 MB at batch 32).
@@ -1309,26 +942,16 @@ static int conv_run(int variant, const void* x, const void* weight, const void* 
             if (wide) hipLaunchKernelGGL((conv_igemm5_kernel<128, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
             else hipLaunchKernelGGL((conv_igemm5_kernel<64, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
         }
-    } else if (variant == 9 && small) {       // 8 waves per workgroup, the step's MFMAs split over two wave groups
-        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
-        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
-        if (wide) hipLaunchKernelGGL(conv_igemm9_kernel<128>, dim3(grid), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(conv_igemm9_kernel<64>, dim3(grid), dim3(512), 0, stream, p);
     } else if (variant == 4) {                // v1's tile with buffer-addressed LDS-DMA and batched fragment reads
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
         if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
         else hipLaunchKernelGGL(conv_igemm4_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
-    } else if (variant == 1) {                // 128-pixel tile, two-stage pipeline (kept for A/B timing)
+    } else {                                  // variant 1: per-lane 64-bit addressing, the fallback for tensors beyond 2 GiB
         p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
         const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
         if (wide) hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
         else hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
-    } else {
-        p.m_tiles = (int)((M + C3_BP - 1) / C3_BP);
-        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
-        if (wide) hipLaunchKernelGGL(conv_igemm3_kernel<128>, dim3(grid), dim3(C3_THREADS), 0, stream, p);
-        else hipLaunchKernelGGL(conv_igemm3_kernel<64>, dim3(grid), dim3(C3_THREADS), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
@@ -1381,7 +1004,7 @@ extern "C" int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const 
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
-    if (variant != 1 && variant != 3 && variant != 4 && variant != 5 && variant != 6 && variant != 9) return SSDHIP_E_BADARG;
+    if (variant != 1 && variant != 4 && variant != 5 && variant != 6) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }
 

@@ -6,16 +6,13 @@
 // Everything is float64 in the reference's operation order (compiled with -ffp-contract=off), so the match
 // assignment is bit exact; only log() may differ from NumPy's in the last place.
 //
-// Three kernels, all on the caller's stream:
-//   E1 iou_kernel      grid (anchor tiles, B): IoU of the tile's anchors with the image's ground truth boxes
-//                      -> sim[G_total][N] (coalesced rows) + each tile's best (value, first column) per GT row.
-//   E2 bipartite_kernel grid (B): the g sequential rounds of match_bipartite_greedy for one image.  The matrix is
-//                      never copied or modified: removed rows / columns are flags in LDS, a row's maximum is only
-//                      re-scanned when the column it pointed to was just taken.  Quirks kept: an all-zero row
-//                      yields column 0, and once everything left is zero GT 0 is re-assigned anchor 0.
-//   E3 finalize_kernel grid (anchor tiles, B): per anchor the 'multi' match (first argmax over GT, >= threshold),
-//                      the neutral test, one-hot/box/offset encoding; rows are staged in LDS and written
-//                      coalesced as float32 and/or float64.
+// Three kernels on the caller's stream; the (g, N) similarity matrix of the reference is never materialised:
+//   R rowmax_kernel    grid (anchor tiles, B): each ground truth row's best (IoU, first column) inside the tile.
+//   M match_kernel     grid (B): match_bipartite_greedy for one image -- the g sequential rounds on the row maxima; a row is
+//                      re-scanned (its IoUs recomputed by 1024 threads, taken columns masked) only when its column was taken.
+//   F finalize_kernel  grid (anchor tiles, B): per anchor its g IoUs again (a few hundred float64 operations), the 'multi' match
+//                      (first argmax over GT, >= threshold), the neutral test, one-hot / box / offset encoding; rows are staged
+//                      in LDS and written as 16-byte stores (float32) and / or float64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -92,13 +89,19 @@ __device__ __forceinline__ void wave_argmax(double& v, int& c) {
     }
 }
 
+__device__ __forceinline__ PxBox<double> load_anchor_view(const double* __restrict__ anchors, int n, const EncodeParams& p) {
+    const double a[4] = {anchors[(size_t)n * 4], anchors[(size_t)n * 4 + 1], anchors[(size_t)n * 4 + 2], anchors[(size_t)n * 4 + 3]};
+    return corner_view(a, p.coords, border_d(p.border));
+}
+
 // ======================================================================================
-// E1
+// R: per-tile row maxima
 // ======================================================================================
-__global__ __launch_bounds__(ENC_THREADS) void iou_kernel(EncodeParams p, const double* __restrict__ anchors,
-                                                          const double* __restrict__ gt, const int* __restrict__ gt_off,
-                                                          double* __restrict__ sim, double* __restrict__ part_val,
-                                                          int* __restrict__ part_col) {
+// grid (anchor tiles, B): IoU of the tile's 256 anchors with the image's ground truth boxes, reduced at once to each row's best
+// (value, first column) inside the tile -- what the bipartite matching starts from.  The similarities themselves are not stored.
+__global__ __launch_bounds__(ENC_THREADS) void rowmax_kernel(EncodeParams p, const double* __restrict__ anchors,
+                                                             const double* __restrict__ gt, const int* __restrict__ gt_off,
+                                                             double* __restrict__ part_val, int* __restrict__ part_col) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     GtBox* gts = reinterpret_cast<GtBox*>(smem_raw);
     __shared__ double wv[ENC_THREADS / 64];
@@ -111,18 +114,11 @@ __global__ __launch_bounds__(ENC_THREADS) void iou_kernel(EncodeParams p, const 
     const int n = tile * ENC_THREADS + tid;
     const bool active = n < p.N;
     PxBox<double> an = {};
-    if (active) {
-        const double a[4] = {anchors[(size_t)n * 4], anchors[(size_t)n * 4 + 1], anchors[(size_t)n * 4 + 2], anchors[(size_t)n * 4 + 3]};
-        an = corner_view(a, p.coords, border_d(p.border));
-    }
+    if (active) an = load_anchor_view(anchors, n, p);
     for (int r = 0; r < g; ++r) {
         double v = -1.0;                           // IoU >= 0, so inactive lanes never win
         int c = 0x7fffffff;
-        if (active) {
-            v = iou_px<double>(gts[r].cr, an);
-            sim[(size_t)(g0 + r) * p.N + n] = v;
-            c = n;
-        }
+        if (active) { v = iou_px<double>(gts[r].cr, an); c = n; }
         wave_argmax(v, c);
         if (lane == 0) { wv[wave] = v; wc[wave] = c; }
         __syncthreads();
@@ -138,27 +134,40 @@ __global__ __launch_bounds__(ENC_THREADS) void iou_kernel(EncodeParams p, const 
 }
 
 // ======================================================================================
-// E2
+// M: bipartite matching of one image, similarities recomputed on the fly
 // ======================================================================================
-__global__ __launch_bounds__(ENC_THREADS) void bipartite_kernel(EncodeParams p, const int* __restrict__ gt_off,
-                                                                const double* __restrict__ sim,
-                                                                const double* __restrict__ part_val,
-                                                                const int* __restrict__ part_col, int* __restrict__ matches,
-                                                                int* __restrict__ matchmap) {
+// One workgroup of MATCH_THREADS per image.  match_bipartite_greedy (matching_utils.py:22-79) needs, per ground truth row, the
+// first arg-max over ALL anchors, then g sequential rounds; neither needs the (g, N) similarity matrix in memory: the row maxima
+// come from rowmax_kernel's per-tile results, and a row is re-scanned -- its IoUs recomputed, the taken columns masked by an
+// LDS bitmap -- only when the column it pointed to was just taken.  Output: matches[g0 + r] = anchor of row r.
+// Quirks kept: an all-zero row yields column 0, and once everything left is zero GT 0 is re-assigned anchor 0.
+constexpr int MATCH_THREADS = 1024;
+
+__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(EncodeParams p, const double* __restrict__ anchors,
+                                                              const double* __restrict__ gt, const int* __restrict__ gt_off,
+                                                              const double* __restrict__ part_val, const int* __restrict__ part_col,
+                                                              int* __restrict__ matches) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NW = MATCH_THREADS / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g0 = gt_off[b], g = gt_off[b + 1] - g0;
     if (g <= 0) return;
-    double* rowval = reinterpret_cast<double*>(smem_raw);                 // [max_gt]
-    int* rowcol = reinterpret_cast<int*>(rowval + p.max_gt);              // [max_gt]
-    int* match = rowcol + p.max_gt;                                       // [max_gt]
-    int* rowgone = match + p.max_gt;                                      // [max_gt]
-    u32* colgone = reinterpret_cast<u32*>(rowgone + p.max_gt);            // [(N+31)/32] bitmap
-    __shared__ double wv[ENC_THREADS / 64];
-    __shared__ int wc[ENC_THREADS / 64];
+    GtBox* gts = reinterpret_cast<GtBox*>(smem_raw);                               // [max_gt]
+    double* rowval = reinterpret_cast<double*>(gts + p.max_gt);                    // [max_gt]
+    int* rowcol = reinterpret_cast<int*>(rowval + p.max_gt);                       // [max_gt]
+    int* match = rowcol + p.max_gt;                                                // [max_gt]
+    int* rowgone = match + p.max_gt;                                               // [max_gt]
+    u32* colgone = reinterpret_cast<u32*>(rowgone + p.max_gt);                     // [(N+31)/32] bitmap
+    __shared__ double wv[1][NW];
+    __shared__ int wc[1][NW];
     __shared__ int pick_col;
 
-    for (int r = tid; r < g; r += ENC_THREADS) {
+    for (int r = tid; r < g; r += MATCH_THREADS) { load_gt(gts[r], gt + (size_t)(g0 + r) * 5, p); match[r] = 0; rowgone[r] = 0; }
+    for (int i = tid; i < (p.N + 31) / 32; i += MATCH_THREADS) colgone[i] = 0;
+    __syncthreads();
+
+    // ---- first arg-max of every row over all anchors: the best of the per-tile maxima (rowmax_kernel) ----
+    for (int r = tid; r < g; r += MATCH_THREADS) {
         double bv = -1.0;
         int bc = 0x7fffffff;
         for (int t = 0; t < p.tiles; ++t) {
@@ -166,10 +175,9 @@ __global__ __launch_bounds__(ENC_THREADS) void bipartite_kernel(EncodeParams p, 
             const int c = part_col[(size_t)(g0 + r) * p.tiles + t];
             if (better(v, c, bv, bc)) { bv = v; bc = c; }
         }
-        if (!(bv > 0.0)) bc = 0;                                           // np.argmax of an all-zero row
-        rowval[r] = bv; rowcol[r] = bc; match[r] = 0; rowgone[r] = 0;     // matches = np.zeros(...) (:59)
+        if (!(bv > 0.0)) bc = 0;                                                    // np.argmax of an all-zero row
+        rowval[r] = bv; rowcol[r] = bc;
     }
-    for (int i = tid; i < (p.N + 31) / 32; i += ENC_THREADS) colgone[i] = 0;
     __syncthreads();
 
     for (int round = 0; round < g; ++round) {
@@ -195,18 +203,18 @@ __global__ __launch_bounds__(ENC_THREADS) void bipartite_kernel(EncodeParams p, 
         // rows that pointed at the column just taken need a new maximum
         for (int r = 0; r < g; ++r) {
             if (rowgone[r] || rowcol[r] != col || !(rowval[r] > 0.0)) continue;      // uniform across the block
-            const double* srow = sim + (size_t)(g0 + r) * p.N;
             double bv = -1.0;
             int bc = 0x7fffffff;
-            for (int n = tid; n < p.N; n += ENC_THREADS) {
-                const double v = ((colgone[n >> 5] >> (n & 31)) & 1u) ? 0.0 : srow[n];
-                if (better(v, n, bv, bc)) { bv = v; bc = n; }
+            for (int n = tid; n < p.N; n += MATCH_THREADS) {
+                double v = 0.0;
+                if (!((colgone[n >> 5] >> (n & 31)) & 1u)) v = iou_px<double>(gts[r].cr, load_anchor_view(anchors, n, p));
+                if (v > bv) { bv = v; bc = n; }
             }
             wave_argmax(bv, bc);
-            if (lane == 0) { wv[wave] = bv; wc[wave] = bc; }
+            if (lane == 0) { wv[0][wave] = bv; wc[0][wave] = bc; }
             __syncthreads();
             if (tid == 0) {
-                for (int w = 1; w < ENC_THREADS / 64; ++w) if (better(wv[w], wc[w], bv, bc)) { bv = wv[w]; bc = wc[w]; }
+                for (int w = 1; w < NW; ++w) if (better(wv[0][w], wc[0][w], bv, bc)) { bv = wv[0][w]; bc = wc[0][w]; }
                 if (!(bv > 0.0)) bc = 0;
                 rowval[r] = bv; rowcol[r] = bc;
             }
@@ -214,20 +222,21 @@ __global__ __launch_bounds__(ENC_THREADS) void bipartite_kernel(EncodeParams p, 
         }
         __syncthreads();
     }
-    // y_encoded[i, bipartite_matches, :-8] = labels_one_hot (:363): duplicates -> the last (highest) GT wins
-    for (int r = tid; r < g; r += ENC_THREADS) {
-        matches[g0 + r] = match[r];
-        atomicMax(&matchmap[(size_t)b * p.N + match[r]], r);
-    }
+    for (int r = tid; r < g; r += MATCH_THREADS) matches[g0 + r] = match[r];
 }
 
 // ======================================================================================
-// E3
+// F: targets
 // ======================================================================================
+// grid (anchor tiles, B).  Per anchor: is it a bipartite match (y_encoded[i, bipartite_matches, :-8] = labels_one_hot, :363: with
+// duplicates the highest GT wins), else its similarities with the image's ground truth boxes -- recomputed, g IoUs per anchor --
+// give the 'multi' match (first argmax over GT, >= threshold, :105-109) and the neutral test (:388-390); then one-hot / box /
+// offset encoding.  Rows are staged in LDS (float32, or float64 when the float64 copy is requested) and leave as 16-byte stores.
+template <typename TileT>
 __global__ __launch_bounds__(ENC_THREADS) void finalize_kernel(EncodeParams p, const double* __restrict__ anchors,
                                                                const double* __restrict__ variances,
                                                                const double* __restrict__ gt, const int* __restrict__ gt_off,
-                                                               const double* __restrict__ sim, const int* __restrict__ matchmap,
+                                                               const int* __restrict__ matches,
                                                                float* __restrict__ y32, double* __restrict__ y64,
                                                                int* __restrict__ match_gt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -237,9 +246,13 @@ __global__ __launch_bounds__(ENC_THREADS) void finalize_kernel(EncodeParams p, c
     const int na = min(TA, p.N - a0);
     const int L = p.L, C = p.C;
     const int g0 = gt_off[b], g = gt_off[b + 1] - g0;
-    double* tile = reinterpret_cast<double*>(smem_raw);                       // [TA][L] staged rows
-    GtBox* gts = reinterpret_cast<GtBox*>(tile + (size_t)TA * L);            // [max_gt]
-    for (int r = tid; r < g; r += TA) load_gt(gts[r], gt + (size_t)(g0 + r) * 5, p);
+    const size_t base = ((size_t)b * p.N + a0) * (size_t)L;
+    // the LDS image keeps the 16-byte phase of the float32 destination, so that whole uint4 chunks can be copied out
+    const int phase = (sizeof(TileT) == 4 && y32) ? (int)((((uintptr_t)(y32 + base)) & 15u) >> 2) : 0;
+    TileT* tile = reinterpret_cast<TileT*>(smem_raw) + phase;                 // [TA][L] staged rows
+    GtBox* gts = reinterpret_cast<GtBox*>(smem_raw + (((size_t)TA * L + 4) * sizeof(TileT) + 15) / 16 * 16);   // [max_gt]
+    int* smatch = reinterpret_cast<int*>(gts + p.max_gt);                     // [max_gt]
+    for (int r = tid; r < g; r += TA) { load_gt(gts[r], gt + (size_t)(g0 + r) * 5, p); smatch[r] = matches[g0 + r]; }
     __syncthreads();
 
     if (tid < na) {
@@ -249,14 +262,16 @@ __global__ __launch_bounds__(ENC_THREADS) void finalize_kernel(EncodeParams p, c
         int gt_idx = -1;
         bool neutral = false;
         if (g > 0) {
-            const int bip = matchmap[(size_t)b * p.N + n];                   // -1: column not taken by bipartite matching
+            int bip = -1;                                                    // the highest GT row whose bipartite match is this anchor
+            for (int r = 0; r < g; ++r) if (smatch[r] == n) bip = r;
             const bool colzero = bip >= 0;                                   // similarities[:, bipartite_matches] = 0 (:366)
             double best = 0.0;
             int best_r = 0;
             if (!colzero) {
-                best = sim[(size_t)g0 * p.N + n];
+                const PxBox<double> an = corner_view(a, p.coords, border_d(p.border));
+                best = iou_px<double>(gts[0].cr, an);
                 for (int r = 1; r < g; ++r) {                                // np.argmax over GT: first maximum (:105)
-                    const double v = sim[(size_t)(g0 + r) * p.N + n];
+                    const double v = iou_px<double>(gts[r].cr, an);
                     if (v > best) { best = v; best_r = r; }
                 }
             }
@@ -265,17 +280,17 @@ __global__ __launch_bounds__(ENC_THREADS) void finalize_kernel(EncodeParams p, c
             const double bg_sim = (colzero || multi) ? 0.0 : best;           // matched columns are zero by now (:381)
             neutral = bg_sim >= p.neg_limit;                                 // :388-390
         }
-        double* row = tile + (size_t)tid * L;
-        for (int c = 0; c < C; ++c) row[c] = 0.0;
+        TileT* row = tile + (size_t)tid * L;
+        for (int c = 0; c < C; ++c) row[c] = (TileT)0;
         double box[4] = {a[0], a[1], a[2], a[3]};                            // template: anchor in place of the GT
         if (gt_idx >= 0) {
             const GtBox& gb = gts[gt_idx];
-            if (gb.cls >= 0 && gb.cls < C) row[gb.cls] = 1.0;
+            if (gb.cls >= 0 && gb.cls < C) row[gb.cls] = (TileT)1;
             for (int k = 0; k < 4; ++k) box[k] = gb.lab[k];
         } else {
-            row[p.background_id] = 1.0;
+            row[p.background_id] = (TileT)1;
         }
-        if (neutral) row[p.background_id] = 0.0;
+        if (neutral) row[p.background_id] = (TileT)0;
         if (match_gt) {
             int code = gt_idx;
             if (gt_idx < 0) code = neutral ? -2 : -1;
@@ -300,31 +315,42 @@ __global__ __launch_bounds__(ENC_THREADS) void finalize_kernel(EncodeParams p, c
             t[2] = ((box[2] - a[2]) / h) / var[2];
             t[3] = ((box[3] - a[3]) / h) / var[3];
         }
-        for (int k = 0; k < 4; ++k) { row[C + k] = t[k]; row[C + 4 + k] = a[k]; row[C + 8 + k] = var[k]; }
+        for (int k = 0; k < 4; ++k) { row[C + k] = (TileT)t[k]; row[C + 4 + k] = (TileT)a[k]; row[C + 8 + k] = (TileT)var[k]; }
     }
     __syncthreads();
-    const size_t base = ((size_t)b * p.N + a0) * (size_t)L;
     const int total = na * L;
-    if (y64) for (int i = tid; i < total; i += TA) y64[base + i] = tile[i];
-    if (y32) for (int i = tid; i < total; i += TA) y32[base + i] = (float)tile[i];
+    if (sizeof(TileT) == 8) {
+        const double* dt = reinterpret_cast<const double*>(tile);
+        if (y64) for (int i = tid; i < total; i += TA) y64[base + i] = dt[i];
+        if (y32) for (int i = tid; i < total; i += TA) y32[base + i] = (float)dt[i];
+    } else if (y32) {
+        const float* ft = reinterpret_cast<const float*>(tile);
+        float* dst = y32 + base;
+        const int head = min(total, (4 - phase) & 3);
+        if (tid < head) dst[tid] = ft[tid];
+        const int nvec = (total - head) >> 2;
+        const float4* vsrc = reinterpret_cast<const float4*>(ft + head);
+        float4* vdst = reinterpret_cast<float4*>(dst + head);
+        for (int i = tid; i < nvec; i += TA) vdst[i] = vsrc[i];
+        const int done = head + (nvec << 2);
+        if (tid < total - done) dst[done + tid] = ft[done + tid];
+    }
 }
 
 struct EncodeWs {
-    size_t sim, part_val, part_col, matches, matchmap, total;
+    size_t part_val, part_col, matches, total;
 };
 
 static inline size_t enc_align(size_t v) { return (v + 255) / 256 * 256; }
 
 static EncodeWs encode_ws_layout(int B, int N, int G_total) {
-    const size_t tiles = (size_t)(N + ENC_THREADS - 1) / ENC_THREADS;
     const size_t G = G_total > 0 ? (size_t)G_total : 1;
+    const size_t tiles = (size_t)(N + ENC_THREADS - 1) / ENC_THREADS;
     EncodeWs w;
     size_t o = 0;
-    w.sim = o;      o = enc_align(o + G * N * sizeof(double));
     w.part_val = o; o = enc_align(o + G * tiles * sizeof(double));
     w.part_col = o; o = enc_align(o + G * tiles * sizeof(int));
     w.matches = o;  o = enc_align(o + G * sizeof(int));
-    w.matchmap = o; o = enc_align(o + (size_t)B * N * sizeof(int));
     w.total = o;
     return w;
 }
@@ -363,32 +389,38 @@ extern "C" int ssdhip_encode(const double* anchors, const double* variances, con
     p.coords = coords; p.normalize = normalize_coords ? 1 : 0; p.border = border_pixels; p.background_id = background_id;
     p.img_h = img_height; p.img_w = img_width; p.pos_thr = pos_iou_threshold; p.neg_limit = neg_iou_limit;
 
-    unsigned char* base = static_cast<unsigned char*>(ws);
-    double* sim = reinterpret_cast<double*>(base + lay.sim);
-    double* part_val = reinterpret_cast<double*>(base + lay.part_val);
-    int* part_col = reinterpret_cast<int*>(base + lay.part_col);
-    int* matches = reinterpret_cast<int*>(base + lay.matches);
-    int* matchmap = reinterpret_cast<int*>(base + lay.matchmap);
-
-    if (hipMemsetAsync(matchmap, 0xff, (size_t)B * N * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    unsigned char* wsb = static_cast<unsigned char*>(ws);
+    double* part_val = reinterpret_cast<double*>(wsb + lay.part_val);
+    int* part_col = reinterpret_cast<int*>(wsb + lay.part_col);
+    int* matches = reinterpret_cast<int*>(wsb + lay.matches);
     if (G_total > 0) {
-        const size_t gt_lds = (size_t)p.max_gt * sizeof(GtBox);
-        hipLaunchKernelGGL(iou_kernel, dim3(p.tiles, B), dim3(ENC_THREADS), gt_lds, stream, p, anchors, gt, gt_offsets, sim,
-                           part_val, part_col);
+        hipLaunchKernelGGL(rowmax_kernel, dim3(p.tiles, B), dim3(ENC_THREADS), (size_t)p.max_gt * sizeof(GtBox), stream, p, anchors, gt,
+                           gt_offsets, part_val, part_col);
         if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-        const size_t bp_lds = (size_t)p.max_gt * (sizeof(double) + 3 * sizeof(int)) + (size_t)((N + 31) / 32) * sizeof(u32) + 16;
-        if (bp_lds > 150 * 1024) return SSDHIP_E_BADARG;
-        hipLaunchKernelGGL(bipartite_kernel, dim3(B), dim3(ENC_THREADS), bp_lds, stream, p, gt_offsets, sim, part_val, part_col,
-                           matches, matchmap);
+        const size_t m_lds = (size_t)p.max_gt * (sizeof(GtBox) + sizeof(double) + 3 * sizeof(int)) + (size_t)((N + 31) / 32) * sizeof(u32) + 16;
+        if (m_lds > 150 * 1024) return SSDHIP_E_BADARG;
+        if (m_lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)m_lds) != hipSuccess)
+            return SSDHIP_E_LAUNCH;
+        hipLaunchKernelGGL(match_kernel, dim3(B), dim3(MATCH_THREADS), m_lds, stream, p, anchors, gt, gt_offsets, part_val, part_col, matches);
         if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     }
-    // E3: tile = anchors whose float64 rows fit ~48 KiB of LDS next to the GT table
+    // F: tile = anchors whose staged rows fit ~36 KiB of LDS next to the GT table (float32 rows unless the float64 copy is asked for)
+    const bool want64 = y_encoded_f64 != nullptr;
+    const size_t esz = want64 ? sizeof(double) : sizeof(float);
     int TA = 256;
-    while (TA > 64 && (size_t)TA * p.L * sizeof(double) > 48 * 1024) TA >>= 1;
-    const size_t fin_lds = (size_t)TA * p.L * sizeof(double) + (size_t)p.max_gt * sizeof(GtBox);
+    while (TA > 64 && (size_t)TA * p.L * esz > 36 * 1024) TA >>= 1;
+    const size_t fin_lds = (((size_t)TA * p.L + 4) * esz + 15) / 16 * 16 + (size_t)p.max_gt * (sizeof(GtBox) + sizeof(int));
     if (fin_lds > 150 * 1024) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(finalize_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), fin_lds, stream, p, anchors, variances, gt,
-                       gt_offsets, sim, matchmap, y_encoded_f32, y_encoded_f64, match_gt);
+    const void* fk = want64 ? reinterpret_cast<const void*>(finalize_kernel<double>) : reinterpret_cast<const void*>(finalize_kernel<float>);
+    if (fin_lds > 48 * 1024 && hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds) != hipSuccess)
+        return SSDHIP_E_LAUNCH;
+    if (want64)
+        hipLaunchKernelGGL(finalize_kernel<double>, dim3((N + TA - 1) / TA, B), dim3(TA), fin_lds, stream, p, anchors, variances, gt,
+                           gt_offsets, matches, y_encoded_f32, y_encoded_f64, match_gt);
+    else
+        hipLaunchKernelGGL(finalize_kernel<float>, dim3((N + TA - 1) / TA, B), dim3(TA), fin_lds, stream, p, anchors, variances, gt,
+                           gt_offsets, matches, y_encoded_f32, y_encoded_f64, match_gt);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     return SSDHIP_OK;
 }

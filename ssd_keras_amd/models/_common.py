@@ -78,10 +78,11 @@ class _ConvBiasActFn(torch.autograd.Function):
     gradient kernels) behind it.  `run` is the libssdhip thunk picked for this layer shape: (x_bf16, w_bf16, b_bf16) -> y."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu):
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu, wb=None, bb=None):
         xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        bb = bias.detach().to(torch.bfloat16) if bias is not None else None
+        if wb is None:                                   # no bf16 shadow of the parameters at hand: cast here
+            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            bb = bias.detach().to(torch.bfloat16) if bias is not None else None
         y = run(xb, wb, bb)
         ctx.save_for_backward(xb, wb, y if relu else None)
         ctx.conf = (stride, padding, dilation, relu, weight.dtype, None if bias is None else bias.dtype, x.dtype)
@@ -119,7 +120,7 @@ class _ConvBiasActFn(torch.autograd.Function):
                                                           masks)
         if gx is None:
             gx = gx_m
-        return (gx.to(xdt) if need_x else None), gw.to(wdt), gb, None, None, None, None, None
+        return (gx.to(xdt) if need_x else None), gw.to(wdt), gb, None, None, None, None, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -270,7 +271,8 @@ class SSDModel(nn.Module):
         if self._fused_train(x, conv):
             run, _name = self._train_thunk(conv, x, relu)
             if run is not None:
-                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu)
+                wb, bb = self._bf16_shadow(conv)
+                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu, wb, bb)
         y = conv(x)
         return F.relu(y) if relu else y
 
@@ -279,6 +281,33 @@ class SSDModel(nn.Module):
     def _fused_train(self, x, conv):
         return (self.fused_training and x.is_cuda and torch.is_grad_enabled() and conv.bias is not None and conv.groups == 1
                 and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
+
+    def _bf16_shadow(self, conv):
+        """bf16 copies of a convolution's float32 master weight and bias for the libssdhip forward.  All shadows of the model are
+        refreshed together by ONE multi-tensor copy whenever a parameter changed (the optimizer's in-place update bumps
+        `_version`), instead of two cast kernels per layer per step."""
+        if conv.weight.dtype == torch.bfloat16:
+            return conv.weight.detach(), conv.bias.detach()
+        st = self.__dict__.get("_shadow_state")
+        if st is None or st["device"] != conv.weight.device:
+            convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m.bias is not None]
+            src = [c.weight for c in convs] + [c.bias for c in convs]
+            with torch.no_grad():
+                dst = [torch.empty_like(t, dtype=torch.bfloat16) for t in src]
+            st = {"device": conv.weight.device, "src": src, "dst": dst, "versions": None,
+                  "index": {id(c): i for i, c in enumerate(convs)}, "n": len(convs)}
+            self.__dict__["_shadow_state"] = st
+        if not self.__dict__.get("_shadow_fresh", False):                 # checked once per forward pass (raw_predictions resets it)
+            versions = tuple(t._version for t in st["src"])
+            if versions != st["versions"]:
+                with torch.no_grad():
+                    torch._foreach_copy_(st["dst"], [t.detach() for t in st["src"]])
+                st["versions"] = versions
+            self.__dict__["_shadow_fresh"] = True
+        i = st["index"].get(id(conv))
+        if i is None:
+            return None, None
+        return st["dst"][i], st["dst"][st["n"] + i]
 
     def _train_thunk(self, conv, x, relu):
         """The libssdhip kernel for this layer as `(x_bf16, w_bf16, b_bf16) -> y`, or (None, None).  The variant is the one the
@@ -387,6 +416,7 @@ class SSDModel(nn.Module):
     def raw_predictions(self, images, decode=False):
         """The `(batch, #boxes, #classes + 12)` prediction tensor; with `decode=True` (used by `forward` in the inference modes) the
         decoded detections, which on the fused bf16 path come straight from the head outputs."""
+        self.__dict__["_shadow_fresh"] = False
         x = self.preprocess(images)
         dtype = next(self.parameters()).dtype
         feats = self.features(x.to(dtype) if not torch.is_autocast_enabled() else x)

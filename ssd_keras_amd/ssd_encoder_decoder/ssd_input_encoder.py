@@ -171,24 +171,35 @@ class SSDInputEncoder:
         gt, offsets, max_g = self._pack_ground_truth(ground_truth_labels)
         if max_g > 1024:
             raise ValueError("at most 1024 ground truth boxes per image are supported, got {}".format(max_g))
-        B, N, C = len(ground_truth_labels), self.n_anchors, self.n_classes
-        anchors, variances = self._device_constants(device)
+        B = len(ground_truth_labels)
         # one upload: [offsets int32 (B+1), padded to 8 bytes | ground truth rows float64]
         n_off = (offsets.shape[0] + 1) // 2
         packed = np.empty(n_off + max(int(gt.shape[0]), 1) * 5, dtype=np.float64)
         packed[:n_off].view(np.int32)[:offsets.shape[0]] = offsets
         packed[n_off:n_off + gt.size] = gt.ravel()
         packed_d = torch.from_numpy(packed).to(device)
-        off_d = packed_d[:n_off].view(torch.int32)
-        gt_d = packed_d[n_off:]
+        return self.encode_packed(packed_d[n_off:], packed_d[:n_off].view(torch.int32), int(gt.shape[0]), int(max_g), B, want_f32,
+                                  want_f64, want_matches)
+
+    def encode_packed(self, gt_d, off_d, n_gt, max_gt_per_image, batch_size, want_f32=True, want_f64=False, want_matches=False):
+        '''The encoder kernels on labels that are ALREADY on the GPU in CSR form (e.g. produced by a device-side input pipeline):
+        `gt_d` float64 (n_gt, 5) rows `[class, xmin, ymin, xmax, ymax]` of all images concatenated, `off_d` int32 (batch + 1,)
+        row offsets.  No host work, no PCIe traffic, nothing but `ssdhip_encode`'s two launches on the current stream; the caller
+        vouches for the checks `encode_to_device` makes on the host (no degenerate boxes, class ids in range, <= 1024 boxes per
+        image).  Returns (y_f32 | None, y_f64 | None, match_gt | None).'''
+        import torch
+        lib = nat.load()
+        device = off_d.device
+        B, N, C = int(batch_size), self.n_anchors, self.n_classes
+        anchors, variances = self._device_constants(device)
         y32 = torch.empty((B, N, C + 12), dtype=torch.float32, device=device) if want_f32 else None
         y64 = torch.empty((B, N, C + 12), dtype=torch.float64, device=device) if want_f64 else None
         mm = torch.empty((B, N), dtype=torch.int32, device=device) if want_matches else None
-        need = lib.ssdhip_encode_workspace_bytes(B, N, C, int(gt.shape[0]))
+        need = lib.ssdhip_encode_workspace_bytes(B, N, C, int(n_gt))
         ws = nat.workspaces.get(device, 'encode', need)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(device):
-            rc = lib.ssdhip_encode(ptr(anchors), ptr(variances), ptr(gt_d), ptr(off_d), int(gt.shape[0]), int(max_g), B, N, C,
+            rc = lib.ssdhip_encode(ptr(anchors), ptr(variances), ptr(gt_d), ptr(off_d), int(n_gt), int(max_gt_per_image), B, N, C,
                                    float(self.img_height), float(self.img_width), 1 if self.matching_type == 'multi' else 0,
                                    float(self.pos_iou_threshold), float(self.neg_iou_limit), nat.COORDS[self.coords],
                                    int(bool(self.normalize_coords)), nat.BORDER[self.border_pixels], int(self.background_id),

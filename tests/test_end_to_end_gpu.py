@@ -146,3 +146,48 @@ def test_training_forward_through_libssdhip_matches_the_framework_path():
     assert dp_new <= 1.5 * dp_ref + 1e-3
     assert e_new <= 1.5 * e_ref + 1e-3
     assert all(torch.isfinite(g).all() for g in g_new)
+
+
+def test_bf16_backbone_drift_against_the_float32_model():
+    """The reference's convolutions are float32; the benchmarked backbone is bf16 (MFMA).  Same weights, same synthetic images:
+    how far do the predictions and the decoded detections move?  The conv heads are tamed (x 1e-3 weights, background bias +4)
+    so that the softmax is neither saturated nor uniform -- on raw He-init outputs both models produce chaotic, tie-dominated
+    detections and the comparison would measure nothing.  Bars: class probabilities within 5e-3, offsets within 2e-2, and at
+    least 90 % of the float32 model's detections (class, anchor) reappear in the bf16 model's output with boxes within 0.5 px."""
+    import copy
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.ssd_encoder_decoder import ssd_output_decoder as dec
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(11)
+    m32 = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"],
+                  aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"]).cuda()
+    m32 = m32.to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        for head in m32.conf_heads:
+            head.weight.mul_(1e-3)
+            head.bias.view(-1, 21)[:, 0] = 4.0
+        for head in m32.loc_heads:
+            head.weight.mul_(1e-3)
+        for p in m32.parameters():                                        # both models hold bf16-representable weights
+            p.copy_(p.to(torch.bfloat16).float())
+    m16 = copy.deepcopy(m32).to(torch.bfloat16)
+    images = torch.from_numpy(np.random.RandomState(5).randint(0, 256, size=(4, 300, 300, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        p32 = m32(images).float()
+        p16 = m16(images).float()
+    d_conf = float((p16[:, :, :21] - p32[:, :, :21]).abs().max())
+    d_loc = float((p16[:, :, 21:25] - p32[:, :, 21:25]).abs().max())
+    kw = dict(confidence_thresh=0.01, iou_threshold=0.45, top_k=200, normalize_coords=True, img_height=300, img_width=300)
+    a = dec.decode_detections_debug(p32, **kw)
+    b = dec.decode_detections_debug(p16, **kw)
+    found = total = 0
+    for ra, rb in zip(a, b):
+        kb = {(int(r[0]), int(r[1])): r for r in rb}
+        for r in ra:
+            total += 1
+            o = kb.get((int(r[0]), int(r[1])))
+            found += int(o is not None and np.abs(o[3:] - r[3:]).max() <= 0.5)
+    print("bf16 vs float32 backbone: max |d prob| %.2e, max |d offset| %.2e, detections kept %d / %d" % (d_conf, d_loc, found, total))
+    assert d_conf < 5e-3 and d_loc < 2e-2
+    assert total > 0 and found >= 0.9 * total

@@ -41,7 +41,7 @@ def test_workspace_sizes(lib):
     assert 32 * 8732 * (40 + 20 * 13) <= d64 < 2 * 32 * 8732 * (40 + 20 * 13)
     assert lib.ssdhip_decode_workspace_bytes(32, 8732, 21, 200, 400, 0, 2) == 0        # unknown element type
     assert lib.ssdhip_decode_workspace_bytes(0, 8732, 21, 200, 400, 0, 0) == 0
-    assert lib.ssdhip_encode_workspace_bytes(32, 8732, 21, 256) >= 256 * 8732 * 8
+    assert lib.ssdhip_encode_workspace_bytes(32, 8732, 21, 256) >= 256 * 4        # one matched anchor per ground truth box: no similarity matrix
     assert lib.ssdhip_loss_workspace_bytes(32, 8732, 21) >= 2 * 32 * 8732 * 4
 
 

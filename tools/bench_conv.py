@@ -44,7 +44,7 @@ def main():
         t_v4 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=4))
         t_v5 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=5))
         t_v6 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=6))
-        t_v7 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=9))
+        t_v7 = ev_ms(lambda: nat.conv2d_same(x, w, b, dilation=dil, relu=True, variant=6))
         t_pool = t_unf = float("nan")
         if name in ("conv1_2", "conv2_2", "conv3_2"):
             t_pool = ev_ms(lambda: nat.conv2d_same_pool2(x, w, b, dilation=dil, relu=True))
