@@ -158,7 +158,8 @@ def main():
             for _ in range(10):
                 model(images)
         torch.cuda.synchronize()
-        decode_ms_in_step = float(np.mean([a.elapsed_time(b) for a, b in model.decoder.timing_events]))
+        in_step = [a.elapsed_time(b) for a, b in model.decoder.timing_events]
+        decode_ms_in_step = float(np.median(in_step))                 # (median: a first call can carry a one-off allocation)
         model.decoder.timing_events = None
     step_out = out                                   # (B, top_k, 6) float32: what the timed steps returned
     with torch.no_grad():
@@ -181,7 +182,7 @@ def main():
     with torch.no_grad():
         fwd_ms = event_ms(lambda: model.raw_predictions(images), 10)
     dom = max(("scan_kernel", "nms_kernel", "topk_kernel"), key=lambda k: stage_ms[k])
-    full_name = {"scan_kernel": "scan_kernel", "nms_kernel": "nms_kernel<POL_TF32, 256>", "topk_kernel": "topk_kernel<float>"}
+    full_name = {"scan_kernel": "scan_kernel", "nms_kernel": "nms_kernel<POL_TF32, 512>", "topk_kernel": "topk_kernel<float>"}
     achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
     traffic = None                                   # HBM bytes per launch of the dominant kernel from the committed PMC passes
     import glob

@@ -771,13 +771,17 @@ __global__ __launch_bounds__(C1_BP) void conv3x3_cin3_kernel(const bf16_t* __res
     constexpr int X2_OFF = 0, W2_OFF = 16384, STRIP_OFF = W2_OFF + COUT * 64, STRIP_STRIDE = SCHUNKS * 16;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[STRIP_OFF + 3 * STRIP_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * C1_BP;
     bf16_t* w2 = reinterpret_cast<bf16_t*>(lds + W2_OFF);                     // [64][32] bf16, chunk c of row r at c ^ ((r>>2)&3)
     for (int i = tid; i < COUT * 32; i += C1_BP) {
         const int co = i >> 5, k = i & 31;
         const bf16_t v = k < K ? w[co * K + k] : (bf16_t)0;                   // w[co][kh][kw][ci] is already k-major
         w2[co * 32 + ((((k >> 3) ^ ((co >> 2) & 3)) << 3) | (k & 7))] = v;
     }
+    // persistent workgroups: the filter bank is repacked into LDS once, then the workgroup walks its tiles (the per-tile
+    // barriers below order every reuse of the LDS regions; the store stage of a wave overlays only that wave's im2col rows)
+    const int n_tiles = (M + C1_BP - 1) / C1_BP;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int m0 = tile * C1_BP;
     // the three input strips (image rows h-1, h, h+1 of the tile's pixels, one pixel of halo each side) are contiguous
     // byte ranges of x: copied as aligned 16-byte chunks, the 2-byte phase is kept and added back when indexing
     const long total_bytes = (long)M * CIN * 2;
@@ -905,6 +909,7 @@ __global__ __launch_bounds__(C1_BP) void conv3x3_cin3_kernel(const bf16_t* __res
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    }   // tiles
 }
 
 }  // namespace ssdhip
@@ -1094,7 +1099,7 @@ extern "C" int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, 
     if ((((uintptr_t)y) & 15) || (((uintptr_t)bias) & 7)) return SSDHIP_E_BADARG;
     const long long M = (long long)B * H * W;
     if (M > 0x7fffff00LL) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(conv3x3_cin3_kernel, dim3((unsigned)((M + C1_BP - 1) / C1_BP)), dim3(C1_BP), 0, stream,
+    hipLaunchKernelGGL(conv3x3_cin3_kernel, dim3((unsigned)(((M + C1_BP - 1) / C1_BP) < 1536 ? ((M + C1_BP - 1) / C1_BP) : 1536)), dim3(C1_BP), 0, stream,
                        static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(weight), static_cast<const bf16_t*>(bias),
                        static_cast<bf16_t*>(y), H, W, (int)M, relu ? 1 : 0);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;

@@ -182,7 +182,7 @@ __device__ __forceinline__ void scan_tile_body(const float* tile, int* wave_cnt,
             for (int j0 = 0; j0 < ng; j0 += 8) {                  // eight scores per step: their LDS reads are in flight together
                 float s8[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s8[u] = (j0 + u < ng) ? sc[j0 + u] : 0.f;
+                for (int u = 0; u < 8; ++u) s8[u] = sc[min(j0 + u, ng - 1)];      // clamped index: branch-free, masked below
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool pr = active && (j0 + u < ng) && (incl ? (s8[u] >= t) : (s8[u] > t));
@@ -218,7 +218,7 @@ __device__ __forceinline__ void scan_tile_body(const float* tile, int* wave_cnt,
         for (int j0 = 0; j0 < ng; j0 += 8) {
             float s8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] = p.class_agnostic ? fast_conf : ((j0 + u < ng) ? sc[j0 + u] : 0.f);
+            for (int u = 0; u < 8; ++u) s8[u] = p.class_agnostic ? fast_conf : sc[min(j0 + u, ng - 1)];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u;

@@ -1,0 +1,23 @@
+"""Timing of the first-layer convolution (3 -> 64 channels, 300 x 300, batch 32).  GPU box."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ssd_keras_amd import _native as nat  # noqa: E402
+
+x = torch.randn((32, 300, 300, 3), device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+w = (torch.randn((64, 3, 3, 3), device="cuda") / 5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+b = torch.randn((64,), device="cuda").to(torch.bfloat16)
+for _ in range(3):
+    y = nat.conv3x3_cin3(x, w, b, relu=True)
+torch.cuda.synchronize()
+a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(50):
+    y = nat.conv3x3_cin3(x, w, b, relu=True)
+e.record()
+e.synchronize()
+ms = a.elapsed_time(e) / 50
+print("conv1_1: %.1f us, output write %.2f TB/s" % (1e3 * ms, y.numel() * 2 / ms / 1e9))
