@@ -1004,11 +1004,15 @@ extern "C" int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const 
 }
 
 // Profiling aid: the same with an explicit kernel variant (4: the shipped kernel; 1: its predecessor with per-lane
-// pointers, per-step divisions and per-kk fragment waits -- 10-27 % slower on the VGG shapes; 3: the
-// 256-pixel / three-stage / kw-reuse experiment, which halves L2 traffic but loses to barrier stalls at one workgroup per CU).
+// pointers, per-step divisions and per-kk fragment waits -- 10-27 % slower on the VGG shapes; 5 / 6: the multi-stage LDS ring;
+// 7: ssdhip_conv3x3_halo_nhwc_bf16).
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
+    if (variant == 7) {                       // the slab kernel of ssdhip_convh.hip (3x3, dilation 1, Cin % 128 == 0, W <= 94)
+        if (kernel != 3 || dilation != 1) return SSDHIP_E_BADARG;
+        return ssdhip_conv3x3_halo_nhwc_bf16(x, weight, bias, y, B, H, W, Cin, Cout, relu, stream);
+    }
     if (variant != 1 && variant != 4 && variant != 5 && variant != 6) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);
 }

@@ -1,0 +1,383 @@
+// ssdhip_convh.hip -- 3x3 'same' convolution (stride 1, dilation 1) + bias + ReLU for the deep VGG layers (Cin a multiple of
+// 128: conv3_x, conv4_x, conv5_x of models/keras_ssd300.py:284-296 and twins), gfx950, bf16 NHWC, float32 accumulation.
+//
+// Why its own kernel.  The implicit-GEMM kernel of ssdhip_conv.hip moves 32 KB from L2 into LDS per K-step (one tap of one
+// 64-channel slice: a 128-pixel activation tile + a 128-channel weight tile) for 512 cycles of MFMA work; two workgroups per
+// CU make that 64 KB per 1024 cycles -- exactly what the CU's vector-memory path delivers (64 B/clk).  Loads and MFMAs are
+// balanced, so the kernel tops out at ~41 % of the MFMA peak whatever the prefetch depth (measured).  The cure
+// is fewer bytes per FLOP:
+//   * the nine taps of a 64-channel slice read the SAME activations shifted by a pixel / an image row, so the tile's
+//     activations come in ONCE per slice as a 'slab' (the tile's positions plus a halo of W + 2 positions on either side)
+//     and the taps are nine row displacements into it: activation traffic / 9 x (1 + halo);
+//   * positions, not pixels: the batch is laid out on a padded grid -- image b, row h, column w sits at position
+//     q = (b (H + 1) + h)(W + 1) + w, with one dummy column (w = W) per row and one dummy row (h = H) per image.  Dummy
+//     positions are out-of-range buffer offsets (the buffer unit writes zeros into LDS), and every tap of every pixel that
+//     falls outside its image lands on one: tap (kh, kw) is the SAME displacement (kh - 1)(W + 1) + (kw - 1) for all positions,
+//     with no per-tap validity masks.  A tile is 256 consecutive positions; dummy positions cost (H + 1)(W + 1) / HW - 1 of the
+//     MFMA work (5 % on a 38 x 38 map) and are skipped by the epilogue;
+//   * tile = 128 channels x 256 positions, 8 waves as 2 x 4 (64 x 64 each, 16 v_mfma_f32_32x32x16_bf16 per K-step), ONE
+//     workgroup per CU: per K-step 16 KB of weights + 1/9 slab (~6 KB) for 1024 cycles of MFMA work per SIMD -- a third of the
+//     implicit-GEMM kernel's bytes per FLOP.
+// Pipeline (per K-step = one tap of one slice, one s_barrier):
+//   * weights: ring of NW 16 KB stages, loads NW steps ahead; slab: two buffers, slice cs + 1 arrives during the first taps
+//     of slice cs; all by LDS-DMA from inline asm with hand-counted vmcnt (see ssdhip_conv.hip v5 for why not the builtin);
+//   * the MFMA operands of step s + 1 are read from LDS into a second register set WHILE the 16 MFMAs of step s issue
+//     (fragment reads interleaved with the MFMAs), so no LDS latency is exposed and the barrier only orders LDS reuse.
+// LDS rows are 128 bytes (64 channels); 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) (source-side permutation
+// of the lane-linear DMA image, undone by the fragment reads): conflict-free ds_read_b128 for ANY 32 consecutive rows, so a
+// tap displacement only changes the swizzle term, which the readers recompute per step (a handful of VALU operations).
+// Accumulation order per output = ssdhip_conv.hip's (slices outer, taps, 16-channel blocks): results are bit-identical to it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_THREADS = 512;
+constexpr int CH_BN = 256;                               // positions per tile
+constexpr int CH_BM = 128;                               // output channels per tile
+constexpr int CH_WST = CH_BM * 128;                      // bytes of one weight stage
+constexpr int ch_lds_bytes(int nw, int spw) { return nw * CH_WST + 2 * spw * 8192; }
+
+struct ConvHParams {
+    const bf16_t* x;             // [B, H, W, Cin]
+    const bf16_t* w;             // [Cout, 3, 3, Cin]
+    const bf16_t* bias;          // [Cout] or null
+    bf16_t* y;                   // [B, H, W, Cout]
+    int H, W, Cin, Cout, relu;
+    int Q, q_tiles, n_tiles;     // padded positions B (H+1)(W+1); tiles of 256 positions; tiles of 128 channels
+    int x_bytes, w_bytes;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 ch_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ch_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 ch_pack2(float a, float b) {           // v_cvt_pk_bf16_f32: round to nearest even
+    const ch_f32x2 v = {a, b};
+    return __builtin_bit_cast(u32, __builtin_convertvector(v, ch_bf16x2));
+}
+__device__ __forceinline__ float ch_relu(float v) { return v <= 0.f ? 0.f : v; }       // NaN stays NaN, -0 -> +0
+
+// one wave-wide 1 KiB LDS-DMA load: lane L writes 16 bytes at lds_dst + 16 L from base(rsrc) + soff + voff (zeros if the offset
+// is out of range).  M0 is saved and restored inside the statement (hipcc does not model it around asm).
+__device__ __forceinline__ void ch_bload(u32 voff, i32x4 rsrc, u32 lds_dst, u32 soff) {
+    u32 keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    i32x4 r;
+    r.x = (int)(u32)a;
+    r.y = (int)((u32)(a >> 32) & 0xffffu);
+    r.z = num_records;
+    r.w = 0x00020000;
+    return r;
+}
+// MODE bits -- 8: waves 4..7 (the second wave of every SIMD) issue their loads in the middle of the step instead of at its start.
+// Profiling build only (wrong results, they isolate one cost each): 1 no loads in the K loop, 2 no fragment reads, 4 no waits / barrier,
+// 32 no MFMAs.
+template <int NW, int SPW, int MODE>
+__device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds) {
+    constexpr int D = NW;                                // weights of step s + D are requested during step s
+    constexpr int SLAB0 = NW * CH_WST, SLB = SPW * 8192;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(SPW + D <= 10, "slice cs+1's slab must have landed two steps before tap 8 of slice cs reads it");
+
+    const int id = (int)blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;     // the channel tiles of a position tile share an XCD
+    if (qt >= p.q_tiles) return;
+    const int q0 = qt * CH_BN, co0 = nt * CH_BM;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // 64-channel half, 64-position quarter of the tile
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int H = p.H, W = p.W, Cin = p.Cin, W1 = W + 1, H1 = H + 1;
+    const int csteps = Cin >> 6;
+    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const i32x4 rx = ch_rsrc(p.x, p.x_bytes);
+    const i32x4 rw = ch_rsrc(p.w, p.w_bytes);
+
+    // ---- per-lane load descriptors --------------------------------------------------------------------------------------
+    // slab row r <-> position q0 - (W + 2) + r; piece (k, wave) = rows 64 k + 8 wave .. + 7, lane -> row (lane >> 3), chunk slot
+    // (lane & 7) holding source chunk (lane & 7) ^ ((row >> 1) & 7)
+    const int SP = CH_BN + 2 * W + 4;                    // slab rows a tile reads
+    u32 xoff[SPW];
+    {
+        const int row0 = wave * 8 + (lane >> 3);
+        int q = q0 - (W + 2) + row0;
+        int b = 0, h = 0, w = 0;
+        if (q >= 0) { b = q / (H1 * W1); const int r = q - b * (H1 * W1); h = r / W1; w = r - h * W1; }
+        else { w = q; }                                  // negative positions: before the first image (zeros)
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) {
+            const int row = row0 + 64 * k;
+            const int j = (lane & 7) ^ ((row >> 1) & 7);
+            const bool ok = w >= 0 && w < W && h < H && q < p.Q && row < SP;
+            xoff[k] = ok ? (u32)(((b * H + h) * W + w) * (Cin * 2) + j * 16) : OOB;
+            q += 64;
+            w += 64;
+            while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+        }
+    }
+    u32 woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int j = (lane & 7) ^ ((row >> 1) & 7);
+        woff[i] = (u32)((co0 + row) * (9 * Cin * 2) + j * 16);
+    }
+
+    // the weights of tap `tap` of slice `cs` into ring stage `stage` (all wave-uniform)
+    auto issue_w = [&](const int cs, const int tap, const int stage) {
+        const u32 soff = (u32)((tap * Cin + cs * 64) * 2);
+        const u32 dst = lds0 + stage * CH_WST + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ch_bload(woff[i], rw, dst + i * 8192, soff);
+    };
+
+    // ---- fragment addressing -----------------------------------------------------------------------------------------------
+    u32 abase[4];                                        // weight stage: row = channel, chunk (2 kk + khalf) ^ ((row >> 1) & 7)
+    {
+        const int row = wm * 64 + r31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) abase[kk] = (u32)(row * 128 + (((2 * kk + khalf) ^ ((row >> 1) & 7)) << 4));
+    }
+    const int prow = wn * 64 + r31;                      // slab row of the lane's first position at tap (0, 0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    bf16x8 fa[2][4][2], fb[2][4][2];                     // [register set][k16 block][ci | pi]
+
+    u32 ra[4], rb[2], re[2];                             // addresses of the pending fragment reads
+    auto read_addr = [&](const int cs, const int tap, const int stage) {     // the fragments of tap `tap` of slice `cs`
+        u32 wst = (u32)(stage * CH_WST);
+        u32 toff = (u32)((tap / 3) * W1 + tap % 3);
+        u32 sl = (u32)(SLAB0 + (cs & 1) * SLB);
+        // opaque to the optimiser: with the taps unrolled it otherwise computes the addresses of all nine steps up front (72 VGPRs)
+        asm volatile("" : "+s"(wst), "+s"(toff), "+s"(sl));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ra[kk] = abase[kk] + wst;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const u32 row = (u32)(prow + pi * 32) + toff;
+            rb[pi] = sl + (row << 7);
+            re[pi] = (((row >> 1) & 7u) ^ (u32)khalf) << 4;     // chunk (2 kk + khalf) ^ swz = (2 kk) ^ (khalf ^ swz)
+        }
+    };
+    auto read_kk = [&](auto setc, auto kkc) {
+        constexpr int S = decltype(setc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) fa[S][kk][ci] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + ci * 4096);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) fb[S][kk][pi] = *reinterpret_cast<const bf16x8*>(lds + rb[pi] + (re[pi] ^ (u32)(kk << 5)));
+    };
+    auto mfma_kk = [&](auto setc, auto kkc) {
+        constexpr int S = decltype(setc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+                acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: slab of slice 0, weights of steps 0 .. D-1 ---------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) ch_bload(xoff[k], rx, lds0 + SLAB0 + wave * 1024 + k * 8192, 0u);
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue_w(0, d, d);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (D - 2)) : "memory");     // slab 0 and the weights of steps 0 and 1 (this wave's share)
+    __builtin_amdgcn_s_barrier();                        // ... everybody's
+    read_addr(0, 0, 0);
+    read_kk(I0{}, I0{}); read_kk(I0{}, I1{}); read_kk(I0{}, I2{}); read_kk(I0{}, I3{});
+
+    // One K-step; its tap is known at compile time, so the vmcnt immediates below are exact counts.  `last` (wave-uniform): the
+    // last slice, which requests no further slab and, from tap 9 - D on, no further weights.
+    auto step = [&](auto setc, auto tapc, const int cs, const bool last) {
+        constexpr int S = decltype(setc)::value, TAP = decltype(tapc)::value;
+        using Sn = std::integral_constant<int, 1 - S>;
+        // loads this wave issues during tap t of a slice: 2 weight pieces (+ 1 slab piece)
+        constexpr auto issued = [](int t, bool lst) { return lst ? (t < 9 - D ? 2 : 0) : 2 + (t < SPW ? 1 : 0); };
+        constexpr int n_mid = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, false) : 2)) + issued(TAP, false);
+        constexpr int n_last = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, true) : 2)) + issued(TAP, true);
+        // (a) requests: weights of step s + D into the stage step s just vacated; one piece of the next slice's slab.
+        //     Ring stage of step s = 9 cs + TAP is s mod NW: TAP mod 3 for three stages, (cs + TAP) mod 4 for four
+        const int st = NW == 3 ? TAP % 3 : ((cs + TAP) & 3);
+        auto requests = [&]() {
+            if constexpr (MODE & 1) return;
+            if (!last || TAP < 9 - D) issue_w(cs + (TAP + D >= 9 ? 1 : 0), (TAP + D) % 9, st);
+            if constexpr (TAP < SPW)
+                if (!last) ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192, (u32)((cs + 1) * 128));
+        };
+        if constexpr (MODE & 8) { if (wave < 4) requests(); } else requests();
+        // (b) the MFMAs of step s, interleaved with the fragment reads of step s + 1.  The step opens with MFMAs: hipcc puts an
+        //     s_waitcnt lgkmcnt(0) in front of the first use of a register set (it cannot see that (c) of the previous step already
+        //     waited), and that must not catch reads issued in this step.  After the last step the reads fetch a stage nobody
+        //     uses (in-bounds LDS addresses): cheaper than a branch around every group.
+        read_addr(cs + (TAP == 8 ? 1 : 0), (TAP + 1) % 9, NW == 3 ? (TAP + 1) % 3 : ((cs + TAP + 1) & 3));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 32)) mfma_kk(setc, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 2)) { read_kk(Sn{}, I0{}); read_kk(Sn{}, I1{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 32)) mfma_kk(setc, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE & 8) { if (wave >= 4) requests(); }
+        if constexpr (!(MODE & 2)) read_kk(Sn{}, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 32)) mfma_kk(setc, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 2)) read_kk(Sn{}, I3{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(MODE & 32)) mfma_kk(setc, I3{});
+        __builtin_amdgcn_sched_barrier(0);
+        // (c) everything step s + 2 needs has landed (in-order completion: only the newest D - 2 steps' requests may be in
+        //     flight), this wave's fragment reads are done (their stage is overwritten next step), then the barrier
+        if constexpr (!(MODE & 4)) {
+            if (!last) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_last) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    auto slice = [&](auto parc, const int cs, const bool last) {      // the nine taps of slice cs; register set of tap t: (par + t) & 1
+        constexpr int P = decltype(parc)::value;
+        using A = std::integral_constant<int, P>; using B = std::integral_constant<int, 1 - P>;
+        step(A{}, std::integral_constant<int, 0>{}, cs, last); step(B{}, std::integral_constant<int, 1>{}, cs, last);
+        step(A{}, std::integral_constant<int, 2>{}, cs, last); step(B{}, std::integral_constant<int, 3>{}, cs, last);
+        step(A{}, std::integral_constant<int, 4>{}, cs, last); step(B{}, std::integral_constant<int, 5>{}, cs, last);
+        step(A{}, std::integral_constant<int, 6>{}, cs, last); step(B{}, std::integral_constant<int, 7>{}, cs, last);
+        step(A{}, std::integral_constant<int, 8>{}, cs, last);
+    };
+    for (int cs = 0; cs < csteps; cs += 2) {             // csteps is even (Cin % 128 == 0): the last slice is an odd one
+        slice(I0{}, cs, false);
+        slice(I1{}, cs + 1, cs + 2 >= csteps);
+    }
+
+    // ---- epilogue: bias + ReLU + one rounding, transpose through LDS (the slab buffers are dead), 16-byte stores ------------
+    unsigned char* stage = lds + SLAB0 + wave * 8192;    // [64 positions][128 B = 64 channels]
+    float bv[2][16];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
+                bv[ci][4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
+            }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int px = pi * 32 + r31;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[ci][pi][4 * g + e] + bv[ci][4 * g + e];
+                    o[e] = p.relu ? ch_relu(v) : v;
+                }
+                const int chunk = ci * 4 + g;
+                *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
+                    make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private stage: DS operations of one wave execute in order
+    {
+        int q = q0 + wn * 64 + (lane >> 3);
+        int b = q / (H1 * W1);
+        const int r = q - b * (H1 * W1);
+        int h = r / W1, w = r - h * W1;
+        const int c = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = j * 8 + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+            if (w < W && h < H && q < p.Q)
+                *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + h) * W + w)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+            q += 8;
+            w += 8;
+            while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+        }
+    }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+template <int NW, int SPW, int MODE>
+__global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
+    convh_body<NW, SPW, MODE>(p, lds);
+#endif
+}
+
+template <int MODE>
+static void convh_launch(const ConvHParams& p, int grid, hipStream_t stream) {
+    // slab rows = 256 + 2 W + 4 <= 64 SPW: three weight stages + 7 pieces per wave (W <= 94), four + 6 (W <= 62), four + 5 (W <= 30)
+    if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
+    else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL((convh_kernel<3, 7, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+// y[b,h,w,co] = act(bias[co] + sum_{kh,kw,ci} x[b, h + kh - 1, w + kw - 1, ci] * w[co,kh,kw,ci]), zero padding: the 3x3 'same'
+// convolutions of the deep VGG blocks.  Cin % 128 == 0, Cout % 128 == 0, W <= 94; SSDHIP_E_BADARG otherwise (callers fall back to
+// ssdhip_conv2d_same_nhwc_bf16, whose results are bit-identical).
+extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                             int Cin, int Cout, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM) || W > 94) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2;
+    const long long Q = (long long)B * (H + 1) * (W + 1);
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+    ConvHParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
+    p.Q = (int)Q;
+    p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+    p.n_tiles = Cout / CH_BM;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+    const int grid = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+    int mode = 0;
+    if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
+    switch (mode) {
+        case 8: convh_launch<8>(p, grid, stream); break;
+#if defined(SSDHIP_PROFILE)                               // ablations (wrong results): tools/ablate_convh.py
+        case 1: convh_launch<1>(p, grid, stream); break;
+        case 2: convh_launch<2>(p, grid, stream); break;
+        case 3: convh_launch<3>(p, grid, stream); break;
+        case 4: convh_launch<4>(p, grid, stream); break;
+        case 7: convh_launch<7>(p, grid, stream); break;
+        case 32: convh_launch<32>(p, grid, stream); break;
+        case 34: convh_launch<34>(p, grid, stream); break;
+#endif
+        default: convh_launch<0>(p, grid, stream); break;
+    }
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

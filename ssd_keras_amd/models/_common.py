@@ -201,6 +201,12 @@ class SSDModel(nn.Module):
                 and conv.padding_mode == 'zeros' and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
                 and conv.bias is not None)
 
+    @staticmethod
+    def _halo_ok(conv, x):
+        """csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin and Cout multiples of 128, map at most 94 wide (the slab must fit in LDS)."""
+        return (conv.kernel_size == (3, 3) and conv.dilation == (1, 1) and conv.in_channels % 128 == 0
+                and conv.out_channels % 128 == 0 and x.shape[3] <= 94)
+
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
         import os
@@ -262,6 +268,8 @@ class SSDModel(nn.Module):
                 cands["igemm6"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=6)
                 if conv.in_channels == 64 and k == 3 and conv.dilation[0] == 1:
                     cands["c64"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=relu, pool=False)
+                if self._halo_ok(conv, x):
+                    cands["halo"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=1, relu=relu, variant=7)
             elif self._igemm_general_ok(conv, x):
                 cands["igemm"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                     dilation=conv.dilation[0], relu=relu)
@@ -322,6 +330,8 @@ class SSDModel(nn.Module):
                      "igemm6": lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=d, relu=relu, variant=6)}
             if conv.in_channels == 64 and k == 3 and d == 1:
                 cands["c64"] = lambda xb, wb, bb: nat.conv3x3_c64(xb, wb, bb, relu=relu, pool=False)
+            if self._halo_ok(conv, x):
+                cands["halo"] = lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=1, relu=relu, variant=7)
         elif self._igemm_general_ok(conv, x):
             cands = {"igemm": lambda xb, wb, bb: nat.conv2d(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
                                                             relu=relu)}
@@ -351,6 +361,10 @@ class SSDModel(nn.Module):
                 cands["igemm6"] = lambda: nat.bias_act_maxpool(
                     nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True, variant=6), None, kernel, stride,
                     pad, ceil_mode, relu=False)
+                if self._halo_ok(conv, x):               # the slab kernel + a separate pooling pass can beat the fused epilogue
+                    cands["halo"] = lambda: nat.bias_act_maxpool(
+                        nat.conv2d_same(x, conv.weight, conv.bias, dilation=1, relu=True, variant=7), None, kernel, stride, pad,
+                        ceil_mode, relu=False)
                 if (kernel == 2 and stride == 2 and pad == 0 and (ceil_mode or x.shape[2] % 2 == 0) and (ceil_mode or x.shape[3] % 2 == 0)):
                     # pooling fused into the convolution's epilogue: the full-resolution activation is never written
                     cands["igemm_pool"] = lambda: nat.conv2d_same_pool2(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True)
@@ -419,7 +433,19 @@ class SSDModel(nn.Module):
         self.__dict__["_shadow_fresh"] = False
         x = self.preprocess(images)
         dtype = next(self.parameters()).dtype
-        feats = self.features(x.to(dtype) if not torch.is_autocast_enabled() else x)
+        xin = x.to(dtype) if not torch.is_autocast_enabled() else x
+        split = self._split_heads(xin)
+        if split is not None:
+            feats, confs = split
+            sizes = [(f.shape[2], f.shape[3]) for f in feats]
+            anchors = self.anchors_and_variances(sizes, x.device)
+            head_args = (confs, [None] * len(confs), [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
+                         [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
+            if decode and self.decoder is not None and self.n_classes <= 81:
+                return self.decoder.forward_from_heads(*head_args)
+            pred = nat.assemble_predictions(*head_args)
+            return self.decoder(pred) if (decode and self.decoder is not None) else pred
+        feats = self.features(xin)
         b = x.shape[0]
         sizes = [(f.shape[2], f.shape[3]) for f in feats]
         if all(self._fused_head_ok(f, ch) for f, ch in zip(feats, self.conf_heads)):
@@ -449,6 +475,44 @@ class SSDModel(nn.Module):
         anchors = self.anchors_and_variances(sizes, conf.device)
         pred = torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
         return self.decoder(pred) if (decode and self.decoder is not None) else pred
+
+    def _split_heads(self, x):
+        """Fused bf16 inference only.  The packed heads of the trunk's two source maps (conv4_3, fc7: ~85 % of the head FLOPs) run
+        on a SECOND HIP stream while the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- run on
+        the current one; the extra maps' heads follow as one grouped launch.  Returns (feature maps, packed head outputs) or None
+        when the model / dtype / mode does not qualify (SSDHIP_HEAD_OVERLAP=0 switches it off)."""
+        import os
+        if (os.environ.get("SSDHIP_HEAD_OVERLAP", "1") == "0" or not hasattr(self, "trunk_features") or not x.is_cuda
+                or torch.is_grad_enabled() or not self.fused_inference or x.dtype != torch.bfloat16
+                or len(self.conf_heads) > 8 + 2):
+            return None
+        if not all(conv.weight.dtype == torch.bfloat16 for conv in self.conf_heads):
+            return None
+        early = self.trunk_features(x)
+        n_early = len(early)
+        if not all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
+                   for f, ch, lh in zip(early, self.conf_heads, self.loc_heads)):
+            rest = self.extra_features(early[1])
+            self.__dict__["_split_feats_cache"] = early + rest      # not reached on the shipped models; keep the general path correct
+            return None if True else None
+        main = torch.cuda.current_stream(x.device)
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != x.device:
+            side = torch.cuda.Stream(device=x.device)
+            self.__dict__["_side_stream"] = side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            big = nat.conv2d_same_group(list(early), [self._packed_head_weight(l) for l in range(n_early)], None, relu=False)
+        for t in list(early) + big:
+            t.record_stream(side)
+        rest = self.extra_features(early[1])
+        ok_rest = all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
+                      for f, ch, lh in zip(rest, self.conf_heads[n_early:], self.loc_heads[n_early:]))
+        if not ok_rest:
+            raise RuntimeError("predictor heads of the extra layers do not qualify for the packed kernel")
+        small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None, relu=False)
+        main.wait_stream(side)
+        return early + rest, big + small
 
     def _heads_grouped(self, feats):
         outs = nat.conv2d_same_group(list(feats), [self._packed_head_weight(l) for l in range(len(feats))], None, relu=False)

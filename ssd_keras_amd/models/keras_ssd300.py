@@ -71,14 +71,23 @@ class SSD300(_VGGBase):
                                           [n + '_mbox_priorbox' for n in self.NAMES])
         he_normal_(self)
 
-    def features(self, x):
-        ca = self.conv_act
+    def trunk_features(self, x):
+        """The two source maps the VGG trunk yields (conv4_3 after L2Normalization, fc7): their predictor heads do not depend on
+        the extra layers, which `extra_features` derives from fc7."""
         conv4_3, fc7 = self._vgg(x)
+        return [self.conv4_3_norm(conv4_3), fc7]
+
+    def extra_features(self, fc7):
+        ca = self.conv_act
         conv6_2 = ca(self.conv6_2, ca(self.conv6_1, fc7))
         conv7_2 = ca(self.conv7_2, ca(self.conv7_1, conv6_2))
         conv8_2 = ca(self.conv8_2, ca(self.conv8_1, conv7_2))
         conv9_2 = ca(self.conv9_2, ca(self.conv9_1, conv8_2))
-        return [self.conv4_3_norm(conv4_3), fc7, conv6_2, conv7_2, conv8_2, conv9_2]
+        return [conv6_2, conv7_2, conv8_2, conv9_2]
+
+    def features(self, x):
+        early = self.trunk_features(x)
+        return early + self.extra_features(early[1])
 
     def predictor_sizes(self):
         out = []

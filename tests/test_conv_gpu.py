@@ -225,3 +225,71 @@ def test_resident_weight_conv_c64(case):
     rms = ref.pow(2).mean().sqrt().item()
     bad = int(((got - ref).abs() > ref.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
     assert bad == 0
+
+
+HALO_CASES = [  # B, H, W, Cin, Cout, bias, relu      (csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin % 128 == 0, Cout % 128 == 0)
+    (2, 38, 38, 512, 512, True, True),       # conv4_2: four weight stages, six slab pieces per wave
+    (1, 75, 75, 256, 256, True, True),       # conv3_2: three weight stages, seven slab pieces (all 160 KB of LDS)
+    (2, 19, 19, 512, 512, True, True),       # conv5_x: four stages, five pieces
+    (3, 10, 10, 128, 256, True, False),      # two slices only (first + last), no ReLU
+    (1, 64, 64, 256, 512, False, True),      # SSD512 conv4_1, no bias
+    (2, 5, 94, 128, 128, True, True),        # the widest map the slab supports
+    (1, 1, 1, 128, 128, True, True),         # one pixel: eight of the nine taps are padding
+    (5, 7, 31, 256, 128, True, True),        # W + 1 = 32: a tile row boundary on every image row
+    (1, 3, 63, 128, 128, True, True),        # W + 1 = 64
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_slab_conv_equals_implicit_gemm(case):
+    """ssdhip_conv3x3_halo_nhwc_bf16 promises the implicit-GEMM kernel's accumulation order: BIT-identical outputs; and the
+    float32 reference within the usual bar.  Repeated launches must agree with each other (LDS-DMA / barrier races show up as rare
+    differing tiles)."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, has_bias, relu = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
+    base = nat.conv2d_same(x, wt, bias, dilation=1, relu=relu, variant=4)
+    got = nat.conv2d_same(x, wt, bias, dilation=1, relu=relu, variant=7)
+    assert got.shape == base.shape and got.dtype == base.dtype
+    diff = int((got.view(torch.int16) != base.view(torch.int16)).sum().item())
+    assert diff == 0, "%d of %d outputs differ from the implicit-GEMM kernel" % (diff, got.numel())
+    want = F.conv2d(x.float(), wt.float(), bias.float() if has_bias else None, 1, 1, 1)
+    if relu:
+        want = torch.relu(want)
+    rms = want.pow(2).mean().sqrt().item()
+    err = (got.float() - want).abs()
+    assert int((err > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
+    for _ in range(10):
+        again = nat.conv2d_same(x, wt, bias, dilation=1, relu=relu, variant=7)
+        assert torch.equal(again.view(torch.int16), got.view(torch.int16))
+
+
+def test_slab_conv_full_batch_race_screen():
+    """BASELINE configs[1] sizes (batch 32): conv3_2, conv4_2, conv5_1 -- every CU busy, 20 launches each, all bit-identical to
+    the implicit-GEMM kernel."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    for (B, H, W, Cin, Cout) in ((32, 75, 75, 256, 256), (32, 38, 38, 512, 512), (32, 19, 19, 512, 512), (32, 75, 75, 128, 256)):
+        g = torch.Generator(device="cuda").manual_seed(B * H + Cin)
+        x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+        wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+        bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+        base = nat.conv2d_same(x, wt, bias, dilation=1, relu=True, variant=4).view(torch.int16)
+        for _ in range(20):
+            got = nat.conv2d_same(x, wt, bias, dilation=1, relu=True, variant=7).view(torch.int16)
+            assert torch.equal(got, base), (B, H, W, Cin, Cout)
+
+
+def test_slab_conv_rejects_unsupported_shapes():
+    import torch
+    from ssd_keras_amd import _native as nat
+    for (H, W, Cin, Cout, dil) in ((8, 95, 128, 128, 1), (8, 8, 64, 128, 1), (8, 8, 128, 64, 1), (8, 8, 128, 128, 2)):
+        x = torch.zeros((1, H, W, Cin), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
+        wt = torch.zeros((Cout, 3, 3, Cin), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
+        with pytest.raises(nat.SsdHipError):
+            nat.conv2d_same(x, wt, None, dilation=dil, relu=True, variant=7)

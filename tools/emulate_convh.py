@@ -1,0 +1,202 @@
+"""CPU emulation of the INDEX SCHEME of csrc/ssdhip_convh.hip (development aid, no GPU needed).
+
+The slab kernel's correctness rests on integer bookkeeping that is easy to get wrong and expensive to debug on a GPU box:
+the padded position grid (one dummy column per row, one dummy row per image), the slab <-> position map, the source-side
+chunk permutation of the LDS-DMA image, the per-tap row displacement with its recomputed swizzle, the weight ring, the MFMA
+fragment <-> (channel, position) map and the epilogue's position -> pixel map.  This script replays exactly that bookkeeping
+lane by lane in NumPy -- LDS as a byte-addressed array of 16-byte chunks, an LDS-DMA piece as "lane L writes chunk at dst + 16 L",
+an MFMA as the documented 32x32x16 operand / result layout -- and compares the result with a direct convolution.
+
+    python tools/emulate_convh.py            # a few small shapes, ~10 s
+"""
+import itertools
+import sys
+
+import numpy as np
+
+BN, BM, WST = 256, 128, 128 * 128
+
+
+def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
+    rng = np.random.RandomState(seed)
+    x = rng.randint(-3, 4, size=(B, H, W, Cin)).astype(np.float32)
+    wt = rng.randint(-2, 3, size=(Cout, 3, 3, Cin)).astype(np.float32)
+    xf = x.reshape(-1)                               # element units; the kernel's byte offsets are 2x these
+    wf = wt.reshape(-1)
+    D = NW
+    SLAB0, SLB = NW * WST, SPW * 8192
+    lds_bytes = SLAB0 + 2 * SLB
+    W1, H1 = W + 1, H + 1
+    Q = B * H1 * W1
+    q_tiles = (Q + BN - 1) // BN
+    n_tiles = Cout // BM
+    csteps = Cin // 64
+    assert Cin % 128 == 0 and Cout % 128 == 0 and 256 + 2 * W + 4 <= 64 * SPW and SPW + D <= 10
+    y = np.full((B, H, W, Cout), np.nan, np.float32)
+    OOB = None
+
+    for qt, nt in itertools.product(range(q_tiles), range(n_tiles)):
+        q0, co0 = qt * BN, nt * BM
+        # LDS as chunks of 8 elements (16 bytes); chunk address = byte address / 16
+        lds = np.full((lds_bytes // 16, 8), np.nan, np.float32)
+        SP = BN + 2 * W + 4
+
+        def dma(src, voff_elems, soff_elems, dst_byte):           # one wave-wide piece: per-lane element offsets or OOB
+            for lane in range(64):
+                v = voff_elems[lane]
+                c = dst_byte // 16 + lane
+                if v is OOB:
+                    lds[c] = 0.0
+                else:
+                    o = v + soff_elems
+                    lds[c] = src[o:o + 8]
+
+        # per-(wave, lane) descriptors
+        xoff = np.empty((8, 64, SPW), object)
+        woff = np.empty((8, 64, 2), object)
+        for wave in range(8):
+            for lane in range(64):
+                row0 = wave * 8 + (lane >> 3)
+                q = q0 - (W + 2) + row0
+                b = h = w = 0
+                if q >= 0:
+                    b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
+                else:
+                    w = q
+                for k in range(SPW):
+                    row = row0 + 64 * k
+                    j = (lane & 7) ^ ((row >> 1) & 7)
+                    ok = 0 <= w < W and h < H and q < Q and row < SP
+                    xoff[wave, lane, k] = (((b * H + h) * W + w) * Cin + j * 8) if ok else OOB
+                    q += 64; w += 64
+                    while w >= W1:
+                        w -= W1; h += 1
+                        if h == H1:
+                            h = 0; b += 1
+                for i in range(2):
+                    row = (i * 8 + wave) * 8 + (lane >> 3)
+                    j = (lane & 7) ^ ((row >> 1) & 7)
+                    woff[wave, lane, i] = (co0 + row) * 9 * Cin + j * 8
+
+        def issue_w(cs, tap, stage):
+            for wave in range(8):
+                for i in range(2):
+                    dma(wf, woff[wave, :, i], tap * Cin + cs * 64, stage * WST + wave * 1024 + i * 8192)
+
+        def issue_slab_piece(cs, k):
+            for wave in range(8):
+                dma(xf, xoff[wave, :, k], cs * 64, SLAB0 + (cs & 1) * SLB + wave * 1024 + k * 8192)
+
+        acc = np.zeros((8, 64, 2, 2, 16), np.float32)     # [wave][lane][ci][pi][v]
+
+        def read_frags(cs, tap, stage):
+            """-> fa[wave][lane][kk][ci] (8 elems), fb[wave][lane][kk][pi]"""
+            fa = np.empty((8, 64, 4, 2, 8), np.float32)
+            fb = np.empty((8, 64, 4, 2, 8), np.float32)
+            toff = (tap // 3) * W1 + tap % 3
+            sl = SLAB0 + (cs & 1) * SLB
+            for wave in range(8):
+                wm, wn = wave >> 2, wave & 3
+                for lane in range(64):
+                    r31, khalf = lane & 31, lane >> 5
+                    rowa = wm * 64 + r31
+                    prow = wn * 64 + r31
+                    for kk in range(4):
+                        abase = rowa * 128 + (((2 * kk + khalf) ^ ((rowa >> 1) & 7)) << 4)
+                        for ci in range(2):
+                            fa[wave, lane, kk, ci] = lds[(stage * WST + abase + ci * 4096) // 16]
+                        for pi in range(2):
+                            row = prow + pi * 32 + toff
+                            rb = sl + (row << 7)
+                            re = (((row >> 1) & 7) ^ khalf) << 4
+                            fb[wave, lane, kk, pi] = lds[(rb + (re ^ (kk << 5))) // 16]
+            return fa, fb
+
+        def mfma_step(fa, fb):
+            # v_mfma_f32_32x32x16: A[row = r31][k = 8 khalf ..], B[k = 8 khalf ..][col = r31]; D[row = 8 g + 4 khalf + e][col = r31] in v = 4 g + e
+            for wave in range(8):
+                for kk in range(4):
+                    for ci in range(2):
+                        A = np.zeros((32, 16), np.float32)
+                        for lane in range(64):
+                            A[lane & 31, 8 * (lane >> 5):8 * (lane >> 5) + 8] = fa[wave, lane, kk, ci]
+                        for pi in range(2):
+                            Bm = np.zeros((16, 32), np.float32)
+                            for lane in range(64):
+                                Bm[8 * (lane >> 5):8 * (lane >> 5) + 8, lane & 31] = fb[wave, lane, kk, pi]
+                            Dm = A @ Bm
+                            for lane in range(64):
+                                r31, khalf = lane & 31, lane >> 5
+                                for g in range(4):
+                                    for e in range(4):
+                                        acc[wave, lane, ci, pi, 4 * g + e] += Dm[8 * g + 4 * khalf + e, r31]
+
+        # prologue
+        for k in range(SPW):
+            issue_slab_piece(0, k)
+        for d in range(D):
+            issue_w(0, d, d)
+        cur = read_frags(0, 0, 0)
+        assert not np.isnan(cur[0]).any() and not np.isnan(cur[1]).any()
+        for cs in range(csteps):
+            last = cs + 1 >= csteps
+            for tap in range(9):
+                s = 9 * cs + tap
+                st = s % NW
+                assert st == (tap % 3 if NW == 3 else (cs + tap) & 3)
+                if not last or tap < 9 - D:
+                    t2 = (tap + D) % 9
+                    issue_w(cs + (1 if tap + D >= 9 else 0), t2, st)
+                if tap < SPW and not last:
+                    issue_slab_piece(cs + 1, tap)
+                # NOTE: the emulation completes loads instantly, so it checks addressing, not the wait counts
+                nxt = read_frags(cs + (1 if tap == 8 else 0), (tap + 1) % 9, (s + 1) % NW) if s + 1 < 9 * csteps else None
+                mfma_step(*cur)
+                cur = nxt
+        # epilogue
+        for wave in range(8):
+            wm, wn = wave >> 2, wave & 3
+            stage = np.full((64, 8, 8), np.nan, np.float32)            # [px][chunk position][8 channels]
+            for lane in range(64):
+                r31, khalf = lane & 31, lane >> 5
+                for pi in range(2):
+                    px = pi * 32 + r31
+                    for ci in range(2):
+                        for g in range(4):
+                            chunk = ci * 4 + g
+                            stage[px, chunk ^ (px & 7), khalf * 4:khalf * 4 + 4] = acc[wave, lane, ci, pi, 4 * g:4 * g + 4]
+            for lane in range(64):
+                q = q0 + wn * 64 + (lane >> 3)
+                b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
+                c = lane & 7
+                for j in range(8):
+                    px = j * 8 + (lane >> 3)
+                    v = stage[px, c ^ (px & 7)]
+                    if w < W and h < H and q < Q:
+                        ch = co0 + wm * 64 + c * 8
+                        assert np.isnan(y[b, h, w, ch])
+                        y[b, h, w, ch:ch + 8] = v
+                    q += 8; w += 8
+                    while w >= W1:
+                        w -= W1; h += 1
+                        if h == H1:
+                            h = 0; b += 1
+
+    # direct convolution
+    xp = np.zeros((B, H + 2, W + 2, Cin), np.float32)
+    xp[:, 1:-1, 1:-1] = x
+    ref = np.zeros((B, H, W, Cout), np.float32)
+    for kh in range(3):
+        for kw in range(3):
+            ref += np.einsum("bhwc,oc->bhwo", xp[:, kh:kh + H, kw:kw + W], wt[:, kh, kw])
+    return np.array_equal(y, ref), y, ref
+
+
+if __name__ == "__main__":
+    ok = True
+    for (B, H, W, Cin, Cout, NW, SPW) in ((2, 5, 6, 128, 128, 4, 5), (1, 9, 40, 128, 128, 4, 6), (3, 3, 70, 128, 128, 3, 7),
+                                          (2, 19, 19, 256, 256, 4, 5)):
+        good, y, ref = emulate(B, H, W, Cin, Cout, NW, SPW)
+        print((B, H, W, Cin, Cout, NW, SPW), "OK" if good else "MISMATCH (%d wrong, %d unwritten)" % ((y != ref).sum(), np.isnan(y).sum()))
+        ok &= good
+    sys.exit(0 if ok else 1)
