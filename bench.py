@@ -43,6 +43,7 @@ def parse():
                     help="0 (default): decode on the forward's stream; 1: on a second stream beside the next forward -- measured 3 %% "
                          "SLOWER since the convolutions fill the CUs (the persistent conv64 kernel owns every CU's LDS)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images for the CPU baseline (0: auto, ~10-30 s)")
+    ap.add_argument("--graph", type=int, default=1, help="1: the timed step is one HIP-graph launch (model.graphed); 0: eager launches")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (encoder / loss / sparse decode / training step)")
     ap.add_argument("--train-steps", type=int, default=6, help="timed steps of the training-step leg (0: skip it)")
     return ap.parse_args()
@@ -124,11 +125,30 @@ def main():
     # every step's decode finishes inside the timed region either way.
     dec_stream = torch.cuda.Stream(device=dev) if args.overlap else torch.cuda.current_stream(dev)
     dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # The step as ONE HIP-graph launch (the same kernels on the same streams, recorded once): the eager step issues ~45 launches
+    # from Python, and on a busy host that alone can exceed the 3 ms of GPU work.  --graph 0, --overlap 1 or a failed capture: eager.
+    runner, launch = None, "eager (one Python-issued launch per kernel)"
+    if args.graph and not args.overlap:
+        try:
+            runner = model.graphed(images)
+            for _ in range(3):
+                out = runner(images)
+            torch.cuda.synchronize()
+            launch = "hip_graph (forward + DecodeDetections captured once, replayed per step)"
+        except Exception as exc:                     # noqa: BLE001 -- reported, and the eager step is the same work
+            runner = None
+            launch = "eager (graph capture failed: %s)" % (repr(exc)[:160])
+            torch.cuda.synchronize()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    g0.record()
     for i in range(args.steps):
         with torch.no_grad():
+            if runner is not None:
+                out = runner(images)
+                continue
             if not args.overlap:
                 out = model(images)                  # forward + DecodeDetections straight from the head outputs (no y_pred in HBM)
                 continue
@@ -141,9 +161,11 @@ def main():
                 out = model.decoder(pred)
                 dec_ev[i][1].record()
             pred.record_stream(dec_stream)
+    g1.record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    gpu_ms_per_step = g0.elapsed_time(g1) / args.steps   # device-side span of the same K steps (< wall clock when the host is the limit)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -314,6 +336,7 @@ def main():
                                        "300x300x3 uint8-range images" % B,
                            "per_gpu_batch": B, "global_batch": world * B, "anchors": int(N), "classes": int(C),
                            "conv_dtype": args.dtype, "decode_dtype": "f32 decode + f32 IoU (DecodeDetections layer); decode_detections: f32 decode, f64 IoU", "parallelism": "replicas x%d" % world,
+                           "launch": launch, "gpu_ms_per_step": round(gpu_ms_per_step, 4),
                            "decode_stream": "second HIP stream, overlapped with the next forward" if args.overlap else
                                             "same stream; DecodeDetections reads the head outputs directly (no y_pred in HBM)"},
                 "roofline": roofline, "conv_roofline": conv, "cpu_baseline": cpu}

@@ -282,6 +282,12 @@ int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, const void* 
  *   y [B,Ho,Wo,Cout], Ho = (H + 2*pad - dilation*(kernel-1) - 1) / stride + 1.  Tensors below 2 GiB (31-bit buffer offsets). */
 int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
                             int kernel, int stride, int pad, int dilation, int relu, void* stream);
+/* The same with an explicit kernel variant (4: the default, two LDS stages; 5 / 6: the multi-stage ring of 32-channel slices with
+ * loads three / two steps ahead of the MFMAs): the 10x10 ... 1x1 maps of the extra layers leave at most one workgroup per CU, where
+ * only the prefetch depth hides the L2 latency.  Results are bit-identical across variants. */
+int ssdhip_conv2d_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                    int Cin, int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream);
+
 /* Profiling aid: the same with an explicit kernel variant (4: the shipped kernel -- 128-pixel tile, two LDS stages, buffer-addressed
  * LDS-DMA loads, batched fragment reads; 1: its predecessor with per-lane pointers; 3: 256-pixel tile, three-stage weight pipeline,
  * kw-reuse of the activation strip; 5 / 6: four / three-stage LDS ring of 32-channel slices; 9: eight waves per workgroup with the

@@ -451,7 +451,7 @@ def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
     return y
 
 
-def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True):
+def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True, variant=None):
     """Convolution (kernel 1 or 3, stride 1..4, zero padding <= (k//2)*dilation: torch.nn.Conv2d semantics) + bias + ReLU in
     ONE libssdhip MFMA kernel -- the strided / 'valid' extra layers of the SSD trunk.  Layouts as conv2d_same."""
     torch = _torch()
@@ -459,6 +459,8 @@ def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True):
     if not getattr(lib, "_convgen_bound", False):
         lib.ssdhip_conv2d_nhwc_bf16.restype = ctypes.c_int
         lib.ssdhip_conv2d_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 10 + [ctypes.c_void_p]
+        lib.ssdhip_conv2d_nhwc_bf16_variant.restype = ctypes.c_int
+        lib.ssdhip_conv2d_nhwc_bf16_variant.argtypes = [ctypes.c_int] + lib.ssdhip_conv2d_nhwc_bf16.argtypes
         lib._convgen_bound = True
     x, (b, h, w, cin) = _nhwc_bf16(x, "x")
     cout, cin_w, kh, kw = weight.shape
@@ -471,8 +473,9 @@ def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True):
         raise SsdHipError("convolution output would be empty")
     y = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
     with torch.cuda.device(x.device):
-        rc = lib.ssdhip_conv2d_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(kh), int(stride), int(padding),
-                                         int(dilation), int(bool(relu)), current_stream_ptr(x.device))
+        args = (_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(kh), int(stride), int(padding), int(dilation),
+                int(bool(relu)), current_stream_ptr(x.device))
+        rc = lib.ssdhip_conv2d_nhwc_bf16(*args) if variant is None else lib.ssdhip_conv2d_nhwc_bf16_variant(int(variant), *args)
     check(rc, "ssdhip_conv2d_nhwc_bf16")
     return y
 

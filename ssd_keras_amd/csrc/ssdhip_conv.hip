@@ -600,14 +600,36 @@ __device__ __forceinline__ void conv_igemm5_body(const ConvParams& p, unsigned c
     const int csteps = Cin / BK, T = KK * csteps;
 
     const int neg = (half * dil * p.W + half * dil) * Cin * 2;
-    const i32x4 rx = make_rsrc(p.x, -(long)neg, p.M * Cin * 2 + 2 * neg);
+    const i32x4 rx = make_rsrc(p.x, -(long)neg, p.Min * Cin * 2 + 2 * neg);
     const i32x4 rw = make_rsrc(p.w, 0, p.Cout * KK * Cin * 2);
     const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     // ---- per-thread load descriptors: a 1 KiB piece = 16 rows x 64 bytes; lane L -> row L >> 2, position L & 3 ------
     u32 xoff[XP], xok[XP], woff[WP];
     const int pos = lane & 3;
-    {
+    if (p.stride != 1 || p.coff != 0) {
+        // strided and / or partially padded (see v4): the tile's OUTPUT pixels, each centred on its own input pixel
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int row = (i * 4 + wave) * 16 + (lane >> 2);
+            const int j = pos ^ ((row >> 2) & 3);
+            const int m = m0 + row;
+            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, b = t / p.Ho;
+            const int hq = ho * p.stride + p.coff, wq = wo * p.stride + p.coff;
+            u32 rmask = 0, cmask = 0;
+            for (int k = 0; k < KS; ++k) {
+                const int d = (k - half) * dil;
+                if ((unsigned)(hq + d) < (unsigned)p.H) rmask |= 1u << k;
+                if ((unsigned)(wq + d) < (unsigned)p.W) cmask |= 1u << k;
+            }
+            u32 ok = 0;
+            if (m < p.M)
+                for (int kh = 0; kh < KS; ++kh)
+                    if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
+            xok[i] = ok;
+            xoff[i] = (u32)((b * p.H + hq) * p.W + wq) * (u32)(Cin * 2) + (u32)(j * 16);
+        }
+    } else {
         int m = m0 + wave * 16 + (lane >> 2);
         int wq = m % p.W, hq = (m / p.W) % p.H;
 #pragma unroll
@@ -972,8 +994,8 @@ extern "C" int ssdhip_conv2d_same_nhwc_bf16(const void* x, const void* weight, c
 //   Ho = (H + 2*pad - dil*(kernel-1) - 1) / stride + 1 (same for Wo).
 // The SSD extra layers: conv6_2 / conv7_2 (ZeroPadding2D(1) + 3x3 stride 2, models/keras_ssd300.py:302-307) and conv8_2 /
 // conv9_2 (3x3 'valid', :310-313).  Same kernel as the 'same' convolution: only the tile prologue's pixel -> address map differs.
-extern "C" int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
-                                       int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream_) {
+static int conv_general_run(int variant, const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                            int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || dilation <= 0 || dilation > 8) return SSDHIP_E_BADARG;
     if ((kernel != 1 && kernel != 3) || stride < 1 || stride > 4) return SSDHIP_E_BADARG;
@@ -998,9 +1020,31 @@ extern "C" int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const 
     p.n_tiles = Cout / (wide ? 128 : 64);
     p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
     const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
-    if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL(conv_igemm4_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    if (variant == 5) {                        // four-stage ring of 32-channel slices: loads three steps ahead
+        if (wide) hipLaunchKernelGGL((conv_igemm5_kernel<128, 4>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm5_kernel<64, 4>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    } else if (variant == 6) {
+        if (wide) hipLaunchKernelGGL((conv_igemm5_kernel<128, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm5_kernel<64, 3>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    } else {
+        if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL(conv_igemm4_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                                       int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream) {
+    return conv_general_run(4, x, weight, bias, y, B, H, W, Cin, Cout, kernel, stride, pad, dilation, relu, stream);
+}
+
+// The same with an explicit kernel variant: 4 the default (two LDS stages), 5 / 6 the multi-stage ring (loads three / two steps
+// ahead of the MFMAs) -- small maps leave one workgroup per CU, where nothing but the prefetch depth hides the L2 latency.
+extern "C" int ssdhip_conv2d_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y, int B, int H,
+                                               int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation, int relu,
+                                               void* stream) {
+    if (variant != 4 && variant != 5 && variant != 6) return SSDHIP_E_BADARG;
+    return conv_general_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, stride, pad, dilation, relu, stream);
 }
 
 // Profiling aid: the same with an explicit kernel variant (4: the shipped kernel; 1: its predecessor with per-lane

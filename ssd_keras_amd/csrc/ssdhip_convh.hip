@@ -139,12 +139,14 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         woff[i] = (u32)((co0 + row) * (9 * Cin * 2) + j * 16);
     }
 
-    // the weights of tap `tap` of slice `cs` into ring stage `stage` (all wave-uniform)
-    auto issue_w = [&](const int cs, const int tap, const int stage) {
+    // the weights of tap `tap` of slice `cs` into ring stage `stage` (all wave-uniform): this wave's two 1 KiB pieces
+    auto issue_w_piece = [&](const int cs, const int tap, const int stage, const int i) {
         const u32 soff = (u32)((tap * Cin + cs * 64) * 2);
-        const u32 dst = lds0 + stage * CH_WST + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ch_bload(woff[i], rw, dst + i * 8192, soff);
+        ch_bload(woff[i], rw, lds0 + stage * CH_WST + wave * 1024 + i * 8192, soff);
+    };
+    auto issue_w = [&](const int cs, const int tap, const int stage) {
+        issue_w_piece(cs, tap, stage, 0);
+        issue_w_piece(cs, tap, stage, 1);
     };
 
     // ---- fragment addressing -----------------------------------------------------------------------------------------------
@@ -197,6 +199,15 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             for (int pi = 0; pi < 2; ++pi)
                 acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
     };
+    auto read_one = [&](auto setc, auto jc) {             // fragment read j of a step: k16 block j / 4; weights ci 0, 1 then positions pi 0, 1
+        constexpr int S = decltype(setc)::value, j = decltype(jc)::value, kk = j >> 2, w = j & 3;
+        if constexpr (w < 2) fa[S][kk][w] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + w * 4096);
+        else fb[S][kk][w - 2] = *reinterpret_cast<const bf16x8*>(lds + rb[w - 2] + (re[w - 2] ^ (u32)(kk << 5)));
+    };
+    auto mfma_one = [&](auto setc, auto ic) {             // MFMA i of a step: k16 block i / 4, accumulator (ci, pi) = ((i >> 1) & 1, i & 1)
+        constexpr int S = decltype(setc)::value, i = decltype(ic)::value, kk = i >> 2, ci = (i >> 1) & 1, pi = i & 1;
+        acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
+    };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
@@ -212,8 +223,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 
     // One K-step; its tap is known at compile time, so the vmcnt immediates below are exact counts.  `last` (wave-uniform): the
     // last slice, which requests no further slab and, from tap 9 - D on, no further weights.
-    auto step = [&](auto setc, auto tapc, const int cs, const bool last) {
-        constexpr int S = decltype(setc)::value, TAP = decltype(tapc)::value;
+    auto step = [&](auto grpc, auto setc, auto tapc, const int cs, const bool last) {
+        constexpr int GRP = decltype(grpc)::value, S = decltype(setc)::value, TAP = decltype(tapc)::value;
         using Sn = std::integral_constant<int, 1 - S>;
         // loads this wave issues during tap t of a slice: 2 weight pieces (+ 1 slab piece)
         constexpr auto issued = [](int t, bool lst) { return lst ? (t < 9 - D ? 2 : 0) : 2 + (t < SPW ? 1 : 0); };
@@ -222,6 +233,43 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         // (a) requests: weights of step s + D into the stage step s just vacated; one piece of the next slice's slab.
         //     Ring stage of step s = 9 cs + TAP is s mod NW: TAP mod 3 for three stages, (cs + TAP) mod 4 for four
         const int st = NW == 3 ? TAP % 3 : ((cs + TAP) & 3);
+        if constexpr (MODE & 16) {
+            // Fine schedule: 16 slots, slot i = MFMA i, then 0..2 fragment reads of step s + 1, then at three slots one LDS-DMA
+            // request.  Nothing comes in bursts: with 4 MFMAs, then 8 reads from all eight waves at once, the LDS queue filled up,
+            // the waves stalled on issuing reads and the MFMA pipe drained -- the reads' 512 LDS cycles per step ADDED to the 1024
+            // MFMA cycles (ablation r02n: 29 % of the kernel).  GRP 1 = the second wave of every SIMD: bit 64 delays its reads by
+            // two slots, bit 8 its requests by two slots, so the two waves of a SIMD do not want the same unit at the same time.
+            constexpr int RSH = ((MODE & 64) && GRP) ? 2 : 0, QSH = ((MODE & 8) && GRP) ? 2 : 0;
+            read_addr(cs + (TAP == 8 ? 1 : 0), (TAP + 1) % 9, NW == 3 ? (TAP + 1) % 3 : ((cs + TAP + 1) & 3));
+            auto slot = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, j = i - RSH;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(MODE & 32)) mfma_one(setc, ic);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(MODE & 2)) {
+                    if constexpr (j >= 0 && j < 4) {
+                        read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j)>{});
+                        read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j) + 1>{});
+                    } else if constexpr (j >= 4 && j < 12) {
+                        read_one(Sn{}, std::integral_constant<int, (j < 4 ? 4 : j) + 4>{});
+                    }
+                }
+                if constexpr (!(MODE & 1)) {
+                    if constexpr (i == 1 + QSH || i == 5 + QSH) {
+                        if (!last || TAP < 9 - D) issue_w_piece(cs + (TAP + D >= 9 ? 1 : 0), (TAP + D) % 9, st, i == 1 + QSH ? 0 : 1);
+                    } else if constexpr (i == 9 + QSH && TAP < SPW) {
+                        if (!last) ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192, (u32)((cs + 1) * 128));
+                    }
+                }
+            };
+            slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{}); slot(std::integral_constant<int, 2>{});
+            slot(std::integral_constant<int, 3>{}); slot(std::integral_constant<int, 4>{}); slot(std::integral_constant<int, 5>{});
+            slot(std::integral_constant<int, 6>{}); slot(std::integral_constant<int, 7>{}); slot(std::integral_constant<int, 8>{});
+            slot(std::integral_constant<int, 9>{}); slot(std::integral_constant<int, 10>{}); slot(std::integral_constant<int, 11>{});
+            slot(std::integral_constant<int, 12>{}); slot(std::integral_constant<int, 13>{}); slot(std::integral_constant<int, 14>{});
+            slot(std::integral_constant<int, 15>{});
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         auto requests = [&]() {
             if constexpr (MODE & 1) return;
             if (!last || TAP < 9 - D) issue_w(cs + (TAP + D >= 9 ? 1 : 0), (TAP + D) % 9, st);
@@ -250,6 +298,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(MODE & 32)) mfma_kk(setc, I3{});
         __builtin_amdgcn_sched_barrier(0);
+        }
         // (c) everything step s + 2 needs has landed (in-order completion: only the newest D - 2 steps' requests may be in
         //     flight), this wave's fragment reads are done (their stage is overwritten next step), then the barrier
         if constexpr (!(MODE & 4)) {
@@ -258,18 +307,25 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             __builtin_amdgcn_s_barrier();
         }
     };
-    auto slice = [&](auto parc, const int cs, const bool last) {      // the nine taps of slice cs; register set of tap t: (par + t) & 1
+    auto slice = [&](auto grpc, auto parc, const int cs, const bool last) {   // the nine taps of slice cs; register set of tap t: (par + t) & 1
         constexpr int P = decltype(parc)::value;
         using A = std::integral_constant<int, P>; using B = std::integral_constant<int, 1 - P>;
-        step(A{}, std::integral_constant<int, 0>{}, cs, last); step(B{}, std::integral_constant<int, 1>{}, cs, last);
-        step(A{}, std::integral_constant<int, 2>{}, cs, last); step(B{}, std::integral_constant<int, 3>{}, cs, last);
-        step(A{}, std::integral_constant<int, 4>{}, cs, last); step(B{}, std::integral_constant<int, 5>{}, cs, last);
-        step(A{}, std::integral_constant<int, 6>{}, cs, last); step(B{}, std::integral_constant<int, 7>{}, cs, last);
-        step(A{}, std::integral_constant<int, 8>{}, cs, last);
+        step(grpc, A{}, std::integral_constant<int, 0>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 1>{}, cs, last);
+        step(grpc, A{}, std::integral_constant<int, 2>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 3>{}, cs, last);
+        step(grpc, A{}, std::integral_constant<int, 4>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 5>{}, cs, last);
+        step(grpc, A{}, std::integral_constant<int, 6>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 7>{}, cs, last);
+        step(grpc, A{}, std::integral_constant<int, 8>{}, cs, last);
     };
-    for (int cs = 0; cs < csteps; cs += 2) {             // csteps is even (Cin % 128 == 0): the last slice is an odd one
-        slice(I0{}, cs, false);
-        slice(I1{}, cs + 1, cs + 2 >= csteps);
+    auto k_loop = [&](auto grpc) {
+        for (int cs = 0; cs < csteps; cs += 2) {         // csteps is even (Cin % 128 == 0): the last slice is an odd one
+            slice(grpc, I0{}, cs, false);
+            slice(grpc, I1{}, cs + 1, cs + 2 >= csteps);
+        }
+    };
+    if constexpr ((MODE & 16) && (MODE & (8 | 64))) {    // the two waves of a SIMD run differently ordered code (same barriers)
+        if (wave < 4) k_loop(I0{}); else k_loop(I1{});
+    } else {
+        k_loop(I0{});
     }
 
     // ---- epilogue: bias + ReLU + one rounding, transpose through LDS (the slab buffers are dead), 16-byte stores ------------
@@ -364,20 +420,29 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
     const int grid = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
-    int mode = 0;
+    // Shipped schedule: 80 = fine MFMA / read interleave with the second wave of every SIMD reading two slots later (r02o: 1-7 %
+    // faster than the coarse schedule 0 on every SSD layer, bit-identical).  SSDHIP_CONVH_MODE=0 selects the coarse one.
+    int mode = 80;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     switch (mode) {
+        case 0: convh_launch<0>(p, grid, stream); break;
+#if defined(SSDHIP_PROFILE)                               // other schedules and ablations (1, 2, 4, 32: wrong results): tools/ablate_convh.py
         case 8: convh_launch<8>(p, grid, stream); break;
-#if defined(SSDHIP_PROFILE)                               // ablations (wrong results): tools/ablate_convh.py
+        case 16: convh_launch<16>(p, grid, stream); break;
+        case 24: convh_launch<24>(p, grid, stream); break;
+        case 88: convh_launch<88>(p, grid, stream); break;
         case 1: convh_launch<1>(p, grid, stream); break;
         case 2: convh_launch<2>(p, grid, stream); break;
         case 3: convh_launch<3>(p, grid, stream); break;
         case 4: convh_launch<4>(p, grid, stream); break;
         case 7: convh_launch<7>(p, grid, stream); break;
         case 32: convh_launch<32>(p, grid, stream); break;
-        case 34: convh_launch<34>(p, grid, stream); break;
+        case 81: convh_launch<81>(p, grid, stream); break;
+        case 82: convh_launch<82>(p, grid, stream); break;
+        case 84: convh_launch<84>(p, grid, stream); break;
+        case 87: convh_launch<87>(p, grid, stream); break;
 #endif
-        default: convh_launch<0>(p, grid, stream); break;
+        default: convh_launch<80>(p, grid, stream); break;
     }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

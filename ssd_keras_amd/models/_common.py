@@ -140,6 +140,39 @@ class _MaxPoolFn(torch.autograd.Function):
         return nat.maxpool_bwd(x, gy.to(torch.bfloat16), kernel, stride, pad), None, None, None, None
 
 
+class GraphedInference:
+    """`model(images)` (forward + DecodeDetections) of a fixed input shape as a HIP graph.
+
+    The graph reads the tensor handed to the constructor (`static_in`) and writes `static_out`: calling the object with another
+    tensor copies it into `static_in` first (one device copy); the returned tensor is overwritten by the next call.  Capture happens
+    after `warmup` eager steps on the capture stream, so the per-shape kernel autotune, the workspaces and the side stream of the
+    predictor heads exist before anything is recorded (allocations, host -> device copies and timing syncs are illegal inside a
+    capture).  Inference only (no_grad)."""
+
+    def __init__(self, model, images, warmup=3):
+        if not images.is_cuda:
+            raise ValueError("HIP graphs need a CUDA/HIP tensor")
+        self.model = model
+        self.static_in = images
+        dev = images.device
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(max(1, warmup)):
+                model(self.static_in)
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
+            self.static_out = model(self.static_in)
+
+    def __call__(self, images=None):
+        if images is not None and images.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(images, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
 class SSDModel(nn.Module):
     """Base class: subclasses define `features(x) -> list of predictor feature maps` plus
     `conf_heads`, `loc_heads` (ModuleLists) and `priorboxes` (ModuleList of AnchorBoxes)."""
@@ -204,8 +237,9 @@ class SSDModel(nn.Module):
     @staticmethod
     def _halo_ok(conv, x):
         """csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin and Cout multiples of 128, map at most 94 wide (the slab must fit in LDS)."""
+        import os
         return (conv.kernel_size == (3, 3) and conv.dilation == (1, 1) and conv.in_channels % 128 == 0
-                and conv.out_channels % 128 == 0 and x.shape[3] <= 94)
+                and conv.out_channels % 128 == 0 and x.shape[3] <= 94 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
 
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
@@ -266,13 +300,18 @@ class SSDModel(nn.Module):
                 cands["igemm"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu)
                 # the three-stage / 32-channel-slice / 3-workgroups-per-CU variant wins on the shallow-K layers (Cin = 64)
                 cands["igemm6"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=6)
+                if x.shape[0] * x.shape[2] * x.shape[3] <= 128 * 128:          # at most one workgroup per CU: the deepest ring too
+                    cands["igemm5"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=5)
                 if conv.in_channels == 64 and k == 3 and conv.dilation[0] == 1:
                     cands["c64"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=relu, pool=False)
                 if self._halo_ok(conv, x):
                     cands["halo"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=1, relu=relu, variant=7)
             elif self._igemm_general_ok(conv, x):
-                cands["igemm"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
-                                                    dilation=conv.dilation[0], relu=relu)
+                # the extra layers: small maps, one workgroup per CU at most -- the deeper LDS rings (loads three / two steps ahead)
+                # hide the L2 latency that the two-stage kernel exposes on every K-step
+                for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6)):
+                    cands[nm] = lambda v=v: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
+                                                       dilation=conv.dilation[0], relu=relu, variant=v)
             name = (self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu, conv.stride[0], conv.padding[0]), cands)
                     if len(cands) > 1 else "miopen")
             return cands[name]()
@@ -333,8 +372,9 @@ class SSDModel(nn.Module):
             if self._halo_ok(conv, x):
                 cands["halo"] = lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=1, relu=relu, variant=7)
         elif self._igemm_general_ok(conv, x):
-            cands = {"igemm": lambda xb, wb, bb: nat.conv2d(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
-                                                            relu=relu)}
+            cands = {nm: (lambda xb, wb, bb, v=v: nat.conv2d(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
+                                                            relu=relu, variant=v))
+                     for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6))}
         else:
             return None, None
         if len(cands) == 1:
@@ -492,24 +532,39 @@ class SSDModel(nn.Module):
         n_early = len(early)
         if not all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
                    for f, ch, lh in zip(early, self.conf_heads, self.loc_heads)):
-            rest = self.extra_features(early[1])
-            self.__dict__["_split_feats_cache"] = early + rest      # not reached on the shipped models; keep the general path correct
-            return None if True else None
+            raise RuntimeError("predictor heads of the trunk do not qualify for the packed kernel")
         main = torch.cuda.current_stream(x.device)
+        mode = os.environ.get("SSDHIP_HEAD_OVERLAP", "1")
         side = self.__dict__.get("_side_stream")
         if side is None or side.device != x.device:
-            side = torch.cuda.Stream(device=x.device)
+            # high priority: when both streams have workgroups pending, the dispatcher serves this one first
+            side = torch.cuda.Stream(device=x.device, priority=-1)
             self.__dict__["_side_stream"] = side
+
+        def check_rest(rest):
+            if not all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
+                       for f, ch, lh in zip(rest, self.conf_heads[n_early:], self.loc_heads[n_early:])):
+                raise RuntimeError("predictor heads of the extra layers do not qualify for the packed kernel")
+
+        # No record_stream anywhere: every tensor the other stream touches outlives the join in program order, and a block of the
+        # side stream's pool is only reused after that stream has waited for the current one again.
+        if mode == "2":
+            # the latency-bound chain (extra layers + their small heads) on the high-priority stream, the two big heads on the current
+            # one: the chain's few workgroups no longer queue behind ~600 head workgroups at every one of its eight launches
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rest = self.extra_features(early[1])
+                check_rest(rest)
+                small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None,
+                                              relu=False)
+            big = nat.conv2d_same_group(list(early), [self._packed_head_weight(l) for l in range(n_early)], None, relu=False)
+            main.wait_stream(side)
+            return early + rest, big + small
         side.wait_stream(main)
         with torch.cuda.stream(side):
             big = nat.conv2d_same_group(list(early), [self._packed_head_weight(l) for l in range(n_early)], None, relu=False)
-        for t in list(early) + big:
-            t.record_stream(side)
         rest = self.extra_features(early[1])
-        ok_rest = all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
-                      for f, ch, lh in zip(rest, self.conf_heads[n_early:], self.loc_heads[n_early:]))
-        if not ok_rest:
-            raise RuntimeError("predictor heads of the extra layers do not qualify for the packed kernel")
+        check_rest(rest)
         small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None, relu=False)
         main.wait_stream(side)
         return early + rest, big + small
@@ -559,6 +614,12 @@ class SSDModel(nn.Module):
 
     def forward(self, images):
         return self.raw_predictions(images, decode=self.decoder is not None)
+
+    def graphed(self, images, warmup=3):
+        """`forward` for inputs of this shape captured ONCE into a HIP graph: a step is then a single graph launch instead of ~45
+        kernel launches issued from Python (the step is 3 ms of GPU work; on a slow or busy host the eager launches alone can take
+        longer).  Returns a callable; see GraphedInference."""
+        return GraphedInference(self, images, warmup)
 
     predict = forward
 

@@ -58,9 +58,10 @@ GENERAL_CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil, bias, relu
 ]
 
 
+@pytest.mark.parametrize("variant", [None, 5, 6])
 @pytest.mark.parametrize("case", GENERAL_CASES)
-def test_general_conv_vs_float32_reference(case):
-    """Strided / partially padded convolutions (the SSD extra layers) through ssdhip_conv2d_nhwc_bf16."""
+def test_general_conv_vs_float32_reference(case, variant):
+    """Strided / partially padded convolutions (the SSD extra layers) through ssdhip_conv2d_nhwc_bf16[_variant]."""
     import torch
     import torch.nn.functional as F
     from ssd_keras_amd import _native as nat
@@ -69,7 +70,9 @@ def test_general_conv_vs_float32_reference(case):
     x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
     wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
     bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
-    got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=dil, relu=relu).float()
+    got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=dil, relu=relu, variant=variant).float()
+    if variant is not None:                                # same accumulation order: bit-identical to the default kernel
+        assert torch.equal(got, nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=dil, relu=relu).float())
     want = F.conv2d(x.float(), wt.float(), bias.float() if has_bias else None, stride, pad, dil)
     if relu:
         want = torch.relu(want)

@@ -191,3 +191,47 @@ def test_bf16_backbone_drift_against_the_float32_model():
     print("bf16 vs float32 backbone: max |d prob| %.2e, max |d offset| %.2e, detections kept %d / %d" % (d_conf, d_loc, found, total))
     assert d_conf < 5e-3 and d_loc < 2e-2
     assert total > 0 and found >= 0.9 * total
+
+
+def test_graphed_step_and_two_stream_heads_equal_the_plain_step():
+    """BASELINE configs[1] (SSD300, batch 32, bf16 backbone): the step as a HIP graph (model.graphed) and the predictor heads of
+    conv4_3 / fc7 on a second stream beside the extra layers must reproduce the single-stream eager step bit for bit -- the same
+    kernels in a different launch order.  A second input through the captured graph (device copy into the static buffer) checks
+    that the graph reads its input at replay time."""
+    import os
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(7)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="inference", scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"],
+                    confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400).cuda()
+    model = model.to(memory_format=torch.channels_last).eval().to(torch.bfloat16)
+    rs = np.random.RandomState(3)
+    img_a = torch.from_numpy(rs.randint(0, 256, size=(32, 300, 300, 3)).astype(np.float32)).cuda()
+    img_b = torch.from_numpy(rs.randint(0, 256, size=(32, 300, 300, 3)).astype(np.float32)).cuda()
+    old = os.environ.get("SSDHIP_HEAD_OVERLAP")
+    try:
+        os.environ["SSDHIP_HEAD_OVERLAP"] = "0"
+        with torch.no_grad():
+            plain_a = model(img_a).clone()
+            plain_b = model(img_b).clone()
+            pred_plain = model.raw_predictions(img_a).clone()
+        for mode in ("2", "1"):                                  # extra layers / big heads on the second stream
+            os.environ["SSDHIP_HEAD_OVERLAP"] = mode
+            with torch.no_grad():
+                for _ in range(3):                               # the second stream must not race the first
+                    assert torch.equal(model(img_a), plain_a)
+                assert torch.equal(model.raw_predictions(img_a), pred_plain)
+        with torch.no_grad():
+            runner = model.graphed(img_a.clone())
+            for _ in range(3):
+                assert torch.equal(runner(img_a), plain_a)
+            assert torch.equal(runner(img_b), plain_b)
+            assert torch.equal(runner(img_a), plain_a)
+    finally:
+        if old is None:
+            os.environ.pop("SSDHIP_HEAD_OVERLAP", None)
+        else:
+            os.environ["SSDHIP_HEAD_OVERLAP"] = old
+    assert int((plain_a[:, :, 0] > 0).sum()) > 0                 # the comparison is not between two empty outputs

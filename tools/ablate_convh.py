@@ -1,9 +1,8 @@
 """Ablations of the slab kernel's K loop (needs tools/libssdhip_prof.so: tools/prof_build.sh).  GPU box only.
 
 Each mode removes ONE ingredient of the loop (results are wrong by construction) so the time it costs can be read off:
-    0 shipped      8 second wave of every SIMD issues its loads mid-step
-    1 no loads     2 no fragment reads     3 neither (MFMAs + barrier)     4 no waits / barrier     7 MFMAs only
-    32 loads + barrier only
+    80 shipped (fine interleave)      0 coarse schedule
+    81 no loads     82 no fragment reads     84 no waits / barrier     87 MFMAs only     32 loads + barrier only (coarse)
     python tools/ablate_convh.py [out.json]
 """
 import json
@@ -18,7 +17,7 @@ import torch  # noqa: E402
 from ssd_keras_amd import _native as nat  # noqa: E402
 
 LAYERS = [("conv3_2", 32, 75, 75, 256, 256), ("conv4_2", 32, 38, 38, 512, 512), ("conv5_1", 32, 19, 19, 512, 512)]
-MODES = [0, 8, 1, 2, 3, 4, 7, 32]
+MODES = [80, 0, 81, 82, 84, 87, 32]
 
 
 def timed(fn, reps=20):
@@ -50,7 +49,7 @@ for name, B, H, W, Cin, Cout in LAYERS:
     base = nat.conv2d_same(x, wt, bias, relu=True, variant=4).view(torch.int16)
     for m in MODES:
         os.environ["SSDHIP_CONVH_MODE"] = str(m)
-        if m in (0, 8):
+        if m in (0, 80):
             got = nat.conv2d_same(x, wt, bias, relu=True, variant=7).view(torch.int16)
             row["mode%d_differs" % m] = int((got != base).sum().item())
         us = timed(lambda: nat.conv2d_same(x, wt, bias, relu=True, variant=7))

@@ -12,6 +12,7 @@ import torch  # noqa: E402
 
 from ssd_keras_amd import _native as nat  # noqa: E402
 
+MODES = [int(m) for m in os.environ.get("CONVH_MODES", "80,0").split(",")]
 LAYERS = [  # name, B, H, W, Cin, Cout
     ("conv3_1", 32, 75, 75, 128, 256), ("conv3_2", 32, 75, 75, 256, 256), ("conv4_1", 32, 38, 38, 256, 512),
     ("conv4_2", 32, 38, 38, 512, 512), ("conv5_1", 32, 19, 19, 512, 512),
@@ -50,12 +51,19 @@ for name, B, H, W, Cin, Cout in LAYERS:
         row["differs_from_variant4"] = int((got != base).sum().item())
     except Exception as exc:                               # noqa: BLE001
         row["error"] = repr(exc)[:200]
-    for v in (4, 6, 7):
-        if v == 7 and "error" in row:
-            continue
+    for v in (4, 6):
         us = timed(lambda v=v: nat.conv2d_same(x, wt, bias, relu=True, variant=v))
         row["v%d_us" % v] = round(us, 1)
-        row["v%d_tflops" % v] = round(flop / us / 1e6, 1)
+    if "error" not in row:
+        for mode in MODES:                                 # SSDHIP_CONVH_MODE is read at every launch
+            os.environ["SSDHIP_CONVH_MODE"] = str(mode)
+            bad = 0
+            for _ in range(5):
+                got = nat.conv2d_same(x, wt, bias, relu=True, variant=7).view(torch.int16)
+                bad += int((got != base).sum().item())
+            us = timed(lambda: nat.conv2d_same(x, wt, bias, relu=True, variant=7))
+            row["mode%d" % mode] = {"us": round(us, 1), "tflops": round(flop / us / 1e6, 1), "differs": bad}
+        os.environ.pop("SSDHIP_CONVH_MODE", None)
     print(json.dumps(row), flush=True)
     rows.append(row)
 if len(sys.argv) > 1:
