@@ -284,7 +284,8 @@ int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias,
                             int kernel, int stride, int pad, int dilation, int relu, void* stream);
 /* The same with an explicit kernel variant (4: the default, two LDS stages; 5 / 6: the multi-stage ring of 32-channel slices with
  * loads three / two steps ahead of the MFMAs): the 10x10 ... 1x1 maps of the extra layers leave at most one workgroup per CU, where
- * only the prefetch depth hides the L2 latency.  Results are bit-identical across variants. */
+ * only the prefetch depth hides the L2 latency.  Same numerics bar (the ring accumulates 32-channel slices: a different float32
+ * summation order). */
 int ssdhip_conv2d_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                     int Cin, int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream);
 

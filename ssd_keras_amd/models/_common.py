@@ -114,7 +114,11 @@ class _ConvBiasActFn(torch.autograd.Function):
             # the data gradient of a stride-1 'same' convolution IS a 'same' convolution of dL/dy with the filters transposed
             # (Cin <-> Cout) and their taps flipped: the forward's MFMA kernel runs it, no bias, no activation
             wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
-            gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False)
+            # (the deep 3x3 layers through the slab kernel, csrc/ssdhip_convh.hip: bit-identical and faster, r02o)
+            import os
+            halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0 and gy.shape[3] <= 94
+                    and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
+            gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
         masks = [need_x and gx is None, True, False]
         gx_m, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
                                                           masks)
@@ -517,12 +521,14 @@ class SSDModel(nn.Module):
         return self.decoder(pred) if (decode and self.decoder is not None) else pred
 
     def _split_heads(self, x):
-        """Fused bf16 inference only.  The packed heads of the trunk's two source maps (conv4_3, fc7: ~85 % of the head FLOPs) run
-        on a SECOND HIP stream while the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- run on
-        the current one; the extra maps' heads follow as one grouped launch.  Returns (feature maps, packed head outputs) or None
-        when the model / dtype / mode does not qualify (SSDHIP_HEAD_OVERLAP=0 switches it off)."""
+        """Fused bf16 inference only, OPT-IN (SSDHIP_HEAD_OVERLAP=1 | 2).  The packed heads of the trunk's two source maps (conv4_3,
+        fc7: ~85 % of the head FLOPs) and the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- on
+        two HIP streams (1: the heads on the second stream; 2: the chain on a high-priority second stream); the extra maps' heads
+        follow as one grouped launch.  Measured (r02p, HIP-graph step): ~190 us of kernels do run side by side, but they slow each
+        other down by as much -- 2.831 (off) / 2.832 (1) / 2.815 ms (2) per step: not worth a default.  Returns (feature maps, packed
+        head outputs) or None."""
         import os
-        if (os.environ.get("SSDHIP_HEAD_OVERLAP", "1") == "0" or not hasattr(self, "trunk_features") or not x.is_cuda
+        if (os.environ.get("SSDHIP_HEAD_OVERLAP", "0") == "0" or not hasattr(self, "trunk_features") or not x.is_cuda
                 or torch.is_grad_enabled() or not self.fused_inference or x.dtype != torch.bfloat16
                 or len(self.conf_heads) > 8 + 2):
             return None
@@ -534,7 +540,7 @@ class SSDModel(nn.Module):
                    for f, ch, lh in zip(early, self.conf_heads, self.loc_heads)):
             raise RuntimeError("predictor heads of the trunk do not qualify for the packed kernel")
         main = torch.cuda.current_stream(x.device)
-        mode = os.environ.get("SSDHIP_HEAD_OVERLAP", "1")
+        mode = os.environ.get("SSDHIP_HEAD_OVERLAP", "0")
         side = self.__dict__.get("_side_stream")
         if side is None or side.device != x.device:
             # high priority: when both streams have workgroups pending, the dispatcher serves this one first

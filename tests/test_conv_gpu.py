@@ -71,8 +71,6 @@ def test_general_conv_vs_float32_reference(case, variant):
     wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
     bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
     got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=dil, relu=relu, variant=variant).float()
-    if variant is not None:                                # same accumulation order: bit-identical to the default kernel
-        assert torch.equal(got, nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=dil, relu=relu).float())
     want = F.conv2d(x.float(), wt.float(), bias.float() if has_bias else None, stride, pad, dil)
     if relu:
         want = torch.relu(want)
