@@ -56,6 +56,7 @@ struct ConvHParams {
     bf16_t* y;                   // [B, H, W, Cout]
     int H, W, Cin, Cout, relu;
     int Q, q_tiles, n_tiles;     // padded positions B (H+1)(W+1); tiles of 256 positions; tiles of 128 channels
+    int total_ids;               // workgroup ids that map to tiles: ceil(q_tiles / 8) * n_tiles * 8 (some of the last ones to none)
     int x_bytes, w_bytes;
 };
 
@@ -72,6 +73,10 @@ __device__ __forceinline__ float ch_relu(float v) { return v <= 0.f ? 0.f : v; }
 // is out of range).  M0 is saved and restored inside the statement (hipcc does not model it around asm).
 __device__ __forceinline__ void ch_bload(u32 voff, i32x4 rsrc, u32 lds_dst, u32 soff) {
     u32 keep;
+    // wave-uniform by construction; the explicit readfirstlane keeps them in SGPRs when hipcc has folded a common factor of the
+    // expression into a vector register (an "s" constraint does not insert one by itself)
+    lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst);
+    soff = (u32)__builtin_amdgcn_readfirstlane((int)soff);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
 }
@@ -84,20 +89,29 @@ __device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
     r.w = 0x00020000;
     return r;
 }
-// MODE bits -- 8: waves 4..7 (the second wave of every SIMD) issue their loads in the middle of the step instead of at its start.
-// Profiling build only (wrong results, they isolate one cost each): 1 no loads in the K loop, 2 no fragment reads, 4 no waits / barrier,
-// 32 no MFMAs.
+// MODE bits -- 64: the second wave of every SIMD (waves 4..7) reads its fragments two slots later; 8: ... issues its requests two
+// slots later; 128: persistent workgroups (one per CU) that walk over tiles and request the next tile's first slab and weights during
+// the last slice of the current one.  Profiling build only (wrong results, they isolate one cost each): 1 no loads in the K loop, 2 no
+// fragment reads, 4 no waits / barrier, 32 no MFMAs.
 template <int NW, int SPW, int MODE>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds) {
     constexpr int D = NW;                                // weights of step s + D are requested during step s
     constexpr int SLAB0 = NW * CH_WST, SLB = SPW * 8192;
     constexpr unsigned OOB = 0x80000000u;
+    constexpr bool PERSIST = (MODE & 128) != 0;
     static_assert(SPW + D <= 10, "slice cs+1's slab must have landed two steps before tap 8 of slice cs reads it");
+    static_assert(SLB >= 32768, "the epilogue stages half a tile (8 waves x 32 positions x 128 B) in the idle slab buffer");
 
-    const int id = (int)blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int qt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;     // the channel tiles of a position tile share an XCD
-    if (qt >= p.q_tiles) return;
-    const int q0 = qt * CH_BN, co0 = nt * CH_BM;
+    // workgroup id -> tile: the channel tiles of a position tile share an XCD (ids are dealt to the XCDs round robin)
+    auto tile_of = [&](const int id, int& q0, int& co0) {
+        const int xcd = id & 7, slot = id >> 3;
+        const int qt = (slot / p.n_tiles) * 8 + xcd;
+        q0 = qt * CH_BN;
+        co0 = (slot % p.n_tiles) * CH_BM;
+        return id < p.total_ids && qt < p.q_tiles;
+    };
+    int id = (int)blockIdx.x, q0, co0;
+    if (!tile_of(id, q0, co0)) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,9 +128,9 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     // (lane & 7) holding source chunk (lane & 7) ^ ((row >> 1) & 7)
     const int SP = CH_BN + 2 * W + 4;                    // slab rows a tile reads
     u32 xoff[SPW];
-    {
+    auto make_xoff = [&](const int tile_q0) {
         const int row0 = wave * 8 + (lane >> 3);
-        int q = q0 - (W + 2) + row0;
+        int q = tile_q0 - (W + 2) + row0;
         int b = 0, h = 0, w = 0;
         if (q >= 0) { b = q / (H1 * W1); const int r = q - b * (H1 * W1); h = r / W1; w = r - h * W1; }
         else { w = q; }                                  // negative positions: before the first image (zeros)
@@ -130,23 +144,20 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             w += 64;
             while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
         }
-    }
-    u32 woff[2];
+    };
+    make_xoff(q0);
+    u32 woff[2];                                         // relative to the tile's first channel (which rides in the scalar offset)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (i * 8 + wave) * 8 + (lane >> 3);
         const int j = (lane & 7) ^ ((row >> 1) & 7);
-        woff[i] = (u32)((co0 + row) * (9 * Cin * 2) + j * 16);
+        woff[i] = (u32)(row * (9 * Cin * 2) + j * 16);
     }
 
-    // the weights of tap `tap` of slice `cs` into ring stage `stage` (all wave-uniform): this wave's two 1 KiB pieces
-    auto issue_w_piece = [&](const int cs, const int tap, const int stage, const int i) {
-        const u32 soff = (u32)((tap * Cin + cs * 64) * 2);
+    // the weights of tap `tap` of slice `cs` of channel tile `co` into ring stage `stage` (all wave-uniform): this wave's piece i
+    auto issue_w_piece = [&](const int co, const int cs, const int tap, const int stage, const int i) {
+        const u32 soff = (u32)(((co * 9 + tap) * Cin + cs * 64) * 2);
         ch_bload(woff[i], rw, lds0 + stage * CH_WST + wave * 1024 + i * 8192, soff);
-    };
-    auto issue_w = [&](const int cs, const int tap, const int stage) {
-        issue_w_piece(cs, tap, stage, 0);
-        issue_w_piece(cs, tap, stage, 1);
     };
 
     // ---- fragment addressing -----------------------------------------------------------------------------------------------
@@ -159,13 +170,6 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     const int prow = wn * 64 + r31;                      // slab row of the lane's first position at tap (0, 0)
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
-
     bf16x8 fa[2][4][2], fb[2][4][2];                     // [register set][k16 block][ci | pi]
 
     u32 ra[4], rb[2], re[2];                             // addresses of the pending fragment reads
@@ -184,21 +188,6 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             re[pi] = (((row >> 1) & 7u) ^ (u32)khalf) << 4;     // chunk (2 kk + khalf) ^ swz = (2 kk) ^ (khalf ^ swz)
         }
     };
-    auto read_kk = [&](auto setc, auto kkc) {
-        constexpr int S = decltype(setc)::value, kk = decltype(kkc)::value;
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci) fa[S][kk][ci] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + ci * 4096);
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) fb[S][kk][pi] = *reinterpret_cast<const bf16x8*>(lds + rb[pi] + (re[pi] ^ (u32)(kk << 5)));
-    };
-    auto mfma_kk = [&](auto setc, auto kkc) {
-        constexpr int S = decltype(setc)::value, kk = decltype(kkc)::value;
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi)
-                acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
-    };
     auto read_one = [&](auto setc, auto jc) {             // fragment read j of a step: k16 block j / 4; weights ci 0, 1 then positions pi 0, 1
         constexpr int S = decltype(setc)::value, j = decltype(jc)::value, kk = j >> 2, w = j & 3;
         if constexpr (w < 2) fa[S][kk][w] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + w * 4096);
@@ -209,172 +198,177 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
-    // ---- prologue: slab of slice 0, weights of steps 0 .. D-1 ---------------------------------------------------------------
+    // ---- prologue of the workgroup's first tile: slab of slice 0, weights of steps 0 .. D-1 ------------------------------------
 #pragma unroll
     for (int k = 0; k < SPW; ++k) ch_bload(xoff[k], rx, lds0 + SLAB0 + wave * 1024 + k * 8192, 0u);
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue_w(0, d, d);
+    for (int d = 0; d < D; ++d) { issue_w_piece(co0, 0, d, d, 0); issue_w_piece(co0, 0, d, d, 1); }
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (D - 2)) : "memory");     // slab 0 and the weights of steps 0 and 1 (this wave's share)
     __builtin_amdgcn_s_barrier();                        // ... everybody's
     read_addr(0, 0, 0);
-    read_kk(I0{}, I0{}); read_kk(I0{}, I1{}); read_kk(I0{}, I2{}); read_kk(I0{}, I3{});
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) fa[0][kk][ci] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + ci * 4096);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) fb[0][kk][pi] = *reinterpret_cast<const bf16x8*>(lds + rb[pi] + (re[pi] ^ (u32)(kk << 5)));
+    }
 
-    // One K-step; its tap is known at compile time, so the vmcnt immediates below are exact counts.  `last` (wave-uniform): the
-    // last slice, which requests no further slab and, from tap 9 - D on, no further weights.
-    auto step = [&](auto grpc, auto setc, auto tapc, const int cs, const bool last) {
+    int vbase = 0;                                       // slices this workgroup has finished (the weight ring runs on across tiles)
+    bool has_next = false;
+    int q0n = 0, co0n = 0;                               // the workgroup's next tile
+
+    // One K-step; its tap is known at compile time, so the vmcnt immediates below are exact counts.  Wave-uniform flags: `nomore` =
+    // the last slice of the workgroup's last tile (requests nothing beyond the tile), `nxt` = the last slice of any other tile (what
+    // it requests beyond the slice belongs to the NEXT tile: its slice 0 slab through the refreshed xoff[], its weights at co0n).
+    auto step = [&](auto grpc, auto setc, auto tapc, const int cs, const bool nomore, const bool nxt) {
         constexpr int GRP = decltype(grpc)::value, S = decltype(setc)::value, TAP = decltype(tapc)::value;
         using Sn = std::integral_constant<int, 1 - S>;
         // loads this wave issues during tap t of a slice: 2 weight pieces (+ 1 slab piece)
         constexpr auto issued = [](int t, bool lst) { return lst ? (t < 9 - D ? 2 : 0) : 2 + (t < SPW ? 1 : 0); };
         constexpr int n_mid = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, false) : 2)) + issued(TAP, false);
         constexpr int n_last = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, true) : 2)) + issued(TAP, true);
-        // (a) requests: weights of step s + D into the stage step s just vacated; one piece of the next slice's slab.
-        //     Ring stage of step s = 9 cs + TAP is s mod NW: TAP mod 3 for three stages, (cs + TAP) mod 4 for four
-        const int st = NW == 3 ? TAP % 3 : ((cs + TAP) & 3);
-        if constexpr (MODE & 16) {
-            // Fine schedule: 16 slots, slot i = MFMA i, then 0..2 fragment reads of step s + 1, then at three slots one LDS-DMA
-            // request.  Nothing comes in bursts: with 4 MFMAs, then 8 reads from all eight waves at once, the LDS queue filled up,
-            // the waves stalled on issuing reads and the MFMA pipe drained -- the reads' 512 LDS cycles per step ADDED to the 1024
-            // MFMA cycles (ablation r02n: 29 % of the kernel).  GRP 1 = the second wave of every SIMD: bit 64 delays its reads by
-            // two slots, bit 8 its requests by two slots, so the two waves of a SIMD do not want the same unit at the same time.
-            constexpr int RSH = ((MODE & 64) && GRP) ? 2 : 0, QSH = ((MODE & 8) && GRP) ? 2 : 0;
-            read_addr(cs + (TAP == 8 ? 1 : 0), (TAP + 1) % 9, NW == 3 ? (TAP + 1) % 3 : ((cs + TAP + 1) & 3));
-            auto slot = [&](auto ic) {
-                constexpr int i = decltype(ic)::value, j = i - RSH;
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(MODE & 32)) mfma_one(setc, ic);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(MODE & 2)) {
-                    if constexpr (j >= 0 && j < 4) {
-                        read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j)>{});
-                        read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j) + 1>{});
-                    } else if constexpr (j >= 4 && j < 12) {
-                        read_one(Sn{}, std::integral_constant<int, (j < 4 ? 4 : j) + 4>{});
-                    }
-                }
-                if constexpr (!(MODE & 1)) {
-                    if constexpr (i == 1 + QSH || i == 5 + QSH) {
-                        if (!last || TAP < 9 - D) issue_w_piece(cs + (TAP + D >= 9 ? 1 : 0), (TAP + D) % 9, st, i == 1 + QSH ? 0 : 1);
-                    } else if constexpr (i == 9 + QSH && TAP < SPW) {
-                        if (!last) ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192, (u32)((cs + 1) * 128));
-                    }
-                }
-            };
-            slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{}); slot(std::integral_constant<int, 2>{});
-            slot(std::integral_constant<int, 3>{}); slot(std::integral_constant<int, 4>{}); slot(std::integral_constant<int, 5>{});
-            slot(std::integral_constant<int, 6>{}); slot(std::integral_constant<int, 7>{}); slot(std::integral_constant<int, 8>{});
-            slot(std::integral_constant<int, 9>{}); slot(std::integral_constant<int, 10>{}); slot(std::integral_constant<int, 11>{});
-            slot(std::integral_constant<int, 12>{}); slot(std::integral_constant<int, 13>{}); slot(std::integral_constant<int, 14>{});
-            slot(std::integral_constant<int, 15>{});
+        // Ring stage of a step is (global step number) mod NW: 9 slices-so-far + TAP -> TAP mod 3 for three stages, (slices + TAP) mod 4
+        const int vs = vbase + cs;
+        const int st = NW == 3 ? TAP % 3 : ((vs + TAP) & 3);
+        // 16 slots, slot i = MFMA i, then 0..2 fragment reads of step s + 1, then at three slots one LDS-DMA request.  Nothing comes
+        // in bursts: with 4 MFMAs, then 8 reads from all eight waves at once, the LDS queue fills up, the waves stall on issuing reads
+        // and the MFMA pipe drains.  The step opens with an MFMA: hipcc puts an s_waitcnt lgkmcnt in front of the first use of a
+        // register set (it cannot see that the previous step already waited), and that must not catch reads issued in this step.
+        // After the very last step the reads fetch a stage nobody uses (in-bounds LDS addresses): cheaper than branches.
+        constexpr int RSH = ((MODE & 64) && GRP) ? 2 : 0, QSH = ((MODE & 8) && GRP) ? 2 : 0;
+        read_addr(cs + (TAP == 8 ? 1 : 0), (TAP + 1) % 9, NW == 3 ? (TAP + 1) % 3 : ((vs + TAP + 1) & 3));
+        auto slot = [&](auto ic) {
+            constexpr int i = decltype(ic)::value, j = i - RSH;
             __builtin_amdgcn_sched_barrier(0);
-        } else {
-        auto requests = [&]() {
-            if constexpr (MODE & 1) return;
-            if (!last || TAP < 9 - D) issue_w(cs + (TAP + D >= 9 ? 1 : 0), (TAP + D) % 9, st);
-            if constexpr (TAP < SPW)
-                if (!last) ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192, (u32)((cs + 1) * 128));
+            if constexpr (!(MODE & 32)) mfma_one(setc, ic);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(MODE & 2)) {
+                if constexpr (j >= 0 && j < 4) {
+                    read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j)>{});
+                    read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j) + 1>{});
+                } else if constexpr (j >= 4 && j < 12) {
+                    read_one(Sn{}, std::integral_constant<int, (j < 4 ? 4 : j) + 4>{});
+                }
+            }
+            if constexpr (!(MODE & 1)) {
+                if constexpr (i == 1 + QSH || i == 5 + QSH) {
+                    // weights of step s + D: the same slice, the next one, or slice 0 of the next tile
+                    constexpr bool CARRY = TAP + D >= 9;
+                    if (!nomore || !CARRY) {
+                        const bool over = CARRY && nxt;
+                        issue_w_piece(over ? co0n : co0, over ? 0 : cs + (CARRY ? 1 : 0), (TAP + D) % 9, st, i == 1 + QSH ? 0 : 1);
+                    }
+                } else if constexpr (i == 9 + QSH && TAP < SPW) {
+                    if (!nomore)
+                        ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192, nxt ? 0u : (u32)((cs + 1) * 128));
+                }
+            }
         };
-        if constexpr (MODE & 8) { if (wave < 4) requests(); } else requests();
-        // (b) the MFMAs of step s, interleaved with the fragment reads of step s + 1.  The step opens with MFMAs: hipcc puts an
-        //     s_waitcnt lgkmcnt(0) in front of the first use of a register set (it cannot see that (c) of the previous step already
-        //     waited), and that must not catch reads issued in this step.  After the last step the reads fetch a stage nobody
-        //     uses (in-bounds LDS addresses): cheaper than a branch around every group.
-        read_addr(cs + (TAP == 8 ? 1 : 0), (TAP + 1) % 9, NW == 3 ? (TAP + 1) % 3 : ((cs + TAP + 1) & 3));
+        slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{}); slot(std::integral_constant<int, 2>{});
+        slot(std::integral_constant<int, 3>{}); slot(std::integral_constant<int, 4>{}); slot(std::integral_constant<int, 5>{});
+        slot(std::integral_constant<int, 6>{}); slot(std::integral_constant<int, 7>{}); slot(std::integral_constant<int, 8>{});
+        slot(std::integral_constant<int, 9>{}); slot(std::integral_constant<int, 10>{}); slot(std::integral_constant<int, 11>{});
+        slot(std::integral_constant<int, 12>{}); slot(std::integral_constant<int, 13>{}); slot(std::integral_constant<int, 14>{});
+        slot(std::integral_constant<int, 15>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 32)) mfma_kk(setc, I0{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 2)) { read_kk(Sn{}, I0{}); read_kk(Sn{}, I1{}); }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 32)) mfma_kk(setc, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE & 8) { if (wave >= 4) requests(); }
-        if constexpr (!(MODE & 2)) read_kk(Sn{}, I2{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 32)) mfma_kk(setc, I2{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 2)) read_kk(Sn{}, I3{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(MODE & 32)) mfma_kk(setc, I3{});
-        __builtin_amdgcn_sched_barrier(0);
-        }
-        // (c) everything step s + 2 needs has landed (in-order completion: only the newest D - 2 steps' requests may be in
-        //     flight), this wave's fragment reads are done (their stage is overwritten next step), then the barrier
+        // everything step s + 2 needs has landed (in-order completion: only the newest D - 2 steps' requests may be in flight), this
+        // wave's fragment reads are done (their stage is overwritten next step), then the barrier
         if constexpr (!(MODE & 4)) {
-            if (!last) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
+            if (!nomore) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_last) : "memory");
             __builtin_amdgcn_s_barrier();
         }
     };
-    auto slice = [&](auto grpc, auto parc, const int cs, const bool last) {   // the nine taps of slice cs; register set of tap t: (par + t) & 1
+    auto slice = [&](auto grpc, auto parc, const int cs, const bool nomore, const bool nxt) {   // nine taps; register set of tap t: (par + t) & 1
         constexpr int P = decltype(parc)::value;
         using A = std::integral_constant<int, P>; using B = std::integral_constant<int, 1 - P>;
-        step(grpc, A{}, std::integral_constant<int, 0>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 1>{}, cs, last);
-        step(grpc, A{}, std::integral_constant<int, 2>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 3>{}, cs, last);
-        step(grpc, A{}, std::integral_constant<int, 4>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 5>{}, cs, last);
-        step(grpc, A{}, std::integral_constant<int, 6>{}, cs, last); step(grpc, B{}, std::integral_constant<int, 7>{}, cs, last);
-        step(grpc, A{}, std::integral_constant<int, 8>{}, cs, last);
+        step(grpc, A{}, std::integral_constant<int, 0>{}, cs, nomore, nxt); step(grpc, B{}, std::integral_constant<int, 1>{}, cs, nomore, nxt);
+        step(grpc, A{}, std::integral_constant<int, 2>{}, cs, nomore, nxt); step(grpc, B{}, std::integral_constant<int, 3>{}, cs, nomore, nxt);
+        step(grpc, A{}, std::integral_constant<int, 4>{}, cs, nomore, nxt); step(grpc, B{}, std::integral_constant<int, 5>{}, cs, nomore, nxt);
+        step(grpc, A{}, std::integral_constant<int, 6>{}, cs, nomore, nxt); step(grpc, B{}, std::integral_constant<int, 7>{}, cs, nomore, nxt);
+        step(grpc, A{}, std::integral_constant<int, 8>{}, cs, nomore, nxt);
     };
     auto k_loop = [&](auto grpc) {
         for (int cs = 0; cs < csteps; cs += 2) {         // csteps is even (Cin % 128 == 0): the last slice is an odd one
-            slice(grpc, I0{}, cs, false);
-            slice(grpc, I1{}, cs + 1, cs + 2 >= csteps);
+            const bool fin = cs + 2 >= csteps;
+            slice(grpc, I0{}, cs, false, false);
+            if (PERSIST && fin && has_next) make_xoff(q0n);   // the current tile's xoff[] was used for the last time in the slice above
+            slice(grpc, I1{}, cs + 1, fin && !has_next, fin && has_next);
         }
     };
-    if constexpr ((MODE & 16) && (MODE & (8 | 64))) {    // the two waves of a SIMD run differently ordered code (same barriers)
-        if (wave < 4) k_loop(I0{}); else k_loop(I1{});
-    } else {
-        k_loop(I0{});
-    }
 
-    // ---- epilogue: bias + ReLU + one rounding, transpose through LDS (the slab buffers are dead), 16-byte stores ------------
-    unsigned char* stage = lds + SLAB0 + wave * 8192;    // [64 positions][128 B = 64 channels]
-    float bv[2][16];
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
-                bv[ci][4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
-            }
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        const int px = pi * 32 + r31;
+    for (;;) {
+        if constexpr (PERSIST) has_next = tile_of(id + (int)gridDim.x, q0n, co0n);
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float o[4];
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+        if constexpr ((MODE & (8 | 64)) != 0) {          // the two waves of a SIMD run differently ordered code (same barriers)
+            if (wave < 4) k_loop(I0{}); else k_loop(I1{});
+        } else {
+            k_loop(I0{});
+        }
+
+        // ---- epilogue: bias + ReLU + one rounding, transpose through LDS, 16-byte stores.  The stage is the slab buffer of the
+        //      last (odd) slice: everything else in LDS may already hold the next tile's first slab and weights.  Two passes of 32
+        //      positions per wave (4 KB, wave private: DS operations of one wave execute in order). ----------------------------------
+        unsigned char* stage = lds + SLAB0 + SLB + wave * 4096;
+        float bv[2][16];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = acc[ci][pi][4 * g + e] + bv[ci][4 * g + e];
-                    o[e] = p.relu ? ch_relu(v) : v;
+                    const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
+                    bv[ci][4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
                 }
-                const int chunk = ci * 4 + g;
-                *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
-                    make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private stage: DS operations of one wave execute in order
-    {
-        int q = q0 + wn * 64 + (lane >> 3);
-        int b = q / (H1 * W1);
-        const int r = q - b * (H1 * W1);
-        int h = r / W1, w = r - h * W1;
-        const int c = lane & 7;
+        {
+            int q = q0 + wn * 64 + (lane >> 3);
+            int b = q / (H1 * W1);
+            const int r = q - b * (H1 * W1);
+            int h = r / W1, w = r - h * W1;
+            const int c = lane & 7;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int px = j * 8 + (lane >> 3);
-            const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
-            if (w < W && h < H && q < p.Q)
-                *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + h) * W + w)) * p.Cout + co0 + wm * 64 + c * 8) = v;
-            q += 8;
-            w += 8;
-            while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+            for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[ci][pi][4 * g + e] + bv[ci][4 * g + e];
+                            o[e] = p.relu ? ch_relu(v) : v;
+                        }
+                        const int chunk = ci * 4 + g;
+                        *reinterpret_cast<uint2*>(stage + r31 * 128 + ((chunk ^ (r31 & 7)) << 4) + khalf * 8) =
+                            make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int px = j * 8 + (lane >> 3);                  // of this pass's 32 positions
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+                    if (w < W && h < H && q < p.Q)
+                        *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + h) * W + w)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                    q += 8;
+                    w += 8;
+                    while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
+            }
         }
+        if (!has_next) break;
+        __builtin_amdgcn_s_barrier();                    // the stage is a slab buffer again: the next tile's slice 1 lands there
+        id += (int)gridDim.x;
+        q0 = q0n;
+        co0 = co0n;
+        vbase += csteps;
     }
 }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -388,7 +382,9 @@ __global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
 }
 
 template <int MODE>
-static void convh_launch(const ConvHParams& p, int grid, hipStream_t stream) {
+static void convh_launch(const ConvHParams& p, int n_cu, hipStream_t stream) {
+    int grid = p.total_ids;
+    if ((MODE & 128) && grid > n_cu) grid = n_cu;        // persistent: one workgroup per CU (a multiple of 8: the id -> XCD map)
     // slab rows = 256 + 2 W + 4 <= 64 SPW: three weight stages + 7 pieces per wave (W <= 94), four + 6 (W <= 62), four + 5 (W <= 30)
     if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
     else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
@@ -419,30 +415,31 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
-    const int grid = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
-    // Shipped schedule: 80 = fine MFMA / read interleave with the second wave of every SIMD reading two slots later (r02o: 1-7 %
-    // faster than the coarse schedule 0 on every SSD layer, bit-identical).  SSDHIP_CONVH_MODE=0 selects the coarse one.
-    int mode = 80;
+    p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+    static int cu_count = 0;                              // persistent variants launch one workgroup per CU
+    if (cu_count == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cu_count = (n / 8) * 8 > 0 ? (n / 8) * 8 : 8;
+    }
+    // Schedules: 128 (shipped) = persistent workgroups, one per CU, that request the next tile's first slab and weights during the
+    // last slice of the current tile (r02q: -10 % on conv3_1, -6 % on conv3_2, -1 % on the conv4 block against 64); 64 = one
+    // workgroup per tile, the second wave of every SIMD reading its fragments two slots later.  SSDHIP_CONVH_MODE selects.
+    int mode = 128;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     switch (mode) {
-        case 0: convh_launch<0>(p, grid, stream); break;
-#if defined(SSDHIP_PROFILE)                               // other schedules and ablations (1, 2, 4, 32: wrong results): tools/ablate_convh.py
-        case 8: convh_launch<8>(p, grid, stream); break;
-        case 16: convh_launch<16>(p, grid, stream); break;
-        case 24: convh_launch<24>(p, grid, stream); break;
-        case 88: convh_launch<88>(p, grid, stream); break;
-        case 1: convh_launch<1>(p, grid, stream); break;
-        case 2: convh_launch<2>(p, grid, stream); break;
-        case 3: convh_launch<3>(p, grid, stream); break;
-        case 4: convh_launch<4>(p, grid, stream); break;
-        case 7: convh_launch<7>(p, grid, stream); break;
-        case 32: convh_launch<32>(p, grid, stream); break;
-        case 81: convh_launch<81>(p, grid, stream); break;
-        case 82: convh_launch<82>(p, grid, stream); break;
-        case 84: convh_launch<84>(p, grid, stream); break;
-        case 87: convh_launch<87>(p, grid, stream); break;
+        case 64: convh_launch<64>(p, cu_count, stream); break;
+#if defined(SSDHIP_PROFILE)
+        case 192: convh_launch<192>(p, cu_count, stream); break;                               // other schedules and ablations (1, 2, 4, 32: wrong results): tools/ablate_convh.py
+        case 0: convh_launch<0>(p, cu_count, stream); break;
+        case 72: convh_launch<72>(p, cu_count, stream); break;
+        case 65: convh_launch<65>(p, cu_count, stream); break;
+        case 66: convh_launch<66>(p, cu_count, stream); break;
+        case 68: convh_launch<68>(p, cu_count, stream); break;
+        case 71: convh_launch<71>(p, cu_count, stream); break;
+        case 32: convh_launch<32>(p, cu_count, stream); break;
 #endif
-        default: convh_launch<80>(p, grid, stream); break;
+        default: convh_launch<128>(p, cu_count, stream); break;
     }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -238,11 +238,26 @@ HALO_CASES = [  # B, H, W, Cin, Cout, bias, relu      (csrc/ssdhip_convh.hip: 3x
     (1, 1, 1, 128, 128, True, True),         # one pixel: eight of the nine taps are padding
     (5, 7, 31, 256, 128, True, True),        # W + 1 = 32: a tile row boundary on every image row
     (1, 3, 63, 128, 128, True, True),        # W + 1 = 64
+    (64, 38, 38, 128, 256, True, True),      # 3044 tiles: every persistent workgroup walks over ~12 of them
+    (48, 19, 19, 256, 384, True, True),      # three channel tiles per position tile; tiles change channel tile between hops
 ]
 
 
+@pytest.fixture(params=["64", "128"])
+def slab_mode(request):
+    """SSDHIP_CONVH_MODE: 64 = one workgroup per tile, 128 = persistent workgroups prefetching across tiles (read at every launch)."""
+    import os
+    old = os.environ.get("SSDHIP_CONVH_MODE")
+    os.environ["SSDHIP_CONVH_MODE"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("SSDHIP_CONVH_MODE", None)
+    else:
+        os.environ["SSDHIP_CONVH_MODE"] = old
+
+
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_slab_conv_equals_implicit_gemm(case):
+def test_slab_conv_equals_implicit_gemm(case, slab_mode):
     """ssdhip_conv3x3_halo_nhwc_bf16 promises the implicit-GEMM kernel's accumulation order: BIT-identical outputs; and the
     float32 reference within the usual bar.  Repeated launches must agree with each other (LDS-DMA / barrier races show up as rare
     differing tiles)."""
@@ -270,7 +285,7 @@ def test_slab_conv_equals_implicit_gemm(case):
         assert torch.equal(again.view(torch.int16), got.view(torch.int16))
 
 
-def test_slab_conv_full_batch_race_screen():
+def test_slab_conv_full_batch_race_screen(slab_mode):
     """BASELINE configs[1] sizes (batch 32): conv3_2, conv4_2, conv5_1 -- every CU busy, 20 launches each, all bit-identical to
     the implicit-GEMM kernel."""
     import torch

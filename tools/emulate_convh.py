@@ -17,7 +17,9 @@ import numpy as np
 BN, BM, WST = 256, 128, 128 * 128
 
 
-def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
+def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
+    """G: None = one workgroup per tile; an int (multiple of 8) = that many PERSISTENT workgroups, each walking over its tiles with
+    one LDS image and requesting the next tile's first slab / weights during the last slice of the current one (MODE bit 128)."""
     rng = np.random.RandomState(seed)
     x = rng.randint(-3, 4, size=(B, H, W, Cin)).astype(np.float32)
     wt = rng.randint(-2, 3, size=(Cout, 3, 3, Cin)).astype(np.float32)
@@ -35,13 +37,21 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
     y = np.full((B, H, W, Cout), np.nan, np.float32)
     OOB = None
 
-    for qt, nt in itertools.product(range(q_tiles), range(n_tiles)):
-        q0, co0 = qt * BN, nt * BM
-        # LDS as chunks of 8 elements (16 bytes); chunk address = byte address / 16
-        lds = np.full((lds_bytes // 16, 8), np.nan, np.float32)
-        SP = BN + 2 * W + 4
+    total_ids = ((q_tiles + 7) // 8) * n_tiles * 8
 
-        def dma(src, voff_elems, soff_elems, dst_byte):           # one wave-wide piece: per-lane element offsets or OOB
+    def tile_of(i):
+        xcd, slot = i & 7, i >> 3
+        qt = (slot // n_tiles) * 8 + xcd
+        return (qt * BN, (slot % n_tiles) * BM) if (i < total_ids and qt < q_tiles) else None
+
+    SP = BN + 2 * W + 4
+    stride = G if G else total_ids
+    for wg in range(min(stride, total_ids)):
+        if tile_of(wg) is None:
+            continue
+        lds = np.full((lds_bytes // 16, 8), np.nan, np.float32)      # chunks of 8 elements (16 bytes); chunk address = byte address / 16
+
+        def dma(src, voff_elems, soff_elems, dst_byte):               # one wave-wide piece: per-lane element offsets or OOB
             for lane in range(64):
                 v = voff_elems[lane]
                 c = dst_byte // 16 + lane
@@ -51,43 +61,45 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
                     o = v + soff_elems
                     lds[c] = src[o:o + 8]
 
-        # per-(wave, lane) descriptors
-        xoff = np.empty((8, 64, SPW), object)
-        woff = np.empty((8, 64, 2), object)
+        def make_xoff(q0):
+            xo = np.empty((8, 64, SPW), object)
+            for wave in range(8):
+                for lane in range(64):
+                    row0 = wave * 8 + (lane >> 3)
+                    q = q0 - (W + 2) + row0
+                    b = h = w = 0
+                    if q >= 0:
+                        b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
+                    else:
+                        w = q
+                    for k in range(SPW):
+                        row = row0 + 64 * k
+                        j = (lane & 7) ^ ((row >> 1) & 7)
+                        ok = 0 <= w < W and h < H and q < Q and row < SP
+                        xo[wave, lane, k] = (((b * H + h) * W + w) * Cin + j * 8) if ok else OOB
+                        q += 64; w += 64
+                        while w >= W1:
+                            w -= W1; h += 1
+                            if h == H1:
+                                h = 0; b += 1
+            return xo
+
+        woff = np.empty((8, 64, 2), object)                           # tile invariant: the tile's first channel rides in the scalar offset
         for wave in range(8):
             for lane in range(64):
-                row0 = wave * 8 + (lane >> 3)
-                q = q0 - (W + 2) + row0
-                b = h = w = 0
-                if q >= 0:
-                    b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
-                else:
-                    w = q
-                for k in range(SPW):
-                    row = row0 + 64 * k
-                    j = (lane & 7) ^ ((row >> 1) & 7)
-                    ok = 0 <= w < W and h < H and q < Q and row < SP
-                    xoff[wave, lane, k] = (((b * H + h) * W + w) * Cin + j * 8) if ok else OOB
-                    q += 64; w += 64
-                    while w >= W1:
-                        w -= W1; h += 1
-                        if h == H1:
-                            h = 0; b += 1
                 for i in range(2):
                     row = (i * 8 + wave) * 8 + (lane >> 3)
                     j = (lane & 7) ^ ((row >> 1) & 7)
-                    woff[wave, lane, i] = (co0 + row) * 9 * Cin + j * 8
+                    woff[wave, lane, i] = row * 9 * Cin + j * 8
 
-        def issue_w(cs, tap, stage):
+        def issue_w(co, cs, tap, stage):
             for wave in range(8):
                 for i in range(2):
-                    dma(wf, woff[wave, :, i], tap * Cin + cs * 64, stage * WST + wave * 1024 + i * 8192)
+                    dma(wf, woff[wave, :, i], (co * 9 + tap) * Cin + cs * 64, stage * WST + wave * 1024 + i * 8192)
 
-        def issue_slab_piece(cs, k):
+        def issue_slab_piece(xo, cs_parity, soff, k):
             for wave in range(8):
-                dma(xf, xoff[wave, :, k], cs * 64, SLAB0 + (cs & 1) * SLB + wave * 1024 + k * 8192)
-
-        acc = np.zeros((8, 64, 2, 2, 16), np.float32)     # [wave][lane][ci][pi][v]
+                dma(xf, xo[wave, :, k], soff, SLAB0 + cs_parity * SLB + wave * 1024 + k * 8192)
 
         def read_frags(cs, tap, stage):
             """-> fa[wave][lane][kk][ci] (8 elems), fb[wave][lane][kk][pi]"""
@@ -112,8 +124,9 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
                             fb[wave, lane, kk, pi] = lds[(rb + (re ^ (kk << 5))) // 16]
             return fa, fb
 
-        def mfma_step(fa, fb):
+        def mfma_step(acc, fa, fb):
             # v_mfma_f32_32x32x16: A[row = r31][k = 8 khalf ..], B[k = 8 khalf ..][col = r31]; D[row = 8 g + 4 khalf + e][col = r31] in v = 4 g + e
+            assert not np.isnan(fa).any() and not np.isnan(fb).any(), "a fragment read hit LDS nobody wrote (or the epilogue's stage)"
             for wave in range(8):
                 for kk in range(4):
                     for ci in range(2):
@@ -131,56 +144,74 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
                                     for e in range(4):
                                         acc[wave, lane, ci, pi, 4 * g + e] += Dm[8 * g + 4 * khalf + e, r31]
 
-        # prologue
+        # prologue of the workgroup's first tile
+        i = wg
+        q0, co0 = tile_of(i)
+        xoff = make_xoff(q0)
         for k in range(SPW):
-            issue_slab_piece(0, k)
+            issue_slab_piece(xoff, 0, 0, k)
         for d in range(D):
-            issue_w(0, d, d)
+            issue_w(co0, 0, d, d)
         cur = read_frags(0, 0, 0)
-        assert not np.isnan(cur[0]).any() and not np.isnan(cur[1]).any()
-        for cs in range(csteps):
-            last = cs + 1 >= csteps
-            for tap in range(9):
-                s = 9 * cs + tap
-                st = s % NW
-                assert st == (tap % 3 if NW == 3 else (cs + tap) & 3)
-                if not last or tap < 9 - D:
-                    t2 = (tap + D) % 9
-                    issue_w(cs + (1 if tap + D >= 9 else 0), t2, st)
-                if tap < SPW and not last:
-                    issue_slab_piece(cs + 1, tap)
-                # NOTE: the emulation completes loads instantly, so it checks addressing, not the wait counts
-                nxt = read_frags(cs + (1 if tap == 8 else 0), (tap + 1) % 9, (s + 1) % NW) if s + 1 < 9 * csteps else None
-                mfma_step(*cur)
-                cur = nxt
-        # epilogue
-        for wave in range(8):
-            wm, wn = wave >> 2, wave & 3
-            stage = np.full((64, 8, 8), np.nan, np.float32)            # [px][chunk position][8 channels]
-            for lane in range(64):
-                r31, khalf = lane & 31, lane >> 5
+        vbase = 0
+        while True:
+            nxt_tile = tile_of(i + stride) if G else None
+            has_next = nxt_tile is not None
+            acc = np.zeros((8, 64, 2, 2, 16), np.float32)     # [wave][lane][ci][pi][v]
+            for cs in range(csteps):
+                fin = cs + 1 >= csteps
+                nomore, nxt = fin and not has_next, fin and has_next
+                if nxt:
+                    xoff = make_xoff(nxt_tile[0])              # refreshed before the last slice
+                for tap in range(9):
+                    s = 9 * (vbase + cs) + tap                 # global step number of this workgroup
+                    st = s % NW
+                    assert st == (tap % 3 if NW == 3 else (vbase + cs + tap) & 3)
+                    carry = tap + D >= 9
+                    if not nomore or not carry:
+                        over = carry and nxt
+                        issue_w(nxt_tile[1] if over else co0, 0 if over else cs + (1 if carry else 0), (tap + D) % 9, st)
+                    if tap < SPW and not nomore:
+                        issue_slab_piece(xoff, (cs + 1) & 1, 0 if nxt else (cs + 1) * 64, tap)
+                    # NOTE: the emulation completes loads instantly, so it checks addressing, not the wait counts
+                    last_step = nomore and tap == 8
+                    nxt_frags = None if last_step else read_frags(cs + (1 if tap == 8 else 0), (tap + 1) % 9, (s + 1) % NW)
+                    mfma_step(acc, *cur)
+                    cur = nxt_frags
+            # epilogue: two passes through the slab buffer of the last (odd) slice
+            stage_lo = (SLAB0 + SLB) // 16
+            lds[stage_lo:stage_lo + 32768 // 16] = np.nan          # the stage clobbers that buffer (and nothing else)
+            for wave in range(8):
+                wm, wn = wave >> 2, wave & 3
                 for pi in range(2):
-                    px = pi * 32 + r31
-                    for ci in range(2):
-                        for g in range(4):
-                            chunk = ci * 4 + g
-                            stage[px, chunk ^ (px & 7), khalf * 4:khalf * 4 + 4] = acc[wave, lane, ci, pi, 4 * g:4 * g + 4]
-            for lane in range(64):
-                q = q0 + wn * 64 + (lane >> 3)
-                b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
-                c = lane & 7
-                for j in range(8):
-                    px = j * 8 + (lane >> 3)
-                    v = stage[px, c ^ (px & 7)]
-                    if w < W and h < H and q < Q:
-                        ch = co0 + wm * 64 + c * 8
-                        assert np.isnan(y[b, h, w, ch])
-                        y[b, h, w, ch:ch + 8] = v
-                    q += 8; w += 8
-                    while w >= W1:
-                        w -= W1; h += 1
-                        if h == H1:
-                            h = 0; b += 1
+                    stage = np.full((32, 8, 8), np.nan, np.float32)            # [px][chunk position][8 channels]
+                    for lane in range(64):
+                        r31, khalf = lane & 31, lane >> 5
+                        for ci in range(2):
+                            for g in range(4):
+                                chunk = ci * 4 + g
+                                stage[r31, chunk ^ (r31 & 7), khalf * 4:khalf * 4 + 4] = acc[wave, lane, ci, pi, 4 * g:4 * g + 4]
+                    for lane in range(64):
+                        q = q0 + wn * 64 + pi * 32 + (lane >> 3)
+                        b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
+                        c = lane & 7
+                        for j in range(4):
+                            px = j * 8 + (lane >> 3)
+                            v = stage[px, c ^ (px & 7)]
+                            if w < W and h < H and q < Q:
+                                ch = co0 + wm * 64 + c * 8
+                                assert np.isnan(y[b, h, w, ch])
+                                y[b, h, w, ch:ch + 8] = v
+                            q += 8; w += 8
+                            while w >= W1:
+                                w -= W1; h += 1
+                                if h == H1:
+                                    h = 0; b += 1
+            if not has_next:
+                break
+            i += stride
+            q0, co0 = nxt_tile
+            vbase += csteps
 
     # direct convolution
     xp = np.zeros((B, H + 2, W + 2, Cin), np.float32)
@@ -194,9 +225,11 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0):
 
 if __name__ == "__main__":
     ok = True
-    for (B, H, W, Cin, Cout, NW, SPW) in ((2, 5, 6, 128, 128, 4, 5), (1, 9, 40, 128, 128, 4, 6), (3, 3, 70, 128, 128, 3, 7),
-                                          (2, 19, 19, 256, 256, 4, 5)):
-        good, y, ref = emulate(B, H, W, Cin, Cout, NW, SPW)
-        print((B, H, W, Cin, Cout, NW, SPW), "OK" if good else "MISMATCH (%d wrong, %d unwritten)" % ((y != ref).sum(), np.isnan(y).sum()))
+    for (B, H, W, Cin, Cout, NW, SPW, G) in ((2, 5, 6, 128, 128, 4, 5, None), (1, 9, 40, 128, 128, 4, 6, None), (3, 3, 70, 128, 128, 3, 7, None),
+                                             (2, 19, 19, 256, 256, 4, 5, None),
+                                             (24, 19, 19, 128, 256, 4, 5, 8), (5, 38, 38, 128, 128, 4, 6, 8), (3, 40, 75, 128, 256, 3, 7, 8),
+                                             (40, 7, 9, 256, 128, 4, 5, 8)):
+        good, y, ref = emulate(B, H, W, Cin, Cout, NW, SPW, G=G)
+        print((B, H, W, Cin, Cout, NW, SPW, G), "OK" if good else "MISMATCH (%d wrong, %d unwritten)" % ((y != ref).sum(), np.isnan(y).sum()))
         ok &= good
     sys.exit(0 if ok else 1)
