@@ -331,12 +331,13 @@ int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* const* x_h, c
 int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                  int Cin, int Cout, int relu, int pool, int n_workgroups, void* stream);
 
-/* 3x3 'same' convolution (stride 1, dilation 1) + bias + ReLU for the deep VGG blocks (conv3_x, conv4_x, conv5_x:
- * models/keras_ssd300.py:284-296, keras_ssd512.py twins): the activations of a 256-position tile come into LDS once per 64-channel
- * slice and the nine taps read them at nine displacements (csrc/ssdhip_convh.hip).  Cin % 128 == 0, Cout % 128 == 0, W <= 94;
- * SSDHIP_E_BADARG otherwise.  Same numerics as ssdhip_conv2d_same_nhwc_bf16 (bit-identical results). */
+/* 3x3 'same' convolution (stride 1, dilation 1) + bias + ReLU for the VGG blocks with Cin % 128 == 0 and Cout % 128 == 0 (conv2_2,
+ * conv3_x, conv4_x, conv5_x: models/keras_ssd300.py:279-296, keras_ssd512.py twins), optionally with MaxPooling2D(2, 2, 'same')
+ * fused (pool != 0: y is [B, ceil(H/2), ceil(W/2), Cout]): the activations of a 256-pixel tile come into LDS once per 64-channel
+ * slice and the nine taps read them at nine displacements (csrc/ssdhip_convh.hip).  SSDHIP_E_BADARG for other channel counts.
+ * Same numerics as ssdhip_conv2d_same[_pool2]_nhwc_bf16 (bit-identical results). */
 int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
-                                  int Cin, int Cout, int relu, void* stream);
+                                  int Cin, int Cout, int relu, int pool, void* stream);
 
 /* First layer (conv1_1, models/keras_ssd300.py:274): 3x3 'same' convolution of a 3-channel NHWC bf16 image into 64 channels
  * + bias + ReLU, one thread per pixel (the op is bound by writing the 64-channel map).  Cin must be 3, Cout 64. */

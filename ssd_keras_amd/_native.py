@@ -451,6 +451,29 @@ def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
     return y
 
 
+def conv3x3_halo(x, weight, bias, relu=True, pool=False):
+    """3x3 'same' convolution + bias + ReLU [+ 2x2 / stride-2 'same' max-pool] through the slab kernel (csrc/ssdhip_convh.hip):
+    Cin % 128 == 0, Cout % 128 == 0.  Layouts as conv2d_same; bit-identical to conv2d_same / conv2d_same_pool2."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_halo_bound", False):
+        lib.ssdhip_conv3x3_halo_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_halo_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+        lib._halo_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or kh != 3 or kw != 3:
+        raise SsdHipError("weight must be bfloat16 (Cout, %d, 3, 3)" % cin)
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    y = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_halo_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(bool(relu)), int(bool(pool)),
+                                               current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_halo_nhwc_bf16")
+    return y
+
+
 def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True, variant=None):
     """Convolution (kernel 1 or 3, stride 1..4, zero padding <= (k//2)*dilation: torch.nn.Conv2d semantics) + bias + ReLU in
     ONE libssdhip MFMA kernel -- the strided / 'valid' extra layers of the SSD trunk.  Layouts as conv2d_same."""

@@ -1053,9 +1053,9 @@ extern "C" int ssdhip_conv2d_nhwc_bf16_variant(int variant, const void* x, const
 extern "C" int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                                     int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu,
                                                     void* stream) {
-    if (variant == 7) {                       // the slab kernel of ssdhip_convh.hip (3x3, dilation 1, Cin % 128 == 0, W <= 94)
+    if (variant == 7) {                       // the slab kernel of ssdhip_convh.hip (3x3, dilation 1, Cin % 128 == 0, Cout % 128 == 0)
         if (kernel != 3 || dilation != 1) return SSDHIP_E_BADARG;
-        return ssdhip_conv3x3_halo_nhwc_bf16(x, weight, bias, y, B, H, W, Cin, Cout, relu, stream);
+        return ssdhip_conv3x3_halo_nhwc_bf16(x, weight, bias, y, B, H, W, Cin, Cout, relu, 0, stream);
     }
     if (variant != 1 && variant != 4 && variant != 5 && variant != 6) return SSDHIP_E_BADARG;
     return conv_run(variant, x, weight, bias, y, B, H, W, Cin, Cout, kernel, dilation, relu, stream);

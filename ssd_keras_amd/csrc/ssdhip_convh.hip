@@ -57,6 +57,7 @@ struct ConvHParams {
     int H, W, Cin, Cout, relu;
     int Q, q_tiles, n_tiles;     // padded positions B (H+1)(W+1); tiles of 256 positions; tiles of 128 channels
     int total_ids;               // workgroup ids that map to tiles: ceil(q_tiles / 8) * n_tiles * 8 (some of the last ones to none)
+    int HT, WT, Ho, Wo;          // 2-D tiles: tiles per image (q_tiles = B HT WT); pooled map size
     int x_bytes, w_bytes;
 };
 
@@ -93,8 +94,17 @@ __device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
 // slots later; 128: persistent workgroups (one per CU) that walk over tiles and request the next tile's first slab and weights during
 // the last slice of the current one.  Profiling build only (wrong results, they isolate one cost each): 1 no loads in the K loop, 2 no
 // fragment reads, 4 no waits / barrier, 32 no MFMAs.
-template <int NW, int SPW, int MODE>
+// CSH = 0: tiles of 256 consecutive positions of the padded grid (maps up to 94 wide).  CSH = 4 | 5: 2-D tiles of 16 x 16 | 8 x 32
+// pixels of ONE image with a one-pixel halo ring in the slab ((TR + 2)(TC + 2) <= 340 rows whatever the map size): the same pipeline,
+// only the slab <-> pixel map, the lanes' slab rows and the epilogue differ.  A lane's two position blocks (pi = 0, 1) are then the
+// same column of the two rows of a row pair and lane ^ 1 is the neighbouring column, so POOL (MaxPooling2D(2, 2, 'same') fused:
+// models/keras_ssd300.py:279-283) takes the 2 x 2 maximum on the float32 accumulators in registers, as conv_igemm4_pool_kernel does.
+template <int NW, int SPW, int MODE, int CSH, bool POOL>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds) {
+    constexpr bool G2 = CSH != 0;
+    constexpr int TC = G2 ? (1 << CSH) : 1, TR = G2 ? (CH_BN >> CSH) : 1, SC2 = TC + 2;   // tile columns, rows; slab columns
+    static_assert(!POOL || G2, "the pooled epilogue needs 2-D tiles");
+    static_assert(!G2 || (TR + 2) * (TC + 2) <= 64 * SPW, "the 2-D slab must fit the slab buffer");
     constexpr int D = NW;                                // weights of step s + D are requested during step s
     constexpr int SLAB0 = NW * CH_WST, SLB = SPW * 8192;
     constexpr unsigned OOB = 0x80000000u;
@@ -106,7 +116,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     auto tile_of = [&](const int id, int& q0, int& co0) {
         const int xcd = id & 7, slot = id >> 3;
         const int qt = (slot / p.n_tiles) * 8 + xcd;
-        q0 = qt * CH_BN;
+        q0 = G2 ? qt : qt * CH_BN;                       // 1-D: first position of the tile; 2-D: the tile's index (image, tile row, tile column)
         co0 = (slot % p.n_tiles) * CH_BM;
         return id < p.total_ids && qt < p.q_tiles;
     };
@@ -126,10 +136,31 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     // ---- per-lane load descriptors --------------------------------------------------------------------------------------
     // slab row r <-> position q0 - (W + 2) + r; piece (k, wave) = rows 64 k + 8 wave .. + 7, lane -> row (lane >> 3), chunk slot
     // (lane & 7) holding source chunk (lane & 7) ^ ((row >> 1) & 7)
-    const int SP = CH_BN + 2 * W + 4;                    // slab rows a tile reads
+    const int SP = G2 ? (TR + 2) * SC2 : CH_BN + 2 * W + 4;   // slab rows a tile reads
+    auto tile_origin = [&](const int qt, int& b, int& h0, int& w0) {       // 2-D
+        const int wt = qt % p.WT, r = qt / p.WT;
+        b = r / p.HT;
+        h0 = (r - b * p.HT) * TR;
+        w0 = wt * TC;
+    };
     u32 xoff[SPW];
     auto make_xoff = [&](const int tile_q0) {
         const int row0 = wave * 8 + (lane >> 3);
+        if constexpr (G2) {
+            // slab row s = (sr, sc) of the (TR + 2) x (TC + 2) halo window: pixel (h0 - 1 + sr, w0 - 1 + sc), zeros outside the image
+            int b, h0, w0;
+            tile_origin(tile_q0, b, h0, w0);
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                const int row = row0 + 64 * k;
+                const int j = (lane & 7) ^ ((row >> 1) & 7);
+                const int sr = row / SC2, sc = row - sr * SC2;
+                const int hh = h0 - 1 + sr, ww = w0 - 1 + sc;
+                const bool ok = row < SP && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+                xoff[k] = ok ? (u32)(((b * H + hh) * W + ww) * (Cin * 2) + j * 16) : OOB;
+            }
+            return;
+        }
         int q = tile_q0 - (W + 2) + row0;
         int b = 0, h = 0, w = 0;
         if (q >= 0) { b = q / (H1 * W1); const int r = q - b * (H1 * W1); h = r / W1; w = r - h * W1; }
@@ -167,7 +198,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) abase[kk] = (u32)(row * 128 + (((2 * kk + khalf) ^ ((row >> 1) & 7)) << 4));
     }
-    const int prow = wn * 64 + r31;                      // slab row of the lane's first position at tap (0, 0)
+    // slab row of the lane's first position (pi = 0) at tap (0, 0), and the distance to its second one.  2-D: slot = wn * 32 + r31 is
+    // (row pair, column) = (slot / TC, slot % TC) of the tile, pi the row of the pair
+    const int slot2 = wn * 32 + r31;
+    const int prow = G2 ? (2 * (slot2 >> CSH)) * SC2 + (slot2 & (TC - 1)) : wn * 64 + r31;
+    constexpr int PISTEP = G2 ? SC2 : 32;
 
     f32x16 acc[2][2];
     bf16x8 fa[2][4][2], fb[2][4][2];                     // [register set][k16 block][ci | pi]
@@ -175,7 +210,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     u32 ra[4], rb[2], re[2];                             // addresses of the pending fragment reads
     auto read_addr = [&](const int cs, const int tap, const int stage) {     // the fragments of tap `tap` of slice `cs`
         u32 wst = (u32)(stage * CH_WST);
-        u32 toff = (u32)((tap / 3) * W1 + tap % 3);
+        u32 toff = (u32)((tap / 3) * (G2 ? SC2 : W1) + tap % 3);
         u32 sl = (u32)(SLAB0 + (cs & 1) * SLB);
         // opaque to the optimiser: with the taps unrolled it otherwise computes the addresses of all nine steps up front (72 VGPRs)
         asm volatile("" : "+s"(wst), "+s"(toff), "+s"(sl));
@@ -183,7 +218,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         for (int kk = 0; kk < 4; ++kk) ra[kk] = abase[kk] + wst;
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
-            const u32 row = (u32)(prow + pi * 32) + toff;
+            const u32 row = (u32)(prow + pi * PISTEP) + toff;
             rb[pi] = sl + (row << 7);
             re[pi] = (((row >> 1) & 7u) ^ (u32)khalf) << 4;     // chunk (2 kk + khalf) ^ swz = (2 kk) ^ (khalf ^ swz)
         }
@@ -327,11 +362,57 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                     const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
                     bv[ci][4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
                 }
-        {
-            int q = q0 + wn * 64 + (lane >> 3);
-            int b = q / (H1 * W1);
-            const int r = q - b * (H1 * W1);
-            int h = r / W1, w = r - h * W1;
+        if constexpr (POOL) {
+            // 2 x 2 maximum in registers (vertical: the lane's two position blocks; horizontal: lane ^ 1 by DPP), THEN bias + ReLU +
+            // one rounding -- all monotonic, so this equals pooling the rounded activations.  Even lanes hold the wave's 16 pooled
+            // pixels; they go through the LDS transpose and leave as 16-byte stores.
+            int b, h0, w0;
+            tile_origin(q0, b, h0, w0);
+            const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
+            const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[ci][0][4 * g + e];
+                        const float below = acc[ci][1][4 * g + e];
+                        if (has_below) v = below > v ? below : v;
+                        const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+                        if (has_right) v = right > v ? right : v;
+                        v += bv[ci][4 * g + e];
+                        o[e] = p.relu ? ch_relu(v) : v;
+                    }
+                    if (!(r31 & 1)) {
+                        const int px = r31 >> 1, chunk = ci * 4 + g;
+                        *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
+                            make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = j * 64 + lane, px = idx >> 3, c = idx & 7;     // 16 pooled pixels x 8 chunks
+                const int se = wn * 32 + 2 * px;                                // the even lane's slot
+                const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+                if (ho < p.Ho && wo < p.Wo)
+                    *reinterpret_cast<uint4*>(p.y + ((size_t)((b * p.Ho + ho) * p.Wo + wo)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            int q = 0, b = 0, h = 0, w = 0, h0 = 0, w0 = 0;
+            if constexpr (G2) {
+                tile_origin(q0, b, h0, w0);
+            } else {
+                q = q0 + wn * 64 + (lane >> 3);
+                b = q / (H1 * W1);
+                const int r = q - b * (H1 * W1);
+                h = r / W1;
+                w = r - h * W1;
+            }
             const int c = lane & 7;
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
@@ -354,11 +435,18 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 for (int j = 0; j < 4; ++j) {
                     const int px = j * 8 + (lane >> 3);                  // of this pass's 32 positions
                     const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
-                    if (w < W && h < H && q < p.Q)
-                        *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + h) * W + w)) * p.Cout + co0 + wm * 64 + c * 8) = v;
-                    q += 8;
-                    w += 8;
-                    while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+                    if constexpr (G2) {
+                        const int sl = wn * 32 + px;
+                        const int hh = h0 + 2 * (sl >> CSH) + pi, ww = w0 + (sl & (TC - 1));
+                        if (hh < H && ww < W)
+                            *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + hh) * W + ww)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                    } else {
+                        if (w < W && h < H && q < p.Q)
+                            *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + h) * W + w)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                        q += 8;
+                        w += 8;
+                        while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
             }
@@ -373,22 +461,31 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int NW, int SPW, int MODE>
+template <int NW, int SPW, int MODE, int CSH, bool POOL>
 __global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE>(p, lds);
+    convh_body<NW, SPW, MODE, CSH, POOL>(p, lds);
 #endif
 }
 
+// geom: 0 = padded position grid; 4 | 5 = 2-D tiles of 16 x 16 | 8 x 32 pixels
 template <int MODE>
-static void convh_launch(const ConvHParams& p, int n_cu, hipStream_t stream) {
+static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hipStream_t stream) {
     int grid = p.total_ids;
     if ((MODE & 128) && grid > n_cu) grid = n_cu;        // persistent: one workgroup per CU (a multiple of 8: the id -> XCD map)
+    const dim3 g(grid), t(CH_THREADS);
+    if (geom == 4) {
+        if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, true>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, false>), g, t, 0, stream, p);
+    } else if (geom == 5) {
+        if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, true>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, false>), g, t, 0, stream, p);
+    }
     // slab rows = 256 + 2 W + 4 <= 64 SPW: three weight stages + 7 pieces per wave (W <= 94), four + 6 (W <= 62), four + 5 (W <= 30)
-    if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
-    else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL((convh_kernel<3, 7, MODE>), dim3(grid), dim3(CH_THREADS), 0, stream, p);
+    else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false>), g, t, 0, stream, p);
+    else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false>), g, t, 0, stream, p);
 }
 
 }  // namespace ssdhip
@@ -396,23 +493,40 @@ static void convh_launch(const ConvHParams& p, int n_cu, hipStream_t stream) {
 using namespace ssdhip;
 
 // y[b,h,w,co] = act(bias[co] + sum_{kh,kw,ci} x[b, h + kh - 1, w + kw - 1, ci] * w[co,kh,kw,ci]), zero padding: the 3x3 'same'
-// convolutions of the deep VGG blocks.  Cin % 128 == 0, Cout % 128 == 0, W <= 94; SSDHIP_E_BADARG otherwise (callers fall back to
-// ssdhip_conv2d_same_nhwc_bf16, whose results are bit-identical).
+// convolutions of the VGG blocks with Cin % 128 == 0 and Cout % 128 == 0; pool != 0: MaxPooling2D(2, 2, 'same') fused, y is
+// [B, ceil(H/2), ceil(W/2), Cout].  Maps up to 94 wide without pooling run on the padded position grid, everything else on 2-D
+// tiles.  SSDHIP_E_BADARG for other channel counts (callers fall back to ssdhip_conv2d_same[_pool2]_nhwc_bf16: bit-identical results).
 extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
-                                             int Cin, int Cout, int relu, void* stream_) {
+                                             int Cin, int Cout, int relu, int pool, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
-    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM) || W > 94) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
     const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2;
-    const long long Q = (long long)B * (H + 1) * (W + 1);
-    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL) return SSDHIP_E_BADARG;
     ConvHParams p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
-    p.Q = (int)Q;
-    p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.HT = p.WT = 0;
+    int geom = 0;
+    if (pool || W > 94) {                                 // 2-D tiles: 16 x 16 or 8 x 32 pixels, whichever pads the map less
+        long long best = -1;
+        for (int csh = 4; csh <= 5; ++csh) {
+            const long long wt = (W + (1 << csh) - 1) >> csh, ht = (H + (256 >> csh) - 1) / (256 >> csh);
+            if (best < 0 || wt * ht < best) { best = wt * ht; geom = csh; p.WT = (int)wt; p.HT = (int)ht; }
+        }
+        const long long tiles = (long long)B * p.HT * p.WT;
+        if (tiles > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        p.Q = 0;
+        p.q_tiles = (int)tiles;
+    } else {
+        const long long Q = (long long)B * (H + 1) * (W + 1);
+        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        p.Q = (int)Q;
+        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+    }
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
@@ -428,18 +542,18 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     int mode = 128;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     switch (mode) {
-        case 64: convh_launch<64>(p, cu_count, stream); break;
+        case 64: convh_launch<64>(p, geom, pool, cu_count, stream); break;
 #if defined(SSDHIP_PROFILE)
-        case 192: convh_launch<192>(p, cu_count, stream); break;                               // other schedules and ablations (1, 2, 4, 32: wrong results): tools/ablate_convh.py
-        case 0: convh_launch<0>(p, cu_count, stream); break;
-        case 72: convh_launch<72>(p, cu_count, stream); break;
-        case 65: convh_launch<65>(p, cu_count, stream); break;
-        case 66: convh_launch<66>(p, cu_count, stream); break;
-        case 68: convh_launch<68>(p, cu_count, stream); break;
-        case 71: convh_launch<71>(p, cu_count, stream); break;
-        case 32: convh_launch<32>(p, cu_count, stream); break;
+        case 192: convh_launch<192>(p, geom, pool, cu_count, stream); break;                               // other schedules and ablations (1, 2, 4, 32: wrong results): tools/ablate_convh.py
+        case 0: convh_launch<0>(p, geom, pool, cu_count, stream); break;
+        case 72: convh_launch<72>(p, geom, pool, cu_count, stream); break;
+        case 65: convh_launch<65>(p, geom, pool, cu_count, stream); break;
+        case 66: convh_launch<66>(p, geom, pool, cu_count, stream); break;
+        case 68: convh_launch<68>(p, geom, pool, cu_count, stream); break;
+        case 71: convh_launch<71>(p, geom, pool, cu_count, stream); break;
+        case 32: convh_launch<32>(p, geom, pool, cu_count, stream); break;
 #endif
-        default: convh_launch<128>(p, cu_count, stream); break;
+        default: convh_launch<128>(p, geom, pool, cu_count, stream); break;
     }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

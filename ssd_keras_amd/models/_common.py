@@ -116,7 +116,7 @@ class _ConvBiasActFn(torch.autograd.Function):
             wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
             # (the deep 3x3 layers through the slab kernel, csrc/ssdhip_convh.hip: bit-identical and faster, r02o)
             import os
-            halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0 and gy.shape[3] <= 94
+            halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0
                     and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
             gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
         masks = [need_x and gx is None, True, False]
@@ -240,10 +240,11 @@ class SSDModel(nn.Module):
 
     @staticmethod
     def _halo_ok(conv, x):
-        """csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin and Cout multiples of 128, map at most 94 wide (the slab must fit in LDS)."""
+        """csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin and Cout multiples of 128 (maps up to 94 wide on the padded position grid,
+        wider ones and the pooled form on 2-D tiles)."""
         import os
         return (conv.kernel_size == (3, 3) and conv.dilation == (1, 1) and conv.in_channels % 128 == 0
-                and conv.out_channels % 128 == 0 and x.shape[3] <= 94 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
+                and conv.out_channels % 128 == 0 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
 
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
@@ -412,6 +413,8 @@ class SSDModel(nn.Module):
                 if (kernel == 2 and stride == 2 and pad == 0 and (ceil_mode or x.shape[2] % 2 == 0) and (ceil_mode or x.shape[3] % 2 == 0)):
                     # pooling fused into the convolution's epilogue: the full-resolution activation is never written
                     cands["igemm_pool"] = lambda: nat.conv2d_same_pool2(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True)
+                    if self._halo_ok(conv, x):
+                        cands["halo_pool"] = lambda: nat.conv3x3_halo(x, conv.weight, conv.bias, relu=True, pool=True)
                     if conv.in_channels == 64 and conv.kernel_size == (3, 3) and conv.dilation[0] == 1:
                         cands["c64_pool"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=True, pool=True)
             name = (self._pick(("pool", tuple(x.shape), conv.out_channels, conv.kernel_size[0], conv.dilation[0], kernel, stride, pad),

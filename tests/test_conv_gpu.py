@@ -301,10 +301,55 @@ def test_slab_conv_full_batch_race_screen(slab_mode):
             assert torch.equal(got, base), (B, H, W, Cin, Cout)
 
 
+HALO_2D_CASES = [  # B, H, W, Cin, Cout, bias, relu, pool      (2-D tiles: maps wider than 94 and every pooled call)
+    (2, 150, 150, 128, 128, True, True, True),     # conv2_2 -> pool2: 8 x 32 tiles (150 = 4.7 x 32: one ragged tile column)
+    (2, 150, 150, 128, 128, True, True, False),
+    (1, 75, 75, 256, 256, True, True, True),       # conv3_3 -> pool3: odd map, 'same' pooling clips the last window
+    (3, 37, 21, 128, 256, False, True, True),      # odd in both directions, no bias, two channel tiles
+    (1, 128, 128, 128, 256, True, True, False),    # SSD512 conv3_1: 16 x 16 tiles, no padding waste
+    (2, 9, 100, 128, 128, True, False, False),     # wide and flat, no ReLU
+    (5, 2, 2, 128, 128, True, True, True),         # one pooling window per image
+    (2, 16, 16, 256, 128, True, True, True),       # exactly one tile per image
+]
+
+
+@pytest.mark.parametrize("case", HALO_2D_CASES)
+def test_slab_conv_2d_tiles_and_fused_pool(case, slab_mode):
+    """ssdhip_conv3x3_halo_nhwc_bf16 on 2-D tiles, plain and with MaxPooling2D(2, 2, 'same') fused: BIT-identical to the
+    implicit-GEMM kernels (conv2d_same / conv2d_same_pool2), stable across repeated launches."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, has_bias, relu, pool = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
+    base = (nat.conv2d_same_pool2(x, wt, bias, relu=relu) if pool else nat.conv2d_same(x, wt, bias, relu=relu, variant=4))
+    got = nat.conv3x3_halo(x, wt, bias, relu=relu, pool=pool)
+    assert got.shape == base.shape
+    diff = int((got.view(torch.int16) != base.view(torch.int16)).sum().item())
+    assert diff == 0, "%d of %d outputs differ from the implicit-GEMM kernel" % (diff, got.numel())
+    for _ in range(8):
+        assert torch.equal(nat.conv3x3_halo(x, wt, bias, relu=relu, pool=pool).view(torch.int16), got.view(torch.int16))
+
+
+def test_slab_conv_pool_full_batch_race_screen(slab_mode):
+    """conv2_2 -> pool2 at batch 32 (BASELINE configs[1]): 15 launches, all bit-identical to conv_igemm4_pool_kernel."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((32, 150, 150, 128), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((128, 3, 3, 128), generator=g, device="cuda") / 34.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((128,), generator=g, device="cuda").to(torch.bfloat16)
+    base = nat.conv2d_same_pool2(x, wt, bias, relu=True).view(torch.int16)
+    for _ in range(15):
+        assert torch.equal(nat.conv3x3_halo(x, wt, bias, relu=True, pool=True).view(torch.int16), base)
+
+
 def test_slab_conv_rejects_unsupported_shapes():
     import torch
     from ssd_keras_amd import _native as nat
-    for (H, W, Cin, Cout, dil) in ((8, 95, 128, 128, 1), (8, 8, 64, 128, 1), (8, 8, 128, 64, 1), (8, 8, 128, 128, 2)):
+    for (H, W, Cin, Cout, dil) in ((8, 8, 64, 128, 1), (8, 8, 128, 64, 1), (8, 8, 128, 128, 2)):
         x = torch.zeros((1, H, W, Cin), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
         wt = torch.zeros((Cout, 3, 3, Cin), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
         with pytest.raises(nat.SsdHipError):

@@ -17,7 +17,7 @@ import numpy as np
 BN, BM, WST = 256, 128, 128 * 128
 
 
-def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
+def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None, csh=0, pool=False):
     """G: None = one workgroup per tile; an int (multiple of 8) = that many PERSISTENT workgroups, each walking over its tiles with
     one LDS image and requesting the next tile's first slab / weights during the last slice of the current one (MODE bit 128)."""
     rng = np.random.RandomState(seed)
@@ -31,10 +31,18 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
     W1, H1 = W + 1, H + 1
     Q = B * H1 * W1
     q_tiles = (Q + BN - 1) // BN
+    G2 = csh != 0
+    TC, TR = (1 << csh, 256 >> csh) if G2 else (1, 1)
+    SC2 = TC + 2
+    if G2:                                               # 2-D tiles of TR x TC pixels of one image
+        WT, HT = (W + TC - 1) // TC, (H + TR - 1) // TR
+        q_tiles = B * HT * WT
+        assert (TR + 2) * SC2 <= 64 * SPW
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
     n_tiles = Cout // BM
     csteps = Cin // 64
-    assert Cin % 128 == 0 and Cout % 128 == 0 and 256 + 2 * W + 4 <= 64 * SPW and SPW + D <= 10
-    y = np.full((B, H, W, Cout), np.nan, np.float32)
+    assert Cin % 128 == 0 and Cout % 128 == 0 and (G2 or 256 + 2 * W + 4 <= 64 * SPW) and SPW + D <= 10
+    y = np.full((B, Ho, Wo, Cout) if pool else (B, H, W, Cout), np.nan, np.float32)
     OOB = None
 
     total_ids = ((q_tiles + 7) // 8) * n_tiles * 8
@@ -42,9 +50,14 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
     def tile_of(i):
         xcd, slot = i & 7, i >> 3
         qt = (slot // n_tiles) * 8 + xcd
-        return (qt * BN, (slot % n_tiles) * BM) if (i < total_ids and qt < q_tiles) else None
+        return ((qt if G2 else qt * BN), (slot % n_tiles) * BM) if (i < total_ids and qt < q_tiles) else None
 
-    SP = BN + 2 * W + 4
+    def tile_origin(qt):
+        wt, r = qt % WT, qt // WT
+        b = r // HT
+        return b, (r - b * HT) * TR, wt * TC
+
+    SP = (TR + 2) * SC2 if G2 else BN + 2 * W + 4
     stride = G if G else total_ids
     for wg in range(min(stride, total_ids)):
         if tile_of(wg) is None:
@@ -66,6 +79,16 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
             for wave in range(8):
                 for lane in range(64):
                     row0 = wave * 8 + (lane >> 3)
+                    if G2:
+                        b, h0, w0 = tile_origin(q0)
+                        for k in range(SPW):
+                            row = row0 + 64 * k
+                            j = (lane & 7) ^ ((row >> 1) & 7)
+                            sr, sc = row // SC2, row % SC2
+                            hh, ww = h0 - 1 + sr, w0 - 1 + sc
+                            ok = row < SP and 0 <= hh < H and 0 <= ww < W
+                            xo[wave, lane, k] = (((b * H + hh) * W + ww) * Cin + j * 8) if ok else OOB
+                        continue
                     q = q0 - (W + 2) + row0
                     b = h = w = 0
                     if q >= 0:
@@ -105,20 +128,22 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
             """-> fa[wave][lane][kk][ci] (8 elems), fb[wave][lane][kk][pi]"""
             fa = np.empty((8, 64, 4, 2, 8), np.float32)
             fb = np.empty((8, 64, 4, 2, 8), np.float32)
-            toff = (tap // 3) * W1 + tap % 3
+            toff = (tap // 3) * (SC2 if G2 else W1) + tap % 3
             sl = SLAB0 + (cs & 1) * SLB
             for wave in range(8):
                 wm, wn = wave >> 2, wave & 3
                 for lane in range(64):
                     r31, khalf = lane & 31, lane >> 5
                     rowa = wm * 64 + r31
-                    prow = wn * 64 + r31
+                    slot2 = wn * 32 + r31
+                    prow = (2 * (slot2 >> csh)) * SC2 + (slot2 & (TC - 1)) if G2 else wn * 64 + r31
+                    pistep = SC2 if G2 else 32
                     for kk in range(4):
                         abase = rowa * 128 + (((2 * kk + khalf) ^ ((rowa >> 1) & 7)) << 4)
                         for ci in range(2):
                             fa[wave, lane, kk, ci] = lds[(stage * WST + abase + ci * 4096) // 16]
                         for pi in range(2):
-                            row = prow + pi * 32 + toff
+                            row = prow + pi * pistep + toff
                             rb = sl + (row << 7)
                             re = (((row >> 1) & 7) ^ khalf) << 4
                             fb[wave, lane, kk, pi] = lds[(rb + (re ^ (kk << 5))) // 16]
@@ -183,6 +208,44 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
             lds[stage_lo:stage_lo + 32768 // 16] = np.nan          # the stage clobbers that buffer (and nothing else)
             for wave in range(8):
                 wm, wn = wave >> 2, wave & 3
+                if pool:
+                    b, h0, w0 = tile_origin(q0)
+                    pooled = np.full((64, 2, 16), np.nan, np.float32)           # [lane][ci][v] after the vertical + horizontal maxima
+                    for lane in range(64):
+                        r31 = lane & 31
+                        slot2 = wn * 32 + r31
+                        pair, col = slot2 >> csh, slot2 & (TC - 1)
+                        has_below, has_right = h0 + 2 * pair + 1 < H, w0 + col + 1 < W
+                        for ci in range(2):
+                            v = acc[wave, lane, ci, 0].copy()
+                            if has_below:
+                                v = np.maximum(v, acc[wave, lane, ci, 1])
+                            pooled[lane, ci] = v
+                    hp = pooled.copy()
+                    for lane in range(64):
+                        slot2 = wn * 32 + (lane & 31)
+                        if w0 + (slot2 & (TC - 1)) + 1 < W:
+                            hp[lane] = np.maximum(pooled[lane], pooled[lane ^ 1])      # DPP quad_perm [1, 0, 3, 2]
+                    stage = np.full((16, 8, 8), np.nan, np.float32)
+                    for lane in range(64):
+                        r31, khalf = lane & 31, lane >> 5
+                        if r31 & 1:
+                            continue
+                        px = r31 >> 1
+                        for ci in range(2):
+                            for g in range(4):
+                                stage[px, (ci * 4 + g) ^ (px & 7), khalf * 4:khalf * 4 + 4] = hp[lane, ci, 4 * g:4 * g + 4]
+                    for lane in range(64):
+                        for j in range(2):
+                            idx = j * 64 + lane
+                            px, c = idx >> 3, idx & 7
+                            se = wn * 32 + 2 * px
+                            ho, wo = (h0 >> 1) + (se >> csh), (w0 + (se & (TC - 1))) >> 1
+                            if ho < Ho and wo < Wo:
+                                ch = co0 + wm * 64 + c * 8
+                                assert np.isnan(y[b, ho, wo, ch])
+                                y[b, ho, wo, ch:ch + 8] = stage[px, c ^ (px & 7)]
+                    continue
                 for pi in range(2):
                     stage = np.full((32, 8, 8), np.nan, np.float32)            # [px][chunk position][8 channels]
                     for lane in range(64):
@@ -192,9 +255,20 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
                                 chunk = ci * 4 + g
                                 stage[r31, chunk ^ (r31 & 7), khalf * 4:khalf * 4 + 4] = acc[wave, lane, ci, pi, 4 * g:4 * g + 4]
                     for lane in range(64):
+                        c = lane & 7
+                        if G2:
+                            b, h0, w0 = tile_origin(q0)
+                            for j in range(4):
+                                px = j * 8 + (lane >> 3)
+                                sl2 = wn * 32 + px
+                                hh, ww = h0 + 2 * (sl2 >> csh) + pi, w0 + (sl2 & (TC - 1))
+                                if hh < H and ww < W:
+                                    ch = co0 + wm * 64 + c * 8
+                                    assert np.isnan(y[b, hh, ww, ch])
+                                    y[b, hh, ww, ch:ch + 8] = stage[px, c ^ (px & 7)]
+                            continue
                         q = q0 + wn * 64 + pi * 32 + (lane >> 3)
                         b = q // (H1 * W1); r = q - b * H1 * W1; h = r // W1; w = r - h * W1
-                        c = lane & 7
                         for j in range(4):
                             px = j * 8 + (lane >> 3)
                             v = stage[px, c ^ (px & 7)]
@@ -220,16 +294,28 @@ def emulate(B, H, W, Cin, Cout, NW, SPW, seed=0, G=None):
     for kh in range(3):
         for kw in range(3):
             ref += np.einsum("bhwc,oc->bhwo", xp[:, kh:kh + H, kw:kw + W], wt[:, kh, kw])
+    if pool:                                              # MaxPooling2D(2, 2, 'same'): windows clipped to the map
+        pr = np.full((B, Ho, Wo, Cout), -np.inf, np.float32)
+        for dh in range(2):
+            for dw in range(2):
+                part = ref[:, dh::2, dw::2]
+                pr[:, :part.shape[1], :part.shape[2]] = np.maximum(pr[:, :part.shape[1], :part.shape[2]], part)
+        ref = pr
     return np.array_equal(y, ref), y, ref
 
 
 if __name__ == "__main__":
     ok = True
-    for (B, H, W, Cin, Cout, NW, SPW, G) in ((2, 5, 6, 128, 128, 4, 5, None), (1, 9, 40, 128, 128, 4, 6, None), (3, 3, 70, 128, 128, 3, 7, None),
-                                             (2, 19, 19, 256, 256, 4, 5, None),
-                                             (24, 19, 19, 128, 256, 4, 5, 8), (5, 38, 38, 128, 128, 4, 6, 8), (3, 40, 75, 128, 256, 3, 7, 8),
-                                             (40, 7, 9, 256, 128, 4, 5, 8)):
-        good, y, ref = emulate(B, H, W, Cin, Cout, NW, SPW, G=G)
-        print((B, H, W, Cin, Cout, NW, SPW, G), "OK" if good else "MISMATCH (%d wrong, %d unwritten)" % ((y != ref).sum(), np.isnan(y).sum()))
+    cases = [(2, 5, 6, 128, 128, 4, 5, None, 0, False), (1, 9, 40, 128, 128, 4, 6, None, 0, False), (3, 3, 70, 128, 128, 3, 7, None, 0, False),
+             (2, 19, 19, 256, 256, 4, 5, None, 0, False),
+             (24, 19, 19, 128, 256, 4, 5, 8, 0, False), (5, 38, 38, 128, 128, 4, 6, 8, 0, False), (3, 40, 75, 128, 256, 3, 7, 8, 0, False),
+             (40, 7, 9, 256, 128, 4, 5, 8, 0, False),
+             (2, 20, 37, 128, 128, 4, 6, None, 4, True), (1, 9, 40, 128, 128, 4, 6, 8, 5, False), (3, 17, 33, 128, 256, 4, 6, 8, 5, True),
+             (2, 33, 18, 128, 128, 4, 6, 8, 4, False)]
+    if len(sys.argv) > 1 and sys.argv[1] == "2d":
+        cases = cases[8:]
+    for (B, H, W, Cin, Cout, NW, SPW, G, csh, pool) in cases:
+        good, y, ref = emulate(B, H, W, Cin, Cout, NW, SPW, G=G, csh=csh, pool=pool)
+        print((B, H, W, Cin, Cout, NW, SPW, G, csh, pool), "OK" if good else "MISMATCH (%d wrong, %d unwritten)" % ((y != ref).sum(), np.isnan(y).sum()))
         ok &= good
     sys.exit(0 if ok else 1)

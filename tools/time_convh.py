@@ -66,5 +66,24 @@ for name, B, H, W, Cin, Cout in LAYERS:
         os.environ.pop("SSDHIP_CONVH_MODE", None)
     print(json.dumps(row), flush=True)
     rows.append(row)
+# conv2_2 -> pool2 (and its SSD512 twin): the fused-pool kernels
+for name, B, H, W, Cin, Cout in (("conv2_2_pool", 32, 150, 150, 128, 128), ("conv3_3_pool", 32, 75, 75, 256, 256),
+                                 ("ssd512_conv2_2_pool", 16, 256, 256, 128, 128)):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+    flop = 2.0 * 9 * Cin * Cout * B * H * W
+    row = {"layer": name, "gflop": flop / 1e9}
+    base = nat.conv2d_same_pool2(x, wt, bias, relu=True).view(torch.int16)
+    row["igemm_pool_us"] = round(timed(lambda: nat.conv2d_same_pool2(x, wt, bias, relu=True)), 1)
+    for mode in MODES:
+        os.environ["SSDHIP_CONVH_MODE"] = str(mode)
+        got = nat.conv3x3_halo(x, wt, bias, relu=True, pool=True).view(torch.int16)
+        us = timed(lambda: nat.conv3x3_halo(x, wt, bias, relu=True, pool=True))
+        row["mode%d" % mode] = {"us": round(us, 1), "tflops": round(flop / us / 1e6, 1), "differs": int((got != base).sum().item())}
+    os.environ.pop("SSDHIP_CONVH_MODE", None)
+    print(json.dumps(row), flush=True)
+    rows.append(row)
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)
