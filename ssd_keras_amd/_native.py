@@ -458,7 +458,7 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     lib = load()
     if not getattr(lib, "_halo_bound", False):
         lib.ssdhip_conv3x3_halo_nhwc_bf16.restype = ctypes.c_int
-        lib.ssdhip_conv3x3_halo_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+        lib.ssdhip_conv3x3_halo_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
         lib._halo_bound = True
     x, (b, h, w, cin) = _nhwc_bf16(x, "x")
     cout, cin_w, kh, kw = weight.shape
