@@ -339,6 +339,13 @@ int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* 
 int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, int pool, void* stream);
 
+/* conv1_1 -> conv1_2 [-> pool1] as ONE kernel (models/keras_ssd300.py:274-276): x3 [B, H, W, 3] bf16 image, w1 [64, 3, 3, 3] + b1 the
+ * first layer (ReLU), weight [Cout, 3, 3, 64] + bias the second one, pool != 0 fuses MaxPooling2D(2, 2, 'same').  The 64-channel map
+ * between the two layers is never written: each tile's halo of it is recomputed from the image inside the kernel
+ * (csrc/ssdhip_conv64.hip).  Bit-identical to ssdhip_conv3x3_cin3_nhwc_bf16 followed by ssdhip_conv3x3_c64_nhwc_bf16. */
+int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, const void* b1, const void* weight, const void* bias, void* y,
+                                 int B, int H, int W, int Cout, int relu, int pool, int n_workgroups, void* stream);
+
 /* First layer (conv1_1, models/keras_ssd300.py:274): 3x3 'same' convolution of a 3-channel NHWC bf16 image into 64 channels
  * + bias + ReLU, one thread per pixel (the op is bound by writing the 64-channel map).  Cin must be 3, Cout 64. */
 int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,

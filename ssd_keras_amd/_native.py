@@ -612,6 +612,40 @@ def conv3x3_cin3(x, weight, bias, relu=True):
     return y
 
 
+def conv1_block(x, w1, b1, weight, bias, relu=True, pool=False):
+    """conv1_1 (3 -> 64 channels, ReLU) -> conv1_2 (64 -> Cout) + bias + ReLU [-> 2x2 / stride-2 'same' max-pool] as ONE kernel
+    (csrc/ssdhip_conv64.hip, FRONT): the 64-channel map between the two layers is never written.  x (B, 3, H, W) bf16 NHWC memory;
+    w1 (64, 3, 3, 3), weight (Cout, 64, 3, 3) bf16 channels_last.  Bit-identical to conv3x3_cin3 followed by conv3x3_c64."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_conv1blk_bound", False):
+        lib.ssdhip_conv1_block_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv1_block_nhwc_bf16.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+        lib._conv1blk_bound = True
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4 or x.shape[1] != 3:
+        raise SsdHipError("x must be a (B, 3, H, W) bfloat16 CUDA tensor")
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    b, _, h, w = x.shape
+    if tuple(w1.shape) != (64, 3, 3, 3) or weight.shape[1:] != (64, 3, 3) or w1.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+        raise SsdHipError("conv1_block needs bfloat16 (64, 3, 3, 3) and (Cout, 64, 3, 3) weights")
+    cl = lambda t: t if t.permute(0, 2, 3, 1).is_contiguous() else t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    w1c, w2c = cl(w1), cl(weight)
+    cout = weight.shape[0]
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    y = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    dev = x.device
+    n_cu = _CU_COUNT.get(dev.index)
+    if n_cu is None:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        _CU_COUNT[dev.index] = n_cu
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_conv1_block_nhwc_bf16(_ptr(x), _ptr(w1c), _ptr(b1), _ptr(w2c), _ptr(bias), _ptr(y), b, h, w, cout, int(bool(relu)),
+                                              int(bool(pool)), int(n_cu), current_stream_ptr(dev))
+    check(rc, "ssdhip_conv1_block_nhwc_bf16")
+    return y
+
+
 # ------------------------------------------------------------------------------------------------
 # public box utilities (csrc/ssdhip_boxes.hip)
 # ------------------------------------------------------------------------------------------------

@@ -35,10 +35,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C64_THREADS = 320;                         // four multiplying waves (one per SIMD) + one loader wave
+constexpr int C64_NPROD = 3;                             // FRONT: producer waves
+constexpr int C64_FRONT_THREADS = (4 + C64_NPROD) * 64;  // FRONT: four multiplying waves + the producers
 constexpr int C64_WBYTES = 9 * 64 * 128;                 // resident weight slice: [tap][co][64 ci] bf16, 128-byte rows
 constexpr int C64_STAGE = 4 * 2048;                      // per-wave output transpose: 32 px x 64 B (non-pooled: twice per tile)
 constexpr int c64_halo_bytes(int cs) { return ((9 * (2 * (64 >> cs) + 2) * ((1 << cs) + 2) + 63) / 64) * 1024; }
-constexpr int c64_lds_bytes(int cs, int nb) { return C64_WBYTES + nb * c64_halo_bytes(cs) + C64_STAGE; }
+constexpr int C64_PATCH1 = 1600;                         // FRONT: one producer's copy of the 3-channel input patch of a tile's halo (13 x 20 px x 3 ch bf16 = 1560 B)
+constexpr int C64_PATCH = ((C64_NPROD * C64_PATCH1 + 1023) / 1024) * 1024;
+constexpr int c64_lds_bytes(int cs, int nb, bool front = false) { return C64_WBYTES + nb * c64_halo_bytes(cs) + C64_STAGE + (front ? C64_PATCH : 0); }
 
 struct C64Params {
     const bf16_t* x;             // [B, H, W, 64]
@@ -49,6 +53,9 @@ struct C64Params {
     int HT, WT, n_slices, tiles; // tiles per image grid: HT x WT, tiles = B * HT * WT
     int Ho, Wo;                  // pooled map (POOL)
     int x_bytes, w_bytes;
+    const bf16_t* x3;            // FRONT: [B, H, W, 3] image; x is unused
+    const bf16_t* w1;            // FRONT: [64, 3, 3, 3] first-layer filters
+    const bf16_t* b1;            // FRONT: [64] first-layer bias or null
 };
 
 __device__ __forceinline__ u32 c64_f2bf_rn(float f) {
@@ -92,7 +99,9 @@ __device__ __forceinline__ i32x4 c64_rsrc(const void* base, int num_records) {
     return r;
 }
 
-template <int CS, bool POOL, int NB>
+// FRONT: the 64-channel input map is never read from memory -- it is conv1_1 (3 -> 64 channels, models/keras_ssd300.py:274) of the
+// 3-channel image, recomputed per tile by the fifth wave straight into the halo buffer (see the producer section below).
+template <int CS, bool POOL, int NB, bool FRONT>
 __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* lds) {
     constexpr int CC = 1 << CS, RP = 64 >> CS;           // tile: RP row pairs x CC columns = 128 pixels
     constexpr int HC = CC + 2, HR = 2 * RP + 2;          // halo columns / rows
@@ -100,8 +109,8 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     constexpr int SLOTS = 9 * HPX;                       // 16-byte slots of a halo buffer
     constexpr int NP = (SLOTS + 63) / 64;                // 1 KiB LDS-DMA pieces per halo
     constexpr int HB = NP * 1024;                        // NB halo buffers: loads run NB - 1 tiles ahead of the MFMAs
-    static_assert(HB == c64_halo_bytes(CS) && c64_lds_bytes(CS, NB) <= 160 * 1024, "LDS budget");
-    constexpr int W_OFF = 0, H_OFF = C64_WBYTES, STAGE_OFF = C64_WBYTES + NB * HB;
+    static_assert(HB == c64_halo_bytes(CS) && c64_lds_bytes(CS, NB, FRONT) <= 160 * 1024, "LDS budget");
+    constexpr int W_OFF = 0, H_OFF = C64_WBYTES, STAGE_OFF = C64_WBYTES + NB * HB, PATCH_OFF = STAGE_OFF + C64_STAGE;
     constexpr unsigned OOB = 0x80000000u;
 
     const int G = (int)gridDim.x;
@@ -142,12 +151,161 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         w0 = wt * CC;
     };
 
+    // ---- FRONT: the producer wave.  The halo of a tile is conv1_1 of the (HR + 2) x (HC + 2) x 3 input patch around it: K = 27
+    //      (padded to 32, k = kh * 9 + kw * 3 + ci as in conv3x3_cin3_kernel -- same operands, same MFMA, hence the same bf16 values
+    //      the separate kernel would have written to memory), 64 channels x 180 halo pixels = 24 v_mfma_f32_32x32x16_bf16 per tile
+    //      against the 288 of the four multiplying waves.  Per tile: 12 two-byte global loads per lane (requested a tile ahead),
+    //      the patch into LDS, per 32 halo pixels 16 two-byte gathers -> B operand, 4 MFMAs, bias + ReLU + rounding (halo pixels
+    //      outside the image become ZERO: they are conv1_2's padding, not conv1_1 of padding), 8-byte stores into the 144-byte halo
+    //      rows.  Two halo buffers: tile i + 1's halo is produced while tile i is multiplied. ----------------------------------
+    if constexpr (FRONT) {
+      if (wave >= 4) {
+        const int prod = wave - 4;                           // producer p: halo pixel blocks p, p + NPROD, ...; each producer keeps its own patch copy
+        constexpr int PR = HR + 2, PC = HC + 2, PROW = PC * 3, PATCH = PR * PROW;      // patch rows / columns / elements per row
+        constexpr int NRAW = (PATCH + 63) / 64, NBLK = (HPX + 31) / 32, MYB = NBLK / C64_NPROD;
+        static_assert(NB == 2 && (PR + 1) * PROW * 2 <= C64_PATCH1 && NRAW * 64 * 2 <= C64_PATCH1 && NBLK % C64_NPROD == 0,
+                      "two halo buffers; a patch copy holds the patch, a spare row and every raw slot");
+        unsigned char* patch = lds + PATCH_OFF + prod * C64_PATCH1;
+        for (int i = lane; i < C64_PATCH1 / 4; i += 64) reinterpret_cast<u32*>(patch)[i] = 0u;   // the spare row is read (x zero weights)
+        // first-layer filters as the MFMA 'A' operand: row = channel, k = (2 st + khalf) * 8 + j, zero beyond k = 26
+        bf16x8 aw[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                union { bf16x8 v; unsigned short u[8]; } t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (2 * st + khalf) * 8 + j;
+                    t.u[j] = k < 27 ? p.w1[(cb * 32 + r31) * 27 + k] : (unsigned short)0;
+                }
+                aw[cb][st] = t.v;
+            }
+        float b1v[2][16];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    b1v[cb][4 * g + e] = p.b1 ? __uint_as_float((u32)p.b1[cb * 32 + 8 * g + 4 * khalf + e] << 16) : 0.f;
+        // gather offsets (bytes into the patch) of the lane's 16 k values relative to its pixel: k -> (kh, r = kw * 3 + ci)
+        u32 kofs[2][8];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = (2 * st + khalf) * 8 + j;
+                kofs[st][j] = (u32)(((k / 9) * PROW + (k % 9)) * 2);          // k = 27 .. 31 read row kh = 3 (x zero weights)
+            }
+        // the lane's halo pixel in each block of 32: patch offset of its top-left tap, halo-row offset, (hr, hc)
+        u32 pbase[MYB], hdst[MYB], hcoord[MYB];
+#pragma unroll
+        for (int blk = 0; blk < MYB; ++blk) {
+            const int hp = (C64_NPROD * blk + prod) * 32 + r31, hpc = hp < HPX ? hp : HPX - 1;
+            const int hr = hpc / HC, hc = hpc - hr * HC;
+            pbase[blk] = (u32)((hr * PROW + hc * 3) * 2);
+            hdst[blk] = (u32)(hpc * 144 + 8 * khalf);
+            hcoord[blk] = (u32)((hr << 8) | hc | (hp < HPX ? 0 : 0x10000));
+        }
+        // raw-load slots: element n = 64 i + lane of the patch = (pr, pc, ci); two-byte buffer loads, an out-of-range offset reads 0
+        const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x3), 0, p.B * p.H * p.W * 6, 0x00020000);
+        u32 rrel[NRAW], rco[NRAW];
+#pragma unroll
+        for (int i = 0; i < NRAW; ++i) {
+            const int n = 64 * i + lane, nn = n < PATCH ? n : 0;
+            const int pr = nn / PROW, rem = nn - pr * PROW, pc = rem / 3;
+            rrel[i] = n < PATCH ? (u32)(((pr * p.W) * 3 + rem) * 2) : OOB;
+            rco[i] = (u32)((pr << 8) | pc);
+        }
+        auto request = [&](int tile, u32 (&raw)[NRAW]) {
+            int b, h0, w0;
+            tile_origin(tile, b, h0, w0);
+            const int ph = h0 - 2, pw = w0 - 2;                               // image position of patch element (0, 0)
+            const bool inside = ph >= 0 && pw >= 0 && ph + PR <= p.H && pw + PC <= p.W;
+            if (inside) {                                                     // the tile's position is a scalar offset
+                const u32 soff = (u32)((((b * p.H + ph) * p.W + pw) * 3) * 2);
+#pragma unroll
+                for (int i = 0; i < NRAW; ++i) raw[i] = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r3, rrel[i], soff, 0);
+            } else {
+                const int base = ((b * p.H + ph) * p.W + pw) * 6;             // may be negative: only added to offsets of in-image elements
+#pragma unroll
+                for (int i = 0; i < NRAW; ++i) {
+                    const int pr = (int)(rco[i] >> 8) & 0xff, pc = (int)rco[i] & 0xff;
+                    const bool ok = rrel[i] != OOB && (unsigned)(ph + pr) < (unsigned)p.H && (unsigned)(pw + pc) < (unsigned)p.W;
+                    raw[i] = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r3, ok ? (u32)(base + (int)rrel[i]) : OOB, 0, 0);
+                }
+            }
+        };
+        auto produce = [&](int tile, const u32 (&raw)[NRAW], int buf) {
+            int b, h0, w0;
+            tile_origin(tile, b, h0, w0);
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) reinterpret_cast<unsigned short*>(patch)[64 * i + lane] = (unsigned short)raw[i];   // slots beyond the patch hold 0
+            unsigned char* hb = lds + H_OFF + buf * HB;
+#pragma unroll
+            for (int blk = 0; blk < MYB; ++blk) {
+                bf16x8 bfr[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    union { bf16x8 v; unsigned short u[8]; } t;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t.u[j] = *reinterpret_cast<const unsigned short*>(patch + pbase[blk] + kofs[st][j]);
+                    bfr[st] = t.v;
+                }
+                const int hr = (int)(hcoord[blk] >> 8) & 0xff, hc = (int)hcoord[blk] & 0xff;
+                // only the very last block of 32 has lanes beyond the halo's pixels
+                const bool live = (blk + 1 < MYB) || !(hcoord[blk] & 0x10000);
+                const bool in_img = (unsigned)(h0 - 1 + hr) < (unsigned)p.H && (unsigned)(w0 - 1 + hc) < (unsigned)p.W;
+                f32x16 a1[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) a1[cb][v] = 0.f;
+                    a1[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[cb][0], bfr[0], a1[cb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) a1[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[cb][1], bfr[1], a1[cb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = c64_relu(a1[cb][4 * g + e] + b1v[cb][4 * g + e]);   // conv1_1's ReLU; branch-free
+                        const u32 lo = c64_pack2(o[0], o[1]), hi = c64_pack2(o[2], o[3]);                    // one rounding, as the separate kernel
+                        if (live)
+                            *reinterpret_cast<uint2*>(hb + hdst[blk] + (cb * 32 + 8 * g) * 2) = make_uint2(in_img ? lo : 0u, in_img ? hi : 0u);
+                    }
+            }
+        };
+        u32 raw_c[NRAW], raw_n[NRAW];
+        request(first, raw_c);
+        produce(first, raw_c, 0);
+        if (first + stride < p.tiles) request(first + stride, raw_c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // halo of the first tile (+ the multipliers' weights) in place
+        int buf = 0;
+        for (int tile = first; tile < p.tiles; tile += stride) {
+            const bool more = tile + stride < p.tiles;
+            if (tile + 2 * stride < p.tiles) request(tile + 2 * stride, raw_n);
+            if (more) produce(tile + stride, raw_c, buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // multipliers done with `buf`; halo of the next tile complete in the other one
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) raw_c[i] = raw_n[i];
+            buf ^= 1;
+        }
+        return;
+      }
+    }
+
     // ---- the loader wave.  VMEM operations complete in issue order and a global store takes microseconds to be acknowledged:
     //      a wave that both stores outputs and waits for halo loads ends up waiting for its own older stores every tile (the
     //      first version of this kernel: 4 us per tile whatever the prefetch depth).  So the halos are fetched by a fifth wave
     //      that never stores -- its vmcnt counts loads only -- and the four multiplying waves never wait on vmcnt at all.
     //      Per tile i:  loader: halo i+1 landed (halo i+2 may fly) | barrier | issue halo i+3 into the buffer tile i released. ----
-    if (wave == 4) {
+    if (!FRONT && wave == 4) {
         // slot n = 64 * piece + lane of a halo buffer -> halo pixel n / 9 (row hr, column hc), 16-byte chunk n % 9 (8 = padding)
         int hrc[NP];                                     // hr << 16 | hc << 4 | chunk, or -1 (padding slot / beyond the halo)
         u32 rel[NP];                                     // byte offset of the slot's 16 bytes from the halo origin pixel (or OOB)
@@ -181,7 +339,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
                 }
             }
         };
-        static_assert(NB == 3 && 2 * NP <= 63, "wait accounting: two halos of NP loads in flight must fit vmcnt");
+        static_assert(FRONT || (NB == 3 && 2 * NP <= 63), "wait accounting: two halos of NP loads in flight must fit vmcnt");
         issue_halo(first, 0);
         if (first + stride < p.tiles) issue_halo(first + stride, 1);
         if (first + 2 * stride < p.tiles) issue_halo(first + 2 * stride, 2);
@@ -343,11 +501,11 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int CS, bool POOL, int NB>
-__global__ __launch_bounds__(C64_THREADS, 1) void conv64_kernel(C64Params p) {
+template <int CS, bool POOL, int NB, bool FRONT = false>
+__global__ __launch_bounds__(FRONT ? C64_FRONT_THREADS : C64_THREADS, 1) void conv64_kernel(C64Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[c64_lds_bytes(CS, NB)];
-    conv64_body<CS, POOL, NB>(p, lds);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[c64_lds_bytes(CS, NB, FRONT)];
+    conv64_body<CS, POOL, NB, FRONT>(p, lds);
 #endif
 }
 
@@ -370,6 +528,7 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+    p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr;
     p.n_slices = Cout / 64;
     int cs_best = 4;
     long long best = -1;
@@ -391,5 +550,48 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
         if (cs_best == 3) C64_LAUNCH(3, false); else C64_LAUNCH(4, false);
     }
 #undef C64_LAUNCH
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// conv1_1 -> conv1_2 [-> pool1] as ONE kernel (models/keras_ssd300.py:274-276, keras_ssd512.py twin): x3 [B, H, W, 3] bf16 (the
+// in-graph preprocessing's output), w1 [64, 3, 3, 3] + b1 the first layer (always followed by ReLU), weight [Cout, 3, 3, 64] + bias
+// the second one.  The 64-channel map between them (368 MB at batch 32, 300 x 300) never exists: every tile's halo of it is
+// recomputed from the image by a producer wave.  Results are bit-identical to ssdhip_conv3x3_cin3_nhwc_bf16 followed by
+// ssdhip_conv3x3_c64_nhwc_bf16.
+extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, const void* b1, const void* weight, const void* bias, void* y,
+                                            int B, int H, int W, int Cout, int relu, int pool, int n_workgroups, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x3 || !w1 || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)weight | (uintptr_t)y) & 15 || (((uintptr_t)x3 | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)bias) & 1)) return SSDHIP_E_BADARG;
+    const long long wb = (long long)Cout * 1152;
+    if ((long long)B * H * W * 3 > 0x7fffff00LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL) return SSDHIP_E_BADARG;
+    C64Params p;
+    p.x = nullptr; p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.x3 = static_cast<const bf16_t*>(x3); p.w1 = static_cast<const bf16_t*>(w1); p.b1 = static_cast<const bf16_t*>(b1);
+    p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.x_bytes = 0; p.w_bytes = (int)wb;
+    p.n_slices = Cout / 64;
+    int cs_best = 4;
+    long long best = -1;
+    for (int cs = 4; cs >= 3; --cs) {                     // tile shape (16 x 8 or 8 x 16 pixels) with the fewer padded tiles
+        const long long wt = (W + (1 << cs) - 1) >> cs, ht = (p.Ho + (64 >> cs) - 1) / (64 >> cs);
+        if (best < 0 || wt * ht < best) { best = wt * ht; cs_best = cs; p.WT = (int)wt; p.HT = (int)ht; }
+    }
+    const long long tiles = (long long)B * p.HT * p.WT;
+    if (tiles > 0x3fffffffLL) return SSDHIP_E_BADARG;
+    p.tiles = (int)tiles;
+    int G = n_workgroups > 0 ? n_workgroups : 256;
+    if (G > 4096) G = 4096;
+    G = (G / p.n_slices) * p.n_slices;
+    if (G < p.n_slices) G = p.n_slices;
+#define C64F_LAUNCH(CS_, POOL_) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 2, true>), dim3(G), dim3(C64_FRONT_THREADS), 0, stream, p)
+    if (pool) {
+        if (cs_best == 3) C64F_LAUNCH(3, true); else C64F_LAUNCH(4, true);
+    } else {
+        if (cs_best == 3) C64F_LAUNCH(3, false); else C64F_LAUNCH(4, false);
+    }
+#undef C64F_LAUNCH
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

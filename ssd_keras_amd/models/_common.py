@@ -422,6 +422,20 @@ class SSDModel(nn.Module):
             return cands[name]()
         return self.max_pool(self.conv_act(conv, x, relu=True), kernel, stride, pad, ceil_mode=ceil_mode)
 
+    def conv1_block_pool(self, c1, c2, x):
+        """conv1_1 -> conv1_2 -> MaxPooling2D(2, 2, 'same') (models/keras_ssd300.py:274-276).  On the fused bf16 inference path the
+        three can run as ONE kernel that never writes the 64-channel full-resolution map (csrc/ssdhip_conv64.hip, FRONT); timed once
+        per shape against the two-kernel form."""
+        same3 = lambda c: (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
+                           and c.groups == 1 and c.bias is not None)
+        if (self._fused(x, c1) and self._fused(x, c2) and same3(c1) and same3(c2) and c1.in_channels == 3 and c1.out_channels == 64
+                and c2.in_channels == 64 and c2.out_channels % 64 == 0):
+            cands = {"separate": lambda: self.conv_act_pool(c2, self.conv_act(c1, x), 2, 2, ceil_mode=True),
+                     "conv1_block": lambda: nat.conv1_block(x, c1.weight, c1.bias, c2.weight, c2.bias, relu=True, pool=True)}
+            cands["separate"]()                              # settles the inner per-layer choices before the two forms are compared
+            return cands[self._pick(("conv1_block", tuple(x.shape), c2.out_channels), cands)]()
+        return self.conv_act_pool(c2, self.conv_act(c1, x), 2, 2, ceil_mode=True)
+
     def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):
         if self._fused(x) and x.shape[1] % 8 == 0:
             return nat.bias_act_maxpool(x, None, kernel, stride, pad, ceil_mode, relu=False)

@@ -31,7 +31,7 @@ class _VGGBase(SSDModel):
 
     def _vgg(self, x):
         ca, cap = self.conv_act, self.conv_act_pool
-        x = cap(self.conv1_2, ca(self.conv1_1, x), 2, 2, ceil_mode=True)          # 'same' pooling pads bottom/right
+        x = self.conv1_block_pool(self.conv1_1, self.conv1_2, x)                # conv1_1 -> conv1_2 -> pool1 ('same' pooling pads bottom/right)
         x = cap(self.conv2_2, ca(self.conv2_1, x), 2, 2, ceil_mode=True)
         x = cap(self.conv3_3, ca(self.conv3_2, ca(self.conv3_1, x)), 2, 2, ceil_mode=True)
         conv4_3 = ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x)))

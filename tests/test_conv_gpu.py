@@ -354,3 +354,43 @@ def test_slab_conv_rejects_unsupported_shapes():
         wt = torch.zeros((Cout, 3, 3, Cin), device="cuda", dtype=torch.bfloat16).permute(0, 3, 1, 2)
         with pytest.raises(nat.SsdHipError):
             nat.conv2d_same(x, wt, None, dilation=dil, relu=True, variant=7)
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 300), (1, 37, 53), (3, 16, 16), (2, 7, 150), (1, 1, 1), (4, 150, 2)])
+@pytest.mark.parametrize("pool", [True, False])
+def test_conv1_block_equals_the_two_kernels(shape, pool):
+    """conv1_1 -> conv1_2 [-> pool1] in one kernel (the 64-channel map between them recomputed per tile from the image): BIT-identical
+    to conv3x3_cin3 followed by conv3x3_c64, repeatable."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(H * 1000 + W)
+    x = (torch.randn((B, H, W, 3), generator=g, device="cuda") * 60).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w1 = (torch.randn((64, 3, 3, 3), generator=g, device="cuda") / 5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    b1 = torch.randn((64,), generator=g, device="cuda").to(torch.bfloat16)
+    w2 = (torch.randn((64, 3, 3, 64), generator=g, device="cuda") / 24).to(torch.bfloat16).permute(0, 3, 1, 2)
+    b2 = torch.randn((64,), generator=g, device="cuda").to(torch.bfloat16)
+    mid = nat.conv3x3_cin3(x, w1, b1, relu=True)
+    base = nat.conv3x3_c64(mid, w2, b2, relu=True, pool=pool)
+    got = nat.conv1_block(x, w1, b1, w2, b2, relu=True, pool=pool)
+    assert got.shape == base.shape
+    diff = int((got.view(torch.int16) != base.view(torch.int16)).sum().item())
+    assert diff == 0, "%d of %d outputs differ from the two-kernel form" % (diff, got.numel())
+    for _ in range(5):
+        assert torch.equal(nat.conv1_block(x, w1, b1, w2, b2, relu=True, pool=pool).view(torch.int16), got.view(torch.int16))
+
+
+def test_conv1_block_full_batch():
+    """Batch 32, 300 x 300 (BASELINE configs[1]) and a 128-channel second layer: 10 launches, all bit-identical to the two kernels."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    for cout in (64, 128):
+        g = torch.Generator(device="cuda").manual_seed(cout)
+        x = (torch.randn((32, 300, 300, 3), generator=g, device="cuda") * 60).to(torch.bfloat16).permute(0, 3, 1, 2)
+        w1 = (torch.randn((64, 3, 3, 3), generator=g, device="cuda") / 5).to(torch.bfloat16).permute(0, 3, 1, 2)
+        b1 = torch.randn((64,), generator=g, device="cuda").to(torch.bfloat16)
+        w2 = (torch.randn((cout, 3, 3, 64), generator=g, device="cuda") / 24).to(torch.bfloat16).permute(0, 3, 1, 2)
+        b2 = torch.randn((cout,), generator=g, device="cuda").to(torch.bfloat16)
+        base = nat.conv3x3_c64(nat.conv3x3_cin3(x, w1, b1, relu=True), w2, b2, relu=True, pool=True).view(torch.int16)
+        for _ in range(10):
+            assert torch.equal(nat.conv1_block(x, w1, b1, w2, b2, relu=True, pool=True).view(torch.int16), base)

@@ -21,3 +21,28 @@ e.record()
 e.synchronize()
 ms = a.elapsed_time(e) / 50
 print("conv1_1: %.1f us, output write %.2f TB/s" % (1e3 * ms, y.numel() * 2 / ms / 1e9))
+
+# conv1_1 -> conv1_2 -> pool1: two kernels against the fused one
+w2 = (torch.randn((64, 3, 3, 64), device="cuda") / 24).to(torch.bfloat16).permute(0, 3, 1, 2)
+b2 = torch.randn((64,), device="cuda").to(torch.bfloat16)
+
+
+def timed(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    e.synchronize()
+    return a.elapsed_time(e) / reps * 1e3
+
+
+two = timed(lambda: nat.conv3x3_c64(nat.conv3x3_cin3(x, w, b, relu=True), w2, b2, relu=True, pool=True))
+c64 = timed(lambda: nat.conv3x3_c64(y, w2, b2, relu=True, pool=True))
+one = timed(lambda: nat.conv1_block(x, w, b, w2, b2, relu=True, pool=True))
+same = torch.equal(nat.conv1_block(x, w, b, w2, b2, relu=True, pool=True),
+                   nat.conv3x3_c64(nat.conv3x3_cin3(x, w, b, relu=True), w2, b2, relu=True, pool=True))
+print("conv1_1 + conv1_2 + pool1: two kernels %.1f us (conv1_2 + pool alone %.1f), fused %.1f us, identical %s" % (two, c64, one, same))
