@@ -474,6 +474,42 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
+def conv3x3_halo_group(xs, weights, biases=None, relu=False):
+    """Several independent 3x3 'same' convolutions through the slab kernel in ONE launch (persistent workgroups, deepest problem
+    first): the packed predictor heads.  xs[i] (B, Cin_i, H_i, W_i) bf16 NHWC memory, weights[i] (Cout_i, Cin_i, 3, 3) bf16
+    channels_last; Cin_i % 128 == 0, Cout_i % 128 == 0, W_i <= 62 -> list of outputs (bit-identical to conv2d_same)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_halogroup_bound", False):
+        lib.ssdhip_conv3x3_halo_group_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_halo_group_nhwc_bf16.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_void_p]
+        lib._halogroup_bound = True
+    n = len(xs)
+    keep, xp, wp, bp, yp, dims, ys = [], [], [], [], [], [], []
+    for i in range(n):
+        x, (b, h, w, cin) = _nhwc_bf16(xs[i], "x")
+        wt = weights[i]
+        cout, cin_w, kh, kw = wt.shape
+        if wt.dtype != torch.bfloat16 or cin_w != cin or kh != 3 or kw != 3:
+            raise SsdHipError("weight %d must be bfloat16 (Cout, %d, 3, 3)" % (i, cin))
+        if not wt.permute(0, 2, 3, 1).is_contiguous():
+            wt = wt.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+        keep += [x, wt]
+        ys.append(y)
+        xp.append(x.data_ptr()); wp.append(wt.data_ptr()); yp.append(y.data_ptr())
+        bp.append(biases[i].data_ptr() if (biases is not None and biases[i] is not None) else 0)
+        dims.append((b, h, w, cin, cout))
+    parr = lambda v: (ctypes.c_void_p * n)(*v)
+    iarr = lambda k: (ctypes.c_int * n)(*[d[k] for d in dims])
+    dev = ys[0].device
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_conv3x3_halo_group_nhwc_bf16(n, parr(xp), parr(wp), parr(bp), parr(yp), iarr(0), iarr(1), iarr(2), iarr(3),
+                                                     iarr(4), int(bool(relu)), current_stream_ptr(dev))
+    check(rc, "ssdhip_conv3x3_halo_group_nhwc_bf16")
+    return ys
+
+
 def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True, variant=None):
     """Convolution (kernel 1 or 3, stride 1..4, zero padding <= (k//2)*dilation: torch.nn.Conv2d semantics) + bias + ReLU in
     ONE libssdhip MFMA kernel -- the strided / 'valid' extra layers of the SSD trunk.  Layouts as conv2d_same."""

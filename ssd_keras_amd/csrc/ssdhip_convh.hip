@@ -100,7 +100,7 @@ __device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
 // same column of the two rows of a row pair and lane ^ 1 is the neighbouring column, so POOL (MaxPooling2D(2, 2, 'same') fused:
 // models/keras_ssd300.py:279-283) takes the 2 x 2 maximum on the float32 accumulators in registers, as conv_igemm4_pool_kernel does.
 template <int NW, int SPW, int MODE, int CSH, bool POOL>
-__device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds) {
+__device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
     constexpr int TC = G2 ? (1 << CSH) : 1, TR = G2 ? (CH_BN >> CSH) : 1, SC2 = TC + 2;   // tile columns, rows; slab columns
     static_assert(!POOL || G2, "the pooled epilogue needs 2-D tiles");
@@ -120,7 +120,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         co0 = (slot % p.n_tiles) * CH_BM;
         return id < p.total_ids && qt < p.q_tiles;
     };
-    int id = (int)blockIdx.x, q0, co0;
+    int id = first_id, q0, co0;
     if (!tile_of(id, q0, co0)) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -465,7 +465,30 @@ template <int NW, int SPW, int MODE, int CSH, bool POOL>
 __global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL>(p, lds);
+    convh_body<NW, SPW, MODE, CSH, POOL>(p, lds, (int)blockIdx.x);
+#endif
+}
+
+// Several independent convolutions in ONE launch -- the packed predictor heads of all source maps (models/keras_ssd300.py:322-335):
+// persistent workgroups take work items off one list, problems with the longest K loop first (the fc7 head walks 144 K-steps; started
+// last it would be the tail of the launch).  Every problem runs on the padded position grid with the <4 stages, 6 pieces> layout
+// (maps up to 62 wide); a tile is processed as in the one-workgroup-per-tile schedule (no prefetch across tiles of different problems).
+constexpr int CH_MAX_GROUP = 8;
+struct ConvHGroup {
+    ConvHParams p[CH_MAX_GROUP];
+    int first_id[CH_MAX_GROUP + 1];                      // work items of problem k: [first_id[k], first_id[k+1]), each count a multiple of 8
+    int n;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(CH_THREADS) void convh_group_kernel(ConvHGroup g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(4, 6)];
+    for (int id = (int)blockIdx.x; id < g.first_id[g.n]; id += (int)gridDim.x) {
+        int k = 0;
+        while (k + 1 < g.n && id >= g.first_id[k + 1]) ++k;
+        convh_body<4, 6, MODE, 0, false>(g.p[k], lds, id - g.first_id[k]);
+    }
 #endif
 }
 
@@ -491,6 +514,61 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
 }  // namespace ssdhip
 
 using namespace ssdhip;
+
+static int convh_cu_count() {
+    static int cu_count = 0;                              // persistent variants launch one workgroup per CU
+    if (cu_count == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cu_count = (n / 8) * 8 > 0 ? (n / 8) * 8 : 8;
+    }
+    return cu_count;
+}
+
+// n_problems (<= 8) independent 3x3 'same' convolutions (no pooling; Cin % 128 == 0, Cout % 128 == 0, maps up to 62 wide) in one
+// launch; arrays are HOST arrays of per-problem arguments.  Results are bit-identical to the single-problem entry.
+extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* const* x_h, const void* const* weight_h,
+                                                   const void* const* bias_h, void* const* y_h, const int* B_h, const int* H_h,
+                                                   const int* W_h, const int* Cin_h, const int* Cout_h, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_problems < 1 || n_problems > CH_MAX_GROUP || !x_h || !weight_h || !y_h || !B_h || !H_h || !W_h || !Cin_h || !Cout_h) return SSDHIP_E_BADARG;
+    int order[CH_MAX_GROUP];
+    for (int k = 0; k < n_problems; ++k) order[k] = k;
+    for (int i = 1; i < n_problems; ++i)                  // deepest K loop first (stable insertion sort)
+        for (int j = i; j > 0 && Cin_h[order[j]] > Cin_h[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    ConvHGroup g;
+    long long ids = 0;
+    for (int s = 0; s < n_problems; ++s) {
+        const int k = order[s];
+        const int B = B_h[k], H = H_h[k], W = W_h[k], Cin = Cin_h[k], Cout = Cout_h[k];
+        const void* x = x_h[k]; const void* weight = weight_h[k]; const void* bias = bias_h ? bias_h[k] : nullptr; void* y = y_h[k];
+        if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || W > 62) return SSDHIP_E_BADARG;
+        if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
+        if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+        const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, Q = (long long)B * (H + 1) * (W + 1);
+        if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        ConvHParams& p = g.p[s];
+        p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+        p.y = static_cast<bf16_t*>(y);
+        p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
+        p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2; p.HT = p.WT = 0;
+        p.Q = (int)Q;
+        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+        p.n_tiles = Cout / CH_BM;
+        p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+        p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+        g.first_id[s] = (int)ids;
+        ids += p.total_ids;
+        if (ids > 0x3fffffffLL) return SSDHIP_E_BADARG;
+    }
+    for (int s = n_problems; s <= CH_MAX_GROUP; ++s) g.first_id[s] = (int)ids;
+    for (int s = n_problems; s < CH_MAX_GROUP; ++s) g.p[s] = g.p[0];
+    g.n = n_problems;
+    int grid = (int)ids;
+    if (grid > convh_cu_count()) grid = convh_cu_count();
+    hipLaunchKernelGGL((convh_group_kernel<0>), dim3(grid), dim3(CH_THREADS), 0, stream, g);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
 
 // y[b,h,w,co] = act(bias[co] + sum_{kh,kw,ci} x[b, h + kh - 1, w + kw - 1, ci] * w[co,kh,kw,ci]), zero padding: the 3x3 'same'
 // convolutions of the VGG blocks with Cin % 128 == 0 and Cout % 128 == 0; pool != 0: MaxPooling2D(2, 2, 'same') fused, y is
@@ -530,12 +608,7 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
-    static int cu_count = 0;                              // persistent variants launch one workgroup per CU
-    if (cu_count == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cu_count = (n / 8) * 8 > 0 ? (n / 8) * 8 : 8;
-    }
+    const int cu_count = convh_cu_count();
     // Schedules: 128 (shipped) = persistent workgroups, one per CU, that request the next tile's first slab and weights during the
     // last slice of the current tile (r02q: -10 % on conv3_1, -6 % on conv3_2, -1 % on the conv4 block against 64); 64 = one
     // workgroup per tile, the second wave of every SIMD reading its fragments two slots later.  SSDHIP_CONVH_MODE selects.

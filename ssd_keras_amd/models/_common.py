@@ -428,12 +428,16 @@ class SSDModel(nn.Module):
         per shape against the two-kernel form."""
         same3 = lambda c: (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
                            and c.groups == 1 and c.bias is not None)
-        if (self._fused(x, c1) and self._fused(x, c2) and same3(c1) and same3(c2) and c1.in_channels == 3 and c1.out_channels == 64
+        import os
+        if (os.environ.get("SSDHIP_NO_CONV1_BLOCK", "0") != "1" and self._fused(x, c1) and self._fused(x, c2) and same3(c1) and same3(c2)
+                and c1.in_channels == 3 and c1.out_channels == 64
                 and c2.in_channels == 64 and c2.out_channels % 64 == 0):
             cands = {"separate": lambda: self.conv_act_pool(c2, self.conv_act(c1, x), 2, 2, ceil_mode=True),
                      "conv1_block": lambda: nat.conv1_block(x, c1.weight, c1.bias, c2.weight, c2.bias, relu=True, pool=True)}
-            cands["separate"]()                              # settles the inner per-layer choices before the two forms are compared
-            return cands[self._pick(("conv1_block", tuple(x.shape), c2.out_channels), cands)]()
+            key = ("conv1_block", tuple(x.shape), c2.out_channels)
+            if SSDModel._conv_choice.get(key) is None:
+                cands["separate"]()                          # settles the inner per-layer choices before the two forms are compared
+            return cands[self._pick(key, cands)]()
         return self.conv_act_pool(c2, self.conv_act(c1, x), 2, 2, ceil_mode=True)
 
     def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):
@@ -516,9 +520,12 @@ class SSDModel(nn.Module):
             if packable and len(feats) <= 8:
                 # all packed heads as ONE grouped launch vs one launch per layer: the 1x1..5x5 heads are single workgroups
                 # walking long K loops (pure latency); side by side they hide behind the 38x38 / 19x19 heads
-                how = self._pick(("heads", tuple(tuple(f.shape) for f in feats), self.n_classes),
-                                 {"per_layer": lambda: self._heads_per_layer(feats), "grouped": lambda: self._heads_grouped(feats)})
-            confs, locs = self._heads_grouped(feats) if how == "grouped" else self._heads_per_layer(feats)
+                hc = {"per_layer": lambda: self._heads_per_layer(feats), "grouped": lambda: self._heads_grouped(feats)}
+                if self._halo_heads_ok(feats):
+                    hc["halo_grouped"] = lambda: self._heads_halo_grouped(feats)
+                how = self._pick(("heads", tuple(tuple(f.shape) for f in feats), self.n_classes), hc)
+            confs, locs = (self._heads_halo_grouped(feats) if how == "halo_grouped" else
+                           self._heads_grouped(feats) if how == "grouped" else self._heads_per_layer(feats))
             anchors = self.anchors_and_variances(sizes, x.device)
             head_args = (confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
                          [pb.n_boxes for pb in self.priorboxes], anchors, self.n_classes)
@@ -596,6 +603,17 @@ class SSDModel(nn.Module):
         outs = nat.conv2d_same_group(list(feats), [self._packed_head_weight(l) for l in range(len(feats))], None, relu=False)
         return outs, [None] * len(outs)
 
+    def _heads_halo_grouped(self, feats):
+        """All packed heads through the slab kernel in one launch of persistent workgroups (csrc/ssdhip_convh.hip): filters padded to a
+        multiple of 128 output channels; the deepest head (fc7's: 144 K-steps) is dispatched first."""
+        outs = nat.conv3x3_halo_group(list(feats), [self._packed_head_weight(l, 128) for l in range(len(feats))], None, relu=False)
+        return outs, [None] * len(outs)
+
+    def _halo_heads_ok(self, feats):
+        import os
+        return (os.environ.get("SSDHIP_NO_HALO", "0") != "1" and len(feats) <= 8
+                and all(f.shape[1] % 128 == 0 and f.shape[3] <= 62 for f in feats))
+
     def _heads_per_layer(self, feats):
         """Per layer the two heads run either as two MIOpen convolutions or PACKED into one libssdhip implicit-GEMM launch
         (conf and loc filters concatenated along Cout, zero-padded to 64 channels): timed once per shape, faster kept."""
@@ -615,20 +633,20 @@ class SSDModel(nn.Module):
         same = lambda c: (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1)
         return same(ch) and same(lh) and ch.in_channels % 64 == 0 and ch.in_channels == lh.in_channels
 
-    def _packed_head_weight(self, l):
-        """[conf filters | loc filters | zero rows up to a multiple of 64] of predictor layer l as one (Cout, Cin, 3, 3) bf16
+    def _packed_head_weight(self, l, multiple=64):
+        """[conf filters | loc filters | zero rows up to a multiple of `multiple`] of predictor layer l as one (Cout, Cin, 3, 3) bf16
         weight in channels_last memory; rebuilt when either head's weight tensor changes (in-place updates bump `_version`)."""
         ch, lh = self.conf_heads[l], self.loc_heads[l]
         key = (ch.weight._version, lh.weight._version, ch.weight.data_ptr(), lh.weight.data_ptr())
-        hit = self._packed_heads.get(l)
+        hit = self._packed_heads.get((l, multiple))
         if hit is None or hit[0] != key:
             n = ch.out_channels + lh.out_channels
-            pad = (-n) % 64
+            pad = (-n) % multiple
             with torch.no_grad():
                 w = torch.cat([ch.weight, lh.weight] + ([ch.weight.new_zeros((pad,) + tuple(ch.weight.shape[1:]))] if pad else []), dim=0)
                 w = w.contiguous(memory_format=torch.channels_last)
             hit = (key, w)
-            self._packed_heads[l] = hit
+            self._packed_heads[(l, multiple)] = hit
         return hit[1]
 
     def _fused_head_ok(self, f, conv):

@@ -394,3 +394,24 @@ def test_conv1_block_full_batch():
         base = nat.conv3x3_c64(nat.conv3x3_cin3(x, w1, b1, relu=True), w2, b2, relu=True, pool=True).view(torch.int16)
         for _ in range(10):
             assert torch.equal(nat.conv1_block(x, w1, b1, w2, b2, relu=True, pool=True).view(torch.int16), base)
+
+
+def test_slab_group_equals_single_launches():
+    """The packed predictor heads of SSD300 (batch 32, filters padded to 128 channels) in ONE slab-kernel launch: every output
+    BIT-identical to the implicit-GEMM kernel on the same problem; 5 launches agree."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(32, 38, 38, 512, 128), (32, 19, 19, 1024, 256), (32, 10, 10, 512, 256), (32, 5, 5, 256, 256), (32, 3, 3, 256, 128),
+              (32, 1, 1, 256, 128)]
+    xs, ws = [], []
+    for (B, H, W, Cin, Cout) in shapes:
+        xs.append(torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2))
+        ws.append((torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2))
+    base = [nat.conv2d_same(x, w, None, relu=False, variant=4).view(torch.int16) for x, w in zip(xs, ws)]
+    for _ in range(5):
+        got = nat.conv3x3_halo_group(xs, ws, None, relu=False)
+        for k, (a, b) in enumerate(zip(got, base)):
+            assert torch.equal(a.view(torch.int16), b), "problem %d differs" % k
+    with pytest.raises(nat.SsdHipError):                   # a 64-channel-multiple filter bank is not the slab kernel's
+        nat.conv3x3_halo_group(xs[:1], [ws[0][:64]], None)
