@@ -339,6 +339,13 @@ int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* 
 int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, int pool, void* stream);
 
+/* 3x3 convolution, stride 1 | 2, zero padding 0 | 1 (torch.nn.Conv2d semantics), Cin % 128 == 0, Cout % 128 == 0, map up to 94 wide,
+ * through the same kernel: the SSD extra layers conv6_2 / conv7_2 (ZeroPadding2D(1) + stride 2, models/keras_ssd300.py:302-307) and
+ * conv8_2 / conv9_2 ('valid', :310-313).  y is [B, (H + 2 pad - 3) / stride + 1, (W + 2 pad - 3) / stride + 1, Cout]; bit-identical to
+ * ssdhip_conv2d_nhwc_bf16. */
+int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                          int Cin, int Cout, int stride, int pad, int relu, void* stream);
+
 /* n_problems (<= 8) independent convolutions of the kind above (no pooling, maps up to 62 wide) in ONE launch of persistent
  * workgroups, deepest problem first -- the packed predictor heads of all source maps (models/keras_ssd300.py:322-335); arrays are HOST
  * arrays of per-problem arguments. */

@@ -534,7 +534,17 @@ def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True, variant=
     with torch.cuda.device(x.device):
         args = (_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(kh), int(stride), int(padding), int(dilation),
                 int(bool(relu)), current_stream_ptr(x.device))
-        rc = lib.ssdhip_conv2d_nhwc_bf16(*args) if variant is None else lib.ssdhip_conv2d_nhwc_bf16_variant(int(variant), *args)
+        if variant == 7:                                     # the slab kernel's strided / cropped form (3x3, dilation 1 only)
+            if not getattr(lib, "_halostr_bound", False):
+                lib.ssdhip_conv3x3_halo_strided_nhwc_bf16.restype = ctypes.c_int
+                lib.ssdhip_conv3x3_halo_strided_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+                lib._halostr_bound = True
+            if int(kh) != 3 or int(dilation) != 1:
+                raise SsdHipError("variant 7 is a 3x3, dilation-1 kernel")
+            rc = lib.ssdhip_conv3x3_halo_strided_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(stride),
+                                                           int(padding), int(bool(relu)), current_stream_ptr(x.device))
+        else:
+            rc = lib.ssdhip_conv2d_nhwc_bf16(*args) if variant is None else lib.ssdhip_conv2d_nhwc_bf16_variant(int(variant), *args)
     check(rc, "ssdhip_conv2d_nhwc_bf16")
     return y
 

@@ -58,6 +58,8 @@ struct ConvHParams {
     int Q, q_tiles, n_tiles;     // padded positions B (H+1)(W+1); tiles of 256 positions; tiles of 128 channels
     int total_ids;               // workgroup ids that map to tiles: ceil(q_tiles / 8) * n_tiles * 8 (some of the last ones to none)
     int HT, WT, Ho, Wo;          // 2-D tiles: tiles per image (q_tiles = B HT WT); pooled map size
+    int os, ooff, Hs, Ws;        // position grid only: output pixel (ho, wo) = the 'same' result at (ho os + ooff, wo os + ooff), map Hs x Ws
+                                 // (os = 1, ooff = 0, Hs = H, Ws = W: the plain 'same' convolution)
     int x_bytes, w_bytes;
 };
 
@@ -441,8 +443,13 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         if (hh < H && ww < W)
                             *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + hh) * W + ww)) * p.Cout + co0 + wm * 64 + c * 8) = v;
                     } else {
-                        if (w < W && h < H && q < p.Q)
-                            *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + h) * W + w)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                        if (w < W && h < H && q < p.Q) {
+                            // strided / 'valid' forms keep the positions (ho os + ooff, wo os + ooff) of the 'same' result
+                            const int hh = h - p.ooff, ww = w - p.ooff;
+                            const int ho = hh / p.os, wo = ww / p.os;
+                            if (hh >= 0 && ww >= 0 && ho * p.os == hh && wo * p.os == ww && ho < p.Hs && wo < p.Ws)
+                                *reinterpret_cast<uint4*>(p.y + ((size_t)((b * p.Hs + ho) * p.Ws + wo)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                        }
                         q += 8;
                         w += 8;
                         while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
@@ -525,6 +532,35 @@ static int convh_cu_count() {
     return cu_count;
 }
 
+// 3x3 convolution with stride 1 | 2 and zero padding 0 | 1 (torch.nn.Conv2d semantics) on a map up to 94 wide: the SSD extra layers
+// conv6_2 / conv7_2 (ZeroPadding2D(1) + stride 2, models/keras_ssd300.py:302-307) and conv8_2 / conv9_2 ('valid', :310-313).  The
+// slab kernel computes the stride-1 'same' result on the position grid and keeps the positions the strided / cropped form asks for:
+// up to 4x redundant MFMA work, on layers whose cost is the latency of a K loop one workgroup deep, not FLOPs.
+extern "C" int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                                     int Cin, int Cout, int stride, int pad, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || W > 94) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM) || (stride != 1 && stride != 2) || (pad != 0 && pad != 1)) return SSDHIP_E_BADARG;
+    if (H + 2 * pad < 3 || W + 2 * pad < 3) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, Q = (long long)B * (H + 1) * (W + 1);
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+    ConvHParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2; p.HT = p.WT = 0;
+    p.os = stride; p.ooff = 1 - pad;
+    p.Hs = (H + 2 * pad - 3) / stride + 1; p.Ws = (W + 2 * pad - 3) / stride + 1;
+    p.Q = (int)Q;
+    p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+    p.n_tiles = Cout / CH_BM;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+    p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+    convh_launch<128>(p, 0, 0, convh_cu_count(), stream);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 // n_problems (<= 8) independent 3x3 'same' convolutions (no pooling; Cin % 128 == 0, Cout % 128 == 0, maps up to 62 wide) in one
 // launch; arrays are HOST arrays of per-problem arguments.  Results are bit-identical to the single-problem entry.
 extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* const* x_h, const void* const* weight_h,
@@ -552,6 +588,7 @@ extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* c
         p.y = static_cast<bf16_t*>(y);
         p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
         p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2; p.HT = p.WT = 0;
+        p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
         p.Q = (int)Q;
         p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
         p.n_tiles = Cout / CH_BM;
@@ -588,6 +625,7 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.HT = p.WT = 0;
+    p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
     int geom = 0;
     if (pool || W > 94) {                                 // 2-D tiles: 16 x 16 or 8 x 32 pixels, whichever pads the map less
         long long best = -1;

@@ -317,6 +317,12 @@ class SSDModel(nn.Module):
                 for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6)):
                     cands[nm] = lambda v=v: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                        dilation=conv.dilation[0], relu=relu, variant=v)
+                if (self._halo_ok(conv, x) and conv.stride[0] in (1, 2) and conv.padding[0] in (0, 1) and x.shape[3] <= 94
+                        and x.shape[2] + 2 * conv.padding[0] >= 3 and x.shape[3] + 2 * conv.padding[0] >= 3):
+                    # the slab kernel keeps the strided / cropped positions of the stride-1 'same' result: redundant FLOPs, but
+                    # these layers cost the latency of their K loop, not arithmetic
+                    cands["halo"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
+                                                       dilation=1, relu=relu, variant=7)
             name = (self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu, conv.stride[0], conv.padding[0]), cands)
                     if len(cands) > 1 else "miopen")
             return cands[name]()

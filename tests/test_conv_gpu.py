@@ -415,3 +415,23 @@ def test_slab_group_equals_single_launches():
             assert torch.equal(a.view(torch.int16), b), "problem %d differs" % k
     with pytest.raises(nat.SsdHipError):                   # a 64-channel-multiple filter bank is not the slab kernel's
         nat.conv3x3_halo_group(xs[:1], [ws[0][:64]], None)
+
+
+@pytest.mark.parametrize("case", [(32, 19, 19, 256, 512, 2, 1), (32, 10, 10, 128, 256, 2, 1), (32, 5, 5, 128, 256, 1, 0),
+                                  (32, 3, 3, 128, 256, 1, 0), (2, 32, 32, 128, 256, 2, 1), (3, 11, 7, 128, 128, 1, 1),
+                                  (1, 20, 20, 256, 128, 2, 0), (2, 9, 94, 128, 128, 1, 0)])
+def test_slab_conv_strided_and_valid_forms(case):
+    """conv6_2 ... conv9_2 through the slab kernel (stride-1 'same' result, strided / cropped positions kept): BIT-identical to the
+    general implicit-GEMM kernel."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, stride, pad = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+    base = nat.conv2d(x, wt, bias, stride=stride, padding=pad, relu=True)
+    for _ in range(4):
+        got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, relu=True, variant=7)
+        assert got.shape == base.shape
+        assert torch.equal(got.view(torch.int16), base.view(torch.int16))
