@@ -232,8 +232,10 @@ def main():
         choices[conv_choice_label(key)] = name
     conv = {"bound": "mfma", "forward_ms": round(fwd_ms, 4), "achieved": round(conv_tflops, 2),
             "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(conv_tflops / MFMA_PEAK_TFLOPS[args.dtype], 5),
-            "note": "per layer the faster of libssdhip's implicit-GEMM MFMA kernel (fused bias/ReLU epilogue; packed conf+loc heads) "
-                    "and MIOpen + one libssdhip bias/ReLU[/pool] pass, %s; 62.747 GFLOP/img (SURVEY App. B)" % args.dtype,
+            "note": "per layer shape the fastest of libssdhip's MFMA kernels, timed once (kernel_per_layer): the slab kernel "
+                    "(csrc/ssdhip_convh.hip: halo / halo_pool / halo_grouped), the fused conv1_1 + conv1_2 + pool1 kernel "
+                    "(conv1_block), the resident-weight kernel (c64), the implicit-GEMM kernels (igemm*); %s; 62.747 GFLOP/img "
+                    "(SURVEY App. B); per-kernel MFMA-busy counters of this forward: profiles/*_pmc_mfma_per_kernel.txt" % args.dtype,
             "kernel_per_layer": choices}
 
     # ---- CPU baseline: NumPy port of the reference decoder on a bounded sample (rank 0, N=1) -----
