@@ -435,7 +435,8 @@ class SSDModel(nn.Module):
         same3 = lambda c: (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
                            and c.groups == 1 and c.bias is not None)
         import os
-        if (os.environ.get("SSDHIP_NO_CONV1_BLOCK", "0") != "1" and self._fused(x, c1) and self._fused(x, c2) and same3(c1) and same3(c2)
+        if (os.environ.get("SSDHIP_NO_CONV1_BLOCK", "0") != "1" and os.environ.get("SSDHIP_CONV", "auto") in ("auto", "auto_miopen")
+                and self._fused(x, c1) and self._fused(x, c2) and same3(c1) and same3(c2)
                 and c1.in_channels == 3 and c1.out_channels == 64
                 and c2.in_channels == 64 and c2.out_channels % 64 == 0):
             cands = {"separate": lambda: self.conv_act_pool(c2, self.conv_act(c1, x), 2, 2, ceil_mode=True),
@@ -443,7 +444,8 @@ class SSDModel(nn.Module):
             key = ("conv1_block", tuple(x.shape), c2.out_channels)
             if SSDModel._conv_choice.get(key) is None:
                 cands["separate"]()                          # settles the inner per-layer choices before the two forms are compared
-            return cands[self._pick(key, cands)]()
+            name = self._pick(key, cands)
+            return cands[name if name in cands else "separate"]()       # a forced SSDHIP_CONV mode names per-layer kernels: two-kernel form
         return self.conv_act_pool(c2, self.conv_act(c1, x), 2, 2, ceil_mode=True)
 
     def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):
