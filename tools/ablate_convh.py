@@ -1,8 +1,8 @@
 """Ablations of the slab kernel's K loop (needs tools/libssdhip_prof.so: tools/prof_build.sh).  GPU box only.
 
 Each mode removes ONE ingredient of the loop (results are wrong by construction) so the time it costs can be read off:
-    80 shipped (fine interleave)      0 coarse schedule
-    81 no loads     82 no fragment reads     84 no waits / barrier     87 MFMAs only     32 loads + barrier only (coarse)
+    128 shipped (persistent workgroups)     64 one workgroup per tile, second wave of every SIMD reading two slots later     0 neither
+    65 no loads     66 no fragment reads     68 no waits / barrier     71 MFMAs only     32 no MFMAs
     python tools/ablate_convh.py [out.json]
 """
 import json
@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from ssd_keras_amd import _native as nat  # noqa: E402
 
 LAYERS = [("conv3_2", 32, 75, 75, 256, 256), ("conv4_2", 32, 38, 38, 512, 512), ("conv5_1", 32, 19, 19, 512, 512)]
-MODES = [80, 0, 81, 82, 84, 87, 32]
+MODES = [128, 64, 0, 65, 66, 68, 71, 32]
 
 
 def timed(fn, reps=20):
@@ -49,7 +49,7 @@ for name, B, H, W, Cin, Cout in LAYERS:
     base = nat.conv2d_same(x, wt, bias, relu=True, variant=4).view(torch.int16)
     for m in MODES:
         os.environ["SSDHIP_CONVH_MODE"] = str(m)
-        if m in (0, 80):
+        if m in (128, 64, 0):
             got = nat.conv2d_same(x, wt, bias, relu=True, variant=7).view(torch.int16)
             row["mode%d_differs" % m] = int((got != base).sum().item())
         us = timed(lambda: nat.conv2d_same(x, wt, bias, relu=True, variant=7))
