@@ -491,7 +491,14 @@ template <int MODE>
 __global__ __launch_bounds__(CH_THREADS) void convh_group_kernel(ConvHGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(4, 6)];
-    for (int id = (int)blockIdx.x; id < g.first_id[g.n]; id += (int)gridDim.x) {
+    // Work items are sorted by depth and dealt in SNAKE order (workgroup w takes items w, 2G-1-w, 2G+w, ...): the workgroups that
+    // started with the deepest items (the fc7 head's 144 K-steps) get their second item last, if at all -- with the plain stride the
+    // same workgroups took a long AND a medium item and the launch ended ~70 us after most CUs had gone idle.
+    const int G = (int)gridDim.x, total = g.first_id[g.n];
+    for (int round = 0;; ++round) {
+        const int id = (round & 1) ? (round + 1) * G - 1 - (int)blockIdx.x : round * G + (int)blockIdx.x;
+        if (round * G >= total) break;
+        if (id >= total) continue;
         int k = 0;
         while (k + 1 < g.n && id >= g.first_id[k + 1]) ++k;
         convh_body<4, 6, MODE, 0, false>(g.p[k], lds, id - g.first_id[k]);
