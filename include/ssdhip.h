@@ -348,10 +348,10 @@ int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* weight, con
 
 /* n_problems (<= 8) independent convolutions of the kind above (no pooling, maps up to 62 wide) in ONE launch of persistent
  * workgroups, deepest problem first -- the packed predictor heads of all source maps (models/keras_ssd300.py:322-335); arrays are HOST
- * arrays of per-problem arguments. */
+ * arrays of per-problem arguments; max_workgroups > 0 caps the workgroups (one per CU) so a concurrent stream finds free CUs. */
 int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* const* x_h, const void* const* weight_h, const void* const* bias_h,
                                         void* const* y_h, const int* B_h, const int* H_h, const int* W_h, const int* Cin_h,
-                                        const int* Cout_h, int relu, void* stream);
+                                        const int* Cout_h, int relu, int max_workgroups, void* stream);
 
 /* conv1_1 -> conv1_2 [-> pool1] as ONE kernel (models/keras_ssd300.py:274-276): x3 [B, H, W, 3] bf16 image, w1 [64, 3, 3, 3] + b1 the
  * first layer (ReLU), weight [Cout, 3, 3, 64] + bias the second one, pool != 0 fuses MaxPooling2D(2, 2, 'same').  The 64-channel map

@@ -474,7 +474,7 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
-def conv3x3_halo_group(xs, weights, biases=None, relu=False):
+def conv3x3_halo_group(xs, weights, biases=None, relu=False, max_workgroups=0):
     """Several independent 3x3 'same' convolutions through the slab kernel in ONE launch (persistent workgroups, deepest problem
     first): the packed predictor heads.  xs[i] (B, Cin_i, H_i, W_i) bf16 NHWC memory, weights[i] (Cout_i, Cin_i, 3, 3) bf16
     channels_last; Cin_i % 128 == 0, Cout_i % 128 == 0, W_i <= 62 -> list of outputs (bit-identical to conv2d_same)."""
@@ -482,7 +482,7 @@ def conv3x3_halo_group(xs, weights, biases=None, relu=False):
     lib = load()
     if not getattr(lib, "_halogroup_bound", False):
         lib.ssdhip_conv3x3_halo_group_nhwc_bf16.restype = ctypes.c_int
-        lib.ssdhip_conv3x3_halo_group_nhwc_bf16.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_void_p]
+        lib.ssdhip_conv3x3_halo_group_nhwc_bf16.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib._halogroup_bound = True
     n = len(xs)
     keep, xp, wp, bp, yp, dims, ys = [], [], [], [], [], [], []
@@ -505,7 +505,7 @@ def conv3x3_halo_group(xs, weights, biases=None, relu=False):
     dev = ys[0].device
     with torch.cuda.device(dev):
         rc = lib.ssdhip_conv3x3_halo_group_nhwc_bf16(n, parr(xp), parr(wp), parr(bp), parr(yp), iarr(0), iarr(1), iarr(2), iarr(3),
-                                                     iarr(4), int(bool(relu)), current_stream_ptr(dev))
+                                                     iarr(4), int(bool(relu)), int(max_workgroups), current_stream_ptr(dev))
     check(rc, "ssdhip_conv3x3_halo_group_nhwc_bf16")
     return ys
 

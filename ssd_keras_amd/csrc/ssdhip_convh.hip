@@ -569,10 +569,12 @@ extern "C" int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* 
 }
 
 // n_problems (<= 8) independent 3x3 'same' convolutions (no pooling; Cin % 128 == 0, Cout % 128 == 0, maps up to 62 wide) in one
-// launch; arrays are HOST arrays of per-problem arguments.  Results are bit-identical to the single-problem entry.
+// launch; arrays are HOST arrays of per-problem arguments; max_workgroups > 0 caps the persistent workgroups (one per CU) so that a
+// concurrent stream finds free CUs.  Results are bit-identical to the single-problem entry.
 extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* const* x_h, const void* const* weight_h,
                                                    const void* const* bias_h, void* const* y_h, const int* B_h, const int* H_h,
-                                                   const int* W_h, const int* Cin_h, const int* Cout_h, int relu, void* stream_) {
+                                                   const int* W_h, const int* Cin_h, const int* Cout_h, int relu, int max_workgroups,
+                                                   void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_problems < 1 || n_problems > CH_MAX_GROUP || !x_h || !weight_h || !y_h || !B_h || !H_h || !W_h || !Cin_h || !Cout_h) return SSDHIP_E_BADARG;
     int order[CH_MAX_GROUP];
@@ -610,6 +612,7 @@ extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* c
     g.n = n_problems;
     int grid = (int)ids;
     if (grid > convh_cu_count()) grid = convh_cu_count();
+    if (max_workgroups >= 8 && grid > (max_workgroups / 8) * 8) grid = (max_workgroups / 8) * 8;   // leave CUs to a concurrent stream
     hipLaunchKernelGGL((convh_group_kernel<0>), dim3(grid), dim3(CH_THREADS), 0, stream, g);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -161,14 +161,19 @@ class GraphedInference:
         dev = images.device
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream), torch.no_grad():
-            for _ in range(max(1, warmup)):
-                model(self.static_in)
-        torch.cuda.current_stream(dev).wait_stream(self.stream)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
-            self.static_out = model(self.static_in)
+        had = model.__dict__.get("_head_overlap")
+        model.__dict__["_head_overlap"] = "3"             # two streams inside the graph: explicit dependencies, no allocator subtleties
+        try:
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                for _ in range(max(1, warmup)):
+                    model(self.static_in)
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
+                self.static_out = model(self.static_in)
+        finally:
+            model.__dict__["_head_overlap"] = had
 
     def __call__(self, images=None):
         if images is not None and images.data_ptr() != self.static_in.data_ptr():
@@ -553,14 +558,18 @@ class SSDModel(nn.Module):
         return self.decoder(pred) if (decode and self.decoder is not None) else pred
 
     def _split_heads(self, x):
-        """Fused bf16 inference only, OPT-IN (SSDHIP_HEAD_OVERLAP=1 | 2).  The packed heads of the trunk's two source maps (conv4_3,
+        """Fused bf16 inference only.  Mode 3 is what the HIP-graph step uses (GraphedInference; the eager path stays on one stream
+        unless SSDHIP_HEAD_OVERLAP says otherwise): the two trunk heads as a grouped slab launch capped at 160 of the 256 CUs on a
+        second stream beside the latency-bound chain of extra layers, then the four small heads -- 2.766 -> 2.727 ms per step
+        within one visit (r03b).  Modes 1 | 2 are the older forms with the implicit-GEMM heads:  The packed heads of the trunk's two source maps (conv4_3,
         fc7: ~85 % of the head FLOPs) and the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- on
         two HIP streams (1: the heads on the second stream; 2: the chain on a high-priority second stream); the extra maps' heads
         follow as one grouped launch.  Measured (r02p, HIP-graph step): ~190 us of kernels do run side by side, but they slow each
         other down by as much -- 2.831 (off) / 2.832 (1) / 2.815 ms (2) per step: not worth a default.  Returns (feature maps, packed
         head outputs) or None."""
         import os
-        if (os.environ.get("SSDHIP_HEAD_OVERLAP", "0") == "0" or not hasattr(self, "trunk_features") or not x.is_cuda
+        mode = os.environ.get("SSDHIP_HEAD_OVERLAP") or self.__dict__.get("_head_overlap") or "0"
+        if (mode == "0" or not hasattr(self, "trunk_features") or not x.is_cuda
                 or torch.is_grad_enabled() or not self.fused_inference or x.dtype != torch.bfloat16
                 or len(self.conf_heads) > 8 + 2):
             return None
@@ -571,8 +580,9 @@ class SSDModel(nn.Module):
         if not all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
                    for f, ch, lh in zip(early, self.conf_heads, self.loc_heads)):
             raise RuntimeError("predictor heads of the trunk do not qualify for the packed kernel")
+        if mode == "3" and not self._halo_heads_ok(early):
+            mode = "1"
         main = torch.cuda.current_stream(x.device)
-        mode = os.environ.get("SSDHIP_HEAD_OVERLAP", "0")
         side = self.__dict__.get("_side_stream")
         if side is None or side.device != x.device:
             # high priority: when both streams have workgroups pending, the dispatcher serves this one first
@@ -586,6 +596,21 @@ class SSDModel(nn.Module):
 
         # No record_stream anywhere: every tensor the other stream touches outlives the join in program order, and a block of the
         # side stream's pool is only reused after that stream has waited for the current one again.
+        if mode == "3":
+            # the two trunk heads as a grouped slab launch capped at HALF the CUs (persistent workgroups, one per CU) on the second
+            # stream, the latency-bound chain of extra layers on the current one in the other half, then the four small heads
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                big = nat.conv3x3_halo_group(list(early), [self._packed_head_weight(l, 128) for l in range(n_early)], None, relu=False,
+                                             max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "160")))
+            rest = self.extra_features(early[1])
+            check_rest(rest)
+            if not self._halo_heads_ok(rest):
+                raise RuntimeError("SSDHIP_HEAD_OVERLAP=3 needs heads the slab kernel covers")
+            small = nat.conv3x3_halo_group(list(rest), [self._packed_head_weight(n_early + l, 128) for l in range(len(rest))], None,
+                                           relu=False)
+            main.wait_stream(side)
+            return early + rest, big + small
         if mode == "2":
             # the latency-bound chain (extra layers + their small heads) on the high-priority stream, the two big heads on the current
             # one: the chain's few workgroups no longer queue behind ~600 head workgroups at every one of its eight launches

@@ -217,7 +217,7 @@ def test_graphed_step_and_two_stream_heads_equal_the_plain_step():
             plain_a = model(img_a).clone()
             plain_b = model(img_b).clone()
             pred_plain = model.raw_predictions(img_a).clone()
-        for mode in ("2", "1"):                                  # extra layers / big heads on the second stream
+        for mode in ("3", "2", "1"):                             # big heads (half the CUs) / extra layers / big heads on the second stream
             os.environ["SSDHIP_HEAD_OVERLAP"] = mode
             with torch.no_grad():
                 for _ in range(3):                               # the second stream must not race the first
