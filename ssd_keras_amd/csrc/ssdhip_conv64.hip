@@ -21,6 +21,7 @@
 // bf16 rounding.  Results are bit-identical to the implicit-GEMM kernel (same K order per output: taps outer, channels inner).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -56,6 +57,7 @@ struct C64Params {
     const bf16_t* x3;            // FRONT: [B, H, W, 3] image; x is unused
     const bf16_t* w1;            // FRONT: [64, 3, 3, 3] first-layer filters
     const bf16_t* b1;            // FRONT: [64] first-layer bias or null
+    int prio;                    // FRONT: raise the multiplying waves' issue priority over the producers'
 };
 
 __device__ __forceinline__ u32 c64_f2bf_rn(float f) {
@@ -358,6 +360,9 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         return;
     }
 
+    if constexpr (FRONT) {                               // the multipliers go first whenever they and a producer wave of their SIMD can issue
+        if (p.prio) __builtin_amdgcn_s_setprio(2);
+    }
     // ---- fragment addresses: everything per-lane is fixed for the whole kernel -------------------------------------------
     const int q = wp * 32 + r31;                         // pixel slot of the lane: row pair q >> CS, column q & (CC-1)
     const int rp = q >> CS, col = q & (CC - 1);
@@ -528,7 +533,7 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
-    p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr;
+    p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr; p.prio = 0;
     p.n_slices = Cout / 64;
     int cs_best = 4;
     long long best = -1;
@@ -569,6 +574,7 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     p.x = nullptr; p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.x3 = static_cast<const bf16_t*>(x3); p.w1 = static_cast<const bf16_t*>(w1); p.b1 = static_cast<const bf16_t*>(b1);
+    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // r03d: 317 -> 296 us
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = 0; p.w_bytes = (int)wb;

@@ -46,3 +46,9 @@ one = timed(lambda: nat.conv1_block(x, w, b, w2, b2, relu=True, pool=True))
 same = torch.equal(nat.conv1_block(x, w, b, w2, b2, relu=True, pool=True),
                    nat.conv3x3_c64(nat.conv3x3_cin3(x, w, b, relu=True), w2, b2, relu=True, pool=True))
 print("conv1_1 + conv1_2 + pool1: two kernels %.1f us (conv1_2 + pool alone %.1f), fused %.1f us, identical %s" % (two, c64, one, same))
+
+import os
+for prio in ("0", "1"):
+    os.environ["SSDHIP_C64_PRIO"] = prio
+    print("SSDHIP_C64_PRIO=%s: fused %.1f us" % (prio, timed(lambda: nat.conv1_block(x, w, b, w2, b2, relu=True, pool=True))))
+os.environ.pop("SSDHIP_C64_PRIO", None)
