@@ -360,9 +360,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         return;
     }
 
-    if constexpr (FRONT) {                               // the multipliers go first whenever they and a producer wave of their SIMD can issue
-        if (p.prio) __builtin_amdgcn_s_setprio(2);
-    }
+    if (p.prio) __builtin_amdgcn_s_setprio(2);           // the multipliers go first whenever they and a producer / loader wave of their SIMD can issue
     // ---- fragment addresses: everything per-lane is fixed for the whole kernel -------------------------------------------
     const int q = wp * 32 + r31;                         // pixel slot of the lane: row pair q >> CS, column q & (CC-1)
     const int rp = q >> CS, col = q & (CC - 1);
@@ -533,7 +531,8 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
-    p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr; p.prio = 0;
+    p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr;
+    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // conv2_1: 151 -> 145 us, 171 -> 166 us (r03f)
     p.n_slices = Cout / 64;
     int cs_best = 4;
     long long best = -1;
