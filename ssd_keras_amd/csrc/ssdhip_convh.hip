@@ -20,9 +20,16 @@
 //     implicit-GEMM kernel's bytes per FLOP.
 // Pipeline (per K-step = one tap of one slice, one s_barrier):
 //   * weights: ring of NW 16 KB stages, loads NW steps ahead; slab: two buffers, slice cs + 1 arrives during the first taps
-//     of slice cs; all by LDS-DMA from inline asm with hand-counted vmcnt (see ssdhip_conv.hip v5 for why not the builtin);
-//   * the MFMA operands of step s + 1 are read from LDS into a second register set WHILE the 16 MFMAs of step s issue
-//     (fragment reads interleaved with the MFMAs), so no LDS latency is exposed and the barrier only orders LDS reuse.
+//     of slice cs; all by LDS-DMA from inline asm with hand-counted vmcnt (see ssdhip_conv.hip v5 for why not the builtin) --
+//     the taps are unrolled, so every s_waitcnt immediate is an exact compile-time count;
+//   * the MFMA operands of step s + 1 are read from LDS into a second register set WHILE the 16 MFMAs of step s issue, in 16
+//     slots of one MFMA + 0..2 reads (reads in bursts fill the LDS queue and drain the MFMA pipe), so no LDS latency is exposed
+//     and the barrier only orders LDS reuse;
+//   * persistent workgroups (one per CU) walk over tiles and request the next tile's first slab and weights during the last
+//     slice of the current one; the epilogue stages through the slab buffer the last slice has just vacated.
+// Geometries: the padded position grid above (maps up to 94 wide), or 2-D tiles of 16 x 16 / 8 x 32 pixels with a one-pixel ring
+// (any map size; MaxPooling2D(2, 2, 'same') fused on the float32 accumulators).  Several problems can share one launch (the
+// packed predictor heads): work items sorted by depth, dealt to the workgroups in snake order.
 // LDS rows are 128 bytes (64 channels); 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) (source-side permutation
 // of the lane-linear DMA image, undone by the fragment reads): conflict-free ds_read_b128 for ANY 32 consecutive rows, so a
 // tap displacement only changes the swizzle term, which the readers recompute per step (a handful of VALU operations).
