@@ -558,15 +558,14 @@ class SSDModel(nn.Module):
         return self.decoder(pred) if (decode and self.decoder is not None) else pred
 
     def _split_heads(self, x):
-        """Fused bf16 inference only.  Mode 3 is what the HIP-graph step uses (GraphedInference; the eager path stays on one stream
-        unless SSDHIP_HEAD_OVERLAP says otherwise): the two trunk heads as a grouped slab launch capped at 160 of the 256 CUs on a
-        second stream beside the latency-bound chain of extra layers, then the four small heads -- 2.766 -> 2.727 ms per step
-        within one visit (r03b).  Modes 1 | 2 are the older forms with the implicit-GEMM heads:  The packed heads of the trunk's two source maps (conv4_3,
-        fc7: ~85 % of the head FLOPs) and the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- on
-        two HIP streams (1: the heads on the second stream; 2: the chain on a high-priority second stream); the extra maps' heads
-        follow as one grouped launch.  Measured (r02p, HIP-graph step): ~190 us of kernels do run side by side, but they slow each
-        other down by as much -- 2.831 (off) / 2.832 (1) / 2.815 ms (2) per step: not worth a default.  Returns (feature maps, packed
-        head outputs) or None."""
+        """Fused bf16 inference only: the predictor heads of the trunk's two source maps (conv4_3, fc7: ~85 % of the head FLOPs) do not
+        depend on the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- so the two can share the chip
+        on two HIP streams.  Mode 3 is what the HIP-graph step uses (GraphedInference; the eager path stays on one stream unless
+        SSDHIP_HEAD_OVERLAP says otherwise): the two trunk heads as a grouped slab launch capped at 160 of the 256 CUs on the second
+        stream beside the chain, then the four small heads: 2.766 -> 2.727 and 2.435 -> 2.419 ms per step in two within-visit A/Bs
+        (r03b, r03c).  Modes 1 | 2 are the older forms with the implicit-GEMM heads (1: the heads on the second stream; 2: the chain on
+        a high-priority second stream): ~190 us of kernels run side by side but slow each other down by as much -- those heads fill
+        every CU (r02p: 2.831 off / 2.832 / 2.815 ms).  Returns (feature maps, packed head outputs), or None for the one-stream path."""
         import os
         mode = os.environ.get("SSDHIP_HEAD_OVERLAP") or self.__dict__.get("_head_overlap") or "0"
         if (mode == "0" or not hasattr(self, "trunk_features") or not x.is_cuda
@@ -605,10 +604,12 @@ class SSDModel(nn.Module):
                                              max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "160")))
             rest = self.extra_features(early[1])
             check_rest(rest)
-            if not self._halo_heads_ok(rest):
-                raise RuntimeError("SSDHIP_HEAD_OVERLAP=3 needs heads the slab kernel covers")
-            small = nat.conv3x3_halo_group(list(rest), [self._packed_head_weight(n_early + l, 128) for l in range(len(rest))], None,
-                                           relu=False)
+            if self._halo_heads_ok(rest):
+                small = nat.conv3x3_halo_group(list(rest), [self._packed_head_weight(n_early + l, 128) for l in range(len(rest))], None,
+                                               relu=False)
+            else:                                            # extra maps the slab kernel does not cover: the implicit-GEMM group
+                small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None,
+                                              relu=False)
             main.wait_stream(side)
             return early + rest, big + small
         if mode == "2":
