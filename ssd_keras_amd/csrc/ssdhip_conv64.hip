@@ -568,7 +568,7 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     if (!x3 || !w1 || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
     if (((uintptr_t)weight | (uintptr_t)y) & 15 || (((uintptr_t)x3 | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)bias) & 1)) return SSDHIP_E_BADARG;
     const long long wb = (long long)Cout * 1152;
-    if ((long long)B * H * W * 3 > 0x7fffff00LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL) return SSDHIP_E_BADARG;
+    if ((long long)B * H * W * 6 >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
     C64Params p;
     p.x = nullptr; p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
