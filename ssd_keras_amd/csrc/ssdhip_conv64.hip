@@ -28,6 +28,10 @@
 #include "ssdhip.h"
 #include "ssdhip_math.h"
 
+#ifndef SSDHIP_C64_ABLATE
+#define SSDHIP_C64_ABLATE 0      // profiling builds only (tools/prof_build.sh): 1 no global stores, 2 no epilogue, 4 no fragment reads (wrong results)
+#endif
+
 namespace ssdhip {
 
 typedef unsigned short bf16_t;
@@ -290,8 +294,8 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         int buf = 0;
         for (int tile = first; tile < p.tiles; tile += stride) {
             const bool more = tile + stride < p.tiles;
-            if (tile + 2 * stride < p.tiles) request(tile + 2 * stride, raw_n);
-            if (more) produce(tile + stride, raw_c, buf ^ 1);
+            if (!(SSDHIP_C64_ABLATE & 8) && tile + 2 * stride < p.tiles) request(tile + 2 * stride, raw_n);      // 8: idle producers
+            if (!(SSDHIP_C64_ABLATE & 8) && more) produce(tile + stride, raw_c, buf ^ 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // multipliers done with `buf`; halo of the next tile complete in the other one
 #pragma unroll
@@ -413,7 +417,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (s + RD < 36) rd(s + RD, (s + RD) % RS);
+            if ((s + RD < 36) && (!(SSDHIP_C64_ABLATE & 4) || s + RD < RS)) rd(s + RD, (s + RD) % RS);
             __builtin_amdgcn_sched_barrier(0);             // pin the order: hipcc otherwise sinks the reads next to their use
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % RS], fb1[s % RS], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % RS], fb0[s % RS], acc[0], 0, 0, 0);
@@ -426,6 +430,9 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         // ---- epilogue (wave-private LDS stage: DS operations of one wave execute in order) ------------------------------
         int b, h0, w0;
         tile_origin(tile, b, h0, w0);
+        if constexpr ((SSDHIP_C64_ABLATE & 2) != 0) {
+            asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
+        } else
         if constexpr (POOL) {
             unsigned char* stage = lds + STAGE_OFF + wave * 2048;          // [16 pooled px][64 B]
             const int hq = h0 + 2 * rp, wq = w0 + col;
@@ -468,7 +475,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
                 const int qe = wp * 32 + 2 * px;
                 const int ho = (h0 >> 1) + (qe >> CS), wo = (w0 + (qe & (CC - 1))) >> 1;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 64 + ((c ^ (px & 3)) << 4));
-                if (ho < p.Ho && wo < p.Wo)
+                if (!(SSDHIP_C64_ABLATE & 1) && ho < p.Ho && wo < p.Wo)
                     *reinterpret_cast<uint4*>(p.y + ((size_t)(b * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + wc * 32 + c * 8) = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -494,7 +501,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
                     const int qq = wp * 32 + px;
                     const int h = h0 + 2 * (qq >> CS) + pi, w = w0 + (qq & (CC - 1));
                     const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 64 + ((c ^ (px & 3)) << 4));
-                    if (h < p.H && w < p.W)
+                    if (!(SSDHIP_C64_ABLATE & 1) && h < p.H && w < p.W)
                         *reinterpret_cast<uint4*>(p.y + ((size_t)(b * p.H + h) * p.W + w) * p.Cout + co0 + wc * 32 + c * 8) = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

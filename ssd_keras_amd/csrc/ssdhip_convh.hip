@@ -67,7 +67,7 @@ struct ConvHParams {
     int HT, WT, Ho, Wo;          // 2-D tiles: tiles per image (q_tiles = B HT WT); pooled map size
     int os, ooff, Hs, Ws;        // position grid only: output pixel (ho, wo) = the 'same' result at (ho os + ooff, wo os + ooff), map Hs x Ws
                                  // (os = 1, ooff = 0, Hs = H, Ws = W: the plain 'same' convolution)
-    int x_bytes, w_bytes;
+    int x_bytes, w_bytes, y_bytes;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -108,7 +108,8 @@ __device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
 // only the slab <-> pixel map, the lanes' slab rows and the epilogue differ.  A lane's two position blocks (pi = 0, 1) are then the
 // same column of the two rows of a row pair and lane ^ 1 is the neighbouring column, so POOL (MaxPooling2D(2, 2, 'same') fused:
 // models/keras_ssd300.py:279-283) takes the 2 x 2 maximum on the float32 accumulators in registers, as conv_igemm4_pool_kernel does.
-template <int NW, int SPW, int MODE, int CSH, bool POOL>
+// SMALL: the map may be narrower than 7 pixels (the epilogue then steps its positions with a loop instead of one select).
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
     constexpr int TC = G2 ? (1 << CSH) : 1, TR = G2 ? (CH_BN >> CSH) : 1, SC2 = TC + 2;   // tile columns, rows; slab columns
@@ -141,6 +142,18 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const i32x4 rx = ch_rsrc(p.x, p.x_bytes);
     const i32x4 rw = ch_rsrc(p.w, p.w_bytes);
+    // Outputs leave through a buffer descriptor: a lane that has nothing to store gets an out-of-range offset (dropped by the
+    // buffer unit), so every wave issues EXACTLY NST store instructions per tile -- the K loop's first waits after an epilogue
+    // count on that (see `post` in step()).
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
+    auto store16 = [&](const uint4 v, const bool ok, const u32 elem) {     // elem: index of the first of the 8 channels (y is below 2 GB)
+        if constexpr (!(MODE & 256)) {
+            const ch_u32x4 d = {v.x, v.y, v.z, v.w};
+            __builtin_amdgcn_raw_buffer_store_b128(d, ry, ok ? elem * 2u : OOB, 0, 0);
+        }
+    };
+    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8);       // global stores a wave issues per epilogue
 
     // ---- per-lane load descriptors --------------------------------------------------------------------------------------
     // slab row r <-> position q0 - (W + 2) + r; piece (k, wave) = rows 64 k + 8 wave .. + 7, lane -> row (lane >> 3), chunk slot
@@ -275,6 +288,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         constexpr int n_last = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, true) : 2)) + issued(TAP, true);
         // Ring stage of a step is (global step number) mod NW: 9 slices-so-far + TAP -> TAP mod 3 for three stages, (slices + TAP) mod 4
         const int vs = vbase + cs;
+        const bool post = cs == 0 && vbase > 0;
         const int st = NW == 3 ? TAP % 3 : ((vs + TAP) & 3);
         // 16 slots, slot i = MFMA i, then 0..2 fragment reads of step s + 1, then at three slots one LDS-DMA request.  Nothing comes
         // in bursts: with 4 MFMAs, then 8 reads from all eight waves at once, the LDS queue fills up, the waves stall on issuing reads
@@ -320,7 +334,14 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         // everything step s + 2 needs has landed (in-order completion: only the newest D - 2 steps' requests may be in flight), this
         // wave's fragment reads are done (their stage is overwritten next step), then the barrier
         if constexpr (!(MODE & 4)) {
-            if (!nomore) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
+            // Right after an epilogue (`post`: the first slice of a tile that is not the workgroup's first) the wave's VMEM queue
+            // reads [next-tile requests of the last slice | NST stores | the bias load | this tile's requests].  vmcnt counts loads
+            // AND stores in issue order and a store is acknowledged microseconds after it was issued, while what steps 0 .. D-3 need
+            // (the weights of steps 2 .. D-1) was requested BEFORE the stores: these steps let the stores and the bias load stay in
+            // flight too.  From step D-2 on the awaited requests are younger than the stores and the plain counts apply.
+            constexpr bool TOL = (MODE & 1024) != 0 && TAP < D - 2;
+            if (TOL && post) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid + NST + 1) : "memory");
+            else if (!nomore) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_last) : "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -345,6 +366,16 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 
     for (;;) {
         if constexpr (PERSIST) has_next = tile_of(id + (int)gridDim.x, q0n, co0n);
+        // The tile's bias: ONE dword per lane (lane l: channels 2 (l & 31), + 1 of the wave's 64), requested here -- ahead of the
+        // tile's K loop in the VMEM queue, so the loop's counted waits retire it -- and handed round by ds_bpermute in the
+        // epilogue.  (32 two-byte loads per lane IN the epilogue made every tile wait for a full memory round trip, and with it
+        // for every request of the next tile already in flight: r03h, 10-47 us per layer.)  An asm load so that hipcc does not
+        // drain vmcnt before its first use; without a bias the lanes read the filters (any valid address) and ignore the value.
+        u32 bias_dw;
+        {
+            const bf16_t* bsrc = (p.bias ? p.bias + co0 + wm * 64 : p.w) + 2 * r31;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(bias_dw) : "v"(bsrc) : "memory");
+        }
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -360,17 +391,29 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         // ---- epilogue: bias + ReLU + one rounding, transpose through LDS, 16-byte stores.  The stage is the slab buffer of the
         //      last (odd) slice: everything else in LDS may already hold the next tile's first slab and weights.  Two passes of 32
         //      positions per wave (4 KB, wave private: DS operations of one wave execute in order). ----------------------------------
+        asm volatile("" : "+v"(bias_dw));                 // landed: the K loop's last counted wait is younger than the request
+        if constexpr ((MODE & 512) != 0) {                 // ablation: no epilogue (the accumulators only stay alive)
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+        } else {
         unsigned char* stage = lds + SLAB0 + SLB + wave * 4096;
         float bv[2][16];
+        if (!p.bias) bias_dw = 0u;
+        // ReLU as "v <= floor ? floor : v" with floor = +0 (NaN stays NaN, -0 -> +0), no activation as floor = -inf: one compare and one
+        // select per value either way (a runtime `relu ? ... : v` costs a third, scalar, instruction per value)
+        const float rfloor = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
-                    bv[ci][4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
-                }
+            for (int g = 0; g < 4; ++g) {
+                // channels ci 32 + 8 g + 4 khalf + e, e = 0 .. 3: dwords ci 16 + 4 g + 2 khalf, + 1 (held by the lanes of that number)
+                const int dw = ci * 16 + 4 * g + 2 * khalf;
+                const u32 lo = (u32)__builtin_amdgcn_ds_bpermute(dw * 4, (int)bias_dw);
+                const u32 hi = (u32)__builtin_amdgcn_ds_bpermute(dw * 4 + 4, (int)bias_dw);
+                bv[ci][4 * g + 0] = __uint_as_float(lo << 16);
+                bv[ci][4 * g + 1] = __uint_as_float(lo & 0xffff0000u);
+                bv[ci][4 * g + 2] = __uint_as_float(hi << 16);
+                bv[ci][4 * g + 3] = __uint_as_float(hi & 0xffff0000u);
+            }
         if constexpr (POOL) {
             // 2 x 2 maximum in registers (vertical: the lane's two position blocks; horizontal: lane ^ 1 by DPP), THEN bias + ReLU +
             // one rounding -- all monotonic, so this equals pooling the rounded activations.  Even lanes hold the wave's 16 pooled
@@ -392,7 +435,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
                         if (has_right) v = right > v ? right : v;
                         v += bv[ci][4 * g + e];
-                        o[e] = p.relu ? ch_relu(v) : v;
+                        o[e] = v <= rfloor ? rfloor : v;
                     }
                     if (!(r31 & 1)) {
                         const int px = r31 >> 1, chunk = ci * 4 + g;
@@ -407,8 +450,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 const int se = wn * 32 + 2 * px;                                // the even lane's slot
                 const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
-                if (ho < p.Ho && wo < p.Wo)
-                    *reinterpret_cast<uint4*>(p.y + ((size_t)((b * p.Ho + ho) * p.Wo + wo)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * (u32)p.Cout + (u32)(co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
@@ -433,7 +475,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = acc[ci][pi][4 * g + e] + bv[ci][4 * g + e];
-                            o[e] = p.relu ? ch_relu(v) : v;
+                            o[e] = v <= rfloor ? rfloor : v;
                         }
                         const int chunk = ci * 4 + g;
                         *reinterpret_cast<uint2*>(stage + r31 * 128 + ((chunk ^ (r31 & 7)) << 4) + khalf * 8) =
@@ -447,23 +489,35 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                     if constexpr (G2) {
                         const int sl = wn * 32 + px;
                         const int hh = h0 + 2 * (sl >> CSH) + pi, ww = w0 + (sl & (TC - 1));
-                        if (hh < H && ww < W)
-                            *reinterpret_cast<uint4*>(p.y + ((size_t)((b * H + hh) * W + ww)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                        store16(v, hh < H && ww < W, (u32)((b * H + hh) * W + ww) * (u32)p.Cout + (u32)(co0 + wm * 64 + c * 8));
                     } else {
-                        if (w < W && h < H && q < p.Q) {
-                            // strided / 'valid' forms keep the positions (ho os + ooff, wo os + ooff) of the 'same' result
+                        {
+                            // strided / 'valid' forms keep the positions (ho os + ooff, wo os + ooff) of the 'same' result; os is 1 or 2:
+                            // a shift and a parity test (an integer division by a runtime value is ~35 instructions, and there were
+                            // sixteen of them per tile in this loop)
+                            const int sh = p.os - 1;
                             const int hh = h - p.ooff, ww = w - p.ooff;
-                            const int ho = hh / p.os, wo = ww / p.os;
-                            if (hh >= 0 && ww >= 0 && ho * p.os == hh && wo * p.os == ww && ho < p.Hs && wo < p.Ws)
-                                *reinterpret_cast<uint4*>(p.y + ((size_t)((b * p.Hs + ho) * p.Ws + wo)) * p.Cout + co0 + wm * 64 + c * 8) = v;
+                            const int ho = hh >> sh, wo = ww >> sh;
+                            const bool ok = w < W && h < H && q < p.Q && (hh | ww) >= 0 && !((hh | ww) & sh) && ho < p.Hs && wo < p.Ws;
+                            store16(v, ok, (u32)((b * p.Hs + ho) * p.Ws + wo) * (u32)p.Cout + (u32)(co0 + wm * 64 + c * 8));
                         }
                         q += 8;
                         w += 8;
-                        while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+                        if (!SMALL || W1 >= 8) {           // at most one row wrap per step: branch-free selects, no divergent loop
+                            const bool wr = w >= W1;
+                            w -= wr ? W1 : 0;
+                            h += wr ? 1 : 0;
+                            const bool hr = h == H1;
+                            h = hr ? 0 : h;
+                            b += hr ? 1 : 0;
+                        } else {
+                            while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+                        }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
             }
+        }
         }
         if (!has_next) break;
         __builtin_amdgcn_s_barrier();                    // the stage is a slab buffer again: the next tile's slice 1 lands there
@@ -479,7 +533,7 @@ template <int NW, int SPW, int MODE, int CSH, bool POOL>
 __global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL>(p, lds, (int)blockIdx.x);
+    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
 #endif
 }
 
@@ -508,7 +562,7 @@ __global__ __launch_bounds__(CH_THREADS) void convh_group_kernel(ConvHGroup g) {
         if (id >= total) continue;
         int k = 0;
         while (k + 1 < g.n && id >= g.first_id[k + 1]) ++k;
-        convh_body<4, 6, MODE, 0, false>(g.p[k], lds, id - g.first_id[k]);
+        convh_body<4, 6, MODE, 0, false, true>(g.p[k], lds, id - g.first_id[k]);
     }
 #endif
 }
@@ -558,7 +612,7 @@ extern "C" int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* 
     if (H + 2 * pad < 3 || W + 2 * pad < 3) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
     const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, Q = (long long)B * (H + 1) * (W + 1);
-    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout * 2 >= 0x7ffff000LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
     ConvHParams p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
@@ -569,7 +623,7 @@ extern "C" int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* 
     p.Q = (int)Q;
     p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
     p.n_tiles = Cout / CH_BM;
-    p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)((long long)B * p.Hs * p.Ws * Cout * 2);
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
     convh_launch<128>(p, 0, 0, convh_cu_count(), stream);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
@@ -598,7 +652,7 @@ extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* c
         if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
         if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
         const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, Q = (long long)B * (H + 1) * (W + 1);
-        if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout * 2 >= 0x7ffff000LL || Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
         ConvHParams& p = g.p[s];
         p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
         p.y = static_cast<bf16_t*>(y);
@@ -608,7 +662,7 @@ extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* c
         p.Q = (int)Q;
         p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
         p.n_tiles = Cout / CH_BM;
-        p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+        p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)((long long)B * H * W * Cout * 2);
         p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
         g.first_id[s] = (int)ids;
         ids += p.total_ids;
@@ -635,7 +689,7 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
     const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2;
-    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL) return SSDHIP_E_BADARG;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout * 2 >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
     ConvHParams p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
@@ -661,25 +715,23 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
         p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
     }
     p.n_tiles = Cout / CH_BM;
-    p.x_bytes = (int)xb; p.w_bytes = (int)wb;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)(pool ? (long long)B * p.Ho * p.Wo * Cout * 2 : (long long)B * H * W * Cout * 2);
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
     const int cu_count = convh_cu_count();
-    // Schedules: 128 (shipped) = persistent workgroups, one per CU, that request the next tile's first slab and weights during the
-    // last slice of the current tile (r02q: -10 % on conv3_1, -6 % on conv3_2, -1 % on the conv4 block against 64); 64 = one
-    // workgroup per tile, the second wave of every SIMD reading its fragments two slots later.  SSDHIP_CONVH_MODE selects.
+    // Schedules: 128 = persistent workgroups, one per CU, that request the next tile's first slab and weights during the last slice
+    // of the current tile; 1152 = the same with the tolerant waits after an epilogue.  SSDHIP_CONVH_MODE selects.  (The round-2
+    // schedule with one workgroup per tile is gone: it bought nothing over 128 and its <3, 7> variant spilled registers.)
     int mode = 128;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     switch (mode) {
-        case 64: convh_launch<64>(p, geom, pool, cu_count, stream); break;
+        case 1152: convh_launch<1152>(p, geom, pool, cu_count, stream); break;                             // 128 + 1024: the first waits after an epilogue let its stores stay in flight
 #if defined(SSDHIP_PROFILE)
-        case 192: convh_launch<192>(p, geom, pool, cu_count, stream); break;                               // other schedules and ablations (1, 2, 4, 32: wrong results): tools/ablate_convh.py
-        case 0: convh_launch<0>(p, geom, pool, cu_count, stream); break;
-        case 72: convh_launch<72>(p, geom, pool, cu_count, stream); break;
-        case 65: convh_launch<65>(p, geom, pool, cu_count, stream); break;
-        case 66: convh_launch<66>(p, geom, pool, cu_count, stream); break;
-        case 68: convh_launch<68>(p, geom, pool, cu_count, stream); break;
-        case 71: convh_launch<71>(p, geom, pool, cu_count, stream); break;
-        case 32: convh_launch<32>(p, geom, pool, cu_count, stream); break;
+        // ablations (wrong results by construction): tools/ablate_convh.py, tools/ablate_convh2.py
+        case 129: convh_launch<129>(p, geom, pool, cu_count, stream); break;                               // no loads in the K loop
+        case 130: convh_launch<130>(p, geom, pool, cu_count, stream); break;                               // no fragment reads
+        case 135: convh_launch<135>(p, geom, pool, cu_count, stream); break;                               // MFMAs only
+        case 384: convh_launch<384>(p, geom, pool, cu_count, stream); break;                               // the epilogue without its global stores
+        case 640: convh_launch<640>(p, geom, pool, cu_count, stream); break;                               // no epilogue at all
 #endif
         default: convh_launch<128>(p, geom, pool, cu_count, stream); break;
     }

@@ -579,8 +579,11 @@ __device__ __forceinline__ void load_keys_cached(const u64* keys, int n, int tid
 #endif
 }
 
+#ifndef SSDHIP_NMS_WAVES512
+#define SSDHIP_NMS_WAVES512 6      // minimum waves per SIMD the 512-thread variant is compiled for (tools/prof_build.sh sweeps it)
+#endif
 template <int POL, int T>
-__global__ __launch_bounds__(T, (T >= 512 ? 6 : 3)) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
+__global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
                                                const u64* __restrict__ cand, const int* __restrict__ cand_count,
                                                const int* __restrict__ work_order,
                                                u64* __restrict__ kept, int* __restrict__ kept_count) {

@@ -11,15 +11,16 @@
 //                     log loss (only where y_true != 0), smooth L1, positive / negative weights; writes cls_loss[B,N], neg_all[B,N] and the tile's four partial sums (float64).
 //                     No atomics anywhere in the sums: L2b and L4 add the partials in a fixed order, so the loss is
 //                     bit-reproducible from run to run.
-//   L2 sel_*_kernel   k, then a radix select (11+11+10 bits of the order-preserving float key) for the k-th largest negative
-//                     loss: a chip-wide histogram of the top 11 bits (L2a), the pivot digit (L2b), a chip-wide compaction
-//                     of that digit's [key | index] pairs (L2c), and one workgroup finishing on the short list (L2d) --
-//                     including, only if ties straddle the cut, the flat-index limit.
-//   L3 keep_kernel    grid-stride over B*N: keep mask + per-image sum of the kept negative losses.
+//   L2 sel_pass*      k, then a radix select (11+11+10 bits of the order-preserving float key) for the k-th largest negative
+//                     loss: level 1's histogram comes out of L1 itself; two chip-wide passes over neg_all build levels 2 and 3,
+//                     each finding the previous level's digit redundantly in every block.  No single-workgroup step, no list.
+//   L3 keep_kernel    the last digit and -- only if ties straddle the cut -- the flat-index limit (from per-block level-3
+//                     counts), then grid-stride over B*N: keep mask + per-image sum of the kept negative losses.
 //   L4 total_kernel   B threads: (pos_cls + neg_cls + alpha*loc) / max(1, n_pos) * B.
 // Backward = one kernel with the same LDS tiling writing d loss / d y_pred coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssdhip.h"
 #include "ssdhip_math.h"
@@ -28,18 +29,18 @@
 namespace ssdhip {
 
 constexpr int LOSS_THREADS = 256;
-constexpr int SEL_THREADS = 1024;
-constexpr int SELG_THREADS = 256;
-constexpr int SELG_MAX_BLOCKS = 256;
-constexpr int SELC_ITEMS = 8;
 constexpr int KEEP_BLOCKS = 64;
 constexpr int SEL_BINS = 2048;
+constexpr int SELP_THREADS = 256;                   // a select pass block: 256 threads x 8 values = SELP_CHUNK consecutive flat indices
+constexpr int SELP_ITEMS = 8;
+constexpr int SELP_CHUNK = SELP_THREADS * SELP_ITEMS;
 
 struct LossWs {
-    size_t sums, counts, hist, sel, cls, neg, list, part, keep_part, total;
-    // sums: per-image positive class loss [B] | loc loss [B] | (unused [B]) | n_pos; counts[1]: list length; hist: L2a bins;
-    // sel: select state; list: L2c pairs; part: L1's per-tile partial sums [4][B][tiles]; keep_part: L3's [B][KEEP_BLOCKS]
-    int tiles;
+    size_t sums, hist, sel, cls, neg, part, keep_part, bcol, total;
+    // sums: per-image positive class loss [B] | loc loss [B] | (unused [B]) | n_pos; hist: the three levels' bins [3][SEL_BINS] (zeroed
+    // per call); sel: select state; part: L1's per-tile partial sums [4][B][tiles]; keep_part: L3's [B][KEEP_BLOCKS];
+    // bcol: level-3 bin counts per pass block [nblk][1024] u16 (where among the ties the cut falls)
+    int tiles, nblk;
 };
 
 struct SelectResult {
@@ -49,8 +50,9 @@ struct SelectResult {
     int n_neg_losses;
     float n_pos;
     float thresh;
-    int digit;                    // L2b -> L2c/L2d: top 11 key bits of the threshold
-    int want;                     //                 how many of that digit's values are kept
+    int digit;                    // level 1: top 11 key bits of the threshold
+    int want;                     //          how many of that digit's values are kept
+    int digit2, want2;            // level 2: the next 11 bits, how many of the 22-bit prefix's values are kept
 };
 
 static inline size_t lalign(size_t v) { return (v + 255) / 256 * 256; }
@@ -58,6 +60,9 @@ static inline size_t lalign(size_t v) { return (v + 255) / 256 * 256; }
 // anchors per L1 / backward tile: both row tiles ([TA][C+12] of y_true and y_pred) within 64 KB of LDS
 static int loss_tile(int L) {
     int TA = 256;
+#if defined(SSDHIP_PROFILE)
+    if (const char* e = getenv("SSDHIP_LOSS_TA")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) TA = v; }   // tile sweep (tools/time_loss.py)
+#endif
     while (TA > 64 && 2 * ((size_t)TA * L + 8) * sizeof(float) > 64 * 1024) TA >>= 1;
     return TA;
 }
@@ -66,16 +71,16 @@ static LossWs loss_ws_layout(int B, int N, int C) {
     LossWs w;
     const int TA = loss_tile(C + 12);
     w.tiles = (N + TA - 1) / TA;
+    w.nblk = (int)(((long long)B * N + SELP_CHUNK - 1) / SELP_CHUNK);
     size_t o = 0;
+    w.hist = o;   o = lalign(o + 3 * SEL_BINS * sizeof(u32));            // first: one memset covers it
     w.sums = o;   o = lalign(o + (size_t)(3 * B + 1) * sizeof(double));
-    w.counts = o; o = lalign(o + 4 * sizeof(int));
-    w.hist = o;   o = lalign(o + SEL_BINS * sizeof(u32));
     w.sel = o;    o = lalign(o + sizeof(SelectResult));
     w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.neg = o;    o = lalign(o + (size_t)B * N * sizeof(float));
-    w.list = o;   o = lalign(o + (size_t)B * N * sizeof(u64));
     w.part = o;   o = lalign(o + (size_t)4 * B * w.tiles * sizeof(double));
     w.keep_part = o; o = lalign(o + (size_t)B * KEEP_BLOCKS * sizeof(double));
+    w.bcol = o;   o = lalign(o + (size_t)w.nblk * 1024 * sizeof(unsigned short));
     w.total = o;
     return w;
 }
@@ -85,25 +90,45 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// hist[bin] += 1 for every active lane, with the lanes of a wave that share a bin combined into one LDS atomic: mined losses
+// cluster (every clipped loss is -log(1e-15); a saturated background scores the same few values), and 64 lanes on one LDS
+// address serialise.  Up to four rounds of "everybody who shares the first remaining lane's bin", then plain atomics.
+__device__ __forceinline__ void hist_add_aggregated(u32* hist, u32 bin, bool active) {
+    u64 todo = __ballot(active);
+#pragma unroll 1
+    for (int round = 0; round < 4 && todo; ++round) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const u32 b0 = (u32)__shfl((int)bin, leader);
+        const u64 same = __ballot(active && bin == b0) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], (u32)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> (threadIdx.x & 63)) & 1ull) atomicAdd(&hist[bin], 1u);
+}
+
 // ======================================================================================
 // L1
 // ======================================================================================
 __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
                                                               int B, int N, int C, float* __restrict__ cls_out,
-                                                              float* __restrict__ neg_out, double* __restrict__ part) {
+                                                              float* __restrict__ neg_out, double* __restrict__ part,
+                                                              u32* __restrict__ ghist1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4][LOSS_THREADS / 64];
+    __shared__ u32 hist[SEL_BINS];                                      // level 1 of the hard-negative select: top 11 key bits of neg_all
     const int TA = blockDim.x, L = C + 12;
     const int b = blockIdx.y, a0 = blockIdx.x * TA, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int na = min(TA, N - a0);
     const size_t off = ((size_t)b * N + a0) * (size_t)L;
     float* lds = reinterpret_cast<float*>(smem_raw);
     const size_t half = ((size_t)TA * L + 4 + 3) / 4 * 4;
+    for (int i = tid; i < SEL_BINS; i += TA) hist[i] = 0u;
     const float* yt = tile_copy_f32(lds, y_true + off, na * L, tid, TA);
     const float* yp = tile_copy_f32(lds + half, y_pred + off, na * L, tid, TA);
     __syncthreads();
     double s_poscls = 0.0, s_loc = 0.0, s_npos = 0.0;
     int nonzero = 0;
+    u32 bin = 0;
     if (tid < na) {
         const float* t = yt + (size_t)tid * L;
         const float* q = yp + (size_t)tid * L;
@@ -127,12 +152,18 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
         s_loc = (double)(loc * pos);
         s_npos = (double)pos;
         nonzero = neg != 0.f;
+        bin = float_key(neg) >> 21;
     }
+    hist_add_aggregated(hist, bin, tid < na);
     s_poscls = wave_sum(s_poscls); s_loc = wave_sum(s_loc); s_npos = wave_sum(s_npos);
     const double s_nz = wave_sum((double)nonzero);
     if (lane == 0) { red[0][wave] = s_poscls; red[1][wave] = s_loc; red[2][wave] = s_npos; red[3][wave] = s_nz; }
     __syncthreads();
-    if (tid == 0) {                                                     // per-tile partial sums, reduced in a fixed order by L2b
+    for (int i = tid; i < SEL_BINS; i += TA) {                          // integer atomics: the order does not show in the result
+        const u32 c = hist[i];
+        if (c) atomicAdd(&ghist1[i], c);
+    }
+    if (tid == 0) {                                                     // per-tile partial sums, reduced in a fixed order by L2
         double a = 0, l = 0, n = 0, z = 0;
         for (int w = 0; w < TA / 64; ++w) { a += red[0][w]; l += red[1][w]; n += red[2][w]; z += red[3][w]; }
         const size_t tiles = gridDim.x, slot = (size_t)b * tiles + blockIdx.x, plane = (size_t)B * tiles;
@@ -141,185 +172,195 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
 }
 
 // ======================================================================================
-// L2: k and the k-th largest negative loss.  Four short launches; only the two streaming passes use the whole chip.
+// L2: k and the k-th largest negative loss by a three-level radix select (11 + 11 + 10 bits of the order-preserving float key).
+// Every level is a CHIP-WIDE histogram pass over neg_all (1.1 MB at SSD300 / batch 32: L2-resident); the digit of level l is found
+// from level l's bins by EVERY block of the next pass (a 2048-bin suffix scan: cheaper than a launch of its own).  Nothing runs on
+// one workgroup, and nothing depends on how the values are distributed: when every mined loss ties (random-init predictions: all
+// clipped at -log(1e-15)), the first two generations' single-workgroup finish over a 279 k-entry list took 0.28 ms.
+// Ties straddling the cut ("the lowest flat indices win", tf.nn.top_k) are resolved from the per-block level-3 bin counts the
+// last pass leaves behind: which block holds the want-th tie is a scan over nblk numbers, where inside it a scan over its 2048 values.
 // ======================================================================================
-// L2a: histogram of the top 11 key bits over all B*N values, privatised in LDS per workgroup
-__global__ __launch_bounds__(SELG_THREADS) void sel_hist_kernel(const float* __restrict__ neg_all, int total, u32* __restrict__ ghist) {
-    __shared__ u32 hist[SEL_BINS];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < SEL_BINS; i += SELG_THREADS) hist[i] = 0;
-    __syncthreads();
-    for (int i = blockIdx.x * SELG_THREADS + tid; i < total; i += gridDim.x * SELG_THREADS)
-        atomicAdd(&hist[float_key(neg_all[i]) >> 21], 1u);
-    __syncthreads();
-    for (int i = tid; i < SEL_BINS; i += SELG_THREADS) {
-        const u32 c = hist[i];
-        if (c) atomicAdd(&ghist[i], c);
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot, int& total) {   // blockDim.x == 256; all threads call it
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
     }
+    __syncthreads();                                                    // wave_tot may still be read from a previous call
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) base += wave_tot[w]; t += wave_tot[w]; }
+    total = t;
+    return base + incl - v;
 }
 
-// L2b: k (:166-177) and the top-11-bit digit the k-th largest value falls in
-__global__ __launch_bounds__(SEL_THREADS) void sel_pivot_kernel(const u32* __restrict__ ghist, int neg_pos_ratio, int n_neg_min,
-                                                                const double* __restrict__ part, int tiles, double* __restrict__ sums,
-                                                                int B, SelectResult* __restrict__ res, float* __restrict__ stats) {
+// L2a: k (:166-177) + the level-1 digit (every block), per-image sums and the select state (block 0); level-2 histogram of the
+// values whose top 11 bits equal that digit
+__global__ __launch_bounds__(SELP_THREADS) void sel_pass2_kernel(const float* __restrict__ neg_all, int total, u32* __restrict__ ghist,
+                                                                 int neg_pos_ratio, int n_neg_min, const double* __restrict__ part,
+                                                                 int tiles, double* __restrict__ sums, int B,
+                                                                 SelectResult* __restrict__ res, float* __restrict__ stats) {
     __shared__ u32 hist[SEL_BINS];
     __shared__ int sh_out[2];
-    __shared__ int wave_cnt[SEL_THREADS / 64];
-    __shared__ double tot[2][SEL_THREADS / 64];
+    __shared__ int wave_cnt[SELP_THREADS / 64];
+    __shared__ double tot[2][SELP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // L1's per-tile partial sums -> per-image sums (one wave each) and the two batch totals: fixed order, no atomics
     const size_t plane = (size_t)B * tiles;
-    for (int job = wave; job < 2 * B; job += SEL_THREADS / 64) {         // job = q * B + b, q = 0 positive class loss, 1 loc loss
-        double v = 0.0;
-        for (int t = lane; t < tiles; t += 64) v += part[(size_t)job * tiles + t];
-        v = wave_sum(v);
-        if (lane == 0) sums[job] = v;
+    if (blockIdx.x == 0) {
+        // L1's per-tile partial sums -> per-image sums (one wave each): fixed order, no atomics
+        for (int job = wave; job < 2 * B; job += SELP_THREADS / 64) {    // job = q * B + b, q = 0 positive class loss, 1 loc loss
+            double v = 0.0;
+            for (int t = lane; t < tiles; t += 64) v += part[(size_t)job * tiles + t];
+            v = wave_sum(v);
+            if (lane == 0) sums[job] = v;
+        }
     }
-    double np_ = 0.0, nz_ = 0.0;
-    for (size_t i = tid; i < plane; i += SEL_THREADS) { np_ += part[2 * plane + i]; nz_ += part[3 * plane + i]; }
+    double np_ = 0.0, nz_ = 0.0;                                        // the same order in every block: identical k everywhere
+    for (size_t i = tid; i < plane; i += SELP_THREADS) { np_ += part[2 * plane + i]; nz_ += part[3 * plane + i]; }
     np_ = wave_sum(np_); nz_ = wave_sum(nz_);
     if (lane == 0) { tot[0][wave] = np_; tot[1][wave] = nz_; }
+    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = ghist[i];
     __syncthreads();
     np_ = 0.0; nz_ = 0.0;
-    for (int w = 0; w < SEL_THREADS / 64; ++w) { np_ += tot[0][w]; nz_ += tot[1][w]; }
+    for (int w = 0; w < SELP_THREADS / 64; ++w) { np_ += tot[0][w]; nz_ += tot[1][w]; }
     const float n_pos = (float)np_;
     const int n_neg_losses = (int)nz_;
     int k = neg_pos_ratio * (int)n_pos;                                  // tf.to_int32(n_positive) truncates (:166)
     k = k > n_neg_min ? k : n_neg_min;
     k = k < n_neg_losses ? k : n_neg_losses;
-    if (k > 0) {
-        for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = ghist[i];
-        __syncthreads();
-        block_find_digit<SEL_BINS / SEL_THREADS>(hist, k, wave_cnt, sh_out);
-    }
-    if (tid == 0) {
+    if (k > 0) block_find_digit<SEL_BINS / SELP_THREADS>(hist, k, wave_cnt, sh_out);
+    const int digit = k > 0 ? sh_out[0] : 0, want = k > 0 ? k - sh_out[1] : 0;
+    if (blockIdx.x == 0 && tid == 0) {
         sums[3 * B] = np_;
         res->k = k; res->thresh_key = 0; res->tie_limit = 0x7fffffff; res->n_neg_losses = n_neg_losses;
         res->n_pos = n_pos; res->thresh = 0.f;
-        res->digit = k > 0 ? sh_out[0] : 0;
-        res->want = k > 0 ? k - sh_out[1] : 0;
+        res->digit = digit; res->want = want; res->digit2 = 0; res->want2 = 0;
         stats[0] = n_pos; stats[1] = (float)n_neg_losses; stats[2] = (float)k; stats[3] = 0.f;
     }
-}
-
-// L2c: the values of that digit, as [key | flat index] pairs, appended to a list (order does not matter): each workgroup
-// takes SELC_ITEMS * 256 values, counts its matches, reserves its slice of the list with one atomic
-__global__ __launch_bounds__(SELG_THREADS) void sel_compact_kernel(const float* __restrict__ neg_all, int total,
-                                                                   const SelectResult* __restrict__ res, int* __restrict__ list_count,
-                                                                   u64* __restrict__ list) {
-    __shared__ int wave_tot[SELG_THREADS / 64];
-    __shared__ int base_sh;
-    if (res->k <= 0) return;
-    const u32 digit = (u32)res->digit;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * (SELG_THREADS * SELC_ITEMS) + tid;
-    u32 keys[SELC_ITEMS];
-    u32 hit = 0;
-#pragma unroll
-    for (int j = 0; j < SELC_ITEMS; ++j) {
-        const int i = i0 + j * SELG_THREADS;
-        keys[j] = i < total ? float_key(neg_all[i]) : 0u;
-        if (i < total && (keys[j] >> 21) == digit) hit |= 1u << j;
-    }
-    const int cnt = __popc(hit);
-    int incl = cnt;                                                     // inclusive prefix over the lanes of this wave
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
+    if (k <= 0) return;
     __syncthreads();
-    if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < SELG_THREADS / 64; ++w) t += wave_tot[w];
-        base_sh = t ? atomicAdd(list_count, t) : 0;
+    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = 0u;
+    __syncthreads();
+    const int i0 = blockIdx.x * SELP_CHUNK + tid;
+#pragma unroll
+    for (int j = 0; j < SELP_ITEMS; ++j) {
+        const int i = i0 + j * SELP_THREADS;
+        const u32 key = i < total ? float_key(neg_all[i]) : 0u;
+        hist_add_aggregated(hist, (key >> 10) & 0x7ffu, i < total && (key >> 21) == (u32)digit);
     }
     __syncthreads();
-    int pos = base_sh + incl - cnt;
-    for (int w = 0; w < wave; ++w) pos += wave_tot[w];
-#pragma unroll
-    for (int j = 0; j < SELC_ITEMS; ++j)
-        if (hit & (1u << j)) list[pos++] = ((u64)keys[j] << 32) | (u64)(u32)(i0 + j * SELG_THREADS);
+    u32* g2 = ghist + SEL_BINS;
+    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) {
+        const u32 c = hist[i];
+        if (c) atomicAdd(&g2[i], c);
+    }
 }
 
-// L2d: one workgroup finishes on the list: the remaining 21 key bits, then -- only if ties straddle the cut -- the flat
-// index limit: the want-th smallest index among the ties, found by the same radix select on the inverted index.
-__global__ __launch_bounds__(SEL_THREADS) void sel_finish_kernel(const u64* __restrict__ list, const int* __restrict__ list_count,
-                                                                 SelectResult* __restrict__ res, float* __restrict__ stats) {
+// L2b: the level-2 digit (every block); level-3 histogram (the last 10 bits) of the values with that 22-bit prefix, to the global bins
+// and, per block, to bcol[block][1024]
+__global__ __launch_bounds__(SELP_THREADS) void sel_pass3_kernel(const float* __restrict__ neg_all, int total, u32* __restrict__ ghist,
+                                                                 SelectResult* __restrict__ res, unsigned short* __restrict__ bcol) {
     __shared__ u32 hist[SEL_BINS];
     __shared__ int sh_out[2];
-    __shared__ int wave_cnt[SEL_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (res->k <= 0) return;
-    const int n = *list_count;
-    int want = res->want;
-    u32 prefix = (u32)res->digit << 21, pmask = 0x7ffu << 21;
-    {
-        const int shifts[2] = {10, 0};
-        const u32 masks[2] = {0x7ffu, 0x3ffu};
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += SEL_THREADS) {
-                const u32 key = (u32)(list[i] >> 32);
-                if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & masks[pass]], 1u);
-            }
-            __syncthreads();
-            block_find_digit<SEL_BINS / SEL_THREADS>(hist, want, wave_cnt, sh_out);
-            want -= sh_out[1];
-            prefix |= (u32)sh_out[0] << shifts[pass];
-            pmask |= masks[pass] << shifts[pass];
-            __syncthreads();
-        }
-    }
-    // `want` of the elements equal to the threshold are kept; if that is not all of them, the lowest flat indices win
-    int eq_local = 0;
-    for (int i = tid; i < n; i += SEL_THREADS) eq_local += (u32)(list[i] >> 32) == prefix;
-    eq_local = (int)wave_sum((double)eq_local);
-    if (lane == 0) wave_cnt[wave] = eq_local;
+    __shared__ int wave_cnt[SELP_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int k = res->k;
+    if (k <= 0) return;
+    const u32* g2 = ghist + SEL_BINS;
+    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = g2[i];
     __syncthreads();
-    int eq_total = 0;
-    for (int w = 0; w < SEL_THREADS / 64; ++w) eq_total += wave_cnt[w];
+    const int want1 = res->want;
+    block_find_digit<SEL_BINS / SELP_THREADS>(hist, want1, wave_cnt, sh_out);
+    const int digit2 = sh_out[0], want2 = want1 - sh_out[1];
+    const u32 prefix22 = ((u32)res->digit << 11) | (u32)digit2;          // key >> 10
     __syncthreads();
-    int tie_limit = 0x7fffffff;
-    if (eq_total != want) {
-        u32 ip = 0, im = 0;
-        int w2 = want;
-        const int shifts[3] = {21, 10, 0};
-        const u32 masks[3] = {0x7ffu, 0x7ffu, 0x3ffu};
-        for (int pass = 0; pass < 3; ++pass) {
-            for (int i = tid; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += SEL_THREADS) {
-                const u64 e = list[i];
-                const u32 inv = ~(u32)e;
-                if ((u32)(e >> 32) == prefix && (inv & im) == ip) atomicAdd(&hist[(inv >> shifts[pass]) & masks[pass]], 1u);
-            }
-            __syncthreads();
-            block_find_digit<SEL_BINS / SEL_THREADS>(hist, w2, wave_cnt, sh_out);
-            w2 -= sh_out[1];
-            ip |= (u32)sh_out[0] << shifts[pass];
-            im |= masks[pass] << shifts[pass];
-            __syncthreads();
-        }
-        tie_limit = (int)(~ip) + 1;                                     // one past the want-th tie
+    if (blockIdx.x == 0 && tid == 0) { res->digit2 = digit2; res->want2 = want2; }
+    for (int i = tid; i < 1024; i += SELP_THREADS) hist[i] = 0u;
+    __syncthreads();
+    const int i0 = blockIdx.x * SELP_CHUNK + tid;
+#pragma unroll
+    for (int j = 0; j < SELP_ITEMS; ++j) {
+        const int i = i0 + j * SELP_THREADS;
+        const u32 key = i < total ? float_key(neg_all[i]) : 0u;
+        hist_add_aggregated(hist, key & 0x3ffu, i < total && (key >> 10) == prefix22);
     }
-    if (tid == 0) {
-        res->thresh_key = prefix; res->tie_limit = tie_limit; res->thresh = key_float(prefix);
-        stats[3] = res->thresh;
+    __syncthreads();
+    u32* g3 = ghist + 2 * SEL_BINS;
+    for (int i = tid; i < 1024; i += SELP_THREADS) {
+        const u32 c = hist[i];
+        bcol[(size_t)blockIdx.x * 1024 + i] = (unsigned short)c;         // <= SELP_CHUNK = 2048
+        if (c) atomicAdd(&g3[i], c);
     }
 }
 
 // ======================================================================================
 // L3 / L4
 // ======================================================================================
+// L3: the last digit, the threshold key and -- only if ties straddle the cut -- the flat-index limit (every block, redundantly),
+// then the keep mask + per-image partial sums of the kept negative losses
 __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restrict__ cls, const float* __restrict__ neg_all,
-                                                            int B, int N, const SelectResult* __restrict__ res,
-                                                            unsigned char* __restrict__ keep, double* __restrict__ keep_part) {
+                                                            int B, int N, const u32* __restrict__ ghist, int nblk,
+                                                            const unsigned short* __restrict__ bcol, SelectResult* __restrict__ res,
+                                                            float* __restrict__ stats, unsigned char* __restrict__ keep,
+                                                            double* __restrict__ keep_part) {
     __shared__ double red[LOSS_THREADS / 64];
+    __shared__ u32 hist[1024];
+    __shared__ int sh_out[2];
+    __shared__ int wave_cnt[LOSS_THREADS / 64];
+    __shared__ int sh_found[2];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = res->k, tie_limit = res->tie_limit;
-    const u32 tk = res->thresh_key;
+    const int k = res->k;
+    u32 tk = 0;
+    int tie_limit = 0x7fffffff;
+    if (k > 0) {
+        const u32* g3 = ghist + 2 * SEL_BINS;
+        for (int i = tid; i < 1024; i += LOSS_THREADS) hist[i] = g3[i];
+        __syncthreads();
+        const int want2 = res->want2;
+        block_find_digit<1024 / LOSS_THREADS>(hist, want2, wave_cnt, sh_out);
+        const int digit3 = sh_out[0], want3 = want2 - sh_out[1];         // want3 of the values equal to the threshold are kept
+        const int eq_total = (int)hist[digit3];
+        tk = ((u32)res->digit << 21) | ((u32)res->digit2 << 10) | (u32)digit3;
+        if (want3 < eq_total) {                                          // the lowest flat indices among the ties win
+            // the pass block that holds the want3-th tie ...
+            int before = 0, jstar = -1, rank = 0;
+            for (int j0 = 0; j0 < nblk && jstar < 0; j0 += LOSS_THREADS) {
+                const int j = j0 + tid;
+                const int c = j < nblk ? (int)bcol[(size_t)j * 1024 + digit3] : 0;
+                int tot;
+                const int excl = block_exclusive_scan(c, wave_cnt, tot);
+                if (tid == 0) sh_found[0] = -1;
+                __syncthreads();
+                if (c > 0 && before + excl < want3 && want3 <= before + excl + c) { sh_found[0] = j; sh_found[1] = want3 - (before + excl); }
+                __syncthreads();
+                jstar = sh_found[0]; rank = sh_found[1];
+                before += tot;
+            }
+            // ... and the rank-th tie inside it, in flat order (a thread takes 8 consecutive values)
+            const int f0 = jstar * SELP_CHUNK + tid * SELP_ITEMS, total = B * N;
+            int c = 0;
+            u32 hit = 0;
+#pragma unroll
+            for (int j = 0; j < SELP_ITEMS; ++j)
+                if (f0 + j < total && float_key(neg_all[f0 + j]) == tk) { hit |= 1u << j; ++c; }
+            int tot;
+            const int excl = block_exclusive_scan(c, wave_cnt, tot);
+            if (c > 0 && excl < rank && rank <= excl + c) {
+                int need = rank - excl;
+#pragma unroll
+                for (int j = 0; j < SELP_ITEMS; ++j)
+                    if ((hit >> j) & 1u) { if (--need == 0) sh_found[0] = f0 + j + 1; }   // one past the want3-th tie
+            }
+            __syncthreads();
+            tie_limit = sh_found[0];
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            res->thresh_key = tk; res->tie_limit = tie_limit; res->thresh = key_float(tk);
+            stats[3] = key_float(tk);
+        }
+    }
     double s = 0.0;
     for (int n = blockIdx.x * LOSS_THREADS + tid; n < N; n += gridDim.x * LOSS_THREADS) {
         const int flat = b * N + n;
@@ -414,38 +455,31 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     if (!ws || ws_bytes < lay.total) return SSDHIP_E_WORKSPACE;
     unsigned char* base = static_cast<unsigned char*>(ws);
     double* sums = reinterpret_cast<double*>(base + lay.sums);
-    int* counts = reinterpret_cast<int*>(base + lay.counts);
     SelectResult* sel = reinterpret_cast<SelectResult*>(base + lay.sel);
     float* cls = reinterpret_cast<float*>(base + lay.cls);
     float* neg = reinterpret_cast<float*>(base + lay.neg);
     u32* ghist = reinterpret_cast<u32*>(base + lay.hist);
-    u64* list = reinterpret_cast<u64*>(base + lay.list);
     double* part = reinterpret_cast<double*>(base + lay.part);
     double* keep_part = reinterpret_cast<double*>(base + lay.keep_part);
-    if (hipMemsetAsync(base, 0, lay.sel, stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // list length + L2a bins (the sums are plain stores)
+    unsigned short* bcol = reinterpret_cast<unsigned short*>(base + lay.bcol);
+    if (hipMemsetAsync(ghist, 0, 3 * SEL_BINS * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins (sums are plain stores)
 
     const int L = C + 12;
     const int TA = loss_tile(L);
     const size_t lds = 2 * (((size_t)TA * L + 4 + 3) / 4 * 4) * sizeof(float) + 16;
-    if (lds > 150 * 1024) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(anchor_kernel, dim3(lay.tiles, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, part);
+    if (lds > 140 * 1024) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(anchor_kernel, dim3(lay.tiles, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, part, ghist);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     const int total = B * N;
-    int sel_blocks = (total + SELG_THREADS - 1) / SELG_THREADS;
-    if (sel_blocks > SELG_MAX_BLOCKS) sel_blocks = SELG_MAX_BLOCKS;
-    const int compact_blocks = (total + SELG_THREADS * SELC_ITEMS - 1) / (SELG_THREADS * SELC_ITEMS);
-    hipLaunchKernelGGL(sel_hist_kernel, dim3(sel_blocks), dim3(SELG_THREADS), 0, stream, neg, total, ghist);
+    hipLaunchKernelGGL(sel_pass2_kernel, dim3(lay.nblk), dim3(SELP_THREADS), 0, stream, neg, total, ghist, neg_pos_ratio, n_neg_min, part,
+                       lay.tiles, sums, B, sel, stats);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(sel_pivot_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, ghist, neg_pos_ratio, n_neg_min, part, lay.tiles, sums, B, sel,
-                       stats);
-    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(sel_compact_kernel, dim3(compact_blocks), dim3(SELG_THREADS), 0, stream, neg, total, sel, counts + 1, list);
-    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(sel_finish_kernel, dim3(1), dim3(SEL_THREADS), 0, stream, list, counts + 1, sel, stats);
+    hipLaunchKernelGGL(sel_pass3_kernel, dim3(lay.nblk), dim3(SELP_THREADS), 0, stream, neg, total, ghist, sel, bcol);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     int gx = (N + LOSS_THREADS - 1) / LOSS_THREADS;
     if (gx > KEEP_BLOCKS) gx = KEEP_BLOCKS;
-    hipLaunchKernelGGL(keep_kernel, dim3(gx, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, sel, keep_mask, keep_part);
+    hipLaunchKernelGGL(keep_kernel, dim3(gx, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, ghist, lay.nblk, bcol, sel, stats, keep_mask,
+                       keep_part);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     hipLaunchKernelGGL(total_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sums, keep_part, gx, B, alpha, loss_per_item);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;

@@ -175,9 +175,25 @@ class GraphedInference:
         finally:
             model.__dict__["_head_overlap"] = had
 
+        # What the recorded kernels read besides `static_in`: the parameters' own storage (in-place updates -- optimizer steps,
+        # load_state_dict, load_keras_weights -- are seen by the next replay) and the PACKED head filters, separate tensors built from
+        # the conf / loc weights: those are refreshed in place when a head weight changed (`_refresh_packed_heads`).  A parameter
+        # whose storage was REPLACED (`conv.weight = nn.Parameter(...)`, `param.data = t`) is something the graph cannot follow.
+        self._param_ptrs = tuple(p.data_ptr() for p in model.parameters())
+        self._head_key = model._head_weights_key()
+
     def __call__(self, images=None):
         if images is not None and images.data_ptr() != self.static_in.data_ptr():
+            if tuple(images.shape) != tuple(self.static_in.shape) or images.dtype != self.static_in.dtype:
+                raise ValueError("this graph was captured for images of shape %s / %s, got %s / %s" % (
+                    tuple(self.static_in.shape), self.static_in.dtype, tuple(images.shape), images.dtype))
             self.static_in.copy_(images, non_blocking=True)
+        if tuple(p.data_ptr() for p in self.model.parameters()) != self._param_ptrs:
+            raise RuntimeError("a parameter's storage was replaced after the graph was captured: call model.graphed(...) again")
+        key = self.model._head_weights_key()
+        if key != self._head_key:
+            self.model._refresh_packed_heads()
+            self._head_key = key
         self.graph.replay()
         return self.static_out
 
@@ -354,18 +370,21 @@ class SSDModel(nn.Module):
         st = self.__dict__.get("_shadow_state")
         if st is None or st["device"] != conv.weight.device:
             convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m.bias is not None]
-            src = [c.weight for c in convs] + [c.bias for c in convs]
             with torch.no_grad():
-                dst = [torch.empty_like(t, dtype=torch.bfloat16) for t in src]
-            st = {"device": conv.weight.device, "src": src, "dst": dst, "versions": None,
+                dst = [torch.empty_like(t, dtype=torch.bfloat16) for t in [c.weight for c in convs] + [c.bias for c in convs]]
+            st = {"device": conv.weight.device, "convs": convs, "dst": dst, "key": None,
                   "index": {id(c): i for i, c in enumerate(convs)}, "n": len(convs)}
             self.__dict__["_shadow_state"] = st
-        if not self.__dict__.get("_shadow_fresh", False):                 # checked once per forward pass (raw_predictions resets it)
-            versions = tuple(t._version for t in st["src"])
-            if versions != st["versions"]:
+        # Inside raw_predictions the check runs once per forward pass (`_shadow_fresh`); a direct call of features() / conv_act()
+        # checks every time.  The key holds the Parameter OBJECT, its storage and its version: an optimizer step bumps the version,
+        # `param.data = t` changes the storage, `conv.weight = nn.Parameter(...)` the object.
+        if not (self.__dict__.get("_in_forward", False) and self.__dict__.get("_shadow_fresh", False)):
+            src = [c.weight for c in st["convs"]] + [c.bias for c in st["convs"]]
+            key = tuple((id(t), t.data_ptr(), t._version) for t in src)
+            if key != st["key"]:
                 with torch.no_grad():
-                    torch._foreach_copy_(st["dst"], [t.detach() for t in st["src"]])
-                st["versions"] = versions
+                    torch._foreach_copy_(st["dst"], [t.detach() for t in src])
+                st["key"] = key
             self.__dict__["_shadow_fresh"] = True
         i = st["index"].get(id(conv))
         if i is None:
@@ -393,15 +412,21 @@ class SSDModel(nn.Module):
                      for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6))}
         else:
             return None, None
+        import os
+        key = ("act", tuple(x.shape), conv.out_channels, k, d, relu, conv.stride[0], conv.padding[0])
+        forced = os.environ.get("SSDHIP_CONV", "auto")
         if len(cands) == 1:
             name = "igemm"
+        elif forced in cands:
+            name = forced
+        elif SSDModel._conv_choice.get(key) in cands:
+            name = SSDModel._conv_choice[key]                   # settled earlier: no bf16 copies of x / weight / bias just to look it up
         else:
             with torch.no_grad():
                 xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 wb = conv.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 bb = conv.bias.detach().to(torch.bfloat16)
-                name = self._pick(("act", tuple(x.shape), conv.out_channels, k, d, relu, conv.stride[0], conv.padding[0]),
-                                  {n: (lambda fn=fn: fn(xb, wb, bb)) for n, fn in cands.items()})
+                name = self._pick(key, {n: (lambda fn=fn: fn(xb, wb, bb)) for n, fn in cands.items()})
             if name not in cands:
                 name = "igemm"
         return cands[name], name
@@ -509,6 +534,13 @@ class SSDModel(nn.Module):
         """The `(batch, #boxes, #classes + 12)` prediction tensor; with `decode=True` (used by `forward` in the inference modes) the
         decoded detections, which on the fused bf16 path come straight from the head outputs."""
         self.__dict__["_shadow_fresh"] = False
+        self.__dict__["_in_forward"] = True
+        try:
+            return self._raw_predictions(images, decode)
+        finally:
+            self.__dict__["_in_forward"] = False
+
+    def _raw_predictions(self, images, decode):
         x = self.preprocess(images)
         dtype = next(self.parameters()).dtype
         xin = x.to(dtype) if not torch.is_autocast_enabled() else x
@@ -673,8 +705,15 @@ class SSDModel(nn.Module):
         ch, lh = self.conf_heads[l], self.loc_heads[l]
         key = (ch.weight._version, lh.weight._version, ch.weight.data_ptr(), lh.weight.data_ptr())
         hit = self._packed_heads.get((l, multiple))
-        if hit is None or hit[0] != key:
-            n = ch.out_channels + lh.out_channels
+        n = ch.out_channels + lh.out_channels
+        if hit is not None and hit[0] != key and hit[1].device == ch.weight.device and hit[1].dtype == ch.weight.dtype:
+            # refreshed IN PLACE: a captured HIP graph (GraphedInference) keeps reading this storage
+            with torch.no_grad():
+                hit[1][:ch.out_channels].copy_(ch.weight)
+                hit[1][ch.out_channels:n].copy_(lh.weight)
+            hit = (key, hit[1])
+            self._packed_heads[(l, multiple)] = hit
+        elif hit is None or hit[0] != key:
             pad = (-n) % multiple
             with torch.no_grad():
                 w = torch.cat([ch.weight, lh.weight] + ([ch.weight.new_zeros((pad,) + tuple(ch.weight.shape[1:]))] if pad else []), dim=0)
@@ -682,6 +721,14 @@ class SSDModel(nn.Module):
             hit = (key, w)
             self._packed_heads[(l, multiple)] = hit
         return hit[1]
+
+    def _head_weights_key(self):
+        return tuple((c.weight._version, c.weight.data_ptr()) for heads in (self.conf_heads, self.loc_heads) for c in heads)
+
+    def _refresh_packed_heads(self):
+        """Rebuild every cached packed head filter IN ITS OWN STORAGE (a captured HIP graph keeps reading that storage)."""
+        for (l, multiple) in list(self._packed_heads):
+            self._packed_head_weight(l, multiple)
 
     def _fused_head_ok(self, f, conv):
         return (self.fused_inference and f.is_cuda and f.dtype == torch.bfloat16 and not torch.is_grad_enabled()

@@ -243,9 +243,9 @@ HALO_CASES = [  # B, H, W, Cin, Cout, bias, relu      (csrc/ssdhip_convh.hip: 3x
 ]
 
 
-@pytest.fixture(params=["64", "128"])
+@pytest.fixture(params=["128", "1152"])
 def slab_mode(request):
-    """SSDHIP_CONVH_MODE: 64 = one workgroup per tile, 128 = persistent workgroups prefetching across tiles (read at every launch)."""
+    """SSDHIP_CONVH_MODE: 128 = persistent workgroups prefetching across tiles, 1152 = the same with the tolerant waits after an epilogue (read at every launch)."""
     import os
     old = os.environ.get("SSDHIP_CONVH_MODE")
     os.environ["SSDHIP_CONVH_MODE"] = request.param

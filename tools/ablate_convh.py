@@ -10,7 +10,7 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-os.environ["SSDHIP_LIB"] = os.path.join(HERE, "libssdhip_prof.so")
+os.environ.setdefault("SSDHIP_LIB", os.path.join(HERE, "libssdhip_prof.so"))
 sys.path.insert(0, os.path.dirname(HERE))
 import torch  # noqa: E402
 
