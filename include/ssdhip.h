@@ -288,6 +288,33 @@ int ssdhip_conv2d_nhwc_bf16(const void* x, const void* weight, const void* bias,
  * summation order). */
 int ssdhip_conv2d_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                     int Cin, int Cout, int kernel, int stride, int pad, int dilation, int relu, void* stream);
+/* Split-K form of ssdhip_conv2d_nhwc_bf16 for the layers whose K loop is one workgroup deep -- the SSD extra layers conv6_1 ...
+ * conv9_2 (models/keras_ssd300.py:301-313: 10x10 ... 1x1 maps, a handful of 128-pixel tiles, each walking 4-36 K-steps at one L2
+ * round trip per step): every tile's K loop is cut into `ksplit` ranges (0: chosen so that the launch has about one workgroup per
+ * CU) that run side by side and leave float32 partial tiles in the caller's workspace; a second launch adds the ranges IN ORDER
+ * (one fixed float32 summation order whatever the grid), then bias, activation and one rounding to bf16.  Same arguments and
+ * numerics bar as ssdhip_conv2d_nhwc_bf16 (a different float32 summation order: not bit-identical to it).
+ *   ws: ssdhip_conv2d_splitk_workspace_bytes(same geometry, same ksplit) bytes, 16-byte aligned. */
+/* Reference-precision convolution: the reference's Conv2D layers are float32 (models/keras_ssd300.py:274-335).  A float32 value is the
+ * sum of two float16 numbers to 2^-22 (hi = fl16(v), lo = fl16(v - hi)) and x.w = xhi.whi + xhi.wlo + xlo.whi to the same order, so
+ * the convolution runs as ONE float16 MFMA K loop over 3 C channels with float32 accumulation -- float32-grade results at up to a
+ * third of the 16-bit MFMA rate instead of the 1/16-rate float32 MFMA.
+ *   x      [B,H,W,2C] float16 NHWC: channels [0,C) = hi, [C,2C) = lo of the float32 activation
+ *   weight [Cout,k,k,3C] float16: [w hi | w lo | w hi] of (float32 filter / oscale), oscale a power of two chosen by the caller so that
+ *          the scaled filters sit well inside float16's normal range
+ *   bias   [Cout] float32 or NULL;  y = act(oscale * sum + bias) as float32 [B,Ho,Wo,Cout] (out_f32 != 0) or split again as float16
+ *          [B,Ho,Wo,2 Cout]
+ *   kernel 1 | 3, stride 1..4, 0 <= pad <= (kernel/2) dilation (torch.nn.Conv2d semantics); pool != 0: MaxPooling2D(2, 2, 'same')
+ *   fused (stride 1, pad = (kernel/2) dilation only), y is then [B, ceil(H/2), ceil(W/2), .].  C % 64 == 0, Cout % 64 == 0. */
+int ssdhip_conv2d_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
+                              int kernel, int stride, int pad, int dilation, int relu, int pool, int out_f32, float oscale,
+                              void* stream);
+
+size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,
+                                            int ksplit);
+int ssdhip_conv2d_splitk_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                                   int kernel, int stride, int pad, int dilation, int relu, int ksplit, void* ws, size_t ws_bytes,
+                                   void* stream);
 
 /* Profiling aid: the same with an explicit kernel variant (4: the shipped kernel -- 128-pixel tile, two LDS stages, buffer-addressed
  * LDS-DMA loads, batched fragment reads; 1: its predecessor with per-lane pointers; 3: 256-pixel tile, three-stage weight pipeline,

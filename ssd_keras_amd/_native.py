@@ -543,9 +543,82 @@ def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True, variant=
                 raise SsdHipError("variant 7 is a 3x3, dilation-1 kernel")
             rc = lib.ssdhip_conv3x3_halo_strided_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(stride),
                                                            int(padding), int(bool(relu)), current_stream_ptr(x.device))
+        elif variant == 8:                                   # split-K: K ranges side by side, float32 partial tiles, ordered reduction
+            if not getattr(lib, "_splitk_bound", False):
+                lib.ssdhip_conv2d_splitk_workspace_bytes.restype = ctypes.c_size_t
+                lib.ssdhip_conv2d_splitk_workspace_bytes.argtypes = [ctypes.c_int] * 10
+                lib.ssdhip_conv2d_splitk_nhwc_bf16.restype = ctypes.c_int
+                lib.ssdhip_conv2d_splitk_nhwc_bf16.argtypes = ([ctypes.c_void_p] * 4 + [ctypes.c_int] * 11 +
+                                                              [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])
+                lib._splitk_bound = True
+            geo = (b, h, w, cin, cout, int(kh), int(stride), int(padding), int(dilation))
+            need = lib.ssdhip_conv2d_splitk_workspace_bytes(*geo, 0)
+            if need == 0:
+                raise SsdHipError("ssdhip_conv2d_splitk_nhwc_bf16: unsupported geometry")
+            ws = workspaces.get(x.device, "conv_splitk", need)
+            rc = lib.ssdhip_conv2d_splitk_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), *geo, int(bool(relu)), 0, _ptr(ws),
+                                                    ws.numel(), current_stream_ptr(x.device))
         else:
             rc = lib.ssdhip_conv2d_nhwc_bf16(*args) if variant is None else lib.ssdhip_conv2d_nhwc_bf16_variant(int(variant), *args)
     check(rc, "ssdhip_conv2d_nhwc_bf16")
+    return y
+
+
+def x3_split(v):
+    """float32 (B, C, H, W) in channels_last memory -> float16 (B, 2C, H, W) channels_last = [hi | lo], hi = fl16(v), lo = fl16(v - hi):
+    the activation layout of conv2d_x3."""
+    torch = _torch()
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo], dim=1).contiguous(memory_format=torch.channels_last)
+
+
+def x3_pack_weight(weight):
+    """float32 (Cout, Cin, k, k) filters -> (float16 (Cout, 3 Cin, k, k) channels_last = [w hi | w lo | w hi] of weight * 2^e, oscale =
+    2^-e), e chosen so that the largest scaled filter lies in [256, 512): hi and lo parts stay in float16's normal range."""
+    import math
+    torch = _torch()
+    w = weight.detach().float()
+    m = float(w.abs().max().item())
+    e = 8 - int(math.floor(math.log2(m))) if m > 0 and math.isfinite(m) else 0
+    ws = w * (2.0 ** e)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous(memory_format=torch.channels_last), 2.0 ** -e
+
+
+def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, relu=True, pool=False, out_f32=False):
+    """Reference-precision convolution on the float16 MFMA path (ssdhip_conv2d_x3_nhwc_f16): x2 = x3_split(activation),
+    (packed_weight, oscale) = x3_pack_weight(filters), bias float32 or None.  Returns the split float16 (B, 2 Cout, Ho, Wo) map, or
+    with out_f32 the float32 (B, Cout, Ho, Wo) one (both channels_last)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_x3_bound", False):
+        lib.ssdhip_conv2d_x3_nhwc_f16.restype = ctypes.c_int
+        lib.ssdhip_conv2d_x3_nhwc_f16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 12 + [ctypes.c_float, ctypes.c_void_p]
+        lib._x3_bound = True
+    require_cuda(x2.permute(0, 2, 3, 1), "x2")
+    if x2.dtype != torch.float16 or packed_weight.dtype != torch.float16:
+        raise SsdHipError("conv2d_x3 takes float16 split activations and packed float16 filters")
+    b, c2, h, w = x2.shape
+    cout, c3, kh, kw = packed_weight.shape
+    if c2 % 2 or c3 != 3 * (c2 // 2) or kh != kw or not packed_weight.permute(0, 2, 3, 1).is_contiguous():
+        raise SsdHipError("packed filters must be (Cout, 3 C, k, k) channels_last for a (B, 2 C, H, W) input")
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise SsdHipError("bias must be contiguous float32")
+    span = int(dilation) * (int(kh) - 1) + 1
+    ho, wo = (h + 2 * int(padding) - span) // int(stride) + 1, (w + 2 * int(padding) - span) // int(stride) + 1
+    if pool:
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+    if ho < 1 or wo < 1:
+        raise SsdHipError("convolution output would be empty")
+    y = (torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x2.device) if out_f32 else
+         torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device)).permute(0, 3, 1, 2)
+    with torch.cuda.device(x2.device):
+        rc = lib.ssdhip_conv2d_x3_nhwc_f16(_ptr(x2), _ptr(packed_weight), _ptr(bias), _ptr(y), b, h, w, c2 // 2, cout, int(kh), int(stride),
+                                           int(padding), int(dilation), int(bool(relu)), int(bool(pool)), int(bool(out_f32)),
+                                           ctypes.c_float(float(oscale)), current_stream_ptr(x2.device))
+    check(rc, "ssdhip_conv2d_x3_nhwc_f16")
     return y
 
 

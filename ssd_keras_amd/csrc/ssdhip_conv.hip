@@ -18,6 +18,7 @@
 //   * two LDS buffers, one barrier per K-step: loads of step s+1 are in flight while step s is multiplied.
 //   * blockIdx -> tile map keeps the channel tiles of one pixel tile on the same XCD (shared L2 for X).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "ssdhip.h"
@@ -47,6 +48,14 @@ struct ConvParams {
     int stride, coff, Min;       // v4 only: output pixel (ho, wo) is centred on input pixel (ho*stride + coff, wo*stride + coff),
                                  // coff = (KS/2)*dil - pad >= 0; then Ho x Wo is the output map, M = B*Ho*Wo and Min = B*H*W.
                                  // stride 1, coff 0 is the 'same' convolution (Min == M)
+    int ksplit;                  // split-K form only: K ranges per tile; range ks writes its float32 partial tile to slab[ks]
+    float* slab;                 // [ksplit, M, Cout] float32 partial sums (caller's workspace)
+    // reference-precision form (X3) only: x rows hold xC = 2 C float16 channels [hi | lo], the K loop walks Cin = 3 C channels
+    // [x hi . w hi | x hi . w lo | x lo . w hi]; bias32 is float32; the accumulator is multiplied by oscale (the weights' power-of-two
+    // scale undone) before the bias; out_f32: y is float32 [M, Cout], otherwise float16 [M, 2 Cout] = [hi | lo]
+    int xC, out_f32;
+    const float* bias32;
+    float oscale;
 };
 
 __device__ __forceinline__ u32 f2bf_rn(float f) {
@@ -239,12 +248,32 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // the host pass sees just the kernel stubs.
 #if defined(__HIP_DEVICE_COMPILE__)
 // (the body is a __device__ function: the host pass never sees the buffer-resource type, which only exists for amdgcn)
-template <int BC, bool POOL>
-__device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned char* lds, const int id) {
+// SK: the split-K form for layers whose K loop is one workgroup deep (the SSD extra layers: a handful of tiles, each walking 4-36
+// K-steps at one L2 round trip per step): work item = (tile, K range), the partial tile leaves as float32 to slab[range] and
+// splitk_reduce_kernel adds the ranges in order, then bias + activation + one rounding.
+// X3: the reference-precision form.  The reference's convolutions are float32 (models/keras_ssd300.py:274-335); a float32 value is
+// the sum of two float16 numbers to 2^-22 (hi = fl16(v), lo = fl16(v - hi)), and hi.hi + hi.lo + lo.hi reproduces a product to
+// 2^-22 as well -- three float16 MFMA passes with float32 accumulation instead of the 1/16-rate float32 MFMA.  The three passes are
+// ONE K loop over 3 C channels: slices [0, n) multiply x hi by w hi, [n, 2n) x hi by w lo, [2n, 3n) x lo by w hi (the filters are
+// packed [w hi | w lo | w hi] on the host, x is read through the slice map j -> j < n ? j : j - n).  The epilogue scales, adds the
+// float32 bias, applies the activation on float32 values and splits the result again (or leaves it float32 for the graph glue).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32 x3_split2(float a, float b, u32& lo_out) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+    lo_out = (u32)__builtin_bit_cast(unsigned short, la) | ((u32)__builtin_bit_cast(unsigned short, lb) << 16);
+    return (u32)__builtin_bit_cast(unsigned short, ha) | ((u32)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+template <int BC, bool POOL, bool SK = false, bool X3 = false>
+__device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned char* lds, const int id_) {
     constexpr int CI = BC / 64;
     constexpr int XBYTES = CONV_BP * 128, WBYTES = BC * 128, BUF = XBYTES + WBYTES;
     constexpr unsigned OOB = 0x80000000u;
+    static_assert(!(SK && POOL), "the split-K form has no pooled epilogue");
 
+    const int ks = SK ? id_ % p.ksplit : 0;
+    const int id = SK ? id_ / p.ksplit : id_;
     const int xcd = id & 7, slot = id >> 3;
     const int mt = (slot / p.n_tiles) * 8 + xcd, nt = slot % p.n_tiles;
     if (mt >= p.m_tiles) return;
@@ -257,10 +286,12 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     const int wc = wave >> 1, wp = wave & 1;
     const int Cin = p.Cin, KS = p.KS, KK = KS * KS, half = KS >> 1, dil = p.dil;
     const int csteps = Cin / CONV_BK, T = KK * csteps;
+    const int XC = X3 ? p.xC : Cin;                                       // channels of an x row (X3: 2 C of the loop's 3 C)
+    const int xslices = X3 ? csteps / 3 : csteps;                         // X3: slice j of the loop reads x slice j < n ? j : j - n
 
-    const int neg = (half * dil * p.W + half * dil) * Cin * 2;            // bytes; largest negative tap displacement
+    const int neg = (half * dil * p.W + half * dil) * XC * 2;             // bytes; largest negative tap displacement
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.Min * Cin * 2 + 2 * neg, 0x00020000);
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - neg, 0, p.Min * XC * 2 + 2 * neg, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.w)), 0, p.Cout * KK * Cin * 2, 0x00020000);
 
@@ -288,7 +319,7 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
                 for (int kh = 0; kh < KS; ++kh)
                     if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
             xok[i] = ok;
-            xoff[i] = (u32)((b * p.H + hq) * p.W + wq) * (u32)(Cin * 2) + (u32)(j * 16);
+            xoff[i] = (u32)((b * p.H + hq) * p.W + wq) * (u32)(XC * 2) + (u32)(j * 16);
         }
     } else if constexpr (!POOL) {
         int m = m0 + wave * 8 + (lane >> 3);
@@ -308,7 +339,7 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
                 for (int kh = 0; kh < KS; ++kh)
                     if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
             xok[i] = ok;
-            xoff[i] = (u32)m * (u32)(Cin * 2) + (u32)(j * 16);
+            xoff[i] = (u32)m * (u32)(XC * 2) + (u32)(j * 16);
             m += 32;
             wq += 32;
             while (wq >= p.W) { wq -= p.W; if (++hq == p.H) hq = 0; }
@@ -335,7 +366,7 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
                 for (int kh = 0; kh < KS; ++kh)
                     if ((rmask >> kh) & 1u) ok |= cmask << (kh * KS);
             xok[i] = ok;
-            xoff[i] = (u32)((pb * p.H + hq) * p.W + wq) * (u32)(Cin * 2) + (u32)(j * 16);
+            xoff[i] = (u32)((pb * p.H + hq) * p.W + wq) * (u32)(XC * 2) + (u32)(j * 16);
         }
     }
 #pragma unroll
@@ -346,9 +377,19 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     }
 
     int n_kh = 0, n_kw = 0, n_cs = 0;                  // the step the next issue() loads
+    int s_first = 0, s_end = T;
+    if constexpr (SK) {                                // steps [T ks / ksplit, T (ks + 1) / ksplit); step s = (slice, kh, kw), taps innermost
+        s_first = (int)((long long)T * ks / p.ksplit);
+        s_end = (int)((long long)T * (ks + 1) / p.ksplit);
+        n_cs = s_first / KK;
+        const int t0 = s_first - n_cs * KK;
+        n_kh = t0 / KS;
+        n_kw = t0 - n_kh * KS;
+    }
     auto issue = [&](int buf) {
         const int t = n_kh * KS + n_kw;
-        const int soff_x = neg + (((n_kh - half) * dil * p.W + (n_kw - half) * dil) * Cin + n_cs * CONV_BK) * 2;
+        const int xs = (X3 && n_cs >= xslices) ? n_cs - xslices : n_cs;
+        const int soff_x = neg + (((n_kh - half) * dil * p.W + (n_kw - half) * dil) * XC + xs * CONV_BK) * 2;
         const int soff_w = (t * Cin + n_cs * CONV_BK) * 2;
         const u32 tapbit = 1u << t;
         unsigned char* xb = lds + buf * BUF + wave * 1024;
@@ -384,7 +425,8 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int s = 0; s < T; ++s) {
+    const int TS = s_end - s_first;                    // the steps this work item walks (all of them unless split-K)
+    for (int s = 0; s < TS; ++s) {
         const unsigned char* xb = lds + (s & 1) * BUF;
         const unsigned char* wb = xb + XBYTES;
         bf16x8 a[4][CI], b[4][2];
@@ -396,7 +438,7 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
             for (int pi = 0; pi < 2; ++pi) b[kk][pi] = *reinterpret_cast<const bf16x8*>(xb + brow + pi * 4096 + choff[kk]);
         }
         __builtin_amdgcn_sched_barrier(0);             // the step's 16 fragment reads go out first ...
-        if (s + 1 < T) issue((s + 1) & 1);             // ... their latency hides behind issuing the next step's LDS-DMA loads
+        if (s + 1 < TS) issue((s + 1) & 1);             // ... their latency hides behind issuing the next step's LDS-DMA loads
         __builtin_amdgcn_sched_barrier(0);             // (measured: loads before the reads, or s_setprio around the MFMAs, change nothing)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -404,12 +446,72 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
             for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
                 for (int pi = 0; pi < 2; ++pi)
-                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][ci], b[kk][pi], acc[ci][pi], 0, 0, 0);
+                    if constexpr (X3)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[kk][ci]), __builtin_bit_cast(f16x8, b[kk][pi]),
+                                                                             acc[ci][pi], 0, 0, 0);
+                    else
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][ci], b[kk][pi], acc[ci][pi], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);             // all MFMAs are queued before the wave parks on the loads / the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    if constexpr (X3) {
+        // ---- reference-precision epilogue: float32 values straight from the registers (a lane holds 4 consecutive channels of a
+        //      pixel per accumulator quad); POOL: the 2 x 2 maximum first, on the raw accumulators (scale > 0, the bias is per
+        //      channel and the activation monotonic: the same as pooling the finished values) ----------------------------------------
+        const int q = wp * 32 + r31;
+        int pix[2];
+        bool ok[2];
+        if constexpr (POOL) {
+            const int hq = 2 * (php + (q >> p.cshift)), wq = (pwt << p.cshift) + (q & ((1 << p.cshift) - 1));
+            const bool has_below = hq + 1 < p.H, has_right = wq + 1 < p.W;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float m = acc[ci][0][v];
+                    const float below = acc[ci][1][v];
+                    if (has_below) m = below > m ? below : m;
+                    const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false));
+                    if (has_right) m = right > m ? right : m;
+                    acc[ci][0][v] = m;
+                }
+            const int ho = php + (q >> p.cshift), wo = wq >> 1;
+            pix[0] = (pb * p.Ho + ho) * p.Wo + wo;
+            ok[0] = !(r31 & 1) && ho < p.Ho && wo < p.Wo && hq < p.H && wq < p.W;
+            pix[1] = 0; ok[1] = false;
+        } else {
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) { pix[pi] = m0 + wp * 64 + pi * 32 + r31; ok[pi] = pix[pi] < p.M; }
+        }
+#pragma unroll
+        for (int pi = 0; pi < (POOL ? 1 : 2); ++pi)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[ci][pi][4 * g + e] * p.oscale + (p.bias32 ? p.bias32[ch + e] : 0.f);
+                        if (p.relu) t = t > 0.f ? t : (t != t ? t : 0.f);
+                        v[e] = t;
+                    }
+                    if (!ok[pi]) continue;
+                    if (p.out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (size_t)pix[pi] * p.Cout + ch) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        u32 l0, l1;
+                        const u32 h0 = x3_split2(v[0], v[1], l0), h1 = x3_split2(v[2], v[3], l1);
+                        bf16_t* row = p.y + (size_t)pix[pi] * (2 * p.Cout) + ch;
+                        *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(row + p.Cout) = make_uint2(l0, l1);
+                    }
+                }
+        return;
+    }
     if constexpr (POOL) {
         // ---- pooled epilogue: max over the 2x2 window in registers (vertical: the lane's two accumulator blocks; horizontal:
         //      lane ^ 1 by DPP quad_perm), THEN bias + ReLU + one bf16 rounding -- all three are monotonic, so this equals
@@ -462,6 +564,24 @@ __device__ __forceinline__ void conv_igemm4_body(const ConvParams& p, unsigned c
         }
         return;
     }
+    if constexpr (SK) {
+        // a lane holds 4 consecutive channels of a pixel per accumulator quad: 16-byte float32 stores straight from registers
+        float* out = p.slab + (size_t)ks * (size_t)p.M * (size_t)p.Cout;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int m = m0 + wp * 64 + pi * 32 + r31;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = co0 + wc * (BC / 2) + ci * 32 + 8 * g + 4 * khalf;
+                    if (m < p.M)
+                        *reinterpret_cast<float4*>(out + (size_t)m * p.Cout + ch) =
+                            make_float4(acc[ci][pi][4 * g], acc[ci][pi][4 * g + 1], acc[ci][pi][4 * g + 2], acc[ci][pi][4 * g + 3]);
+                }
+        }
+        return;
+    }
     // ---- epilogue: identical to v1 (LDS transpose, 16-byte stores) --------------------------------------------------
     constexpr int ROWB = 64 * CI;
     unsigned char* stage = lds + wave * (64 * ROWB);
@@ -511,6 +631,50 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_kernel(ConvParams
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
     conv_igemm4_body<BC, false>(p, lds, (int)blockIdx.x);
 #endif
+}
+
+template <int BC, bool POOL>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_x3_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
+    conv_igemm4_body<BC, POOL, false, true>(p, lds, (int)blockIdx.x);
+#endif
+}
+
+template <int BC>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm4_splitk_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (CONV_BP * 128 + BC * 128)];
+    conv_igemm4_body<BC, false, true>(p, lds, (int)blockIdx.x);
+#endif
+}
+
+// y[m, co .. co + 7] = act(bias + slab[0][m, co ..] + slab[1][m, co ..] + ...): the ranges are added in order (one fixed float32
+// summation order whatever the grid), one rounding to bf16.  One thread per 8 channels of a pixel.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const bf16_t* __restrict__ bias,
+                                                            bf16_t* __restrict__ y, int M, int Cout, int ksplit, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n8 = (long long)M * Cout / 8;
+    if (i >= n8) return;
+    const size_t plane = (size_t)M * Cout;
+    float a[8];
+    {
+        const float4 lo = *reinterpret_cast<const float4*>(slab + i * 8), hi = *reinterpret_cast<const float4*>(slab + i * 8 + 4);
+        a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+    }
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 lo = *reinterpret_cast<const float4*>(slab + k * plane + i * 8), hi = *reinterpret_cast<const float4*>(slab + k * plane + i * 8 + 4);
+        a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w; a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+    }
+    const int co = (int)((i * 8) % Cout);
+    u32 o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = a[e] + (bias ? __uint_as_float((u32)bias[co + e] << 16) : 0.f);
+        if (relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+        o[e] = f2bf_rn(v);
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
 }
 
 template <int BC>
@@ -1029,6 +1193,127 @@ static int conv_general_run(int variant, const void* x, const void* weight, cons
     } else {
         if (wide) hipLaunchKernelGGL(conv_igemm4_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
         else hipLaunchKernelGGL(conv_igemm4_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// Split-K form of ssdhip_conv2d_nhwc_bf16 for layers with a handful of tiles (the SSD extra layers conv6_1 ... conv9_2,
+// models/keras_ssd300.py:301-313): `ksplit` K ranges per tile (0: chosen so that the launch has about one workgroup per CU)
+// write float32 partial tiles to the caller's workspace, a second launch adds them in order and applies bias / activation.
+static int splitk_choose(long long tiles, int T) {
+    long long ks = (320 + tiles - 1) / tiles;
+    if (ks > T) ks = T;
+    if (ks > 32) ks = 32;
+    return ks < 1 ? 1 : (int)ks;
+}
+static bool splitk_geometry(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation, long long* M_out, int* T_out,
+                            long long* tiles_out) {
+    if (B <= 0 || H <= 0 || W <= 0 || dilation <= 0 || dilation > 8 || (kernel != 1 && kernel != 3) || stride < 1 || stride > 4) return false;
+    const int reach = (kernel / 2) * dilation;
+    if (pad < 0 || pad > reach || Cin <= 0 || (Cin % CONV_BK) || Cout <= 0 || (Cout % 64)) return false;
+    if (H + 2 * pad - 2 * reach < 1 || W + 2 * pad - 2 * reach < 1) return false;
+    const int Ho = (H + 2 * pad - 2 * reach - 1) / stride + 1, Wo = (W + 2 * pad - 2 * reach - 1) / stride + 1;
+    *M_out = (long long)B * Ho * Wo;
+    *T_out = kernel * kernel * (Cin / CONV_BK);
+    *tiles_out = ((*M_out + CONV_BP - 1) / CONV_BP) * (Cout / ((Cout % 128) == 0 ? 128 : 64));
+    return true;
+}
+
+extern "C" size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,
+                                                       int ksplit) {
+    long long M, tiles;
+    int T;
+    if (!splitk_geometry(B, H, W, Cin, Cout, kernel, stride, pad, dilation, &M, &T, &tiles)) return 0;
+    if (ksplit <= 0) ksplit = splitk_choose(tiles, T);
+    if (ksplit > T) ksplit = T;
+    return (size_t)ksplit * (size_t)M * (size_t)Cout * sizeof(float);
+}
+
+extern "C" int ssdhip_conv2d_splitk_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                                              int Cout, int kernel, int stride, int pad, int dilation, int relu, int ksplit, void* ws,
+                                              size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    long long M, tiles;
+    int T;
+    if (!x || !weight || !y || !ws || !splitk_geometry(B, H, W, Cin, Cout, kernel, stride, pad, dilation, &M, &T, &tiles)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)ws) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    const int reach = (kernel / 2) * dilation;
+    const long long Min = (long long)B * H * W;
+    if (Min * Cin * 2 + 4LL * (dilation * W + dilation) * Cin >= 0x7ffff000LL || (long long)Cout * kernel * kernel * Cin * 2 >= 0x7ffff000LL ||
+        M * Cout > 0x7fffffff0LL)
+        return SSDHIP_E_BADARG;                // buffer addressing: 31-bit byte offsets
+    if (ksplit <= 0) ksplit = splitk_choose(tiles, T);
+    if (ksplit > T) ksplit = T;
+    if (ws_bytes < (size_t)ksplit * (size_t)M * (size_t)Cout * sizeof(float)) return SSDHIP_E_WORKSPACE;
+    ConvParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
+    p.y = nullptr;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = 0;
+    p.M = (int)M; p.Min = (int)Min;
+    p.Ho = (H + 2 * pad - 2 * reach - 1) / stride + 1; p.Wo = (W + 2 * pad - 2 * reach - 1) / stride + 1; p.WT = p.HT = p.cshift = 0;
+    p.stride = stride; p.coff = reach - pad;
+    p.ksplit = ksplit; p.slab = static_cast<float*>(ws);
+    const bool wide = (Cout % 128) == 0;
+    p.n_tiles = Cout / (wide ? 128 : 64);
+    p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+    const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8 * ksplit;
+    if (wide) hipLaunchKernelGGL(conv_igemm4_splitk_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_igemm4_splitk_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    const long long n8 = M * Cout / 8;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, p.slab, static_cast<const bf16_t*>(bias),
+                       static_cast<bf16_t*>(y), (int)M, Cout, ksplit, relu ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// Reference-precision convolution (see conv_igemm4_body, X3): x [B,H,W,2C] float16 = [hi | lo], weight [Cout,k,k,3C] float16 =
+// [w hi | w lo | w hi] of the float32 filters times a power of two 1/oscale, bias float32 [Cout] or NULL; y float32 [B,Ho,Wo,Cout]
+// (out_f32) or float16 [B,Ho,Wo,2 Cout] = [hi | lo].  pool != 0: MaxPooling2D(2, 2, 'same') fused (stride 1, pad = reach only).
+extern "C" int ssdhip_conv2d_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
+                                         int kernel, int stride, int pad, int dilation, int relu, int pool, int out_f32, float oscale,
+                                         void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || dilation <= 0 || dilation > 8) return SSDHIP_E_BADARG;
+    if ((kernel != 1 && kernel != 3) || stride < 1 || stride > 4 || !(oscale > 0.f)) return SSDHIP_E_BADARG;
+    const int reach = (kernel / 2) * dilation;
+    if (pad < 0 || pad > reach || C <= 0 || (C % CONV_BK) || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
+    if (pool && (stride != 1 || pad != reach)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 3)) return SSDHIP_E_BADARG;
+    if (H + 2 * pad - 2 * reach < 1 || W + 2 * pad - 2 * reach < 1) return SSDHIP_E_BADARG;
+    const int Ho = (H + 2 * pad - 2 * reach - 1) / stride + 1, Wo = (W + 2 * pad - 2 * reach - 1) / stride + 1;
+    const long long Min = (long long)B * H * W, M = (long long)B * Ho * Wo;
+    if (Min * 2 * C * 2 + 4LL * (dilation * W + dilation) * 2 * C >= 0x7ffff000LL || (long long)Cout * kernel * kernel * 3 * C * 2 >= 0x7ffff000LL ||
+        M * Cout > 0x3fffffff0LL)
+        return SSDHIP_E_BADARG;                // buffer addressing: 31-bit byte offsets
+    ConvParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = 3 * C; p.Cout = Cout; p.KS = kernel; p.dil = dilation; p.relu = relu ? 1 : 0;
+    p.M = (int)M; p.Min = (int)Min;
+    p.Ho = Ho; p.Wo = Wo; p.WT = p.HT = p.cshift = 0;
+    p.stride = stride; p.coff = reach - pad;
+    p.ksplit = 1; p.slab = nullptr;
+    p.xC = 2 * C; p.out_f32 = out_f32 ? 1 : 0; p.bias32 = bias; p.oscale = oscale;
+    const bool wide = (Cout % 128) == 0;
+    p.n_tiles = Cout / (wide ? 128 : 64);
+    if (pool) {
+        p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+        long long best = -1;                  // tile shape (64 >> cs row pairs x 1 << cs columns) with the smallest padded area
+        for (int cs = 6; cs >= 1; --cs) {
+            const long long wt = (W + (1 << cs) - 1) >> cs, ht = (p.Ho + (64 >> cs) - 1) / (64 >> cs);
+            if (best < 0 || wt * ht < best) { best = wt * ht; p.cshift = cs; p.WT = (int)wt; p.HT = (int)ht; }
+        }
+        const long long mt = (long long)B * p.HT * p.WT;
+        if (mt > 0x3fffffffLL / p.n_tiles) return SSDHIP_E_BADARG;
+        p.m_tiles = (int)mt;
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (wide) hipLaunchKernelGGL((conv_igemm4_x3_kernel<128, true>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm4_x3_kernel<64, true>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+    } else {
+        p.m_tiles = (int)((M + CONV_BP - 1) / CONV_BP);
+        const int grid = ((p.m_tiles + 7) / 8) * p.n_tiles * 8;
+        if (wide) hipLaunchKernelGGL((conv_igemm4_x3_kernel<128, false>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm4_x3_kernel<64, false>), dim3(grid), dim3(CONV_THREADS), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

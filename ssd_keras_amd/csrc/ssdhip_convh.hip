@@ -721,7 +721,9 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     // Schedules: 128 = persistent workgroups, one per CU, that request the next tile's first slab and weights during the last slice
     // of the current tile; 1152 = the same with the tolerant waits after an epilogue.  SSDHIP_CONVH_MODE selects.  (The round-2
     // schedule with one workgroup per tile is gone: it bought nothing over 128 and its <3, 7> variant spilled registers.)
-    int mode = 128;
+    // r03i / r03j / r03k A/Bs: the tolerant waits are worth 5-7 % on the pooled tiles (2 stores per wave and tile: the whole burst fits
+    // the tolerance) and nothing measurable on the plain ones
+    int mode = pool ? 1152 : 128;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     switch (mode) {
         case 1152: convh_launch<1152>(p, geom, pool, cu_count, stream); break;                             // 128 + 1024: the first waits after an epilogue let its stores stay in flight

@@ -11,7 +11,7 @@
 //                     log loss (only where y_true != 0), smooth L1, positive / negative weights; writes cls_loss[B,N], neg_all[B,N] and the tile's four partial sums (float64).
 //                     No atomics anywhere in the sums: L2b and L4 add the partials in a fixed order, so the loss is
 //                     bit-reproducible from run to run.
-//   L2 sel_pass*      k, then a radix select (11+11+10 bits of the order-preserving float key) for the k-th largest negative
+//   L2 sel_pass*      k, then a radix select (8+12+12 bits of the order-preserving float key) for the k-th largest negative
 //                     loss: level 1's histogram comes out of L1 itself; two chip-wide passes over neg_all build levels 2 and 3,
 //                     each finding the previous level's digit redundantly in every block.  No single-workgroup step, no list.
 //   L3 keep_kernel    the last digit and -- only if ties straddle the cut -- the flat-index limit (from per-block level-3
@@ -30,16 +30,17 @@ namespace ssdhip {
 
 constexpr int LOSS_THREADS = 256;
 constexpr int KEEP_BLOCKS = 64;
-constexpr int SEL_BINS = 2048;
+constexpr int L1_BINS = 256, L1_SHARDS = 8;         // level 1: the top 8 key bits, counted by L1 itself into 8 global copies (block & 7)
+constexpr int SEL_BINS = 4096;                      // levels 2 and 3: 12 bits each
 constexpr int SELP_THREADS = 256;                   // a select pass block: 256 threads x 8 values = SELP_CHUNK consecutive flat indices
 constexpr int SELP_ITEMS = 8;
 constexpr int SELP_CHUNK = SELP_THREADS * SELP_ITEMS;
 
 struct LossWs {
     size_t sums, hist, sel, cls, neg, part, keep_part, bcol, total;
-    // sums: per-image positive class loss [B] | loc loss [B] | (unused [B]) | n_pos; hist: the three levels' bins [3][SEL_BINS] (zeroed
-    // per call); sel: select state; part: L1's per-tile partial sums [4][B][tiles]; keep_part: L3's [B][KEEP_BLOCKS];
-    // bcol: level-3 bin counts per pass block [nblk][1024] u16 (where among the ties the cut falls)
+    // sums: per-image positive class loss [B] | loc loss [B] | (unused [B]) | n_pos; hist: level 1's bins [L1_SHARDS][L1_BINS], then
+    // levels 2 and 3 [2][SEL_BINS] (zeroed per call); sel: select state; part: L1's per-tile partial sums [4][B][tiles];
+    // keep_part: L3's [B][KEEP_BLOCKS]; bcol: level-3 bin counts per pass block [nblk][SEL_BINS] u16 (where among the ties the cut falls)
     int tiles, nblk;
 };
 
@@ -50,9 +51,9 @@ struct SelectResult {
     int n_neg_losses;
     float n_pos;
     float thresh;
-    int digit;                    // level 1: top 11 key bits of the threshold
+    int digit;                    // level 1: top 8 key bits of the threshold
     int want;                     //          how many of that digit's values are kept
-    int digit2, want2;            // level 2: the next 11 bits, how many of the 22-bit prefix's values are kept
+    int digit2, want2;            // level 2: the next 12 bits, how many of the 20-bit prefix's values are kept
 };
 
 static inline size_t lalign(size_t v) { return (v + 255) / 256 * 256; }
@@ -73,14 +74,14 @@ static LossWs loss_ws_layout(int B, int N, int C) {
     w.tiles = (N + TA - 1) / TA;
     w.nblk = (int)(((long long)B * N + SELP_CHUNK - 1) / SELP_CHUNK);
     size_t o = 0;
-    w.hist = o;   o = lalign(o + 3 * SEL_BINS * sizeof(u32));            // first: one memset covers it
+    w.hist = o;   o = lalign(o + (L1_SHARDS * L1_BINS + 2 * SEL_BINS) * sizeof(u32));   // first: one memset covers it
     w.sums = o;   o = lalign(o + (size_t)(3 * B + 1) * sizeof(double));
     w.sel = o;    o = lalign(o + sizeof(SelectResult));
     w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.neg = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.part = o;   o = lalign(o + (size_t)4 * B * w.tiles * sizeof(double));
     w.keep_part = o; o = lalign(o + (size_t)B * KEEP_BLOCKS * sizeof(double));
-    w.bcol = o;   o = lalign(o + (size_t)w.nblk * 1024 * sizeof(unsigned short));
+    w.bcol = o;   o = lalign(o + (size_t)w.nblk * SEL_BINS * sizeof(unsigned short));
     w.total = o;
     return w;
 }
@@ -92,11 +93,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // hist[bin] += 1 for every active lane, with the lanes of a wave that share a bin combined into one LDS atomic: mined losses
 // cluster (every clipped loss is -log(1e-15); a saturated background scores the same few values), and 64 lanes on one LDS
-// address serialise.  Up to four rounds of "everybody who shares the first remaining lane's bin", then plain atomics.
+// address serialise.  Up to two rounds of "everybody who shares the first remaining lane's bin", then plain atomics.
 __device__ __forceinline__ void hist_add_aggregated(u32* hist, u32 bin, bool active) {
     u64 todo = __ballot(active);
 #pragma unroll 1
-    for (int round = 0; round < 4 && todo; ++round) {
+    for (int round = 0; round < 2 && todo; ++round) {
         const int leader = (int)__builtin_ctzll(todo);
         const u32 b0 = (u32)__shfl((int)bin, leader);
         const u64 same = __ballot(active && bin == b0) & todo;
@@ -115,14 +116,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
                                                               u32* __restrict__ ghist1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4][LOSS_THREADS / 64];
-    __shared__ u32 hist[SEL_BINS];                                      // level 1 of the hard-negative select: top 11 key bits of neg_all
+    __shared__ u32 hist[L1_BINS];                                       // level 1 of the hard-negative select: top 8 key bits of neg_all
     const int TA = blockDim.x, L = C + 12;
     const int b = blockIdx.y, a0 = blockIdx.x * TA, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int na = min(TA, N - a0);
     const size_t off = ((size_t)b * N + a0) * (size_t)L;
     float* lds = reinterpret_cast<float*>(smem_raw);
     const size_t half = ((size_t)TA * L + 4 + 3) / 4 * 4;
-    for (int i = tid; i < SEL_BINS; i += TA) hist[i] = 0u;
+    for (int i = tid; i < L1_BINS; i += TA) hist[i] = 0u;
     const float* yt = tile_copy_f32(lds, y_true + off, na * L, tid, TA);
     const float* yp = tile_copy_f32(lds + half, y_pred + off, na * L, tid, TA);
     __syncthreads();
@@ -152,16 +153,17 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
         s_loc = (double)(loc * pos);
         s_npos = (double)pos;
         nonzero = neg != 0.f;
-        bin = float_key(neg) >> 21;
+        bin = float_key(neg) >> 24;
     }
     hist_add_aggregated(hist, bin, tid < na);
     s_poscls = wave_sum(s_poscls); s_loc = wave_sum(s_loc); s_npos = wave_sum(s_npos);
     const double s_nz = wave_sum((double)nonzero);
     if (lane == 0) { red[0][wave] = s_poscls; red[1][wave] = s_loc; red[2][wave] = s_npos; red[3][wave] = s_nz; }
     __syncthreads();
-    for (int i = tid; i < SEL_BINS; i += TA) {                          // integer atomics: the order does not show in the result
+    u32* gshard = ghist1 + ((blockIdx.x + blockIdx.y) & (L1_SHARDS - 1)) * L1_BINS;     // 8 copies: an eighth of the contention on a hot bin
+    for (int i = tid; i < L1_BINS; i += TA) {                           // integer atomics: the order does not show in the result
         const u32 c = hist[i];
-        if (c) atomicAdd(&ghist1[i], c);
+        if (c) atomicAdd(&gshard[i], c);
     }
     if (tid == 0) {                                                     // per-tile partial sums, reduced in a fixed order by L2
         double a = 0, l = 0, n = 0, z = 0;
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void anchor_kernel(const float* __res
 }
 
 // ======================================================================================
-// L2: k and the k-th largest negative loss by a three-level radix select (11 + 11 + 10 bits of the order-preserving float key).
+// L2: k and the k-th largest negative loss by a three-level radix select (8 + 12 + 12 bits of the order-preserving float key).
 // Every level is a CHIP-WIDE histogram pass over neg_all (1.1 MB at SSD300 / batch 32: L2-resident); the digit of level l is found
-// from level l's bins by EVERY block of the next pass (a 2048-bin suffix scan: cheaper than a launch of its own).  Nothing runs on
+// from level l's bins by EVERY block of the next pass (a suffix scan over the bins: cheaper than a launch of its own).  Nothing runs on
 // one workgroup, and nothing depends on how the values are distributed: when every mined loss ties (random-init predictions: all
 // clipped at -log(1e-15)), the first two generations' single-workgroup finish over a 279 k-entry list took 0.28 ms.
 // Ties straddling the cut ("the lowest flat indices win", tf.nn.top_k) are resolved from the per-block level-3 bin counts the
@@ -197,7 +199,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot, int& t
 }
 
 // L2a: k (:166-177) + the level-1 digit (every block), per-image sums and the select state (block 0); level-2 histogram of the
-// values whose top 11 bits equal that digit
+// values whose top 8 bits equal that digit
 __global__ __launch_bounds__(SELP_THREADS) void sel_pass2_kernel(const float* __restrict__ neg_all, int total, u32* __restrict__ ghist,
                                                                  int neg_pos_ratio, int n_neg_min, const double* __restrict__ part,
                                                                  int tiles, double* __restrict__ sums, int B,
@@ -208,20 +210,39 @@ __global__ __launch_bounds__(SELP_THREADS) void sel_pass2_kernel(const float* __
     __shared__ double tot[2][SELP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t plane = (size_t)B * tiles;
-    if (blockIdx.x == 0) {
-        // L1's per-tile partial sums -> per-image sums (one wave each): fixed order, no atomics
-        for (int job = wave; job < 2 * B; job += SELP_THREADS / 64) {    // job = q * B + b, q = 0 positive class loss, 1 loc loss
-            double v = 0.0;
-            for (int t = lane; t < tiles; t += 64) v += part[(size_t)job * tiles + t];
-            v = wave_sum(v);
-            if (lane == 0) sums[job] = v;
+    // L1's per-tile partial sums -> per-image sums, one wave each: fixed order, no atomics.  Spread over the blocks (a job is one
+    // dependent memory round trip: all 2 B of them on one block's four waves were 16 us of this kernel).
+    for (int job = blockIdx.x * (SELP_THREADS / 64) + wave; job < 2 * B; job += gridDim.x * (SELP_THREADS / 64)) {   // job = q * B + b, q = 0 positive class loss, 1 loc loss
+        double v = 0.0;
+        for (int t = lane; t < tiles; t += 64) v += part[(size_t)job * tiles + t];
+        v = wave_sum(v);
+        if (lane == 0) sums[job] = v;
+    }
+    // n_pos and the number of non-zero negative losses: the same order in every block, identical k everywhere.  Four loads per
+    // plane in flight per trip (a plain accumulate loop waits for one memory round trip per element).
+    double np_ = 0.0, nz_ = 0.0;
+    {
+        const double* pn = part + 2 * plane;
+        const double* pz = part + 3 * plane;
+        for (size_t i0 = tid; i0 < plane; i0 += 4 * SELP_THREADS) {
+            double a[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + (size_t)u * SELP_THREADS;
+                a[u] = i < plane ? pn[i] : 0.0;
+                z[u] = i < plane ? pz[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { np_ += a[u]; nz_ += z[u]; }
         }
     }
-    double np_ = 0.0, nz_ = 0.0;                                        // the same order in every block: identical k everywhere
-    for (size_t i = tid; i < plane; i += SELP_THREADS) { np_ += part[2 * plane + i]; nz_ += part[3 * plane + i]; }
+    u32 l1 = 0;                                                         // level 1: this thread's bin, summed over the 8 copies
+#pragma unroll
+    for (int sh = 0; sh < L1_SHARDS; ++sh) l1 += ghist[sh * L1_BINS + tid];
+    static_assert(L1_BINS == SELP_THREADS, "one level-1 bin per thread");
+    hist[tid] = l1;
     np_ = wave_sum(np_); nz_ = wave_sum(nz_);
     if (lane == 0) { tot[0][wave] = np_; tot[1][wave] = nz_; }
-    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = ghist[i];
     __syncthreads();
     np_ = 0.0; nz_ = 0.0;
     for (int w = 0; w < SELP_THREADS / 64; ++w) { np_ += tot[0][w]; nz_ += tot[1][w]; }
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(SELP_THREADS) void sel_pass2_kernel(const float* __
     int k = neg_pos_ratio * (int)n_pos;                                  // tf.to_int32(n_positive) truncates (:166)
     k = k > n_neg_min ? k : n_neg_min;
     k = k < n_neg_losses ? k : n_neg_losses;
-    if (k > 0) block_find_digit<SEL_BINS / SELP_THREADS>(hist, k, wave_cnt, sh_out);
+    if (k > 0) block_find_digit<L1_BINS / SELP_THREADS>(hist, k, wave_cnt, sh_out);
     const int digit = k > 0 ? sh_out[0] : 0, want = k > 0 ? k - sh_out[1] : 0;
     if (blockIdx.x == 0 && tid == 0) {
         sums[3 * B] = np_;
@@ -244,22 +265,25 @@ __global__ __launch_bounds__(SELP_THREADS) void sel_pass2_kernel(const float* __
     for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = 0u;
     __syncthreads();
     const int i0 = blockIdx.x * SELP_CHUNK + tid;
+    u32 keys[SELP_ITEMS];
 #pragma unroll
-    for (int j = 0; j < SELP_ITEMS; ++j) {
+    for (int j = 0; j < SELP_ITEMS; ++j) {                               // all eight loads in flight together
         const int i = i0 + j * SELP_THREADS;
-        const u32 key = i < total ? float_key(neg_all[i]) : 0u;
-        hist_add_aggregated(hist, (key >> 10) & 0x7ffu, i < total && (key >> 21) == (u32)digit);
+        keys[j] = i < total ? float_key(neg_all[i]) : 0u;
     }
+#pragma unroll
+    for (int j = 0; j < SELP_ITEMS; ++j)
+        hist_add_aggregated(hist, (keys[j] >> 12) & 0xfffu, i0 + j * SELP_THREADS < total && (keys[j] >> 24) == (u32)digit);
     __syncthreads();
-    u32* g2 = ghist + SEL_BINS;
+    u32* g2 = ghist + L1_SHARDS * L1_BINS;
     for (int i = tid; i < SEL_BINS; i += SELP_THREADS) {
         const u32 c = hist[i];
         if (c) atomicAdd(&g2[i], c);
     }
 }
 
-// L2b: the level-2 digit (every block); level-3 histogram (the last 10 bits) of the values with that 22-bit prefix, to the global bins
-// and, per block, to bcol[block][1024]
+// L2b: the level-2 digit (every block); level-3 histogram (the last 12 bits) of the values with that 20-bit prefix, to the global bins
+// and, per block, to bcol[block][SEL_BINS]
 __global__ __launch_bounds__(SELP_THREADS) void sel_pass3_kernel(const float* __restrict__ neg_all, int total, u32* __restrict__ ghist,
                                                                  SelectResult* __restrict__ res, unsigned short* __restrict__ bcol) {
     __shared__ u32 hist[SEL_BINS];
@@ -268,29 +292,32 @@ __global__ __launch_bounds__(SELP_THREADS) void sel_pass3_kernel(const float* __
     const int tid = threadIdx.x;
     const int k = res->k;
     if (k <= 0) return;
-    const u32* g2 = ghist + SEL_BINS;
+    const u32* g2 = ghist + L1_SHARDS * L1_BINS;
+    const int i0 = blockIdx.x * SELP_CHUNK + tid;
+    u32 keys[SELP_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SELP_ITEMS; ++j) {                               // requested before the digit search: both latencies overlap
+        const int i = i0 + j * SELP_THREADS;
+        keys[j] = i < total ? float_key(neg_all[i]) : 0u;
+    }
     for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = g2[i];
     __syncthreads();
     const int want1 = res->want;
     block_find_digit<SEL_BINS / SELP_THREADS>(hist, want1, wave_cnt, sh_out);
     const int digit2 = sh_out[0], want2 = want1 - sh_out[1];
-    const u32 prefix22 = ((u32)res->digit << 11) | (u32)digit2;          // key >> 10
+    const u32 prefix20 = ((u32)res->digit << 12) | (u32)digit2;          // key >> 12
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0) { res->digit2 = digit2; res->want2 = want2; }
-    for (int i = tid; i < 1024; i += SELP_THREADS) hist[i] = 0u;
+    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) hist[i] = 0u;
     __syncthreads();
-    const int i0 = blockIdx.x * SELP_CHUNK + tid;
 #pragma unroll
-    for (int j = 0; j < SELP_ITEMS; ++j) {
-        const int i = i0 + j * SELP_THREADS;
-        const u32 key = i < total ? float_key(neg_all[i]) : 0u;
-        hist_add_aggregated(hist, key & 0x3ffu, i < total && (key >> 10) == prefix22);
-    }
+    for (int j = 0; j < SELP_ITEMS; ++j)
+        hist_add_aggregated(hist, keys[j] & 0xfffu, i0 + j * SELP_THREADS < total && (keys[j] >> 12) == prefix20);
     __syncthreads();
-    u32* g3 = ghist + 2 * SEL_BINS;
-    for (int i = tid; i < 1024; i += SELP_THREADS) {
+    u32* g3 = ghist + L1_SHARDS * L1_BINS + SEL_BINS;
+    for (int i = tid; i < SEL_BINS; i += SELP_THREADS) {
         const u32 c = hist[i];
-        bcol[(size_t)blockIdx.x * 1024 + i] = (unsigned short)c;         // <= SELP_CHUNK = 2048
+        bcol[(size_t)blockIdx.x * SEL_BINS + i] = (unsigned short)c;     // <= SELP_CHUNK = 2048
         if (c) atomicAdd(&g3[i], c);
     }
 }
@@ -306,7 +333,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restr
                                                             float* __restrict__ stats, unsigned char* __restrict__ keep,
                                                             double* __restrict__ keep_part) {
     __shared__ double red[LOSS_THREADS / 64];
-    __shared__ u32 hist[1024];
+    __shared__ u32 hist[SEL_BINS];
     __shared__ int sh_out[2];
     __shared__ int wave_cnt[LOSS_THREADS / 64];
     __shared__ int sh_found[2];
@@ -315,20 +342,20 @@ __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restr
     u32 tk = 0;
     int tie_limit = 0x7fffffff;
     if (k > 0) {
-        const u32* g3 = ghist + 2 * SEL_BINS;
-        for (int i = tid; i < 1024; i += LOSS_THREADS) hist[i] = g3[i];
+        const u32* g3 = ghist + L1_SHARDS * L1_BINS + SEL_BINS;
+        for (int i = tid; i < SEL_BINS; i += LOSS_THREADS) hist[i] = g3[i];
         __syncthreads();
         const int want2 = res->want2;
-        block_find_digit<1024 / LOSS_THREADS>(hist, want2, wave_cnt, sh_out);
+        block_find_digit<SEL_BINS / LOSS_THREADS>(hist, want2, wave_cnt, sh_out);
         const int digit3 = sh_out[0], want3 = want2 - sh_out[1];         // want3 of the values equal to the threshold are kept
         const int eq_total = (int)hist[digit3];
-        tk = ((u32)res->digit << 21) | ((u32)res->digit2 << 10) | (u32)digit3;
+        tk = ((u32)res->digit << 24) | ((u32)res->digit2 << 12) | (u32)digit3;
         if (want3 < eq_total) {                                          // the lowest flat indices among the ties win
             // the pass block that holds the want3-th tie ...
             int before = 0, jstar = -1, rank = 0;
             for (int j0 = 0; j0 < nblk && jstar < 0; j0 += LOSS_THREADS) {
                 const int j = j0 + tid;
-                const int c = j < nblk ? (int)bcol[(size_t)j * 1024 + digit3] : 0;
+                const int c = j < nblk ? (int)bcol[(size_t)j * SEL_BINS + digit3] : 0;
                 int tot;
                 const int excl = block_exclusive_scan(c, wave_cnt, tot);
                 if (tid == 0) sh_found[0] = -1;
@@ -462,7 +489,7 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     double* part = reinterpret_cast<double*>(base + lay.part);
     double* keep_part = reinterpret_cast<double*>(base + lay.keep_part);
     unsigned short* bcol = reinterpret_cast<unsigned short*>(base + lay.bcol);
-    if (hipMemsetAsync(ghist, 0, 3 * SEL_BINS * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins (sums are plain stores)
+    if (hipMemsetAsync(ghist, 0, (L1_SHARDS * L1_BINS + 2 * SEL_BINS) * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins (sums are plain stores)
 
     const int L = C + 12;
     const int TA = loss_tile(L);
@@ -476,7 +503,9 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     hipLaunchKernelGGL(sel_pass3_kernel, dim3(lay.nblk), dim3(SELP_THREADS), 0, stream, neg, total, ghist, sel, bcol);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    int gx = (N + LOSS_THREADS - 1) / LOSS_THREADS;
+    // every keep block repeats the last digit search: a few fat blocks per image (about a chip's worth in all), not one per 256 anchors
+    int gx = (N + 4 * LOSS_THREADS - 1) / (4 * LOSS_THREADS);
+    while (gx > 1 && gx * B > 512) --gx;
     if (gx > KEEP_BLOCKS) gx = KEEP_BLOCKS;
     hipLaunchKernelGGL(keep_kernel, dim3(gx, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, ghist, lay.nblk, bcol, sel, stats, keep_mask,
                        keep_part);

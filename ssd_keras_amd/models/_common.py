@@ -273,6 +273,9 @@ class SSDModel(nn.Module):
         mode = os.environ.get("SSDHIP_CONV", "auto")
         if mode in candidates:
             return mode
+        prefer = os.environ.get("SSDHIP_PREFER")              # A/B aid: this candidate wherever it is offered, the autotune elsewhere
+        if prefer and prefer in candidates:
+            return prefer
         if mode == "igemm" and "igemm" not in candidates:
             return "miopen"
         hit = SSDModel._conv_choice.get(key)
@@ -328,6 +331,9 @@ class SSDModel(nn.Module):
                 cands["igemm6"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=6)
                 if x.shape[0] * x.shape[2] * x.shape[3] <= 128 * 128:          # at most one workgroup per CU: the deepest ring too
                     cands["igemm5"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=5)
+                    # ... and the split-K form: the K ranges of a tile side by side on otherwise idle CUs
+                    cands["splitk"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=1, padding=conv.padding[0],
+                                                         dilation=conv.dilation[0], relu=relu, variant=8)
                 if conv.in_channels == 64 and k == 3 and conv.dilation[0] == 1:
                     cands["c64"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=relu, pool=False)
                 if self._halo_ok(conv, x):
@@ -335,7 +341,7 @@ class SSDModel(nn.Module):
             elif self._igemm_general_ok(conv, x):
                 # the extra layers: small maps, one workgroup per CU at most -- the deeper LDS rings (loads three / two steps ahead)
                 # hide the L2 latency that the two-stage kernel exposes on every K-step
-                for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6)):
+                for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6), ("splitk", 8)):
                     cands[nm] = lambda v=v: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                        dilation=conv.dilation[0], relu=relu, variant=v)
                 if (self._halo_ok(conv, x) and conv.stride[0] in (1, 2) and conv.padding[0] in (0, 1) and x.shape[3] <= 94

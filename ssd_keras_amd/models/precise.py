@@ -1,0 +1,142 @@
+"""The SSD300 / SSD512 forward pass at the REFERENCE's precision on the MFMA path.
+
+The reference's graph is float32 end to end (models/keras_ssd300.py:274-419).  The benchmarked backbone is bf16; MIOpen's float32
+convolutions are bound by the 157 TFLOP/s float32 matrix rate.  `PreciseForward` runs the same float32 model through
+`ssdhip_conv2d_x3_nhwc_f16` (csrc/ssdhip_conv.hip, X3): every activation and filter is carried as a float16 (hi, lo) pair -- a float32
+value to 2^-22 -- and a convolution is hi.hi + hi.lo + lo.hi in one float16 MFMA K loop with float32 accumulation, float32 bias and
+activation, and a re-split in the epilogue.  The graph glue that is not a convolution (the Lambda input pipeline, conv1_1 with its
+three input channels, pool4 / pool5, L2Normalization, Reshape / Concatenate / softmax / AnchorBoxes) stays float32 PyTorch.
+
+    model = ssd_300(...).cuda().to(memory_format=torch.channels_last).eval()        # float32 weights
+    y_pred = PreciseForward(model)(images)                                          # (B, 8732, n_classes + 12) float32
+
+Filters are re-packed when a parameter changes (version / storage check per call).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _native as nat
+
+
+class PreciseForward:
+    def __init__(self, model):
+        if not hasattr(model, "_vgg") or not hasattr(model, "extra_features"):
+            raise TypeError("PreciseForward mirrors the VGG-based builders (ssd_300 / ssd_512)")
+        if next(model.parameters()).dtype != torch.float32:
+            raise TypeError("PreciseForward takes the float32 model (the reference's precision)")
+        self.model = model
+        self._packed = {}
+
+    # -- filters ------------------------------------------------------------------------------------------------------------------
+    def _pack(self, key, tensors, build):
+        sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, build())
+            self._packed[key] = hit
+        return hit[1]
+
+    def _conv_filters(self, conv):
+        def build():
+            w, oscale = nat.x3_pack_weight(conv.weight)
+            return w, oscale, conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        return self._pack(id(conv), [conv.weight] + ([conv.bias] if conv.bias is not None else []), build)
+
+    def _head_filters(self, l):
+        """conf and loc filters of predictor layer l packed along Cout, zero rows up to a multiple of 64 (one launch per source map)."""
+        ch, lh = self.model.conf_heads[l], self.model.loc_heads[l]
+
+        def build():
+            n = ch.out_channels + lh.out_channels
+            pad = (-n) % 64
+            w = torch.cat([ch.weight, lh.weight] + ([ch.weight.new_zeros((pad,) + tuple(ch.weight.shape[1:]))] if pad else []), dim=0)
+            b = torch.cat([ch.bias, lh.bias] + ([ch.bias.new_zeros((pad,))] if pad else []), dim=0).float().contiguous()
+            pw, oscale = nat.x3_pack_weight(w)
+            return pw, oscale, b
+        return self._pack(("head", l), [ch.weight, lh.weight, ch.bias, lh.bias], build)
+
+    # -- layers -------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _supported(conv):
+        k = conv.kernel_size[0]
+        return (k in (1, 3) and conv.kernel_size[1] == k and conv.stride[0] == conv.stride[1] and 1 <= conv.stride[0] <= 4
+                and conv.groups == 1 and conv.dilation[0] == conv.dilation[1] and isinstance(conv.padding, tuple)
+                and conv.padding[0] == conv.padding[1] and 0 <= conv.padding[0] <= conv.dilation[0] * (k // 2)
+                and conv.padding_mode == 'zeros' and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+
+    def conv(self, conv, x2, relu=True, pool=False, out_f32=False):
+        if not self._supported(conv):
+            # a layer the kernel does not cover (SSD512's 4x4 conv10_2): the float32 framework convolution on the merged activation
+            c = x2.shape[1] // 2
+            y = F.conv2d(x2[:, :c].float() + x2[:, c:].float(), conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+            y = torch.relu(y) if relu else y
+            if pool:
+                y = F.max_pool2d(y, 2, 2, ceil_mode=True)
+            y = y.contiguous(memory_format=torch.channels_last)
+            return y if out_f32 else nat.x3_split(y)
+        w, oscale, b = self._conv_filters(conv)
+        return nat.conv2d_x3(x2, w, b, oscale, stride=conv.stride[0], padding=conv.padding[0], dilation=conv.dilation[0], relu=relu,
+                             pool=pool, out_f32=out_f32)
+
+    @staticmethod
+    def _same3(conv):
+        return conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+
+    def _vgg(self, x):
+        m = self.model
+        c = self.conv
+        # conv1_1: three input channels -- a float32 framework convolution (0.5 % of the FLOPs), then the split
+        x = torch.relu(F.conv2d(x, m.conv1_1.weight, m.conv1_1.bias, 1, 1))
+        x2 = nat.x3_split(x)
+        x2 = c(m.conv1_2, x2, pool=True)                                   # MaxPooling2D(2, 2, 'same') fused (:275-276)
+        x2 = c(m.conv2_2, c(m.conv2_1, x2), pool=True)
+        x2 = c(m.conv3_3, c(m.conv3_2, c(m.conv3_1, x2)), pool=True)
+        conv4_3 = c(m.conv4_3, c(m.conv4_2, c(m.conv4_1, x2)), out_f32=True)
+        x2 = nat.x3_split(F.max_pool2d(conv4_3, 2, 2, ceil_mode=True))
+        conv5_3 = c(m.conv5_3, c(m.conv5_2, c(m.conv5_1, x2)), out_f32=True)
+        x2 = nat.x3_split(F.max_pool2d(conv5_3, 3, 1, 1))
+        fc7 = c(m.fc7, c(m.fc6, x2))
+        return conv4_3, fc7
+
+    def _extras(self, fc7):
+        m = self.model
+        c = self.conv
+        outs = []
+        x2 = fc7
+        names = [("conv6_1", "conv6_2"), ("conv7_1", "conv7_2"), ("conv8_1", "conv8_2"), ("conv9_1", "conv9_2"), ("conv10_1", "conv10_2")]
+        for a, b in names:
+            if not hasattr(m, a):
+                break
+            x2 = c(getattr(m, b), c(getattr(m, a), x2))
+            outs.append(x2)
+        return outs
+
+    @torch.no_grad()
+    def __call__(self, images):
+        m = self.model
+        x = m.preprocess(images)                                              # float32, channels_last
+        conv4_3, fc7 = self._vgg(x)
+        norm = m.conv4_3_norm(conv4_3)                                        # L2Normalization on float32 (:316)
+        sources = [nat.x3_split(norm.contiguous(memory_format=torch.channels_last)), fc7] + self._extras(fc7)
+        if len(sources) != len(m.conf_heads):
+            raise RuntimeError("this builder's extra layers are not the ones PreciseForward knows")
+        b = x.shape[0]
+        confs, locs, sizes = [], [], []
+        for l, s2 in enumerate(sources):
+            ch, lh = m.conf_heads[l], m.loc_heads[l]
+            if not (self._same3(ch) and self._same3(lh)):
+                raise RuntimeError("predictor heads must be 3x3 'same' convolutions")
+            w, oscale, bias = self._head_filters(l)
+            y = nat.conv2d_x3(s2, w, bias, oscale, stride=1, padding=1, dilation=1, relu=False, out_f32=True)   # (B, Cpad, h, w)
+            y = y.permute(0, 2, 3, 1)                                         # NHWC view: the channel axis splits as (box, class) (:363-383)
+            confs.append(y[..., :ch.out_channels].reshape(b, -1, m.n_classes))
+            locs.append(y[..., ch.out_channels:ch.out_channels + lh.out_channels].reshape(b, -1, 4))
+            sizes.append((y.shape[1], y.shape[2]))
+        conf = torch.softmax(torch.cat(confs, dim=1), dim=-1)                  # 'mbox_conf_softmax' (:415)
+        loc = torch.cat(locs, dim=1)
+        anchors = m.anchors_and_variances(sizes, conf.device)
+        return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)

@@ -58,10 +58,11 @@ GENERAL_CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil, bias, relu
 ]
 
 
-@pytest.mark.parametrize("variant", [None, 5, 6])
+@pytest.mark.parametrize("variant", [None, 5, 6, 8])
 @pytest.mark.parametrize("case", GENERAL_CASES)
 def test_general_conv_vs_float32_reference(case, variant):
-    """Strided / partially padded convolutions (the SSD extra layers) through ssdhip_conv2d_nhwc_bf16[_variant]."""
+    """Strided / partially padded convolutions (the SSD extra layers) through ssdhip_conv2d_nhwc_bf16[_variant]; variant 8 is the
+    split-K form (ssdhip_conv2d_splitk_nhwc_bf16: K ranges side by side, float32 partial tiles added in a fixed order)."""
     import torch
     import torch.nn.functional as F
     from ssd_keras_amd import _native as nat
@@ -80,6 +81,32 @@ def test_general_conv_vs_float32_reference(case, variant):
     tol = want.abs() * 2.0 ** -7 + 1e-2 * rms
     bad = int((err > tol).sum().item())
     assert bad == 0, "%d of %d outputs off; max err %g (rms %g)" % (bad, err.numel(), err.max().item(), rms)
+
+
+@pytest.mark.parametrize("case", [(32, 19, 19, 256, 512, 3, 2, 1), (32, 10, 10, 512, 128, 1, 1, 0), (32, 10, 10, 128, 256, 3, 2, 1),
+                                  (32, 5, 5, 128, 256, 3, 1, 0), (32, 3, 3, 128, 256, 3, 1, 0), (32, 19, 19, 1024, 256, 1, 1, 0),
+                                  (3, 3, 3, 256, 128, 1, 1, 0)])
+def test_splitk_conv_extra_layers(case):
+    """The SSD300 extra layers at batch 32 through the split-K form: within one bf16 rounding of the float32 reference, within two
+    of the one-pass kernel (another float32 summation order), and bit-identical from launch to launch (the ranges are added in
+    order, no atomics)."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+    got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, relu=True, variant=8)
+    one = nat.conv2d(x, wt, bias, stride=stride, padding=pad, relu=True)
+    want = torch.relu(F.conv2d(x.float(), wt.float(), bias.float(), stride, pad))
+    assert got.shape == want.shape == one.shape
+    rms = want.pow(2).mean().sqrt().item()
+    assert int(((got.float() - want).abs() > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
+    assert int(((got.float() - one.float()).abs() > want.abs() * 2.0 ** -6 + 1e-2 * rms).sum().item()) == 0
+    for _ in range(5):
+        assert torch.equal(nat.conv2d(x, wt, bias, stride=stride, padding=pad, relu=True, variant=8).view(torch.int16), got.view(torch.int16))
 
 
 def test_general_conv_rejects_unsupported_arguments():

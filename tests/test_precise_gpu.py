@@ -1,0 +1,96 @@
+"""The reference-precision convolution path (ssdhip_conv2d_x3_nhwc_f16, models/precise.py): float32-grade results from float16 MFMA
+passes.  Needs an MI355X.  Bars: a single convolution within 1e-5 of a float64 reference (relative to the output's RMS; MIOpen's own
+float32 convolution is measured beside it), the whole SSD300 forward within 1e-4 of the float32 framework model on class probabilities
+and offsets, and >= 99.5 % of the float32 model's detections reproduced with boxes within 1e-2 px."""
+import numpy as np
+import pytest
+
+from ssd_keras_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, H, W, C, Cout, k, stride, pad, dil, relu, pool
+    (2, 38, 38, 256, 512, 3, 1, 1, 1, True, False),
+    (2, 75, 75, 128, 256, 3, 1, 1, 1, True, True),      # pooled, odd map ('same' pooling pads bottom / right)
+    (2, 150, 150, 64, 128, 3, 1, 1, 1, True, False),
+    (2, 19, 19, 512, 1024, 3, 1, 6, 6, True, False),    # fc6: dilation 6
+    (2, 19, 19, 1024, 256, 1, 1, 0, 1, True, False),
+    (3, 19, 19, 256, 512, 3, 2, 1, 1, True, False),     # conv6_2
+    (3, 5, 5, 128, 256, 3, 1, 0, 1, True, False),       # conv8_2 ('valid')
+    (3, 3, 3, 128, 64, 3, 1, 0, 1, False, False),       # 1 x 1 output, no activation, 64-channel tile
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_x3_convolution_is_float32_grade(case, out_f32):
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, C, Cout, k, stride, pad, dil, relu, pool = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = (torch.randn((B, C, H, W), generator=g, device="cuda") * 30).relu().contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, C, k, k), generator=g, device="cuda") * (2.0 / (k * k * C)) ** 0.5
+    bias = torch.randn((Cout,), generator=g, device="cuda")
+    pw, oscale = nat.x3_pack_weight(w)
+    got = nat.conv2d_x3(nat.x3_split(x), pw, bias, oscale, stride=stride, padding=pad, dilation=dil, relu=relu, pool=pool, out_f32=out_f32)
+    if not out_f32:
+        c = got.shape[1] // 2
+        assert got.dtype == torch.float16
+        got = got[:, :c].double() + got[:, c:].double()
+    want = F.conv2d(x.double(), w.double(), bias.double(), stride, pad, dil)
+    fw = F.conv2d(x, w, bias, stride, pad, dil).double()
+    if relu:
+        want, fw = torch.relu(want), torch.relu(fw)
+    if pool:
+        want, fw = F.max_pool2d(want, 2, 2, ceil_mode=True), F.max_pool2d(fw, 2, 2, ceil_mode=True)
+    assert got.shape == want.shape
+    rms = want.pow(2).mean().sqrt().item()
+    e_x3 = (got.double() - want).abs().max().item() / rms
+    e_fw = (fw - want).abs().max().item() / rms
+    print("x3 max error / rms %.2e (framework float32 convolution %.2e)" % (e_x3, e_fw))
+    assert e_x3 <= 1e-5
+
+
+def test_precise_forward_reproduces_the_float32_model():
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.models.precise import PreciseForward
+    from ssd_keras_amd.ssd_encoder_decoder import ssd_output_decoder as dec
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(11)
+    m32 = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"],
+                  aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"]).cuda()
+    m32 = m32.to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():                                                # the tamed heads of the bf16 drift test (neither saturated nor uniform)
+        for head in m32.conf_heads:
+            head.weight.mul_(1e-3)
+            head.bias.view(-1, 21)[:, 0] = 4.0
+        for head in m32.loc_heads:
+            head.weight.mul_(1e-3)
+    images = torch.from_numpy(np.random.RandomState(5).randint(0, 256, size=(4, 300, 300, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        p32 = m32(images).float()
+    px3 = PreciseForward(m32)(images)
+    assert px3.shape == p32.shape and px3.dtype == torch.float32
+    assert torch.equal(px3[:, :, -8:], p32[:, :, -8:])
+    d_conf = float((px3[:, :, :21] - p32[:, :, :21]).abs().max())
+    d_loc = float((px3[:, :, 21:25] - p32[:, :, 21:25]).abs().max())
+    kw = dict(confidence_thresh=0.01, iou_threshold=0.45, top_k=200, normalize_coords=True, img_height=300, img_width=300)
+    a = dec.decode_detections_debug(p32, **kw)
+    b = dec.decode_detections_debug(px3, **kw)
+    found = total = 0
+    worst = 0.0
+    for ra, rb in zip(a, b):
+        kb = {(int(r[0]), int(r[1])): r for r in rb}
+        for r in ra:
+            total += 1
+            o = kb.get((int(r[0]), int(r[1])))
+            if o is not None:
+                d = float(np.abs(o[3:] - r[3:]).max())
+                worst = max(worst, d)
+                found += int(d <= 1e-2)
+    print("float16 x 3 vs float32 framework model: max |d prob| %.2e, max |d offset| %.2e, detections kept %d / %d, worst box shift %.2e px" % (
+        d_conf, d_loc, found, total, worst))
+    assert d_conf < 1e-4 and d_loc < 1e-4
+    assert total > 0 and found >= 0.995 * total
