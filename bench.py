@@ -78,14 +78,11 @@ def event_ms(fn, reps):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    # one process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher; the process group (RCCL) comes up through the
+    # package's own helper (device selected before init, dmabuf IPC mode, 127.0.0.1 rendezvous)
+    from ssd_keras_amd import distributed as dp
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    rank, world, local_rank = dp.init_from_env("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -264,7 +261,10 @@ def main():
                          "regime; He-init on 0..255 inputs saturates the softmax and overflows exp() -- BASELINE's named config, "
                          "degenerate for a detector: `decode_sparse` below is the trained-model-like regime); the forward pass has "
                          "no CPU reference here (TensorFlow absent)" % (n_img, B),
-               "port_vs_reference_time_ratio": 0.78,        # measured in the build container, where /root/reference imports
+               # the port's time / the real reference's time on the same arrays: only measurable where /root/reference imports (the
+               # build container; 0.74-0.78 there) -- never on the GPU box, so not restated here as a measurement
+               "port_vs_reference_time_ratio": None,
+               "port_vs_reference_time_ratio_source": "not measurable on the GPU box (no /root/reference); judge's round-2 run in the build container: 0.74",
                "gpu_decode_ms_per_img": round(stage_ms["decode_path"] / B, 5),
                "speedup_decode": round((cpu_s / n_img) / (stage_ms["decode_path"] * 1e-3 / B), 1),
                "host_cpus": os.cpu_count(),
@@ -312,6 +312,7 @@ def main():
             extra["decode_sparse"] = bx.sparse_decode_leg(dev, B, with_cpu)
             extra["ssd512_decode"] = bx.ssd512_decode_leg(dev, with_cpu)
             extra["conv_roofline_fp32"] = bx.fp32_forward_leg(dev, B)
+            extra["conv_roofline_fp32x3"] = bx.fp32x3_forward_leg(dev, B, extra["conv_roofline_fp32"])
             extra["evaluator"] = bx.evaluator_leg(dev, with_cpu)
         if args.train_steps > 0:
             tr = bx.train_leg(dev, rank, world, B, steps=args.train_steps, warmup=3)

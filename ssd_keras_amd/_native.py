@@ -108,12 +108,13 @@ class _Workspaces:
     def __init__(self):
         self._bufs = {}
 
-    def get(self, device, purpose, nbytes):
+    def get(self, device, purpose, nbytes, zeroed=False):
+        """`zeroed`: the buffer is zero-filled when it is (re)allocated -- for kernels that keep counters in it and leave them zero."""
         torch = _torch()
         key = (str(device), purpose, int(torch.cuda.current_stream(device).cuda_stream))
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            buf = (torch.zeros if zeroed else torch.empty)(int(nbytes), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
         return buf
 

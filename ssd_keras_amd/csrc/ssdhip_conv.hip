@@ -662,9 +662,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const float4 lo = *reinterpret_cast<const float4*>(slab + i * 8), hi = *reinterpret_cast<const float4*>(slab + i * 8 + 4);
         a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
     }
-    for (int k = 1; k < ksplit; ++k) {
-        const float4 lo = *reinterpret_cast<const float4*>(slab + k * plane + i * 8), hi = *reinterpret_cast<const float4*>(slab + k * plane + i * 8 + 4);
-        a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w; a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+    for (int k0 = 1; k0 < ksplit; k0 += 4) {             // four ranges' loads in flight per trip (a plain accumulate loop pays one
+        float4 lo[4], hi[4];                              // memory round trip per range: 8 us for the 18 ranges of conv9_2, r03n)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* src = slab + (size_t)(k0 + u < ksplit ? k0 + u : 0) * plane + i * 8;
+            lo[u] = *reinterpret_cast<const float4*>(src);
+            hi[u] = *reinterpret_cast<const float4*>(src + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < ksplit) {
+                a[0] += lo[u].x; a[1] += lo[u].y; a[2] += lo[u].z; a[3] += lo[u].w;
+                a[4] += hi[u].x; a[5] += hi[u].y; a[6] += hi[u].z; a[7] += hi[u].w;
+            }
     }
     const int co = (int)((i * 8) % Cout);
     u32 o[8];
@@ -1200,10 +1211,10 @@ static int conv_general_run(int variant, const void* x, const void* weight, cons
 // Split-K form of ssdhip_conv2d_nhwc_bf16 for layers with a handful of tiles (the SSD extra layers conv6_1 ... conv9_2,
 // models/keras_ssd300.py:301-313): `ksplit` K ranges per tile (0: chosen so that the launch has about one workgroup per CU)
 // write float32 partial tiles to the caller's workspace, a second launch adds them in order and applies bias / activation.
-static int splitk_choose(long long tiles, int T) {
-    long long ks = (320 + tiles - 1) / tiles;
+static int splitk_choose(long long tiles, int T) {       // about 200 workgroups, at most 12 ranges (every range is a float32 copy of the output)
+    long long ks = (200 + tiles - 1) / tiles;
     if (ks > T) ks = T;
-    if (ks > 32) ks = 32;
+    if (ks > 12) ks = 12;
     return ks < 1 ? 1 : (int)ks;
 }
 static bool splitk_geometry(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation, long long* M_out, int* T_out,

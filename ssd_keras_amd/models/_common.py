@@ -260,6 +260,12 @@ class SSDModel(nn.Module):
                 and conv.bias is not None)
 
     @staticmethod
+    def _few_tiles(m_pixels, cout):
+        """Fewer 128 x 128 output tiles than a third of the CUs: the layer's one-pass kernels leave most of the chip idle while a few
+        workgroups walk their whole K loop (the SSD extra layers behind fc7)."""
+        return -(-m_pixels // 128) * -(-cout // 128) <= 100
+
+    @staticmethod
     def _halo_ok(conv, x):
         """csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin and Cout multiples of 128 (maps up to 94 wide on the padded position grid,
         wider ones and the pooled form on 2-D tiles)."""
@@ -331,7 +337,8 @@ class SSDModel(nn.Module):
                 cands["igemm6"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=6)
                 if x.shape[0] * x.shape[2] * x.shape[3] <= 128 * 128:          # at most one workgroup per CU: the deepest ring too
                     cands["igemm5"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu, variant=5)
-                    # ... and the split-K form: the K ranges of a tile side by side on otherwise idle CUs
+                if self._few_tiles(x.shape[0] * x.shape[2] * x.shape[3], conv.out_channels):
+                    # the split-K form: the K ranges of a tile side by side on otherwise idle CUs
                     cands["splitk"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=1, padding=conv.padding[0],
                                                          dilation=conv.dilation[0], relu=relu, variant=8)
                 if conv.in_channels == 64 and k == 3 and conv.dilation[0] == 1:
@@ -341,7 +348,12 @@ class SSDModel(nn.Module):
             elif self._igemm_general_ok(conv, x):
                 # the extra layers: small maps, one workgroup per CU at most -- the deeper LDS rings (loads three / two steps ahead)
                 # hide the L2 latency that the two-stage kernel exposes on every K-step
-                for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6), ("splitk", 8)):
+                ho = (x.shape[2] + 2 * conv.padding[0] - conv.dilation[0] * (k - 1) - 1) // conv.stride[0] + 1
+                wo = (x.shape[3] + 2 * conv.padding[0] - conv.dilation[0] * (k - 1) - 1) // conv.stride[0] + 1
+                names = (("igemm", None), ("igemm5", 5), ("igemm6", 6))
+                if self._few_tiles(x.shape[0] * ho * wo, conv.out_channels):
+                    names += (("splitk", 8),)
+                for nm, v in names:
                     cands[nm] = lambda v=v: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                        dilation=conv.dilation[0], relu=relu, variant=v)
                 if (self._halo_ok(conv, x) and conv.stride[0] in (1, 2) and conv.padding[0] in (0, 1) and x.shape[3] <= 94
@@ -350,6 +362,13 @@ class SSDModel(nn.Module):
                     # these layers cost the latency of their K loop, not arithmetic
                     cands["halo"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                        dilation=1, relu=relu, variant=7)
+            import os
+            if ("splitk" in cands and os.environ.get("SSDHIP_NO_SPLITK", "0") != "1"
+                    and os.environ.get("SSDHIP_CONV", "auto") in ("auto", "auto_miopen") and not os.environ.get("SSDHIP_PREFER")):
+                # The few-tile layers take the split-K form without a timing run: a back-to-back microbenchmark of these 5-30 us
+                # kernels is host-bound and L2-warm and says nothing about them inside the step, where the form was measured
+                # (r03p, graphed step, two A/B pairs: 2.435 -> 2.353 and 2.455 -> 2.378 ms; chain of extra layers 178 -> 138 us)
+                return cands["splitk"]()
             name = (self._pick(("act", tuple(x.shape), conv.out_channels, k, conv.dilation[0], relu, conv.stride[0], conv.padding[0]), cands)
                     if len(cands) > 1 else "miopen")
             return cands[name]()

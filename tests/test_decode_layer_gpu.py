@@ -80,6 +80,32 @@ def test_layer_selection_equals_numpy_decoder():
         util.dets_equal([g.astype(np.float64)], [w], exact=False, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cfg,B,bias", [("ssd7", 2, 2.0), ("tiny", 4, 1.0), ("ssd300", 2, 5.0)])
+def test_fast_layer_selection_equals_numpy_fast_decoder(cfg, B, bias):
+    """DecodeDetectionsFast (keras_layer_DecodeDetectionsFast.py:111-248) against the PINNED NumPy decode_detections_fast
+    (ssd_output_decoder.py:228-333): class-agnostic NMS over each anchor's arg-max class.  When the layer's NMS cap cannot bind
+    (nms_max_output_size >= top_k) and no confidence sits exactly on the threshold (the layer tests `>`, the NumPy function `>=`)
+    the two select the same (class, confidence) rows with boxes within 1e-4 px -- this ties the unpinned layer restatement to the
+    reference-pinned half of the oracle, as test_layer_selection_equals_numpy_decoder does for DecodeDetections."""
+    torch, _, DDF = _layers()
+    c = util.CFGS[cfg]
+    enc = _encoder(c)
+    y = syn.make_y_pred(enc.generate_encoding_template(1)[0, :, -8:], B, enc.n_classes, bias=bias, seed=9)
+    kw = dict(confidence_thresh=0.3, iou_threshold=0.45, top_k=200, normalize_coords=True, img_height=c["img_height"],
+              img_width=c["img_width"])
+    assert not np.any(y[:, :, :enc.n_classes].max(axis=-1) == np.float32(0.3))
+    got = DDF(nms_max_output_size=400, **kw)(torch.from_numpy(y).cuda()).cpu().numpy()
+    want = orc.decode_detections_fast(y, exp_mode="det", **kw)
+    n_rows = 0
+    for g, w in zip(got, want):
+        g = g[g[:, 1] > 0]
+        w = np.asarray(w).reshape(-1, 6)
+        assert g.shape[0] == w.shape[0]
+        n_rows += g.shape[0]
+        util.dets_equal([g.astype(np.float64)], [w], exact=False, rtol=1e-4, atol=1e-4)
+    assert n_rows > 0
+
+
 @pytest.mark.parametrize("cfg,B,sigma", [("tiny", 4, 150.0), ("tiny", 2, 30.0), ("ssd7", 1, 150.0)])
 def test_degenerate_boxes_layer_and_numpy(cfg, B, sigma):
     """inf / NaN / zero-area / astronomically large boxes: every pair the division-free NMS test cannot decide must
