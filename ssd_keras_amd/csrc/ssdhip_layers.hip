@@ -84,6 +84,27 @@ __global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint4* __re
         const int w0 = max(wo * s - p, 0), w1 = min(wo * s - p + k, W);
         const uint4 bv = bias ? bias[cg] : make_uint4(0, 0, 0, 0);
         uint4 best = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);      // -inf
+        if (k == 3 && s == 1) {
+            // pool5 (MaxPooling2D(3, 1, 'same'), models/keras_ssd300.py:296): the nine loads of the window go out together (clamped
+            // coordinates, a window element outside the map is replaced by -inf afterwards) instead of one dependent load per trip
+            // of a doubly nested loop with runtime bounds (35 -> ~12 us at batch 32)
+            uint4 v[9];
+            bool in[9];
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int hi = ho - p + dh, wi = wo - p + dw;
+                    in[dh * 3 + dw] = hi >= 0 && hi < H && wi >= 0 && wi < W;
+                    const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+                    v[dh * 3 + dw] = x[((size_t)(b * H + hc) * W + wc) * cvec + cg];
+                }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                if (in[q]) best = bfmax8(bias_act8(v[q], bv, relu != 0), best);
+            y[i] = best;
+            continue;
+        }
         for (int hi = h0; hi < h1; ++hi)
             for (int wi = w0; wi < w1; ++wi)
                 best = bfmax8(bias_act8(x[((size_t)(b * H + hi) * W + wi) * cvec + cg], bv, relu != 0), best);

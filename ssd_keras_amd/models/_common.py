@@ -658,7 +658,7 @@ class SSDModel(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 big = nat.conv3x3_halo_group(list(early), [self._packed_head_weight(l, 128) for l in range(n_early)], None, relu=False,
-                                             max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "160")))
+                                             max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "128")))
             rest = self.extra_features(early[1])
             check_rest(rest)
             if self._halo_heads_ok(rest):

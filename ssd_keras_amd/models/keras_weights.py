@@ -7,8 +7,9 @@ whose layers are named exactly like the layers in models/keras_ssd300.py:274-361
 torch's is OIHW; BatchNormalization stores `gamma, beta, moving_mean, moving_variance`.
 
 `keras_layer_map(model)` gives name -> list of (parameter/buffer, to_torch, to_keras) in Keras' `weight_names` order;
-`load_keras_weights(model, source)` takes either a `{layer_name: [arrays in Keras order]}` dict or the path of a Keras
-`.h5` weight file (needs h5py, which is not installed in every environment: ImportError says so);
+`load_keras_weights(model, source)` takes a `{layer_name: [arrays in Keras order]}` dict, the path of an `.npz` container
+(keys "<layer>/<index>": `save_keras_weights_npz`, or `NPZ_CONVERSION` run once next to the Keras file -- no h5py on this side) or the
+path of a Keras `.h5` weight file (needs h5py, which is not installed in every environment: ImportError says so);
 `export_keras_weights(model)` is the inverse (dict).  `by_name` semantics as in Keras: layers missing from the source keep
 their initialisation, layers whose shapes do not match raise ValueError.
 """
@@ -69,9 +70,45 @@ def _read_h5(path):
     return out
 
 
+NPZ_CONVERSION = """# run where Keras / h5py exist (the reference's environment); writes the .npz container load_keras_weights() reads
+import h5py, numpy as np, sys
+with h5py.File(sys.argv[1], "r") as f:
+    g = f["model_weights"] if "model_weights" in f else f
+    out = {}
+    for name in g.attrs["layer_names"]:
+        name = name.decode() if isinstance(name, bytes) else name
+        for i, w in enumerate(g[name].attrs["weight_names"]):
+            out["%s/%d" % (name, i)] = np.asarray(g[name][w.decode() if isinstance(w, bytes) else w])
+np.savez(sys.argv[2], **out)
+"""
+
+
+def save_keras_weights_npz(source, path):
+    """Write a `{layer_name: [arrays in Keras order]}` dict (or a model: its export_keras_weights) as the h5py-free container:
+    an .npz whose keys are "<layer name>/<index in Keras' weight_names order>" -- what NPZ_CONVERSION produces from a Keras .h5."""
+    weights = source if isinstance(source, dict) else export_keras_weights(source)
+    np.savez(path, **{"%s/%d" % (name, i): np.asarray(a) for name, arrays in weights.items() for i, a in enumerate(arrays)})
+
+
+def _read_npz(path):
+    out = {}
+    with np.load(path) as z:
+        for key in z.files:
+            name, _, idx = key.rpartition("/")
+            if not name or not idx.isdigit():
+                raise ValueError("'{}': keys of a weight .npz read '<layer name>/<index>', got '{}'".format(path, key))
+            out.setdefault(name, {})[int(idx)] = z[key]
+    return {name: [parts[i] for i in range(len(parts))] for name, parts in out.items()}
+
+
 def load_keras_weights(model, source, by_name=True, strict_shapes=True):
-    """Load Keras-layout weights into `model` (in place).  Returns (loaded layer names, model layers absent from the source)."""
-    weights = _read_h5(source) if isinstance(source, str) else source
+    """Load Keras-layout weights into `model` (in place).  `source`: a `{layer_name: [arrays]}` dict, the path of an .npz
+    container (save_keras_weights_npz / NPZ_CONVERSION; no h5py needed) or of a Keras .h5 weight file (needs h5py).
+    Returns (loaded layer names, model layers absent from the source)."""
+    if isinstance(source, str):
+        weights = _read_npz(source) if source.endswith(".npz") else _read_h5(source)
+    else:
+        weights = source
     lm = keras_layer_map(model)
     if not by_name and set(weights) != set(lm):
         raise ValueError("by_name=False needs exactly the model's layers; differing: {}".format(sorted(set(weights) ^ set(lm))))

@@ -177,6 +177,36 @@ def test_keras_weight_layout_round_trip():
         assert torch.equal(s1(x), s2(x))
 
 
+def test_keras_weight_file_loads_end_to_end(tmp_path):
+    """`model.load_weights(weights_path, by_name=True)` (ssd300_inference.ipynb:117, ssd300_training.ipynb:162) without h5py: a weight
+    FILE in the .npz container (what keras_weights.NPZ_CONVERSION writes next to a Keras .h5) loaded into a fresh SSD300; the loaded
+    model computes the same predictions, layer for layer named as in models/keras_ssd300.py."""
+    import numpy as np
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.models.keras_weights import NPZ_CONVERSION, load_keras_weights, save_keras_weights_npz
+    sc = [0.1, 0.2, 0.37, 0.54, 0.71, 0.88, 1.05]
+    torch.manual_seed(3)
+    a = ssd_300((300, 300, 3), 20, mode="training", scales=sc).eval()
+    path = str(tmp_path / "VGG_VOC0712_SSD_300x300.npz")
+    save_keras_weights_npz(a, path)
+    with np.load(path) as z:
+        assert "conv1_1/0" in z.files and "conv1_1/1" in z.files and z["fc6/0"].shape == (3, 3, 512, 1024)       # HWIO, Keras order
+    torch.manual_seed(4)
+    b = ssd_300((300, 300, 3), 20, mode="training", scales=sc).eval()
+    loaded, missing = load_keras_weights(b, path, by_name=True)
+    assert not missing and len(loaded) == 36
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    x = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(1, 300, 300, 3)).astype(np.float32))
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
+    compile(NPZ_CONVERSION, "<npz conversion>", "exec")            # the documented one-off conversion script parses
+    with pytest.raises(ValueError):
+        np.savez(str(tmp_path / "bad.npz"), **{"conv1_1": np.zeros(3)})
+        load_keras_weights(b, str(tmp_path / "bad.npz"))
+
+
 def test_evaluator_ground_truth_packing():
     """The vectorised per-class CSR packing of Evaluator.match_predictions == a per-image loop with the reference's masks."""
     import numpy as np

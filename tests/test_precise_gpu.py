@@ -1,5 +1,5 @@
 """The reference-precision convolution path (ssdhip_conv2d_x3_nhwc_f16, models/precise.py): float32-grade results from float16 MFMA
-passes.  Needs an MI355X.  Bars: a single convolution within 2^-21 sum |x| |w| of a float64 reference elementwise and within 8x of the
+passes.  Needs an MI355X.  Bars: a single convolution within 2^-20 sum |x| |w| of a float64 reference elementwise and within 8x of the
 maximum error of MIOpen's own float32 convolution (both relative to the output's RMS), the whole SSD300 forward within 1e-4 of the float32 framework model on class probabilities
 and offsets, and >= 99.5 % of the float32 model's detections reproduced with boxes within 1e-2 px."""
 import numpy as np
@@ -49,14 +49,14 @@ def test_x3_convolution_is_float32_grade(case, out_f32):
     e_x3 = (got.double() - want).abs().max().item() / rms
     e_fw = (fw - want).abs().max().item() / rms
     print("x3 max error / rms %.2e (framework float32 convolution %.2e)" % (e_x3, e_fw))
-    # float32-grade.  Rigorous: every output within 2^-21 of sum |x| |w| (two float16 parts carry a float32 value to 2^-22, the
+    # float32-grade.  Rigorous: every output within 2^-20 of sum |x| |w| (two float16 parts carry each operand to 2^-22, the
     # dropped lo . lo product is 2^-22 of the term, float32 accumulation adds the rest).  Statistical: the largest error within 8x of
     # the framework's own float32 convolution (measured 1.2x - 6.4x, r03o) and below 3e-5 of the output's RMS (bf16 sits at ~4e-3).
-    bound = F.conv2d(x.double().abs(), w.double().abs(), bias.double().abs(), stride, pad, dil) * 2.0 ** -21
+    bound = F.conv2d(x.double().abs(), w.double().abs(), bias.double().abs(), stride, pad, dil) * 2.0 ** -20
     if pool:
         bound = F.max_pool2d(bound, 2, 2, ceil_mode=True)
     ratio = float(((got.double() - want).abs() / bound.clamp_min(1e-300)).max())
-    print("largest error / (2^-21 sum |x| |w|) = %.3f" % ratio)
+    print("largest error / (2^-20 sum |x| |w|) = %.3f" % ratio)
     assert ratio <= 1.0
     assert e_x3 <= 8.0 * e_fw + 1e-6 and e_x3 <= 3e-5
 
