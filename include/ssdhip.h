@@ -254,6 +254,17 @@ int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, co
  * ssdhip_maxpool_bwd_nhwc_bf16     gx [B,H,W,C] = gradient of max-pooling (kernel, stride, pad; windows clipped to the map) given its
  *                                  input x and the gradient gy [B,Ho,Wo,C] of its output: every window's gradient goes to its first
  *                                  maximum in row-major order (NaN wins), as max_pool2d's backward. */
+/* L2Normalization (keras_layers/keras_layer_L2Normalization.py:61-63) for the float32 model and for the training step: x, y, dy, dx
+ * [n_pixels, C] NHWC float32 (is_bf16 = 0, C % 4 == 0) or bf16 (is_bf16 = 1, C % 8 == 0), gamma float32 [C]; float32 math.
+ * ssdhip_l2_normalize_fwd   y = x * rsqrt(max(sum_c x^2, 1e-12)) * gamma[c]; inv_norm [n_pixels] float32 (may be NULL) receives the
+ *                           pixel's rsqrt(...) for the backward.
+ * ssdhip_l2_normalize_bwd   dx = gamma * dy * inv - x * inv^3 * sum_c(dy gamma x) (the second term only where the norm was not clamped)
+ *                           and dgamma_partial [n_waves, C]: per-wave sums of dy * x * inv over the wave's pixels, n_waves =
+ *                           ssdhip_l2_normalize_bwd_waves(n_pixels, C, is_bf16) (0: shape not supported); dgamma is their sum over axis 0. */
+int ssdhip_l2_normalize_bwd_waves(long long n_pixels, int C, int is_bf16);
+int ssdhip_l2_normalize_fwd(const void* x, const float* gamma, void* y, float* inv_norm, long long n_pixels, int C, int is_bf16, void* stream);
+int ssdhip_l2_normalize_bwd(const void* x, const void* dy, const float* gamma, const float* inv_norm, void* dx, float* dgamma_partial,
+                            int n_waves, long long n_pixels, int C, int is_bf16, void* stream);
 int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
 int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, void* out, float* partial, long long n_pixels, int C,
                                    int n_blocks, void* stream);
@@ -309,6 +320,12 @@ int ssdhip_conv2d_nhwc_bf16_variant(int variant, const void* x, const void* weig
 int ssdhip_conv2d_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
                               int kernel, int stride, int pad, int dilation, int relu, int pool, int out_f32, float oscale,
                               void* stream);
+
+/* The same arithmetic on the slab kernel (csrc/ssdhip_convh.hip) for the 3x3 'same' layers with C % 128 == 0 and Cout % 128 == 0
+ * (conv2_2 ... conv5_3 and the packed predictor heads): x [B,H,W,2C], weight [Cout,3,3,3C], bias float32 or NULL, y [B,Ho,Wo,2 Cout]
+ * float16 = [hi | lo] of act(oscale * sum + bias); pool != 0 fuses MaxPooling2D(2, 2, 'same'). */
+int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
+                                    int relu, int pool, float oscale, void* stream);
 
 size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,
                                             int ksplit);

@@ -269,6 +269,74 @@ def l2_normalize(x, gamma):
     return y
 
 
+def _l2_bind(lib):
+    if not getattr(lib, "_l2_bound", False):
+        c_int, c_vp, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+        lib.ssdhip_l2_normalize_bwd_waves.restype = c_int
+        lib.ssdhip_l2_normalize_bwd_waves.argtypes = [c_ll, c_int, c_int]
+        lib.ssdhip_l2_normalize_fwd.restype = c_int
+        lib.ssdhip_l2_normalize_fwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_vp]
+        lib.ssdhip_l2_normalize_bwd.restype = c_int
+        lib.ssdhip_l2_normalize_bwd.argtypes = [c_vp] * 6 + [c_int, c_ll, c_int, c_int, c_vp]
+        lib._l2_bound = True
+    return lib
+
+
+def _l2_view(t, name):
+    """(B, C, H, W) float32 or bf16 CUDA tensor in channels_last memory -> (tensor, n_pixels, C, is_bf16)."""
+    torch = _torch()
+    if not t.is_cuda or t.dim() != 4 or t.dtype not in (torch.float32, torch.bfloat16):
+        raise SsdHipError("%s must be a 4-D float32 / bfloat16 CUDA tensor" % name)
+    if not t.permute(0, 2, 3, 1).is_contiguous():
+        t = t.contiguous(memory_format=torch.channels_last)
+        if not t.permute(0, 2, 3, 1).is_contiguous():
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    b, c, h, w = t.shape
+    return t, b * h * w, c, int(t.dtype == torch.bfloat16)
+
+
+def l2_normalize_supported(x):
+    torch = _torch()
+    if not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    b, c, h, w = x.shape
+    is_bf16 = int(x.dtype == torch.bfloat16)
+    return _l2_bind(load()).ssdhip_l2_normalize_bwd_waves(b * h * w, c, is_bf16) > 0
+
+
+def l2_normalize_fwd(x, gamma, want_inv=True):
+    """L2Normalization forward for float32 / bf16 maps (ssdhip_l2_normalize_fwd): returns (y, inv_norm | None)."""
+    torch = _torch()
+    lib = _l2_bind(load())
+    x, n_px, c, is_bf16 = _l2_view(x, "x")
+    g = gamma.detach().float().contiguous()
+    y = torch.empty_like(x)
+    inv = torch.empty((n_px,), dtype=torch.float32, device=x.device) if want_inv else None
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_l2_normalize_fwd(_ptr(x), _ptr(g), _ptr(y), _ptr(inv), n_px, c, is_bf16, current_stream_ptr(x.device))
+    check(rc, "ssdhip_l2_normalize_fwd")
+    return y, inv
+
+
+def l2_normalize_bwd(x, dy, gamma, inv):
+    """Gradients of L2Normalization (ssdhip_l2_normalize_bwd): returns (dx like x, dgamma float32 (C,))."""
+    torch = _torch()
+    lib = _l2_bind(load())
+    x, n_px, c, is_bf16 = _l2_view(x, "x")
+    dy, _, _, _ = _l2_view(dy.to(x.dtype), "dy")
+    g = gamma.detach().float().contiguous()
+    n_waves = lib.ssdhip_l2_normalize_bwd_waves(n_px, c, is_bf16)
+    if n_waves <= 0:
+        raise SsdHipError("ssdhip_l2_normalize_bwd: unsupported shape")
+    dx = torch.empty_like(x)
+    part = torch.empty((n_waves, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_l2_normalize_bwd(_ptr(x), _ptr(dy), _ptr(g), _ptr(inv), _ptr(dx), _ptr(part), n_waves, n_px, c, is_bf16,
+                                         current_stream_ptr(x.device))
+    check(rc, "ssdhip_l2_normalize_bwd")
+    return dx, part.sum(dim=0)
+
+
 def preprocess(images, mean=None, divide=None, swap=None):
     """(B, H, W, C<=4) float32 CUDA images -> (B, C, H, W) bf16 with NHWC memory: (img[..., swap] - mean[swap]) / divide[swap]."""
     torch = _torch()
@@ -613,6 +681,22 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
         ho, wo = (h + 1) // 2, (w + 1) // 2
     if ho < 1 or wo < 1:
         raise SsdHipError("convolution output would be empty")
+    import os
+    c = c2 // 2
+    if (int(kh) == 3 and int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and c % 128 == 0 and cout % 128 == 0
+            and os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1"):
+        # the slab kernel (csrc/ssdhip_convh.hip): the deep 3x3 layers and the packed heads; it writes split pairs, merged here when
+        # the caller wants float32
+        if not getattr(lib, "_x3h_bound", False):
+            lib.ssdhip_conv3x3_halo_x3_nhwc_f16.restype = ctypes.c_int
+            lib.ssdhip_conv3x3_halo_x3_nhwc_f16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_void_p]
+            lib._x3h_bound = True
+        y2 = torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device).permute(0, 3, 1, 2)
+        with torch.cuda.device(x2.device):
+            rc = lib.ssdhip_conv3x3_halo_x3_nhwc_f16(_ptr(x2), _ptr(packed_weight), _ptr(bias), _ptr(y2), b, h, w, c, cout, int(bool(relu)),
+                                                     int(bool(pool)), ctypes.c_float(float(oscale)), current_stream_ptr(x2.device))
+        check(rc, "ssdhip_conv3x3_halo_x3_nhwc_f16")
+        return (y2[:, :cout].float() + y2[:, cout:].float()) if out_f32 else y2
     y = (torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x2.device) if out_f32 else
          torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device)).permute(0, 3, 1, 2)
     with torch.cuda.device(x2.device):

@@ -68,6 +68,11 @@ struct ConvHParams {
     int os, ooff, Hs, Ws;        // position grid only: output pixel (ho, wo) = the 'same' result at (ho os + ooff, wo os + ooff), map Hs x Ws
                                  // (os = 1, ooff = 0, Hs = H, Ws = W: the plain 'same' convolution)
     int x_bytes, w_bytes, y_bytes;
+    // reference-precision form (X3, see ssdhip_conv.hip conv_igemm4_body): x rows hold xC = 2 C float16 channels [hi | lo], the K loop
+    // walks Cin = 3 C channels (slice j reads x slice j < nx ? j : j - nx), y rows hold 2 Cout float16 channels [hi | lo]; float32 bias
+    int xC, nx;
+    const float* bias32;
+    float oscale;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -109,7 +114,15 @@ __device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
 // same column of the two rows of a row pair and lane ^ 1 is the neighbouring column, so POOL (MaxPooling2D(2, 2, 'same') fused:
 // models/keras_ssd300.py:279-283) takes the 2 x 2 maximum on the float32 accumulators in registers, as conv_igemm4_pool_kernel does.
 // SMALL: the map may be narrower than 7 pixels (the epilogue then steps its positions with a loop instead of one select).
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL>
+typedef _Float16 ch_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32 ch_split2(float a, float b, u32& lo_out) {        // two float32 -> packed float16 hi parts, lo parts
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+    lo_out = (u32)__builtin_bit_cast(unsigned short, la) | ((u32)__builtin_bit_cast(unsigned short, lb) << 16);
+    return (u32)__builtin_bit_cast(unsigned short, ha) | ((u32)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
     constexpr int TC = G2 ? (1 << CSH) : 1, TR = G2 ? (CH_BN >> CSH) : 1, SC2 = TC + 2;   // tile columns, rows; slab columns
@@ -139,6 +152,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     const int r31 = lane & 31, khalf = lane >> 5;
     const int H = p.H, W = p.W, Cin = p.Cin, W1 = W + 1, H1 = H + 1;
     const int csteps = Cin >> 6;
+    const int XC = X3 ? p.xC : Cin;                       // channels of an x row
     const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const i32x4 rx = ch_rsrc(p.x, p.x_bytes);
     const i32x4 rw = ch_rsrc(p.w, p.w_bytes);
@@ -153,7 +167,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             __builtin_amdgcn_raw_buffer_store_b128(d, ry, ok ? elem * 2u : OOB, 0, 0);
         }
     };
-    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8);       // global stores a wave issues per epilogue
+    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8) * (X3 ? 2 : 1);       // global stores a wave issues per epilogue
+    const u32 YC = X3 ? 2u * (u32)p.Cout : (u32)p.Cout;  // channels of a y row (X3: [hi | lo])
 
     // ---- per-lane load descriptors --------------------------------------------------------------------------------------
     // slab row r <-> position q0 - (W + 2) + r; piece (k, wave) = rows 64 k + 8 wave .. + 7, lane -> row (lane >> 3), chunk slot
@@ -179,7 +194,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 const int sr = row / SC2, sc = row - sr * SC2;
                 const int hh = h0 - 1 + sr, ww = w0 - 1 + sc;
                 const bool ok = row < SP && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-                xoff[k] = ok ? (u32)(((b * H + hh) * W + ww) * (Cin * 2) + j * 16) : OOB;
+                xoff[k] = ok ? (u32)(((b * H + hh) * W + ww) * (XC * 2) + j * 16) : OOB;
             }
             return;
         }
@@ -192,7 +207,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             const int row = row0 + 64 * k;
             const int j = (lane & 7) ^ ((row >> 1) & 7);
             const bool ok = w >= 0 && w < W && h < H && q < p.Q && row < SP;
-            xoff[k] = ok ? (u32)(((b * H + h) * W + w) * (Cin * 2) + j * 16) : OOB;
+            xoff[k] = ok ? (u32)(((b * H + h) * W + w) * (XC * 2) + j * 16) : OOB;
             q += 64;
             w += 64;
             while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
@@ -252,7 +267,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     };
     auto mfma_one = [&](auto setc, auto ic) {             // MFMA i of a step: k16 block i / 4, accumulator (ci, pi) = ((i >> 1) & 1, i & 1)
         constexpr int S = decltype(setc)::value, i = decltype(ic)::value, kk = i >> 2, ci = (i >> 1) & 1, pi = i & 1;
-        acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
+        if constexpr (X3)
+            acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ch_f16x8, fa[S][kk][ci]), __builtin_bit_cast(ch_f16x8, fb[S][kk][pi]),
+                                                                 acc[ci][pi], 0, 0, 0);
+        else
+            acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][kk][ci], fb[S][kk][pi], acc[ci][pi], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
@@ -320,7 +339,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                     }
                 } else if constexpr (i == 9 + QSH && TAP < SPW) {
                     if (!nomore)
-                        ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192, nxt ? 0u : (u32)((cs + 1) * 128));
+                        ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192,
+                                 nxt ? 0u : (u32)(((X3 && cs + 1 >= p.nx) ? cs + 1 - p.nx : cs + 1) * 128));
                 }
             }
         };
@@ -401,6 +421,15 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         // ReLU as "v <= floor ? floor : v" with floor = +0 (NaN stays NaN, -0 -> +0), no activation as floor = -inf: one compare and one
         // select per value either way (a runtime `relu ? ... : v` costs a third, scalar, instruction per value)
         const float rfloor = p.relu ? 0.f : -__builtin_inff();
+        if constexpr (X3) {
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        bv[ci][4 * g + e] = p.bias32 ? p.bias32[co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e] : 0.f;
+        } else
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -423,6 +452,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
             const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
 #pragma unroll
+            for (int part = 0; part < (X3 ? 2 : 1); ++part) {             // X3: the hi parts, then the lo parts
+#pragma unroll
             for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -434,13 +465,22 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         if (has_below) v = below > v ? below : v;
                         const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
                         if (has_right) v = right > v ? right : v;
-                        v += bv[ci][4 * g + e];
+                        v = X3 ? v * p.oscale + bv[ci][4 * g + e] : v + bv[ci][4 * g + e];
                         o[e] = v <= rfloor ? rfloor : v;
                     }
                     if (!(r31 & 1)) {
                         const int px = r31 >> 1, chunk = ci * 4 + g;
-                        *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
-                            make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
+                        u32 p0, p1;
+                        if constexpr (X3) {
+                            u32 l0, l1;
+                            const u32 h0_ = ch_split2(o[0], o[1], l0), h1_ = ch_split2(o[2], o[3], l1);
+                            p0 = part ? l0 : h0_;
+                            p1 = part ? l1 : h1_;
+                        } else {
+                            p0 = ch_pack2(o[0], o[1]);
+                            p1 = ch_pack2(o[2], o[3]);
+                        }
+                        *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) = make_uint2(p0, p1);
                     }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -450,9 +490,10 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 const int se = wn * 32 + 2 * px;                                // the even lane's slot
                 const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
-                store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * (u32)p.Cout + (u32)(co0 + wm * 64 + c * 8));
+                store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(part * p.Cout + co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         } else {
             int q = 0, b = 0, h = 0, w = 0, h0 = 0, w0 = 0;
             if constexpr (G2) {
@@ -467,6 +508,10 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             const int c = lane & 7;
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
+              const int q_s = q, b_s = b, h_s = h, w_s = w;             // X3 walks the pass's positions twice (hi parts, lo parts)
+#pragma unroll
+              for (int part = 0; part < (X3 ? 2 : 1); ++part) {
+                q = q_s; b = b_s; h = h_s; w = w_s;
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -474,12 +519,21 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = acc[ci][pi][4 * g + e] + bv[ci][4 * g + e];
+                            const float v = X3 ? acc[ci][pi][4 * g + e] * p.oscale + bv[ci][4 * g + e] : acc[ci][pi][4 * g + e] + bv[ci][4 * g + e];
                             o[e] = v <= rfloor ? rfloor : v;
                         }
                         const int chunk = ci * 4 + g;
-                        *reinterpret_cast<uint2*>(stage + r31 * 128 + ((chunk ^ (r31 & 7)) << 4) + khalf * 8) =
-                            make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
+                        u32 p0, p1;
+                        if constexpr (X3) {
+                            u32 l0, l1;
+                            const u32 h0_ = ch_split2(o[0], o[1], l0), h1_ = ch_split2(o[2], o[3], l1);
+                            p0 = part ? l0 : h0_;
+                            p1 = part ? l1 : h1_;
+                        } else {
+                            p0 = ch_pack2(o[0], o[1]);
+                            p1 = ch_pack2(o[2], o[3]);
+                        }
+                        *reinterpret_cast<uint2*>(stage + r31 * 128 + ((chunk ^ (r31 & 7)) << 4) + khalf * 8) = make_uint2(p0, p1);
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -489,7 +543,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                     if constexpr (G2) {
                         const int sl = wn * 32 + px;
                         const int hh = h0 + 2 * (sl >> CSH) + pi, ww = w0 + (sl & (TC - 1));
-                        store16(v, hh < H && ww < W, (u32)((b * H + hh) * W + ww) * (u32)p.Cout + (u32)(co0 + wm * 64 + c * 8));
+                        store16(v, hh < H && ww < W, (u32)((b * H + hh) * W + ww) * YC + (u32)(part * p.Cout + co0 + wm * 64 + c * 8));
                     } else {
                         {
                             // strided / 'valid' forms keep the positions (ho os + ooff, wo os + ooff) of the 'same' result; os is 1 or 2:
@@ -499,7 +553,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                             const int hh = h - p.ooff, ww = w - p.ooff;
                             const int ho = hh >> sh, wo = ww >> sh;
                             const bool ok = w < W && h < H && q < p.Q && (hh | ww) >= 0 && !((hh | ww) & sh) && ho < p.Hs && wo < p.Ws;
-                            store16(v, ok, (u32)((b * p.Hs + ho) * p.Ws + wo) * (u32)p.Cout + (u32)(co0 + wm * 64 + c * 8));
+                            store16(v, ok, (u32)((b * p.Hs + ho) * p.Ws + wo) * YC + (u32)(part * p.Cout + co0 + wm * 64 + c * 8));
                         }
                         q += 8;
                         w += 8;
@@ -516,6 +570,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
+              }
             }
         }
         }
@@ -529,11 +584,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int NW, int SPW, int MODE, int CSH, bool POOL>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false>
 __global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
+    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
 #endif
 }
 
@@ -568,22 +623,22 @@ __global__ __launch_bounds__(CH_THREADS) void convh_group_kernel(ConvHGroup g) {
 }
 
 // geom: 0 = padded position grid; 4 | 5 = 2-D tiles of 16 x 16 | 8 x 32 pixels
-template <int MODE>
+template <int MODE, bool X3 = false>
 static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hipStream_t stream) {
     int grid = p.total_ids;
     if ((MODE & 128) && grid > n_cu) grid = n_cu;        // persistent: one workgroup per CU (a multiple of 8: the id -> XCD map)
     const dim3 g(grid), t(CH_THREADS);
     if (geom == 4) {
-        if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, true>), g, t, 0, stream, p);
-        else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, false>), g, t, 0, stream, p);
+        if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, true, X3>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, false, X3>), g, t, 0, stream, p);
     } else if (geom == 5) {
-        if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, true>), g, t, 0, stream, p);
-        else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, false>), g, t, 0, stream, p);
+        if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, true, X3>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, false, X3>), g, t, 0, stream, p);
     }
     // slab rows = 256 + 2 W + 4 <= 64 SPW: three weight stages + 7 pieces per wave (W <= 94), four + 6 (W <= 62), four + 5 (W <= 30)
-    else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false>), g, t, 0, stream, p);
-    else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false>), g, t, 0, stream, p);
-    else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false>), g, t, 0, stream, p);
+    else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false, X3>), g, t, 0, stream, p);
+    else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false, X3>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false, X3>), g, t, 0, stream, p);
 }
 
 }  // namespace ssdhip
@@ -675,6 +730,51 @@ extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* c
     if (grid > convh_cu_count()) grid = convh_cu_count();
     if (max_workgroups >= 8 && grid > (max_workgroups / 8) * 8) grid = (max_workgroups / 8) * 8;   // leave CUs to a concurrent stream
     hipLaunchKernelGGL((convh_group_kernel<0>), dim3(grid), dim3(CH_THREADS), 0, stream, g);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// The reference-precision form of ssdhip_conv3x3_halo_nhwc_bf16 (see ssdhip_conv2d_x3_nhwc_f16 for the arithmetic): x [B,H,W,2C]
+// float16 = [hi | lo], weight [Cout,3,3,3C] float16 = [w hi | w lo | w hi] of the float32 filters / oscale, bias float32, y
+// [B,Ho,Wo,2 Cout] float16 = [hi | lo] of act(oscale * sum + bias).  C % 128 == 0, Cout % 128 == 0.
+extern "C" int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C,
+                                               int Cout, int relu, int pool, float oscale, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || !(oscale > 0.f)) return SSDHIP_E_BADARG;
+    if (C <= 0 || (C % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 3)) return SSDHIP_E_BADARG;
+    const long long xb = (long long)B * H * W * 2 * C * 2, wb = (long long)Cout * 9 * 3 * C * 2;
+    const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
+    const long long yb = (long long)B * Ho * Wo * 2 * Cout * 2;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || yb >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
+    ConvHParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
+    p.y = static_cast<bf16_t*>(y);
+    p.H = H; p.W = W; p.Cin = 3 * C; p.Cout = Cout; p.relu = relu ? 1 : 0;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.HT = p.WT = 0;
+    p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
+    p.xC = 2 * C; p.nx = C / 64; p.bias32 = bias; p.oscale = oscale;
+    int geom = 0;
+    if (pool || W > 94) {
+        long long best = -1;
+        for (int csh = 4; csh <= 5; ++csh) {
+            const long long wt = (W + (1 << csh) - 1) >> csh, ht = (H + (256 >> csh) - 1) / (256 >> csh);
+            if (best < 0 || wt * ht < best) { best = wt * ht; geom = csh; p.WT = (int)wt; p.HT = (int)ht; }
+        }
+        const long long tiles = (long long)B * p.HT * p.WT;
+        if (tiles > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        p.Q = 0;
+        p.q_tiles = (int)tiles;
+    } else {
+        const long long Q = (long long)B * (H + 1) * (W + 1);
+        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        p.Q = (int)Q;
+        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+    }
+    p.n_tiles = Cout / CH_BM;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)yb;
+    p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+    convh_launch<128, true>(p, geom, pool, convh_cu_count(), stream);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

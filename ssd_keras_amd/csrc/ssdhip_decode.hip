@@ -253,6 +253,113 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
     scan_tile_body(tile, wave_cnt, p, b, a0, na, boxes, cand, cand_count, cls_out);
 }
 
+// K3 for WIDE rows (C + 12 > 64 floats: SSD512 / COCO's 93).  scan_kernel stages whole rows: 64 rows x 93 floats = 24 KB per wave, six
+// one-wave workgroups per CU -- too few waves to hide the copy -> ballots -> atomic -> store chain (143 us = 1.0 TB/s at batch 16,
+// r02k).  Here a wave stages its 64 rows one 32-column WINDOW at a time (8.4 KB per wave, 20 waves per CU) and finishes a window's
+// classes before the next one comes in: ballots and counts, ONE returning atomic per (wave, class) from the lane that holds the class,
+// then the keys.  The windows are counted from the end of the row, so the last one always holds the 12 box columns.  Same candidate
+// lists as scan_kernel up to the order of their entries (K4 sorts by key).  Per-class semantics only (the class-agnostic mode keeps
+// scan_kernel).
+constexpr int SW_WAVES = 4, SW_CW = 32, SW_PITCH = SW_CW + 1;
+__global__ __launch_bounds__(SW_WAVES * 64) void scan_wide_kernel(const float* __restrict__ y, DecodeParams p, float4* __restrict__ boxes,
+                                                                  u64* __restrict__ cand, int* __restrict__ cand_count) {
+    __shared__ float win_all[SW_WAVES][64 * SW_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int a0 = ((int)blockIdx.x * SW_WAVES + wave) * 64;
+    if (a0 >= p.N) return;                                   // whole wave (no workgroup barrier in this kernel)
+    const int na = min(64, p.N - a0);
+    float* win = win_all[wave];
+    const int L = p.L, C = p.C, G = p.G;
+    const float* src = y + ((size_t)b * p.N + a0) * (size_t)L;
+    const float t = p.thr_eff;
+    const bool incl = p.thr_inclusive != 0;
+    const bool active = lane < na;
+    const u32 inv_idx = IDX_MASK - (u32)(a0 + lane);
+    const int nwin = (L + SW_CW - 1) / SW_CW;
+    for (int wi = nwin - 1; wi >= 0; --wi) {
+        // window wi covers columns [c_lo, c_hi): the last one is [L - 32, L), the one before [L - 64, L - 32), ... the first may be short
+        const int c_hi = L - (nwin - 1 - wi) * SW_CW, c_lo = max(0, c_hi - SW_CW), cw = c_hi - c_lo;
+        // copy: two rows of the window per instruction (each a contiguous run of cw floats)
+        {
+            const int c = lane & 31, rh = lane >> 5;
+#pragma unroll
+            for (int r0 = 0; r0 < 64; r0 += 16) {             // eight loads in flight per trip
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + 2 * u + rh;
+                    v[u] = (r < na && c < cw) ? src[(size_t)r * L + c_lo + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) win[(r0 + 2 * u + rh) * SW_PITCH + c] = v[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const float* row = win + lane * SW_PITCH;
+        if (wi == nwin - 1 && active) {                      // the box columns: the last 12 of the row
+            const float* q = row + (cw - 12);
+            const float o0 = q[0], o1 = q[1], o2 = q[2], o3 = q[3];
+            const float a_0 = q[4], a_1 = q[5], a_2 = q[6], a_3 = q[7];
+            const float v0 = q[8], v1 = q[9], v2 = q[10], v3 = q[11];
+            float4 box;
+            if (p.coords == SSDHIP_CENTROIDS) {
+                float cx, cy;
+                if (p.semantics == SSDHIP_SEM_KERAS) {
+                    cx = decode_center<SSDHIP_SEM_KERAS>(o0, v0, a_2, a_0);
+                    cy = decode_center<SSDHIP_SEM_KERAS>(o1, v1, a_3, a_1);
+                } else if (p.semantics == SSDHIP_SEM_DEBUG) {
+                    cx = decode_center<SSDHIP_SEM_DEBUG>(o0, v0, a_2, a_0);
+                    cy = decode_center<SSDHIP_SEM_DEBUG>(o1, v1, a_3, a_1);
+                } else {
+                    cx = decode_center<SSDHIP_SEM_NUMPY>(o0, v0, a_2, a_0);
+                    cy = decode_center<SSDHIP_SEM_NUMPY>(o1, v1, a_3, a_1);
+                }
+                const float w = det_expf(o2 * v2) * a_2;
+                const float h = det_expf(o3 * v3) * a_3;
+                const float hw = w / 2.0f, hh = h / 2.0f;
+                box = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+            } else if (p.coords == SSDHIP_MINMAX) {
+                const float aw = a_1 - a_0, ah = a_3 - a_2;
+                const float t0 = (o0 * v0) * aw + a_0, t1 = (o1 * v1) * aw + a_1;
+                const float t2 = (o2 * v2) * ah + a_2, t3 = (o3 * v3) * ah + a_3;
+                box = make_float4(t0, t2, t1, t3);
+            } else {
+                const float aw = a_2 - a_0, ah = a_3 - a_1;
+                box = make_float4((o0 * v0) * aw + a_0, (o1 * v1) * ah + a_1, (o2 * v2) * aw + a_2, (o3 * v3) * ah + a_3);
+            }
+            boxes[(size_t)b * p.N + a0 + lane] = box;
+        }
+        // classes of this window: columns [max(c_lo, 1), min(c_hi, C)) -> groups g = column - 1; lane j keeps the count of class j
+        const int k_lo = max(c_lo, 1), k_hi = min(c_hi, C), nk = k_hi - k_lo;
+        if (nk > 0) {
+            int mycnt = 0;
+            for (int j = 0; j < nk; ++j) {
+                const float sc = row[k_lo - c_lo + j];
+                const bool pr = active && (incl ? (sc >= t) : (sc > t));
+                const int cnt = __popcll(__ballot(pr));
+                mycnt = lane == j ? cnt : mycnt;
+            }
+            int mybase = 0;
+            if (lane < nk && mycnt) mybase = atomicAdd(&cand_count[b * G + (k_lo - 1) + lane], mycnt);
+            for (int j = 0; j < nk; ++j) {
+                const float sc = row[k_lo - c_lo + j];
+                const bool pr = active && (incl ? (sc >= t) : (sc > t));
+                const u64 m = __ballot(pr);
+                if (m == 0) continue;
+                const int base_j = __builtin_amdgcn_readlane(mybase, j);
+                if (pr) {
+                    const int slot = base_j + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    cand[((size_t)b * G + (k_lo - 1) + j) * p.N + slot] = ((u64)float_key(sc) << IDX_BITS) | inv_idx;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();                    // the window is rewritten by the next trip
+    }
+}
+
 // K3 fused with the prediction assembly: the [C+12]-float rows are built in LDS straight from the predictor
 // heads' bf16 outputs (bias, softmax, anchors: head_build_rows) and decoded / thresholded at once -- y_pred (36.9 MB at
 // SSD300 / batch 32, a quarter of it the constant anchor + variance columns) is neither written nor read back.
@@ -1346,6 +1453,10 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
         if (lds > 160 * 1024) return SSDHIP_E_BADARG;
         hipLaunchKernelGGL(scan_heads_kernel, dim3(heads->tiles, B), dim3(HT < 64 ? 64 : HT), lds, stream, *heads->hp,
                            heads->anchors_var, p, boxes, cand, cand_count, cls_map);
+    } else if (p.L > 64 && !p.class_agnostic) {
+        // rows wider than 64 floats (SSD512 / COCO): the windowed kernel keeps 20 waves per CU in flight instead of 6
+        dim3 g3((N + SW_WAVES * 64 - 1) / (SW_WAVES * 64), B);
+        hipLaunchKernelGGL(scan_wide_kernel, g3, dim3(SW_WAVES * 64), 0, stream, static_cast<const float*>(y_pred), p, boxes, cand, cand_count);
     } else {
         dim3 g3((N + TA - 1) / TA, B);
         hipLaunchKernelGGL(scan_kernel, g3, dim3(TA), k3_lds, stream, static_cast<const float*>(y_pred), p, boxes, cand,

@@ -104,10 +104,8 @@ __global__ __launch_bounds__(ENC_THREADS) void rowmax_kernel(EncodeParams p, con
                                                              double* __restrict__ part_val, int* __restrict__ part_col) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     GtBox* gts = reinterpret_cast<GtBox*>(smem_raw);
-    __shared__ double wv[ENC_THREADS / 64];
-    __shared__ int wc[ENC_THREADS / 64];
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g0 = gt_off[b], g = gt_off[b + 1] - g0;
+    const int g0 = gt_off[b], g = min(gt_off[b + 1] - g0, p.max_gt);   // the LDS tables hold max_gt boxes: never index beyond them
     if (g <= 0) return;
     for (int r = tid; r < g; r += ENC_THREADS) load_gt(gts[r], gt + (size_t)(g0 + r) * 5, p);
     __syncthreads();
@@ -115,21 +113,18 @@ __global__ __launch_bounds__(ENC_THREADS) void rowmax_kernel(EncodeParams p, con
     const bool active = n < p.N;
     PxBox<double> an = {};
     if (active) an = load_anchor_view(anchors, n, p);
+    // per WAVE partial maxima (part_* [row][tile][wave]): no workgroup combine, no barrier per row -- the matching kernel reduces
+    // the tiles x 4 partials of a row with one wave
+    const size_t pw = (size_t)p.tiles * (ENC_THREADS / 64);
     for (int r = 0; r < g; ++r) {
         double v = -1.0;                           // IoU >= 0, so inactive lanes never win
         int c = 0x7fffffff;
         if (active) { v = iou_px<double>(gts[r].cr, an); c = n; }
         wave_argmax(v, c);
-        if (lane == 0) { wv[wave] = v; wc[wave] = c; }
-        __syncthreads();
-        if (tid == 0) {
-            double bv = wv[0];
-            int bc = wc[0];
-            for (int w = 1; w < ENC_THREADS / 64; ++w) if (better(wv[w], wc[w], bv, bc)) { bv = wv[w]; bc = wc[w]; }
-            part_val[(size_t)(g0 + r) * p.tiles + tile] = bv;
-            part_col[(size_t)(g0 + r) * p.tiles + tile] = bc;
+        if (lane == 0) {
+            part_val[(size_t)(g0 + r) * pw + tile * (ENC_THREADS / 64) + wave] = v;
+            part_col[(size_t)(g0 + r) * pw + tile * (ENC_THREADS / 64) + wave] = c;
         }
-        __syncthreads();
     }
 }
 
@@ -143,6 +138,57 @@ __global__ __launch_bounds__(ENC_THREADS) void rowmax_kernel(EncodeParams p, con
 // Quirks kept: an all-zero row yields column 0, and once everything left is zero GT 0 is re-assigned anchor 0.
 constexpr int MATCH_THREADS = 1024;
 
+// The g sequential rounds of match_bipartite_greedy on the row maxima (match_kernel's second half); all
+// MATCH_THREADS threads of the workgroup call it.  wv / wc: NW-entry LDS scratch, pick_col: one LDS int.
+__device__ __forceinline__ void match_rounds(const EncodeParams& p, const double* __restrict__ anchors, const int g, const GtBox* gts,
+                                             double* rowval, int* rowcol, int* match, int* rowgone, u32* colgone, double* wv, int* wc,
+                                             int* pick_col_p) {
+    constexpr int NW = MATCH_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int round = 0; round < g; ++round) {
+        // the largest remaining entry: first argmax over rows of the per-row first argmax (:63-68)
+        if (wave == 0) {
+            double bv = -1.0;
+            int br = 0x7fffffff;
+            for (int r = lane; r < g; r += 64) {
+                const double v = rowgone[r] ? 0.0 : rowval[r];
+                if (better(v, r, bv, br)) { bv = v; br = r; }
+            }
+            wave_argmax(bv, br);
+            if (lane == 0) {
+                const int col = rowgone[br] ? 0 : rowcol[br];
+                *pick_col_p = col;
+                match[br] = col;
+                rowgone[br] = 1;
+                colgone[col >> 5] |= 1u << (col & 31);
+            }
+        }
+        __syncthreads();
+        const int col = *pick_col_p;
+        // rows that pointed at the column just taken need a new maximum
+        for (int r = 0; r < g; ++r) {
+            if (rowgone[r] || rowcol[r] != col || !(rowval[r] > 0.0)) continue;      // uniform across the block
+            double bv = -1.0;
+            int bc = 0x7fffffff;
+            for (int n = tid; n < p.N; n += MATCH_THREADS) {
+                double v = 0.0;
+                if (!((colgone[n >> 5] >> (n & 31)) & 1u)) v = iou_px<double>(gts[r].cr, load_anchor_view(anchors, n, p));
+                if (v > bv) { bv = v; bc = n; }
+            }
+            wave_argmax(bv, bc);
+            if (lane == 0) { wv[wave] = bv; wc[wave] = bc; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; ++w) if (better(wv[w], wc[w], bv, bc)) { bv = wv[w]; bc = wc[w]; }
+                if (!(bv > 0.0)) bc = 0;
+                rowval[r] = bv; rowcol[r] = bc;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(EncodeParams p, const double* __restrict__ anchors,
                                                               const double* __restrict__ gt, const int* __restrict__ gt_off,
                                                               const double* __restrict__ part_val, const int* __restrict__ part_col,
@@ -150,7 +196,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(EncodeParams p, co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NW = MATCH_THREADS / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g0 = gt_off[b], g = gt_off[b + 1] - g0;
+    const int g0 = gt_off[b], g = min(gt_off[b + 1] - g0, p.max_gt);   // the LDS tables hold max_gt boxes: never index beyond them
     if (g <= 0) return;
     GtBox* gts = reinterpret_cast<GtBox*>(smem_raw);                               // [max_gt]
     double* rowval = reinterpret_cast<double*>(gts + p.max_gt);                    // [max_gt]
@@ -167,61 +213,26 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(EncodeParams p, co
     __syncthreads();
 
     // ---- first arg-max of every row over all anchors: the best of the per-tile maxima (rowmax_kernel) ----
-    for (int r = tid; r < g; r += MATCH_THREADS) {
-        double bv = -1.0;
-        int bc = 0x7fffffff;
-        for (int t = 0; t < p.tiles; ++t) {
-            const double v = part_val[(size_t)(g0 + r) * p.tiles + t];
-            const int c = part_col[(size_t)(g0 + r) * p.tiles + t];
-            if (better(v, c, bv, bc)) { bv = v; bc = c; }
+    {
+        const int pw = p.tiles * (ENC_THREADS / 64);                               // partials per row (rowmax_kernel: [tile][wave])
+        for (int r = wave; r < g; r += NW) {                                        // one wave per row: the loads of a row go out together
+            double bv = -1.0;
+            int bc = 0x7fffffff;
+            for (int t = lane; t < pw; t += 64) {
+                const double v = part_val[(size_t)(g0 + r) * pw + t];
+                const int c = part_col[(size_t)(g0 + r) * pw + t];
+                if (better(v, c, bv, bc)) { bv = v; bc = c; }
+            }
+            wave_argmax(bv, bc);
+            if (lane == 0) {
+                if (!(bv > 0.0)) bc = 0;                                            // np.argmax of an all-zero row
+                rowval[r] = bv; rowcol[r] = bc;
+            }
         }
-        if (!(bv > 0.0)) bc = 0;                                                    // np.argmax of an all-zero row
-        rowval[r] = bv; rowcol[r] = bc;
     }
     __syncthreads();
 
-    for (int round = 0; round < g; ++round) {
-        // the largest remaining entry: first argmax over rows of the per-row first argmax (:63-68)
-        if (wave == 0) {
-            double bv = -1.0;
-            int br = 0x7fffffff;
-            for (int r = lane; r < g; r += 64) {
-                const double v = rowgone[r] ? 0.0 : rowval[r];
-                if (better(v, r, bv, br)) { bv = v; br = r; }
-            }
-            wave_argmax(bv, br);
-            if (lane == 0) {
-                const int col = rowgone[br] ? 0 : rowcol[br];
-                pick_col = col;
-                match[br] = col;
-                rowgone[br] = 1;
-                colgone[col >> 5] |= 1u << (col & 31);
-            }
-        }
-        __syncthreads();
-        const int col = pick_col;
-        // rows that pointed at the column just taken need a new maximum
-        for (int r = 0; r < g; ++r) {
-            if (rowgone[r] || rowcol[r] != col || !(rowval[r] > 0.0)) continue;      // uniform across the block
-            double bv = -1.0;
-            int bc = 0x7fffffff;
-            for (int n = tid; n < p.N; n += MATCH_THREADS) {
-                double v = 0.0;
-                if (!((colgone[n >> 5] >> (n & 31)) & 1u)) v = iou_px<double>(gts[r].cr, load_anchor_view(anchors, n, p));
-                if (v > bv) { bv = v; bc = n; }
-            }
-            wave_argmax(bv, bc);
-            if (lane == 0) { wv[0][wave] = bv; wc[0][wave] = bc; }
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < NW; ++w) if (better(wv[0][w], wc[0][w], bv, bc)) { bv = wv[0][w]; bc = wc[0][w]; }
-                if (!(bv > 0.0)) bc = 0;
-                rowval[r] = bv; rowcol[r] = bc;
-            }
-            __syncthreads();
-        }
-        __syncthreads();
-    }
+    match_rounds(p, anchors, g, gts, rowval, rowcol, match, rowgone, colgone, &wv[0][0], &wc[0][0], &pick_col);
     for (int r = tid; r < g; r += MATCH_THREADS) matches[g0 + r] = match[r];
 }
 
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(ENC_THREADS) void finalize_kernel(EncodeParams p, c
     const int a0 = blockIdx.x * TA;
     const int na = min(TA, p.N - a0);
     const int L = p.L, C = p.C;
-    const int g0 = gt_off[b], g = gt_off[b + 1] - g0;
+    const int g0 = gt_off[b], g = min(gt_off[b + 1] - g0, p.max_gt);   // the LDS tables hold max_gt boxes: never index beyond them
     const size_t base = ((size_t)b * p.N + a0) * (size_t)L;
     // the LDS image keeps the 16-byte phase of the float32 destination, so that whole uint4 chunks can be copied out
     const int phase = (sizeof(TileT) == 4 && y32) ? (int)((((uintptr_t)(y32 + base)) & 15u) >> 2) : 0;
@@ -348,8 +359,8 @@ static EncodeWs encode_ws_layout(int B, int N, int G_total) {
     const size_t tiles = (size_t)(N + ENC_THREADS - 1) / ENC_THREADS;
     EncodeWs w;
     size_t o = 0;
-    w.part_val = o; o = enc_align(o + G * tiles * sizeof(double));
-    w.part_col = o; o = enc_align(o + G * tiles * sizeof(int));
+    w.part_val = o; o = enc_align(o + G * tiles * (ENC_THREADS / 64) * sizeof(double));      // per-wave partial row maxima
+    w.part_col = o; o = enc_align(o + G * tiles * (ENC_THREADS / 64) * sizeof(int));
     w.matches = o;  o = enc_align(o + G * sizeof(int));
     w.total = o;
     return w;

@@ -58,19 +58,47 @@ __device__ __forceinline__ void head_build_rows(const HeadParams& hp, const floa
         for (int i = tid; i < na * C; i += nthreads) cl[i] = csrc[i];
         for (int i = tid; i < na * 4; i += nthreads) ll[i] = lsrc[i];
     } else {                                                                            // heads packed into one wider conv output
+        // element i = (anchor a0 + i / C, class i % C) = (pixel, box, class): the three indices advance by constant steps with
+        // carries -- four integer divisions per ELEMENT (~150 instructions, 21 trips per thread) made this loop the bulk of the
+        // kernel (58 us in the step, r02z)
         const size_t px0 = (size_t)b * (hp.n_anchors[l] / nb);
-        for (int i = tid; i < na * C; i += nthreads) {
-            const int ga = a0 + i / C, c = i % C;
-            cl[i] = hp.conf[l][(px0 + ga / nb) * hp.conf_stride[l] + (ga % nb) * C + c];
+        {
+            const int step_a = nthreads / C, step_c = nthreads - step_a * C;
+            int c = tid % C;
+            const int ga0 = a0 + tid / C;
+            int pix = ga0 / nb, box = ga0 - pix * nb;
+            const hbf16_t* src = hp.conf[l] + px0 * hp.conf_stride[l];
+            const int cs = hp.conf_stride[l];
+            const int q0 = step_a / nb, r0 = step_a - q0 * nb, q1 = (step_a + 1) / nb, r1 = step_a + 1 - q1 * nb;   // anchors -> (pixels, boxes)
+            for (int i = tid; i < na * C; i += nthreads) {
+                cl[i] = src[(size_t)pix * cs + box * C + c];
+                c += step_c;
+                const bool carry = c >= C;
+                c -= carry ? C : 0;
+                box += carry ? r1 : r0;
+                pix += carry ? q1 : q0;
+                if (box >= nb) { box -= nb; ++pix; }
+            }
         }
-        for (int i = tid; i < na * 4; i += nthreads) {
-            const int ga = a0 + (i >> 2), k = i & 3;
-            ll[i] = hp.loc[l][(px0 + ga / nb) * hp.loc_stride[l] + (ga % nb) * 4 + k];
+        {
+            const int step_a = nthreads >> 2;                                           // nthreads is a multiple of 64
+            const int k = tid & 3;
+            const int ga0 = a0 + (tid >> 2);
+            int pix = ga0 / nb, box = ga0 - pix * nb;
+            const hbf16_t* src = hp.loc[l] + px0 * hp.loc_stride[l];
+            const int ls = hp.loc_stride[l];
+            const int q0 = step_a / nb, r0 = step_a - q0 * nb;
+            for (int i = tid; i < na * 4; i += nthreads) {
+                ll[i] = src[(size_t)pix * ls + box * 4 + k];
+                box += r0;
+                pix += q0;
+                if (box >= nb) { box -= nb; ++pix; }
+            }
         }
     }
     __syncthreads();
     for (int a = tid; a < na; a += nthreads) {
-        const int box = (a0 + a) % nb;
+        const int box = (a0 + a) % nb;                        // (one division per row)
         float* r = rows + (size_t)a * L;
         const hbf16_t* cb = hp.conf_bias[l] ? hp.conf_bias[l] + box * C : nullptr;
         float mx = -INFINITY;

@@ -135,6 +135,163 @@ extern "C" int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, voi
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
+namespace ssdhip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// L2Normalization (keras_layers/keras_layer_L2Normalization.py:61-63) for the float32 model and the training step: forward with the
+// pixel's inverse norm saved, backward in one pass.  One wave per pixel, float32 math; T = float (4 channels per 16 bytes) or bf16
+// (8 channels).  With inv = rsqrt(max(s, 1e-12)), s = sum_c x_c^2:
+//     y_c  = x_c inv gamma_c
+//     dx_c = inv gamma_c dy_c - x_c inv^3 sum_k(dy_k gamma_k x_k)        (the second term only where s >= 1e-12: a clamped norm is a constant)
+//     dgamma_c = sum over pixels of dy_c x_c inv                          (per-wave partial sums, added in a fixed order by the caller)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int L2_MAXIT = 8;                                  // channel vectors per lane: C <= 64 * 8 * (4 | 8)
+
+template <bool BF16>
+__device__ __forceinline__ void l2_load(const void* base, size_t vec, float (&v)[8]) {
+    if constexpr (BF16) {
+        const uint4 r = reinterpret_cast<const uint4*>(base)[vec];
+        const u32 w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = tb2f(w[q] & 0xffffu); v[2 * q + 1] = tb2f(w[q] >> 16); }
+    } else {
+        const float4 r = reinterpret_cast<const float4*>(base)[vec];
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+        v[4] = v[5] = v[6] = v[7] = 0.f;
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void l2_store(void* base, size_t vec, const float (&v)[8]) {
+    if constexpr (BF16)
+        reinterpret_cast<uint4*>(base)[vec] = make_uint4(tf2b(v[0]) | (tf2b(v[1]) << 16), tf2b(v[2]) | (tf2b(v[3]) << 16),
+                                                         tf2b(v[4]) | (tf2b(v[5]) << 16), tf2b(v[6]) | (tf2b(v[7]) << 16));
+    else
+        reinterpret_cast<float4*>(base)[vec] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma, void* __restrict__ y,
+                                                         float* __restrict__ inv_out, u32 n_pixels, u32 cvec) {
+    constexpr int CPV = BF16 ? 8 : 4;
+    const u32 lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (u32 px = wave; px < n_pixels; px += nwaves) {
+        float ss = 0.f;
+        for (u32 j = lane; j < cvec; j += 64u) {
+            float v[8];
+            l2_load<BF16>(x, (size_t)px * cvec + j, v);
+#pragma unroll
+            for (int e = 0; e < CPV; ++e) ss += v[e] * v[e];
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        if (lane == 0 && inv_out) inv_out[px] = inv;
+        for (u32 j = lane; j < cvec; j += 64u) {
+            float v[8], o[8];
+            l2_load<BF16>(x, (size_t)px * cvec + j, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = e < CPV ? (v[e] * inv) * gamma[j * CPV + e] : 0.f;
+            l2_store<BF16>(y, (size_t)px * cvec + j, o);
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, const float* __restrict__ gamma,
+                                                         const float* __restrict__ inv_in, void* __restrict__ dx,
+                                                         float* __restrict__ dgamma_partial, u32 n_pixels, u32 cvec) {
+    constexpr int CPV = BF16 ? 8 : 4;
+    const u32 lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    float dg[L2_MAXIT][8];
+#pragma unroll
+    for (int it = 0; it < L2_MAXIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[it][e] = 0.f;
+    for (u32 px = wave; px < n_pixels; px += nwaves) {
+        const float inv = inv_in[px];
+        float dot = 0.f;                                     // sum_k dy_k gamma_k x_k
+#pragma unroll
+        for (int it = 0; it < L2_MAXIT; ++it) {
+            const u32 j = lane + 64u * it;
+            if (j < cvec) {
+                float xv[8], gv[8];
+                l2_load<BF16>(x, (size_t)px * cvec + j, xv);
+                l2_load<BF16>(dy, (size_t)px * cvec + j, gv);
+#pragma unroll
+                for (int e = 0; e < CPV; ++e) {
+                    dot += (gv[e] * gamma[j * CPV + e]) * xv[e];
+                    dg[it][e] += (gv[e] * xv[e]) * inv;
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        // inv = rsqrt(max(s, 1e-12)): the norm is a constant (1e6) where it was clamped
+        const float k3 = inv < 0.999e6f ? (inv * inv) * inv * dot : 0.f;
+#pragma unroll
+        for (int it = 0; it < L2_MAXIT; ++it) {
+            const u32 j = lane + 64u * it;
+            if (j < cvec) {
+                float xv[8], gv[8], o[8];
+                l2_load<BF16>(x, (size_t)px * cvec + j, xv);
+                l2_load<BF16>(dy, (size_t)px * cvec + j, gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = e < CPV ? (inv * gamma[j * CPV + e]) * gv[e] - xv[e] * k3 : 0.f;
+                l2_store<BF16>(dx, (size_t)px * cvec + j, o);
+            }
+        }
+    }
+    // this wave's share of dgamma: row `wave` of dgamma_partial [n_waves][C]
+#pragma unroll
+    for (int it = 0; it < L2_MAXIT; ++it) {
+        const u32 j = lane + 64u * it;
+        if (j < cvec)
+#pragma unroll
+            for (int e = 0; e < CPV; ++e) dgamma_partial[(size_t)wave * (cvec * CPV) + j * CPV + e] = dg[it][e];
+    }
+}
+
+}  // namespace ssdhip
+
+// Waves (= rows of dgamma_partial) the backward launches for n_pixels pixels; 0: shape not supported.
+extern "C" int ssdhip_l2_normalize_bwd_waves(long long n_pixels, int C, int is_bf16) {
+    const int cpv = is_bf16 ? 8 : 4;
+    if (n_pixels <= 0 || n_pixels > 0x7fffffffLL || C <= 0 || (C % cpv) || C / cpv > 64 * ssdhip::L2_MAXIT) return 0;
+    long long blocks = (n_pixels + 4 * 16 - 1) / (4 * 16);            // >= 16 pixels per wave
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks * 4;
+}
+
+extern "C" int ssdhip_l2_normalize_fwd(const void* x, const float* gamma, void* y, float* inv_norm, long long n_pixels, int C, int is_bf16,
+                                       void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int cpv = is_bf16 ? 8 : 4;
+    if (!x || !gamma || !y || n_pixels <= 0 || n_pixels > 0x7fffffffLL || C <= 0 || (C % cpv)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    long long blocks = (n_pixels + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    if (is_bf16)
+        hipLaunchKernelGGL(l2norm_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, gamma, y, inv_norm, (u32)n_pixels, (u32)(C / cpv));
+    else
+        hipLaunchKernelGGL(l2norm_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, gamma, y, inv_norm, (u32)n_pixels, (u32)(C / cpv));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_l2_normalize_bwd(const void* x, const void* dy, const float* gamma, const float* inv_norm, void* dx,
+                                       float* dgamma_partial, int n_waves, long long n_pixels, int C, int is_bf16, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !dy || !gamma || !inv_norm || !dx || !dgamma_partial) return SSDHIP_E_BADARG;
+    if (n_waves <= 0 || n_waves != ssdhip_l2_normalize_bwd_waves(n_pixels, C, is_bf16)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return SSDHIP_E_BADARG;
+    const int cpv = is_bf16 ? 8 : 4;
+    if (is_bf16)
+        hipLaunchKernelGGL(l2norm_bwd_kernel<true>, dim3(n_waves / 4), dim3(256), 0, stream, x, dy, gamma, inv_norm, dx, dgamma_partial,
+                           (u32)n_pixels, (u32)(C / cpv));
+    else
+        hipLaunchKernelGGL(l2norm_bwd_kernel<false>, dim3(n_waves / 4), dim3(256), 0, stream, x, dy, gamma, inv_norm, dx, dgamma_partial,
+                           (u32)n_pixels, (u32)(C / cpv));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 extern "C" int ssdhip_maxpool_bwd_nhwc_bf16(const void* x, const void* gy, void* gx, int B, int H, int W, int C, int kernel, int stride,
                                             int pad, int Ho, int Wo, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);

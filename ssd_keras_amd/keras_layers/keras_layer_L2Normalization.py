@@ -10,6 +10,25 @@ import torch
 from torch import nn
 
 
+class _L2NormFn(torch.autograd.Function):
+    """float32 / bf16 maps on a GPU, with or without gradients: one libssdhip pass forward (the pixel's inverse norm is kept), one
+    backward (csrc/ssdhip_train.hip) -- instead of seven elementwise / reduction kernels each way."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        from .. import _native as nat
+        y, inv = nat.l2_normalize_fwd(x, gamma, want_inv=True)
+        ctx.save_for_backward(x, gamma, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _native as nat
+        x, gamma, inv = ctx.saved_tensors
+        dx, dgamma = nat.l2_normalize_bwd(x, dy, gamma, inv)
+        return dx, dgamma.to(gamma.dtype)
+
+
 class L2Normalization(nn.Module):
     def __init__(self, gamma_init=20, n_channels=None, **kwargs):
         super().__init__()
@@ -28,6 +47,10 @@ class L2Normalization(nn.Module):
                 and x.shape[1] % 8 == 0):
             from .. import _native as nat          # one pass in libssdhip (csrc/ssdhip_layers.hip) instead of seven kernels
             return nat.l2_normalize(x, self.gamma)
+        if self.fused_inference and x.is_cuda and x.dim() == 4:
+            from .. import _native as nat
+            if nat.l2_normalize_supported(x):               # the float32 model, and the training step in either dtype
+                return _L2NormFn.apply(x, self.gamma)
         xf = x.float()
         inv = torch.rsqrt(torch.clamp_min((xf * xf).sum(dim=1, keepdim=True), 1e-12))
         return (xf * inv * self.gamma.view(1, -1, 1, 1)).to(x.dtype)

@@ -47,12 +47,12 @@ class PreciseForward:
         return self._pack(id(conv), [conv.weight] + ([conv.bias] if conv.bias is not None else []), build)
 
     def _head_filters(self, l):
-        """conf and loc filters of predictor layer l packed along Cout, zero rows up to a multiple of 64 (one launch per source map)."""
+        """conf and loc filters of predictor layer l packed along Cout, zero rows up to a multiple of 128 (one launch per source map)."""
         ch, lh = self.model.conf_heads[l], self.model.loc_heads[l]
 
         def build():
             n = ch.out_channels + lh.out_channels
-            pad = (-n) % 64
+            pad = (-n) % 128                                  # a multiple of 128: the slab kernel's channel tile
             w = torch.cat([ch.weight, lh.weight] + ([ch.weight.new_zeros((pad,) + tuple(ch.weight.shape[1:]))] if pad else []), dim=0)
             b = torch.cat([ch.bias, lh.bias] + ([ch.bias.new_zeros((pad,))] if pad else []), dim=0).float().contiguous()
             pw, oscale = nat.x3_pack_weight(w)

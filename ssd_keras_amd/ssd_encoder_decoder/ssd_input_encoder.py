@@ -186,7 +186,9 @@ class SSDInputEncoder:
         `gt_d` float64 (n_gt, 5) rows `[class, xmin, ymin, xmax, ymax]` of all images concatenated, `off_d` int32 (batch + 1,)
         row offsets.  No host work, no PCIe traffic, nothing but `ssdhip_encode`'s two launches on the current stream; the caller
         vouches for the checks `encode_to_device` makes on the host (no degenerate boxes, class ids in range, <= 1024 boxes per
-        image).  Returns (y_f32 | None, y_f64 | None, match_gt | None).'''
+        image).  `max_gt_per_image` must be an UPPER bound of the per-image box counts in `off_d`: the kernels size their tables
+        with it and ignore an image's boxes beyond it (they never index past the tables; the targets of such an image are then
+        wrong, not the memory).  Returns (y_f32 | None, y_f64 | None, match_gt | None).'''
         import torch
         lib = nat.load()
         device = off_d.device

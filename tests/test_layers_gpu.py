@@ -60,6 +60,43 @@ def test_l2_normalize(env):
     assert torch.count_nonzero(nat.l2_normalize(z, gamma)) == 0
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_l2_normalization_forward_backward_kernels(env, dtype):
+    """L2Normalization for the float32 model and the training step (ssdhip_l2_normalize_fwd / _bwd): forward against the oracle
+    restatement of keras_layer_L2Normalization.py:61-63, gradients against autograd through the seven-operation float64 formulation;
+    clamped pixels (all-zero rows: the norm is the constant 1e-6) included."""
+    torch, F, nat = env
+    from oracle import np_oracle as orc
+    from ssd_keras_amd.keras_layers.keras_layer_L2Normalization import L2Normalization
+    dt = getattr(torch, dtype)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn((2, 512, 19, 38), generator=g, device="cuda") * 3.0).to(dt).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        x[0, :, 3, 5] = 0                                               # a clamped pixel
+    layer = L2Normalization(gamma_init=20, n_channels=512).cuda()
+    with torch.no_grad():
+        layer.gamma += torch.arange(512, device="cuda") * 0.01
+    xr = x.clone().requires_grad_(True)
+    y = layer(xr)
+    assert y.dtype == dt and y.shape == x.shape
+    want = orc.l2_normalization(x.permute(0, 2, 3, 1).float().cpu().numpy(), layer.gamma.detach().cpu().numpy())
+    tol = 2.0 ** -8 if dtype == "bfloat16" else 2e-6
+    np.testing.assert_allclose(y.detach().permute(0, 2, 3, 1).float().cpu().numpy(), want, rtol=tol, atol=1e-30)
+    w = torch.randn(x.shape, generator=g, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    (y.float() * w.float()).sum().backward()
+    # reference gradients: the plain formulation in float64
+    x64 = x.double().requires_grad_(True)
+    g64 = layer.gamma.detach().double().requires_grad_(True)
+    inv = torch.rsqrt(torch.clamp_min((x64 * x64).sum(dim=1, keepdim=True), 1e-12))
+    ((x64 * inv * g64.view(1, -1, 1, 1)) * w.double()).sum().backward()
+    gx, gg = xr.grad.double(), layer.gamma.grad.double()
+    ex = float((gx - x64.grad).abs().max() / x64.grad.abs().max())
+    eg = float((gg - g64.grad).abs().max() / g64.grad.abs().max())
+    assert ex < (1e-2 if dtype == "bfloat16" else 1e-5), ex              # bf16: dx is rounded to bf16
+    assert eg < (1e-2 if dtype == "bfloat16" else 1e-5), eg
+    assert bool(torch.isfinite(xr.grad).all())
+
+
 def test_preprocess(env):
     torch, F, nat = env
     img = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(2, 30, 41, 3)).astype(np.float32)).cuda()

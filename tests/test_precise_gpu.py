@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 CASES = [  # B, H, W, C, Cout, k, stride, pad, dil, relu, pool
     (2, 38, 38, 256, 512, 3, 1, 1, 1, True, False),
     (2, 75, 75, 128, 256, 3, 1, 1, 1, True, True),      # pooled, odd map ('same' pooling pads bottom / right)
+    (2, 150, 150, 128, 128, 3, 1, 1, 1, True, True),    # conv2_2 + pool2: 2-D tiles of the slab kernel
+    (2, 19, 19, 512, 512, 3, 1, 1, 1, False, False),    # conv5_x shape, no activation
     (2, 150, 150, 64, 128, 3, 1, 1, 1, True, False),
     (2, 19, 19, 512, 1024, 3, 1, 6, 6, True, False),    # fc6: dilation 6
     (2, 19, 19, 1024, 256, 1, 1, 0, 1, True, False),
@@ -23,8 +25,12 @@ CASES = [  # B, H, W, C, Cout, k, stride, pad, dil, relu, pool
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("out_f32", [False, True])
-def test_x3_convolution_is_float32_grade(case, out_f32):
+@pytest.mark.parametrize("halo", [True, False])
+def test_x3_convolution_is_float32_grade(case, out_f32, halo, monkeypatch):
+    """halo: the eligible cases (3x3, stride 1, 'same', C % 128 == 0) run on the slab kernel (ssdhip_conv3x3_halo_x3_nhwc_f16), the
+    others and halo = False on the implicit-GEMM kernel (ssdhip_conv2d_x3_nhwc_f16)."""
     import torch
+    monkeypatch.setenv("SSDHIP_X3_NO_HALO", "0" if halo else "1")
     import torch.nn.functional as F
     from ssd_keras_amd import _native as nat
     B, H, W, C, Cout, k, stride, pad, dil, relu, pool = case
