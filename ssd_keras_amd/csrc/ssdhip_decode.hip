@@ -1544,8 +1544,12 @@ extern "C" int ssdhip_decode_from_heads(int n_layers, const void* const* conf_h,
     HeadParams hp;
     HeadSource src;
     src.hp = &hp; src.anchors_var = anchors_var; src.tiles = 0;
+    size_t tile_lds = 60 * 1024;
+#if defined(SSDHIP_PROFILE)
+    if (const char* e = getenv("SSDHIP_HEADS_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 120) tile_lds = (size_t)v * 1024; }   // tile sweep
+#endif
     const int rc = head_fill_params(hp, n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h, conf_stride_h,
-                                    loc_stride_h, N, C, 60 * 1024, &src.tiles);
+                                    loc_stride_h, N, C, tile_lds, &src.tiles);
     if (rc != SSDHIP_OK) return rc;
     if (hp.TA < 64) return SSDHIP_E_BADARG;          // C too large for a one-thread-per-row tile
     return decode_run(&src, 7, nullptr, SSDHIP_F32, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,

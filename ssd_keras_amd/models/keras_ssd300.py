@@ -29,16 +29,22 @@ class _VGGBase(SSDModel):
         self.fc7 = nn.Conv2d(1024, 1024, 1)
         self.conv4_3_norm = L2Normalization(gamma_init=20, n_channels=512, name='conv4_3_norm')
 
-    def _vgg(self, x):
+    def _vgg_to_conv4_3(self, x):
         ca, cap = self.conv_act, self.conv_act_pool
         x = self.conv1_block_pool(self.conv1_1, self.conv1_2, x)                # conv1_1 -> conv1_2 -> pool1 ('same' pooling pads bottom/right)
         x = cap(self.conv2_2, ca(self.conv2_1, x), 2, 2, ceil_mode=True)
         x = cap(self.conv3_3, ca(self.conv3_2, ca(self.conv3_1, x)), 2, 2, ceil_mode=True)
-        conv4_3 = ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x)))
+        return ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x)))
+
+    def _vgg_from_conv4_3(self, conv4_3):
+        ca, cap = self.conv_act, self.conv_act_pool
         x = self.max_pool(conv4_3, 2, 2, ceil_mode=True)
         x = cap(self.conv5_3, ca(self.conv5_2, ca(self.conv5_1, x)), 3, 1, pad=1)
-        fc7 = ca(self.fc7, ca(self.fc6, x))
-        return conv4_3, fc7
+        return ca(self.fc7, ca(self.fc6, x))
+
+    def _vgg(self, x):
+        conv4_3 = self._vgg_to_conv4_3(x)
+        return conv4_3, self._vgg_from_conv4_3(conv4_3)
 
     @staticmethod
     def _vgg_sizes(n):
