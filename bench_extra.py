@@ -319,6 +319,12 @@ def fp32x3_forward_leg(dev, B, fp32_leg=None, reps=3):
                     aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"],
                     confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400).to(dev)
     model = model.to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():                                                    # the tamed heads of tests/test_precise_gpu.py: a raw
+        for head in model.conf_heads:                                        # He-init softmax is saturated (logits ~1e4), and two float32
+            head.weight.mul_(1e-3)                                           # forwards of it (CPU vs MIOpen) already differ by 4e-4
+            head.bias.view(-1, cfg["n_classes"] + 1)[:, 0] = 4.0
+        for head in model.loc_heads:
+            head.weight.mul_(1e-3)
     images = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
     pf = PreciseForward(model)
     with torch.cuda.device(dev), torch.no_grad():
@@ -338,8 +344,10 @@ def fp32x3_forward_leg(dev, B, fp32_leg=None, reps=3):
            "vs_framework_float32": {"max_abs_diff_class_probabilities": float(d[:, :, :C][finite[:, :, :C]].max().item()),
                                     "max_rel_diff_offsets": float(rel[:, :, C:][finite[:, :, C:]].max().item()),
                                     "non_finite_in_either": int((~finite).sum().item())},
-           "note": "every convolution but conv1_1 (three input channels: a float32 framework convolution) on the implicit-GEMM MFMA kernel "
-                   "(csrc/ssdhip_conv.hip, X3); pooling / L2Normalization / softmax glue in float32 PyTorch, eager launches"}
+           "note": "3x3 'same' convolutions with 128-multiple channels on the slab kernel (csrc/ssdhip_convh.hip, X3), the rest on the "
+                   "implicit-GEMM kernel (csrc/ssdhip_conv.hip, X3), conv1_1 (K = 27) float32 vector arithmetic (ssdhip_conv1_1_x3_nhwc); "
+                   "pool4 / pool5 / L2Normalization / softmax glue in float32 PyTorch, eager launches; parity flags on tamed heads "
+                   "(filters x 1e-3, background bias 4: an unsaturated softmax)"}
     if isinstance(fp32_leg, dict) and fp32_leg.get("images_per_sec"):
         out["speedup_over_miopen_float32"] = round(out["images_per_sec"] / fp32_leg["images_per_sec"], 3)
     return out

@@ -327,6 +327,16 @@ int ssdhip_conv2d_x3_nhwc_f16(const void* x, const void* weight, const float* bi
 int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
                                     int relu, int pool, float oscale, void* stream);
 
+/* The layers of the reference-precision path that are not 64-channel GEMMs (csrc/ssdhip_layers.hip):
+ * ssdhip_x3_split_nhwc    float32 [n_pixels, C] -> float16 [n_pixels, 2 C] = [hi | lo] (hi = fl16(v), lo = fl16(v - hi)); C % 8 == 0.
+ * ssdhip_x3_merge_nhwc    the inverse: float32 hi + lo.
+ * ssdhip_conv1_1_x3_nhwc  conv1_1 (models/keras_ssd300.py:274: Conv2D(64, (3, 3), padding='same', activation='relu') on the 3-channel
+ *                         image) in float32, x [B,H,W,3] float32, weight [64,3,3,3] float32 (co, kh, kw, ci), bias float32 [64] or
+ *                         NULL, y [B,H,W,128] float16 = [hi | lo]. */
+int ssdhip_x3_split_nhwc(const float* x, void* y, long long n_pixels, int C, void* stream);
+int ssdhip_x3_merge_nhwc(const void* x, float* y, long long n_pixels, int C, void* stream);
+int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const float* bias, void* y, int B, int H, int W, int relu, void* stream);
+
 size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,
                                             int ksplit);
 int ssdhip_conv2d_splitk_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,

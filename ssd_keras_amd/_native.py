@@ -633,10 +633,70 @@ def conv2d(x, weight, bias, stride=1, padding=0, dilation=1, relu=True, variant=
     return y
 
 
+def _x3_glue(lib):
+    if not getattr(lib, "_x3g_bound", False):
+        c_int, c_vp, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+        lib.ssdhip_x3_split_nhwc.restype = c_int
+        lib.ssdhip_x3_split_nhwc.argtypes = [c_vp, c_vp, c_ll, c_int, c_vp]
+        lib.ssdhip_x3_merge_nhwc.restype = c_int
+        lib.ssdhip_x3_merge_nhwc.argtypes = [c_vp, c_vp, c_ll, c_int, c_vp]
+        lib.ssdhip_conv1_1_x3_nhwc.restype = c_int
+        lib.ssdhip_conv1_1_x3_nhwc.argtypes = [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]
+        lib._x3g_bound = True
+    return lib
+
+
+def _nhwc_ok(t):
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def x3_merge(y2):
+    """float16 (B, 2C, H, W) channels_last [hi | lo] -> float32 (B, C, H, W) channels_last: hi + lo (exact), one pass."""
+    torch = _torch()
+    b, c2, h, w = y2.shape
+    c = c2 // 2
+    if not (y2.is_cuda and y2.dtype == torch.float16 and c % 8 == 0 and _nhwc_ok(y2)):
+        return y2[:, :c].float() + y2[:, c:].float()
+    lib = _x3_glue(load())
+    out = torch.empty((b, h, w, c), dtype=torch.float32, device=y2.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(y2.device):
+        rc = lib.ssdhip_x3_merge_nhwc(_ptr(y2), _ptr(out), b * h * w, c, current_stream_ptr(y2.device))
+    check(rc, "ssdhip_x3_merge_nhwc")
+    return out
+
+
+def conv1_1_x3(x, weight, bias, relu=True):
+    """conv1_1 of the reference-precision path: float32 (B, 3, H, W) channels_last images, float32 (64, 3, 3, 3) filters -> the split
+    float16 (B, 128, H, W) map (ssdhip_conv1_1_x3_nhwc)."""
+    torch = _torch()
+    lib = _x3_glue(load())
+    b, c, h, w = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and c == 3 and _nhwc_ok(x) and tuple(weight.shape) == (64, 3, 3, 3)):
+        raise SsdHipError("conv1_1_x3 takes float32 (B, 3, H, W) channels_last images and (64, 3, 3, 3) filters")
+    wk = weight.detach().float().permute(0, 2, 3, 1).contiguous()          # (co, kh, kw, ci)
+    bk = bias.detach().float().contiguous() if bias is not None else None
+    y = torch.empty((b, h, w, 128), dtype=torch.float16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv1_1_x3_nhwc(_ptr(x), _ptr(wk), _ptr(bk), _ptr(y), b, h, w, int(bool(relu)), current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv1_1_x3_nhwc")
+    return y
+
+
 def x3_split(v):
     """float32 (B, C, H, W) in channels_last memory -> float16 (B, 2C, H, W) channels_last = [hi | lo], hi = fl16(v), lo = fl16(v - hi):
     the activation layout of conv2d_x3."""
     torch = _torch()
+    if v.is_cuda and v.dtype == torch.float32 and v.dim() == 4 and v.shape[1] % 8 == 0:
+        if not _nhwc_ok(v):
+            v = v.contiguous(memory_format=torch.channels_last)
+        if _nhwc_ok(v):
+            lib = _x3_glue(load())
+            b, c, h, w = v.shape
+            out = torch.empty((b, h, w, 2 * c), dtype=torch.float16, device=v.device).permute(0, 3, 1, 2)
+            with torch.cuda.device(v.device):
+                rc = lib.ssdhip_x3_split_nhwc(_ptr(v), _ptr(out), b * h * w, c, current_stream_ptr(v.device))
+            check(rc, "ssdhip_x3_split_nhwc")
+            return out
     hi = v.to(torch.float16)
     lo = (v - hi.float()).to(torch.float16)
     return torch.cat([hi, lo], dim=1).contiguous(memory_format=torch.channels_last)
@@ -696,7 +756,7 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
             rc = lib.ssdhip_conv3x3_halo_x3_nhwc_f16(_ptr(x2), _ptr(packed_weight), _ptr(bias), _ptr(y2), b, h, w, c, cout, int(bool(relu)),
                                                      int(bool(pool)), ctypes.c_float(float(oscale)), current_stream_ptr(x2.device))
         check(rc, "ssdhip_conv3x3_halo_x3_nhwc_f16")
-        return (y2[:, :cout].float() + y2[:, cout:].float()) if out_f32 else y2
+        return x3_merge(y2) if out_f32 else y2
     y = (torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x2.device) if out_f32 else
          torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device)).permute(0, 3, 1, 2)
     with torch.cuda.device(x2.device):

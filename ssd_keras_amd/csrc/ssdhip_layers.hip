@@ -228,6 +228,159 @@ extern "C" int ssdhip_l2_normalize_nhwc_bf16(const void* x, const float* gamma, 
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
+namespace ssdhip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reference-precision path (models/precise.py), the layers that are not 64-channel GEMMs.
+//   x3_split_kernel   float32 [n, C] -> float16 [n, 2 C] = [hi | lo], hi = fl16(v), lo = fl16(v - hi): ONE pass instead of the six
+//                     elementwise / concatenation kernels of the PyTorch formulation.
+//   x3_merge_kernel   the inverse: float32 v = hi + lo (exact).
+//   conv1_1_x3_kernel conv1_1 (models/keras_ssd300.py:274: 3 -> 64 channels, 3x3 'same', ReLU) in float32 FMA-free arithmetic
+//                     (one IEEE multiply and one add per term, taps outer, channels inner) with the split output written directly.
+//                     K = 27 is no GEMM: 5 GFLOP of vector work against 0.7 GB of output; MIOpen's float32 path for a 3-channel
+//                     NHWC input is its naive kernel (5.2 ms at batch 32, r03w).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 l_split2(float a, float b, u32& lo_out) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+    lo_out = (u32)__builtin_bit_cast(unsigned short, la) | ((u32)__builtin_bit_cast(unsigned short, lb) << 16);
+    return (u32)__builtin_bit_cast(unsigned short, ha) | ((u32)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+// one thread per 8 channels of a pixel; cvec = C / 8
+__global__ __launch_bounds__(256) void x3_split_kernel(const float4* __restrict__ x, uint4* __restrict__ y, u32 n_pixels, u32 cvec) {
+    const u32 total = n_pixels * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 px = i / cvec, cg = i - px * cvec;
+        const float4 a = x[(size_t)i * 2], b = x[(size_t)i * 2 + 1];
+        u32 l0, l1, l2, l3;
+        const u32 h0 = l_split2(a.x, a.y, l0), h1 = l_split2(a.z, a.w, l1), h2 = l_split2(b.x, b.y, l2), h3 = l_split2(b.z, b.w, l3);
+        y[(size_t)px * (2 * cvec) + cg] = make_uint4(h0, h1, h2, h3);
+        y[(size_t)px * (2 * cvec) + cvec + cg] = make_uint4(l0, l1, l2, l3);
+    }
+}
+
+__device__ __forceinline__ float l_h2f(u32 h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+
+__global__ __launch_bounds__(256) void x3_merge_kernel(const uint4* __restrict__ x, float4* __restrict__ y, u32 n_pixels, u32 cvec) {
+    const u32 total = n_pixels * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 px = i / cvec, cg = i - px * cvec;
+        const uint4 h = x[(size_t)px * (2 * cvec) + cg], l = x[(size_t)px * (2 * cvec) + cvec + cg];
+        const u32 hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[2 * q] = l_h2f(hw[q] & 0xffffu) + l_h2f(lw[q] & 0xffffu);
+            o[2 * q + 1] = l_h2f(hw[q] >> 16) + l_h2f(lw[q] >> 16);
+        }
+        y[(size_t)i * 2] = make_float4(o[0], o[1], o[2], o[3]);
+        y[(size_t)i * 2 + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// x [B, H, W, 3] float32, w [64, 3, 3, 3] float32 (co, kh, kw, ci), bias [64] or null; y [B, H, W, 128] float16 = [hi | lo] of
+// relu(conv + bias).  256 threads = 32 pixel quads x 8 channel groups of 8: a thread computes FOUR consecutive pixels (every filter
+// value read from LDS feeds four FMAs; the first version -- one pixel per thread, separate multiply and add -- was bound by its LDS
+// reads and VALU issue: 668 us at batch 32, r03x).  fmaf: one rounding per term, taps outer, channels inner.
+constexpr int C11_PX = 4;
+__global__ __launch_bounds__(256) void conv1_1_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         uint4* __restrict__ y, int H, int W, u32 n_pixels, int relu) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * 64];
+    __shared__ float bl[64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) { const int co = i / 27, k = i - co * 27; wl[k * 64 + co] = w[i]; }
+    if (threadIdx.x < 64) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const u32 n_quads = (n_pixels + C11_PX - 1) / C11_PX;
+    for (u32 qd = blockIdx.x * 32u + pl; qd < n_quads; qd += gridDim.x * 32u) {
+        const u32 px0 = qd * C11_PX;
+        int wq[C11_PX], hq[C11_PX];
+#pragma unroll
+        for (int u = 0; u < C11_PX; ++u) {
+            const u32 px = min(px0 + u, n_pixels - 1);
+            wq[u] = (int)(px % (u32)W);
+            hq[u] = (int)((px / (u32)W) % (u32)H);
+        }
+        float acc[C11_PX][8];
+#pragma unroll
+        for (int u = 0; u < C11_PX; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[u][e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float v[C11_PX][3];
+#pragma unroll
+                for (int u = 0; u < C11_PX; ++u) {
+                    const int hh = hq[u] + kh - 1, ww = wq[u] + kw - 1;
+                    const bool in = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W && px0 + u < n_pixels;
+                    const float* src = x + ((long long)(px0 + u) + (long long)(kh - 1) * W + (kw - 1)) * 3;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) v[u][ci] = in ? src[ci] : 0.f;
+                }
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(wl + ((kh * 3 + kw) * 3 + ci) * 64 + cg * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wl + ((kh * 3 + kw) * 3 + ci) * 64 + cg * 8 + 4);
+                    const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                    for (int u = 0; u < C11_PX; ++u)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[u][e] = __builtin_fmaf(v[u][ci], wr[e], acc[u][e]);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < C11_PX; ++u) {
+            if (px0 + u >= n_pixels) break;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = acc[u][e] + bl[cg * 8 + e];
+                o[e] = relu ? (t > 0.f ? t : (t != t ? t : 0.f)) : t;
+            }
+            u32 l0, l1, l2, l3;
+            const u32 h0 = l_split2(o[0], o[1], l0), h1 = l_split2(o[2], o[3], l1), h2 = l_split2(o[4], o[5], l2), h3 = l_split2(o[6], o[7], l3);
+            y[(size_t)(px0 + u) * 16 + cg] = make_uint4(h0, h1, h2, h3);
+            y[(size_t)(px0 + u) * 16 + 8 + cg] = make_uint4(l0, l1, l2, l3);
+        }
+    }
+}
+
+}  // namespace ssdhip
+
+extern "C" int ssdhip_x3_split_nhwc(const float* x, void* y, long long n_pixels, int C, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || n_pixels <= 0 || C <= 0 || (C & 7) || n_pixels * (C / 8) > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(ssdhip::x3_split_kernel, dim3(grid_for((size_t)n_pixels * (C / 8), 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(x), static_cast<uint4*>(y), (u32)n_pixels, (u32)(C / 8));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_x3_merge_nhwc(const void* x, float* y, long long n_pixels, int C, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || n_pixels <= 0 || C <= 0 || (C & 7) || n_pixels * (C / 8) > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(ssdhip::x3_merge_kernel, dim3(grid_for((size_t)n_pixels * (C / 8), 256)), dim3(256), 0, stream,
+                       static_cast<const uint4*>(x), reinterpret_cast<float4*>(y), (u32)n_pixels, (u32)(C / 8));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const float* bias, void* y, int B, int H, int W, int relu,
+                                      void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W > 0x3fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    const long long n = (long long)B * H * W;
+    long long blocks = (n + 32 * ssdhip::C11_PX - 1) / (32 * ssdhip::C11_PX);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(ssdhip::conv1_1_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, weight, bias, static_cast<uint4*>(y), H, W,
+                       (u32)n, relu ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 extern "C" int ssdhip_preprocess_nhwc_f32_to_bf16(const float* images, void* out, long long n_pixels, int channels,
                                                   const float* mean_h, const float* divide_h, const int* swap_h, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);

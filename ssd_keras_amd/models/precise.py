@@ -4,8 +4,9 @@ The reference's graph is float32 end to end (models/keras_ssd300.py:274-419).  T
 convolutions are bound by the 157 TFLOP/s float32 matrix rate.  `PreciseForward` runs the same float32 model through
 `ssdhip_conv2d_x3_nhwc_f16` (csrc/ssdhip_conv.hip, X3): every activation and filter is carried as a float16 (hi, lo) pair -- a float32
 value to 2^-22 -- and a convolution is hi.hi + hi.lo + lo.hi in one float16 MFMA K loop with float32 accumulation, float32 bias and
-activation, and a re-split in the epilogue.  The graph glue that is not a convolution (the Lambda input pipeline, conv1_1 with its
-three input channels, pool4 / pool5, L2Normalization, Reshape / Concatenate / softmax / AnchorBoxes) stays float32 PyTorch.
+activation, and a re-split in the epilogue.  conv1_1 (three input channels, K = 27) is float32 vector arithmetic in its own kernel; the
+graph glue that is not a convolution (the Lambda input pipeline, pool4 / pool5, L2Normalization, Reshape / Concatenate / softmax /
+AnchorBoxes) stays float32 PyTorch, with one-pass split / merge kernels between the two representations.
 
     model = ssd_300(...).cuda().to(memory_format=torch.channels_last).eval()        # float32 weights
     y_pred = PreciseForward(model)(images)                                          # (B, 8732, n_classes + 12) float32
@@ -89,9 +90,14 @@ class PreciseForward:
     def _vgg(self, x):
         m = self.model
         c = self.conv
-        # conv1_1: three input channels -- a float32 framework convolution (0.5 % of the FLOPs), then the split
-        x = torch.relu(F.conv2d(x, m.conv1_1.weight, m.conv1_1.bias, 1, 1))
-        x2 = nat.x3_split(x)
+        # conv1_1: three input channels, K = 27 -- float32 vector arithmetic with the split written directly (ssdhip_conv1_1_x3_nhwc;
+        # the framework's float32 convolution of a 3-channel NHWC image is MIOpen's naive kernel: 5.2 ms at batch 32)
+        c11 = m.conv1_1
+        if (c11.in_channels == 3 and c11.out_channels == 64 and self._same3(c11) and x.is_cuda
+                and x.permute(0, 2, 3, 1).is_contiguous()):
+            x2 = nat.conv1_1_x3(x, c11.weight, c11.bias, relu=True)
+        else:
+            x2 = nat.x3_split(torch.relu(F.conv2d(x, c11.weight, c11.bias, c11.stride, c11.padding)))
         x2 = c(m.conv1_2, x2, pool=True)                                   # MaxPooling2D(2, 2, 'same') fused (:275-276)
         x2 = c(m.conv2_2, c(m.conv2_1, x2), pool=True)
         x2 = c(m.conv3_3, c(m.conv3_2, c(m.conv3_1, x2)), pool=True)

@@ -67,6 +67,32 @@ def test_x3_convolution_is_float32_grade(case, out_f32, halo, monkeypatch):
     assert e_x3 <= 8.0 * e_fw + 1e-6 and e_x3 <= 3e-5
 
 
+def test_x3_split_merge_and_first_layer_kernels():
+    """ssdhip_x3_split_nhwc / ssdhip_x3_merge_nhwc against the PyTorch formulation (bit for bit), and ssdhip_conv1_1_x3_nhwc (the
+    3-channel first layer in float32 vector arithmetic) against a float64 convolution."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(3)
+    v = (torch.randn((3, 64, 19, 23), generator=g, device="cuda") * 50).contiguous(memory_format=torch.channels_last)
+    s2 = nat.x3_split(v)
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    assert s2.dtype == torch.float16 and s2.shape == (3, 128, 19, 23)
+    assert torch.equal(s2[:, :64], hi) and torch.equal(s2[:, 64:], lo)
+    m = nat.x3_merge(s2)
+    assert m.dtype == torch.float32 and torch.equal(m, hi.float() + lo.float())
+    assert float((m - v).abs().max() / v.abs().max()) < 2.0 ** -21
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(2, 37, 53, 3)).astype(np.float32)).cuda()
+    x = (x - torch.tensor([123.0, 117.0, 104.0], device="cuda")).permute(0, 3, 1, 2)          # NHWC memory
+    w = torch.randn((64, 3, 3, 3), generator=g, device="cuda") * (2.0 / 27) ** 0.5
+    b = torch.randn((64,), generator=g, device="cuda")
+    got = nat.x3_merge(nat.conv1_1_x3(x, w, b, relu=True)).double()
+    want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+    assert got.shape == want.shape
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-6
+
+
 def test_precise_forward_reproduces_the_float32_model():
     import torch
     from ssd_keras_amd.models.keras_ssd300 import ssd_300
