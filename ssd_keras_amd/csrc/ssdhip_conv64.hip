@@ -47,7 +47,10 @@ constexpr int C64_STAGE = 4 * 2048;                      // per-wave output tran
 constexpr int c64_halo_bytes(int cs) { return ((9 * (2 * (64 >> cs) + 2) * ((1 << cs) + 2) + 63) / 64) * 1024; }
 constexpr int C64_PATCH1 = 1600;                         // FRONT: one producer's copy of the 3-channel input patch of a tile's halo (13 x 20 px x 3 ch bf16 = 1560 B)
 constexpr int C64_PATCH = ((C64_NPROD * C64_PATCH1 + 1023) / 1024) * 1024;
-constexpr int c64_lds_bytes(int cs, int nb, bool front = false) { return C64_WBYTES + nb * c64_halo_bytes(cs) + C64_STAGE + (front ? C64_PATCH : 0); }
+constexpr int C64_WREG_BYTES = 1024;                     // WREG: the filters live in registers; this region only holds the float32 bias of the slice
+constexpr int c64_lds_bytes(int cs, int nb, bool front = false, bool wreg = false) {
+    return (wreg ? C64_WREG_BYTES : C64_WBYTES) + nb * c64_halo_bytes(cs) + C64_STAGE + (front ? C64_PATCH : 0);
+}
 
 struct C64Params {
     const bf16_t* x;             // [B, H, W, 64]
@@ -107,7 +110,11 @@ __device__ __forceinline__ i32x4 c64_rsrc(const void* base, int num_records) {
 
 // FRONT: the 64-channel input map is never read from memory -- it is conv1_1 (3 -> 64 channels, models/keras_ssd300.py:274) of the
 // 3-channel image, recomputed per tile by the fifth wave straight into the halo buffer (see the producer section below).
-template <int CS, bool POOL, int NB, bool FRONT>
+// WREG: each multiplying wave keeps the 36 filter fragments of its 32 output channels in REGISTERS (144 VGPRs, loaded once per launch)
+// instead of reading them from LDS every step.  With the filters in LDS a step reads 3 KB per wave for two MFMAs -- 12 KB per 64 MFMA
+// cycles per CU, 75 % of what ds_read_b128 delivers (256 B/clk), and the producers' gathers and halo stores come on top: the fused
+// block was LDS-bound.  With WREG a step reads the two pixel fragments only (50 %).
+template <int CS, bool POOL, int NB, bool FRONT, bool WREG>
 __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* lds) {
     constexpr int CC = 1 << CS, RP = 64 >> CS;           // tile: RP row pairs x CC columns = 128 pixels
     constexpr int HC = CC + 2, HR = 2 * RP + 2;          // halo columns / rows
@@ -115,8 +122,9 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     constexpr int SLOTS = 9 * HPX;                       // 16-byte slots of a halo buffer
     constexpr int NP = (SLOTS + 63) / 64;                // 1 KiB LDS-DMA pieces per halo
     constexpr int HB = NP * 1024;                        // NB halo buffers: loads run NB - 1 tiles ahead of the MFMAs
-    static_assert(HB == c64_halo_bytes(CS) && c64_lds_bytes(CS, NB, FRONT) <= 160 * 1024, "LDS budget");
-    constexpr int W_OFF = 0, H_OFF = C64_WBYTES, STAGE_OFF = C64_WBYTES + NB * HB, PATCH_OFF = STAGE_OFF + C64_STAGE;
+    static_assert(HB == c64_halo_bytes(CS) && c64_lds_bytes(CS, NB, FRONT, WREG) <= 160 * 1024, "LDS budget");
+    constexpr int WB = WREG ? C64_WREG_BYTES : C64_WBYTES;
+    constexpr int W_OFF = 0, H_OFF = WB, STAGE_OFF = WB + NB * HB, PATCH_OFF = STAGE_OFF + C64_STAGE;
     constexpr unsigned OOB = 0x80000000u;
 
     const int G = (int)gridDim.x;
@@ -137,7 +145,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     const i32x4 rw = c64_rsrc(p.w, p.w_bytes);
 
     // ---- resident weights: tap t -> [64 co rows][128 B], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) ----------
-    if (wave < 4) {
+    if (!WREG && wave < 4) {
         const int pos = lane & 7;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -377,17 +385,31 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) abase[kk] = (u32)(W_OFF + row * 128 + (((2 * kk + khalf) ^ ((row >> 1) & 7)) << 4));
     }
+    // WREG: fragment (tap t, slice kk) of the lane's channel row = 16 bytes of weight[co][t][kk * 16 + khalf * 8 ..], straight from memory
+    bf16x8 wreg[WREG ? 36 : 1];
+    if constexpr (WREG) {
+        const bf16_t* wrow = p.w + (size_t)(co0 + wc * 32 + r31) * 576 + khalf * 8;
+#pragma unroll
+        for (int s = 0; s < 36; ++s) wreg[s] = *reinterpret_cast<const bf16x8*>(wrow + (s >> 2) * 64 + (s & 3) * 16);
+        if (wave == 0) reinterpret_cast<float*>(lds + W_OFF)[lane] = p.bias ? __uint_as_float((u32)p.bias[co0 + lane] << 16) : 0.f;
+    }
     // bias of the lane's 16 channels (D row = channel (v & 3) + 8 * (v >> 2) + 4 * khalf of the wave's 32)
     float bv[16];
+    if constexpr (!WREG) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ch = co0 + wc * 32 + 8 * g + 4 * khalf + e;
-            bv[4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int ch = co0 + wc * 32 + 8 * g + 4 * khalf + e;
+                bv[4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
+            }
+    }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the weights (the only loads it ever waits for)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's share of the weights (the only loads it ever waits for)
+    if constexpr (WREG) {
+#pragma unroll
+        for (int s = 0; s < 36; ++s) asm volatile("" : "+v"(wreg[s]));       // loaded once: never re-fetched, never re-derived
+    }
     __builtin_amdgcn_s_barrier();
 
     int buf = 0;
@@ -403,13 +425,13 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         // 36 steps (tap t = s / 4, k16 slice kk = s % 4).  One wave per SIMD: nothing but this wave's own MFMAs covers the LDS
         // latency, so fragments are read RD steps ahead through an (RD + 1)-slot register ring (hipcc left to itself sinks
         // every read next to its use; the sched_barriers pin the order).
-        constexpr int RD = 5, RS = RD + 1;
-        bf16x8 fa[RS], fb0[RS], fb1[RS];
+        constexpr int RD = WREG ? 4 : 5, RS = RD + 1;
+        bf16x8 fa[WREG ? 1 : RS], fb0[RS], fb1[RS];
         auto rd = [&](const int s, const int slot) {
             const int t = s >> 2, kk = s & 3;
             const int timm = ((t / 3) * HC + (t % 3)) * 144 + kk * 32;
             fb0[slot] = *reinterpret_cast<const bf16x8*>(hb + bbase[0] + timm);   // the step's first MFMA consumes the LAST two reads,
-            fa[slot] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + t * 8192);  // so one counted wait per step covers all three
+            if constexpr (!WREG) fa[slot] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + t * 8192);  // so one counted wait per step covers all three
             fb1[slot] = *reinterpret_cast<const bf16x8*>(hb + bbase[1] + timm);
         };
 #pragma unroll
@@ -419,8 +441,8 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         for (int s = 0; s < 36; ++s) {
             if ((s + RD < 36) && (!(SSDHIP_C64_ABLATE & 4) || s + RD < RS)) rd(s + RD, (s + RD) % RS);
             __builtin_amdgcn_sched_barrier(0);             // pin the order: hipcc otherwise sinks the reads next to their use
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % RS], fb1[s % RS], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % RS], fb0[s % RS], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WREG ? wreg[WREG ? s : 0] : fa[WREG ? 0 : s % RS], fb1[s % RS], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WREG ? wreg[WREG ? s : 0] : fa[WREG ? 0 : s % RS], fb0[s % RS], acc[0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -430,6 +452,13 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         // ---- epilogue (wave-private LDS stage: DS operations of one wave execute in order) ------------------------------
         int b, h0, w0;
         tile_origin(tile, b, h0, w0);
+        if constexpr (WREG) {                              // the lane's 16 bias values from the LDS table (registers hold the filters)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = *reinterpret_cast<const float4*>(lds + W_OFF + (wc * 32 + 8 * g + 4 * khalf) * 4);
+                bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
+            }
+        }
         if constexpr ((SSDHIP_C64_ABLATE & 2) != 0) {
             asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
         } else
@@ -511,11 +540,11 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int CS, bool POOL, int NB, bool FRONT = false>
+template <int CS, bool POOL, int NB, bool FRONT = false, bool WREG = false>
 __global__ __launch_bounds__(FRONT ? C64_FRONT_THREADS : C64_THREADS, 1) void conv64_kernel(C64Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[c64_lds_bytes(CS, NB, FRONT)];
-    conv64_body<CS, POOL, NB, FRONT>(p, lds);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[c64_lds_bytes(CS, NB, FRONT, WREG)];
+    conv64_body<CS, POOL, NB, FRONT, WREG>(p, lds);
 #endif
 }
 
@@ -554,7 +583,9 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     if (G > 4096) G = 4096;
     G = (G / p.n_slices) * p.n_slices;
     if (G < p.n_slices) G = p.n_slices;
-#define C64_LAUNCH(CS_, POOL_) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3>), dim3(G), dim3(C64_THREADS), 0, stream, p)
+    static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
+#define C64_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3, false, true>), dim3(G), dim3(C64_THREADS), 0, stream, p); \
+                                    else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3>), dim3(G), dim3(C64_THREADS), 0, stream, p); } while (0)
     if (pool) {
         if (cs_best == 3) C64_LAUNCH(3, true); else C64_LAUNCH(4, true);
     } else {
@@ -598,7 +629,9 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     if (G > 4096) G = 4096;
     G = (G / p.n_slices) * p.n_slices;
     if (G < p.n_slices) G = p.n_slices;
-#define C64F_LAUNCH(CS_, POOL_) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 2, true>), dim3(G), dim3(C64_FRONT_THREADS), 0, stream, p)
+    static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
+#define C64F_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 2, true, true>), dim3(G), dim3(C64_FRONT_THREADS), 0, stream, p); \
+                                     else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 2, true>), dim3(G), dim3(C64_FRONT_THREADS), 0, stream, p); } while (0)
     if (pool) {
         if (cs_best == 3) C64F_LAUNCH(3, true); else C64F_LAUNCH(4, true);
     } else {
