@@ -360,7 +360,9 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
     25 MB buckets overlapped with backward) -> SGD(momentum 0.9).  Weak scaling: B images per rank.
     `tame`: predictor-head filters x 1e-2 and background bias + 4, so that the softmax of the random-init model is neither saturated
     nor uniform and the timed steps are a descending optimisation (raw He-init on 0..255 inputs clips most losses at -log(1e-15):
-    a tie-saturated hard-negative select and a loss that grows at any usable learning rate -- reported as `raw_init` at N = 1)."""
+    a tie-saturated hard-negative select and a loss that grows at any usable learning rate -- reported as `raw_init` at N = 1).
+    Learning rate 1e-7: the first gradient has norm 4e4 (un-normalised 0..255 inputs through a He-init VGG); 24 eager steps go
+    34.4 -> 30.1 at 1e-7, 34.4 -> 745 -> 113 at 1e-5 (chaotic: one graphed run ended non-finite) -- tools/debug_train.py, r03zc."""
     from ssd_keras_amd import distributed as dp
     from ssd_keras_amd import synthetic as syn
     from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
@@ -384,8 +386,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
     # decay 1e-3 on the kernels only
     decay = [p for p in model.parameters() if p.dim() > 1]
     plain = [p for p in model.parameters() if p.dim() <= 1]
-    opt = torch.optim.SGD([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-5 if tame else 1e-7,
-                          momentum=0.9)
+    opt = torch.optim.SGD([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-7, momentum=0.9)
     enc = SSDInputEncoder(matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5, **cfg)
     gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=7 + rank)
     images = torch.from_numpy(np.random.RandomState(100 + rank).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
@@ -493,7 +494,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         if isinstance(raw, dict):
             out_raw = {k: raw.get(k) for k in ("images_per_sec", "ms_per_step", "eager_ms_per_step", "first_loss", "final_loss", "launch", "error")
                        if raw.get(k) is not None}
-    return {"regime": "tamed heads (filters x 1e-2, background bias + 4), lr 1e-5" if tame else "raw He-normal init, lr 1e-7",
+    return {"regime": "tamed heads (filters x 1e-2, background bias + 4), lr 1e-7" if tame else "raw He-normal init, lr 1e-7",
             "raw_init": out_raw, "eager_ms_per_step": round(eager_max, 3),
             "rank_step_ms_min_max": [round(1e3 * fastest / steps, 3), round(1e3 * elapsed / steps, 3)],
             "allreduce_buckets": n_buckets, "bucket_cap_mb": 25,

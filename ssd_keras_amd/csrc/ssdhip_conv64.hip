@@ -39,7 +39,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int C64_THREADS = 320;                         // four multiplying waves (one per SIMD) + one loader wave
+#ifndef SSDHIP_C64_NLOAD
+#define SSDHIP_C64_NLOAD 1       // loader waves of the non-fused kernel (each issues every NLOAD-th LDS-DMA piece of a halo); 2 measured equal (r03zb)
+#endif
+constexpr int C64_NLOAD = SSDHIP_C64_NLOAD;
+constexpr int C64_THREADS = (4 + C64_NLOAD) * 64;        // four multiplying waves (one per SIMD) + the loader waves
 constexpr int C64_NPROD = 3;                             // FRONT: producer waves
 constexpr int C64_FRONT_THREADS = (4 + C64_NPROD) * 64;  // FRONT: four multiplying waves + the producers
 constexpr int C64_WBYTES = 9 * 64 * 128;                 // resident weight slice: [tap][co][64 ci] bf16, 128-byte rows
@@ -319,13 +323,17 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     //      first version of this kernel: 4 us per tile whatever the prefetch depth).  So the halos are fetched by a fifth wave
     //      that never stores -- its vmcnt counts loads only -- and the four multiplying waves never wait on vmcnt at all.
     //      Per tile i:  loader: halo i+1 landed (halo i+2 may fly) | barrier | issue halo i+3 into the buffer tile i released. ----
-    if (!FRONT && wave == 4) {
+    if (!FRONT && wave >= 4) {
+        // loader wave lw issues pieces lw, lw + NLOAD, ... of every halo (NPW each).
         // slot n = 64 * piece + lane of a halo buffer -> halo pixel n / 9 (row hr, column hc), 16-byte chunk n % 9 (8 = padding)
-        int hrc[NP];                                     // hr << 16 | hc << 4 | chunk, or -1 (padding slot / beyond the halo)
-        u32 rel[NP];                                     // byte offset of the slot's 16 bytes from the halo origin pixel (or OOB)
+        const int lw = wave - 4;
+        constexpr int NPW = NP / C64_NLOAD;
+        static_assert(NP % C64_NLOAD == 0, "every loader wave issues the same number of pieces (compile-time wait counts)");
+        int hrc[NPW];                                    // hr << 16 | hc << 4 | chunk, or -1 (padding slot / beyond the halo)
+        u32 rel[NPW];                                    // byte offset of the slot's 16 bytes from the halo origin pixel (or OOB)
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int n = 64 * k + lane;
+        for (int k = 0; k < NPW; ++k) {
+            const int n = 64 * (k * C64_NLOAD + lw) + lane;
             const int px = n / 9, c = n - 9 * px;
             const int hr = px / HC, hc = px - hr * HC;
             const bool data = c < 8 && px < HPX;
@@ -338,32 +346,32 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         auto issue_halo = [&](int tile, int buf) {
             int b, h0, w0;
             tile_origin(tile, b, h0, w0);
-            const u32 dst = lds0 + H_OFF + buf * HB;
+            const u32 dst = lds0 + H_OFF + buf * HB + lw * 1024;
             if (h0 >= 1 && w0 >= 1 && h0 + 2 * RP + 1 <= p.H && w0 + CC + 1 <= p.W) {
                 const u32 soff = (u32)(((b * p.H + h0 - 1) * p.W + (w0 - 1)) * 128 + xneg);
 #pragma unroll
-                for (int k = 0; k < NP; ++k) c64_bload(rel[k], rx, dst + k * 1024, soff);
+                for (int k = 0; k < NPW; ++k) c64_bload(rel[k], rx, dst + k * C64_NLOAD * 1024, soff);
             } else {
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
+                for (int k = 0; k < NPW; ++k) {
                     const int h = h0 - 1 + (hrc[k] >> 16), w = w0 - 1 + ((hrc[k] >> 4) & 0xfff);
                     const bool ok = hrc[k] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
                     const u32 voff = ok ? (u32)(((b * p.H + h) * p.W + w) * 128 + (hrc[k] & 15) * 16 + xneg) : OOB;
-                    c64_bload(voff, rx, dst + k * 1024);
+                    c64_bload(voff, rx, dst + k * C64_NLOAD * 1024);
                 }
             }
         };
-        static_assert(FRONT || (NB == 3 && 2 * NP <= 63), "wait accounting: two halos of NP loads in flight must fit vmcnt");
+        static_assert(FRONT || (NB == 3 && 2 * NPW <= 63), "wait accounting: two halos of NPW loads in flight must fit vmcnt");
         issue_halo(first, 0);
         if (first + stride < p.tiles) issue_halo(first + stride, 1);
         if (first + 2 * stride < p.tiles) issue_halo(first + 2 * stride, 2);
-        if (first + 2 * stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
-        else if (first + stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+        if (first + 2 * stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPW) : "memory");
+        else if (first + stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // halo of the first tile (+ the multipliers' weights) in place
         int buf = 0;
         for (int tile = first; tile < p.tiles; tile += stride) {
-            if (tile + 2 * stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");   // halo i+1 landed
+            if (tile + 2 * stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");  // halo i+1 landed (this wave's pieces)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // the multipliers are done with buffer `buf`
             if (tile + 3 * stride < p.tiles) issue_halo(tile + 3 * stride, buf);
