@@ -576,7 +576,7 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
     p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr;
-    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // conv2_1: 151 -> 145 us, 171 -> 166 us (r03f)
+    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // multipliers first; equal within the spread since WREG (profiles/r03zd_*)
     p.n_slices = Cout / 64;
     int cs_best = 4;
     long long best = -1;
@@ -619,7 +619,7 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     p.x = nullptr; p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.x3 = static_cast<const bf16_t*>(x3); p.w1 = static_cast<const bf16_t*>(w1); p.b1 = static_cast<const bf16_t*>(b1);
-    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // r03d: 317 -> 296 us
+    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // multipliers first (filters in LDS: 317 -> 296 us; equal since WREG, profiles/r03zd_*)
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = 0; p.w_bytes = (int)wb;

@@ -619,8 +619,8 @@ class SSDModel(nn.Module):
         depend on the extra layers -- a chain of eight small convolutions that leaves most CUs idle -- so the two can share the chip
         on two HIP streams.  Mode 3 is what the HIP-graph step uses (GraphedInference; the eager path stays on one stream unless
         SSDHIP_HEAD_OVERLAP says otherwise): the two trunk heads as a grouped slab launch capped at 160 of the 256 CUs on the second
-        stream beside the chain, then the four small heads: 2.766 -> 2.727 and 2.435 -> 2.419 ms per step in two within-visit A/Bs
-        (r03b, r03c).  Modes 1 | 2 are the older forms with the implicit-GEMM heads (1: the heads on the second stream; 2: the chain on
+        stream beside the chain, then the four small heads (1.4 % / 0.7 % of a step in round 2; no measurable difference since the
+        extra layers are split-K launches: profiles/r03zd_two_stream_heads_and_producer_priority_remeasured.txt).  Modes 1 | 2 are the older forms with the implicit-GEMM heads (1: the heads on the second stream; 2: the chain on
         a high-priority second stream): ~190 us of kernels run side by side but slow each other down by as much -- those heads fill
         every CU (r02p: 2.831 off / 2.832 / 2.815 ms).  Returns (feature maps, packed head outputs), or None for the one-stream path."""
         import os
