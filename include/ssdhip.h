@@ -323,7 +323,9 @@ int ssdhip_conv2d_x3_nhwc_f16(const void* x, const void* weight, const float* bi
 
 /* The same arithmetic on the slab kernel (csrc/ssdhip_convh.hip) for the 3x3 'same' layers with C % 128 == 0 and Cout % 128 == 0
  * (conv2_2 ... conv5_3 and the packed predictor heads): x [B,H,W,2C], weight [Cout,3,3,3C], bias float32 or NULL, y [B,Ho,Wo,2 Cout]
- * float16 = [hi | lo] of act(oscale * sum + bias); pool != 0 fuses MaxPooling2D(2, 2, 'same'). */
+ * float16 = [hi | lo] of act(oscale * sum + bias); pool != 0 fuses MaxPooling2D(2, 2, 'same').
+ * C == 64 (conv2_1) is accepted with the filters padded to four 64-channel slices: weight [Cout,3,3,256] = [w hi | w hi | w lo | 0]
+ * (the K loop walks slices in pairs; the activation slices it meets are hi, lo, hi, lo). */
 int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
                                     int relu, int pool, float oscale, void* stream);
 

@@ -702,9 +702,10 @@ def x3_split(v):
     return torch.cat([hi, lo], dim=1).contiguous(memory_format=torch.channels_last)
 
 
-def x3_pack_weight(weight):
+def x3_pack_weight(weight, slab64=False):
     """float32 (Cout, Cin, k, k) filters -> (float16 (Cout, 3 Cin, k, k) channels_last = [w hi | w lo | w hi] of weight * 2^e, oscale =
-    2^-e), e chosen so that the largest scaled filter lies in [256, 512): hi and lo parts stay in float16's normal range."""
+    2^-e), e chosen so that the largest scaled filter lies in [256, 512): hi and lo parts stay in float16's normal range.
+    slab64 (Cin == 64, 3x3 'same', Cout % 128 == 0: conv2_1 on the slab kernel): (Cout, 256, 3, 3) = [w hi | w hi | w lo | 0]."""
     import math
     torch = _torch()
     w = weight.detach().float()
@@ -713,6 +714,10 @@ def x3_pack_weight(weight):
     ws = w * (2.0 ** e)
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
+    if slab64:
+        if w.shape[1] != 64:
+            raise SsdHipError("slab64 packing is for 64 input channels")
+        return torch.cat([hi, hi, lo, torch.zeros_like(hi)], dim=1).contiguous(memory_format=torch.channels_last), 2.0 ** -e
     return torch.cat([hi, lo, hi], dim=1).contiguous(memory_format=torch.channels_last), 2.0 ** -e
 
 
@@ -731,7 +736,8 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
         raise SsdHipError("conv2d_x3 takes float16 split activations and packed float16 filters")
     b, c2, h, w = x2.shape
     cout, c3, kh, kw = packed_weight.shape
-    if c2 % 2 or c3 != 3 * (c2 // 2) or kh != kw or not packed_weight.permute(0, 2, 3, 1).is_contiguous():
+    slab64 = c2 == 128 and c3 == 256 and int(kh) == 3                       # x3_pack_weight(..., slab64=True)
+    if c2 % 2 or (c3 != 3 * (c2 // 2) and not slab64) or kh != kw or not packed_weight.permute(0, 2, 3, 1).is_contiguous():
         raise SsdHipError("packed filters must be (Cout, 3 C, k, k) channels_last for a (B, 2 C, H, W) input")
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         raise SsdHipError("bias must be contiguous float32")
@@ -743,8 +749,10 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
         raise SsdHipError("convolution output would be empty")
     import os
     c = c2 // 2
-    if (int(kh) == 3 and int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and c % 128 == 0 and cout % 128 == 0
-            and os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1"):
+    if slab64 and not (int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and cout % 128 == 0):
+        raise SsdHipError("slab64 filters are for a 3x3 'same' convolution with Cout % 128 == 0")
+    if (int(kh) == 3 and int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and (c % 128 == 0 or slab64) and cout % 128 == 0
+            and (slab64 or os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1")):
         # the slab kernel (csrc/ssdhip_convh.hip): the deep 3x3 layers and the packed heads; it writes split pairs, merged here when
         # the caller wants float32
         if not getattr(lib, "_x3h_bound", False):

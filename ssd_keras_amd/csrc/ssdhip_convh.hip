@@ -736,24 +736,28 @@ extern "C" int ssdhip_conv3x3_halo_group_nhwc_bf16(int n_problems, const void* c
 // The reference-precision form of ssdhip_conv3x3_halo_nhwc_bf16 (see ssdhip_conv2d_x3_nhwc_f16 for the arithmetic): x [B,H,W,2C]
 // float16 = [hi | lo], weight [Cout,3,3,3C] float16 = [w hi | w lo | w hi] of the float32 filters / oscale, bias float32, y
 // [B,Ho,Wo,2 Cout] float16 = [hi | lo] of act(oscale * sum + bias).  C % 128 == 0, Cout % 128 == 0.
+// C == 64 (conv2_1): the K loop walks 64-channel slices in pairs, and 3 C is three of them -- the filters are then [Cout,3,3,256] =
+// [w hi | w hi | w lo | 0] against the activation slices (hi, lo, hi, lo): the same three products plus a slice of zeros.
 extern "C" int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C,
                                                int Cout, int relu, int pool, float oscale, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || !(oscale > 0.f)) return SSDHIP_E_BADARG;
-    if (C <= 0 || (C % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
+    const bool c64 = C == 64;
+    if (C <= 0 || ((C % 128) && !c64) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 3)) return SSDHIP_E_BADARG;
-    const long long xb = (long long)B * H * W * 2 * C * 2, wb = (long long)Cout * 9 * 3 * C * 2;
+    const int Kc = c64 ? 256 : 3 * C;                   // channels the K loop walks
+    const long long xb = (long long)B * H * W * 2 * C * 2, wb = (long long)Cout * 9 * Kc * 2;
     const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
     const long long yb = (long long)B * Ho * Wo * 2 * Cout * 2;
     if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || yb >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
     ConvHParams p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
     p.y = static_cast<bf16_t*>(y);
-    p.H = H; p.W = W; p.Cin = 3 * C; p.Cout = Cout; p.relu = relu ? 1 : 0;
+    p.H = H; p.W = W; p.Cin = Kc; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.HT = p.WT = 0;
     p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
-    p.xC = 2 * C; p.nx = C / 64; p.bias32 = bias; p.oscale = oscale;
+    p.xC = 2 * C; p.nx = c64 ? 2 : C / 64; p.bias32 = bias; p.oscale = oscale;
     int geom = 0;
     if (pool || W > 94) {
         long long best = -1;

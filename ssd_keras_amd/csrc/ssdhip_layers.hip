@@ -280,21 +280,39 @@ __global__ __launch_bounds__(256) void x3_merge_kernel(const uint4* __restrict__
 }
 
 // x [B, H, W, 3] float32, w [64, 3, 3, 3] float32 (co, kh, kw, ci), bias [64] or null; y [B, H, W, 128] float16 = [hi | lo] of
-// relu(conv + bias).  256 threads = 32 pixel quads x 8 channel groups of 8: a thread computes FOUR consecutive pixels (every filter
-// value read from LDS feeds four FMAs; the first version -- one pixel per thread, separate multiply and add -- was bound by its LDS
-// reads and VALU issue: 668 us at batch 32, r03x).  fmaf: one rounding per term, taps outer, channels inner.
+// relu(conv + bias).  256 threads = 32 pixel quads x 8 channel groups of 8: a thread computes FOUR consecutive pixels of a tile of 128
+// consecutive (flattened) pixels; every filter value read from LDS feeds four FMAs.  The tile's inputs -- three flattened runs of 130
+// pixels, one per filter row -- are staged in LDS by coalesced loads: in the first two versions every thread fetched its 108 input
+// values from global memory itself (eight lanes per address), and the kernel ran at 1.07 TB/s of output (668 / 690 us at batch 32,
+// r03x / r03ze) instead of the ~3 TB/s a write-only kernel reaches.  fmaf: one rounding per term, taps outer, channels inner.
 constexpr int C11_PX = 4;
-__global__ __launch_bounds__(256) void conv1_1_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+constexpr int C11_TILE = 32 * C11_PX;                    // pixels per tile
+constexpr int C11_RUN = (C11_TILE + 2) * 3;              // floats of one staged run: pixels p0 - 1 .. p0 + TILE of one filter row
+__global__ __launch_bounds__(256, 4) void conv1_1_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          uint4* __restrict__ y, int H, int W, u32 n_pixels, int relu) {
     __shared__ __attribute__((aligned(16))) float wl[27 * 64];
     __shared__ float bl[64];
+    __shared__ float sx[3][C11_RUN + 2];
     for (int i = threadIdx.x; i < 27 * 64; i += 256) { const int co = i / 27, k = i - co * 27; wl[k * 64 + co] = w[i]; }
     if (threadIdx.x < 64) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-    __syncthreads();
     const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const u32 n_quads = (n_pixels + C11_PX - 1) / C11_PX;
-    for (u32 qd = blockIdx.x * 32u + pl; qd < n_quads; qd += gridDim.x * 32u) {
-        const u32 px0 = qd * C11_PX;
+    const u32 n_tiles = (n_pixels + C11_TILE - 1) / C11_TILE;
+    const long long n_floats = (long long)n_pixels * 3;
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u32 p0 = tile * C11_TILE;
+        __syncthreads();                                 // the previous tile's readers are done (first trip: the filters are in place)
+        for (int i = threadIdx.x; i < 3 * C11_RUN; i += 256) {
+            const int r = i / C11_RUN, k = i - r * C11_RUN;
+            const long long g = ((long long)p0 - 1 + (long long)(r - 1) * W) * 3 + k;
+            sx[r][k] = (g >= 0 && g < n_floats) ? x[g] : 0.f;
+        }
+        __syncthreads();
+        const u32 px0 = p0 + pl * C11_PX;
+        // the filter reads below are tile-invariant: left visible, LLVM hoists all 216 values out of the tile loop (283 VGPRs, one
+        // wave per SIMD -- the first two versions -- or 868 bytes of scratch under a register cap); an opaque zero keeps them in LDS
+        int wz = 0;
+        asm volatile("" : "+v"(wz));
+        const float* wt = wl + cg * 8 + wz;
         int wq[C11_PX], hq[C11_PX];
 #pragma unroll
         for (int u = 0; u < C11_PX; ++u) {
@@ -302,42 +320,50 @@ __global__ __launch_bounds__(256) void conv1_1_x3_kernel(const float* __restrict
             wq[u] = (int)(px % (u32)W);
             hq[u] = (int)((px / (u32)W) % (u32)H);
         }
-        float acc[C11_PX][8];
+        // packed float32 FMAs (v_pk_fma_f32: two channels per instruction): the kernel's VALU work is 864 FMAs per thread and tile
+        typedef float c11_f2 __attribute__((ext_vector_type(2)));
+        c11_f2 acc[C11_PX][4];
 #pragma unroll
         for (int u = 0; u < C11_PX; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[u][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[u][e] = (c11_f2){0.f, 0.f};
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {                  // not unrolled: one filter row's 72 values in flight at a time
+            // the quad's six input pixels of this filter row (local pixels pl * 4 - 1 .. pl * 4 + 4 -> run offsets pl * 12 .. + 17)
+            float in6[18];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+            for (int k = 0; k < 18; ++k) in6[k] = sx[kh][pl * (C11_PX * 3) + k];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 float v[C11_PX][3];
 #pragma unroll
                 for (int u = 0; u < C11_PX; ++u) {
                     const int hh = hq[u] + kh - 1, ww = wq[u] + kw - 1;
-                    const bool in = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W && px0 + u < n_pixels;
-                    const float* src = x + ((long long)(px0 + u) + (long long)(kh - 1) * W + (kw - 1)) * 3;
+                    const bool in = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
 #pragma unroll
-                    for (int ci = 0; ci < 3; ++ci) v[u][ci] = in ? src[ci] : 0.f;
+                    for (int ci = 0; ci < 3; ++ci) v[u][ci] = in ? in6[(u + kw) * 3 + ci] : 0.f;
                 }
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const float4 w0 = *reinterpret_cast<const float4*>(wl + ((kh * 3 + kw) * 3 + ci) * 64 + cg * 8);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wl + ((kh * 3 + kw) * 3 + ci) * 64 + cg * 8 + 4);
-                    const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    const float4 w0 = *reinterpret_cast<const float4*>(wt + ((kh * 3 + kw) * 3 + ci) * 64);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wt + ((kh * 3 + kw) * 3 + ci) * 64 + 4);
+                    const c11_f2 wr[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
 #pragma unroll
-                    for (int u = 0; u < C11_PX; ++u)
+                    for (int u = 0; u < C11_PX; ++u) {
+                        const c11_f2 vv = {v[u][ci], v[u][ci]};
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[u][e] = __builtin_fmaf(v[u][ci], wr[e], acc[u][e]);
+                        for (int e = 0; e < 4; ++e) acc[u][e] = __builtin_elementwise_fma(vv, wr[e], acc[u][e]);
+                    }
                 }
             }
+        }
 #pragma unroll
         for (int u = 0; u < C11_PX; ++u) {
             if (px0 + u >= n_pixels) break;
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float t = acc[u][e] + bl[cg * 8 + e];
+                const float t = acc[u][e >> 1][e & 1] + bl[cg * 8 + e];
                 o[e] = relu ? (t > 0.f ? t : (t != t ? t : 0.f)) : t;
             }
             u32 l0, l1, l2, l3;
@@ -374,8 +400,8 @@ extern "C" int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W > 0x3fffffffLL) return SSDHIP_E_BADARG;
     if (((uintptr_t)y) & 15) return SSDHIP_E_BADARG;
     const long long n = (long long)B * H * W;
-    long long blocks = (n + 32 * ssdhip::C11_PX - 1) / (32 * ssdhip::C11_PX);
-    if (blocks > 16384) blocks = 16384;
+    long long blocks = (n + ssdhip::C11_TILE - 1) / ssdhip::C11_TILE;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(ssdhip::conv1_1_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, weight, bias, static_cast<uint4*>(y), H, W,
                        (u32)n, relu ? 1 : 0);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;

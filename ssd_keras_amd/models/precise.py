@@ -30,6 +30,7 @@ class PreciseForward:
             raise TypeError("PreciseForward takes the float32 model (the reference's precision)")
         self.model = model
         self._packed = {}
+        self._side = {}
 
     # -- filters ------------------------------------------------------------------------------------------------------------------
     def _pack(self, key, tensors, build):
@@ -42,8 +43,12 @@ class PreciseForward:
         return hit[1]
 
     def _conv_filters(self, conv):
+        # conv2_1 (64 -> 128 channels) goes to the slab kernel with a padded K loop (4/3 of the products, still faster than the
+        # implicit-GEMM form: 523 us there, r03ze)
+        slab64 = conv.in_channels == 64 and conv.out_channels % 128 == 0 and self._same3(conv)
+
         def build():
-            w, oscale = nat.x3_pack_weight(conv.weight)
+            w, oscale = nat.x3_pack_weight(conv.weight, slab64=slab64)
             return w, oscale, conv.bias.detach().float().contiguous() if conv.bias is not None else None
         return self._pack(id(conv), [conv.weight] + ([conv.bias] if conv.bias is not None else []), build)
 
@@ -108,37 +113,66 @@ class PreciseForward:
         fc7 = c(m.fc7, c(m.fc6, x2))
         return conv4_3, fc7
 
-    def _extras(self, fc7):
+    _EXTRA_NAMES = [("conv6_1", "conv6_2"), ("conv7_1", "conv7_2"), ("conv8_1", "conv8_2"), ("conv9_1", "conv9_2"), ("conv10_1", "conv10_2")]
+
+    def _head(self, l, s2):
+        """conf + loc predictors of source map l in one launch -> (B, h, w, Cpad) float32 NHWC view."""
         m = self.model
-        c = self.conv
-        outs = []
-        x2 = fc7
-        names = [("conv6_1", "conv6_2"), ("conv7_1", "conv7_2"), ("conv8_1", "conv8_2"), ("conv9_1", "conv9_2"), ("conv10_1", "conv10_2")]
-        for a, b in names:
-            if not hasattr(m, a):
-                break
-            x2 = c(getattr(m, b), c(getattr(m, a), x2))
-            outs.append(x2)
-        return outs
+        ch, lh = m.conf_heads[l], m.loc_heads[l]
+        if not (self._same3(ch) and self._same3(lh)):
+            raise RuntimeError("predictor heads must be 3x3 'same' convolutions")
+        w, oscale, bias = self._head_filters(l)
+        y = nat.conv2d_x3(s2, w, bias, oscale, stride=1, padding=1, dilation=1, relu=False, out_f32=True)   # (B, Cpad, h, w)
+        return y.permute(0, 2, 3, 1)                      # NHWC view: the channel axis splits as (box, class) (:363-383)
+
+    def _streams(self, device):
+        key = str(device)
+        st = self._side.get(key)
+        if st is None:
+            st = self._side[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return st
 
     @torch.no_grad()
     def __call__(self, images):
         m = self.model
         x = m.preprocess(images)                                              # float32, channels_last
         conv4_3, fc7 = self._vgg(x)
-        norm = m.conv4_3_norm(conv4_3)                                        # L2Normalization on float32 (:316)
-        sources = [nat.x3_split(norm.contiguous(memory_format=torch.channels_last)), fc7] + self._extras(fc7)
-        if len(sources) != len(m.conf_heads):
+        n_heads = len(m.conf_heads)
+        names = [(a, b) for a, b in self._EXTRA_NAMES if hasattr(m, a)]
+        if 2 + len(names) != n_heads:
             raise RuntimeError("this builder's extra layers are not the ones PreciseForward knows")
+        # Three streams, as in the bf16 step (models/_common.py): the extra layers are a chain of eight small launches that leaves
+        # most CUs idle (0.44 ms), the two trunk heads do not depend on it (0.42 ms), and each small head only needs its own source
+        # map.  Main: the chain.  Side 1: conv4_3_norm + its head, fc7's head.  Side 2: the head of every extra map as soon as it
+        # exists.  One after the other they took 1.2 ms of an 8.3 ms forward (profiles/r03ze_x3_timeline.json).
+        main = torch.cuda.current_stream(x.device)
+        side1, side2 = self._streams(x.device)
+        trunk = torch.cuda.Event()
+        trunk.record(main)
+        ys = [None] * n_heads
+        with torch.cuda.stream(side1):
+            side1.wait_event(trunk)
+            norm = m.conv4_3_norm(conv4_3)                                    # L2Normalization on float32 (:316)
+            ys[0] = self._head(0, nat.x3_split(norm.contiguous(memory_format=torch.channels_last)))
+            ys[1] = self._head(1, fc7)
+        conv4_3.record_stream(side1)
+        fc7.record_stream(side1)
+        x2 = fc7
+        for k, (a, b) in enumerate(names):
+            x2 = self.conv(getattr(m, b), self.conv(getattr(m, a), x2))       # main stream
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side2):
+                side2.wait_event(ready)
+                ys[2 + k] = self._head(2 + k, x2)
+            x2.record_stream(side2)
+        main.wait_stream(side1)
+        main.wait_stream(side2)
         b = x.shape[0]
         confs, locs, sizes = [], [], []
-        for l, s2 in enumerate(sources):
+        for l, y in enumerate(ys):
+            y.record_stream(main)
             ch, lh = m.conf_heads[l], m.loc_heads[l]
-            if not (self._same3(ch) and self._same3(lh)):
-                raise RuntimeError("predictor heads must be 3x3 'same' convolutions")
-            w, oscale, bias = self._head_filters(l)
-            y = nat.conv2d_x3(s2, w, bias, oscale, stride=1, padding=1, dilation=1, relu=False, out_f32=True)   # (B, Cpad, h, w)
-            y = y.permute(0, 2, 3, 1)                                         # NHWC view: the channel axis splits as (box, class) (:363-383)
             confs.append(y[..., :ch.out_channels].reshape(b, -1, m.n_classes))
             locs.append(y[..., ch.out_channels:ch.out_channels + lh.out_channels].reshape(b, -1, 4))
             sizes.append((y.shape[1], y.shape[2]))

@@ -14,7 +14,7 @@ CASES = [  # B, H, W, C, Cout, k, stride, pad, dil, relu, pool
     (2, 75, 75, 128, 256, 3, 1, 1, 1, True, True),      # pooled, odd map ('same' pooling pads bottom / right)
     (2, 150, 150, 128, 128, 3, 1, 1, 1, True, True),    # conv2_2 + pool2: 2-D tiles of the slab kernel
     (2, 19, 19, 512, 512, 3, 1, 1, 1, False, False),    # conv5_x shape, no activation
-    (2, 150, 150, 64, 128, 3, 1, 1, 1, True, False),
+    (2, 150, 150, 64, 128, 3, 1, 1, 1, True, False),    # conv2_1: halo = the slab kernel's padded 64-channel form
     (2, 19, 19, 512, 1024, 3, 1, 6, 6, True, False),    # fc6: dilation 6
     (2, 19, 19, 1024, 256, 1, 1, 0, 1, True, False),
     (3, 19, 19, 256, 512, 3, 2, 1, 1, True, False),     # conv6_2
@@ -38,7 +38,10 @@ def test_x3_convolution_is_float32_grade(case, out_f32, halo, monkeypatch):
     x = (torch.randn((B, C, H, W), generator=g, device="cuda") * 30).relu().contiguous(memory_format=torch.channels_last)
     w = torch.randn((Cout, C, k, k), generator=g, device="cuda") * (2.0 / (k * k * C)) ** 0.5
     bias = torch.randn((Cout,), generator=g, device="cuda")
-    pw, oscale = nat.x3_pack_weight(w)
+    # 64 input channels on the slab kernel: the padded four-slice filter packing (conv2_1 in models/precise.py)
+    slab64 = halo and C == 64 and k == 3 and stride == 1 and pad == 1 and dil == 1 and Cout % 128 == 0
+    pw, oscale = nat.x3_pack_weight(w, slab64=slab64)
+    assert pw.shape[1] == (256 if slab64 else 3 * C)
     got = nat.conv2d_x3(nat.x3_split(x), pw, bias, oscale, stride=stride, padding=pad, dilation=dil, relu=relu, pool=pool, out_f32=out_f32)
     if not out_f32:
         c = got.shape[1] // 2
