@@ -82,7 +82,12 @@ def main():
     # package's own helper (device selected before init, dmabuf IPC mode, 127.0.0.1 rendezvous)
     from ssd_keras_amd import distributed as dp
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    rank, world, local_rank = dp.init_from_env("nccl")
+    # (SSD_BENCH_BACKEND=gloo SSD_BENCH_SHARE_GPU=1: every rank on GPU 0 over gloo -- only to exercise the N > 1 code path on a
+    # one-GPU box, tools/gpu_two_ranks_one_gpu.sh; the numbers of such a run mean nothing)
+    backend = os.environ.get("SSD_BENCH_BACKEND", "nccl")
+    if os.environ.get("SSD_BENCH_SHARE_GPU", "0") == "1":
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local_rank = dp.init_from_env(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
