@@ -392,6 +392,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
     images = torch.from_numpy(np.random.RandomState(100 + rank).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
     lf = SSDLoss(neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
     last = {}
+    trace = [] if os.environ.get("SSD_TRAIN_TRACE", "0") == "1" else None     # per-step losses (one host sync per step: not for timing)
 
     def step():
         y_true, _, _ = enc.encode_to_device(gt, device=dev)
@@ -403,11 +404,13 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         opt.step()
         last["loss"] = loss.detach()
         last.setdefault("first", loss.detach())
+        if trace is not None:
+            trace.append(("eager", round(float(loss), 4)))
 
     # One GPU: the step is ~600 launches and the eager host loop cannot issue them as fast as the GPU retires them (measured:
-    # 19.8 ms per step eager with 11 ms of kernels, profiles/r02g_train_timeline.json), so forward + loss + backward + SGD are
-    # captured ONCE into a HIP graph (static buffers for the images and the encoder's targets) and replayed; the encoder stays
-    # outside (its labels arrive from the host every step).  With DDP (N > 1) the step stays eager: RCCL's bucketed all-reduce
+    # 19.8 ms per step eager with 11 ms of kernels, profiles/r02g_train_timeline.json), so forward + loss + backward are
+    # captured ONCE into a HIP graph (static buffers for the images and the encoder's targets) and replayed; the encoder (its labels
+    # arrive from the host every step) and the optimizer step (see capture()) stay outside.  With DDP (N > 1) the step stays eager: RCCL's bucketed all-reduce
     # hooks inside a capture could not be exercised on this single-GPU box.
     graph = None
     how = "eager"
@@ -417,24 +420,37 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         y_static, _, _ = enc.encode_to_device(gt, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                                         # warm the allocator / autotune on the capture stream
+        def warm_step():                                                      # (a function: its autograd graph dies with its locals)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y_pred = ddp(images)
+            loss = lf.compute_loss(y_static, y_pred.float()).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+
+        with torch.cuda.stream(side):                                         # warm the allocator / autotune off the default stream
             for _ in range(2):
-                with torch.autocast("cuda", dtype=torch.bfloat16):
-                    y_pred = ddp(images)
-                loss = lf.compute_loss(y_static, y_pred.float()).mean()
-                opt.zero_grad(set_to_none=True)
-                loss.backward()
-                opt.step()
+                warm_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
+        # The optimizer step stays OUTSIDE the capture.  With torch.optim.SGD's multi-tensor kernels inside it, the replays that follow
+        # the first device-wide synchronize apply corrupted updates: replays 1-2 follow the eager trajectory, then the loss jumps 30.5 ->
+        # 96 (the same value on every box), later now and then to NaN -- the round-2 leg's "diverging" loss and r03z's NaN were this,
+        # not the learning rate.  Bisected with tools/debug_graph_leg.py (profiles/r03zk_train_graph_bisect.txt): it takes the
+        # libssdhip autograd functions AND the captured optimizer AND a synchronize between replays; no single kernel of ours (dgrad,
+        # pooling, ReLU / bias, L2Normalization, weight shadows, the loss -- each switched off in turn), not the encoder, not a stale
+        # autograd graph.  The mechanism inside the framework's graph memory handling is not established; the optimizer step issued
+        # eagerly after each replay follows the eager trajectory step for step.
+        import gc
+        gc.collect()
         g = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(g):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y_pred = ddp(images)
             loss_static = lf.compute_loss(y_static, y_pred.float()).mean()
-            loss_static.backward()
-            opt.step()
+            loss_static.backward()                        # writes the .grad tensors allocated here: the eager opt.step() reads them
+        torch.cuda.synchronize()
         graph = (g, y_static, loss_static)
 
     def graph_step():
@@ -442,7 +458,10 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         y_true, _, _ = enc.encode_to_device(gt, device=dev)
         y_static.copy_(y_true)
         g.replay()
+        opt.step()
         last["loss"] = loss_static.detach()
+        if trace is not None:
+            trace.append(("graph", round(float(loss_static), 4)))
 
     eager_ms = None
     with torch.cuda.device(dev):
@@ -463,7 +482,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
                 for _ in range(2):
                     graph_step()
                 torch.cuda.synchronize()
-                run, how = graph_step, "hipGraph replay (forward + loss + backward + SGD captured once)"
+                run, how = graph_step, "hipGraph replay (forward + loss + backward captured once) + eager SGD step"
             except Exception as exc:                                          # noqa: BLE001 -- fall back to the eager step
                 how = "eager (graph capture failed: %s: %s)" % (type(exc).__name__, str(exc)[:120])
                 torch.cuda.synchronize()
@@ -495,7 +514,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
             out_raw = {k: raw.get(k) for k in ("images_per_sec", "ms_per_step", "eager_ms_per_step", "first_loss", "final_loss", "launch", "error")
                        if raw.get(k) is not None}
     return {"regime": "tamed heads (filters x 1e-2, background bias + 4), lr 1e-7" if tame else "raw He-normal init, lr 1e-7",
-            "raw_init": out_raw, "eager_ms_per_step": round(eager_max, 3),
+            "raw_init": out_raw, "loss_trace": trace, "eager_ms_per_step": round(eager_max, 3),
             "rank_step_ms_min_max": [round(1e3 * fastest / steps, 3), round(1e3 * elapsed / steps, 3)],
             "allreduce_buckets": n_buckets, "bucket_cap_mb": 25,
             "workload": "SSD300 VGG-16 training step, 21 classes, batch %d per GPU (global %d), bf16 autocast + fp32 master "

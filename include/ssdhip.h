@@ -268,6 +268,13 @@ int ssdhip_l2_normalize_bwd(const void* x, const void* dy, const float* gamma, c
 int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
 int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, void* out, float* partial, long long n_pixels, int C,
                                    int n_blocks, void* stream);
+
+/* The same for a Conv2D(relu) -> MaxPooling2D(2, 2, 'same') pair (models/keras_ssd300.py:275-283: pool1 .. pool3) in ONE pass: y
+ * [B,H,W,C] the post-ReLU activation, gp [B,ceil(H/2),ceil(W/2),C] the pooled map's gradient; out [B,H,W,C] = max-pool gradient (first
+ * maximum of a window in row-major order, NaN wins) masked by y > 0; partial [n_blocks][C] as above with n_pixels = B H W.  Bit-identical
+ * to ssdhip_maxpool_bwd_nhwc_bf16 followed by ssdhip_relu_bwd_bias_nhwc_bf16. */
+int ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16(const void* y, const void* gp, void* out, float* partial, int B, int H, int W, int C,
+                                            int n_blocks, void* stream);
 int ssdhip_maxpool_bwd_nhwc_bf16(const void* x, const void* gy, void* gx, int B, int H, int W, int C, int kernel, int stride,
                                  int pad, int Ho, int Wo, void* stream);
 

@@ -459,6 +459,8 @@ def _train_lib():
         lib.ssdhip_relu_bwd_bias_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_vp]
         lib.ssdhip_maxpool_bwd_nhwc_bf16.restype = c_int
         lib.ssdhip_maxpool_bwd_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp]
+        lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16.restype = c_int
+        lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp]
         lib._train_bound = True
     return lib
 
@@ -478,6 +480,27 @@ def relu_bwd_bias(gy, y):
     with torch.cuda.device(gy.device):
         rc = lib.ssdhip_relu_bwd_bias_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(out), _ptr(partial), b * h * w, c, nb, current_stream_ptr(gy.device))
     check(rc, "ssdhip_relu_bwd_bias_nhwc_bf16")
+    return out, partial.sum(dim=0)
+
+
+def maxpool2_relu_bwd_bias(y, gp):
+    """Backward of `p = max_pool2d(y, 2, 2, ceil_mode=True)`, `y = relu(conv + bias)` up to the convolution in ONE pass: returns (the
+    full-resolution gradient masked by y > 0, bias gradient float32 [C]), or None when the channel count is not supported.  y (B, C, H,
+    W), gp (B, C, ceil(H/2), ceil(W/2)) bf16 with NHWC memory.  Bit-identical to maxpool_bwd followed by relu_bwd_bias."""
+    torch = _torch()
+    lib = _train_lib()
+    y, (b, h, w, c) = _nhwc_bf16(y, "y")
+    gp, (b2, ho, wo, c2) = _nhwc_bf16(gp, "gp")
+    if (b2, ho, wo, c2) != (b, (h + 1) // 2, (w + 1) // 2, c):
+        raise SsdHipError("gp must be the gradient of the 2x2 / stride-2 pooled map of y")
+    nb = lib.ssdhip_relu_bwd_bias_blocks(b * h * w, c)
+    if nb == 0:
+        return None
+    out = torch.empty_like(y)
+    partial = torch.empty((nb, c), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16(_ptr(y), _ptr(gp), _ptr(out), _ptr(partial), b, h, w, c, nb, current_stream_ptr(y.device))
+    check(rc, "ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16")
     return out, partial.sum(dim=0)
 
 

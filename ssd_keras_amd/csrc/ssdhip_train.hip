@@ -9,6 +9,10 @@
 //   * maxpool_bwd_kernel     dL/dx of max-pooling by GATHER: each input pixel recomputes the arg-max of the windows that cover it
 //                            (first maximum in row-major window order, NaN wins: max_pool2d's rule) and sums their gradients --
 //                            deterministic, no atomics, one write per element.
+//   * maxpool2_relu_bwd_bias_kernel   the two above in ONE pass for the Conv2D(relu) -> MaxPooling2D(2, 2) pairs (pool1 .. pool3:
+//                            the largest maps of the step): the pre-pool activation is read once, the pooled gradient once, the masked
+//                            full-resolution gradient written once -- the unmasked one (368 MB after conv1_2 at batch 32) is never
+//                            written or re-read.  Bit-identical to the two kernels run one after the other.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -110,6 +114,69 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint4* __restric
     }
 }
 
+// y: [B,H,W,C] post-ReLU activation (the pooling's input), gp: [B,Ho,Wo,C] gradient of the pooled map (2x2 windows, stride 2, clipped to
+// the map: Ho = ceil(H/2), Wo = ceil(W/2)), out: [B,H,W,C] = dL/dy masked by y > 0, partial: [gridDim.x][C] float32 channel sums of out.
+// The thread layout and the summation order are relu_bwd_bias_kernel's.
+__global__ __launch_bounds__(256) void maxpool2_relu_bwd_bias_kernel(const uint4* __restrict__ y, const uint4* __restrict__ gp,
+                                                                     uint4* __restrict__ out, float* __restrict__ partial, int H, int W,
+                                                                     int Ho, int Wo, u32 n_pixels, u32 cvec) {
+    __shared__ float red[256 * 8];
+    const u32 tid = threadIdx.x;
+    const u32 cg = tid % cvec, pl = tid / cvec, ppb = 256u / cvec;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (u32 px = blockIdx.x * ppb + pl; px < n_pixels; px += gridDim.x * ppb) {
+        const int w = (int)(px % (u32)W);
+        const u32 t = px / (u32)W;
+        const int h = (int)(t % (u32)H), b = (int)(t / (u32)H);
+        const int oh = h >> 1, ow = w >> 1;
+        const int h0 = 2 * oh, h1 = min(h0 + 2, H), w0 = 2 * ow, w1 = min(w0 + 2, W);
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { best[q] = -__builtin_inff(); arg[q] = -1; }
+        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+        for (int hi = h0; hi < h1; ++hi)
+            for (int wi = w0; wi < w1; ++wi) {
+                const uint4 v = y[((size_t)(b * H + hi) * W + wi) * cvec + cg];
+                const u32 vw[4] = {v.x, v.y, v.z, v.w};
+                const int pos = hi * W + wi;
+                if (hi == h && wi == w) mine = v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = tb2f(vw[q] & 0xffffu), c = tb2f(vw[q] >> 16);
+                    if (a > best[2 * q] || a != a) { best[2 * q] = a; arg[2 * q] = pos; }          // max_pool2d: first maximum, NaN wins
+                    if (c > best[2 * q + 1] || c != c) { best[2 * q + 1] = c; arg[2 * q + 1] = pos; }
+                }
+            }
+        const uint4 g = gp[((size_t)(b * Ho + oh) * Wo + ow) * cvec + cg];
+        const u32 gw[4] = {g.x, g.y, g.z, g.w}, vw[4] = {mine.x, mine.y, mine.z, mine.w};
+        const int me = h * W + w;
+        u32 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // maxpool_bwd_kernel's value (0 + g, rounded: -0 becomes +0), then relu_bwd_bias_kernel's mask
+            const u32 plo = tf2b(arg[2 * q] == me ? 0.f + tb2f(gw[q] & 0xffffu) : 0.f);
+            const u32 phi = tf2b(arg[2 * q + 1] == me ? 0.f + tb2f(gw[q] >> 16) : 0.f);
+            const u32 lo = (tb2f(vw[q] & 0xffffu) <= 0.f) ? 0u : plo;
+            const u32 hi = (tb2f(vw[q] >> 16) <= 0.f) ? 0u : phi;
+            o[q] = lo | (hi << 16);
+            acc[2 * q] += tb2f(lo);
+            acc[2 * q + 1] += tb2f(hi);
+        }
+        out[(size_t)px * cvec + cg] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[tid * 8 + q] = acc[q];
+    __syncthreads();
+    if (pl == 0) {
+        for (u32 j = 1; j < ppb; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += red[(j * cvec + cg) * 8 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) partial[(size_t)blockIdx.x * cvec * 8 + cg * 8 + q] = acc[q];
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -132,6 +199,20 @@ extern "C" int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, voi
     if (n_blocks <= 0 || n_blocks != ssdhip_relu_bwd_bias_blocks(n_pixels, C)) return SSDHIP_E_BADARG;
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy), static_cast<const uint4*>(y),
                        static_cast<uint4*>(out), partial, (u32)n_pixels, (u32)(C / 8));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// Backward of Conv2D(relu) -> MaxPooling2D(2, 2, clipped windows) up to the convolution, in one pass: y [B,H,W,C] the post-ReLU
+// activation, gp [B,ceil(H/2),ceil(W/2),C] the pooled map's gradient; out = the full-resolution gradient masked by y > 0, partial
+// [n_blocks][C] float32 per-workgroup channel sums of it (n_blocks = ssdhip_relu_bwd_bias_blocks(B H W, C); the caller adds them).
+extern "C" int ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16(const void* y, const void* gp, void* out, float* partial, int B, int H, int W, int C,
+                                                       int n_blocks, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!y || !gp || !out || !partial || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    const long long n = (long long)B * H * W;
+    if (n > 0x7fffffffLL || n_blocks <= 0 || n_blocks != ssdhip_relu_bwd_bias_blocks(n, C)) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(maxpool2_relu_bwd_bias_kernel, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(y),
+                       static_cast<const uint4*>(gp), static_cast<uint4*>(out), partial, H, W, (H + 1) / 2, (W + 1) / 2, (u32)n, (u32)(C / 8));
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

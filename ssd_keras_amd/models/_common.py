@@ -105,26 +105,64 @@ class _ConvBiasActFn(torch.autograd.Function):
                 gy = torch.ops.aten.threshold_backward(gy, y, 0)
         if gb is None and want_gb:
             gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32).to(bdt)
-        need_x = ctx.needs_input_grad[0]
-        gx = None
-        k = wb.shape[2]
-        same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
-                and wb.shape[0] % 64 == 0 and wb.shape[1] % 64 == 0 and k in (1, 3))
-        if need_x and same:
-            # the data gradient of a stride-1 'same' convolution IS a 'same' convolution of dL/dy with the filters transposed
-            # (Cin <-> Cout) and their taps flipped: the forward's MFMA kernel runs it, no bias, no activation
-            wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
-            # (the deep 3x3 layers through the slab kernel, csrc/ssdhip_convh.hip: bit-identical and faster, r02o)
-            import os
-            halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0
-                    and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
-            gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
-        masks = [need_x and gx is None, True, False]
-        gx_m, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
-                                                          masks)
-        if gx is None:
-            gx = gx_m
-        return (gx.to(xdt) if need_x else None), gw.to(wdt), gb, None, None, None, None, None, None, None
+        gx, gw = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0])
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None
+
+
+def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
+    """dL/dx and dL/dw of a convolution from the (masked) dL/dy: the data gradient of a stride-1 'same' layer through the forward's MFMA
+    kernel, the rest through aten.convolution_backward (MIOpen)."""
+    gx = None
+    k = wb.shape[2]
+    same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
+            and wb.shape[0] % 64 == 0 and wb.shape[1] % 64 == 0 and k in (1, 3))
+    import os
+    if need_x and same and os.environ.get("SSDHIP_NO_OWN_DGRAD", "0") != "1":
+        # the data gradient of a stride-1 'same' convolution IS a 'same' convolution of dL/dy with the filters transposed
+        # (Cin <-> Cout) and their taps flipped: the forward's MFMA kernel runs it, no bias, no activation
+        wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+        # (the deep 3x3 layers through the slab kernel, csrc/ssdhip_convh.hip: bit-identical and faster, r02o)
+        halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0
+                and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
+        gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
+    masks = [need_x and gx is None, True, False]
+    gx_m, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
+                                                      masks)
+    if gx is None and need_x:
+        gx = gx_m
+    return gx, gw
+
+
+class _ConvBiasActPoolFn(torch.autograd.Function):
+    """Conv2D(relu) -> MaxPooling2D(2, 2, 'same') of the TRAINING step (pool1 .. pool3) as one autograd node: forward = the layer's
+    MFMA kernel + the one-pass pooling kernel; backward = max-pool gradient, ReLU mask and bias gradient in ONE pass over the
+    full-resolution map (csrc/ssdhip_train.hip, maxpool2_relu_bwd_bias_kernel) -- the unmasked full-resolution gradient is never
+    written -- then the convolution's gradients as in _ConvBiasActFn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, wb=None, bb=None):
+        xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if wb is None:
+            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            bb = bias.detach().to(torch.bfloat16) if bias is not None else None
+        y = run(xb, wb, bb)
+        p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
+        ctx.save_for_backward(xb, wb, y)
+        ctx.conf = (stride, padding, dilation, weight.dtype, None if bias is None else bias.dtype, x.dtype)
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        xb, wb, y = ctx.saved_tensors
+        stride, padding, dilation, wdt, bdt, xdt = ctx.conf
+        gp = gp.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        fused = nat.maxpool2_relu_bwd_bias(y, gp)
+        if fused is None:
+            raise RuntimeError("channel count not supported by the fused pooling backward (the forward checks it)")
+        gy, gb32 = fused
+        gb = gb32.to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+        gx, gw = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0])
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -481,6 +519,13 @@ class SSDModel(nn.Module):
             name = (self._pick(("pool", tuple(x.shape), conv.out_channels, conv.kernel_size[0], conv.dilation[0], kernel, stride, pad),
                                cands) if len(cands) > 1 else "miopen")
             return cands[name]()
+        import os
+        if (kernel == 2 and stride == 2 and pad == 0 and ceil_mode and self._fused_train(x, conv) and conv.out_channels % 8 == 0
+                and 256 % (conv.out_channels // 8) == 0 and os.environ.get("SSDHIP_NO_FUSED_POOL_BWD", "0") != "1"):
+            run, _name = self._train_thunk(conv, x, True)
+            if run is not None:
+                wb, bb = self._bf16_shadow(conv)
+                return _ConvBiasActPoolFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, wb, bb)
         return self.max_pool(self.conv_act(conv, x, relu=True), kernel, stride, pad, ceil_mode=ceil_mode)
 
     def conv1_block_pool(self, c1, c2, x):
@@ -506,8 +551,9 @@ class SSDModel(nn.Module):
     def max_pool(self, x, kernel, stride, pad=0, ceil_mode=False):
         if self._fused(x) and x.shape[1] % 8 == 0:
             return nat.bias_act_maxpool(x, None, kernel, stride, pad, ceil_mode, relu=False)
+        import os
         if (self.fused_training and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and x.shape[1] % 8 == 0
-                and x.requires_grad):
+                and x.requires_grad and os.environ.get("SSDHIP_NO_OWN_POOL", "0") != "1"):
             return _MaxPoolFn.apply(x, kernel, stride, pad, ceil_mode)
         return F.max_pool2d(x, kernel, stride, pad, ceil_mode=ceil_mode)
 

@@ -70,3 +70,31 @@ def test_data_gradient_through_the_forward_kernel(cin, cout, k, d, hw):
     err = (got - want).abs()
     bound = 2.0 ** -7 * want.abs() + 1e-2 * want.pow(2).mean().sqrt()
     assert bool((err <= bound).all()), float((err - bound).max())
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 37, 41), (2, 128, 30, 30), (2, 256, 75, 75), (1, 64, 1, 1), (2, 64, 2, 3)])
+def test_fused_pool_relu_backward_equals_the_two_kernels(shape):
+    """Conv2D(relu) -> MaxPooling2D(2, 2, 'same') backward in one pass (maxpool2_relu_bwd_bias_kernel) against maxpool_bwd followed by
+    relu_bwd_bias on the same tensors: masked gradient bit-identical, bias gradient bit-identical (same thread layout, same order);
+    and against PyTorch's max_pool2d backward + threshold_backward.  Ties (ReLU zeros fill whole windows), NaNs and odd map sizes."""
+    torch, nat = _t()
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(3)
+    b, c, h, w = shape
+    y = torch.randn(shape, device="cuda", generator=g).clamp_min(0).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.permute(0, 2, 3, 1).reshape(-1)[::211] = float("nan")
+    gp = torch.randn((b, c, (h + 1) // 2, (w + 1) // 2), device="cuda", generator=g).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    gp.permute(0, 2, 3, 1).reshape(-1)[::53] = -0.0
+    got, gb = nat.maxpool2_relu_bwd_bias(y, gp)
+    gx = nat.maxpool_bwd(y, gp, 2, 2, 0)
+    want, wb = nat.relu_bwd_bias(gx, y)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(gb, wb)
+    # and the framework's own backward ops on a NaN-free copy (bf16 gradient of a 2x2 window = one term: exact)
+    y2 = torch.nan_to_num(y, nan=0.5)
+    yf = y2.float().requires_grad_(True)
+    F.max_pool2d(yf, 2, 2, 0, ceil_mode=True).backward(gp.float())
+    ref = torch.ops.aten.threshold_backward(yf.grad.to(torch.bfloat16), y2, 0)
+    got2, _ = nat.maxpool2_relu_bwd_bias(y2, gp)
+    assert torch.equal(got2.float(), ref.float())                           # (-0 and +0 compare equal)
