@@ -26,6 +26,8 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYC
     --kernel-trace --output-format csv -d $OUT/pmc_mfma -o fwd -- python $R/bench.py --graph 0 --steps 3 --warmup 8 --no-cpu-baseline --no-extra > $OUT/pmc_mfma.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_enc -o enc -- python $R/tools/time_encoder.py > $OUT/time_encoder.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_loss -o loss -- python $R/tools/time_loss.py > $OUT/time_loss.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x3 -o x3 -- python $R/tools/prof_x3.py > $OUT/prof_x3.log 2>&1
+cp $(find $OUT/trace_x3 -name "*kernel_stats.csv" | head -1) $OUT/x3_kernel_stats.csv 2>/dev/null
 cd $R
 python tools/pmc_fold.py $OUT/pmc_mfma ssdhip > $OUT/pmc_mfma_per_kernel.txt 2>&1
 cp $(find $OUT/trace_enc -name "*kernel_stats.csv" | head -1) $OUT/encoder_kernel_stats.csv 2>/dev/null
