@@ -23,7 +23,7 @@ from .. import _native as nat
 
 
 class PreciseForward:
-    def __init__(self, model):
+    def __init__(self, model, stream_priority=0):
         if not hasattr(model, "_vgg") or not hasattr(model, "extra_features"):
             raise TypeError("PreciseForward mirrors the VGG-based builders (ssd_300 / ssd_512)")
         if next(model.parameters()).dtype != torch.float32:
@@ -31,6 +31,11 @@ class PreciseForward:
         self.model = model
         self._packed = {}
         self._side = {}
+        # The two side streams of __call__ are PICKED: which hardware queues a process's streams share depends on how many were created
+        # before, and a pair that shares one with the default stream (or with each other) loses the overlap -- 6.9 ms against 7.4 ms
+        # with ordinary streams, 6.9 against 8.6 - 9.0 ms with high-priority ones, 8.3 ms inside bench.py against 7.1 ms alone
+        # (tools/time_x3_streams.py, r03zo / r03zz).  The first call per device times a few fresh pairs and keeps the fastest.
+        self._stream_priority = stream_priority
 
     # -- filters ------------------------------------------------------------------------------------------------------------------
     def _pack(self, key, tensors, build):
@@ -126,14 +131,38 @@ class PreciseForward:
         return y.permute(0, 2, 3, 1)                      # NHWC view: the channel axis splits as (box, class) (:363-383)
 
     def _streams(self, device):
-        key = str(device)
-        st = self._side.get(key)
-        if st is None:
-            st = self._side[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-        return st
+        return self._side[str(device)]
+
+    def _pick_streams(self, images, n_pairs=4):
+        key = str(images.device)
+        best = None
+        for _ in range(n_pairs):
+            pair = (torch.cuda.Stream(device=images.device, priority=self._stream_priority),
+                    torch.cuda.Stream(device=images.device, priority=self._stream_priority))
+            self._side[key] = pair
+            self._forward(images)                                             # filters packed, allocator warm
+            torch.cuda.synchronize(images.device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._forward(images)
+            self._forward(images)
+            b.record()
+            b.synchronize()
+            t = a.elapsed_time(b)
+            if best is None or t < best[0]:
+                best = (t, pair)
+        self._side[key] = best[1]
 
     @torch.no_grad()
     def __call__(self, images):
+        if str(images.device) not in self._side:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("call PreciseForward once outside a stream capture first (it times its side streams)")
+            self._pick_streams(images)
+        return self._forward(images)
+
+    @torch.no_grad()
+    def _forward(self, images):
         m = self.model
         x = m.preprocess(images)                                              # float32, channels_last
         conv4_3, fc7 = self._vgg(x)
