@@ -428,6 +428,31 @@ int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, const void* b1,
 int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Image half of the training-time augmentation (csrc/ssdhip_image.hip): what the reference does per image on the host
+ * through OpenCV (data_generator/object_detection_2d_photometric_ops.py:23-480, object_detection_2d_geometric_ops.py:27-148), for a
+ * batch of images resident on the device.  dtype codes: 0 uint8, 1 float32, 2 float64.
+ *
+ * ssdhip_image_program   x [n_images][pixels][3] (uint8 | float32 | float64) -> y (dtype out_dtype): image i runs ops[i][0..15] (0 ends):
+ *     1 astype(float32)   2 np.round(.).astype(uint8)   3 brightness: clip(v + arg, 0, 255)   4 contrast: clip(127.5 + arg (v - 127.5), 0, 255)
+ *     5 saturation: channel 1 = clip(ch1 * arg, 0, 255)   6 hue: channel 0 = (ch0 + arg) % 180   7 RGB -> HSV   8 HSV -> RGB
+ *     9 RGB -> grey on all three channels   10 channel permutation arg = o0 + 4 o1 + 16 o2
+ *   in NumPy's arithmetic for the array's current dtype (:128-130, :185, :242, :300: float32 operations on float32 images; float64
+ *   results for uint8 images under 3 / 4; truncating in-place stores for 5 / 6 on uint8 images); 7 / 8 are cv2.cvtColor's 8-bit
+ *   (H in [0, 180)) or float32 (H in [0, 360)) conversions.  out_dtype must be the dtype the program ends in.  ops / args: device arrays
+ *   [n_images][16] (int32 / float64).
+ * ssdhip_image_resize_u8 cv2.resize as separable resampling (object_detection_2d_geometric_ops.py:70-72): x [B,H,W,C] -> y [B,Ho,Wo,C],
+ *   out = rint(sum_j wy[yo][j] * (sum_t wx[xo][t] * x[iy[yo][j]][ix[xo][t]])) clipped to [0, 255]; the caller builds the tap tables
+ *   (device arrays [Wo][nx], [Ho][ny]; int32 indices, float64 weights) for the interpolation mode it wants.
+ * ssdhip_image_hist_u8   256-bin histogram of one channel of an interleaved uint8 image (cv2.equalizeHist's first half, :407).
+ * ssdhip_image_lut_u8    y = table[x] on the channels of channel_mask, x elsewhere (cv2.LUT :359 / the equalisation table). */
+int ssdhip_image_program(const void* x, int in_dtype, void* y, int out_dtype, int n_images, long long pixels_per_image,
+                         const int* ops_dev, const double* args_dev, void* stream);
+int ssdhip_image_resize_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, const int* ix_dev, const double* wx_dev,
+                           int nx, const int* iy_dev, const double* wy_dev, int ny, void* stream);
+int ssdhip_image_hist_u8(const void* x, long long n_pixels, int C, int channel, unsigned int* hist_dev, void* stream);
+int ssdhip_image_lut_u8(const void* x, void* y, long long n_values, int C, int channel_mask, const void* table_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

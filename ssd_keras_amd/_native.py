@@ -1145,3 +1145,112 @@ def box_filter(boxes, box_image, image_hw, check_overlap, check_min_area, check_
                                    float(lower), float(upper), float(min_area), BORDER[border_pixels], _ptr(keep), current_stream_ptr(dev))
     check(rc, "ssdhip_box_filter")
     return keep
+
+
+# ---- image half of the augmentation (csrc/ssdhip_image.hip) ----------------------------------------------------------------------
+IMG_U8, IMG_F32, IMG_F64 = 0, 1, 2
+IMG_OPS = {"end": 0, "to_f32": 1, "to_u8": 2, "brightness": 3, "contrast": 4, "saturation": 5, "hue": 6, "rgb2hsv": 7, "hsv2rgb": 8,
+           "rgb2gray": 9, "swap": 10}
+IMG_PROG = 16
+
+
+def _image_lib():
+    lib = load()
+    if not getattr(lib, "_image_bound", False):
+        c_int, c_vp, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+        lib.ssdhip_image_program.restype = c_int
+        lib.ssdhip_image_program.argtypes = [c_vp, c_int, c_vp, c_int, c_int, c_ll, c_vp, c_vp, c_vp]
+        lib.ssdhip_image_resize_u8.restype = c_int
+        lib.ssdhip_image_resize_u8.argtypes = [c_vp, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp]
+        lib.ssdhip_image_hist_u8.restype = c_int
+        lib.ssdhip_image_hist_u8.argtypes = [c_vp, c_ll, c_int, c_int, c_vp, c_vp]
+        lib.ssdhip_image_lut_u8.restype = c_int
+        lib.ssdhip_image_lut_u8.argtypes = [c_vp, c_vp, c_ll, c_int, c_int, c_vp, c_vp]
+        lib._image_bound = True
+    return lib
+
+
+def _img_dtype_code(t):
+    torch = _torch()
+    code = {torch.uint8: IMG_U8, torch.float32: IMG_F32, torch.float64: IMG_F64}.get(t.dtype)
+    if code is None:
+        raise SsdHipError("images are uint8, float32 or float64")
+    return code
+
+
+def image_program(images, ops, args, out_dtype):
+    """Run per-image pointwise programs (ssdhip_image_program): images (B, H, W, 3) CUDA uint8 | float32 | float64 contiguous; ops (B, 16) int32,
+    args (B, 16) float64 (host arrays or CUDA tensors); out_dtype a torch dtype (what the programs end in).  Returns (B, H, W, 3)."""
+    torch = _torch()
+    lib = _image_lib()
+    require_cuda(images, "images")
+    if images.dim() != 4 or images.shape[3] != 3 or not images.is_contiguous():
+        raise SsdHipError("images must be a contiguous (B, H, W, 3) tensor")
+    b, h, w, _ = images.shape
+    ops = to_device(ops, device=images.device, dtype=torch.int32).contiguous()
+    args = to_device(args, device=images.device, dtype=torch.float64).contiguous()
+    if tuple(ops.shape) != (b, IMG_PROG) or tuple(args.shape) != (b, IMG_PROG):
+        raise SsdHipError("ops / args must be (%d, %d)" % (b, IMG_PROG))
+    out = torch.empty((b, h, w, 3), dtype=out_dtype, device=images.device)
+    in_code = _img_dtype_code(images)
+    with torch.cuda.device(images.device):
+        rc = lib.ssdhip_image_program(_ptr(images), in_code, _ptr(out), _img_dtype_code(out), b, h * w, _ptr(ops), _ptr(args),
+                                      current_stream_ptr(images.device))
+    check(rc, "ssdhip_image_program")
+    return out
+
+
+def image_resize_u8(images, out_h, out_w, ix, wx, iy, wy):
+    """ssdhip_image_resize_u8: images (B, H, W, C) CUDA uint8; ix / wx (out_w, nx), iy / wy (out_h, ny) tap tables (int32 / float64)."""
+    torch = _torch()
+    lib = _image_lib()
+    require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 4 or not images.is_contiguous():
+        raise SsdHipError("images must be a contiguous (B, H, W, C) uint8 tensor")
+    b, h, w, c = images.shape
+    dev = images.device
+    ix = to_device(ix, device=dev, dtype=torch.int32).contiguous()
+    wx = to_device(wx, device=dev, dtype=torch.float64).contiguous()
+    iy = to_device(iy, device=dev, dtype=torch.int32).contiguous()
+    wy = to_device(wy, device=dev, dtype=torch.float64).contiguous()
+    if ix.shape != wx.shape or iy.shape != wy.shape or ix.shape[0] != out_w or iy.shape[0] != out_h:
+        raise SsdHipError("tap tables must be (out_w, nx) and (out_h, ny)")
+    out = torch.empty((b, out_h, out_w, c), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_image_resize_u8(_ptr(images), _ptr(out), b, h, w, out_h, out_w, c, _ptr(ix), _ptr(wx), int(ix.shape[1]), _ptr(iy),
+                                        _ptr(wy), int(iy.shape[1]), current_stream_ptr(dev))
+    check(rc, "ssdhip_image_resize_u8")
+    return out
+
+
+def image_hist_u8(image, channel):
+    """256-bin histogram (CUDA int64 tensor) of one channel of an (..., C) uint8 CUDA image."""
+    torch = _torch()
+    lib = _image_lib()
+    require_cuda(image, "image")
+    if image.dtype != torch.uint8 or not image.is_contiguous():
+        raise SsdHipError("image must be contiguous uint8")
+    c = int(image.shape[-1])
+    hist = torch.empty((256,), dtype=torch.int32, device=image.device)
+    with torch.cuda.device(image.device):
+        rc = lib.ssdhip_image_hist_u8(_ptr(image), image.numel() // c, c, int(channel), _ptr(hist), current_stream_ptr(image.device))
+    check(rc, "ssdhip_image_hist_u8")
+    return hist.to(torch.int64)
+
+
+def image_lut_u8(image, table, channel_mask):
+    """table[image] on the channels of channel_mask (bit c = channel c), the other channels copied: (..., C) uint8 CUDA image."""
+    torch = _torch()
+    lib = _image_lib()
+    require_cuda(image, "image")
+    if image.dtype != torch.uint8 or not image.is_contiguous():
+        raise SsdHipError("image must be contiguous uint8")
+    table = to_device(table, device=image.device, dtype=torch.uint8).contiguous()
+    if table.numel() != 256:
+        raise SsdHipError("the table has 256 entries")
+    out = torch.empty_like(image)
+    with torch.cuda.device(image.device):
+        rc = lib.ssdhip_image_lut_u8(_ptr(image), _ptr(out), image.numel(), int(image.shape[-1]), int(channel_mask), _ptr(table),
+                                     current_stream_ptr(image.device))
+    check(rc, "ssdhip_image_lut_u8")
+    return out

@@ -1,15 +1,27 @@
-"""Drop-in for the box-level half of the reference's data_generator/data_augmentation_chain_original_ssd.py (SURVEY section 8f row
-4): `SSDRandomCrop` :29-101 and `SSDExpand` :103-162 -- the random crops (Caffe SSD `batch_sampler`) and the random expansion
-(`train_transform_param`) of the original SSD training pipeline.  Both are configurations of the patch sampling ops; the IoU
-validation of the candidate crops runs on the GPU, one launch per sampling round (object_detection_2d_patch_sampling_ops.py).
+"""Drop-in for the reference's data_generator/data_augmentation_chain_original_ssd.py: `SSDRandomCrop`
+:29-101 and `SSDExpand` :103-162 -- the random crops (Caffe SSD `batch_sampler`) and the random expansion (`train_transform_param`)
+of the original SSD training pipeline, both configurations of the patch sampling ops with the IoU validation of the candidate crops on
+the GPU (object_detection_2d_patch_sampling_ops.py) -- `SSDPhotometricDistortions` :146-208 and the whole `SSDDataAugmentation` chain
+:210-280 (photometric distortions -> expansion -> random crop -> random flip -> resize with a random interpolation mode).
 
-Not here: `SSDPhotometricDistortions` and the `SSDDataAugmentation` chain that strings all of them together with a resize -- they
-are OpenCV colour-space and interpolation calls (SURVEY section 8f row 4's image half), not part of the box path.
+The photometric distortions of one image are ONE kernel launch: the chain's random draws are made first, in the reference's order, and
+turned into a per-image program of pointwise steps (csrc/ssdhip_image.hip) -- with its uint8 <-> float32 round trips and their
+roundings, exactly as the reference's list of transforms would apply them one NumPy pass at a time.  `distort_batch` does the same for
+a CUDA batch: one draw sequence per image, one launch for all of them.
 """
 from __future__ import annotations
 
+import inspect
+
+import numpy as np
+
+from . import _image_ops as iop
+from .object_detection_2d_geometric_ops import (INTER_AREA, INTER_CUBIC, INTER_LANCZOS4, INTER_LINEAR, INTER_NEAREST, RandomFlip,
+                                                ResizeRandomInterp)
 from .object_detection_2d_image_boxes_validation_utils import BoundGenerator, BoxFilter, ImageValidator
 from .object_detection_2d_patch_sampling_ops import PatchCoordinateGenerator, RandomPatch, RandomPatchInf
+from .object_detection_2d_photometric_ops import (ConvertTo3Channels, RandomBrightness, RandomChannelSwap, RandomContrast, RandomHue,
+                                                  RandomSaturation)
 
 _DEFAULT_FORMAT = {'class_id': 0, 'xmin': 1, 'ymin': 2, 'xmax': 3, 'ymax': 4}
 
@@ -52,3 +64,70 @@ class SSDExpand:
     def __call__(self, image, labels=None, return_inverter=False):
         self.expand.labels_format = self.labels_format
         return self.expand(image, labels, return_inverter)
+
+
+class SSDPhotometricDistortions:
+    '''The photometric distortions of the original SSD (`train_transform_param`): random brightness (+-32), contrast (0.5-1.5),
+    saturation (0.5-1.5) and hue (+-18), each with probability 0.5, contrast before or after the HSV part with probability 0.5 each,
+    never a channel swap (reference :146-208).'''
+
+    def __init__(self):
+        self.convert_to_3_channels = ConvertTo3Channels()
+        self.random_brightness = RandomBrightness(lower=-32, upper=32, prob=0.5)
+        self.random_contrast = RandomContrast(lower=0.5, upper=1.5, prob=0.5)
+        self.random_saturation = RandomSaturation(lower=0.5, upper=1.5, prob=0.5)
+        self.random_hue = RandomHue(max_delta=18, prob=0.5)
+        self.random_channel_swap = RandomChannelSwap(prob=0.0)
+
+    def draw(self):
+        """The random draws of one call, in the reference's order, as the program of pointwise steps they select."""
+        hsv_part = lambda: ([("to_u8", 0), ("rgb2hsv", 0), ("to_f32", 0)] + self.random_saturation.draw() + self.random_hue.draw()
+                            + [("to_u8", 0), ("hsv2rgb", 0)])
+        if np.random.choice(2):                                            # sequence 1: contrast before the HSV part (:164-175)
+            steps = [("to_f32", 0)] + self.random_brightness.draw() + self.random_contrast.draw() + hsv_part()
+            steps += self.random_channel_swap.draw()
+        else:                                                              # sequence 2: contrast after it (:177-190)
+            steps = [("to_f32", 0)] + self.random_brightness.draw() + hsv_part()
+            steps += [("to_f32", 0)] + self.random_contrast.draw() + [("to_u8", 0)] + self.random_channel_swap.draw()
+        return steps
+
+    def __call__(self, image, labels):
+        image, labels = self.convert_to_3_channels(image, labels)
+        return iop.run(image, self.draw()), labels
+
+    def distort_batch(self, images):
+        """images (B, H, W, 3) CUDA uint8 or float32 -> distorted uint8 batch: one draw sequence per image (the order a loop over the
+        reference's chain would make them in), ONE launch."""
+        return iop.run_batch(images, [self.draw() for _ in range(int(images.shape[0]))])
+
+
+class SSDDataAugmentation:
+    '''The data augmentation pipeline of the original Caffe SSD (reference :210-280): photometric distortions, expansion, random crop,
+    random horizontal flip, resize to the network input with a random interpolation mode (degenerate boxes dropped).'''
+
+    def __init__(self, img_height=300, img_width=300, background=(123, 117, 104), labels_format=_DEFAULT_FORMAT):
+        self.labels_format = labels_format
+        self.photometric_distortions = SSDPhotometricDistortions()
+        self.expand = SSDExpand(background=background, labels_format=self.labels_format)
+        self.random_crop = SSDRandomCrop(labels_format=self.labels_format)
+        self.random_flip = RandomFlip(dim='horizontal', prob=0.5, labels_format=self.labels_format)
+        # resizing can shrink small boxes to zero height / width: those are dropped
+        self.box_filter = BoxFilter(check_overlap=False, check_min_area=False, check_degenerate=True, labels_format=self.labels_format)
+        self.resize = ResizeRandomInterp(height=img_height, width=img_width,
+                                         interpolation_modes=[INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4],
+                                         box_filter=self.box_filter, labels_format=self.labels_format)
+        self.sequence = [self.photometric_distortions, self.expand, self.random_crop, self.random_flip, self.resize]
+
+    def __call__(self, image, labels, return_inverter=False):
+        self.expand.labels_format = self.labels_format
+        self.random_crop.labels_format = self.labels_format
+        self.random_flip.labels_format = self.labels_format
+        self.resize.labels_format = self.labels_format
+        inverters = []
+        for transform in self.sequence:
+            if return_inverter and ('return_inverter' in inspect.signature(transform).parameters):
+                image, labels, inverter = transform(image, labels, return_inverter=True)
+                inverters.append(inverter)
+            else:
+                image, labels = transform(image, labels)
+        return (image, labels, inverters[::-1]) if return_inverter else (image, labels)

@@ -360,6 +360,49 @@ def gen_patch_sampling():
     save("patch_sampling", **out)
 
 
+def gen_image_ops():
+    """The reference's photometric ops, its resize / flip ops, SSDPhotometricDistortions and the whole SSDDataAugmentation chain
+    (data_generator/object_detection_2d_photometric_ops.py, object_detection_2d_geometric_ops.py:27-262,
+    data_augmentation_chain_original_ssd.py:146-280) on the seeded cases of tests/image_cases.py.  OpenCV is not installed: the
+    modules run with a `cv2` built on oracle/np_image.py (cvtColor / LUT / equalizeHist / resize restated from OpenCV's published
+    algorithms).  So these vectors pin everything the reference does AROUND those four primitives -- dtype round trips, NumPy
+    arithmetic, clipping, in-place stores, random draws, label arithmetic, inverters, box filtering -- not the primitives."""
+    import types
+    from oracle import np_image as npi
+    for name in [m for m in sys.modules if m == "cv2" or m.startswith("data_generator")]:
+        del sys.modules[name]
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_RGB2HSV, cv2.COLOR_HSV2RGB, cv2.COLOR_RGB2GRAY = npi.COLOR_RGB2HSV, npi.COLOR_HSV2RGB, npi.COLOR_RGB2GRAY
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.INTER_LANCZOS4 = 0, 1, 2, 3, 4
+    cv2.BORDER_CONSTANT = 0
+    cv2.cvtColor = lambda image, code: npi.cvt_color(np.ascontiguousarray(image), code)
+    cv2.LUT = lambda image, table: npi.lut(image, table)
+    cv2.equalizeHist = lambda plane: npi.equalize_hist(np.ascontiguousarray(plane))
+    cv2.resize = lambda image, dsize=None, interpolation=1: npi.resize(np.ascontiguousarray(image), dsize, interpolation)
+    sys.modules["cv2"] = cv2
+    import data_generator.object_detection_2d_photometric_ops as pho
+    import data_generator.object_detection_2d_geometric_ops as geo
+    import data_generator.object_detection_2d_image_boxes_validation_utils as val
+    import data_generator.data_augmentation_chain_original_ssd as chain
+    from tests import image_cases as ic
+    ns = types.SimpleNamespace(BoxFilter=val.BoxFilter, SSDPhotometricDistortions=chain.SSDPhotometricDistortions,
+                               SSDDataAugmentation=chain.SSDDataAugmentation, Resize=geo.Resize, ResizeRandomInterp=geo.ResizeRandomInterp,
+                               Flip=geo.Flip, RandomFlip=geo.RandomFlip)
+    for name in ("ConvertColor", "ConvertDataType", "ConvertTo3Channels", "Hue", "RandomHue", "Saturation", "RandomSaturation", "Brightness",
+                 "RandomBrightness", "Contrast", "RandomContrast", "HistogramEqualization", "RandomHistogramEqualization", "ChannelSwap",
+                 "RandomChannelSwap"):
+        setattr(ns, name, getattr(pho, name))
+    out = {"n_cases": np.array(len(ic.CASES))}
+    for i, case in enumerate(ic.CASES):
+        res = ic.run(ns, case)
+        for k, v in res.items():
+            out["i%03d_%s" % (i, k)] = v
+        out["i%03d_case" % i] = np.array(repr(case))
+    save("image_ops", **out)
+    for name in [m for m in sys.modules if m == "cv2" or m.startswith("data_generator")]:
+        del sys.modules[name]
+
+
 def gen_anchors():
     out = {}
     for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
@@ -517,7 +560,7 @@ def gen_decoder():
 
 if __name__ == "__main__":
     # box_filter / patch_sampling import the reference's real data_generator package; gen_evaluator stubs what is left of it
-    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
+    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_image_ops, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
     wanted = set(sys.argv[1:])
     for g in gens:
         if not wanted or g.__name__[4:] in wanted:
