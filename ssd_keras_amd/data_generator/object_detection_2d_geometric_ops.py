@@ -110,8 +110,7 @@ class RandomFlip:
         self.flip = Flip(dim=self.dim, labels_format=self.labels_format)
 
     def __call__(self, image, labels=None):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            self.flip.labels_format = self.labels_format
-            return self.flip(image, labels)
-        return image if labels is None else (image, labels)
+        if np.random.uniform(0, 1) < (1.0 - self.prob):
+            return image if labels is None else (image, labels)
+        self.flip.labels_format = self.labels_format
+        return self.flip(image, labels)

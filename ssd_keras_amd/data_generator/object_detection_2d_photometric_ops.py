@@ -20,6 +20,16 @@ def _ret(image, labels):
     return image if labels is None else (image, labels)
 
 
+def _fires(prob):
+    """One uniform draw per call of a random op; it acts when the draw reaches 1 - prob (so prob = 0 never acts: the draw is < 1)."""
+    return np.random.uniform(0, 1) >= (1.0 - prob)
+
+
+def _check_range(lower, upper):
+    if lower >= upper:
+        raise ValueError("`upper` must be greater than `lower`.")
+
+
 def _assign(image, result):
     """The reference's `image[:, :, c] = ...` ops modify the caller's array: so do these."""
     if isinstance(image, np.ndarray) and image.flags.writeable and image.dtype == result.dtype and image.shape == result.shape:
@@ -105,11 +115,10 @@ class RandomHue:
 
     def draw(self):
         """The op's random draws in the reference's order -> the program steps of this call."""
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            self.change_hue.delta = np.random.uniform(-self.max_delta, self.max_delta)
-            return [("hue", self.change_hue.delta)]
-        return []
+        if not _fires(self.prob):
+            return []
+        self.change_hue.delta = np.random.uniform(-self.max_delta, self.max_delta)
+        return [("hue", self.change_hue.delta)]
 
     def __call__(self, image, labels=None):
         steps = self.draw()
@@ -133,19 +142,17 @@ class Saturation:
 
 class RandomSaturation:
     def __init__(self, lower=0.3, upper=2.0, prob=0.5):
-        if lower >= upper:
-            raise ValueError("`upper` must be greater than `lower`.")
+        _check_range(lower, upper)
         self.lower = lower
         self.upper = upper
         self.prob = prob
         self.change_saturation = Saturation(factor=1.0)
 
     def draw(self):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            self.change_saturation.factor = np.random.uniform(self.lower, self.upper)
-            return [("saturation", self.change_saturation.factor)]
-        return []
+        if not _fires(self.prob):
+            return []
+        self.change_saturation.factor = np.random.uniform(self.lower, self.upper)
+        return [("saturation", self.change_saturation.factor)]
 
     def __call__(self, image, labels=None):
         if self.draw():
@@ -166,19 +173,17 @@ class Brightness:
 
 class RandomBrightness:
     def __init__(self, lower=-84, upper=84, prob=0.5):
-        if lower >= upper:
-            raise ValueError("`upper` must be greater than `lower`.")
+        _check_range(lower, upper)
         self.lower = float(lower)
         self.upper = float(upper)
         self.prob = prob
         self.change_brightness = Brightness(delta=0)
 
     def draw(self):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            self.change_brightness.delta = np.random.uniform(self.lower, self.upper)
-            return [("brightness", self.change_brightness.delta)]
-        return []
+        if not _fires(self.prob):
+            return []
+        self.change_brightness.delta = np.random.uniform(self.lower, self.upper)
+        return [("brightness", self.change_brightness.delta)]
 
     def __call__(self, image, labels=None):
         if self.draw():
@@ -201,19 +206,17 @@ class Contrast:
 
 class RandomContrast:
     def __init__(self, lower=0.5, upper=1.5, prob=0.5):
-        if lower >= upper:
-            raise ValueError("`upper` must be greater than `lower`.")
+        _check_range(lower, upper)
         self.lower = lower
         self.upper = upper
         self.prob = prob
         self.change_contrast = Contrast(factor=1.0)
 
     def draw(self):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            self.change_contrast.factor = np.random.uniform(self.lower, self.upper)
-            return [("contrast", self.change_contrast.factor)]
-        return []
+        if not _fires(self.prob):
+            return []
+        self.change_contrast.factor = np.random.uniform(self.lower, self.upper)
+        return [("contrast", self.change_contrast.factor)]
 
     def __call__(self, image, labels=None):
         if self.draw():
@@ -238,19 +241,15 @@ class Gamma:
 
 class RandomGamma:
     def __init__(self, lower=0.25, upper=2.0, prob=0.5):
-        if lower >= upper:
-            raise ValueError("`upper` must be greater than `lower`.")
+        _check_range(lower, upper)
         self.lower = lower
         self.upper = upper
         self.prob = prob
 
     def __call__(self, image, labels=None):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            gamma = np.random.uniform(self.lower, self.upper)
-            change_gamma = Gamma(gamma=gamma)
-            return change_gamma(image, labels)
-        return _ret(image, labels)
+        if not _fires(self.prob):
+            return _ret(image, labels)
+        return Gamma(gamma=np.random.uniform(self.lower, self.upper))(image, labels)
 
 
 class HistogramEqualization:
@@ -270,10 +269,7 @@ class RandomHistogramEqualization:
         self.equalize = HistogramEqualization()
 
     def __call__(self, image, labels=None):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            return self.equalize(image, labels)
-        return _ret(image, labels)
+        return self.equalize(image, labels) if _fires(self.prob) else _ret(image, labels)
 
 
 class ChannelSwap:
@@ -297,12 +293,10 @@ class RandomChannelSwap:
         self.swap_channels = ChannelSwap(order=(0, 1, 2))
 
     def draw(self):
-        p = np.random.uniform(0, 1)
-        if p >= (1.0 - self.prob):
-            i = np.random.randint(5)
-            self.swap_channels.order = self.permutations[i]
-            return [("swap", iop.swap_code(self.swap_channels.order))]
-        return []
+        if not _fires(self.prob):
+            return []
+        self.swap_channels.order = self.permutations[np.random.randint(5)]
+        return [("swap", iop.swap_code(self.swap_channels.order))]
 
     def __call__(self, image, labels=None):
         if self.draw():
