@@ -319,6 +319,7 @@ def main():
             extra["conv_roofline_fp32"] = bx.fp32_forward_leg(dev, B)
             extra["conv_roofline_fp32x3"] = bx.fp32x3_forward_leg(dev, B, extra["conv_roofline_fp32"])
             extra["evaluator"] = bx.evaluator_leg(dev, with_cpu)
+            extra["augmentation"] = bx.augmentation_leg(dev, B, with_cpu)
         if args.train_steps > 0:
             tr = bx.train_leg(dev, rank, world, B, steps=args.train_steps, warmup=3)
             if isinstance(tr, dict) and "miopen" in str(tr.get("error", "")).lower():

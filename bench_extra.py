@@ -528,6 +528,52 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
 
 
 @_guard
+def augmentation_leg(dev, B, with_cpu=True):
+    """SURVEY 8f row 4, image half: the photometric distortions of the original-SSD chain (one launch per batch) and the resize to the
+    network input on device-resident VOC-sized uint8 batches, against the NumPy restatement (oracle/np_image.py: the reference's own
+    expressions + OpenCV's published conversions) on a bounded sample.  Python side included in the GPU times."""
+    from ssd_keras_amd.data_generator import _image_ops as iop
+    from ssd_keras_amd.data_generator.data_augmentation_chain_original_ssd import SSDPhotometricDistortions
+    rng = np.random.RandomState(0)
+    host = rng.randint(0, 256, size=(B, 375, 500, 3)).astype(np.uint8)
+    batch = torch.from_numpy(host).to(dev)
+    d = SSDPhotometricDistortions()
+    state = np.random.get_state()
+    np.random.seed(0)
+    progs = [d.draw() for _ in range(B)]
+    np.random.set_state(state)
+    with torch.cuda.device(dev):
+        out = iop.run_batch(batch, progs)
+        t_pho = _events_ms(lambda: iop.run_batch(batch, progs), 20)
+        res = {}
+        for name, interp in (("nearest", 0), ("linear", 1), ("cubic", 2), ("area", 3), ("lanczos4", 4)):
+            iop.resize(batch, 300, 300, interp)
+            res[name] = round(_events_ms(lambda: iop.resize(batch, 300, 300, interp), 10), 4)
+        small = iop.resize(batch, 300, 300, 1)
+    leg = {"workload": "batch %d of 375 x 500 x 3 uint8 images resident on the device" % B,
+           "photometric_ms_per_batch": round(t_pho, 4), "photometric_images_per_sec": round(B / (t_pho * 1e-3)),
+           "photometric_GBps_read_plus_write": round(2 * batch.numel() / (t_pho * 1e-3) / 1e9, 1),
+           "resize_to_300x300_ms_per_batch": res}
+    if with_cpu:
+        from oracle import np_image as npi
+        n = 2
+        t = time.perf_counter()
+        want = []
+        for i in range(n):
+            enc = iop.encode(progs[i])
+            want.append(npi.run_program(host[i], enc[0], enc[1]))
+        cpu_pho = (time.perf_counter() - t) / n
+        t = time.perf_counter()
+        want_small = npi.resize(host[0], (300, 300), 1)
+        cpu_res = time.perf_counter() - t
+        leg["cpu"] = {"photometric_ms_per_img": round(1e3 * cpu_pho, 2), "resize_linear_ms_per_img": round(1e3 * cpu_res, 2), "cores": 1, "kind": "port",
+                      "sample": "oracle/np_image.py run_program on %d images, resize on 1" % n,
+                      "hip_equals_port_on_the_sample": bool(all(np.array_equal(out[i].cpu().numpy(), want[i]) for i in range(n))
+                                                            and np.array_equal(small[0].cpu().numpy(), want_small))}
+    return leg
+
+
+@_guard
 def evaluator_leg(dev, with_cpu=True):
     """Evaluator.match_predictions (the reference's Python loop over every prediction of every class) with the
     matching on the GPU vs the NumPy port, on a VOC2007-test-sized synthetic problem (4952 images, 20 classes)."""
