@@ -398,6 +398,13 @@ def gen_image_ops():
         for k, v in res.items():
             out["i%03d_%s" % (i, k)] = v
         out["i%03d_case" % i] = np.array(repr(case))
+    # the call surface: constructor and __call__ signatures of every class the drop-in mirrors
+    import inspect
+    sigs = {}
+    for name in sorted(vars(ns)):
+        cls = getattr(ns, name)
+        sigs[name] = (str(inspect.signature(cls.__init__)), str(inspect.signature(cls.__call__)))
+    out["signatures"] = np.array(repr(sigs))
     save("image_ops", **out)
     for name in [m for m in sys.modules if m == "cv2" or m.startswith("data_generator")]:
         del sys.modules[name]

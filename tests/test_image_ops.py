@@ -53,6 +53,17 @@ def test_fixture_matches_the_case_list():
         assert ast.literal_eval(str(z["i%03d_case" % i])) == case
 
 
+def test_call_surface_equals_the_reference():
+    """Constructor and __call__ signatures (names, order, defaults) of every mirrored class, as recorded from the reference."""
+    import inspect
+    want = ast.literal_eval(str(util.load("image_ops")["signatures"]))
+    ns = _ns()
+    for name, (init_sig, call_sig) in want.items():
+        cls = getattr(ns, name)
+        assert str(inspect.signature(cls.__init__)) == init_sig, (name, str(inspect.signature(cls.__init__)), init_sig)
+        assert str(inspect.signature(cls.__call__)) == call_sig, (name, str(inspect.signature(cls.__call__)), call_sig)
+
+
 def test_host_tables_equal_the_oracle_restatement():
     from oracle import np_image as npi
     from ssd_keras_amd.data_generator import _image_ops as iop
