@@ -73,6 +73,20 @@ class SSDLoss:
         self.n_neg_min = n_neg_min
         self.alpha = alpha
 
+    def smooth_L1_loss(self, y_true, y_pred):
+        '''Smooth L1 loss summed over the last axis (reference :53-75): `0.5 d^2` where `|d| < 1`, `|d| - 0.5` elsewhere.  A plain,
+        differentiable tensor expression on whatever device the tensors live on, like the reference's graph ops -- `compute_loss`
+        does not call it: the fused kernel evaluates the same expression per anchor.'''
+        y_true, y_pred = torch.as_tensor(y_true), torch.as_tensor(y_pred)
+        d = y_true - y_pred
+        absolute_loss = d.abs()
+        return torch.where(absolute_loss < 1.0, 0.5 * d * d, absolute_loss - 0.5).sum(dim=-1)
+
+    def log_loss(self, y_true, y_pred):
+        '''Softmax log loss summed over the last axis (reference :77-96): `-sum(y_true * log(max(y_pred, 1e-15)))`; same remarks.'''
+        y_true, y_pred = torch.as_tensor(y_true), torch.as_tensor(y_pred)
+        return -(y_true * torch.log(torch.clamp_min(y_pred, 1e-15))).sum(dim=-1)
+
     def compute_loss(self, y_true, y_pred):
         '''Reference :98-211.  `y_true`, `y_pred`: `(batch, #boxes, #classes + 12)` on the GPU (NumPy `y_true`
         is uploaded).  Returns a `(batch,)` float32 tensor; anchors whose class vector is all zero are ignored,

@@ -410,6 +410,19 @@ def gen_image_ops():
         del sys.modules[name]
 
 
+def gen_api_surface():
+    """The reference's call surface read from its SOURCE with `ast` (tests/api_surface.py): parameter names, order
+    and defaults of every callable the package mirrors -- including the TensorFlow / Keras modules that cannot be imported here."""
+    from tests import api_surface
+    import json
+    out = api_surface.extract(REF)
+    missing = [(m, q) for m, d in out.items() for q, v in d.items() if v is None]
+    assert not missing, missing
+    with open(os.path.join(HERE, "api_surface.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("%-30s %6.1f KB" % ("api_surface.json", os.path.getsize(os.path.join(HERE, "api_surface.json")) / 1024.0))
+
+
 def gen_anchors():
     out = {}
     for name, cfg in (("tiny", syn.TINY), ("ssd7", syn.SSD7_300), ("ssd300", syn.SSD300_VOC), ("ssd512", syn.SSD512_COCO)):
@@ -567,7 +580,7 @@ def gen_decoder():
 
 if __name__ == "__main__":
     # box_filter / patch_sampling import the reference's real data_generator package; gen_evaluator stubs what is left of it
-    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_image_ops, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
+    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_image_ops, gen_api_surface, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
     wanted = set(sys.argv[1:])
     for g in gens:
         if not wanted or g.__name__[4:] in wanted:
