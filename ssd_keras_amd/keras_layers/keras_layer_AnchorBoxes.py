@@ -57,6 +57,10 @@ class AnchorBoxes(nn.Module):
             self._cache[key] = t
         return t
 
+    def build(self, input_shape):
+        """Keras' shape hook (reference :128-131): nothing to create here -- the layer has no weights."""
+        self.input_shape_ = tuple(input_shape) if input_shape is not None else None
+
     def forward(self, x):
         """x: the predictor feature map, (B, C, H, W).  Returns (B, H, W, n_boxes, 8) float32:
         4 anchor coordinates + 4 variances (reference :245-255)."""

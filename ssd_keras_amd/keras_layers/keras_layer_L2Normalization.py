@@ -37,7 +37,10 @@ class L2Normalization(nn.Module):
         self.name = kwargs.get('name')
         self.gamma = nn.Parameter(torch.full((n_channels,), float(gamma_init))) if n_channels else None
 
-    def build(self, n_channels, device=None):
+    def build(self, input_shape, device=None):
+        """Create gamma (reference :54-59: one value per channel, initialised to `gamma_init`).  `input_shape`: the number of channels,
+        or the shape of the NCHW tensors this module takes (channels on axis 1; the Keras layer reads axis 3 of NHWC)."""
+        n_channels = int(input_shape) if isinstance(input_shape, int) else int(tuple(input_shape)[1])
         self.gamma = nn.Parameter(torch.full((n_channels,), float(self.gamma_init), device=device))
 
     def forward(self, x):
