@@ -235,8 +235,8 @@ namespace ssdhip {
 //   x3_split_kernel   float32 [n, C] -> float16 [n, 2 C] = [hi | lo], hi = fl16(v), lo = fl16(v - hi): ONE pass instead of the six
 //                     elementwise / concatenation kernels of the PyTorch formulation.
 //   x3_merge_kernel   the inverse: float32 v = hi + lo (exact).
-//   conv1_1_x3_kernel conv1_1 (models/keras_ssd300.py:274: 3 -> 64 channels, 3x3 'same', ReLU) in float32 FMA-free arithmetic
-//                     (one IEEE multiply and one add per term, taps outer, channels inner) with the split output written directly.
+//   conv1_1_x3_kernel conv1_1 (models/keras_ssd300.py:274: 3 -> 64 channels, 3x3 'same', ReLU) in float32 FMA arithmetic
+//                     (fmaf: ONE rounding per term, taps outer, channels inner) with the split output written directly.
 //                     K = 27 is no GEMM: 5 GFLOP of vector work against 0.7 GB of output; MIOpen's float32 path for a 3-channel
 //                     NHWC input is its naive kernel (5.2 ms at batch 32, r03w).
 // ---------------------------------------------------------------------------------------------------------------

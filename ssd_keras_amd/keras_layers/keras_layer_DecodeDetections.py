@@ -38,11 +38,11 @@ class DecodeDetections(nn.Module):
         self.name = kwargs.get('name')
         self.timing_events = None          # a list: every call appends its (start, end) torch.cuda.Event pair (bench.py)
 
-    @torch.no_grad()
     def build(self, input_shape):
         """Keras' shape hook (reference :105-107): nothing to create here -- the layer has no weights."""
         self.input_shape_ = tuple(input_shape) if input_shape is not None else None
 
+    @torch.no_grad()
     def forward(self, y_pred):
         y = y_pred.detach()
         if y.dtype != torch.float32:

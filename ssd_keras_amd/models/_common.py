@@ -304,6 +304,13 @@ class SSDModel(nn.Module):
         return -(-m_pixels // 128) * -(-cout // 128) <= 100
 
     @staticmethod
+    def _splitk_measured_regime(x):
+        """Where the split-K form was measured inside the graphed step (profiles/r03p_*: the SSD300 / SSD512 extra layers behind fc7 at
+        batch 32: maps of at most 19 x 19 ... 32 x 32 pixels, a batch that fills the K ranges): only there is it taken without a timing
+        run.  Everywhere else (small batches, where `_few_tiles` also covers conv3_x ... fc7) it is an ordinary autotune candidate."""
+        return x.shape[0] >= 16 and x.shape[2] * x.shape[3] <= 32 * 32
+
+    @staticmethod
     def _halo_ok(conv, x):
         """csrc/ssdhip_convh.hip: 3x3, dilation 1, Cin and Cout multiples of 128 (maps up to 94 wide on the padded position grid,
         wider ones and the pooled form on 2-D tiles)."""
@@ -401,7 +408,7 @@ class SSDModel(nn.Module):
                     cands["halo"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                        dilation=1, relu=relu, variant=7)
             import os
-            if ("splitk" in cands and os.environ.get("SSDHIP_NO_SPLITK", "0") != "1"
+            if ("splitk" in cands and self._splitk_measured_regime(x) and os.environ.get("SSDHIP_NO_SPLITK", "0") != "1"
                     and os.environ.get("SSDHIP_CONV", "auto") in ("auto", "auto_miopen") and not os.environ.get("SSDHIP_PREFER")):
                 # The few-tile layers take the split-K form without a timing run: a back-to-back microbenchmark of these 5-30 us
                 # kernels is host-bound and L2-warm and says nothing about them inside the step, where the form was measured
