@@ -83,6 +83,14 @@ __device__ __forceinline__ u32 ch_pack2(float a, float b) {           // v_cvt_p
     return __builtin_bit_cast(u32, __builtin_convertvector(v, ch_bf16x2));
 }
 __device__ __forceinline__ float ch_relu(float v) { return v <= 0.f ? 0.f : v; }       // NaN stays NaN, -0 -> +0
+// Two bf16 values at once as signed 16-bit integers (v_pk_max_i16).  On ROUNDED activations this is the whole activation step:
+// max(x, 0) sends every value with the sign bit set (negative numbers, -0) to +0 and leaves the others (+NaN included) alone -- the
+// same bits as "v <= 0 ? 0 : v" before the rounding, because rounding to bf16 is monotonic and keeps the sign; max(x, 0x8000) is the
+// identity (no activation).  And on NON-NEGATIVE bf16 values integer order is numeric order, so it is also the pooling maximum.
+typedef short ch_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 ch_pkmax_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(ch_s16x2, a), __builtin_bit_cast(ch_s16x2, b)));
+}
 
 // one wave-wide 1 KiB LDS-DMA load: lane L writes 16 bytes at lds_dst + 16 L from base(rsrc) + soff + voff (zeros if the offset
 // is out of range).  M0 is saved and restored inside the statement (hipcc does not model it around asm).
@@ -167,6 +175,13 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             __builtin_amdgcn_raw_buffer_store_b128(d, ry, ok ? elem * 2u : OOB, 0, 0);
         }
     };
+    auto store16_at = [&](const uint4 v, const u32 byte_off) {            // byte_off: OOB for a lane that has nothing to store
+        if constexpr (!(MODE & 256)) {
+            const ch_u32x4 d = {v.x, v.y, v.z, v.w};
+            __builtin_amdgcn_raw_buffer_store_b128(d, ry, byte_off, 0, 0);
+        }
+    };
+    constexpr bool STR = (MODE & 2048) != 0;             // the strided / cropped forms (os, ooff, Hs, Ws); otherwise the plain 'same' result
     constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8) * (X3 ? 2 : 1);       // global stores a wave issues per epilogue
     const u32 YC = X3 ? 2u * (u32)p.Cout : (u32)p.Cout;  // channels of a y row (X3: [hi | lo])
 
@@ -443,6 +458,150 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 bv[ci][4 * g + 2] = __uint_as_float(hi << 16);
                 bv[ci][4 * g + 3] = __uint_as_float(hi & 0xffff0000u);
             }
+        if constexpr (!X3) {
+        // ---- bf16 epilogue (round 4: the instruction diet of DESIGN 8 item 2).  Per 4 values: 2 v_pk_add_f32 (bias), 2
+        //      v_cvt_pk_bf16_f32, 2 v_pk_max_i16 (the activation on the rounded pair, see ch_pkmax_i16) -- instead of four compare +
+        //      select pairs with their VCC hazard states; the store offsets of the 1-D form are computed once per tile, branch-free.
+        const u32 floor16 = p.relu ? 0u : 0x80008000u;
+        auto pack4 = [&](const int ci, const int pi, const int g, u32& p0, u32& p1) {
+            const float s0 = acc[ci][pi][4 * g + 0] + bv[ci][4 * g + 0], s1 = acc[ci][pi][4 * g + 1] + bv[ci][4 * g + 1];
+            const float s2 = acc[ci][pi][4 * g + 2] + bv[ci][4 * g + 2], s3 = acc[ci][pi][4 * g + 3] + bv[ci][4 * g + 3];
+            p0 = ch_pkmax_i16(ch_pack2(s0, s1), floor16);
+            p1 = ch_pkmax_i16(ch_pack2(s2, s3), floor16);
+        };
+        if constexpr (POOL) {
+            // Rounded and activated FIRST, pooled as 16-bit integers: after ReLU every value is non-negative, where integer order is
+            // numeric order, so the 2 x 2 maximum is two v_pk_max_i16 per pair (vertical: the lane's two position blocks; horizontal:
+            // lane ^ 1 by DPP) and exactly MaxPooling2D of the rounded activations.  Pixels outside the image (odd maps: the last row
+            // pair / column pair) are masked to +0, the neutral element.  Without ReLU the float path below (rare: tests only).
+            int b, h0, w0;
+            tile_origin(q0, b, h0, w0);
+            const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
+            if (p.relu) {
+                const u32 mrow1 = h0 + 2 * pair + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        u32 a0, a1, b0, b1;
+                        pack4(ci, 0, g, a0, a1);
+                        pack4(ci, 1, g, b0, b1);
+                        u32 v0 = ch_pkmax_i16(a0, b0 & mrow1) & mcol, v1 = ch_pkmax_i16(a1, b1 & mrow1) & mcol;
+                        v0 = ch_pkmax_i16(v0, (u32)__builtin_amdgcn_update_dpp(0, (int)v0, 0xB1, 0xf, 0xf, false));
+                        v1 = ch_pkmax_i16(v1, (u32)__builtin_amdgcn_update_dpp(0, (int)v1, 0xB1, 0xf, 0xf, false));
+                        if (!(r31 & 1)) {
+                            const int px = r31 >> 1, chunk = ci * 4 + g;
+                            *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) = make_uint2(v0, v1);
+                        }
+                    }
+            } else {
+                const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[ci][0][4 * g + e];
+                            const float below = acc[ci][1][4 * g + e];
+                            if (has_below) v = below > v ? below : v;
+                            const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+                            if (has_right) v = right > v ? right : v;
+                            o[e] = v + bv[ci][4 * g + e];
+                        }
+                        if (!(r31 & 1)) {
+                            const int px = r31 >> 1, chunk = ci * 4 + g;
+                            *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
+                                make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = j * 64 + lane, px = idx >> 3, c = idx & 7;     // 16 pooled pixels x 8 chunks
+                const int se = wn * 32 + 2 * px;                                // the even lane's slot
+                const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+                store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64 + c * 8));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            const int c = lane & 7;
+            u32 soff[2][4];                              // byte offsets of the lane's eight 16-byte stores (OOB: nothing to store)
+            {
+                const u32 cb = (u32)(co0 + wm * 64 + c * 8) * 2u;
+                if constexpr (G2) {
+                    int b, h0, w0;
+                    tile_origin(q0, b, h0, w0);
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int sl = wn * 32 + j * 8 + (lane >> 3);
+                            const int hh = h0 + 2 * (sl >> CSH) + pi, ww = w0 + (sl & (TC - 1));
+                            soff[pi][j] = ((u32)((b * H + hh) * W + ww) * (YC * 2u) + cb) | (((hh < H) & (ww < W)) ? 0u : OOB);
+                        }
+                } else {
+                    int q = q0 + wn * 64 + (lane >> 3);
+                    asm volatile("" : "+v"(q));          // after the K loop: eight more live registers inside it would spill
+                    int b = q / (H1 * W1);
+                    const int r = q - b * (H1 * W1);
+                    int h = r / W1, w = r - h * W1;
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bool ok = (w < W) & (h < H) & (q < p.Q);           // '&': no short-circuit branches
+                            u32 pix;
+                            if constexpr (STR) {
+                                // strided / 'valid' forms keep the positions (ho os + ooff, wo os + ooff) of the 'same' result; os is 1 or 2
+                                const int sh = p.os - 1;
+                                const int hh = h - p.ooff, ww = w - p.ooff;
+                                const int ho = hh >> sh, wo = ww >> sh;
+                                ok = ok & ((hh | ww) >= 0) & !((hh | ww) & sh) & (ho < p.Hs) & (wo < p.Ws);
+                                pix = (u32)((b * p.Hs + ho) * p.Ws + wo);
+                            } else {
+                                pix = (u32)((b * H + h) * W + w);
+                            }
+                            soff[pi][j] = (pix * (YC * 2u) + cb) | (ok ? 0u : OOB);   // y is below 2 GB: bit 31 puts the offset out of range
+                            q += 8;
+                            w += 8;
+                            if (!SMALL || W1 >= 8) {       // at most one row wrap per step: branch-free selects, no divergent loop
+                                const bool wr = w >= W1;
+                                w -= wr ? W1 : 0;
+                                h += wr ? 1 : 0;
+                                const bool hr = h == H1;
+                                h = hr ? 0 : h;
+                                b += hr ? 1 : 0;
+                            } else {
+                                while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        u32 p0, p1;
+                        pack4(ci, pi, g, p0, p1);
+                        const int chunk = ci * 4 + g;
+                        *reinterpret_cast<uint2*>(stage + r31 * 128 + ((chunk ^ (r31 & 7)) << 4) + khalf * 8) = make_uint2(p0, p1);
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int px = j * 8 + (lane >> 3);                  // of this pass's 32 positions
+                    store16_at(*reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4)), soff[pi][j]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
+            }
+        }
+        } else
         if constexpr (POOL) {
             // 2 x 2 maximum in registers (vertical: the lane's two position blocks; horizontal: lane ^ 1 by DPP), THEN bias + ReLU +
             // one rounding -- all monotonic, so this equals pooling the rounded activations.  Even lanes hold the wave's 16 pooled
@@ -628,6 +787,11 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
     int grid = p.total_ids;
     if ((MODE & 128) && grid > n_cu) grid = n_cu;        // persistent: one workgroup per CU (a multiple of 8: the id -> XCD map)
     const dim3 g(grid), t(CH_THREADS);
+    if constexpr ((MODE & 2048) != 0) {                  // the strided / cropped forms exist on the padded position grid only
+        if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false, X3>), g, t, 0, stream, p);
+        else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false, X3>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false, X3>), g, t, 0, stream, p);
+    } else
     if (geom == 4) {
         if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, true, X3>), g, t, 0, stream, p);
         else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, false, X3>), g, t, 0, stream, p);
@@ -680,7 +844,7 @@ extern "C" int ssdhip_conv3x3_halo_strided_nhwc_bf16(const void* x, const void* 
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)((long long)B * p.Hs * p.Ws * Cout * 2);
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
-    convh_launch<128>(p, 0, 0, convh_cu_count(), stream);
+    convh_launch<128 | 2048>(p, 0, 0, convh_cu_count(), stream);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
