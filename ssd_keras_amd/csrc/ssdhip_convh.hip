@@ -130,9 +130,16 @@ __device__ __forceinline__ u32 ch_split2(float a, float b, u32& lo_out) {       
     return (u32)__builtin_bit_cast(unsigned short, ha) | ((u32)__builtin_bit_cast(unsigned short, hb) << 16);
 }
 
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false>
+// NWV = waves per workgroup.  8 (2 x 4, each 64 channels x 64 positions, two waves per SIMD) is the round-2 layout.  4 (round 4: 2 x 2,
+// each 64 channels x 128 positions, ONE wave per SIMD with the 512-register budget) reads 24 fragments for 32 MFMAs per K-step
+// instead of 2 x 16 for 2 x 16: a quarter less LDS read traffic per FLOP, and no second wave competing for the SIMD's matrix pipe.
+// Same tile, same LDS image, same requests (each wave issues twice the pieces), same accumulation order: bit-identical results.
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
+    static_assert(NWV == 8 || (NWV == 4 && !X3), "8 waves, or 4 (bf16 forms only)");
+    constexpr int NPI = 16 / NWV;                        // 32-position blocks per wave: 2 | 4
+    constexpr int WPK = 8 / NWV;                         // 1 KiB request pieces a wave issues per 64-row chunk: 1 | 2
     constexpr int TC = G2 ? (1 << CSH) : 1, TR = G2 ? (CH_BN >> CSH) : 1, SC2 = TC + 2;   // tile columns, rows; slab columns
     static_assert(!POOL || G2, "the pooled epilogue needs 2-D tiles");
     static_assert(!G2 || (TR + 2) * (TC + 2) <= 64 * SPW, "the 2-D slab must fit the slab buffer");
@@ -156,7 +163,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;             // 64-channel half, 64-position quarter of the tile
+    const int wm = NWV == 8 ? wave >> 2 : wave >> 1;     // 64-channel half of the tile
+    const int wn = NWV == 8 ? wave & 3 : wave & 1;       // 64-position quarter | 128-position half
     const int r31 = lane & 31, khalf = lane >> 5;
     const int H = p.H, W = p.W, Cin = p.Cin, W1 = W + 1, H1 = H + 1;
     const int csteps = Cin >> 6;
@@ -182,7 +190,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         }
     };
     constexpr bool STR = (MODE & 2048) != 0;             // the strided / cropped forms (os, ooff, Hs, Ws); otherwise the plain 'same' result
-    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8) * (X3 ? 2 : 1);       // global stores a wave issues per epilogue
+    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8) * (X3 ? 2 : 1) * (NPI / 2);   // global stores a wave issues per epilogue
     const u32 YC = X3 ? 2u * (u32)p.Cout : (u32)p.Cout;  // channels of a y row (X3: [hi | lo])
 
     // ---- per-lane load descriptors --------------------------------------------------------------------------------------
@@ -195,7 +203,9 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         h0 = (r - b * p.HT) * TR;
         w0 = wt * TC;
     };
-    u32 xoff[SPW];
+    // request piece idx = k WPK + u of a wave: slab rows (64 / WPK) idx + 8 wave .. + 7
+    constexpr int NXO = SPW * WPK, XSTEP = 64 / WPK;
+    u32 xoff[NXO];
     auto make_xoff = [&](const int tile_q0) {
         const int row0 = wave * 8 + (lane >> 3);
         if constexpr (G2) {
@@ -203,8 +213,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             int b, h0, w0;
             tile_origin(tile_q0, b, h0, w0);
 #pragma unroll
-            for (int k = 0; k < SPW; ++k) {
-                const int row = row0 + 64 * k;
+            for (int k = 0; k < NXO; ++k) {
+                const int row = row0 + XSTEP * k;
                 const int j = (lane & 7) ^ ((row >> 1) & 7);
                 const int sr = row / SC2, sc = row - sr * SC2;
                 const int hh = h0 - 1 + sr, ww = w0 - 1 + sc;
@@ -218,21 +228,23 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         if (q >= 0) { b = q / (H1 * W1); const int r = q - b * (H1 * W1); h = r / W1; w = r - h * W1; }
         else { w = q; }                                  // negative positions: before the first image (zeros)
 #pragma unroll
-        for (int k = 0; k < SPW; ++k) {
-            const int row = row0 + 64 * k;
+        for (int k = 0; k < NXO; ++k) {
+            const int row = row0 + XSTEP * k;
             const int j = (lane & 7) ^ ((row >> 1) & 7);
             const bool ok = w >= 0 && w < W && h < H && q < p.Q && row < SP;
             xoff[k] = ok ? (u32)(((b * H + h) * W + w) * (XC * 2) + j * 16) : OOB;
-            q += 64;
-            w += 64;
+            q += XSTEP;
+            w += XSTEP;
             while (w >= W1) { w -= W1; if (++h == H1) { h = 0; ++b; } }
         }
     };
     make_xoff(q0);
-    u32 woff[2];                                         // relative to the tile's first channel (which rides in the scalar offset)
+    auto xdst = [&](const int k) { return (u32)((XSTEP * k + 8 * wave) * 128); };   // LDS byte offset of piece k inside a slab buffer
+    constexpr int NWP = 2 * WPK;                         // weight pieces a wave issues per stage (16 pieces of 8 channels)
+    u32 woff[NWP];                                       // relative to the tile's first channel (which rides in the scalar offset)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+    for (int i = 0; i < NWP; ++i) {
+        const int row = (i * NWV + wave) * 8 + (lane >> 3);
         const int j = (lane & 7) ^ ((row >> 1) & 7);
         woff[i] = (u32)(row * (9 * Cin * 2) + j * 16);
     }
@@ -240,7 +252,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     // the weights of tap `tap` of slice `cs` of channel tile `co` into ring stage `stage` (all wave-uniform): this wave's piece i
     auto issue_w_piece = [&](const int co, const int cs, const int tap, const int stage, const int i) {
         const u32 soff = (u32)(((co * 9 + tap) * Cin + cs * 64) * 2);
-        ch_bload(woff[i], rw, lds0 + stage * CH_WST + wave * 1024 + i * 8192, soff);
+        ch_bload(woff[i], rw, lds0 + stage * CH_WST + (i * NWV + wave) * 1024, soff);
     };
 
     // ---- fragment addressing -----------------------------------------------------------------------------------------------
@@ -252,14 +264,17 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     }
     // slab row of the lane's first position (pi = 0) at tap (0, 0), and the distance to its second one.  2-D: slot = wn * 32 + r31 is
     // (row pair, column) = (slot / TC, slot % TC) of the tile, pi the row of the pair
-    const int slot2 = wn * 32 + r31;
-    const int prow = G2 ? (2 * (slot2 >> CSH)) * SC2 + (slot2 & (TC - 1)) : wn * 64 + r31;
-    constexpr int PISTEP = G2 ? SC2 : 32;
+    // (NWV = 4: position block pi = 2 ph + pr is row pr of the row pairs of slots wn 64 + ph 32 + r31)
+    const int slot2 = wn * (16 * NPI) + r31;
+    const int prow = G2 ? (2 * (slot2 >> CSH)) * SC2 + (slot2 & (TC - 1)) : wn * (32 * NPI) + r31;
+    auto pirow = [&](const int pi) {                     // slab row distance of position block pi from block 0
+        return G2 ? (pi >> 1) * (2 * (32 >> CSH)) * SC2 + (pi & 1) * SC2 : pi * 32;
+    };
 
-    f32x16 acc[2][2];
-    bf16x8 fa[2][4][2], fb[2][4][2];                     // [register set][k16 block][ci | pi]
+    f32x16 acc[2][NPI];
+    bf16x8 fa[2][4][2], fb[2][4][NPI];                   // [register set][k16 block][ci | pi]
 
-    u32 ra[4], rb[2], re[2];                             // addresses of the pending fragment reads
+    u32 ra[4], rb[NPI], re[NPI];                         // addresses of the pending fragment reads
     auto read_addr = [&](const int cs, const int tap, const int stage) {     // the fragments of tap `tap` of slice `cs`
         u32 wst = (u32)(stage * CH_WST);
         u32 toff = (u32)((tap / 3) * (G2 ? SC2 : W1) + tap % 3);
@@ -269,19 +284,20 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ra[kk] = abase[kk] + wst;
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            const u32 row = (u32)(prow + pi * PISTEP) + toff;
+        for (int pi = 0; pi < NPI; ++pi) {
+            const u32 row = (u32)(prow + pirow(pi)) + toff;
             rb[pi] = sl + (row << 7);
             re[pi] = (((row >> 1) & 7u) ^ (u32)khalf) << 4;     // chunk (2 kk + khalf) ^ swz = (2 kk) ^ (khalf ^ swz)
         }
     };
-    auto read_one = [&](auto setc, auto jc) {             // fragment read j of a step: k16 block j / 4; weights ci 0, 1 then positions pi 0, 1
-        constexpr int S = decltype(setc)::value, j = decltype(jc)::value, kk = j >> 2, w = j & 3;
+    constexpr int RPK = 2 + NPI;                          // fragment reads per k16 block: weights ci 0, 1 then positions pi 0 ..
+    auto read_one = [&](auto setc, auto jc) {             // fragment read j of a step: k16 block j / RPK
+        constexpr int S = decltype(setc)::value, j = decltype(jc)::value, kk = j / RPK, w = j % RPK;
         if constexpr (w < 2) fa[S][kk][w] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + w * 4096);
         else fb[S][kk][w - 2] = *reinterpret_cast<const bf16x8*>(lds + rb[w - 2] + (re[w - 2] ^ (u32)(kk << 5)));
     };
-    auto mfma_one = [&](auto setc, auto ic) {             // MFMA i of a step: k16 block i / 4, accumulator (ci, pi) = ((i >> 1) & 1, i & 1)
-        constexpr int S = decltype(setc)::value, i = decltype(ic)::value, kk = i >> 2, ci = (i >> 1) & 1, pi = i & 1;
+    auto mfma_one = [&](auto setc, auto ic) {             // MFMA i of a step: k16 block i / (2 NPI), accumulator (ci, pi) = ((i / NPI) & 1, i % NPI)
+        constexpr int S = decltype(setc)::value, i = decltype(ic)::value, kk = i / (2 * NPI), ci = (i / NPI) & 1, pi = i % NPI;
         if constexpr (X3)
             acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ch_f16x8, fa[S][kk][ci]), __builtin_bit_cast(ch_f16x8, fb[S][kk][pi]),
                                                                  acc[ci][pi], 0, 0, 0);
@@ -292,10 +308,12 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 
     // ---- prologue of the workgroup's first tile: slab of slice 0, weights of steps 0 .. D-1 ------------------------------------
 #pragma unroll
-    for (int k = 0; k < SPW; ++k) ch_bload(xoff[k], rx, lds0 + SLAB0 + wave * 1024 + k * 8192, 0u);
+    for (int k = 0; k < NXO; ++k) ch_bload(xoff[k], rx, lds0 + SLAB0 + xdst(k), 0u);
 #pragma unroll
-    for (int d = 0; d < D; ++d) { issue_w_piece(co0, 0, d, d, 0); issue_w_piece(co0, 0, d, d, 1); }
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (D - 2)) : "memory");     // slab 0 and the weights of steps 0 and 1 (this wave's share)
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) issue_w_piece(co0, 0, d, d, i);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWP * (D - 2)) : "memory");   // slab 0 and the weights of steps 0 and 1 (this wave's share)
     __builtin_amdgcn_s_barrier();                        // ... everybody's
     read_addr(0, 0, 0);
 #pragma unroll
@@ -303,7 +321,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci) fa[0][kk][ci] = *reinterpret_cast<const bf16x8*>(lds + ra[kk] + ci * 4096);
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi) fb[0][kk][pi] = *reinterpret_cast<const bf16x8*>(lds + rb[pi] + (re[pi] ^ (u32)(kk << 5)));
+        for (int pi = 0; pi < NPI; ++pi) fb[0][kk][pi] = *reinterpret_cast<const bf16x8*>(lds + rb[pi] + (re[pi] ^ (u32)(kk << 5)));
     }
 
     int vbase = 0;                                       // slices this workgroup has finished (the weight ring runs on across tiles)
@@ -317,9 +335,9 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         constexpr int GRP = decltype(grpc)::value, S = decltype(setc)::value, TAP = decltype(tapc)::value;
         using Sn = std::integral_constant<int, 1 - S>;
         // loads this wave issues during tap t of a slice: 2 weight pieces (+ 1 slab piece)
-        constexpr auto issued = [](int t, bool lst) { return lst ? (t < 9 - D ? 2 : 0) : 2 + (t < SPW ? 1 : 0); };
-        constexpr int n_mid = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, false) : 2)) + issued(TAP, false);
-        constexpr int n_last = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, true) : 2)) + issued(TAP, true);
+        constexpr auto issued = [](int t, bool lst) { return (lst ? (t < 9 - D ? 2 : 0) : 2 + (t < SPW ? 1 : 0)) * WPK; };
+        constexpr int n_mid = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, false) : 2 * WPK)) + issued(TAP, false);
+        constexpr int n_last = (D == 3 ? 0 : (TAP > 0 ? issued(TAP - 1, true) : 2 * WPK)) + issued(TAP, true);
         // Ring stage of a step is (global step number) mod NW: 9 slices-so-far + TAP -> TAP mod 3 for three stages, (slices + TAP) mod 4
         const int vs = vbase + cs;
         const bool post = cs == 0 && vbase > 0;
@@ -331,31 +349,47 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         // After the very last step the reads fetch a stage nobody uses (in-bounds LDS addresses): cheaper than branches.
         constexpr int RSH = ((MODE & 64) && GRP) ? 2 : 0, QSH = ((MODE & 8) && GRP) ? 2 : 0;
         read_addr(cs + (TAP == 8 ? 1 : 0), (TAP + 1) % 9, NW == 3 ? (TAP + 1) % 3 : ((vs + TAP + 1) & 3));
+        // the weight piece `wi` of step s + D: the same slice, the next one, or slice 0 of the next tile
+        auto req_w = [&](const int wi) {
+            constexpr bool CARRY = TAP + D >= 9;
+            if (!nomore || !CARRY) {
+                const bool over = CARRY && nxt;
+                issue_w_piece(over ? co0n : co0, over ? 0 : cs + (CARRY ? 1 : 0), (TAP + D) % 9, st, wi);
+            }
+        };
+        auto req_x = [&](const int u) {                    // piece TAP WPK + u of the next slice's slab (TAP < SPW)
+            if (!nomore)
+                ch_bload(xoff[TAP * WPK + u], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + xdst(TAP * WPK + u),
+                         nxt ? 0u : (u32)(((X3 && cs + 1 >= p.nx) ? cs + 1 - p.nx : cs + 1) * 128));
+        };
         auto slot = [&](auto ic) {
             constexpr int i = decltype(ic)::value, j = i - RSH;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(MODE & 32)) mfma_one(setc, ic);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(MODE & 2)) {
-                if constexpr (j >= 0 && j < 4) {
-                    read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j)>{});
-                    read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j) + 1>{});
-                } else if constexpr (j >= 4 && j < 12) {
-                    read_one(Sn{}, std::integral_constant<int, (j < 4 ? 4 : j) + 4>{});
-                }
-            }
-            if constexpr (!(MODE & 1)) {
-                if constexpr (i == 1 + QSH || i == 5 + QSH) {
-                    // weights of step s + D: the same slice, the next one, or slice 0 of the next tile
-                    constexpr bool CARRY = TAP + D >= 9;
-                    if (!nomore || !CARRY) {
-                        const bool over = CARRY && nxt;
-                        issue_w_piece(over ? co0n : co0, over ? 0 : cs + (CARRY ? 1 : 0), (TAP + D) % 9, st, i == 1 + QSH ? 0 : 1);
+            if constexpr (NWV == 8) {
+                if constexpr (!(MODE & 2)) {
+                    if constexpr (j >= 0 && j < 4) {
+                        read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j)>{});
+                        read_one(Sn{}, std::integral_constant<int, 2 * (j < 0 ? 0 : j) + 1>{});
+                    } else if constexpr (j >= 4 && j < 12) {
+                        read_one(Sn{}, std::integral_constant<int, (j < 4 ? 4 : j) + 4>{});
                     }
-                } else if constexpr (i == 9 + QSH && TAP < SPW) {
-                    if (!nomore)
-                        ch_bload(xoff[TAP], rx, lds0 + SLAB0 + ((cs + 1) & 1) * SLB + wave * 1024 + TAP * 8192,
-                                 nxt ? 0u : (u32)(((X3 && cs + 1 >= p.nx) ? cs + 1 - p.nx : cs + 1) * 128));
+                }
+                if constexpr (!(MODE & 1)) {
+                    if constexpr (i == 1 + QSH) req_w(0);
+                    else if constexpr (i == 5 + QSH) req_w(1);
+                    else if constexpr (i == 9 + QSH && TAP < SPW) req_x(0);
+                }
+            } else {
+                // 32 MFMAs, 24 fragment reads (one per slot), six requests (slots 2, 6, 10, 14: weights; 18, 22: slab)
+                if constexpr (!(MODE & 2) && i < 24) read_one(Sn{}, std::integral_constant<int, (i < 24 ? i : 0)>{});
+                if constexpr (!(MODE & 1)) {
+                    if constexpr (i == 2) req_w(0);
+                    else if constexpr (i == 6) req_w(1);
+                    else if constexpr (i == 10) req_w(2);
+                    else if constexpr (i == 14) req_w(3);
+                    else if constexpr ((i == 18 || i == 22) && TAP < SPW) req_x(i == 18 ? 0 : 1);
                 }
             }
         };
@@ -365,6 +399,14 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         slot(std::integral_constant<int, 9>{}); slot(std::integral_constant<int, 10>{}); slot(std::integral_constant<int, 11>{});
         slot(std::integral_constant<int, 12>{}); slot(std::integral_constant<int, 13>{}); slot(std::integral_constant<int, 14>{});
         slot(std::integral_constant<int, 15>{});
+        if constexpr (NWV == 4) {
+            slot(std::integral_constant<int, 16>{}); slot(std::integral_constant<int, 17>{}); slot(std::integral_constant<int, 18>{});
+            slot(std::integral_constant<int, 19>{}); slot(std::integral_constant<int, 20>{}); slot(std::integral_constant<int, 21>{});
+            slot(std::integral_constant<int, 22>{}); slot(std::integral_constant<int, 23>{}); slot(std::integral_constant<int, 24>{});
+            slot(std::integral_constant<int, 25>{}); slot(std::integral_constant<int, 26>{}); slot(std::integral_constant<int, 27>{});
+            slot(std::integral_constant<int, 28>{}); slot(std::integral_constant<int, 29>{}); slot(std::integral_constant<int, 30>{});
+            slot(std::integral_constant<int, 31>{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         // everything step s + 2 needs has landed (in-order completion: only the newest D - 2 steps' requests may be in flight), this
         // wave's fragment reads are done (their stage is overwritten next step), then the barrier
@@ -414,7 +456,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi)
+            for (int pi = 0; pi < NPI; ++pi)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
         if constexpr ((MODE & (8 | 64)) != 0) {          // the two waves of a SIMD run differently ordered code (same barriers)
@@ -429,6 +471,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         asm volatile("" : "+v"(bias_dw));                 // landed: the K loop's last counted wait is younger than the request
         if constexpr ((MODE & 512) != 0) {                 // ablation: no epilogue (the accumulators only stay alive)
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+            if constexpr (NPI == 4) asm volatile("" :: "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[1][2]), "v"(acc[1][3]));
         } else {
         unsigned char* stage = lds + SLAB0 + SLB + wave * 4096;
         float bv[2][16];
@@ -474,9 +517,14 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             // numeric order, so the 2 x 2 maximum is two v_pk_max_i16 per pair (vertical: the lane's two position blocks; horizontal:
             // lane ^ 1 by DPP) and exactly MaxPooling2D of the rounded activations.  Pixels outside the image (odd maps: the last row
             // pair / column pair) are masked to +0, the neutral element.  Without ReLU the float path below (rare: tests only).
+            // (NWV = 4: two row-pair blocks ph per wave, position blocks 2 ph and 2 ph + 1, staged side by side: 2 KB each)
             int b, h0, w0;
             tile_origin(q0, b, h0, w0);
-            const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
+#pragma unroll
+            for (int ph = 0; ph < NPI / 2; ++ph) {
+            const int slot2p = slot2 + ph * 32;
+            const int pair = slot2p >> CSH, col = slot2p & (TC - 1);
+            unsigned char* pstage = stage + ph * 2048;
             if (p.relu) {
                 const u32 mrow1 = h0 + 2 * pair + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
 #pragma unroll
@@ -484,14 +532,14 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         u32 a0, a1, b0, b1;
-                        pack4(ci, 0, g, a0, a1);
-                        pack4(ci, 1, g, b0, b1);
+                        pack4(ci, 2 * ph, g, a0, a1);
+                        pack4(ci, 2 * ph + 1, g, b0, b1);
                         u32 v0 = ch_pkmax_i16(a0, b0 & mrow1) & mcol, v1 = ch_pkmax_i16(a1, b1 & mrow1) & mcol;
                         v0 = ch_pkmax_i16(v0, (u32)__builtin_amdgcn_update_dpp(0, (int)v0, 0xB1, 0xf, 0xf, false));
                         v1 = ch_pkmax_i16(v1, (u32)__builtin_amdgcn_update_dpp(0, (int)v1, 0xB1, 0xf, 0xf, false));
                         if (!(r31 & 1)) {
                             const int px = r31 >> 1, chunk = ci * 4 + g;
-                            *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) = make_uint2(v0, v1);
+                            *reinterpret_cast<uint2*>(pstage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) = make_uint2(v0, v1);
                         }
                     }
             } else {
@@ -503,8 +551,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float v = acc[ci][0][4 * g + e];
-                            const float below = acc[ci][1][4 * g + e];
+                            float v = acc[ci][2 * ph][4 * g + e];
+                            const float below = acc[ci][2 * ph + 1][4 * g + e];
                             if (has_below) v = below > v ? below : v;
                             const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
                             if (has_right) v = right > v ? right : v;
@@ -512,45 +560,48 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         }
                         if (!(r31 & 1)) {
                             const int px = r31 >> 1, chunk = ci * 4 + g;
-                            *reinterpret_cast<uint2*>(stage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
+                            *reinterpret_cast<uint2*>(pstage + px * 128 + ((chunk ^ (px & 7)) << 4) + khalf * 8) =
                                 make_uint2(ch_pack2(o[0], o[1]), ch_pack2(o[2], o[3]));
                         }
                     }
             }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ph = 0; ph < NPI / 2; ++ph)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int idx = j * 64 + lane, px = idx >> 3, c = idx & 7;     // 16 pooled pixels x 8 chunks
-                const int se = wn * 32 + 2 * px;                                // the even lane's slot
+                const int se = wn * (16 * NPI) + ph * 32 + 2 * px;              // the even lane's slot
                 const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
-                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + ph * 2048 + px * 128 + ((c ^ (px & 7)) << 4));
                 store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
             const int c = lane & 7;
-            u32 soff[2][4];                              // byte offsets of the lane's eight 16-byte stores (OOB: nothing to store)
+            u32 soff[NPI][4];                            // byte offsets of the lane's 16-byte stores (OOB: nothing to store)
             {
                 const u32 cb = (u32)(co0 + wm * 64 + c * 8) * 2u;
                 if constexpr (G2) {
                     int b, h0, w0;
                     tile_origin(q0, b, h0, w0);
 #pragma unroll
-                    for (int pi = 0; pi < 2; ++pi)
+                    for (int pi = 0; pi < NPI; ++pi)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int sl = wn * 32 + j * 8 + (lane >> 3);
-                            const int hh = h0 + 2 * (sl >> CSH) + pi, ww = w0 + (sl & (TC - 1));
+                            const int sl = wn * (16 * NPI) + (pi >> 1) * 32 + j * 8 + (lane >> 3);
+                            const int hh = h0 + 2 * (sl >> CSH) + (pi & 1), ww = w0 + (sl & (TC - 1));
                             soff[pi][j] = ((u32)((b * H + hh) * W + ww) * (YC * 2u) + cb) | (((hh < H) & (ww < W)) ? 0u : OOB);
                         }
                 } else {
-                    int q = q0 + wn * 64 + (lane >> 3);
+                    int q = q0 + wn * (32 * NPI) + (lane >> 3);
                     asm volatile("" : "+v"(q));          // after the K loop: eight more live registers inside it would spill
                     int b = q / (H1 * W1);
                     const int r = q - b * (H1 * W1);
                     int h = r / W1, w = r - h * W1;
 #pragma unroll
-                    for (int pi = 0; pi < 2; ++pi)
+                    for (int pi = 0; pi < NPI; ++pi)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             bool ok = (w < W) & (h < H) & (q < p.Q);           // '&': no short-circuit branches
@@ -582,7 +633,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 }
             }
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
+            for (int pi = 0; pi < NPI; ++pi) {
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -743,11 +794,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false>
-__global__ __launch_bounds__(CH_THREADS) void convh_kernel(ConvHParams p) {
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
+    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
 #endif
 }
 
@@ -786,6 +837,20 @@ template <int MODE, bool X3 = false>
 static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hipStream_t stream) {
     int grid = p.total_ids;
     if ((MODE & 128) && grid > n_cu) grid = n_cu;        // persistent: one workgroup per CU (a multiple of 8: the id -> XCD map)
+    if constexpr ((MODE & 4096) != 0 && !X3) {           // four waves per workgroup (64 channels x 128 positions each)
+        constexpr int M4 = MODE & ~4096;
+        const dim3 g(grid), t(256);
+        if (geom == 4) {
+            if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, M4, 4, true, false, 4>), g, t, 0, stream, p);
+            else hipLaunchKernelGGL((convh_kernel<4, 6, M4, 4, false, false, 4>), g, t, 0, stream, p);
+        } else if (geom == 5) {
+            if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, M4, 5, true, false, 4>), g, t, 0, stream, p);
+            else hipLaunchKernelGGL((convh_kernel<4, 6, M4, 5, false, false, 4>), g, t, 0, stream, p);
+        }
+        else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, M4, 0, false, false, 4>), g, t, 0, stream, p);
+        else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, M4, 0, false, false, 4>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<3, 7, M4, 0, false, false, 4>), g, t, 0, stream, p);
+    } else {
     const dim3 g(grid), t(CH_THREADS);
     if constexpr ((MODE & 2048) != 0) {                  // the strided / cropped forms exist on the padded position grid only
         if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false, X3>), g, t, 0, stream, p);
@@ -803,6 +868,7 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
     else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false, X3>), g, t, 0, stream, p);
     else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false, X3>), g, t, 0, stream, p);
     else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false, X3>), g, t, 0, stream, p);
+    }
 }
 
 }  // namespace ssdhip
@@ -993,8 +1059,11 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     // the tolerance) and nothing measurable on the plain ones
     int mode = pool ? 1152 : 128;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
+    if (const char* e = getenv("SSDHIP_CONVH_WAVES")) { if (atoi(e) == 4) mode |= 4096; }
     switch (mode) {
         case 1152: convh_launch<1152>(p, geom, pool, cu_count, stream); break;                             // 128 + 1024: the first waits after an epilogue let its stores stay in flight
+        case 4224: convh_launch<128 | 4096>(p, geom, pool, cu_count, stream); break;                       // four waves per workgroup (round 4)
+        case 5248: convh_launch<1152 | 4096>(p, geom, pool, cu_count, stream); break;
 #if defined(SSDHIP_PROFILE)
         // ablations (wrong results by construction): tools/ablate_convh.py, tools/ablate_convh2.py
         case 129: convh_launch<129>(p, geom, pool, cu_count, stream); break;                               // no loads in the K loop

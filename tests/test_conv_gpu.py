@@ -270,9 +270,10 @@ HALO_CASES = [  # B, H, W, Cin, Cout, bias, relu      (csrc/ssdhip_convh.hip: 3x
 ]
 
 
-@pytest.fixture(params=["128", "1152"])
+@pytest.fixture(params=["128", "1152", "4224", "5248"])
 def slab_mode(request):
-    """SSDHIP_CONVH_MODE: 128 = persistent workgroups prefetching across tiles, 1152 = the same with the tolerant waits after an epilogue (read at every launch)."""
+    """SSDHIP_CONVH_MODE: 128 = persistent workgroups prefetching across tiles, 1152 = the same with the tolerant waits after an epilogue
+    (read at every launch); + 4096 (round 4) = four waves per workgroup, 64 channels x 128 positions each, one wave per SIMD."""
     import os
     old = os.environ.get("SSDHIP_CONVH_MODE")
     os.environ["SSDHIP_CONVH_MODE"] = request.param

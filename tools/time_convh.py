@@ -12,11 +12,11 @@ import torch  # noqa: E402
 
 from ssd_keras_amd import _native as nat  # noqa: E402
 
-MODES = [int(m) for m in os.environ.get("CONVH_MODES", "64,128").split(",")]
+MODES = [int(m) for m in os.environ.get("CONVH_MODES", "128,1152,4224,5248").split(",")]   # + 4096: four waves per workgroup
 LAYERS = [  # name, B, H, W, Cin, Cout
     ("conv3_1", 32, 75, 75, 128, 256), ("conv3_2", 32, 75, 75, 256, 256), ("conv4_1", 32, 38, 38, 256, 512),
     ("conv4_2", 32, 38, 38, 512, 512), ("conv5_1", 32, 19, 19, 512, 512),
-    ("ssd512_conv4_2", 16, 64, 64, 512, 512), ("ssd512_conv5_1", 16, 32, 32, 512, 512),
+    ("ssd512_conv4_2", 16, 64, 64, 512, 512),
 ]
 
 
@@ -51,7 +51,7 @@ for name, B, H, W, Cin, Cout in LAYERS:
         row["differs_from_variant4"] = int((got != base).sum().item())
     except Exception as exc:                               # noqa: BLE001
         row["error"] = repr(exc)[:200]
-    for v in (4, 6):
+    for v in (4,):
         us = timed(lambda v=v: nat.conv2d_same(x, wt, bias, relu=True, variant=v))
         row["v%d_us" % v] = round(us, 1)
     if "error" not in row:
@@ -68,7 +68,7 @@ for name, B, H, W, Cin, Cout in LAYERS:
     rows.append(row)
 # conv2_2 -> pool2 (and its SSD512 twin): the fused-pool kernels
 for name, B, H, W, Cin, Cout in (("conv2_2_pool", 32, 150, 150, 128, 128), ("conv3_3_pool", 32, 75, 75, 256, 256),
-                                 ("ssd512_conv2_2_pool", 16, 256, 256, 128, 128)):
+                                 ):
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
     wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
