@@ -143,7 +143,12 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     constexpr int TC = G2 ? (1 << CSH) : 1, TR = G2 ? (CH_BN >> CSH) : 1, SC2 = TC + 2;   // tile columns, rows; slab columns
     static_assert(!POOL || G2, "the pooled epilogue needs 2-D tiles");
     static_assert(!G2 || (TR + 2) * (TC + 2) <= 64 * SPW, "the 2-D slab must fit the slab buffer");
-    constexpr int D = NW;                                // weights of step s + D are requested during step s
+    // MODE bit 8192 (four weight stages only): requests run NW - 1 steps ahead instead of NW, i.e. one ring stage of slack -- the stage
+    // a step's requests overwrite was last READ two steps earlier, and those reads were consumed (waited for, per register, by the MFMAs
+    // that use them) before the previous barrier.  The step's closing wait then covers the requests only: fragment reads stay in
+    // flight across the barrier instead of all eight waves draining the LDS queue in lockstep before every barrier.
+    constexpr bool LZ = (MODE & 8192) != 0 && NW == 4;
+    constexpr int D = LZ ? NW - 1 : NW;                  // weights of step s + D are requested during step s
     constexpr int SLAB0 = NW * CH_WST, SLB = SPW * 8192;
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool PERSIST = (MODE & 128) != 0;
@@ -341,7 +346,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         // Ring stage of a step is (global step number) mod NW: 9 slices-so-far + TAP -> TAP mod 3 for three stages, (slices + TAP) mod 4
         const int vs = vbase + cs;
         const bool post = cs == 0 && vbase > 0;
-        const int st = NW == 3 ? TAP % 3 : ((vs + TAP) & 3);
+        const int st = NW == 3 ? (TAP + D) % 3 : ((vs + TAP + D) & 3);   // ring stage of step s + D
         // 16 slots, slot i = MFMA i, then 0..2 fragment reads of step s + 1, then at three slots one LDS-DMA request.  Nothing comes
         // in bursts: with 4 MFMAs, then 8 reads from all eight waves at once, the LDS queue fills up, the waves stall on issuing reads
         // and the MFMA pipe drains.  The step opens with an MFMA: hipcc puts an s_waitcnt lgkmcnt in front of the first use of a
@@ -417,9 +422,15 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             // (the weights of steps 2 .. D-1) was requested BEFORE the stores: these steps let the stores and the bias load stay in
             // flight too.  From step D-2 on the awaited requests are younger than the stores and the plain counts apply.
             constexpr bool TOL = (MODE & 1024) != 0 && TAP < D - 2;
+            if constexpr (LZ) {
+                if (TOL && post) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((MODE & 1) ? 0 : n_mid + NST + 1) : "memory");
+                else if (!nomore) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((MODE & 1) ? 0 : n_last) : "memory");
+            } else {
             if (TOL && post) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid + NST + 1) : "memory");
             else if (!nomore) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_mid) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((MODE & 1) ? 0 : n_last) : "memory");
+            }
             __builtin_amdgcn_s_barrier();
         }
     };
@@ -1059,12 +1070,22 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     // the tolerance) and nothing measurable on the plain ones
     int mode = pool ? 1152 : 128;
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
+#if defined(SSDHIP_PROFILE)
     if (const char* e = getenv("SSDHIP_CONVH_WAVES")) { if (atoi(e) == 4) mode |= 4096; }
+    if (const char* e = getenv("SSDHIP_CONVH_LAZY")) { if (atoi(e) == 1) mode |= 8192; }
+#endif
     switch (mode) {
         case 1152: convh_launch<1152>(p, geom, pool, cu_count, stream); break;                             // 128 + 1024: the first waits after an epilogue let its stores stay in flight
-        case 4224: convh_launch<128 | 4096>(p, geom, pool, cu_count, stream); break;                       // four waves per workgroup (round 4)
-        case 5248: convh_launch<1152 | 4096>(p, geom, pool, cu_count, stream); break;
 #if defined(SSDHIP_PROFILE)
+        // Round-4 experiments, bit-identical to the product modes and tested as such (tests/test_conv_gpu.py with SSDHIP_LIB pointing at
+        // the profiling build), measured and NOT adopted (profiles/r04bc_slab_four_waves_and_lazy_lds_waits_negative.json):
+        // + 4096: four waves per workgroup (a quarter less LDS read traffic per FLOP, one wave per SIMD): 2-7 % SLOWER on every layer;
+        // + 8192: requests three steps ahead, fragment reads in flight across the barrier: equal within 0.5 %.
+        case 4224: convh_launch<128 | 4096>(p, geom, pool, cu_count, stream); break;
+        case 5248: convh_launch<1152 | 4096>(p, geom, pool, cu_count, stream); break;
+        case 8320: convh_launch<128 | 8192>(p, geom, pool, cu_count, stream); break;
+        case 9344: convh_launch<1152 | 8192>(p, geom, pool, cu_count, stream); break;
+        case 12416: convh_launch<128 | 8192 | 4096>(p, geom, pool, cu_count, stream); break;
         // ablations (wrong results by construction): tools/ablate_convh.py, tools/ablate_convh2.py
         case 129: convh_launch<129>(p, geom, pool, cu_count, stream); break;                               // no loads in the K loop
         case 130: convh_launch<130>(p, geom, pool, cu_count, stream); break;                               // no fragment reads

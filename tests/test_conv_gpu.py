@@ -1,6 +1,8 @@
 """Implicit-GEMM MFMA convolution (csrc/ssdhip_conv.hip, through the C ABI) vs a plain PyTorch float32 reference of the
 same op on the same bf16-valued inputs.  Needs an MI355X.  Bar: |got - want| <= 2^-7 |want| + 1e-2 * rms (one bf16
 rounding of a float32-accumulated sum; the reference accumulates in a different order)."""
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -270,10 +272,11 @@ HALO_CASES = [  # B, H, W, Cin, Cout, bias, relu      (csrc/ssdhip_convh.hip: 3x
 ]
 
 
-@pytest.fixture(params=["128", "1152", "4224", "5248"])
+@pytest.fixture(params=["128", "1152"] + (os.environ.get("SSDHIP_TEST_CONVH_MODES", "").split(",") if os.environ.get("SSDHIP_TEST_CONVH_MODES") else []))
 def slab_mode(request):
     """SSDHIP_CONVH_MODE: 128 = persistent workgroups prefetching across tiles, 1152 = the same with the tolerant waits after an epilogue
-    (read at every launch); + 4096 (round 4) = four waves per workgroup, 64 channels x 128 positions each, one wave per SIMD."""
+    (read at every launch).  The profiling build (tools/prof_build.sh) also has the round-4 experiments + 4096 (four waves per workgroup)
+    and + 8192 (fragment reads in flight across the barrier): SSDHIP_TEST_CONVH_MODES=4224,5248,8320,9344,12416 with SSDHIP_LIB set."""
     import os
     old = os.environ.get("SSDHIP_CONVH_MODE")
     os.environ["SSDHIP_CONVH_MODE"] = request.param

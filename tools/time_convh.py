@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from ssd_keras_amd import _native as nat  # noqa: E402
 
-MODES = [int(m) for m in os.environ.get("CONVH_MODES", "128,1152,4224,5248").split(",")]   # + 4096: four waves per workgroup
+MODES = [int(m) for m in os.environ.get("CONVH_MODES", "128,1152").split(",")]   # + 4096: four waves per workgroup
 LAYERS = [  # name, B, H, W, Cin, Cout
     ("conv3_1", 32, 75, 75, 128, 256), ("conv3_2", 32, 75, 75, 256, 256), ("conv4_1", 32, 38, 38, 256, 512),
     ("conv4_2", 32, 38, 38, 512, 512), ("conv5_1", 32, 19, 19, 512, 512),
