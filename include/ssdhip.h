@@ -402,6 +402,18 @@ int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* 
 int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, int pool, void* stream);
 
+/* Weight gradient of a 3x3 'same' stride-1 dilation-1 convolution of the training graph -- what the TensorFlow graph behind
+ * model.fit_generator computes for every Conv2D of models/keras_ssd300.py:274-296 (ssd300_training.ipynb:171-173):
+ *     dw[co][kh][kw][ci] = sum_{b,h,w} dy[b,h,w,co] * x[b, h + kh - 1, w + kw - 1, ci]      (zero padding)
+ * x [B, H, W, Cin] bf16, dy [B, H, W, Cout] bf16 (gradient w.r.t. the convolution's output, activation mask already applied),
+ * dw [Cout, 3, 3, Cin] float32 (the channels_last layout of a [Cout, Cin, 3, 3] tensor).  MFMA kernel on transposed LDS fragments
+ * (ds_read_b64_tr_b16), split over positions with an ordered float32 reduction (csrc/ssdhip_wgrad.hip): bit-reproducible.
+ * Cin % 64 == 0 and (Cout % 128 == 0, W <= 190) or (Cout % 64 == 0, W <= 318); SSDHIP_E_BADARG otherwise.
+ * ssdhip_conv3x3_wgrad_workspace_bytes returns 0 for an unsupported geometry. */
+size_t ssdhip_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                                   size_t ws_bytes, void* stream);
+
 /* 3x3 convolution, stride 1 | 2, zero padding 0 | 1 (torch.nn.Conv2d semantics), Cin % 128 == 0, Cout % 128 == 0, map up to 94 wide,
  * through the same kernel: the SSD extra layers conv6_2 / conv7_2 (ZeroPadding2D(1) + stride 2, models/keras_ssd300.py:302-307) and
  * conv8_2 / conv9_2 ('valid', :310-313).  y is [B, (H + 2 pad - 3) / stride + 1, (W + 2 pad - 3) / stride + 1, Cout]; bit-identical to

@@ -566,6 +566,33 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
+def conv3x3_wgrad(x, dy):
+    """Weight gradient of a 3x3 'same' stride-1 convolution (csrc/ssdhip_wgrad.hip): x (B, Cin, H, W) and dy (B, Cout, H, W) bfloat16
+    channels_last -> float32 (Cout, Cin, 3, 3) in channels_last memory format ([Cout, 3, 3, Cin] physical), or None when the
+    geometry is not supported (the caller falls back to the framework's convolution_backward)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_wgrad_bound", False):
+        lib.ssdhip_conv3x3_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        lib.ssdhip_conv3x3_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 5
+        lib.ssdhip_conv3x3_wgrad_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_wgrad_nhwc_bf16.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        lib._wgrad_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    dy, (b2, h2, w2, cout) = _nhwc_bf16(dy, "dy")
+    if (b2, h2, w2) != (b, h, w):
+        raise SsdHipError("x and dy must cover the same pixels")
+    need = int(lib.ssdhip_conv3x3_wgrad_workspace_bytes(b, h, w, cin, cout))
+    if need == 0:
+        return None
+    ws = workspaces.get(x.device, "wgrad", need)
+    dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(dw), b, h, w, cin, cout, _ptr(ws), need, current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_wgrad_nhwc_bf16")
+    return dw.permute(0, 3, 1, 2)
+
+
 def conv3x3_halo_group(xs, weights, biases=None, relu=False, max_workgroups=0):
     """Several independent 3x3 'same' convolutions through the slab kernel in ONE launch (persistent workgroups, deepest problem
     first): the packed predictor heads.  xs[i] (B, Cin_i, H_i, W_i) bf16 NHWC memory, weights[i] (Cout_i, Cin_i, 3, 3) bf16

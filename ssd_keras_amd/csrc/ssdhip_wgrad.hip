@@ -1,0 +1,346 @@
+// ssdhip_wgrad.hip -- weight gradient of the 3x3 'same' stride-1 convolutions of the VGG trunk (models/keras_ssd300.py:274-296, the layers
+// model.fit_generator trains: ssd300_training.ipynb:171-173), gfx950, bf16 NHWC operands, float32 accumulation and output.
+//
+//     dW[co][kh][kw][ci] = sum_{b,h,w} dY[b,h,w,co] * X[b, h + kh - 1, w + kw - 1, ci]
+//
+// A GEMM whose K dimension is the PIXELS -- and with NHWC tensors both operands have K as their slow index: an MFMA lane wants 8
+// consecutive K values of one row (8 pixels of one channel), which sit a whole pixel row apart in memory.  How this kernel deals with it:
+//   * positions, not pixels (the forward slab kernel's grid, ssdhip_convh.hip): image b, row h, column w sits at position
+//     q = (b (H + 1) + h)(W + 1) + w; the dummy column of every row and the dummy row of every image are out-of-range buffer offsets
+//     (the LDS-DMA writes zeros), so tap (kh, kw) is the SAME displacement (kh - 1)(W + 1) + (kw - 1) for every position, with no border
+//     masks -- every out-of-image tap lands on zeros, and dY is zero on the dummies;
+//   * transposed fragments: both operands are staged in LDS as [position][32 channels] images with 64-byte rows (what the lane-linear
+//     LDS-DMA writes when lane L fetches 16 bytes of position L / 4), and ds_read_b64_tr_b16 hands each lane 4 consecutive positions of
+//     ITS channel from four rows: a 16-lane group reads one 4 x 16 block, the two groups of a half-wave 256 contiguous bytes (all 64
+//     banks once);
+//   * one window per filter row: the 8 K-values of tap (kh, 1) are those of tap (kh, 0) shifted by one position, so a lane reads the 12
+//     positions p - 1 .. p + 10 of a filter row ONCE (three transposed reads) and builds the three taps' operands in registers (kw = 0:
+//     dwords 0..3; kw = 2: dwords 1..4; kw = 1: four v_alignbit): 9 + 2 LDS reads for 9 MFMAs instead of 18 + 2;
+//   * tile: 128 (or 64) output channels x 64 input channels x all nine taps per workgroup, 8 waves as 4 x 2 (COS = 4) or 2 x 2 x two
+//     K halves (COS = 2, Cout = 64: conv1_2), each wave NINE 32 x 32 accumulators (144 registers);
+//   * the positions are streamed in blocks of 64: dY ring of four blocks, X ring of RB blocks (the halo of (W + 2) positions either side
+//     rides along: a block is loaded ONCE per workgroup), requests three blocks ahead with exact vmcnt counts, one barrier per block,
+//     fragments of the next K-step read while the current one multiplies (also across the block boundary);
+//   * split over positions: S workgroups per (co, ci) tile so that ~256 exist, each writes a float32 partial [co][tap][ci] tile; a
+//     second kernel adds the partials in index order (fixed summation order: results are bit-reproducible run to run).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short bf16_t;
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wg_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+
+struct WgParams {
+    const bf16_t* x;             // [B, H, W, Cin]
+    const bf16_t* dy;            // [B, H, W, Cout]
+    float* part;                 // [slots][Cout][9][Cin] partial sums (slots = splits x (COS == 2 ? 2 : 1))
+    int H, W, Cin, Cout;
+    int Q;                       // padded positions B (H + 1)(W + 1)
+    int n_blocks;                // blocks of 64 positions
+    int n_ci_tiles, n_tiles;     // Cin / 64; (Cout / (32 COS)) n_ci_tiles
+    int blocks_per_split;
+    int HB;                      // halo blocks: ceil((W + 2) / 64)
+    int x_bytes, dy_bytes;
+};
+
+constexpr int WG_THREADS = 512;
+constexpr unsigned WG_OOB = 0x80000000u;
+constexpr int wg_lds_bytes(int cos, int rb) { return 2 * (64 * rb + 16) * 64 + 2 * 1024 + cos * 4 * 64 * 64; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void wg_bload(u32 voff, wg_i32x4 rsrc, u32 lds_dst) {     // one 1 KiB LDS-DMA piece (see ch_bload)
+    u32 keep;
+    lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ wg_i32x4 wg_rsrc(const void* base, int num_records) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    wg_i32x4 r;
+    r.x = (int)(u32)a;
+    r.y = (int)((u32)(a >> 32) & 0xffffu);
+    r.z = num_records;
+    r.w = 0x00020000;
+    return r;
+}
+typedef __attribute__((address_space(3))) unsigned char wg_lds_byte;
+__device__ __forceinline__ wg_u32x2 wg_tr_read(wg_lds_byte* lds, u32 off) {   // ds_read_b64_tr_b16 at byte `off` of the workgroup's LDS array
+    const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)(lds + off));
+    return __builtin_bit_cast(wg_u32x2, v);
+}
+
+// position tracker of one request piece: the lane's position advances by 64 per block
+struct WgTrack {
+    int p, w, h, bh;             // position, its column and row on the padded grid, b * H
+};
+#endif
+
+template <int COS, int RB>
+__global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int R = 64 * RB;                           // rows of the X ring (+ 16 guard rows mirroring rows 0..15)
+    constexpr int XSUB = (R + 16) * 64;                  // bytes of one 32-channel X sub-image
+    constexpr int XR = 0, DUMP = 2 * XSUB, DYB = DUMP + 2 * 1024, DSUB = 4 * 64 * 64;
+    constexpr int KS = COS;                              // K-steps (16 positions) a wave multiplies per block: 4, or 2 of the 4 (COS = 2)
+    constexpr int NDY = COS / 2;                         // dY pieces a wave requests per block
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[wg_lds_bytes(COS, RB)];
+    wg_lds_byte* const ldsp = (wg_lds_byte*)lds;
+    const u32 lds0 = (u32)(uintptr_t)ldsp;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1;                             // 32-channel half of the 64 input channels
+    const int wm = COS == 4 ? wave >> 1 : (wave >> 1) & 1;   // 32-channel block of the output channels
+    const int kg = COS == 4 ? 0 : wave >> 2;             // COS = 2: which two K-steps of a block
+    const int H = p.H, W = p.W, W1 = W + 1, H1 = H + 1;
+
+    // workgroup -> (tile, split): the tiles of one split (the same positions) share an XCD's L2 (ids are dealt round robin)
+    const int id = (int)blockIdx.x, xcd = id & 7, slot_id = id >> 3;
+    const int split = xcd + 8 * (slot_id / p.n_tiles), tile = slot_id % p.n_tiles;
+    const int co0 = (tile / p.n_ci_tiles) * (32 * COS), ci0 = (tile % p.n_ci_tiles) * 64;
+    const int sa = split * p.blocks_per_split;
+    int nst = p.n_blocks - sa;
+    nst = nst > p.blocks_per_split ? p.blocks_per_split : nst;          // blocks of this workgroup (may be <= 0: it then writes zeros)
+
+    const wg_i32x4 rx = wg_rsrc(p.x, p.x_bytes), rdy = wg_rsrc(p.dy, p.dy_bytes);
+
+    // ---- request pieces: lane L of a piece fetches 16 bytes of position (block 64 + rg 16 + L / 4), channels sub 32 + (L & 3) 8 ----------
+    const int xsub = wave & 1, xrg = wave >> 1;          // this wave's X piece of a block
+    const bool guard = xrg == 0;                          // ... and the mirror of rows 0..15 when the block lands on ring slot 0
+    int dsub[NDY], drg[NDY];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+        dsub[u] = COS == 4 ? wave & 3 : wave & 1;
+        drg[u] = COS == 4 ? (wave >> 2) * 2 + u : wave >> 1;
+    }
+    auto track_init = [&](WgTrack& t, const int pos) {
+        t.p = pos;
+        if (pos >= 0) {
+            const int b = pos / (H1 * W1), r = pos - b * (H1 * W1);
+            t.h = r / W1;
+            t.w = r - t.h * W1;
+            t.bh = b * H;
+        } else {                                          // before the first image: columns count up to position 0
+            t.w = pos; t.h = 0; t.bh = 0;
+        }
+    };
+    auto track_step = [&](WgTrack& t) {
+        t.p += 64;
+        t.w += 64;
+        while (t.w >= W1) { t.w -= W1; if (++t.h == H1) { t.h = 0; t.bh += H; } }
+    };
+    auto track_off = [&](const WgTrack& t, const int C, const int c) {       // byte offset of the lane's 16 bytes, or out of range
+        const bool ok = (t.w >= 0) & (t.w < W) & (t.h < H) & (t.p < p.Q);
+        return ok ? (u32)(((t.bh + t.h) * W + t.w) * C + c) * 2u : WG_OOB;
+    };
+    WgTrack tx, tdy[NDY];
+    track_init(tx, (sa - p.HB) * 64 + xrg * 16 + (lane >> 2));
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) track_init(tdy[u], sa * 64 + drg[u] * 16 + (lane >> 2));
+    const int xc = ci0 + xsub * 32 + (lane & 3) * 8;
+    int xslot = 0, dslot = 0;                            // ring slots of the NEXT X block / dY block to request
+    auto req_x = [&]() {
+        const u32 off = track_off(tx, p.Cin, xc);
+        wg_bload(off, rx, lds0 + XR + xsub * XSUB + (xslot * 64 + xrg * 16) * 64);
+        if (guard) wg_bload(xslot == 0 ? off : WG_OOB, rx, lds0 + (xslot == 0 ? XR + xsub * XSUB + R * 64 : DUMP + xsub * 1024));
+        track_step(tx);
+        xslot = xslot + 1 == RB ? 0 : xslot + 1;
+    };
+    auto req_dy = [&]() {
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            wg_bload(track_off(tdy[u], p.Cout, co0 + dsub[u] * 32 + (lane & 3) * 8), rdy, lds0 + DYB + dsub[u] * DSUB + (dslot * 64 + drg[u] * 16) * 64);
+            track_step(tdy[u]);
+        }
+        dslot = (dslot + 1) & 3;
+    };
+
+    // ---- fragment addressing ----------------------------------------------------------------------------------------------------------------
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1, khalf = lane >> 5;
+    const u32 lp = (u32)(khalf * 8 + (i16 >> 2));                             // the lane's row inside a 16-position K-step
+    const u32 cbyte = (u32)(g16 * 32 + (i16 & 3) * 8);
+    const u32 a_lane = (u32)(DYB + wm * DSUB) + lp * 64 + cbyte;              // + (slot 64 + kk 16) 64 (+ 256 for the second read)
+    const u32 x_lane = (u32)(XR + wn * XSUB) + cbyte;                         // + ring row 64 (+ 256, + 512)
+
+    wg_f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+    wg_u32x2 fa[2][2];                                   // [register set][read]: dY^T fragment (32 channels x 16 positions)
+    wg_u32x2 fx[2][3][3];                                // [register set][filter row][read]: positions p - 1 .. p + 10 of the lane's channel
+    // ring row of position (64 (block) - W1 - 1) of the CURRENT block, i.e. of tap (0, 0) of the block's first position
+    int ubase = 64 * p.HB - W1 - 1;                      // >= 0 because 64 HB >= W + 2
+    int rslot = 0;                                       // dY ring slot of the current block
+    auto read_frags = [&](auto setc, const int ub, const int ds, const int kk) {
+        constexpr int S = decltype(setc)::value;
+        const u32 a0 = a_lane + (u32)((ds * 64 + kk * 16) * 64);
+        fa[S][0] = wg_tr_read(ldsp, a0);
+        fa[S][1] = wg_tr_read(ldsp, a0 + 256);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            u32 r = (u32)(ub + kk * 16 + kh * W1) + lp;                       // < 2 R
+            const u32 rw = r - (u32)R;
+            r = rw < r ? rw : r;                                              // unsigned: r - R wraps to a huge value when r < R
+            const u32 a = x_lane + r * 64;
+            fx[S][kh][0] = wg_tr_read(ldsp, a);
+            fx[S][kh][1] = wg_tr_read(ldsp, a + 256);
+            fx[S][kh][2] = wg_tr_read(ldsp, a + 512);
+        }
+    };
+    auto mfma_step = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        const wg_u32x4 av = {fa[S][0].x, fa[S][0].y, fa[S][1].x, fa[S][1].y};
+        const wg_bf16x8 a = __builtin_bit_cast(wg_bf16x8, av);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const u32 d0 = fx[S][kh][0].x, d1 = fx[S][kh][0].y, d2 = fx[S][kh][1].x, d3 = fx[S][kh][1].y, d4 = fx[S][kh][2].x;
+            const wg_u32x4 b0 = {d0, d1, d2, d3};
+            const wg_u32x4 b1 = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                 __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
+            const wg_u32x4 b2 = {d1, d2, d3, d4};
+            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 0], 0, 0, 0);
+            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b1), acc[kh * 3 + 1], 0, 0, 0);
+            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b2), acc[kh * 3 + 2], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+    if (nst > 0) {
+        // ---- prologue: X blocks sa - HB .. sa + HB + 2 and dY blocks sa .. sa + 2 ----------------------------------------------------------
+        for (int j = 0; j < 2 * p.HB + 3; ++j) req_x();
+        for (int j = 0; j < 3; ++j) req_dy();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(I0{}, ubase, 0, kg * 2);
+
+        for (int t = 0; t < nst; ++t) {
+            // requests of block t + 3 (X: t + HB + 3): their ring slots were last read in block t - 1, which every wave has left
+            req_x();
+            req_dy();
+            int ubn = ubase + 64;
+            ubn = ubn >= R ? ubn - R : ubn;
+            const int dsn = (rslot + 1) & 3;
+            if constexpr (KS == 4) {
+                read_frags(I1{}, ubase, rslot, 1); mfma_step(I0{});
+                read_frags(I0{}, ubase, rslot, 2); mfma_step(I1{});
+                read_frags(I1{}, ubase, rslot, 3); mfma_step(I0{});
+                read_frags(I0{}, ubn, dsn, 0);     mfma_step(I1{});            // block t + 1 landed before the barrier that closed block t - 1
+            } else {
+                read_frags(I1{}, ubase, rslot, kg * 2 + 1); mfma_step(I0{});
+                read_frags(I0{}, ubn, dsn, kg * 2);         mfma_step(I1{});
+            }
+            ubase = ubn;
+            rslot = dsn;
+            // everything requested before this block has landed (block t + 2's data); this block's requests may stay in flight
+            if (guard) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + 1) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // requests still in flight write into LDS: they must not outlive the workgroup
+
+    // ---- partial tile: lane (r31 = input channel, khalf), register v: output channel 8 (v / 4) + 4 khalf + v % 4 ------------------------------
+    const int r31 = lane & 31;
+    const int slot = COS == 4 ? split : split * 2 + kg;
+    float* out = p.part + (size_t)slot * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int co = co0 + wm * 32 + 8 * (v >> 2) + 4 * khalf + (v & 3);
+            out[((size_t)co * 9 + t) * p.Cin + ci0 + wn * 32 + r31] = acc[t][v];
+        }
+#endif
+}
+
+// out[i] = sum over the slots, in index order (float4 per thread)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out, int n4, int slots) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 s = part[i];
+        for (int k = 1; k < slots; ++k) {
+            const float4 v = part[(size_t)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[i] = s;
+    }
+}
+
+struct WgPlan {
+    int cos, splits, slots, n_tiles, n_ci_tiles, n_blocks, blocks_per_split, HB;
+    long long Q;
+    size_t ws_bytes;
+};
+
+static bool wg_plan(int B, int H, int W, int Cin, int Cout, WgPlan& pl) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64)) return false;
+    pl.cos = (Cout % 128) ? 2 : 4;
+    pl.HB = (W + 2 + 63) / 64;
+    if (pl.HB > (pl.cos == 4 ? 3 : 5)) return false;                          // ring blocks: 2 HB + 4 <= 10 | 14
+    pl.Q = (long long)B * (H + 1) * (W + 1);
+    if (pl.Q > 0x3fffff00LL) return false;
+    if ((long long)B * H * W * Cin * 2 >= 0x7ffff000LL || (long long)B * H * W * Cout * 2 >= 0x7ffff000LL) return false;   // 31-bit byte offsets
+    pl.n_blocks = (int)((pl.Q + 63) / 64);
+    pl.n_ci_tiles = Cin / 64;
+    pl.n_tiles = (Cout / (32 * pl.cos)) * pl.n_ci_tiles;
+    // ~256 workgroups (one per CU; the LDS rings take a whole CU), a multiple of 8 splits (the id -> XCD map), at least 12 blocks each
+    int s = (256 / pl.n_tiles) / 8 * 8;
+    if (s < 8) s = 8;
+    while (s > 8 && (pl.n_blocks + s - 1) / s < 12) s -= 8;
+    pl.splits = s;
+    pl.blocks_per_split = (pl.n_blocks + s - 1) / s;
+    pl.slots = pl.cos == 4 ? s : 2 * s;
+    pl.ws_bytes = (size_t)pl.slots * Cout * 9 * Cin * sizeof(float);
+    return true;
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+// Bytes of scratch ssdhip_conv3x3_wgrad_nhwc_bf16 needs for this geometry (0: geometry not supported).
+extern "C" size_t ssdhip_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    WgPlan pl;
+    return wg_plan(B, H, W, Cin, Cout, pl) ? pl.ws_bytes : 0;
+}
+
+// dw[co][kh][kw][ci] (float32, [Cout, 3, 3, Cin] = the channels_last layout of a [Cout, Cin, 3, 3] filter gradient) of the 3x3 'same'
+// stride-1 dilation-1 convolution y = conv(x, w): x [B, H, W, Cin] bf16, dy [B, H, W, Cout] bf16 (the gradient w.r.t. the convolution's
+// output, ReLU mask applied by the caller).  Cin % 64 == 0; Cout % 128 == 0 with W <= 190, or Cout % 64 == 0 with W <= 318.
+// Bit-reproducible run to run (fixed summation order).  SSDHIP_E_BADARG for other geometries (callers fall back to the framework).
+extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                                              size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    WgPlan pl;
+    if (!x || !dy || !dw || !wg_plan(B, H, W, Cin, Cout, pl)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) return SSDHIP_E_BADARG;
+    if (!ws || ws_bytes < pl.ws_bytes || ((uintptr_t)ws & 15)) return SSDHIP_E_WORKSPACE;
+    WgParams p;
+    p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.part = static_cast<float*>(ws);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.Q = (int)pl.Q; p.n_blocks = pl.n_blocks; p.n_ci_tiles = pl.n_ci_tiles; p.n_tiles = pl.n_tiles;
+    p.blocks_per_split = pl.blocks_per_split; p.HB = pl.HB;
+    p.x_bytes = (int)((long long)B * H * W * Cin * 2); p.dy_bytes = (int)((long long)B * H * W * Cout * 2);
+    const dim3 grid(pl.splits * pl.n_tiles), block(WG_THREADS);
+    if (pl.cos == 4) hipLaunchKernelGGL((conv_wgrad_kernel<4, 10>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<2, 14>), grid, block, 0, stream, p);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    const int n4 = Cout * 9 * Cin / 4;
+    int rb = (n4 + 255) / 256;
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw),
+                       n4, pl.slots);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

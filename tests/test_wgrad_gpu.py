@@ -1,0 +1,79 @@
+"""ssdhip_conv3x3_wgrad_nhwc_bf16 (csrc/ssdhip_wgrad.hip): the weight gradient of the 3x3 'same' convolutions of the training graph
+(models/keras_ssd300.py:274-296 under model.fit_generator, ssd300_training.ipynb:171-173) against a float32 / float64 PyTorch reference
+of the same op on the same bf16 operands.  Needs an MI355X.
+
+Bar: the kernel multiplies exact bf16 products and accumulates in float32 (MFMA), so against the float64 sum of the same products the
+error of one output is bounded by float32 summation noise: |got - want| <= 2^-18 * sum|dy||x| per element is comfortable for up to
+3 M positions split over >= 8 ordered partial sums; and two runs are BIT-identical (fixed summation order, no atomics)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, H, W, Cin, Cout
+    (2, 19, 19, 128, 128),       # conv5-like map, one tile pair
+    (3, 10, 7, 64, 128),         # Cin = 64 (conv2_1's channel shape), narrow map: several row wraps per 64-position block
+    (2, 38, 38, 256, 256),       # four (co, ci) tiles x 8 ci tiles
+    (1, 75, 75, 128, 256),       # conv3_1: two halo blocks
+    (1, 150, 150, 64, 128),      # conv2_1: three halo blocks, the ring wraps many times
+    (1, 40, 150, 128, 128),      # conv2_2's width
+    (1, 60, 300, 64, 64),        # conv1_2's width: the 64-output-channel form (two K halves per block), five halo blocks
+    (2, 1, 1, 64, 128),          # one pixel per image: eight of the nine taps see only padding
+    (1, 5, 190, 64, 128),        # the widest map of the 128-channel form
+    (4, 19, 19, 512, 512),       # conv5_x at a small batch: 32 tiles
+]
+
+
+def _ref(x, dy):
+    import torch
+    # d/dw of sum(conv(x, w) * dy): exact bf16 operands, float64 accumulation
+    return torch.nn.grad.conv2d_weight(x.double(), (dy.shape[1], x.shape[1], 3, 3), dy.double(), stride=1, padding=1)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wgrad_matches_float64_reference(case):
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout = case
+    g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    dy = torch.randn((B, H, W, Cout), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    dy = dy * (torch.rand((B, Cout, H, W), generator=g, device="cuda") > 0.4).to(torch.bfloat16)      # a ReLU-masked gradient has zeros
+    got = nat.conv3x3_wgrad(x, dy)
+    assert got is not None, "geometry must be supported"
+    assert got.shape == (Cout, Cin, 3, 3) and got.dtype == torch.float32
+    want = _ref(x, dy)
+    mag = torch.nn.grad.conv2d_weight(x.double().abs(), (Cout, Cin, 3, 3), dy.double().abs(), stride=1, padding=1)
+    err = (got.double() - want).abs()
+    bad = int((err > mag * 2.0 ** -18 + 1e-30).sum().item())
+    assert bad == 0, "%d of %d weight gradients off (worst %.3g of bound)" % (bad, got.numel(), float((err / (mag * 2.0 ** -18 + 1e-30)).max()))
+    again = nat.conv3x3_wgrad(x, dy)
+    assert torch.equal(again, got), "two runs must be bit-identical"
+
+
+def test_wgrad_full_batch_conv4_and_race_screen():
+    """BASELINE configs[2] sizes: conv4_2 at batch 32 (32 tiles x 8 splits = 256 workgroups), ten launches bit-identical, and within the
+    convolution bar of the framework's own float32 weight gradient."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout = 32, 38, 38, 512, 512
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    dy = torch.randn((B, H, W, Cout), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    got = nat.conv3x3_wgrad(x, dy)
+    want = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cin, 3, 3), dy.float(), stride=1, padding=1)
+    rms = want.pow(2).mean().sqrt().item()
+    assert float((got - want).abs().max()) <= 1e-3 * rms
+    for _ in range(10):
+        assert torch.equal(nat.conv3x3_wgrad(x, dy), got)
+
+
+def test_wgrad_unsupported_geometries_return_none():
+    import torch
+    from ssd_keras_amd import _native as nat
+    x = torch.zeros((1, 3, 8, 8), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv3x3_wgrad(x, torch.zeros((1, 64, 8, 8), device="cuda", dtype=torch.bfloat16))          # 3 channels: not a multiple of 8
+    x = torch.zeros((1, 32, 8, 8), device="cuda", dtype=torch.bfloat16)
+    assert nat.conv3x3_wgrad(x, torch.zeros((1, 64, 8, 8), device="cuda", dtype=torch.bfloat16)) is None   # Cin % 64 != 0
+    x = torch.zeros((1, 64, 4, 200), device="cuda", dtype=torch.bfloat16)
+    assert nat.conv3x3_wgrad(x, torch.zeros((1, 128, 4, 200), device="cuda", dtype=torch.bfloat16)) is None  # too wide for the 128-channel form
