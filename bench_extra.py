@@ -462,6 +462,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         last["loss"] = loss_static.detach()
         if trace is not None:
             trace.append(("graph", round(float(loss_static), 4)))
+            torch.cuda.synchronize()                     # a device-wide synchronize between replays was part of the round-3 failure
 
     eager_ms = None
     with torch.cuda.device(dev):

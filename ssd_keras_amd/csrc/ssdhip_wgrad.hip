@@ -25,6 +25,7 @@
 //     second kernel adds the partials in index order (fixed summation order: results are bit-reproducible run to run).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -86,7 +87,9 @@ struct WgTrack {
 };
 #endif
 
-template <int COS, int RB>
+// ABL (profiling build only, wrong results by construction -- each bit removes one cost): 1 no requests inside the block loop, 2 no
+// fragment reads, 4 no operand building (every tap multiplies the kw = 0 operand), 8 no MFMAs, 16 no wait / barrier per block.
+template <int COS, int RB, int ABL = 0>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = 64 * RB;                           // rows of the X ring (+ 16 guard rows mirroring rows 0..15)
@@ -184,37 +187,71 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     // ring row of position (64 (block) - W1 - 1) of the CURRENT block, i.e. of tap (0, 0) of the block's first position
     int ubase = 64 * p.HB - W1 - 1;                      // >= 0 because 64 HB >= W + 2
     int rslot = 0;                                       // dY ring slot of the current block
-    auto read_frags = [&](auto setc, const int ub, const int ds, const int kk) {
+    // One K-step = 9 MFMAs on register set S while the 11 transposed reads of the NEXT K-step fill the other set, in three groups of
+    // (reads of one filter row, the row's three MFMAs): reads in one burst would queue up in front of the LDS and stall the in-order wave.
+    auto read_a = [&](auto setc, const int ds, const int kk) {
         constexpr int S = decltype(setc)::value;
         const u32 a0 = a_lane + (u32)((ds * 64 + kk * 16) * 64);
+        if constexpr (ABL & 2) { asm volatile("" : "+v"(fa[S][0]), "+v"(fa[S][1]) : "v"(a0)); return; }
         fa[S][0] = wg_tr_read(ldsp, a0);
         fa[S][1] = wg_tr_read(ldsp, a0 + 256);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            u32 r = (u32)(ub + kk * 16 + kh * W1) + lp;                       // < 2 R
-            const u32 rw = r - (u32)R;
-            r = rw < r ? rw : r;                                              // unsigned: r - R wraps to a huge value when r < R
-            const u32 a = x_lane + r * 64;
-            fx[S][kh][0] = wg_tr_read(ldsp, a);
-            fx[S][kh][1] = wg_tr_read(ldsp, a + 256);
-            fx[S][kh][2] = wg_tr_read(ldsp, a + 512);
-        }
     };
-    auto mfma_step = [&](auto setc) {
+    auto read_x = [&](auto setc, const int ub, const int kk, const int kh) {
+        constexpr int S = decltype(setc)::value;
+        u32 r = (u32)(ub + kk * 16 + kh * W1) + lp;                           // < 2 R
+        const u32 rw = r - (u32)R;
+        r = rw < r ? rw : r;                                                  // unsigned: r - R wraps to a huge value when r < R
+        const u32 a = x_lane + r * 64;
+        if constexpr (ABL & 2) { asm volatile("" : "+v"(fx[S][kh][0]), "+v"(fx[S][kh][1]), "+v"(fx[S][kh][2]) : "v"(a)); return; }
+        fx[S][kh][0] = wg_tr_read(ldsp, a);
+        fx[S][kh][1] = wg_tr_read(ldsp, a + 256);
+        fx[S][kh][2] = wg_tr_read(ldsp, a + 512);
+    };
+    auto read_frags = [&](auto setc, const int ub, const int ds, const int kk) {
+        read_a(setc, ds, kk);
+        read_x(setc, ub, kk, 0); read_x(setc, ub, kk, 1); read_x(setc, ub, kk, 2);
+    };
+    auto mfma_row = [&](auto setc, const int kh) {
         constexpr int S = decltype(setc)::value;
         const wg_u32x4 av = {fa[S][0].x, fa[S][0].y, fa[S][1].x, fa[S][1].y};
         const wg_bf16x8 a = __builtin_bit_cast(wg_bf16x8, av);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const u32 d0 = fx[S][kh][0].x, d1 = fx[S][kh][0].y, d2 = fx[S][kh][1].x, d3 = fx[S][kh][1].y, d4 = fx[S][kh][2].x;
-            const wg_u32x4 b0 = {d0, d1, d2, d3};
-            const wg_u32x4 b1 = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
-                                 __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
-            const wg_u32x4 b2 = {d1, d2, d3, d4};
+        const u32 d0 = fx[S][kh][0].x, d1 = fx[S][kh][0].y, d2 = fx[S][kh][1].x, d3 = fx[S][kh][1].y, d4 = fx[S][kh][2].x;
+        const wg_u32x4 b0 = {d0, d1, d2, d3};
+        const wg_u32x4 b1 = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                             __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
+        const wg_u32x4 b2 = {d1, d2, d3, d4};
+        if constexpr (ABL & 8) {
+            // (keeps the operands alive: a few VALU operations instead of the three MFMAs)
+            acc[kh * 3 + 0][0] = __uint_as_float(__float_as_uint(acc[kh * 3 + 0][0]) ^ (b0.x & b0.w & av.x & av.w & 1u));
+            acc[kh * 3 + 1][0] = __uint_as_float(__float_as_uint(acc[kh * 3 + 1][0]) ^ (b1.x & b1.w & 1u));
+            acc[kh * 3 + 2][0] = __uint_as_float(__float_as_uint(acc[kh * 3 + 2][0]) ^ (b2.x & b2.w & 1u));
+        } else if constexpr (ABL & 4) {
             acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 0], 0, 0, 0);
-            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b1), acc[kh * 3 + 1], 0, 0, 0);
-            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b2), acc[kh * 3 + 2], 0, 0, 0);
+            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 1], 0, 0, 0);
+            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 2], 0, 0, 0);
+            asm volatile("" :: "v"(d4));
+        } else {
+        acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 0], 0, 0, 0);
+        acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b1), acc[kh * 3 + 1], 0, 0, 0);
+        acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b2), acc[kh * 3 + 2], 0, 0, 0);
         }
+    };
+    // multiply set S, fill the other set with the fragments of K-step (ub, ds, kk)
+    auto kstep = [&](auto setc, auto nextc, const int ub, const int ds, const int kk) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(nextc, ds, kk);
+        read_x(nextc, ub, kk, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(setc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(nextc, ub, kk, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(setc, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(nextc, ub, kk, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(setc, 2);
+        __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
@@ -228,26 +265,30 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 
         for (int t = 0; t < nst; ++t) {
             // requests of block t + 3 (X: t + HB + 3): their ring slots were last read in block t - 1, which every wave has left
-            req_x();
-            req_dy();
+            if constexpr (!(ABL & 1)) {
+                req_x();
+                req_dy();
+            }
             int ubn = ubase + 64;
             ubn = ubn >= R ? ubn - R : ubn;
             const int dsn = (rslot + 1) & 3;
             if constexpr (KS == 4) {
-                read_frags(I1{}, ubase, rslot, 1); mfma_step(I0{});
-                read_frags(I0{}, ubase, rslot, 2); mfma_step(I1{});
-                read_frags(I1{}, ubase, rslot, 3); mfma_step(I0{});
-                read_frags(I0{}, ubn, dsn, 0);     mfma_step(I1{});            // block t + 1 landed before the barrier that closed block t - 1
+                kstep(I0{}, I1{}, ubase, rslot, 1);
+                kstep(I1{}, I0{}, ubase, rslot, 2);
+                kstep(I0{}, I1{}, ubase, rslot, 3);
+                kstep(I1{}, I0{}, ubn, dsn, 0);                                // block t + 1 landed before the barrier that closed block t - 1
             } else {
-                read_frags(I1{}, ubase, rslot, kg * 2 + 1); mfma_step(I0{});
-                read_frags(I0{}, ubn, dsn, kg * 2);         mfma_step(I1{});
+                kstep(I0{}, I1{}, ubase, rslot, kg * 2 + 1);
+                kstep(I1{}, I0{}, ubn, dsn, kg * 2);
             }
             ubase = ubn;
             rslot = dsn;
             // everything requested before this block has landed (block t + 2's data); this block's requests may stay in flight
-            if (guard) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + 2) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDY + 1) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 16)) {
+                if (guard) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ABL & 1) ? 0 : NDY + 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ABL & 1) ? 0 : NDY + 1) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // requests still in flight write into LDS: they must not outlive the workgroup
@@ -334,7 +375,25 @@ extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, flo
     p.blocks_per_split = pl.blocks_per_split; p.HB = pl.HB;
     p.x_bytes = (int)((long long)B * H * W * Cin * 2); p.dy_bytes = (int)((long long)B * H * W * Cout * 2);
     const dim3 grid(pl.splits * pl.n_tiles), block(WG_THREADS);
-    if (pl.cos == 4) hipLaunchKernelGGL((conv_wgrad_kernel<4, 10>), grid, block, 0, stream, p);
+    int abl = 0;
+#if defined(SSDHIP_PROFILE)
+    if (const char* e = getenv("SSDHIP_WGRAD_ABL")) abl = atoi(e);             // tools/ablate_wgrad.py
+    if (pl.cos == 4 && abl) {
+        switch (abl) {
+            case 1: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 1>), grid, block, 0, stream, p); break;
+            case 2: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 2>), grid, block, 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 4>), grid, block, 0, stream, p); break;
+            case 6: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 6>), grid, block, 0, stream, p); break;
+            case 7: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 7>), grid, block, 0, stream, p); break;
+            case 8: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 8>), grid, block, 0, stream, p); break;
+            case 16: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 16>), grid, block, 0, stream, p); break;
+            case 23: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 23>), grid, block, 0, stream, p); break;
+            default: abl = 0; break;
+        }
+    }
+#endif
+    if (abl) {}
+    else if (pl.cos == 4) hipLaunchKernelGGL((conv_wgrad_kernel<4, 10>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<2, 14>), grid, block, 0, stream, p);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     const int n4 = Cout * 9 * Cin / 4;

@@ -125,11 +125,19 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
         halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0
                 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
         gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
-    masks = [need_x and gx is None, True, False]
-    gx_m, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
-                                                      masks)
-    if gx is None and need_x:
-        gx = gx_m
+    gw = None
+    if (k == 3 and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1) and os.environ.get("SSDHIP_NO_OWN_WGRAD", "0") != "1"):
+        # the weight gradient through libssdhip's MFMA kernel (csrc/ssdhip_wgrad.hip; float32, fixed summation order); None: geometry
+        # not covered (3 input channels, predictor heads whose channel counts are not multiples of 64)
+        gw = nat.conv3x3_wgrad(xb, gy) if (xb.shape[1] % 64 == 0 and gy.shape[1] % 64 == 0) else None
+    masks = [need_x and gx is None, gw is None, False]
+    if masks[0] or masks[1]:
+        gx_m, gw_m, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0],
+                                                            1, masks)
+        if gx is None and need_x:
+            gx = gx_m
+        if gw is None:
+            gw = gw_m
     return gx, gw
 
 
