@@ -13,11 +13,16 @@
 //     LDS-DMA writes when lane L fetches 16 bytes of position L / 4), and ds_read_b64_tr_b16 hands each lane 4 consecutive positions of
 //     ITS channel from four rows: a 16-lane group reads one 4 x 16 block, the two groups of a half-wave 256 contiguous bytes (all 64
 //     banks once);
-//   * one window per filter row: the 8 K-values of tap (kh, 1) are those of tap (kh, 0) shifted by one position, so a lane reads the 12
-//     positions p - 1 .. p + 10 of a filter row ONCE (three transposed reads) and builds the three taps' operands in registers (kw = 0:
-//     dwords 0..3; kw = 2: dwords 1..4; kw = 1: four v_alignbit): 9 + 2 LDS reads for 9 MFMAs instead of 18 + 2;
-//   * tile: 128 (or 64) output channels x 64 input channels x all nine taps per workgroup, 8 waves as 4 x 2 (COS = 4) or 2 x 2 x two
-//     K halves (COS = 2, Cout = 64: conv1_2), each wave NINE 32 x 32 accumulators (144 registers);
+//   * every tap's operand is read straight from LDS (two transposed reads each): the row of a lane is free in a transposed read, so the
+//     nine taps are nine row displacements of ONE per-lane base address per filter row, the kw and the second-read displacements ride in
+//     the instruction's immediate offset.  (First version: one 12-position window per filter row and the kw = 1 / kw = 2 operands built
+//     in registers -- 9 + 2 reads but 24 v_perm / v_mov and 12 address operations per 9 MFMAs; the profiling build's ablations,
+//     profiles/r04g_wgrad_ablation.json, showed the kernel bound by instruction issue: everything but the MFMAs took as long as the MFMAs.)
+//   * tile: 128 (or 64) output channels x 64 input channels x all nine taps per workgroup.  A wave owns 64 output channels x 32 input
+//     channels x FIVE or FOUR of the nine taps (ten / eight 32 x 32 accumulators, 160 registers): 8 waves = 2 (output channels) x 2
+//     (input channels) x 2 (tap groups), the two tap groups of a channel pair on the SAME SIMD (18 MFMAs per K-step and SIMD, as with
+//     nine taps per wave) -- but a wave reads 2 + 5 fragments for 10 MFMAs instead of 1 + 9 for 9 (r04h: the first layout's LDS read
+//     stream alone took longer than its MFMAs).  COS = 2 (Cout = 64, conv1_2): 1 x 2 x 2 tap groups x 2 K halves of every block;
 //   * the positions are streamed in blocks of 64: dY ring of four blocks, X ring of RB blocks (the halo of (W + 2) positions either side
 //     rides along: a block is loaded ONCE per workgroup), requests three blocks ahead with exact vmcnt counts, one barrier per block,
 //     fragments of the next K-step read while the current one multiplies (also across the block boundary);
@@ -52,12 +57,13 @@ struct WgParams {
     int n_ci_tiles, n_tiles;     // Cin / 64; (Cout / (32 COS)) n_ci_tiles
     int blocks_per_split;
     int HB;                      // halo blocks: ceil((W + 2) / 64)
+    int step_h, step_w;          // 64 = step_h (W + 1) + step_w: how a position tracker advances per block
     int x_bytes, dy_bytes;
 };
 
 constexpr int WG_THREADS = 512;
 constexpr unsigned WG_OOB = 0x80000000u;
-constexpr int wg_lds_bytes(int cos, int rb) { return 2 * (64 * rb + 16) * 64 + 2 * 1024 + cos * 4 * 64 * 64; }
+constexpr int wg_lds_bytes(int cos, int rb) { return 2 * (64 * rb + 32) * 64 + 4 * 1024 + cos * 4 * 64 * 64; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void wg_bload(u32 voff, wg_i32x4 rsrc, u32 lds_dst) {     // one 1 KiB LDS-DMA piece (see ch_bload)
@@ -88,13 +94,13 @@ struct WgTrack {
 #endif
 
 // ABL (profiling build only, wrong results by construction -- each bit removes one cost): 1 no requests inside the block loop, 2 no
-// fragment reads, 4 no operand building (every tap multiplies the kw = 0 operand), 8 no MFMAs, 16 no wait / barrier per block.
+// fragment reads, 8 no MFMAs, 16 no wait / barrier per block.
 template <int COS, int RB, int ABL = 0>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int R = 64 * RB;                           // rows of the X ring (+ 16 guard rows mirroring rows 0..15)
-    constexpr int XSUB = (R + 16) * 64;                  // bytes of one 32-channel X sub-image
-    constexpr int XR = 0, DUMP = 2 * XSUB, DYB = DUMP + 2 * 1024, DSUB = 4 * 64 * 64;
+    constexpr int R = 64 * RB;                           // rows of the X ring (+ 32 guard rows mirroring rows 0..31)
+    constexpr int XSUB = (R + 32) * 64;                  // bytes of one 32-channel X sub-image
+    constexpr int XR = 0, DUMP = 2 * XSUB, DYB = DUMP + 4 * 1024, DSUB = 4 * 64 * 64;
     constexpr int KS = COS;                              // K-steps (16 positions) a wave multiplies per block: 4, or 2 of the 4 (COS = 2)
     constexpr int NDY = COS / 2;                         // dY pieces a wave requests per block
     __shared__ __attribute__((aligned(1024))) unsigned char lds[wg_lds_bytes(COS, RB)];
@@ -104,8 +110,9 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1;                             // 32-channel half of the 64 input channels
-    const int wm = COS == 4 ? wave >> 1 : (wave >> 1) & 1;   // 32-channel block of the output channels
-    const int kg = COS == 4 ? 0 : wave >> 2;             // COS = 2: which two K-steps of a block
+    const int wm = COS == 4 ? (wave >> 1) & 1 : 0;       // 64-channel half of the output channels
+    const int kg = COS == 4 ? 0 : (wave >> 1) & 1;       // COS = 2: which two K-steps of a block
+    const int tg = wave >> 2;                            // tap group: 0 = taps 0..4, 1 = taps 5..8 (waves w and w + 4 share a SIMD)
     const int H = p.H, W = p.W, W1 = W + 1, H1 = H + 1;
 
     // workgroup -> (tile, split): the tiles of one split (the same positions) share an XCD's L2 (ids are dealt round robin)
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 
     // ---- request pieces: lane L of a piece fetches 16 bytes of position (block 64 + rg 16 + L / 4), channels sub 32 + (L & 3) 8 ----------
     const int xsub = wave & 1, xrg = wave >> 1;          // this wave's X piece of a block
-    const bool guard = xrg == 0;                          // ... and the mirror of rows 0..15 when the block lands on ring slot 0
+    const bool guard = xrg < 2;                           // ... and the mirror of its rows (0..31) when the block lands on ring slot 0
     int dsub[NDY], drg[NDY];
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
@@ -128,24 +135,34 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
         drg[u] = COS == 4 ? (wave >> 2) * 2 + u : wave >> 1;
     }
     auto track_init = [&](WgTrack& t, const int pos) {
+        const int hw1 = H1 * W1;
+        int b = pos / hw1;
+        if (pos < 0 && b * hw1 != pos) --b;               // floor: positions before the first image sit in "image -1" (never valid)
+        const int r = pos - b * hw1;
         t.p = pos;
-        if (pos >= 0) {
-            const int b = pos / (H1 * W1), r = pos - b * (H1 * W1);
-            t.h = r / W1;
-            t.w = r - t.h * W1;
-            t.bh = b * H;
-        } else {                                          // before the first image: columns count up to position 0
-            t.w = pos; t.h = 0; t.bh = 0;
+        t.h = r / W1;
+        t.w = r - t.h * W1;
+        t.bh = b * H;
+    };
+    const bool tiny = p.step_h + 1 >= H1;                 // maps of a handful of rows: a block spans more than one image
+    auto track_step = [&](WgTrack& t) {                   // + 64 positions, branch-free (64 = step_h W1 + step_w)
+        t.p += 64;
+        t.w += p.step_w;
+        t.h += p.step_h;
+        const bool cw = t.w >= W1;
+        t.w -= cw ? W1 : 0;
+        t.h += cw ? 1 : 0;
+        if (!tiny) {
+            const bool ch = t.h >= H1;
+            t.h -= ch ? H1 : 0;
+            t.bh += ch ? H : 0;
+        } else {
+            while (t.h >= H1) { t.h -= H1; t.bh += H; }
         }
     };
-    auto track_step = [&](WgTrack& t) {
-        t.p += 64;
-        t.w += 64;
-        while (t.w >= W1) { t.w -= W1; if (++t.h == H1) { t.h = 0; t.bh += H; } }
-    };
     auto track_off = [&](const WgTrack& t, const int C, const int c) {       // byte offset of the lane's 16 bytes, or out of range
-        const bool ok = (t.w >= 0) & (t.w < W) & (t.h < H) & (t.p < p.Q);
-        return ok ? (u32)(((t.bh + t.h) * W + t.w) * C + c) * 2u : WG_OOB;
+        const bool ok = (t.p >= 0) & (t.w < W) & (t.h < H) & (t.p < p.Q);
+        return ((u32)(((t.bh + t.h) * W + t.w) * C + c) * 2u) | (ok ? 0u : WG_OOB);      // tensors are below 2 GB: bit 31 = out of range
     };
     WgTrack tx, tdy[NDY];
     track_init(tx, (sa - p.HB) * 64 + xrg * 16 + (lane >> 2));
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     auto req_x = [&]() {
         const u32 off = track_off(tx, p.Cin, xc);
         wg_bload(off, rx, lds0 + XR + xsub * XSUB + (xslot * 64 + xrg * 16) * 64);
-        if (guard) wg_bload(xslot == 0 ? off : WG_OOB, rx, lds0 + (xslot == 0 ? XR + xsub * XSUB + R * 64 : DUMP + xsub * 1024));
+        if (guard) wg_bload(xslot == 0 ? off : WG_OOB, rx, lds0 + (xslot == 0 ? XR + xsub * XSUB + (R + xrg * 16) * 64 : DUMP + wave * 1024));
         track_step(tx);
         xslot = xslot + 1 == RB ? 0 : xslot + 1;
     };
@@ -171,86 +188,82 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 
     // ---- fragment addressing ----------------------------------------------------------------------------------------------------------------
     const int i16 = lane & 15, g16 = (lane >> 4) & 1, khalf = lane >> 5;
-    const u32 lp = (u32)(khalf * 8 + (i16 >> 2));                             // the lane's row inside a 16-position K-step
+    // K order of the operands: element j of lane (khalf) is position (j >> 2) 8 + khalf 4 + (j & 3) of the K-step -- NOT khalf 8 + j.  Both
+    // operands use it (any permutation of K is fine as long as A and B agree), and it makes the 64 lanes of ONE transposed read cover 8
+    // consecutive 64-byte rows = 512 contiguous bytes: with the natural order the two half-waves read rows r .. r + 3 and r + 8 .. r + 11,
+    // 512 bytes apart = the same banks, and the reads ran at half rate (r04h ablation: 4.5 cycles per read instead of 2).
+    const u32 lp = (u32)(khalf * 4 + (i16 >> 2));                             // the lane's row inside a 16-position K-step (first read; second + 8)
     const u32 cbyte = (u32)(g16 * 32 + (i16 & 3) * 8);
-    const u32 a_lane = (u32)(DYB + wm * DSUB) + lp * 64 + cbyte;              // + (slot 64 + kk 16) 64 (+ 256 for the second read)
-    const u32 x_lane = (u32)(XR + wn * XSUB) + cbyte;                         // + ring row 64 (+ 256, + 512)
+    const u32 a_lane = (u32)(DYB + wm * 2 * DSUB) + lp * 64 + cbyte;          // + cb DSUB + (slot 64 + kk 16) 64 (+ 512 for the second read)
+    const u32 x_lane = (u32)(XR + wn * XSUB) + lp * 64 + cbyte;               // + ring row 64 + kw 64 (+ 512)
 
-    wg_f32x16 acc[9];
+    wg_f32x16 acc[2][5];                                 // [32-channel block of the wave's 64 output channels][tap of the group]
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[cb][t][v] = 0.f;
 
-    wg_u32x2 fa[2][2];                                   // [register set][read]: dY^T fragment (32 channels x 16 positions)
-    wg_u32x2 fx[2][3][3];                                // [register set][filter row][read]: positions p - 1 .. p + 10 of the lane's channel
+    wg_u32x4 fa[2][2];                                   // [set][cb]: dY^T fragments (32 channels x 16 positions) of this K-step and the next
+    wg_u32x4 fx[5];                                      // X fragments of the group's taps: ONE set -- a tap's registers are refilled for
+                                                         // the next K-step as soon as its two MFMAs have issued
     // ring row of position (64 (block) - W1 - 1) of the CURRENT block, i.e. of tap (0, 0) of the block's first position
     int ubase = 64 * p.HB - W1 - 1;                      // >= 0 because 64 HB >= W + 2
     int rslot = 0;                                       // dY ring slot of the current block
-    // One K-step = 9 MFMAs on register set S while the 11 transposed reads of the NEXT K-step fill the other set, in three groups of
-    // (reads of one filter row, the row's three MFMAs): reads in one burst would queue up in front of the LDS and stall the in-order wave.
     auto read_a = [&](auto setc, const int ds, const int kk) {
         constexpr int S = decltype(setc)::value;
         const u32 a0 = a_lane + (u32)((ds * 64 + kk * 16) * 64);
         if constexpr (ABL & 2) { asm volatile("" : "+v"(fa[S][0]), "+v"(fa[S][1]) : "v"(a0)); return; }
-        fa[S][0] = wg_tr_read(ldsp, a0);
-        fa[S][1] = wg_tr_read(ldsp, a0 + 256);
-    };
-    auto read_x = [&](auto setc, const int ub, const int kk, const int kh) {
-        constexpr int S = decltype(setc)::value;
-        u32 r = (u32)(ub + kk * 16 + kh * W1) + lp;                           // < 2 R
-        const u32 rw = r - (u32)R;
-        r = rw < r ? rw : r;                                                  // unsigned: r - R wraps to a huge value when r < R
-        const u32 a = x_lane + r * 64;
-        if constexpr (ABL & 2) { asm volatile("" : "+v"(fx[S][kh][0]), "+v"(fx[S][kh][1]), "+v"(fx[S][kh][2]) : "v"(a)); return; }
-        fx[S][kh][0] = wg_tr_read(ldsp, a);
-        fx[S][kh][1] = wg_tr_read(ldsp, a + 256);
-        fx[S][kh][2] = wg_tr_read(ldsp, a + 512);
-    };
-    auto read_frags = [&](auto setc, const int ub, const int ds, const int kk) {
-        read_a(setc, ds, kk);
-        read_x(setc, ub, kk, 0); read_x(setc, ub, kk, 1); read_x(setc, ub, kk, 2);
-    };
-    auto mfma_row = [&](auto setc, const int kh) {
-        constexpr int S = decltype(setc)::value;
-        const wg_u32x4 av = {fa[S][0].x, fa[S][0].y, fa[S][1].x, fa[S][1].y};
-        const wg_bf16x8 a = __builtin_bit_cast(wg_bf16x8, av);
-        const u32 d0 = fx[S][kh][0].x, d1 = fx[S][kh][0].y, d2 = fx[S][kh][1].x, d3 = fx[S][kh][1].y, d4 = fx[S][kh][2].x;
-        const wg_u32x4 b0 = {d0, d1, d2, d3};
-        const wg_u32x4 b1 = {__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
-                             __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)};
-        const wg_u32x4 b2 = {d1, d2, d3, d4};
-        if constexpr (ABL & 8) {
-            // (keeps the operands alive: a few VALU operations instead of the three MFMAs)
-            acc[kh * 3 + 0][0] = __uint_as_float(__float_as_uint(acc[kh * 3 + 0][0]) ^ (b0.x & b0.w & av.x & av.w & 1u));
-            acc[kh * 3 + 1][0] = __uint_as_float(__float_as_uint(acc[kh * 3 + 1][0]) ^ (b1.x & b1.w & 1u));
-            acc[kh * 3 + 2][0] = __uint_as_float(__float_as_uint(acc[kh * 3 + 2][0]) ^ (b2.x & b2.w & 1u));
-        } else if constexpr (ABL & 4) {
-            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 0], 0, 0, 0);
-            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 1], 0, 0, 0);
-            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 2], 0, 0, 0);
-            asm volatile("" :: "v"(d4));
-        } else {
-        acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b0), acc[kh * 3 + 0], 0, 0, 0);
-        acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b1), acc[kh * 3 + 1], 0, 0, 0);
-        acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wg_bf16x8, b2), acc[kh * 3 + 2], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const wg_u32x2 lo = wg_tr_read(ldsp, a0 + cb * DSUB), hi = wg_tr_read(ldsp, a0 + cb * DSUB + 512);
+            fa[S][cb] = wg_u32x4{lo.x, lo.y, hi.x, hi.y};
         }
     };
-    // multiply set S, fill the other set with the fragments of K-step (ub, ds, kk)
-    auto kstep = [&](auto setc, auto nextc, const int ub, const int ds, const int kk) {
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(nextc, ds, kk);
-        read_x(nextc, ub, kk, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(setc, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_x(nextc, ub, kk, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(setc, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_x(nextc, ub, kk, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(setc, 2);
+    // the address of filter row kh of K-step (ub, kk): the row's first ring row is wrapped in SCALAR arithmetic; the lanes' rows (+ lp <= 7,
+    // + kw <= 2, + 8 for the second read) run at most 17 rows past it, into the guard rows that mirror the ring's first 32
+    auto row_addr = [&](const int ub, const int kk, const int kh) {
+        int rs = ub + kk * 16 + kh * W1;
+        rs = rs >= R ? rs - R : rs;
+        return x_lane + (u32)(rs * 64);
+    };
+    auto read_tap = [&](const int slot, const u32 a, const int kw) {
+        if constexpr (ABL & 2) { asm volatile("" : "+v"(fx[slot]) : "v"(a)); return; }
+        const wg_u32x2 lo = wg_tr_read(ldsp, a + kw * 64), hi = wg_tr_read(ldsp, a + kw * 64 + 512);
+        fx[slot] = wg_u32x4{lo.x, lo.y, hi.x, hi.y};
+    };
+    auto mfma_tap = [&](auto setc, const int slot) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if constexpr (ABL & 8) {                      // (keeps the operands alive: a VALU operation instead of the MFMA)
+                acc[cb][slot][0] = __uint_as_float(__float_as_uint(acc[cb][slot][0]) ^ (fx[slot].x & fx[slot].w & fa[S][cb].x & fa[S][cb].w & 1u));
+            } else {
+                acc[cb][slot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, fa[S][cb]), __builtin_bit_cast(wg_bf16x8, fx[slot]),
+                                                                        acc[cb][slot], 0, 0, 0);
+            }
+        }
+    };
+    // the fragments of K-step (ub, ds, kk) into A set S and fx (prologue)
+    auto read_all = [&](auto tgc, auto setc, const int ub, const int ds, const int kk) {
+        constexpr int TG = decltype(tgc)::value, T0 = TG ? 5 : 0, NT = TG ? 4 : 5;
+        read_a(setc, ds, kk);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) read_tap(j, row_addr(ub, kk, (T0 + j) / 3), (T0 + j) % 3);
+    };
+    // One K-step of tap group TG: per tap the two MFMAs of (A set S, fx[tap]), then the reads that refill fx[tap] for K-step (ub, ds, kk);
+    // the next A fragments go to the other A set.
+    auto kstep = [&](auto tgc, auto setc, auto nextc, const int ub, const int ds, const int kk) {
+        constexpr int TG = decltype(tgc)::value, T0 = TG ? 5 : 0, NT = TG ? 4 : 5;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tap(setc, j);
+            __builtin_amdgcn_sched_barrier(0);
+            read_tap(j, row_addr(ub, kk, (T0 + j) / 3), (T0 + j) % 3);
+            if (j == 1) read_a(nextc, ds, kk);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -261,35 +274,44 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
         for (int j = 0; j < 3; ++j) req_dy();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(I0{}, ubase, 0, kg * 2);
-
-        for (int t = 0; t < nst; ++t) {
-            // requests of block t + 3 (X: t + HB + 3): their ring slots were last read in block t - 1, which every wave has left
-            if constexpr (!(ABL & 1)) {
-                req_x();
-                req_dy();
+        auto blocks = [&](auto tgc) {
+            read_all(tgc, I0{}, ubase, 0, kg * 2);
+            for (int t = 0; t < nst; ++t) {
+                // requests of block t + 3 (X: t + HB + 3): their ring slots were last read before block t - 1's barrier
+                if constexpr (!(ABL & 1)) {
+                    req_x();
+                    req_dy();
+                }
+                int ubn = ubase + 64;
+                ubn = ubn >= R ? ubn - R : ubn;
+                const int dsn = (rslot + 1) & 3;
+                // The block's ONE barrier sits in front of its last K-step: that step prefetches block t + 1's first fragments, so block
+                // t + 1's data (requested during block t - 2) must have landed and be visible -- while the requests of blocks t - 1 and t
+                // may stay in flight: two blocks (~4 us) of latency cover instead of one.  After the barrier nobody reads block t's
+                // LDS data any more (the last K-step's fragments were read before it), so the next block's requests may overwrite it.
+                auto sync = [&]() {
+                    if constexpr (!(ABL & 16)) {
+                        if (guard) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((ABL & 1) ? 0 : 2 * (NDY + 2)) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((ABL & 1) ? 0 : 2 * (NDY + 1)) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                };
+                if constexpr (KS == 4) {
+                    kstep(tgc, I0{}, I1{}, ubase, rslot, 1);
+                    kstep(tgc, I1{}, I0{}, ubase, rslot, 2);
+                    kstep(tgc, I0{}, I1{}, ubase, rslot, 3);
+                    sync();
+                    kstep(tgc, I1{}, I0{}, ubn, dsn, 0);
+                } else {
+                    kstep(tgc, I0{}, I1{}, ubase, rslot, kg * 2 + 1);
+                    sync();
+                    kstep(tgc, I1{}, I0{}, ubn, dsn, kg * 2);
+                }
+                ubase = ubn;
+                rslot = dsn;
             }
-            int ubn = ubase + 64;
-            ubn = ubn >= R ? ubn - R : ubn;
-            const int dsn = (rslot + 1) & 3;
-            if constexpr (KS == 4) {
-                kstep(I0{}, I1{}, ubase, rslot, 1);
-                kstep(I1{}, I0{}, ubase, rslot, 2);
-                kstep(I0{}, I1{}, ubase, rslot, 3);
-                kstep(I1{}, I0{}, ubn, dsn, 0);                                // block t + 1 landed before the barrier that closed block t - 1
-            } else {
-                kstep(I0{}, I1{}, ubase, rslot, kg * 2 + 1);
-                kstep(I1{}, I0{}, ubn, dsn, kg * 2);
-            }
-            ubase = ubn;
-            rslot = dsn;
-            // everything requested before this block has landed (block t + 2's data); this block's requests may stay in flight
-            if constexpr (!(ABL & 16)) {
-                if (guard) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ABL & 1) ? 0 : NDY + 2) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((ABL & 1) ? 0 : NDY + 1) : "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
+        };
+        if (tg == 0) blocks(I0{}); else blocks(I1{});
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // requests still in flight write into LDS: they must not outlive the workgroup
 
@@ -297,13 +319,18 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     const int r31 = lane & 31;
     const int slot = COS == 4 ? split : split * 2 + kg;
     float* out = p.part + (size_t)slot * p.Cout * 9 * p.Cin;
+    const int t0 = tg ? 5 : 0, nt = tg ? 4 : 5;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int co = co0 + wm * 32 + 8 * (v >> 2) + 4 * khalf + (v & 3);
-            out[((size_t)co * 9 + t) * p.Cin + ci0 + wn * 32 + r31] = acc[t][v];
-        }
+        for (int j = 0; j < 5; ++j)
+            if (j < nt) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int co = co0 + wm * 64 + cb * 32 + 8 * (v >> 2) + 4 * khalf + (v & 3);
+                    out[((size_t)co * 9 + t0 + j) * p.Cin + ci0 + wn * 32 + r31] = acc[cb][j][v];
+                }
+            }
 #endif
 }
 
@@ -373,6 +400,7 @@ extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, flo
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.Q = (int)pl.Q; p.n_blocks = pl.n_blocks; p.n_ci_tiles = pl.n_ci_tiles; p.n_tiles = pl.n_tiles;
     p.blocks_per_split = pl.blocks_per_split; p.HB = pl.HB;
+    p.step_h = 64 / (W + 1); p.step_w = 64 % (W + 1);
     p.x_bytes = (int)((long long)B * H * W * Cin * 2); p.dy_bytes = (int)((long long)B * H * W * Cout * 2);
     const dim3 grid(pl.splits * pl.n_tiles), block(WG_THREADS);
     int abl = 0;
@@ -382,9 +410,7 @@ extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, flo
         switch (abl) {
             case 1: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 1>), grid, block, 0, stream, p); break;
             case 2: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 2>), grid, block, 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 4>), grid, block, 0, stream, p); break;
-            case 6: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 6>), grid, block, 0, stream, p); break;
-            case 7: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 7>), grid, block, 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 3>), grid, block, 0, stream, p); break;
             case 8: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 8>), grid, block, 0, stream, p); break;
             case 16: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 16>), grid, block, 0, stream, p); break;
             case 23: hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 23>), grid, block, 0, stream, p); break;

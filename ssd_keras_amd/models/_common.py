@@ -462,7 +462,11 @@ class SSDModel(nn.Module):
             if key != st["key"]:
                 with torch.no_grad():
                     torch._foreach_copy_(st["dst"], [t.detach() for t in src])
-                st["key"] = key
+                # Inside a stream capture the copy is only RECORDED (it runs at every replay): the shadows are not fresh for the next
+                # eager call, which must refresh them itself (tests/test_train_graph_gpu.py: the first eager step after a capture
+                # multiplied the previous step's filters, 1.3e-3 off on the loss).
+                if not torch.cuda.is_current_stream_capturing():
+                    st["key"] = key
             self.__dict__["_shadow_fresh"] = True
         i = st["index"].get(id(conv))
         if i is None:

@@ -9,8 +9,8 @@ import torch  # noqa: E402
 
 from ssd_keras_amd import _native as nat  # noqa: E402
 
-MODES = {0: "product", 1: "no requests in the loop", 2: "no fragment reads", 4: "no operand building", 6: "no reads, no operand building",
-         7: "MFMAs + barrier only", 8: "no MFMAs", 16: "no wait / barrier", 23: "MFMAs only"}
+MODES = {0: "product", 1: "no requests in the loop", 2: "no fragment reads", 3: "MFMAs + barrier only", 8: "no MFMAs", 16: "no wait / barrier",
+         23: "MFMAs only"}
 
 
 def timed(fn, reps=10):
