@@ -459,7 +459,7 @@ extern "C" int ssdhip_match_multi(const double* weight_matrix, int m, int n, dou
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!weight_matrix || !gt_idx || !anchor_idx || !count || m <= 0 || n < 0) return SSDHIP_E_BADARG;
     if (!ws || ws_bytes < ssdhip_match_multi_workspace_bytes(m, n)) return SSDHIP_E_WORKSPACE;
-    if (n == 0) return hipMemsetAsync(count, 0, sizeof(int), stream) == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    if (n == 0) return zero_async(count, sizeof(int), stream) == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
     const int tiles = (n + BX_THREADS - 1) / BX_THREADS;
     int* best_row = static_cast<int*>(ws);
     int* tile_count = reinterpret_cast<int*>(static_cast<unsigned char*>(ws) + bx_align((size_t)n * sizeof(int)));

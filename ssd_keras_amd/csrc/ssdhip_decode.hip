@@ -1440,7 +1440,7 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     u64* kept = reinterpret_cast<u64*>(base + lay.kept);
 
     if (stages & 1) {
-    if (hipMemsetAsync(cand_count, 0, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    if (zero_async(cand_count, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
 
     // K3: small tiles (<= 24 KiB of LDS) keep many workgroups in flight per CU to hide the load -> atomic -> store chain
     int TA = 256;

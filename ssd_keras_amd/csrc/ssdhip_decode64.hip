@@ -329,7 +329,7 @@ int decode64_run(int stages, const double* y_pred, int B, int N, int C, double c
     int* flat_pos = reinterpret_cast<int*>(base + lay.flat_pos);
 
     if (stages & 1) {
-        if (hipMemsetAsync(cand_count, 0, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+        if (zero_async(cand_count, (size_t)B * p.G * sizeof(int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
         hipLaunchKernelGGL(scan64_kernel, dim3((N + D64_THREADS - 1) / D64_THREADS, B), dim3(D64_THREADS), 0, stream, y_pred, p, boxes,
                            cand_score, cand_idx, cand_count, cls_map);
         if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;

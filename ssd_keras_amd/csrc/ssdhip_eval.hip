@@ -150,7 +150,7 @@ extern "C" int ssdhip_match_predictions(const float* pred, const int* pred_image
     void* tmp = base + lay.tmp;
     size_t tmp_bytes = lay.tmp_bytes;
 
-    if (hipMemsetAsync(winner, 0, (size_t)(G > 0 ? G : 1) * sizeof(u64), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    if (zero_async(winner, (size_t)(G > 0 ? G : 1) * sizeof(u64), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
     EvmParams q;
     q.P = P; q.n_images = n_images; q.G = G; q.border = border_pixels; q.thr = matching_iou_threshold;
     const int blocks = (P + EVM_THREADS - 1) / EVM_THREADS;

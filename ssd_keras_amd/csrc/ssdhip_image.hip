@@ -271,7 +271,7 @@ extern "C" int ssdhip_image_resize_u8(const void* x, void* y, int B, int H, int 
 extern "C" int ssdhip_image_hist_u8(const void* x, long long n_pixels, int C, int channel, unsigned int* hist_dev, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !hist_dev || n_pixels <= 0 || C <= 0 || channel < 0 || channel >= C) return SSDHIP_E_BADARG;
-    if (hipMemsetAsync(hist_dev, 0, 256 * sizeof(unsigned int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    if (zero_async(hist_dev, 256 * sizeof(unsigned int), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
     hipLaunchKernelGGL(hist_u8_kernel, dim3(img_blocks(n_pixels, 1024)), dim3(256), 0, stream, static_cast<const unsigned char*>(x), n_pixels, C,
                        channel, hist_dev);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;

@@ -489,7 +489,7 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     double* part = reinterpret_cast<double*>(base + lay.part);
     double* keep_part = reinterpret_cast<double*>(base + lay.keep_part);
     unsigned short* bcol = reinterpret_cast<unsigned short*>(base + lay.bcol);
-    if (hipMemsetAsync(ghist, 0, (L1_SHARDS * L1_BINS + 2 * SEL_BINS) * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins (sums are plain stores)
+    if (zero_async(ghist, (L1_SHARDS * L1_BINS + 2 * SEL_BINS) * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins (sums are plain stores)
 
     const int L = C + 12;
     const int TA = loss_tile(L);

@@ -11,6 +11,24 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 typedef unsigned __int128 u128;
 
+// Zero `bytes` (a multiple of 4) of device memory on `stream` with a plain KERNEL instead of hipMemsetAsync.  Inside a captured HIP
+// graph the runtime's memset node is not reliable on this stack (ROCm 7.2, graph packet capture on -- the default): replayed after a
+// device-wide synchronize, the second and later replays of SSDLoss saw histograms that had NOT been cleared (loss 754 instead of 18.7,
+// the same value on every replay; tools/debug_loss_graph.py, profiles/r04l_loss_graph_memset_node.txt; correct with
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE=0) -- the "diverging" graph-replayed training leg of rounds 2 and 3.  A kernel node has no such
+// problem, and is cheaper than the runtime's fill kernel (4.3 us in the step timeline).
+static __global__ void zero_words_kernel(u32* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<u32*>(p), n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // float32 exp through a fixed chain of float64 adds/multiplies (the reference decodes box
 // sizes with np.exp on float32, whose SIMD implementation is neither correctly rounded nor
