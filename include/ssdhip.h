@@ -402,6 +402,18 @@ int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* 
 int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, int pool, void* stream);
 
+/* A chain of small convolutions (+ bias + ReLU) in ONE launch, one workgroup per image, the intermediate maps in LDS: the tail of the SSD
+ * extra layers conv7_1 ... conv9_2 (models/keras_ssd300.py:304-313).  x [B, H, W, C0] bf16 NHWC; layer i: k_i x k_i, stride_i, zero padding
+ * pad_i, Cout_i, bias_i (bf16 or NULL), ReLU if relu_i != 0; y_h[i] != NULL: that layer's map is also written to y_h[i]
+ * [B, H_i, W_i, Cout_i].  All arrays are HOST arrays of n_layers (<= 8) entries; packed_h[i] = the layer's filters [Cout, k, k, Cin] bf16
+ * re-ordered by ssdhip_conv_chain_pack_weight (MFMA fragment order, same byte count: ssdhip_conv_chain_packed_bytes, 0 = unsupported).
+ * Cin_i % 128 == 0, Cout_i % 32 == 0 and one image's maps must fit the CU's LDS; SSDHIP_E_BADARG otherwise (csrc/ssdhip_chain.hip). */
+size_t ssdhip_conv_chain_packed_bytes(int k, int Cin, int Cout);
+int ssdhip_conv_chain_pack_weight(const void* weight, void* packed, int k, int Cin, int Cout, void* stream);
+int ssdhip_conv_chain_nhwc_bf16(const void* x, int B, int H, int W, int C0, int n_layers, const void* const* packed_h,
+                                const void* const* bias_h, void* const* y_h, const int* k_h, const int* stride_h, const int* pad_h,
+                                const int* cout_h, const int* relu_h, void* stream);
+
 /* Weight gradient of a 3x3 'same' stride-1 dilation-1 convolution of the training graph -- what the TensorFlow graph behind
  * model.fit_generator computes for every Conv2D of models/keras_ssd300.py:274-296 (ssd300_training.ipynb:171-173):
  *     dw[co][kh][kw][ci] = sum_{b,h,w} dy[b,h,w,co] * x[b, h + kh - 1, w + kw - 1, ci]      (zero padding)

@@ -566,6 +566,70 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
+def conv_chain_pack(weight):
+    """[Cout, Cin, k, k] bfloat16 (channels_last) filters in the fragment order `conv_chain` streams; None if the geometry is not supported."""
+    torch = _torch()
+    lib = load()
+    _bind_chain(lib)
+    cout, cin, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or kh != kw:
+        raise SsdHipError("weight must be bfloat16 (Cout, Cin, k, k)")
+    n = int(lib.ssdhip_conv_chain_packed_bytes(kh, cin, cout))
+    if n == 0:
+        return None
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    packed = torch.empty((n,), dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        check(lib.ssdhip_conv_chain_pack_weight(_ptr(wt), _ptr(packed), kh, cin, cout, current_stream_ptr(weight.device)), "ssdhip_conv_chain_pack_weight")
+    return packed
+
+
+def _bind_chain(lib):
+    if not getattr(lib, "_chain_bound", False):
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.ssdhip_conv_chain_packed_bytes.restype = ctypes.c_size_t
+        lib.ssdhip_conv_chain_packed_bytes.argtypes = [ci, ci, ci]
+        lib.ssdhip_conv_chain_pack_weight.restype = ci
+        lib.ssdhip_conv_chain_pack_weight.argtypes = [vp, vp, ci, ci, ci, vp]
+        lib.ssdhip_conv_chain_nhwc_bf16.restype = ci
+        lib.ssdhip_conv_chain_nhwc_bf16.argtypes = [vp, ci, ci, ci, ci, ci] + [vp] * 8 + [vp]
+        lib._chain_bound = True
+
+
+def conv_chain(x, layers):
+    """A chain of small convolutions in one launch (csrc/ssdhip_chain.hip).  x (B, C0, H, W) bfloat16 channels_last; `layers`: a list of
+    dicts {packed, bias (bfloat16 or None), k, stride, pad, cout, relu, keep}; returns the list of the kept layers' outputs
+    (B, Cout, Ho, Wo) channels_last, or None when the chain does not fit (the caller runs the layers one by one)."""
+    torch = _torch()
+    lib = load()
+    _bind_chain(lib)
+    x, (b, h, w, c0) = _nhwc_bf16(x, "x")
+    n = len(layers)
+    outs, ys = [], []
+    hh, ww = h, w
+    for l in layers:
+        hh = (hh + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        ww = (ww + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        if hh < 1 or ww < 1:
+            return None
+        if l.get("keep", False):
+            y = torch.empty((b, hh, ww, l["cout"]), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+            outs.append(y)
+            ys.append(y)
+        else:
+            ys.append(None)
+    parr = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    iarr = lambda key: (ctypes.c_int * n)(*[int(l[key]) for l in layers])
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv_chain_nhwc_bf16(_ptr(x), b, h, w, c0, n, parr([l["packed"] for l in layers]), parr([l.get("bias") for l in layers]),
+                                             parr(ys), iarr("k"), iarr("stride"), iarr("pad"), iarr("cout"), iarr("relu"),
+                                             current_stream_ptr(x.device))
+    if rc == -1:                                          # SSDHIP_E_BADARG: the chain does not fit this kernel
+        return None
+    check(rc, "ssdhip_conv_chain_nhwc_bf16")
+    return outs
+
+
 def conv3x3_wgrad(x, dy):
     """Weight gradient of a 3x3 'same' stride-1 convolution (csrc/ssdhip_wgrad.hip): x (B, Cin, H, W) and dy (B, Cout, H, W) bfloat16
     channels_last -> float32 (Cout, Cin, 3, 3) in channels_last memory format ([Cout, 3, 3, Cin] physical), or None when the

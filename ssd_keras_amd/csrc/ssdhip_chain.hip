@@ -1,0 +1,250 @@
+// ssdhip_chain.hip -- a CHAIN of small convolutions (+ bias + ReLU) in ONE launch, one workgroup per image, every intermediate map in LDS:
+// the tail of the SSD extra layers, conv7_1 -> conv7_2 -> conv8_1 -> conv8_2 -> conv9_1 -> conv9_2 (models/keras_ssd300.py:304-313:
+// 1x1 reduce + 3x3 stride-2 / 'valid' pairs on maps of 10 x 10 pixels and below), gfx950, bf16 NHWC, float32 accumulation.
+//
+// Why.  At batch 32 these six layers are 25 / 9 / 1 pixels per image: as separate launches each is a handful of tiles walking a K loop
+// of 16-72 steps -- pure latency (split-K + reduce: twelve launches, ~85 us of a 2.3 ms step, the matrix pipe busy 6 % of it).  But a
+// whole image's chain fits one CU: the 10 x 10 x 512 input is 102 KB, every later map is below 26 KB.  So one workgroup per image loads
+// the input map once, runs the six layers back to back out of LDS (ping-pong buffers, a barrier between layers) and writes only the three
+// maps the predictor heads read.  What remains is streaming 2 MB of filters from L2 per workgroup:
+//   * filters are PRE-PACKED in MFMA fragment order (ssdhip_conv_chain_pack_weight, once per set of weights): fragment (32-channel
+//     block, tap, 16-channel block) is 1 KiB contiguous, lane L's 16 bytes at offset 16 L -- a wave reads it with ONE fully coalesced
+//     global_load_dwordx4 straight into the MFMA operand registers, no LDS round trip;
+//   * every wave keeps eight fragments in flight (a register ring) -- the K loops are latency chains, this is what hides L2;
+//   * the pixel operand comes from the LDS map by per-lane row addresses (tap displacement, stride, zero row for padding): im2col on
+//     the fly, rows padded by 16 bytes so that 32 pixels do not hit one bank group.
+// GEMM view as everywhere in libssdhip: MFMA 'A' = filters (row = output channel), 'B' = pixels; K order = taps outer, channels inner.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short bf16_t;
+typedef __bf16 cc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float cc_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 cc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cc_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CC_MAX_LAYERS = 8;
+constexpr int CC_THREADS = 512;
+constexpr int CC_LDS = 156 * 1024;
+constexpr int CC_PF = 8;                                 // filter fragments a wave keeps in flight
+
+struct ChainLayerDev {
+    const uint4* wp;             // packed filters: [Cout / 32][k k][Cin / 16][64 lanes] x 16 bytes
+    const bf16_t* bias;          // [Cout] or null
+    bf16_t* y;                   // [B, Hout, Wout, Cout] or null (the map stays in LDS only)
+    int k, stride, pad, Cin, Cout, relu;
+    int Hin, Win, Hout, Wout;
+    int in_off, out_off;         // LDS byte offsets of the input / output map ([pixel][C] rows of C 2 + 16 bytes)
+};
+struct ChainParams {
+    const bf16_t* x;             // [B, H, W, C0]
+    int n_layers, zero_off;      // zero_off: LDS offset of a row of zeros (padding taps)
+    ChainLayerDev L[CC_MAX_LAYERS];
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u32 cc_pack2(float a, float b) {
+    const cc_f32x2 v = {a, b};
+    return __builtin_bit_cast(u32, __builtin_convertvector(v, cc_bf16x2));
+}
+#endif
+
+__global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[CC_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int b = (int)blockIdx.x;
+
+    // ---- the image's input map -> LDS (16-byte chunks, coalesced), the zero row ------------------------------------------------------------
+    {
+        const ChainLayerDev& l0 = p.L[0];
+        const int cpr = l0.Cin / 8, n = l0.Hin * l0.Win * cpr, stride = l0.Cin * 2 + 16;
+        const uint4* src = reinterpret_cast<const uint4*>(p.x + (size_t)b * l0.Hin * l0.Win * l0.Cin);
+        for (int i = tid; i < n; i += CC_THREADS) {
+            const int pix = i / cpr, c = i - pix * cpr;
+            *reinterpret_cast<uint4*>(lds + l0.in_off + pix * stride + c * 16) = src[i];
+        }
+        for (int i = tid; i < 66; i += CC_THREADS) *reinterpret_cast<uint4*>(lds + p.zero_off + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+
+    for (int li = 0; li < p.n_layers; ++li) {
+        const ChainLayerDev& l = p.L[li];
+        const int c16n = l.Cin >> 4;                     // 16-channel blocks per tap (a multiple of 8)
+        const int taps = l.k * l.k, kt = taps * c16n;    // K-steps of 16
+        const int bpt = c16n >> 3;                       // blocks of eight K-steps per tap
+        const int nblk = l.Cout >> 5, npix = l.Hout * l.Wout, mblk = (npix + 31) >> 5;
+        const int in_stride = l.Cin * 2 + 16, out_stride = l.Cout * 2 + 16;
+        for (int t = wave; t < nblk * mblk; t += CC_THREADS / 64) {      // wave-uniform: a tile = 32 output channels x 32 pixels
+            const int nb = t % nblk, mb = t / nblk;
+            const int pix = mb * 32 + r31;
+            const bool live = pix < npix;
+            const int ho = live ? pix / l.Wout : 0, wo = live ? pix - ho * l.Wout : 0;
+            const int hi0 = ho * l.stride - l.pad, wi0 = wo * l.stride - l.pad;
+            const uint4* wsrc = l.wp + (size_t)nb * kt * 64 + lane;
+            cc_f32x16 acc, acc1;                          // even / odd K-steps: two dependency chains through the matrix pipe instead of one
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { acc[v] = 0.f; acc1[v] = 0.f; }
+            uint4 ring[CC_PF];
+#pragma unroll
+            for (int j = 0; j < CC_PF; ++j) ring[j] = wsrc[(size_t)j * 64];
+            // the pixel operands of a block of eight K-steps (one tap, 128 channels) are read from LDS a whole block AHEAD, into the
+            // other half of `bq`: read right before their MFMA, every step waited out an LDS round trip (r04o: 417 cycles per step)
+            uint4 bq[2][CC_PF];
+            auto brow_of = [&](const int kb) {
+                const int tap = (kb >> 3) / bpt, cb = (kb >> 3) - tap * bpt;
+                const int kh = tap / l.k, kw = tap - kh * l.k;
+                const int hi = hi0 + kh, wi = wi0 + kw;
+                const bool ok = live & ((unsigned)hi < (unsigned)l.Hin) & ((unsigned)wi < (unsigned)l.Win) & (kb < kt);
+                // a padding tap (or a lane without a pixel) reads the row of zeros, eight times the same 16 bytes
+                return ok ? l.in_off + (hi * l.Win + wi) * in_stride + cb * 256 + khalf * 16 : -(p.zero_off + khalf * 16);
+            };
+            auto read_block = [&](auto hc, const int kb) {
+                constexpr int HB = decltype(hc)::value;
+                const int a = brow_of(kb);
+                const unsigned char* brow = lds + (a < 0 ? -a : a);
+                const int step = a < 0 ? 0 : 32;
+#pragma unroll
+                for (int j = 0; j < CC_PF; ++j) bq[HB][j] = *reinterpret_cast<const uint4*>(brow + j * step);
+            };
+            auto mul_block = [&](auto hc, const int kb) {
+                constexpr int HB = decltype(hc)::value;
+#pragma unroll
+                for (int j = 0; j < CC_PF; ++j) {
+                    const uint4 a = ring[j];
+                    // (unconditional, the index clamped: a conditional load makes the compiler wait for ALL loads in flight at every
+                    // step -- vmcnt(0) -- and the ring hides nothing)
+                    const int kn = kb + CC_PF + j;
+                    ring[j] = wsrc[(size_t)(kn < kt ? kn : kt - 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);    // the refill is issued HERE, eight steps ahead of its use, not batched at the block's end
+                    if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cc_bf16x8, a), __builtin_bit_cast(cc_bf16x8, bq[HB][j]), acc1, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cc_bf16x8, a), __builtin_bit_cast(cc_bf16x8, bq[HB][j]), acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
+            read_block(H0{}, 0);
+            for (int kb = 0; kb < kt; kb += 2 * CC_PF) {                     // kt / 8 may be odd: the second half then multiplies nothing
+                read_block(H1{}, kb + CC_PF);
+                mul_block(H0{}, kb);
+                if (kb + CC_PF < kt) {
+                    read_block(H0{}, kb + 2 * CC_PF);
+                    mul_block(H1{}, kb + CC_PF);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] += acc1[v];
+            // bias + ReLU + one rounding; the lane holds 16 channels (four runs of four) of ONE pixel
+            if (live) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = nb * 32 + 8 * g + 4 * khalf;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[4 * g + e];
+                        if (l.bias) v += __uint_as_float((u32)l.bias[c + e] << 16);
+                        o[e] = l.relu ? (v <= 0.f ? 0.f : v) : v;
+                    }
+                    const uint2 pk = make_uint2(cc_pack2(o[0], o[1]), cc_pack2(o[2], o[3]));
+                    *reinterpret_cast<uint2*>(lds + l.out_off + pix * out_stride + c * 2) = pk;
+                    if (l.y) *reinterpret_cast<uint2*>(l.y + ((size_t)b * npix + pix) * l.Cout + c) = pk;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+// packed[((nb T + tap) (Cin / 16) + c16) 64 + lane] (16 bytes) = w[nb 32 + (lane & 31)][tap][c16 16 + (lane >> 5) 8 .. + 7]
+__global__ __launch_bounds__(256) void chain_pack_kernel(const uint4* __restrict__ w, uint4* __restrict__ packed, int taps, int Cin, int Cout) {
+    const int c16n = Cin >> 4;
+    const size_t n = (size_t)(Cout >> 5) * taps * c16n * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        size_t r = i >> 6;
+        const int c16 = (int)(r % c16n); r /= c16n;
+        const int tap = (int)(r % taps);
+        const int nb = (int)(r / taps);
+        const int co = nb * 32 + (lane & 31);
+        packed[i] = w[((size_t)co * taps + tap) * (Cin >> 3) + c16 * 2 + (lane >> 5)];
+    }
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+extern "C" size_t ssdhip_conv_chain_packed_bytes(int k, int Cin, int Cout) {
+    if (k <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 128) || (Cout % 32)) return 0;
+    return (size_t)Cout * k * k * Cin * 2;
+}
+
+// weight [Cout, k, k, Cin] bf16 -> the fragment order conv_chain_kernel streams (same byte count)
+extern "C" int ssdhip_conv_chain_pack_weight(const void* weight, void* packed, int k, int Cin, int Cout, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!weight || !packed || !ssdhip_conv_chain_packed_bytes(k, Cin, Cout)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)weight | (uintptr_t)packed) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(256), dim3(256), 0, stream, static_cast<const uint4*>(weight), static_cast<uint4*>(packed), k * k, Cin,
+                       Cout);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// n_layers (<= 8) convolutions applied one after the other to x [B, H, W, C0] (bf16 NHWC), layer i: k_i x k_i, stride_i, zero padding
+// pad_i, bias, ReLU if relu_i; y_i [B, H_i, W_i, Cout_i] is written for the layers whose y_h[i] is not null (the others exist in LDS only).
+// Arrays are HOST arrays.  packed_h[i] from ssdhip_conv_chain_pack_weight.  Cin_i % 128 == 0, Cout_i % 32 == 0, and the maps of one
+// image must fit the CU's LDS (SSDHIP_E_BADARG otherwise; callers fall back to one launch per layer).
+extern "C" int ssdhip_conv_chain_nhwc_bf16(const void* x, int B, int H, int W, int C0, int n_layers, const void* const* packed_h,
+                                           const void* const* bias_h, void* const* y_h, const int* k_h, const int* stride_h, const int* pad_h,
+                                           const int* cout_h, const int* relu_h, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || B <= 0 || H <= 0 || W <= 0 || n_layers < 1 || n_layers > CC_MAX_LAYERS || !packed_h || !y_h || !k_h || !stride_h || !pad_h || !cout_h)
+        return SSDHIP_E_BADARG;
+    ChainParams p;
+    p.x = static_cast<const bf16_t*>(x);
+    p.n_layers = n_layers;
+    int h = H, w = W, c = C0;
+    // ping-pong: even layers read buffer 0 and write buffer 1, odd layers the other way round; buffer sizes = the largest map placed there
+    size_t need[2] = {0, 0};
+    int hs[CC_MAX_LAYERS + 1], wsz[CC_MAX_LAYERS + 1], cs[CC_MAX_LAYERS + 1];
+    hs[0] = h; wsz[0] = w; cs[0] = c;
+    for (int i = 0; i < n_layers; ++i) {
+        const int k = k_h[i], s = stride_h[i], pd = pad_h[i], co = cout_h[i];
+        if (k < 1 || k > 7 || s < 1 || pd < 0 || !ssdhip_conv_chain_packed_bytes(k, c, co) || !packed_h[i]) return SSDHIP_E_BADARG;
+        if (h + 2 * pd < k || w + 2 * pd < k) return SSDHIP_E_BADARG;
+        if (((uintptr_t)packed_h[i] & 15) || (bias_h && bias_h[i] && ((uintptr_t)bias_h[i] & 1)) || (y_h[i] && ((uintptr_t)y_h[i] & 7))) return SSDHIP_E_BADARG;
+        h = (h + 2 * pd - k) / s + 1; w = (w + 2 * pd - k) / s + 1; c = co;
+        hs[i + 1] = h; wsz[i + 1] = w; cs[i + 1] = c;
+    }
+    for (int i = 0; i <= n_layers; ++i) {
+        const size_t bytes = (size_t)hs[i] * wsz[i] * (cs[i] * 2 + 16);
+        if (bytes > need[i & 1]) need[i & 1] = bytes;
+    }
+    const size_t off1 = (need[0] + 15) / 16 * 16, zoff = off1 + (need[1] + 15) / 16 * 16;
+    if (zoff + 66 * 16 > (size_t)CC_LDS) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x & 15) || (C0 % 8)) return SSDHIP_E_BADARG;
+    p.zero_off = (int)zoff;
+    for (int i = 0; i < n_layers; ++i) {
+        ChainLayerDev& l = p.L[i];
+        l.wp = static_cast<const uint4*>(packed_h[i]);
+        l.bias = bias_h ? static_cast<const bf16_t*>(bias_h[i]) : nullptr;
+        l.y = static_cast<bf16_t*>(y_h[i]);
+        l.k = k_h[i]; l.stride = stride_h[i]; l.pad = pad_h[i]; l.Cin = cs[i]; l.Cout = cs[i + 1]; l.relu = relu_h ? relu_h[i] : 1;
+        l.Hin = hs[i]; l.Win = wsz[i]; l.Hout = hs[i + 1]; l.Wout = wsz[i + 1];
+        l.in_off = (i & 1) ? (int)off1 : 0;
+        l.out_off = (i & 1) ? 0 : (int)off1;
+    }
+    for (int i = n_layers; i < CC_MAX_LAYERS; ++i) p.L[i] = p.L[0];
+    hipLaunchKernelGGL(conv_chain_kernel, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

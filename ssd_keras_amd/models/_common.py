@@ -7,6 +7,8 @@ constant, softmax, the `(B, N, C+12)` prediction layout and the optional decode 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -208,7 +210,7 @@ class GraphedInference:
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         had = model.__dict__.get("_head_overlap")
-        model.__dict__["_head_overlap"] = "3"             # two streams inside the graph: explicit dependencies, no allocator subtleties
+        model.__dict__["_head_overlap"] = os.environ.get("SSDHIP_GRAPH_HEAD_OVERLAP", "3")   # two streams inside the graph: explicit dependencies, no allocator subtleties
         try:
             with torch.cuda.stream(self.stream), torch.no_grad():
                 for _ in range(max(1, warmup)):
@@ -701,7 +703,7 @@ class SSDModel(nn.Module):
         if not all(self._fused_head_ok(f, ch) and self._packed_head_ok(ch, lh, f)
                    for f, ch, lh in zip(early, self.conf_heads, self.loc_heads)):
             raise RuntimeError("predictor heads of the trunk do not qualify for the packed kernel")
-        if mode == "3" and not self._halo_heads_ok(early):
+        if mode in ("3", "4") and not self._halo_heads_ok(early):
             mode = "1"
         main = torch.cuda.current_stream(x.device)
         side = self.__dict__.get("_side_stream")
@@ -717,7 +719,26 @@ class SSDModel(nn.Module):
 
         # No record_stream anywhere: every tensor the other stream touches outlives the join in program order, and a block of the
         # side stream's pool is only reused after that stream has waited for the current one again.
-        if mode == "3":
+        if mode == "4" and hasattr(self, "extra_features_front") and hasattr(self, "extra_features_tail"):
+            # Round 4: the tail of the extra layers is ONE launch on one CU per image (csrc/ssdhip_chain.hip: 32 CUs, ~55 us), so the
+            # balance moved: first the front of the extra layers (conv6_1, conv6_2: split-K launches that want the whole chip), THEN
+            # the two trunk heads on the second stream capped so that one CU per image stays free, beside the tail and the small heads
+            front = self.extra_features_front(early[1])
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                big = nat.conv3x3_halo_group(list(early), [self._packed_head_weight(l, 128) for l in range(n_early)], None, relu=False,
+                                             max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "216")))
+            rest = self.extra_features_tail(front)
+            check_rest(rest)
+            if self._halo_heads_ok(rest):
+                small = nat.conv3x3_halo_group(list(rest), [self._packed_head_weight(n_early + l, 128) for l in range(len(rest))], None,
+                                               relu=False)
+            else:
+                small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None,
+                                              relu=False)
+            main.wait_stream(side)
+            return early + rest, big + small
+        if mode in ("3", "4"):
             # the two trunk heads as a grouped slab launch capped at HALF the CUs (persistent workgroups, one per CU) on the second
             # stream, the latency-bound chain of extra layers on the current one in the other half, then the four small heads
             side.wait_stream(main)

@@ -8,7 +8,10 @@ reference so ported weights can be loaded by name.
 from __future__ import annotations
 
 import numpy as np
+import torch
 from torch import nn
+
+from .. import _native as nat
 
 from ..keras_layers.keras_layer_L2Normalization import L2Normalization
 from ._common import SSDModel, conv_out, he_normal_, make_priorboxes, pool_out, resolve_anchor_config
@@ -84,12 +87,49 @@ class SSD300(_VGGBase):
         return [self.conv4_3_norm(conv4_3), fc7]
 
     def extra_features(self, fc7):
+        return self.extra_features_tail(self.extra_features_front(fc7))
+
+    def extra_features_front(self, fc7):
+        """conv6_1 -> conv6_2: the part of the extra layers that still wants the whole chip (split-K launches)."""
+        return self.conv_act(self.conv6_2, self.conv_act(self.conv6_1, fc7))
+
+    def extra_features_tail(self, conv6_2):
+        """conv7_1 ... conv9_2 from conv6_2; returns [conv6_2, conv7_2, conv8_2, conv9_2]."""
         ca = self.conv_act
-        conv6_2 = ca(self.conv6_2, ca(self.conv6_1, fc7))
+        tail = self._extras_tail_chain(conv6_2)
+        if tail is not None:
+            return [conv6_2] + tail
         conv7_2 = ca(self.conv7_2, ca(self.conv7_1, conv6_2))
         conv8_2 = ca(self.conv8_2, ca(self.conv8_1, conv7_2))
         conv9_2 = ca(self.conv9_2, ca(self.conv9_1, conv8_2))
         return [conv6_2, conv7_2, conv8_2, conv9_2]
+
+    def _extras_tail_chain(self, conv6_2):
+        """conv7_1 ... conv9_2 (reference models/keras_ssd300.py:304-313) as ONE launch, one workgroup per image, the intermediate maps in
+        LDS (csrc/ssdhip_chain.hip) on the fused bf16 inference path; None -> the caller runs the six layers one by one.  The filters are
+        re-packed in MFMA fragment order once per set of weights (keyed on the parameters' versions)."""
+        import os
+        if not self._fused(conv6_2) or os.environ.get("SSDHIP_NO_CHAIN", "0") == "1":
+            return None
+        convs = [self.conv7_1, self.conv7_2, self.conv8_1, self.conv8_2, self.conv9_1, self.conv9_2]
+        key = tuple((id(c.weight), c.weight.data_ptr(), c.weight._version, c.bias.data_ptr(), c.bias._version) for c in convs) + (str(conv6_2.device),)
+        st = self.__dict__.get("_tail_chain")
+        if st is None or st["key"] != key:
+            layers = []
+            with torch.no_grad():
+                for i, c in enumerate(convs):
+                    wb = c.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                    packed = nat.conv_chain_pack(wb)
+                    if packed is None:
+                        layers = None
+                        break
+                    layers.append(dict(packed=packed, bias=c.bias.detach().to(torch.bfloat16), k=c.kernel_size[0], stride=c.stride[0],
+                                       pad=c.padding[0], cout=c.out_channels, relu=1, keep=bool(i & 1)))
+            st = {"key": key, "layers": layers}
+            self.__dict__["_tail_chain"] = st
+        if st["layers"] is None:
+            return None
+        return nat.conv_chain(conv6_2, st["layers"])
 
     def features(self, x):
         early = self.trunk_features(x)

@@ -466,3 +466,77 @@ def test_slab_conv_strided_and_valid_forms(case):
         got = nat.conv2d(x, wt, bias, stride=stride, padding=pad, relu=True, variant=7)
         assert got.shape == base.shape
         assert torch.equal(got.view(torch.int16), base.view(torch.int16))
+
+
+CHAIN_CASES = [  # B, H, W, C0, [(k, stride, pad, cout, relu, keep), ...]
+    (3, 10, 10, 512, [(1, 1, 0, 128, 1, 0), (3, 2, 1, 256, 1, 1), (1, 1, 0, 128, 1, 0), (3, 1, 0, 256, 1, 1), (1, 1, 0, 128, 1, 0),
+                      (3, 1, 0, 256, 1, 1)]),                               # the SSD300 tail: conv7_1 ... conv9_2
+    (2, 7, 5, 128, [(3, 1, 1, 128, 0, 1), (1, 1, 0, 96, 1, 1)]),             # 'same' padding, no ReLU, 96 output channels, every map kept
+    (1, 4, 4, 256, [(3, 2, 1, 32, 1, 1)]),                                   # one layer
+]
+
+
+@pytest.mark.parametrize("case", CHAIN_CASES)
+def test_conv_chain_matches_layer_by_layer_reference(case):
+    """ssdhip_conv_chain_nhwc_bf16 (csrc/ssdhip_chain.hip: the extra-layer tail of models/keras_ssd300.py:304-313 in one launch, the
+    intermediate maps in LDS) against a float32 PyTorch chain that rounds every layer's output to bf16 like the kernel does: within one
+    bf16 rounding of the float32-accumulated sums per layer (2^-7 |want| + 1e-2 rms on every kept map), and bit-identical run to run."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, C0, spec = case
+    g = torch.Generator(device="cuda").manual_seed(hash(str(case)) & 0xffff)
+    x = torch.randn((B, H, W, C0), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    layers, ref, cin, want = [], x.float(), C0, []
+    for (k, s, pd, cout, relu, keep) in spec:
+        w = (torch.randn((cout, k, k, cin), generator=g, device="cuda") / (k * k * cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+        bias = torch.randn((cout,), generator=g, device="cuda").to(torch.bfloat16)
+        packed = nat.conv_chain_pack(w)
+        assert packed is not None
+        layers.append(dict(packed=packed, bias=bias, k=k, stride=s, pad=pd, cout=cout, relu=relu, keep=bool(keep)))
+        ref = F.conv2d(ref, w.float(), bias.float(), s, pd)
+        if relu:
+            ref = torch.relu(ref)
+        if keep:
+            want.append(ref)
+        ref = ref.to(torch.bfloat16).float()              # the next layer reads the rounded map
+        cin = cout
+    got = nat.conv_chain(x, layers)
+    assert got is not None and len(got) == len(want)
+    for y, wnt in zip(got, want):
+        assert y.shape == wnt.shape and y.dtype == torch.bfloat16
+        rms = wnt.pow(2).mean().sqrt().item()
+        err = (y.float() - wnt).abs()
+        assert int((err > wnt.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
+    again = nat.conv_chain(x, layers)
+    for a, y in zip(again, got):
+        assert torch.equal(a.view(torch.int16), y.view(torch.int16))
+
+
+def test_conv_chain_in_the_ssd300_model_equals_the_layer_by_layer_path():
+    """the graphed inference model with and without the chain kernel (SSDHIP_NO_CHAIN=1): same detections up to bf16 rounding of the
+    extra-layer maps (the chain sums a tile's K loop in two interleaved accumulators, the split-K kernels in ranges)."""
+    import os
+    import numpy as np
+    import torch
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(5)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"], aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"],
+                    steps=cfg["steps"], offsets=cfg["offsets"]).cuda().to(torch.bfloat16).to(memory_format=torch.channels_last).eval()
+    images = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(4, 300, 300, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        x = model.preprocess(images)
+        feats = model.features(x)
+        os.environ["SSDHIP_NO_CHAIN"] = "1"
+        try:
+            base = model.features(x)
+        finally:
+            os.environ.pop("SSDHIP_NO_CHAIN", None)
+    assert len(feats) == len(base) == 6
+    for a, b in zip(feats[:3], base[:3]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for a, b in zip(feats[3:], base[3:]):
+        rms = b.float().pow(2).mean().sqrt().item()
+        assert float((a.float() - b.float()).abs().max()) <= 3e-2 * rms + 2.0 ** -6 * float(b.float().abs().max())
