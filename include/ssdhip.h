@@ -452,6 +452,15 @@ int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, const void* b1,
 int ssdhip_conv3x3_cin3_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, void* stream);
 
+/* The geometric half of SSDDataAugmentation (data_generator/data_augmentation_chain_original_ssd.py:208-280: expansion -> random crop ->
+ * random flip -> resize with a random interpolation mode) for a whole batch in ONE launch: x [B, H, W, C] uint8 (device), y [B, Ho, Wo, C];
+ * per image its own tap tables ix / wx [B][Wo][nx], iy / wy [B][Ho][ny]: the taps of cv2.resize on that image's patch, composed on the
+ * host with its expansion / crop / flip index maps -- an index addresses a column / row of the ORIGINAL image, -1 = background
+ * (background [B][C] uint8).  Arithmetic of ssdhip_image_resize_u8. */
+int ssdhip_image_resize_gather_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, const int* ix_dev,
+                                  const double* wx_dev, int nx, const int* iy_dev, const double* wy_dev, int ny,
+                                  const void* background_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Image half of the training-time augmentation (csrc/ssdhip_image.hip): what the reference does per image on the host
  * through OpenCV (data_generator/object_detection_2d_photometric_ops.py:23-480, object_detection_2d_geometric_ops.py:27-148), for a

@@ -1314,6 +1314,37 @@ def image_resize_u8(images, out_h, out_w, ix, wx, iy, wy):
     return out
 
 
+def image_resize_gather_u8(images, out_h, out_w, ix, wx, iy, wy, background):
+    """ssdhip_image_resize_gather_u8: images (B, H, W, C) CUDA uint8; per-image tap tables ix / wx (B, out_w, nx), iy / wy (B, out_h, ny)
+    (index -1 = background), background (B, C) uint8.  Returns the (B, out_h, out_w, C) uint8 batch."""
+    torch = _torch()
+    lib = _image_lib()
+    if not getattr(lib, "_gather_bound", False):
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.ssdhip_image_resize_gather_u8.restype = ci
+        lib.ssdhip_image_resize_gather_u8.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, ci, vp, vp, ci, vp, vp]
+        lib._gather_bound = True
+    require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 4 or not images.is_contiguous():
+        raise SsdHipError("images must be a contiguous (B, H, W, C) uint8 tensor")
+    b, h, w, c = images.shape
+    dev = images.device
+    ix = to_device(ix, device=dev, dtype=torch.int32).contiguous()
+    wx = to_device(wx, device=dev, dtype=torch.float64).contiguous()
+    iy = to_device(iy, device=dev, dtype=torch.int32).contiguous()
+    wy = to_device(wy, device=dev, dtype=torch.float64).contiguous()
+    bg = to_device(background, device=dev, dtype=torch.uint8).contiguous()
+    if (ix.shape != wx.shape or iy.shape != wy.shape or tuple(ix.shape[:2]) != (b, out_w) or tuple(iy.shape[:2]) != (b, out_h)
+            or tuple(bg.shape) != (b, c)):
+        raise SsdHipError("tap tables must be (B, out_w, nx) / (B, out_h, ny), background (B, C)")
+    out = torch.empty((b, out_h, out_w, c), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_image_resize_gather_u8(_ptr(images), _ptr(out), b, h, w, out_h, out_w, c, _ptr(ix), _ptr(wx), int(ix.shape[2]), _ptr(iy),
+                                               _ptr(wy), int(iy.shape[2]), _ptr(bg), current_stream_ptr(dev))
+    check(rc, "ssdhip_image_resize_gather_u8")
+    return out
+
+
 def image_hist_u8(image, channel):
     """256-bin histogram (CUDA int64 tensor) of one channel of an (..., C) uint8 CUDA image."""
     torch = _torch()

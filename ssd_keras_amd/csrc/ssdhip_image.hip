@@ -52,12 +52,14 @@ __device__ __forceinline__ int img_div_table(int numerator_shifted, int i, int s
     return q;
 }
 
-__device__ __forceinline__ void img_rgb2hsv_u8(double (&c)[3]) {
+// sdiv / hdiv: OpenCV's two 256-entry division tables (saturate_cast<int>((255 << 12) / v), ((180 << 12) / (6 diff))) in LDS, or null:
+// the entries computed on the spot (two integer divisions per pixel -- what the first version did for every pixel)
+__device__ __forceinline__ void img_rgb2hsv_u8(double (&c)[3], const int* sdiv = nullptr, const int* hdiv = nullptr) {
     const int r = (int)c[0], g = (int)c[1], b = (int)c[2];
     const int v = max(max(r, g), b), vmin = min(min(r, g), b), diff = v - vmin;
-    const int s = (diff * img_div_table(255 << 12, v, 1) + (1 << 11)) >> 12;
+    const int s = (diff * (sdiv ? sdiv[v] : img_div_table(255 << 12, v, 1)) + (1 << 11)) >> 12;
     int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
-    h = (h * img_div_table(180 << 12, diff, 6) + (1 << 11)) >> 12;
+    h = (h * (hdiv ? hdiv[diff] : img_div_table(180 << 12, diff, 6)) + (1 << 11)) >> 12;
     if (h < 0) h += 180;
     c[0] = (double)min(max(h, 0), 255); c[1] = (double)s; c[2] = (double)v;
 }
@@ -91,6 +93,77 @@ __device__ __forceinline__ void img_rgb2hsv_f32(double (&c)[3]) {
     c[0] = (double)h; c[1] = (double)s; c[2] = (double)v;
 }
 
+// One program step on N pixels (the same step for all of them: a program is per image).  `tag` = the dtype the reference's array has at
+// this point of the chain; arithmetic per dtype as NumPy / OpenCV do it (see the file header).
+template <int N>
+__device__ __forceinline__ void img_apply(double (&px)[N][3], int& tag, const int o, const double a, const int* sdiv, const int* hdiv) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        double (&c)[3] = px[n];
+        if (o == OP_TO_F32) {
+            if (tag == IMG_F64) { c[0] = (double)(float)c[0]; c[1] = (double)(float)c[1]; c[2] = (double)(float)c[2]; }
+        } else if (o == OP_TO_U8) {                                  // np.round(image, 0).astype(uint8)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) c[q] = img_clip255(tag == IMG_F32 ? (double)rintf((float)c[q]) : rint(c[q]));
+        } else if (o == OP_BRIGHTNESS) {                             // np.clip(image + delta, 0, 255)
+            if (tag == IMG_F32) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = (double)img_clip255f((float)c[q] + (float)a);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = img_clip255(c[q] + a);
+            }
+        } else if (o == OP_CONTRAST) {                               // np.clip(127.5 + factor * (image - 127.5), 0, 255)
+            if (tag == IMG_F32) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = (double)img_clip255f(127.5f + (float)a * ((float)c[q] - 127.5f));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = img_clip255(127.5 + a * (c[q] - 127.5));
+            }
+        } else if (o == OP_SATURATION) {                             // image[:, :, 1] = np.clip(image[:, :, 1] * factor, 0, 255)
+            if (tag == IMG_F32) c[1] = (double)img_clip255f((float)c[1] * (float)a);
+            else if (tag == IMG_U8) c[1] = img_trunc_u8(img_clip255(c[1] * a));
+            else c[1] = img_clip255(c[1] * a);
+        } else if (o == OP_HUE) {                                    // image[:, :, 0] = (image[:, :, 0] + delta) % 180.0
+            if (tag == IMG_F32) c[0] = (double)img_modf((float)c[0] + (float)a, 180.f);
+            else if (tag == IMG_U8) c[0] = img_trunc_u8(img_mod(c[0] + a, 180.0));
+            else c[0] = img_mod(c[0] + a, 180.0);
+        } else if (o == OP_RGB2HSV) {
+            if (tag == IMG_U8) img_rgb2hsv_u8(c, sdiv, hdiv);
+            else img_rgb2hsv_f32(c);
+        } else if (o == OP_HSV2RGB) {
+            float rgb[3];
+            if (tag == IMG_U8) {
+                img_hsv2rgb_float((float)c[0], (float)c[1] * (float)(1.0 / 255.0), (float)c[2] * (float)(1.0 / 255.0), (float)(6.0 / 180.0), rgb);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = (double)img_clip255f(rintf(rgb[q] * 255.f));
+            } else {
+                img_hsv2rgb_float((float)c[0], (float)c[1], (float)c[2], (float)(6.0 / 360.0), rgb);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) c[q] = (double)rgb[q];
+            }
+        } else if (o == OP_RGB2GRAY) {
+            double gr;
+            if (tag == IMG_U8) {
+                gr = (double)(((int)c[0] * 4899 + (int)c[1] * 9617 + (int)c[2] * 1868 + (1 << 13)) >> 14);
+            } else {
+                const float t = (float)c[0] * 0.299f + (float)c[1] * 0.587f;
+                gr = (double)(t + (float)c[2] * 0.114f);
+            }
+            c[0] = c[1] = c[2] = gr;
+        } else if (o == OP_SWAP) {                                   // image[:, :, order], order packed as o0 + 4 o1 + 16 o2
+            const int code = (int)a;
+            const double t0 = c[code & 3], t1 = c[(code >> 2) & 3], t2 = c[(code >> 4) & 3];
+            c[0] = t0; c[1] = t1; c[2] = t2;
+        }
+    }
+    // the dtype after the step (the same for every pixel)
+    if (o == OP_TO_F32) tag = IMG_F32;
+    else if (o == OP_TO_U8) tag = IMG_U8;
+    else if ((o == OP_BRIGHTNESS || o == OP_CONTRAST) && tag != IMG_F32) tag = IMG_F64;
+}
+
 // x: [n_images][pixels][3] uint8, float32 or float64; y: uint8 / float32 / float64 as out_tag says; ops / args: [n_images][IMG_PROG].
 __global__ __launch_bounds__(256) void pixel_program_kernel(const void* __restrict__ x, int in_tag, void* __restrict__ y, int out_tag,
                                                             long long pixels, const int* __restrict__ ops, const double* __restrict__ args) {
@@ -111,72 +184,13 @@ __global__ __launch_bounds__(256) void pixel_program_kernel(const void* __restri
             const double* s = static_cast<const double*>(x) + e;
             c[0] = s[0]; c[1] = s[1]; c[2] = s[2];
         }
+        double px[1][3] = {{c[0], c[1], c[2]}};
         for (int k = 0; k < IMG_PROG; ++k) {
             const int o = op[k];
             if (o == OP_END) break;
-            const double a = arg[k];
-            if (o == OP_TO_F32) {
-                if (tag == IMG_F64) { c[0] = (double)(float)c[0]; c[1] = (double)(float)c[1]; c[2] = (double)(float)c[2]; }
-                tag = IMG_F32;
-            } else if (o == OP_TO_U8) {                                  // np.round(image, 0).astype(uint8)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) c[q] = img_clip255(tag == IMG_F32 ? (double)rintf((float)c[q]) : rint(c[q]));
-                tag = IMG_U8;
-            } else if (o == OP_BRIGHTNESS) {                             // np.clip(image + delta, 0, 255)
-                if (tag == IMG_F32) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) c[q] = (double)img_clip255f((float)c[q] + (float)a);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) c[q] = img_clip255(c[q] + a);
-                    tag = IMG_F64;
-                }
-            } else if (o == OP_CONTRAST) {                               // np.clip(127.5 + factor * (image - 127.5), 0, 255)
-                if (tag == IMG_F32) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) c[q] = (double)img_clip255f(127.5f + (float)a * ((float)c[q] - 127.5f));
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) c[q] = img_clip255(127.5 + a * (c[q] - 127.5));
-                    tag = IMG_F64;
-                }
-            } else if (o == OP_SATURATION) {                             // image[:, :, 1] = np.clip(image[:, :, 1] * factor, 0, 255)
-                if (tag == IMG_F32) c[1] = (double)img_clip255f((float)c[1] * (float)a);
-                else if (tag == IMG_U8) c[1] = img_trunc_u8(img_clip255(c[1] * a));
-                else c[1] = img_clip255(c[1] * a);
-            } else if (o == OP_HUE) {                                    // image[:, :, 0] = (image[:, :, 0] + delta) % 180.0
-                if (tag == IMG_F32) c[0] = (double)img_modf((float)c[0] + (float)a, 180.f);
-                else if (tag == IMG_U8) c[0] = img_trunc_u8(img_mod(c[0] + a, 180.0));
-                else c[0] = img_mod(c[0] + a, 180.0);
-            } else if (o == OP_RGB2HSV) {
-                if (tag == IMG_U8) img_rgb2hsv_u8(c);
-                else img_rgb2hsv_f32(c);
-            } else if (o == OP_HSV2RGB) {
-                float rgb[3];
-                if (tag == IMG_U8) {
-                    img_hsv2rgb_float((float)c[0], (float)c[1] * (float)(1.0 / 255.0), (float)c[2] * (float)(1.0 / 255.0), (float)(6.0 / 180.0), rgb);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) c[q] = (double)img_clip255f(rintf(rgb[q] * 255.f));
-                } else {
-                    img_hsv2rgb_float((float)c[0], (float)c[1], (float)c[2], (float)(6.0 / 360.0), rgb);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) c[q] = (double)rgb[q];
-                }
-            } else if (o == OP_RGB2GRAY) {
-                double gr;
-                if (tag == IMG_U8) {
-                    gr = (double)(((int)c[0] * 4899 + (int)c[1] * 9617 + (int)c[2] * 1868 + (1 << 13)) >> 14);
-                } else {
-                    const float t = (float)c[0] * 0.299f + (float)c[1] * 0.587f;
-                    gr = (double)(t + (float)c[2] * 0.114f);
-                }
-                c[0] = c[1] = c[2] = gr;
-            } else if (o == OP_SWAP) {                                   // image[:, :, order], order packed as o0 + 4 o1 + 16 o2
-                const int code = (int)a;
-                const double t0 = c[code & 3], t1 = c[(code >> 2) & 3], t2 = c[(code >> 4) & 3];
-                c[0] = t0; c[1] = t1; c[2] = t2;
-            }
+            img_apply<1>(px, tag, o, arg[k], nullptr, nullptr);
         }
+        c[0] = px[0][0]; c[1] = px[0][1]; c[2] = px[0][2];
         if (out_tag == IMG_U8) {
             unsigned char* d = static_cast<unsigned char*>(y) + e;
             d[0] = (unsigned char)c[0]; d[1] = (unsigned char)c[1]; d[2] = (unsigned char)c[2];
@@ -187,6 +201,45 @@ __global__ __launch_bounds__(256) void pixel_program_kernel(const void* __restri
             double* d = static_cast<double*>(y) + e;
             d[0] = c[0]; d[1] = c[1]; d[2] = c[2];
         }
+    }
+}
+
+// The uint8 -> uint8 form (the photometric distortions of a whole batch): FOUR pixels = 12 bytes = three dwords per thread and trip, so
+// a wave moves 768 contiguous bytes per load / store instruction instead of 64 single bytes at a 3-byte stride; every program step is
+// decoded once for the four pixels; OpenCV's two 8-bit HSV division tables sit in LDS (built once per workgroup) instead of two integer
+// divisions per pixel.  Same arithmetic, same results as pixel_program_kernel.  pixels % 4 == 0 (the host checks; else the generic kernel).
+__global__ __launch_bounds__(256) void pixel_program_u8x4_kernel(const unsigned int* __restrict__ x, unsigned int* __restrict__ y, long long pixels,
+                                                                 const int* __restrict__ ops, const double* __restrict__ args) {
+    __shared__ int sdiv[256], hdiv[256];
+    sdiv[threadIdx.x] = img_div_table(255 << 12, (int)threadIdx.x, 1);
+    hdiv[threadIdx.x] = img_div_table(180 << 12, (int)threadIdx.x, 6);
+    __syncthreads();
+    const int img = blockIdx.y;
+    const int* op = ops + (size_t)img * IMG_PROG;
+    const double* arg = args + (size_t)img * IMG_PROG;
+    const long long groups = pixels / 4;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+        const size_t e = ((size_t)img * groups + g) * 3;                 // dword index of the group's 12 bytes
+        const unsigned int w0 = x[e], w1 = x[e + 1], w2 = x[e + 2];
+        double px[4][3];
+        px[0][0] = w0 & 255u; px[0][1] = (w0 >> 8) & 255u; px[0][2] = (w0 >> 16) & 255u;
+        px[1][0] = w0 >> 24; px[1][1] = w1 & 255u; px[1][2] = (w1 >> 8) & 255u;
+        px[2][0] = (w1 >> 16) & 255u; px[2][1] = w1 >> 24; px[2][2] = w2 & 255u;
+        px[3][0] = (w2 >> 8) & 255u; px[3][1] = (w2 >> 16) & 255u; px[3][2] = w2 >> 24;
+        int tag = IMG_U8;
+        for (int k = 0; k < IMG_PROG; ++k) {
+            const int o = op[k];
+            if (o == OP_END) break;
+            img_apply<4>(px, tag, o, arg[k], sdiv, hdiv);
+        }
+        unsigned int b[12];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[n * 3 + q] = (unsigned int)(unsigned char)px[n][q];
+        y[e] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        y[e + 1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        y[e + 2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
     }
 }
 
@@ -212,6 +265,71 @@ __global__ __launch_bounds__(256) void resize_taps_kernel(const unsigned char* _
         const double r = rint(acc);
         y[(size_t)b * total + i] = (unsigned char)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
     }
+}
+
+// The same resampling with the work laid out for the memory system: one workgroup = 256 consecutive values of ONE output row (grid
+// y = row, z = image), so the row's vertical taps are wave-uniform (scalar loads), a thread keeps ITS column's horizontal taps in
+// registers for all the rows it combines (nx <= 8: every mode but strong 'area' shrinks), there is no 64-bit division per value, and the
+// 256 gathers of a tap fall into one short stretch of one source row.  Same operations in the same order: identical results.
+__global__ __launch_bounds__(256) void resize_rows_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ y, int H, int W,
+                                                          int Ho, int Wo, int C, const int* __restrict__ ix, const double* __restrict__ wx,
+                                                          int nx, const int* __restrict__ iy, const double* __restrict__ wy, int ny) {
+    const int v = (int)blockIdx.x * 256 + (int)threadIdx.x, yo = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (v >= Wo * C) return;
+    const int xo = v / C, ch = v - xo * C;
+    int ixr[8];
+    double wxr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        ixr[k] = k < nx ? ix[xo * nx + k] * C + ch : 0;
+        wxr[k] = k < nx ? wx[xo * nx + k] : 0.0;
+    }
+    const unsigned char* src = x + (size_t)b * H * W * C;
+    double acc = 0.0;
+    for (int j = 0; j < ny; ++j) {
+        const unsigned char* row = src + (size_t)iy[yo * ny + j] * W * C;
+        double racc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nx) racc = racc + wxr[k] * (double)row[ixr[k]];
+        acc = acc + wy[yo * ny + j] * racc;
+    }
+    const double r = rint(acc);
+    y[((size_t)b * Ho + yo) * Wo * C + v] = (unsigned char)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+}
+
+// The geometric half of the augmentation chain for a whole BATCH in one launch: every image has its OWN tap tables -- the taps of
+// cv2.resize on the image's crop, composed on the host with the crop / expansion / flip index maps, so a tap addresses a column (row) of
+// the ORIGINAL image, or -1 = a position the expansion filled with the background colour.  Nothing but the final 300 x 300 batch is ever
+// materialised (the reference builds the expanded canvas, the crop and the flipped view per image on the host).  Layout and arithmetic as
+// resize_rows_kernel: out = rint(sum_j wy[j] (sum_k wx[k] pixel)), float64, rows outer; unused taps carry weight 0 and a valid index.
+__global__ __launch_bounds__(256) void resize_gather_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ y, int H, int W,
+                                                            int Ho, int Wo, int C, const int* __restrict__ ix, const double* __restrict__ wx,
+                                                            int nx, const int* __restrict__ iy, const double* __restrict__ wy, int ny,
+                                                            const unsigned char* __restrict__ background) {
+    const int v = (int)blockIdx.x * 256 + (int)threadIdx.x, yo = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (v >= Wo * C) return;
+    const int xo = v / C, ch = v - xo * C;
+    const double bg = (double)background[b * C + ch];
+    const int* ixb = ix + ((size_t)b * Wo + xo) * nx;
+    const double* wxb = wx + ((size_t)b * Wo + xo) * nx;
+    const int* iyb = iy + ((size_t)b * Ho + yo) * ny;
+    const double* wyb = wy + ((size_t)b * Ho + yo) * ny;
+    const unsigned char* src = x + (size_t)b * H * W * C;
+    double acc = 0.0;
+    for (int j = 0; j < ny; ++j) {
+        const int sy = iyb[j];
+        const unsigned char* row = src + (size_t)(sy < 0 ? 0 : sy) * W * C;
+        double racc = 0.0;
+        for (int k = 0; k < nx; ++k) {
+            const int sx = ixb[k];
+            const double pv = (sy < 0 || sx < 0) ? bg : (double)row[(size_t)sx * C + ch];
+            racc = racc + wxb[k] * pv;
+        }
+        acc = acc + wyb[j] * racc;
+    }
+    const double r = rint(acc);
+    y[((size_t)b * Ho + yo) * Wo * C + v] = (unsigned char)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
 }
 
 __global__ __launch_bounds__(256) void hist_u8_kernel(const unsigned char* __restrict__ x, long long n_pixels, int C, int channel,
@@ -253,6 +371,11 @@ extern "C" int ssdhip_image_program(const void* x, int in_dtype, void* y, int ou
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !y || !ops_dev || !args_dev || n_images <= 0 || n_images > 65535 || pixels_per_image <= 0) return SSDHIP_E_BADARG;
     if (in_dtype < IMG_U8 || in_dtype > IMG_F64 || out_dtype < IMG_U8 || out_dtype > IMG_F64) return SSDHIP_E_BADARG;
+    if (in_dtype == IMG_U8 && out_dtype == IMG_U8 && pixels_per_image % 4 == 0 && !(((uintptr_t)x | (uintptr_t)y) & 3)) {
+        hipLaunchKernelGGL(pixel_program_u8x4_kernel, dim3(img_blocks(pixels_per_image / 4, 2048), n_images), dim3(256), 0, stream,
+                           static_cast<const unsigned int*>(x), static_cast<unsigned int*>(y), pixels_per_image, ops_dev, args_dev);
+        return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    }
     hipLaunchKernelGGL(pixel_program_kernel, dim3(img_blocks(pixels_per_image, 4096), n_images), dim3(256), 0, stream, x, in_dtype, y, out_dtype,
                        pixels_per_image, ops_dev, args_dev);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
@@ -263,8 +386,26 @@ extern "C" int ssdhip_image_resize_u8(const void* x, void* y, int B, int H, int 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !y || !ix_dev || !wx_dev || !iy_dev || !wy_dev) return SSDHIP_E_BADARG;
     if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || C > 4 || nx <= 0 || ny <= 0 || nx > 64 || ny > 64) return SSDHIP_E_BADARG;
+    if (nx <= 8 && Ho <= 65535 && (long long)Wo * C < 0x7fffff00LL) {
+        hipLaunchKernelGGL(resize_rows_kernel, dim3((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)B), dim3(256), 0, stream,
+                           static_cast<const unsigned char*>(x), static_cast<unsigned char*>(y), H, W, Ho, Wo, C, ix_dev, wx_dev, nx, iy_dev, wy_dev, ny);
+        return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    }
     hipLaunchKernelGGL(resize_taps_kernel, dim3(img_blocks((long long)Ho * Wo * C, 4096), B), dim3(256), 0, stream,
                        static_cast<const unsigned char*>(x), static_cast<unsigned char*>(y), H, W, Ho, Wo, C, ix_dev, wx_dev, nx, iy_dev, wy_dev, ny);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_image_resize_gather_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, const int* ix_dev,
+                                             const double* wx_dev, int nx, const int* iy_dev, const double* wy_dev, int ny,
+                                             const void* background_dev, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || !ix_dev || !wx_dev || !iy_dev || !wy_dev || !background_dev) return SSDHIP_E_BADARG;
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || Ho <= 0 || Ho > 65535 || Wo <= 0 || C <= 0 || C > 4 || nx <= 0 || ny <= 0 || nx > 64 || ny > 64)
+        return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(resize_gather_kernel, dim3((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)B), dim3(256), 0, stream,
+                       static_cast<const unsigned char*>(x), static_cast<unsigned char*>(y), H, W, Ho, Wo, C, ix_dev, wx_dev, nx, iy_dev, wy_dev, ny,
+                       static_cast<const unsigned char*>(background_dev));
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -79,6 +79,94 @@ def run_batch(images, programs):
     return nat.image_program(images.contiguous(), np.stack([e[0] for e in enc]), np.stack([e[1] for e in enc]), _torch_dtype(tags.pop()))
 
 
+# ---- lazy geometry: the geometric ops of a chain recorded instead of executed ----------------------------------------------------------
+class GeoImage:
+    """An image that EXISTS ONLY AS INDEX MAPS into an image resident on the device: what the geometric ops of the augmentation chain
+    (expansion / crop = a window with a background, flips = reversed slices, the final resize) do to it is recorded as two index arrays
+    -- `ys[i]` / `xs[j]` = the row / column of the original image that row i / column j of the current virtual image shows, -1 = a
+    position filled with `background` -- and executed once, for a whole batch, by `ssdhip_image_resize_gather_u8`.  Quacks like the
+    (H, W, 3) uint8 array the ops expect: `shape`, `ndim`, `dtype`, slicing with plain / reversed slices."""
+
+    ndim = 3
+    dtype = np.dtype(np.uint8)
+
+    def __init__(self, ys, xs, background=None, resized=None):
+        self.ys, self.xs, self.background, self.resized = ys, xs, background, resized
+
+    @classmethod
+    def of(cls, height, width):
+        return cls(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64))
+
+    @property
+    def shape(self):
+        if self.resized is not None:
+            return (self.resized[0], self.resized[1], 3)
+        return (len(self.ys), len(self.xs), 3)
+
+    def __getitem__(self, key):
+        if self.resized is not None:
+            raise TypeError("a resized lazy image is final")
+        if not isinstance(key, tuple):
+            key = (key,)
+        if len(key) > 2 or not all(isinstance(k, slice) for k in key):
+            raise TypeError("lazy images take row / column slices only")
+        ys = self.ys[key[0]]
+        xs = self.xs[key[1]] if len(key) > 1 else self.xs
+        return GeoImage(ys, xs, self.background)
+
+    def window(self, top, left, height, width, background):
+        """CropPad's window (data_generator/object_detection_2d_patch_sampling_ops.py: the patch, background where it leaves the image)."""
+        h, w = len(self.ys), len(self.xs)
+        rows = np.arange(top, top + height)
+        cols = np.arange(left, left + width)
+        ys = np.where((rows >= 0) & (rows < h), self.ys[np.clip(rows, 0, h - 1)], -1)
+        xs = np.where((cols >= 0) & (cols < w), self.xs[np.clip(cols, 0, w - 1)], -1)
+        bg = tuple(int(v) for v in background)
+        padded = bool(top < 0 or left < 0 or top + height > h or left + width > w)     # THIS window leaves the (virtual) image
+        had = bool((self.ys < 0).any() or (self.xs < 0).any())
+        if padded and had and self.background is not None and tuple(self.background) != bg:
+            raise NotImplementedError("two paddings with different background colours cannot be composed lazily")
+        return GeoImage(ys, xs, bg if (padded or self.background is None) else self.background)
+
+    def resize(self, out_h, out_w, interp):
+        return GeoImage(self.ys, self.xs, self.background, resized=(int(out_h), int(out_w), int(interp)))
+
+    def taps(self, n_taps):
+        """(ix, wx, iy, wy): the resize's taps composed with the index maps, padded to n_taps per output position (weight 0)."""
+        out_h, out_w, interp = self.resized
+        res = []
+        for idx_map, n_dst in ((self.xs, out_w), (self.ys, out_h)):
+            i, w = axis_taps(len(idx_map), n_dst, interp)
+            t = i.shape[1]
+            if t > n_taps:
+                raise ValueError("%d taps needed, %d provided" % (t, n_taps))
+            src = idx_map[i].astype(np.int32)
+            ii = np.zeros((n_dst, n_taps), dtype=np.int32)
+            ww = np.zeros((n_dst, n_taps), dtype=np.float64)
+            ii[:, :t], ww[:, :t] = src, w
+            res += [ii, ww]
+        return res
+
+    def n_taps(self):
+        out_h, out_w, interp = self.resized
+        return max(axis_taps(len(self.xs), out_w, interp)[0].shape[1], axis_taps(len(self.ys), out_h, interp)[0].shape[1])
+
+
+def gather_batch(images, lazies):
+    """Execute the recorded geometry of a batch: images (B, H, W, 3) CUDA uint8, lazies[i] a resized GeoImage of image i -> the
+    (B, out_h, out_w, 3) uint8 batch, ONE launch."""
+    sizes = {l.resized[:2] for l in lazies}
+    if len(sizes) != 1:
+        raise ValueError("every image of a batch must end in the same size")
+    out_h, out_w = sizes.pop()
+    n = max(l.n_taps() for l in lazies)
+    n = 1 if n <= 1 else (2 if n <= 2 else (4 if n <= 4 else (8 if n <= 8 else 16 if n <= 16 else n)))
+    tabs = [l.taps(n) for l in lazies]
+    bg = np.array([(l.background if l.background is not None else (0, 0, 0)) for l in lazies], dtype=np.uint8)
+    return nat.image_resize_gather_u8(images.contiguous(), out_h, out_w, np.stack([t[0] for t in tabs]), np.stack([t[1] for t in tabs]),
+                                      np.stack([t[2] for t in tabs]), np.stack([t[3] for t in tabs]), bg)
+
+
 # ---- cv2.resize as separable taps ------------------------------------------------------------------------------------------------
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
 
@@ -131,6 +219,8 @@ def axis_taps(n_src, n_dst, interp):
 
 def resize(image, out_h, out_w, interp):
     """cv2.resize(image, dsize=(out_w, out_h), interpolation=interp) for uint8 images: NumPy (H, W[, C]) or CUDA (B, H, W, C)."""
+    if isinstance(image, GeoImage):
+        return image.resize(out_h, out_w, interp)
     if isinstance(image, np.ndarray):
         if image.dtype != np.uint8:
             raise TypeError("resize takes uint8 images")

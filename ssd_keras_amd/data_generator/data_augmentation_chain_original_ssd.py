@@ -131,3 +131,30 @@ class SSDDataAugmentation:
             else:
                 image, labels = transform(image, labels)
         return (image, labels, inverters[::-1]) if return_inverter else (image, labels)
+
+    def augment_batch(self, images, labels):
+        """The whole chain on a device-resident batch: images (B, H, W, 3) CUDA uint8, labels a list of B
+        (n_i, 5) arrays -> ((B, img_height, img_width, 3) CUDA uint8 batch, list of B label arrays).  TWO launches for the pixels of
+        the whole batch -- the photometric distortions (`ssdhip_image_program`, one program per image) and expansion + crop + flip +
+        resize fused into one gather (`ssdhip_image_resize_gather_u8`: the geometric ops only record index maps, nothing but the final
+        batch is materialised) -- and no PCIe traffic besides the tap tables.  The random draws, the label arithmetic and the box
+        filtering are the per-image chain's own code in the per-image chain's order: with the same NumPy random state the result
+        equals calling the chain on image 0, 1, 2, ... (tests/test_image_ops.py)."""
+        import torch
+        if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3):
+            raise TypeError("augment_batch takes a (B, H, W, 3) CUDA uint8 batch")
+        if len(labels) != images.shape[0]:
+            raise ValueError("one label array per image")
+        for t in (self.expand, self.random_crop, self.random_flip, self.resize):
+            t.labels_format = self.labels_format
+        h, w = int(images.shape[1]), int(images.shape[2])
+        programs, lazies, out_labels = [], [], []
+        for lab in labels:
+            programs.append(self.photometric_distortions.draw())         # the draws of this image's photometric part, then its geometry
+            img, lab = iop.GeoImage.of(h, w), np.asarray(lab)
+            for transform in (self.expand, self.random_crop, self.random_flip, self.resize):
+                img, lab = transform(img, lab)
+            lazies.append(img)
+            out_labels.append(lab)
+        distorted = iop.run_batch(images, programs)
+        return iop.gather_batch(distorted, lazies), out_labels

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import _image_ops as iop
+
 from .object_detection_2d_image_boxes_validation_utils import BoundGenerator, BoxFilter, ImageValidator
 
 _DEFAULT_FORMAT = {'class_id': 0, 'xmin': 1, 'ymin': 2, 'xmax': 3, 'ymax': 4}
@@ -112,6 +114,8 @@ class CropPad:
         '''The patch as a fresh uint8 array: background canvas + the part of the image the window covers.'''
         img_height, img_width = image.shape[:2]
         top, left, height, width = self.patch_ymin, self.patch_xmin, self.patch_height, self.patch_width
+        if isinstance(image, iop.GeoImage):              # a lazy image (SSDDataAugmentation.augment_batch): record, do not copy
+            return image.window(top, left, height, width, self.background)
         if image.ndim == 3:
             canvas = np.zeros((height, width, 3), dtype=np.uint8)
             canvas[:, :] = self.background

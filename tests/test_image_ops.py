@@ -181,3 +181,34 @@ def test_gamma_and_batched_resize():
     big = rng.randint(0, 256, size=(2, 375, 500, 3)).astype(np.uint8)          # a VOC-sized image down to the network input
     got = iop.resize(torch.from_numpy(big).cuda(), 300, 300, 3).cpu().numpy()
     assert np.array_equal(got[1], npi.resize(big[1], (300, 300), 3))
+
+
+@pytest.mark.gpu
+def test_augment_batch_equals_the_per_image_chain():
+    """`SSDDataAugmentation.augment_batch` (device pipeline: one photometric launch + one gather launch per batch; reference
+    data_generator/data_augmentation_chain_original_ssd.py:208-280) == the per-image chain called on image 0, 1, 2, ... with the same
+    NumPy random state: images and labels bit for bit, and the random stream ends in the same place."""
+    import torch
+    from ssd_keras_amd.data_generator.data_augmentation_chain_original_ssd import SSDDataAugmentation
+    rng = np.random.RandomState(42)
+    B, H, W = 12, 120, 160
+    batch = rng.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    labels = []
+    for _ in range(B):
+        n = rng.randint(1, 5)
+        x0, y0 = rng.randint(0, W - 40, size=n), rng.randint(0, H - 40, size=n)
+        labels.append(np.stack([rng.randint(1, 21, size=n), x0, y0, x0 + rng.randint(12, 40, size=n), y0 + rng.randint(12, 40, size=n)], axis=1))
+    for seed in (0, 1, 2):
+        aug = SSDDataAugmentation(img_height=64, img_width=64)
+        np.random.seed(seed)
+        want = [aug(batch[i], labels[i]) for i in range(B)]
+        after_want = np.random.uniform()
+        np.random.seed(seed)
+        got_img, got_lab = aug.augment_batch(torch.from_numpy(batch).cuda(), labels)
+        after_got = np.random.uniform()
+        assert after_got == after_want, "the random stream must end where the per-image chain leaves it"
+        assert got_img.is_cuda and got_img.dtype == torch.uint8 and tuple(got_img.shape) == (B, 64, 64, 3)
+        g = got_img.cpu().numpy()
+        for i in range(B):
+            assert np.array_equal(g[i], want[i][0]), "seed %d image %d: %d pixels differ" % (seed, i, int((g[i] != want[i][0]).sum()))
+            assert np.array_equal(got_lab[i], want[i][1]), (seed, i)
