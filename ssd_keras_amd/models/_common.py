@@ -175,6 +175,42 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None
 
 
+class _PackedHeadFn(torch.autograd.Function):
+    """The two predictor heads of one source map in the TRAINING step as one libssdhip node (round 4): conf and loc filters packed along
+    Cout (zero rows up to a multiple of 128), forward = the slab kernel (no activation), data gradient = the slab kernel on the flipped /
+    transposed pack, weight gradient = ssdhip_conv3x3_wgrad on the packed gradient, bias gradient = one reduction -- instead of two
+    framework convolutions forward and four backward per map (MIOpen: 1.7 ms of a 12.7 ms step, profiles/r04za).  Returns the packed
+    (B, Cp, H, W) bf16 map; the caller slices conf / loc out of it (reference: models/keras_ssd300.py:322-335)."""
+
+    @staticmethod
+    def forward(ctx, x, wc, bc, wl, bl, wcb, bcb, wlb, blb):
+        xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        nc, nl = wc.shape[0], wl.shape[0]
+        pad = (-(nc + nl)) % 128
+        parts_w = [wcb, wlb] + ([wcb.new_zeros((pad,) + tuple(wcb.shape[1:]))] if pad else [])
+        parts_b = [bcb, blb] + ([bcb.new_zeros((pad,))] if pad else [])
+        w = torch.cat(parts_w, dim=0).contiguous(memory_format=torch.channels_last)
+        y = nat.conv3x3_halo(xb, w, torch.cat(parts_b, dim=0), relu=False, pool=False)
+        ctx.save_for_backward(xb, w)
+        ctx.conf = (nc, nl, wc.dtype, bc.dtype, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, w = ctx.saved_tensors
+        nc, nl, wdt, bdt, xdt = ctx.conf
+        gyb = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+            gx = nat.conv2d_same(gyb, wt, None, dilation=1, relu=False, variant=7).to(xdt)
+        gw = nat.conv3x3_wgrad(xb, gyb)
+        if gw is None:
+            raise RuntimeError("packed predictor head: weight-gradient geometry not covered")
+        gb = gyb.float().sum(dim=(0, 2, 3))
+        return (gx, gw[:nc].to(wdt), gb[:nc].to(bdt), gw[nc:nc + nl].to(wdt), gb[nc:nc + nl].to(bdt), None, None, None, None)
+
+
 class _MaxPoolFn(torch.autograd.Function):
     """max_pool2d of a bf16 NHWC map in the training step: libssdhip forward (one pass) and backward (gather, deterministic)."""
 
@@ -690,6 +726,13 @@ class SSDModel(nn.Module):
         confs, locs = [], []
         for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads):
             # NCHW -> NHWC before the reshape so the channel axis splits as (box, class) like Keras (:363-383)
+            if self._packed_train_head_ok(f, ch, lh):
+                wcb, bcb = self._bf16_shadow(ch)
+                wlb, blb = self._bf16_shadow(lh)
+                y = _PackedHeadFn.apply(f, ch.weight, ch.bias, lh.weight, lh.bias, wcb, bcb, wlb, blb).permute(0, 2, 3, 1)
+                confs.append(y[..., :ch.out_channels].reshape(b, -1, self.n_classes))
+                locs.append(y[..., ch.out_channels:ch.out_channels + lh.out_channels].reshape(b, -1, 4))
+                continue
             confs.append(ch(f).permute(0, 2, 3, 1).reshape(b, -1, self.n_classes))
             locs.append(lh(f).permute(0, 2, 3, 1).reshape(b, -1, 4))
         conf = torch.softmax(torch.cat(confs, dim=1).float(), dim=-1)          # 'mbox_conf_softmax' (:415)
@@ -792,6 +835,13 @@ class SSDModel(nn.Module):
         small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None, relu=False)
         main.wait_stream(side)
         return early + rest, big + small
+
+    def _packed_train_head_ok(self, f, ch, lh):
+        """Training step, bf16 autocast on the GPU, 3x3 'same' heads on a map the slab / weight-gradient kernels cover."""
+        import os
+        return (self._fused_train(f, ch) and lh.bias is not None and self._packed_head_ok(ch, lh, f) and f.shape[1] % 128 == 0
+                and f.shape[3] <= 190 and os.environ.get("SSDHIP_NO_OWN_HEADS", "0") != "1"
+                and self._bf16_shadow(ch)[0] is not None and self._bf16_shadow(lh)[0] is not None)
 
     def _heads_grouped(self, feats):
         outs = nat.conv2d_same_group(list(feats), [self._packed_head_weight(l) for l in range(len(feats))], None, relu=False)

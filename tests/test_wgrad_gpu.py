@@ -77,3 +77,38 @@ def test_wgrad_unsupported_geometries_return_none():
     assert nat.conv3x3_wgrad(x, torch.zeros((1, 64, 8, 8), device="cuda", dtype=torch.bfloat16)) is None   # Cin % 64 != 0
     x = torch.zeros((1, 64, 4, 200), device="cuda", dtype=torch.bfloat16)
     assert nat.conv3x3_wgrad(x, torch.zeros((1, 128, 4, 200), device="cuda", dtype=torch.bfloat16)) is None  # too wide for the 128-channel form
+
+
+@pytest.mark.parametrize("shape", [(3, 19, 19, 1024, 126, 24), (2, 38, 38, 512, 84, 16), (4, 1, 1, 256, 84, 16), (2, 5, 5, 256, 126, 24)])
+def test_packed_head_node_matches_two_framework_convolutions(shape):
+    """models/_common.py _PackedHeadFn (the two predictor heads of a source map in the training step: slab-kernel forward and data
+    gradient, MFMA weight gradient, one bias reduction; reference models/keras_ssd300.py:322-335) against the two float32 framework
+    convolutions on the same bf16-rounded operands: outputs within one bf16 rounding, every gradient within 1e-2 of its norm."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd.models._common import _PackedHeadFn
+    B, H, W, Cin, nc, nl = shape
+    g = torch.Generator(device="cuda").manual_seed(B * H + nc)
+    x = torch.randn((B, Cin, H, W), generator=g, device="cuda").to(memory_format=torch.channels_last).to(torch.bfloat16).float().requires_grad_(True)
+    mk = lambda n: (torch.randn((n, Cin, 3, 3), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).float().requires_grad_(True)
+    wc, wl = mk(nc), mk(nl)
+    bc = torch.randn((nc,), generator=g, device="cuda").to(torch.bfloat16).float().requires_grad_(True)
+    bl = torch.randn((nl,), generator=g, device="cuda").to(torch.bfloat16).float().requires_grad_(True)
+    go = torch.randn((B, nc + nl, H, W), generator=g, device="cuda").to(torch.bfloat16).float()
+    want = torch.cat([F.conv2d(x, wc, bc, 1, 1), F.conv2d(x, wl, bl, 1, 1)], dim=1)
+    (want * go).sum().backward()
+    ref = [t.grad.clone() for t in (x, wc, bc, wl, bl)]
+    for t in (x, wc, bc, wl, bl):
+        t.grad = None
+    bf = lambda t: t.detach().to(torch.bfloat16)
+    wcb = bf(wc).contiguous(memory_format=torch.channels_last)
+    wlb = bf(wl).contiguous(memory_format=torch.channels_last)
+    y = _PackedHeadFn.apply(x, wc, bc, wl, bl, wcb, bf(bc), wlb, bf(bl))
+    assert y.shape[0] == B and y.shape[1] % 128 == 0 and y.dtype == torch.bfloat16
+    got = y[:, :nc + nl].float()
+    rms = want.pow(2).mean().sqrt().item()
+    assert int(((got - want).abs() > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
+    (got * go).sum().backward()
+    for name, t, r in zip(("x", "w conf", "b conf", "w loc", "b loc"), (x, wc, bc, wl, bl), ref):
+        d = float((t.grad - r).norm() / (r.norm() + 1e-20))
+        assert d <= 1e-2, "%s gradient %.3g of its norm away" % (name, d)

@@ -12,6 +12,7 @@
 #                         @LIB runs the same code on tools/libssdhip_LIB.so (a within-visit A/B against an older build)
 #   pmc_decode            FETCH_SIZE / WRITE_SIZE passes of the decode kernels -> decode_pmc_traffic.json
 #   pmc_mfma              MFMA-busy counters per kernel of one eager forward   -> pmc_mfma_per_kernel.txt
+#   train_timeline        one training step of bench_extra.train_leg by kernel (rocprofv3 trace) -> train_step_timeline.json
 #   stats=SCRIPT          rocprofv3 --kernel-trace --stats around `python tools/SCRIPT.py` -> SCRIPT_kernel_stats.csv + SCRIPT.log
 #   py=SCRIPT[:ARGS]      python tools/SCRIPT.py ARGS           -> SCRIPT.log
 #   env:K=V               export K=V for the steps that follow (env:K= unsets)
@@ -51,6 +52,10 @@ for step in "$@"; do
       ( cd /tmp; timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 \
           --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o fwd -- python "$R/bench.py" --graph 0 --steps 3 --warmup 8 --no-cpu-baseline --no-extra > "$OUT/pmc_mfma.log" 2>&1 )
       python tools/pmc_fold.py "$OUT/pmc_mfma" ssdhip > "$OUT/pmc_mfma_per_kernel.txt" 2>&1; head -n 40 "$OUT/pmc_mfma_per_kernel.txt" ;;
+    train_timeline)
+      ( cd /tmp; SSD_TRAIN_RAW=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_train" -o train -- python "$R/tools/time_train_leg.py" > "$OUT/train_leg.log" 2>&1 )
+      python tools/train_timeline.py "$(find "$OUT/trace_train" -name "*kernel_trace.csv" | head -1)" "$OUT/train_step_timeline.json" rowmax_kernel | head -45
+      tail -n 2 "$OUT/train_leg.log" ;;
     stats=*)
       s=${step#stats=}
       ( cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$s" -o "$s" -- python "$R/tools/$s.py" > "$OUT/$s.log" 2>&1 )
