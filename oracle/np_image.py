@@ -166,14 +166,26 @@ def _lanczos_w(t, a=4):
     return np.where(nzm, val, out)
 
 
-def resize_taps(n_src, n_dst, interp):
-    """(index [n_dst, T] int32, weight [n_dst, T] float64) of one axis: dst[i] = sum_t weight[i, t] * src[index[i, t]]."""
+def resize_taps(n_src, n_dst, interp, area_linear=False):
+    """(index [n_dst, T] int32, weight [n_dst, T] float64) of one axis: dst[i] = sum_t weight[i, t] * src[index[i, t]].
+    `area_linear`: INTER_AREA when NOT both axes shrink -- OpenCV's resize() then emulates it "using some variant of bilinear" on BOTH
+    axes (imgproc/resize.cpp, 3.x / 4.x: `area_mode`): sx = floor(dx scale), fx = (float)((dx + 1) - (sx + 1) / scale), fx <= 0 -> 0 else
+    its fractional part; taps (sx, sx + 1) with weights (1 - fx, fx), clamped at the last pixel."""
     scale = n_src / n_dst
     i = np.arange(n_dst, dtype=np.float64)
+    if interp == INTER_AREA and area_linear:
+        sx = np.floor(i * scale)
+        fx = ((i + 1) - (sx + 1) * (1.0 / scale)).astype(np.float32)
+        fx = np.where(fx <= 0, np.float32(0), fx - np.floor(fx)).astype(np.float64)
+        last = sx >= n_src - 1
+        sx = np.where(last, n_src - 1, sx).astype(np.int64)
+        fx = np.where(last, 0.0, fx)
+        idx = np.clip(np.stack([sx, sx + 1], axis=1), 0, n_src - 1).astype(np.int32)
+        return idx, np.stack([1.0 - fx, fx], axis=1)
     if interp == INTER_NEAREST:
         idx = np.minimum(np.floor(i * scale), n_src - 1).astype(np.int32)[:, None]
         return idx, np.ones((n_dst, 1))
-    if interp == INTER_AREA and scale > 1:
+    if interp == INTER_AREA and scale >= 1:
         # box filter: the overlap of [i * scale, (i + 1) * scale) with each source cell, normalised
         lo, hi = i * scale, (i + 1) * scale
         first = np.floor(lo).astype(np.int64)
@@ -207,8 +219,9 @@ def resize(img, dsize, interpolation=INTER_LINEAR):
         raise TypeError("resize: 8-bit images")
     wo, ho = int(dsize[0]), int(dsize[1])
     src = img if img.ndim == 3 else img[:, :, None]
-    ix, wx = resize_taps(src.shape[1], wo, int(interpolation))
-    iy, wy = resize_taps(src.shape[0], ho, int(interpolation))
+    al = int(interpolation) == INTER_AREA and not (src.shape[1] >= wo and src.shape[0] >= ho)     # cv2: the box filter only if BOTH axes shrink
+    ix, wx = resize_taps(src.shape[1], wo, int(interpolation), al)
+    iy, wy = resize_taps(src.shape[0], ho, int(interpolation), al)
     srcd = src.astype(np.float64)
     acc = np.zeros((ho, wo, src.shape[2]))
     for j in range(iy.shape[1]):                                            # rows outer, columns inner: the kernel's order

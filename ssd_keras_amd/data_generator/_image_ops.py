@@ -134,9 +134,10 @@ class GeoImage:
     def taps(self, n_taps):
         """(ix, wx, iy, wy): the resize's taps composed with the index maps, padded to n_taps per output position (weight 0)."""
         out_h, out_w, interp = self.resized
+        al = _area_linear(len(self.ys), len(self.xs), out_h, out_w, interp)
         res = []
         for idx_map, n_dst in ((self.xs, out_w), (self.ys, out_h)):
-            i, w = axis_taps(len(idx_map), n_dst, interp)
+            i, w = axis_taps(len(idx_map), n_dst, interp, al)
             t = i.shape[1]
             if t > n_taps:
                 raise ValueError("%d taps needed, %d provided" % (t, n_taps))
@@ -149,7 +150,8 @@ class GeoImage:
 
     def n_taps(self):
         out_h, out_w, interp = self.resized
-        return max(axis_taps(len(self.xs), out_w, interp)[0].shape[1], axis_taps(len(self.ys), out_h, interp)[0].shape[1])
+        al = _area_linear(len(self.ys), len(self.xs), out_h, out_w, interp)
+        return max(axis_taps(len(self.xs), out_w, interp, al)[0].shape[1], axis_taps(len(self.ys), out_h, interp, al)[0].shape[1])
 
 
 def gather_batch(images, lazies):
@@ -187,14 +189,25 @@ def _kernel_lanczos4(t):
     return np.where(inside, val, np.where(np.abs(t) < 1e-12, 1.0, 0.0))
 
 
-def axis_taps(n_src, n_dst, interp):
+def axis_taps(n_src, n_dst, interp, area_linear=False):
     """Source indices (n_dst, T) int32 and float64 weights (n_dst, T) of one axis for an OpenCV interpolation mode: pixel centres
-    (src = (dst + 0.5) * scale - 0.5), replicated border; 'area' is the box filter when shrinking and the linear kernel when enlarging."""
+    (src = (dst + 0.5) * scale - 0.5), replicated border.  INTER_AREA is the box filter only when BOTH axes shrink (the caller decides:
+    `area_linear=False`); otherwise cv2.resize emulates it on both axes with its `area_mode` bilinear variant (imgproc/resize.cpp):
+    sx = floor(dx scale), fx = (float)((dx + 1) - (sx + 1) / scale), 0 if fx <= 0 else its fractional part -- an integer enlargement
+    then replicates pixels (the first version decided per axis and used the centre-based linear kernel)."""
     scale = n_src / n_dst
     i = np.arange(n_dst, dtype=np.float64)
+    if interp == INTER_AREA and area_linear:
+        sx = np.floor(i * scale)
+        fx = ((i + 1) - (sx + 1) * (1.0 / scale)).astype(np.float32)
+        fx = np.where(fx <= 0, np.float32(0), fx - np.floor(fx)).astype(np.float64)
+        last = sx >= n_src - 1
+        sx = np.where(last, n_src - 1, sx).astype(np.int64)
+        fx = np.where(last, 0.0, fx)
+        return np.clip(np.stack([sx, sx + 1], axis=1), 0, n_src - 1).astype(np.int32), np.stack([1.0 - fx, fx], axis=1)
     if interp == INTER_NEAREST:
         return np.minimum(np.floor(i * scale), n_src - 1).astype(np.int32)[:, None], np.ones((n_dst, 1))
-    if interp == INTER_AREA and scale > 1:
+    if interp == INTER_AREA and scale >= 1:
         lo, hi = i * scale, (i + 1) * scale
         first = np.floor(lo).astype(np.int64)
         cells = first[:, None] + np.arange(int(np.ceil(scale)) + 1)[None, :]
@@ -217,6 +230,11 @@ def axis_taps(n_src, n_dst, interp):
     return np.clip(base[:, None].astype(np.int64) + offs[None, :], 0, n_src - 1).astype(np.int32), w
 
 
+def _area_linear(h, w, out_h, out_w, interp):
+    """cv2.resize: INTER_AREA is the true area (box) filter only if scale_x >= 1 and scale_y >= 1."""
+    return int(interp) == INTER_AREA and not (w >= out_w and h >= out_h)
+
+
 def resize(image, out_h, out_w, interp):
     """cv2.resize(image, dsize=(out_w, out_h), interpolation=interp) for uint8 images: NumPy (H, W[, C]) or CUDA (B, H, W, C)."""
     if isinstance(image, GeoImage):
@@ -225,12 +243,14 @@ def resize(image, out_h, out_w, interp):
         if image.dtype != np.uint8:
             raise TypeError("resize takes uint8 images")
         src = image if image.ndim == 3 else image[:, :, None]
-        ix, wx = axis_taps(src.shape[1], out_w, int(interp))
-        iy, wy = axis_taps(src.shape[0], out_h, int(interp))
+        al = _area_linear(src.shape[0], src.shape[1], out_h, out_w, interp)
+        ix, wx = axis_taps(src.shape[1], out_w, int(interp), al)
+        iy, wy = axis_taps(src.shape[0], out_h, int(interp), al)
         out = nat.image_resize_u8(nat.to_device(np.ascontiguousarray(src)[None]), out_h, out_w, ix, wx, iy, wy)[0].cpu().numpy()
         return out if image.ndim == 3 else out[:, :, 0]
-    ix, wx = axis_taps(int(image.shape[2]), out_w, int(interp))
-    iy, wy = axis_taps(int(image.shape[1]), out_h, int(interp))
+    al = _area_linear(int(image.shape[1]), int(image.shape[2]), out_h, out_w, interp)
+    ix, wx = axis_taps(int(image.shape[2]), out_w, int(interp), al)
+    iy, wy = axis_taps(int(image.shape[1]), out_h, int(interp), al)
     return nat.image_resize_u8(image.contiguous(), out_h, out_w, ix, wx, iy, wy)
 
 
