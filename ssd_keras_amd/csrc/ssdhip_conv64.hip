@@ -39,6 +39,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// In-kernel phase timers of the Cin = 64 kernels, profiling build only (tools/prof_build.sh): shader cycles of wave 0 (multiplier) and
+// wave 4 (loader / first producer) per phase, summed over tiles and workgroups; read back with ssdhip_profile_read_c64.
+#ifdef SSDHIP_PROFILE
+__device__ unsigned long long g_prof64[32];
+#define C64_PROF_DECL long long _pt = clock64(); long long _pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int _pn = 0;
+#define C64_PROF_MARK(i) { const long long _t = clock64(); _pa[i] += _t - _pt; _pt = _t; }
+#define C64_PROF_TILE ++_pn;
+#define C64_PROF_FLUSH(base) if (lane == 0) { for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_prof64[(base) + _i], (unsigned long long)_pa[_i]); atomicAdd(&g_prof64[(base) + 8], (unsigned long long)_pn); }
+#else
+#define C64_PROF_DECL
+#define C64_PROF_MARK(i)
+#define C64_PROF_TILE
+#define C64_PROF_FLUSH(base)
+#endif
+
 #ifndef SSDHIP_C64_NLOAD
 #define SSDHIP_C64_NLOAD 1       // loader waves of the non-fused kernel (each issues every NLOAD-th LDS-DMA piece of a halo); 2 measured equal (r03zb)
 #endif
@@ -47,7 +62,7 @@ constexpr int C64_THREADS = (4 + C64_NLOAD) * 64;        // four multiplying wav
 constexpr int C64_NPROD = 3;                             // FRONT: producer waves
 constexpr int C64_FRONT_THREADS = (4 + C64_NPROD) * 64;  // FRONT: four multiplying waves + the producers
 constexpr int C64_WBYTES = 9 * 64 * 128;                 // resident weight slice: [tap][co][64 ci] bf16, 128-byte rows
-constexpr int C64_STAGE = 4 * 2048;                      // per-wave output transpose: 32 px x 64 B (non-pooled: twice per tile)
+constexpr int C64_STAGE = 0;                             // (rounds 2-3: a per-wave LDS stage for the output transpose; the epilogue now stores from the accumulator layout)
 constexpr int c64_halo_bytes(int cs) { return ((9 * (2 * (64 >> cs) + 2) * ((1 << cs) + 2) + 63) / 64) * 1024; }
 constexpr int C64_PATCH1 = 1600;                         // FRONT: one producer's copy of the 3-channel input patch of a tile's halo (13 x 20 px x 3 ch bf16 = 1560 B)
 constexpr int C64_PATCH = ((C64_NPROD * C64_PATCH1 + 1023) / 1024) * 1024;
@@ -69,6 +84,7 @@ struct C64Params {
     const bf16_t* w1;            // FRONT: [64, 3, 3, 3] first-layer filters
     const bf16_t* b1;            // FRONT: [64] first-layer bias or null
     int prio;                    // FRONT: raise the multiplying waves' issue priority over the producers'
+    int xcd_pairs;               // slice / tile-sequence mapping that keeps a tile's n_slices workgroups on one XCD (needs G % (8 n_slices) == 0)
 };
 
 __device__ __forceinline__ u32 c64_f2bf_rn(float f) {
@@ -93,6 +109,26 @@ __device__ __forceinline__ float c64_max_with_lane_xor1(float v) {
     asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
     return r;
 }
+typedef short c64_s16x2 __attribute__((ext_vector_type(2)));
+typedef u32 c64_u32x2 __attribute__((ext_vector_type(2)));
+// v_pk_max_i16 on two packed bf16 values (see the epilogue)
+__device__ __forceinline__ u32 c64_pkmax_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(c64_s16x2, a), __builtin_bit_cast(c64_s16x2, b)));
+}
+typedef u32 c64_u32x4 __attribute__((ext_vector_type(4)));
+// The epilogue's stores.  In the accumulator layout the lane (pixel, khalf) holds channels 8 g + 4 khalf + (0 .. 3) of the wave's 32 as
+// (lo[g], hi[g]) for g = 0 .. 3: 8-byte runs.  v_permlane32_swap trades them between the two lanes of a pixel (lane, lane + 32) so that
+// the khalf = 0 lane ends up with all 16 bytes of g = 0 / 2 and the khalf = 1 lane with those of g = 1 / 3: two 16-byte stores per
+// lane instead of four 8-byte ones -- the CU's vector memory pipe (these stores + the loader's LDS-DMA pieces) is what a tile of the
+// non-fused kernels waits for.  voff = the lane's pixel offset + 16 khalf (or out of range), soff = the tile origin.
+__device__ __forceinline__ void c64_store_runs(const u32 (&lo)[4], const u32 (&hi)[4], __amdgpu_buffer_rsrc_t ry, u32 voff, u32 soff) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const auto sl = __builtin_amdgcn_permlane32_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+        const auto sh = __builtin_amdgcn_permlane32_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+        if (!(SSDHIP_C64_ABLATE & 1)) __builtin_amdgcn_raw_buffer_store_b128(c64_u32x4{sl[0], sh[0], sl[1], sh[1]}, ry, voff + pr * 32, soff, 0);
+    }
+}
 __device__ __forceinline__ float c64_relu(float v) { return v <= 0.f ? 0.f : v; }     // NaN stays NaN, -0 -> +0 (as ssdhip_conv.hip)
 
 // one wave-wide 1 KiB LDS-DMA load (see ssdhip_conv.hip: inline asm so hipcc does not drain vmcnt before aliasing ds_reads)
@@ -100,6 +136,13 @@ __device__ __forceinline__ void c64_bload(u32 voff, i32x4 rsrc, u32 lds_dst, u32
     u32 keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+
+// one two-byte buffer load (zero-extended), not tracked by hipcc's wait-count insertion: the caller counts vmcnt
+__device__ __forceinline__ u32 c64_load_u16(u32 voff, i32x4 rsrc, u32 soff) {
+    u32 v;
+    asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
 }
 
 __device__ __forceinline__ i32x4 c64_rsrc(const void* base, int num_records) {
@@ -132,8 +175,16 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     constexpr unsigned OOB = 0x80000000u;
 
     const int G = (int)gridDim.x;
-    const int slice = (int)blockIdx.x % p.n_slices;
-    const int first = (int)blockIdx.x / p.n_slices, stride = G / p.n_slices;
+    // The n_slices workgroups that walk the SAME tile sequence (one per 64-channel output slice) read the same halos at about the same
+    // time.  Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2: with slice = blockIdx % n_slices the
+    // partners sat on different XCDs and every halo came from memory once per slice.  So partners share blockIdx % 8.
+    int slice = (int)blockIdx.x % p.n_slices, first = (int)blockIdx.x / p.n_slices;
+    const int stride = G / p.n_slices;
+    if (p.xcd_pairs) {
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        slice = j % p.n_slices;
+        first = xcd + 8 * (j / p.n_slices);
+    }
     if (first >= p.tiles) return;
     const int co0 = slice * 64;
 
@@ -227,7 +278,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
             hcoord[blk] = (u32)((hr << 8) | hc | (hp < HPX ? 0 : 0x10000));
         }
         // raw-load slots: element n = 64 i + lane of the patch = (pr, pc, ci); two-byte buffer loads, an out-of-range offset reads 0
-        const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x3), 0, p.B * p.H * p.W * 6, 0x00020000);
+        const i32x4 r3 = c64_rsrc(p.x3, p.B * p.H * p.W * 6);
         u32 rrel[NRAW], rco[NRAW];
 #pragma unroll
         for (int i = 0; i < NRAW; ++i) {
@@ -236,6 +287,9 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
             rrel[i] = n < PATCH ? (u32)(((pr * p.W) * 3 + rem) * 2) : OOB;
             rco[i] = (u32)((pr << 8) | pc);
         }
+        // (asm loads + a hand-counted wait in front of the patch stores a tile later: with the builtin hipcc converted / paired the
+        //  16-bit values right behind the loads and waited for them there -- one exposed memory round trip per tile, the largest
+        //  single item of this wave's 6 500 cycles per tile in the in-kernel timers of profiles/r04p1_*)
         auto request = [&](int tile, u32 (&raw)[NRAW]) {
             int b, h0, w0;
             tile_origin(tile, b, h0, w0);
@@ -244,76 +298,124 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
             if (inside) {                                                     // the tile's position is a scalar offset
                 const u32 soff = (u32)((((b * p.H + ph) * p.W + pw) * 3) * 2);
 #pragma unroll
-                for (int i = 0; i < NRAW; ++i) raw[i] = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r3, rrel[i], soff, 0);
+                for (int i = 0; i < NRAW; ++i) raw[i] = c64_load_u16(rrel[i], r3, soff);
             } else {
                 const int base = ((b * p.H + ph) * p.W + pw) * 6;             // may be negative: only added to offsets of in-image elements
 #pragma unroll
                 for (int i = 0; i < NRAW; ++i) {
                     const int pr = (int)(rco[i] >> 8) & 0xff, pc = (int)rco[i] & 0xff;
                     const bool ok = rrel[i] != OOB && (unsigned)(ph + pr) < (unsigned)p.H && (unsigned)(pw + pc) < (unsigned)p.W;
-                    raw[i] = (u32)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r3, ok ? (u32)(base + (int)rrel[i]) : OOB, 0, 0);
+                    raw[i] = c64_load_u16(ok ? (u32)(base + (int)rrel[i]) : OOB, r3, 0u);
                 }
             }
         };
+        C64_PROF_DECL
+        // every request is exactly NRAW loads and this wave issues no other VMEM operation: `newer` = a younger request is in flight
+        auto landed = [&](u32 (&raw)[NRAW], bool newer) {
+            if (newer) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRAW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) asm volatile("" : "+v"(raw[i]));
+        };
+        // Gathers of ALL the wave's blocks first, then all their MFMAs, then the epilogues: the LDS and matrix-pipe latencies of one block
+        // are covered by the other's work (the pipe is shared with the SIMD's multiplying wave, whose MFMAs run back to back).
         auto produce = [&](int tile, const u32 (&raw)[NRAW], int buf) {
             int b, h0, w0;
             tile_origin(tile, b, h0, w0);
 #pragma unroll
             for (int i = 0; i < NRAW; ++i) reinterpret_cast<unsigned short*>(patch)[64 * i + lane] = (unsigned short)raw[i];   // slots beyond the patch hold 0
             unsigned char* hb = lds + H_OFF + buf * HB;
+            bf16x8 bfr[MYB][2];
 #pragma unroll
-            for (int blk = 0; blk < MYB; ++blk) {
-                bf16x8 bfr[2];
+            for (int blk = 0; blk < MYB; ++blk)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     union { bf16x8 v; unsigned short u[8]; } t;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) t.u[j] = *reinterpret_cast<const unsigned short*>(patch + pbase[blk] + kofs[st][j]);
-                    bfr[st] = t.v;
+                    bfr[blk][st] = t.v;
                 }
-                const int hr = (int)(hcoord[blk] >> 8) & 0xff, hc = (int)hcoord[blk] & 0xff;
-                // only the very last block of 32 has lanes beyond the halo's pixels
-                const bool live = (blk + 1 < MYB) || !(hcoord[blk] & 0x10000);
-                const bool in_img = (unsigned)(h0 - 1 + hr) < (unsigned)p.H && (unsigned)(w0 - 1 + hc) < (unsigned)p.W;
-                f32x16 a1[2];
+            // The matrix pipe of this SIMD is shared with its multiplying wave, whose MFMAs are always ready and which wins the issue
+            // arbitration (older wave; raised priority): this wave's eight MFMAs used to sit out the multiplier's whole K loop (in-kernel
+            // timers, r04p5: 3 200 cycles in this section, the multipliers then waiting 1 000 at the barrier for the epilogue below).
+            // For these eight instructions the producer goes first; they cost the multiplier 256 cycles of pipe time per tile.
+            if (p.prio & 2) __builtin_amdgcn_s_setprio(3);
+            f32x16 a1[MYB][2];
+#pragma unroll
+            for (int blk = 0; blk < MYB; ++blk)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) a1[cb][v] = 0.f;
-                    a1[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[cb][0], bfr[0], a1[cb], 0, 0, 0);
+                    for (int v = 0; v < 16; ++v) a1[blk][cb][v] = 0.f;
+                    a1[blk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[cb][0], bfr[blk][0], a1[blk][cb], 0, 0, 0);
                 }
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) a1[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[cb][1], bfr[1], a1[cb], 0, 0, 0);
+            for (int blk = 0; blk < MYB; ++blk)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb) a1[blk][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[cb][1], bfr[blk][1], a1[blk][cb], 0, 0, 0);
+            if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
+            C64_PROF_MARK(2)
+            // bias, one rounding (as the separate kernel), conv1_1's ReLU on the rounded pair (v_pk_max_i16 with 0: the compare + select
+            // pairs and their hazard states were a third of this wave's instructions).  Halo pixels outside the image are conv1_2's
+            // zero padding; only border tiles have any (16 % of a 300 x 300 map), the others skip the masks.
+            auto finish = [&](auto edge) {
+                constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float o[4];
+                for (int blk = 0; blk < MYB; ++blk) {
+                    const int hr = (int)(hcoord[blk] >> 8) & 0xff, hc = (int)hcoord[blk] & 0xff;
+                    // only the very last block of 32 has lanes beyond the halo's pixels
+                    const bool live = (blk + 1 < MYB) || !(hcoord[blk] & 0x10000);
+                    const bool in_img = !EDGE || ((unsigned)(h0 - 1 + hr) < (unsigned)p.H && (unsigned)(w0 - 1 + hc) < (unsigned)p.W);
+                    const u32 keep = in_img ? 0xffffffffu : 0u;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = c64_relu(a1[cb][4 * g + e] + b1v[cb][4 * g + e]);   // conv1_1's ReLU; branch-free
-                        const u32 lo = c64_pack2(o[0], o[1]), hi = c64_pack2(o[2], o[3]);                    // one rounding, as the separate kernel
-                        if (live)
-                            *reinterpret_cast<uint2*>(hb + hdst[blk] + (cb * 32 + 8 * g) * 2) = make_uint2(in_img ? lo : 0u, in_img ? hi : 0u);
-                    }
-            }
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = a1[blk][cb][4 * g + e] + b1v[cb][4 * g + e];
+                            u32 lo = c64_pkmax_i16(c64_pack2(o[0], o[1]), 0u), hi = c64_pkmax_i16(c64_pack2(o[2], o[3]), 0u);
+                            if constexpr (EDGE) { lo &= keep; hi &= keep; }
+                            if (live) *reinterpret_cast<uint2*>(hb + hdst[blk] + (cb * 32 + 8 * g) * 2) = make_uint2(lo, hi);
+                        }
+                }
+            };
+            if (h0 >= 1 && w0 >= 1 && h0 - 1 + HR <= p.H && w0 - 1 + HC <= p.W) finish(std::false_type{});
+            else finish(std::true_type{});
+            C64_PROF_MARK(3)
         };
-        u32 raw_c[NRAW], raw_n[NRAW];
-        request(first, raw_c);
-        produce(first, raw_c, 0);
-        if (first + stride < p.tiles) request(first + stride, raw_c);
+        // Two register sets used alternately (the tile loop is unrolled by two by hand): the set requested in step i is stored into the
+        // patch in step i + 1 and never copied, so the only wait for it sits in front of those stores, a whole tile after the request.
+        u32 raw_a[NRAW], raw_b[NRAW];
+        request(first, raw_a);
+        landed(raw_a, false);
+        produce(first, raw_a, 0);
+        if (first + stride < p.tiles) request(first + stride, raw_a);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // halo of the first tile (+ the multipliers' weights) in place
         int buf = 0;
-        for (int tile = first; tile < p.tiles; tile += stride) {
-            const bool more = tile + stride < p.tiles;
-            if (!(SSDHIP_C64_ABLATE & 8) && tile + 2 * stride < p.tiles) request(tile + 2 * stride, raw_n);      // 8: idle producers
-            if (!(SSDHIP_C64_ABLATE & 8) && more) produce(tile + stride, raw_c, buf ^ 1);
+        auto step = [&](int tile, u32 (&cur)[NRAW], u32 (&nxt)[NRAW]) {
+            const bool req = !(SSDHIP_C64_ABLATE & 8) && tile + 2 * stride < p.tiles;                       // 8: idle producers
+            if (req) request(tile + 2 * stride, nxt);
+            C64_PROF_MARK(0)
+            if (!(SSDHIP_C64_ABLATE & 8) && tile + stride < p.tiles) {
+                landed(cur, req);
+                C64_PROF_MARK(1)
+                produce(tile + stride, cur, buf ^ 1);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            C64_PROF_MARK(4)
             __builtin_amdgcn_s_barrier();                // multipliers done with `buf`; halo of the next tile complete in the other one
-#pragma unroll
-            for (int i = 0; i < NRAW; ++i) raw_c[i] = raw_n[i];
+            C64_PROF_MARK(5)
+            C64_PROF_TILE
             buf ^= 1;
+        };
+        for (int tile = first; tile < p.tiles; tile += 2 * stride) {
+            step(tile, raw_a, raw_b);
+            if (tile + stride >= p.tiles) break;
+            step(tile + stride, raw_b, raw_a);
         }
+        if (wave == 4) { C64_PROF_FLUSH(16) }
         return;
       }
     }
@@ -370,23 +472,37 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // halo of the first tile (+ the multipliers' weights) in place
         int buf = 0;
+        C64_PROF_DECL
         for (int tile = first; tile < p.tiles; tile += stride) {
             if (tile + 2 * stride < p.tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");  // halo i+1 landed (this wave's pieces)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            C64_PROF_MARK(0)
             __builtin_amdgcn_s_barrier();                // the multipliers are done with buffer `buf`
+            C64_PROF_MARK(1)
             if (tile + 3 * stride < p.tiles) issue_halo(tile + 3 * stride, buf);
+            C64_PROF_MARK(2)
+            C64_PROF_TILE
             buf = buf + 1 == NB ? 0 : buf + 1;
         }
+        if (wave == 4) { C64_PROF_FLUSH(16) }
         return;
     }
 
-    if (p.prio) __builtin_amdgcn_s_setprio(2);           // the multipliers go first whenever they and a producer / loader wave of their SIMD can issue
+    if (p.prio & 1) __builtin_amdgcn_s_setprio(2);           // the multipliers go first whenever they and a producer / loader wave of their SIMD can issue
     // ---- fragment addresses: everything per-lane is fixed for the whole kernel -------------------------------------------
     const int q = wp * 32 + r31;                         // pixel slot of the lane: row pair q >> CS, column q & (CC-1)
     const int rp = q >> CS, col = q & (CC - 1);
     u32 bbase[2];
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) bbase[pi] = (u32)(H_OFF + ((2 * rp + pi) * HC + col) * 144 + khalf * 16);
+    // output: byte offset of the lane's pixel (pooled form: its pooled pixel) from the tile origin, + its 16-byte column of a 32-byte pair (c64_store_runs)
+    u32 ylane[2];
+    if constexpr (POOL) {
+        ylane[0] = ylane[1] = (u32)(((rp * p.Wo + (col >> 1)) * p.Cout) * 2 + khalf * 16);
+    } else {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) ylane[pi] = (u32)((((2 * rp + pi) * p.W + col) * p.Cout) * 2 + khalf * 16);
+    }
     u32 abase[4];
     {
         const int row = wc * 32 + r31;
@@ -421,6 +537,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     __builtin_amdgcn_s_barrier();
 
     int buf = 0;
+    C64_PROF_DECL
     for (int tile = first; tile < p.tiles; tile += stride) {
         const unsigned char* hb = lds + buf * HB;
 
@@ -454,30 +571,47 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        __builtin_amdgcn_s_barrier();                      // the loader wave arrives here once halo i+1 has landed; all four
-        buf = buf + 1 == NB ? 0 : buf + 1;                 // multipliers are done reading buffer `buf`, which it may now refill
-
-        // ---- epilogue (wave-private LDS stage: DS operations of one wave execute in order) ------------------------------
-        int b, h0, w0;
-        tile_origin(tile, b, h0, w0);
-        if constexpr (WREG) {                              // the lane's 16 bias values from the LDS table (registers hold the filters)
-#pragma unroll
+        if constexpr (WREG) {                              // the lane's 16 bias values from the LDS table (registers hold the filters),
+#pragma unroll                                             // requested ahead of the barrier so that they land while the wave waits there
             for (int g = 0; g < 4; ++g) {
                 const float4 t4 = *reinterpret_cast<const float4*>(lds + W_OFF + (wc * 32 + 8 * g + 4 * khalf) * 4);
                 bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
             }
         }
+        C64_PROF_MARK(0)
+        __builtin_amdgcn_s_barrier();                      // the loader wave arrives here once halo i+1 has landed; all four
+        buf = buf + 1 == NB ? 0 : buf + 1;                 // multipliers are done reading buffer `buf`, which it may now refill
+        C64_PROF_MARK(1)
+
+        // ---- epilogue, straight from the accumulator layout (round 4).  A lane holds, for its pixel, channels 8 g + 4 khalf + (0 .. 3)
+        //      of the wave's 32 for g = 0 .. 3: four 8-byte runs, and the (khalf = 0, 1) lane pair of a pixel makes each a 16-byte run.
+        //      So the values go out as four buffer_store_dwordx2 per accumulator block with NO transpose through LDS: the first
+        //      version staged every block through LDS for 16-byte stores -- write, wait, read, wait, 64-bit address arithmetic per
+        //      store -- and with one wave per SIMD all of it was MFMA idle time (in-kernel timers, profiles/r04p1_*: 1 700 - 2 400 of
+        //      a tile's 4 600 - 5 200 cycles).  L2 merges the partial lines; a tile writes 16 KB per ~3 000 cycles, nowhere near a
+        //      store-path limit.  Per 4 values: 2 packed bias adds, 2 packed conversions, 2 v_pk_max_i16 (ReLU on the rounded pair:
+        //      for bf16 bit patterns integer order is numeric order and -0 / negative values become +0, as c64_relu; +NaN stays NaN).
+        //      The store address is image base (descriptor) + tile origin (scalar) + a per-lane constant; pixels outside the map get
+        //      an out-of-range offset, which the buffer unit drops -- no branches. ------------------------------------------------
+        int b, h0, w0;
+        tile_origin(tile, b, h0, w0);
+        const u32 floor16 = p.relu ? 0u : 0x80008000u;
         if constexpr ((SSDHIP_C64_ABLATE & 2) != 0) {
             asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
         } else
         if constexpr (POOL) {
-            unsigned char* stage = lds + STAGE_OFF + wave * 2048;          // [16 pooled px][64 B]
+            const size_t img = (size_t)p.Ho * p.Wo * p.Cout * 2;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
+            const u32 sbase = (u32)((((h0 >> 1) * p.Wo + (w0 >> 1)) * p.Cout + co0 + wc * 32) * 2);
             const int hq = h0 + 2 * rp, wq = w0 + col;
-            // 2x2 maximum in registers, then bias + ReLU + rounding (monotonic: equals pooling the rounded activations).
-            // Interior tiles (all 128 pixels inside the image: 95 % of a 300x300 map) take the mask-free path.
+            const bool okp = (!(r31 & 1)) & (((h0 >> 1) + rp) < p.Ho) & ((wq >> 1) < p.Wo);
+            const u32 voff = ylane[0] | (okp ? 0u : OOB);
+            // 2x2 maximum on the float32 accumulators (vertical in-lane, horizontal by DPP), then bias, rounding, ReLU (monotonic:
+            // equals pooling the rounded activations).  Interior tiles (95 % of a 300x300 map) take the mask-free path.
             auto pooled = [&](auto edge) {
                 constexpr bool EDGE = decltype(edge)::value;
                 const bool has_below = !EDGE || hq + 1 < p.H, has_right = !EDGE || wq + 1 < p.W;
+                u32 lo[4], hi[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float o[4];
@@ -494,57 +628,36 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
                             v = below > v ? below : v;
                             v = c64_max_with_lane_xor1(v);
                         }
-                        v += bv[4 * g + e];
-                        o[e] = p.relu ? c64_relu(v) : v;
+                        o[e] = v + bv[4 * g + e];
                     }
-                    if (!(r31 & 1)) {
-                        const int px = r31 >> 1;
-                        *reinterpret_cast<uint2*>(stage + px * 64 + ((g ^ (px & 3)) << 4) + khalf * 8) =
-                            make_uint2(c64_pack2(o[0], o[1]), c64_pack2(o[2], o[3]));
-                    }
+                    lo[g] = c64_pkmax_i16(c64_pack2(o[0], o[1]), floor16);
+                    hi[g] = c64_pkmax_i16(c64_pack2(o[2], o[3]), floor16);
                 }
+                c64_store_runs(lo, hi, ry, voff, sbase);
             };
             if (h0 + 2 * RP <= p.H && w0 + CC <= p.W) pooled(std::false_type{});
             else pooled(std::true_type{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            {
-                const int px = lane >> 2, c = lane & 3;                    // 16 px x 4 chunks = 64 lanes
-                const int qe = wp * 32 + 2 * px;
-                const int ho = (h0 >> 1) + (qe >> CS), wo = (w0 + (qe & (CC - 1))) >> 1;
-                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 64 + ((c ^ (px & 3)) << 4));
-                if (!(SSDHIP_C64_ABLATE & 1) && ho < p.Ho && wo < p.Wo)
-                    *reinterpret_cast<uint4*>(p.y + ((size_t)(b * p.Ho + ho) * p.Wo + wo) * p.Cout + co0 + wc * 32 + c * 8) = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
-            unsigned char* stage = lds + STAGE_OFF + wave * 2048;          // [32 px][64 B], used once per accumulator block
+            const size_t img = (size_t)p.H * p.W * p.Cout * 2;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
+            const u32 sbase = (u32)(((h0 * p.W + w0) * p.Cout + co0 + wc * 32) * 2);
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
+                const bool ok = ((h0 + 2 * rp + pi) < p.H) & ((w0 + col) < p.W);
+                const u32 voff = ylane[pi] | (ok ? 0u : OOB);
+                u32 lo[4], hi[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[pi][4 * g + e] + bv[4 * g + e];
-                        o[e] = p.relu ? c64_relu(v) : v;
-                    }
-                    *reinterpret_cast<uint2*>(stage + r31 * 64 + ((g ^ (r31 & 3)) << 4) + khalf * 8) =
-                        make_uint2(c64_pack2(o[0], o[1]), c64_pack2(o[2], o[3]));
+                    lo[g] = c64_pkmax_i16(c64_pack2(acc[pi][4 * g] + bv[4 * g], acc[pi][4 * g + 1] + bv[4 * g + 1]), floor16);
+                    hi[g] = c64_pkmax_i16(c64_pack2(acc[pi][4 * g + 2] + bv[4 * g + 2], acc[pi][4 * g + 3] + bv[4 * g + 3]), floor16);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int idx = j * 64 + lane, px = idx >> 2, c = idx & 3;          // 32 px x 4 chunks
-                    const int qq = wp * 32 + px;
-                    const int h = h0 + 2 * (qq >> CS) + pi, w = w0 + (qq & (CC - 1));
-                    const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 64 + ((c ^ (px & 3)) << 4));
-                    if (!(SSDHIP_C64_ABLATE & 1) && h < p.H && w < p.W)
-                        *reinterpret_cast<uint4*>(p.y + ((size_t)(b * p.H + h) * p.W + w) * p.Cout + co0 + wc * 32 + c * 8) = v;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                c64_store_runs(lo, hi, ry, voff, sbase);
             }
         }
+        C64_PROF_MARK(2)
+        C64_PROF_TILE
     }
+    if (wave == 0) { C64_PROF_FLUSH(0) }
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
@@ -591,6 +704,7 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     if (G > 4096) G = 4096;
     G = (G / p.n_slices) * p.n_slices;
     if (G < p.n_slices) G = p.n_slices;
+    { const char* e = getenv("SSDHIP_C64_XCD"); p.xcd_pairs = (p.n_slices > 1 && G % (8 * p.n_slices) == 0 && !(e && atoi(e) == 0)) ? 1 : 0; }
     static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
 #define C64_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3, false, true>), dim3(G), dim3(C64_THREADS), 0, stream, p); \
                                     else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3>), dim3(G), dim3(C64_THREADS), 0, stream, p); } while (0)
@@ -619,7 +733,7 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     p.x = nullptr; p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.x3 = static_cast<const bf16_t*>(x3); p.w1 = static_cast<const bf16_t*>(w1); p.b1 = static_cast<const bf16_t*>(b1);
-    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // multipliers first (filters in LDS: 317 -> 296 us; equal since WREG, profiles/r03zd_*)
+    { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 3; }   // bit 0: multipliers above the producers (equal since WREG, profiles/r03zd_*); bit 1: the producers' own MFMAs above everything
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = 0; p.w_bytes = (int)wb;
@@ -637,6 +751,7 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     if (G > 4096) G = 4096;
     G = (G / p.n_slices) * p.n_slices;
     if (G < p.n_slices) G = p.n_slices;
+    { const char* e = getenv("SSDHIP_C64_XCD"); p.xcd_pairs = (p.n_slices > 1 && G % (8 * p.n_slices) == 0 && !(e && atoi(e) == 0)) ? 1 : 0; }
     static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
 #define C64F_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 2, true, true>), dim3(G), dim3(C64_FRONT_THREADS), 0, stream, p); \
                                      else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 2, true>), dim3(G), dim3(C64_FRONT_THREADS), 0, stream, p); } while (0)
@@ -648,3 +763,14 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
 #undef C64F_LAUNCH
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
+
+#ifdef SSDHIP_PROFILE
+// profiling build only (32 words): out[0..2] = multiplier wave 0's cycles in (K loop, barrier, epilogue), out[8] its tiles; out[16..] = wave 4's
+// (loader: wait, barrier, halo issue; producer: request, wait for the older request, block 0, block 1, LDS drain, barrier), out[24] its
+// tiles -- summed over workgroups since the last reset
+extern "C" int ssdhip_profile_read_c64(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_prof64), sizeof(g_prof64)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof64), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -45,6 +45,21 @@
 
 namespace ssdhip {
 
+// In-kernel phase timers, profiling build only (tools/prof_build.sh): shader cycles of waves 0 and 4 (the two waves of SIMD 0) in
+// (K loop, epilogue, end-of-tile barrier), summed over tiles and workgroups; read back with ssdhip_profile_read_convh.
+#ifdef SSDHIP_PROFILE
+__device__ unsigned long long g_profh[16];
+#define CH_PROF_DECL long long _pt = clock64(); long long _pa[4] = {0, 0, 0, 0}; int _pn = 0;
+#define CH_PROF_MARK(i) { const long long _t = clock64(); _pa[i] += _t - _pt; _pt = _t; }
+#define CH_PROF_TILE ++_pn;
+#define CH_PROF_FLUSH(base) if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_profh[(base) + _i], (unsigned long long)_pa[_i]); atomicAdd(&g_profh[(base) + 4], (unsigned long long)_pn); }
+#else
+#define CH_PROF_DECL
+#define CH_PROF_MARK(i)
+#define CH_PROF_TILE
+#define CH_PROF_FLUSH(base)
+#endif
+
 typedef unsigned short bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -459,6 +474,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         }
     };
 
+    CH_PROF_DECL
     for (;;) {
         if constexpr (PERSIST) has_next = tile_of(id + (int)gridDim.x, q0n, co0n);
         // The tile's bias: ONE dword per lane (lane l: channels 2 (l & 31), + 1 of the wave's 64), requested here -- ahead of the
@@ -487,6 +503,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         //      last (odd) slice: everything else in LDS may already hold the next tile's first slab and weights.  Two passes of 32
         //      positions per wave (4 KB, wave private: DS operations of one wave execute in order). ----------------------------------
         asm volatile("" : "+v"(bias_dw));                 // landed: the K loop's last counted wait is younger than the request
+        CH_PROF_MARK(0)
         if constexpr ((MODE & 512) != 0) {                 // ablation: no epilogue (the accumulators only stay alive)
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
             if constexpr (NPI == 4) asm volatile("" :: "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[1][2]), "v"(acc[1][3]));
@@ -802,13 +819,18 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             }
         }
         }
+        CH_PROF_MARK(1)
+        CH_PROF_TILE
         if (!has_next) break;
         __builtin_amdgcn_s_barrier();                    // the stage is a slab buffer again: the next tile's slice 1 lands there
+        CH_PROF_MARK(2)
         id += (int)gridDim.x;
         q0 = q0n;
         co0 = co0n;
         vbase += csteps;
     }
+    if (wave == 0) { CH_PROF_FLUSH(0) }
+    if (wave == 4) { CH_PROF_FLUSH(8) }
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
@@ -1104,3 +1126,12 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     }
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
+
+#ifdef SSDHIP_PROFILE
+// profiling build only: out[0..2] = wave 0's cycles in (K loop, epilogue, end-of-tile barrier), out[4] its tiles; out[8..12] the same for wave 4
+extern "C" int ssdhip_profile_read_convh(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_profh), sizeof(g_profh)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_profh), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
