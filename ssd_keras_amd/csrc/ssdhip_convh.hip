@@ -210,7 +210,8 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         }
     };
     constexpr bool STR = (MODE & 2048) != 0;             // the strided / cropped forms (os, ooff, Hs, Ws); otherwise the plain 'same' result
-    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? 2 : 8) * (X3 ? 2 : 1) * (NPI / 2);   // global stores a wave issues per epilogue
+    constexpr bool DIRECT = (MODE & 16384) != 0 && !X3;  // the epilogue stores from the accumulator layout (v_permlane32_swap), no LDS transpose
+    constexpr int NST = (MODE & (256 | 512)) ? 0 : (POOL ? (DIRECT ? 4 : 2) : 8) * (X3 ? 2 : 1) * (NPI / 2);   // global stores a wave issues per epilogue
     const u32 YC = X3 ? 2u * (u32)p.Cout : (u32)p.Cout;  // channels of a y row (X3: [hi | lo])
 
     // ---- per-lane load descriptors --------------------------------------------------------------------------------------
@@ -547,6 +548,59 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             p0 = ch_pkmax_i16(ch_pack2(s0, s1), floor16);
             p1 = ch_pkmax_i16(ch_pack2(s2, s3), floor16);
         };
+        // DIRECT: a lane holds channels ci 32 + 8 g + 4 khalf + (0 .. 3) of its position as (lo[g], hi[g]); v_permlane32_swap between the
+        // two lanes of a position (lane, lane + 32) leaves the khalf = 0 lane with the 16 bytes of g = 0 / 2 and the khalf = 1 lane with
+        // those of g = 1 / 3: two 16-byte stores per (ci, position block), at off = the position's byte offset + 16 khalf (or OOB).
+        auto store_runs = [&](const u32 (&lo)[4], const u32 (&hi)[4], const u32 off) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const auto sl = __builtin_amdgcn_permlane32_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+                const auto sh = __builtin_amdgcn_permlane32_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+                store16_at(make_uint4(sl[0], sh[0], sl[1], sh[1]), off + pr * 32);
+            }
+        };
+        if constexpr (POOL && DIRECT) {
+            // as the staged form below (rounded and activated first, pooled as 16-bit integers; float path without ReLU), the even lanes
+            // store their pooled pixel straight from the registers
+            static_assert(NPI == 2, "eight-wave form");
+            int b, h0, w0;
+            tile_origin(q0, b, h0, w0);
+            const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
+            const int ho = (h0 >> 1) + pair, wo = (w0 + col) >> 1;
+            const bool okp = (!(r31 & 1)) & (ho < p.Ho) & (wo < p.Wo);
+            const u32 off = (((u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64)) * 2u + (u32)khalf * 16u) | (okp ? 0u : OOB);
+            const u32 mrow1 = h0 + 2 * pair + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
+            const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                u32 lo[4], hi[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (p.relu) {
+                        u32 a0, a1, b0, b1;
+                        pack4(ci, 0, g, a0, a1);
+                        pack4(ci, 1, g, b0, b1);
+                        u32 v0 = ch_pkmax_i16(a0, b0 & mrow1) & mcol, v1 = ch_pkmax_i16(a1, b1 & mrow1) & mcol;
+                        lo[g] = ch_pkmax_i16(v0, (u32)__builtin_amdgcn_update_dpp(0, (int)v0, 0xB1, 0xf, 0xf, false));
+                        hi[g] = ch_pkmax_i16(v1, (u32)__builtin_amdgcn_update_dpp(0, (int)v1, 0xB1, 0xf, 0xf, false));
+                    } else {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[ci][0][4 * g + e];
+                            const float below = acc[ci][1][4 * g + e];
+                            if (has_below) v = below > v ? below : v;
+                            const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+                            if (has_right) v = right > v ? right : v;
+                            o[e] = v + bv[ci][4 * g + e];
+                        }
+                        lo[g] = ch_pack2(o[0], o[1]);
+                        hi[g] = ch_pack2(o[2], o[3]);
+                    }
+                }
+                store_runs(lo, hi, off + ci * 64);
+            }
+        } else
         if constexpr (POOL) {
             // Rounded and activated FIRST, pooled as 16-bit integers: after ReLU every value is non-negative, where integer order is
             // numeric order, so the 2 x 2 maximum is two v_pk_max_i16 per pair (vertical: the lane's two position blocks; horizontal:
@@ -613,6 +667,53 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (DIRECT) {
+            static_assert(NPI == 2, "eight-wave form");
+            u32 soff1[NPI];                              // byte offset of the lane's position in block pi (+ its 16-byte column), or OOB
+            {
+                const u32 cb = (u32)(co0 + wm * 64) * 2u + (u32)khalf * 16u;
+                if constexpr (G2) {
+                    int b, h0, w0;
+                    tile_origin(q0, b, h0, w0);
+#pragma unroll
+                    for (int pi = 0; pi < NPI; ++pi) {
+                        const int sl = wn * (16 * NPI) + (pi >> 1) * 32 + r31;
+                        const int hh = h0 + 2 * (sl >> CSH) + (pi & 1), ww = w0 + (sl & (TC - 1));
+                        soff1[pi] = ((u32)((b * H + hh) * W + ww) * (YC * 2u) + cb) | (((hh < H) & (ww < W)) ? 0u : OOB);
+                    }
+                } else {
+                    int q = q0 + wn * (32 * NPI) + r31;
+                    asm volatile("" : "+v"(q));          // after the K loop: more live registers inside it would spill
+#pragma unroll
+                    for (int pi = 0; pi < NPI; ++pi) {
+                        const int b = q / (H1 * W1);
+                        const int r = q - b * (H1 * W1);
+                        const int h = r / W1, w = r - h * W1;
+                        bool ok = (w < W) & (h < H) & (q < p.Q);
+                        u32 pix;
+                        if constexpr (STR) {
+                            const int sh = p.os - 1;
+                            const int hh = h - p.ooff, ww = w - p.ooff;
+                            const int ho = hh >> sh, wo = ww >> sh;
+                            ok = ok & ((hh | ww) >= 0) & !((hh | ww) & sh) & (ho < p.Hs) & (wo < p.Ws);
+                            pix = (u32)((b * p.Hs + ho) * p.Ws + wo);
+                        } else {
+                            pix = (u32)((b * H + h) * W + w);
+                        }
+                        soff1[pi] = (pix * (YC * 2u) + cb) | (ok ? 0u : OOB);
+                        q += 32;
+                    }
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < NPI; ++pi)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    u32 lo[4], hi[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) pack4(ci, pi, g, lo[g], hi[g]);
+                    store_runs(lo, hi, soff1[pi] + ci * 64);
+                }
         } else {
             const int c = lane & 7;
             u32 soff[NPI][4];                            // byte offsets of the lane's 16-byte stores (OOB: nothing to store)
@@ -1115,6 +1216,12 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
         case 8320: convh_launch<128 | 8192>(p, geom, pool, cu_count, stream); break;
         case 9344: convh_launch<1152 | 8192>(p, geom, pool, cu_count, stream); break;
         case 12416: convh_launch<128 | 8192 | 4096>(p, geom, pool, cu_count, stream); break;
+        // + 16384: the epilogue stores from the accumulator layout (v_permlane32_swap, 32-byte runs per position and instruction) instead
+        // of transposing through LDS for 128-byte runs -- what paid on the one-wave-per-SIMD Cin = 64 kernels (ssdhip_conv64.hip) is
+        // 1-3 % SLOWER here on every layer (profiles/r04p8_slab_direct_epilogue_stores_negative.txt): with two waves per SIMD the LDS
+        // round trips are covered, and the four-times-more cache lines per store instruction are not.
+        case 16512: convh_launch<128 | 16384>(p, geom, pool, cu_count, stream); break;
+        case 17536: convh_launch<1152 | 16384>(p, geom, pool, cu_count, stream); break;
         // ablations (wrong results by construction): tools/ablate_convh.py, tools/ablate_convh2.py
         case 129: convh_launch<129>(p, geom, pool, cu_count, stream); break;                               // no loads in the K loop
         case 130: convh_launch<130>(p, geom, pool, cu_count, stream); break;                               // no fragment reads

@@ -32,8 +32,8 @@ def report(name, fn):
     g = read(lib)
     n0, n4 = max(g[8], 1), max(g[24], 1)
     print("%-16s %.1f us | multiplier tiles %d: K loop %.0f  barrier %.0f  epilogue %.0f cycles/tile | wave 4 tiles %d: %s"
-          % (name, a.elapsed_time(e) * 1e3, g[8], g[0] / n0, g[1] / n0, g[2] / n0, g[24], "  ".join("%.0f" % (v / n4) for v in g[16:22])), flush=True)
-    # wave 4 columns: loader = wait for halo | barrier | issue; producer = request | wait older request | block 0 | block 1 | LDS drain | barrier
+          % (name, a.elapsed_time(e) * 1e3, g[8], g[0] / n0, g[1] / n0, g[2] / n0, g[24], "  ".join("%.0f" % (v / n4) for v in g[16:24])), flush=True)
+    # wave 4 columns: loader = wait for halo | barrier | issue; producer = request | wait older request | MFMAs | epilogue | LDS drain | barrier | patch stores | gathers
 
 
 x3 = torch.randn((32, 300, 300, 3), device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
