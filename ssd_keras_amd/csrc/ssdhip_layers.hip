@@ -113,6 +113,65 @@ __global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint4* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pool5 (MaxPooling2D(3, 1, 'same'), models/keras_ssd300.py:296, keras_ssd512.py twin) when a 64-channel slab of the whole map fits
+// in LDS: one workgroup per (image, 64 channels) reads its slab ONCE (H W x 128 bytes) and takes the nine-element maxima from LDS.
+// The per-output kernel above reads every input nine times through L1 / L2: 106 MB of cache traffic for an 11.8 MB map, 27 us
+// in the batch-32 step (r04n timeline) -- bound by what a CU can pull from L2.
+// ---------------------------------------------------------------------------------------------------------------
+// The maxima are taken on an ORDER-PRESERVING 16-bit integer image of the values (one v_pk_max_i16 per pair and window element, the
+// float compare + select of bfmax8 is ~15 instructions per pair): a bf16 pattern v maps to v ^ ((v >> 15) & 0x7fff) as a signed
+// 16-bit integer -- negative values in reversed magnitude order below the positive ones -- after NaNs have lost their sign, which
+// puts every NaN above +inf: a NaN in the window wins, as in max_pool2d.  (-0 maps below +0: a window of zeros of both signs gives
+// +0 where the compare-based maximum keeps the first one; equal as numbers.)  The map is applied once per element on the way into
+// LDS and inverted once per output.
+constexpr int POOL3_THREADS = 1024;
+typedef short l_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short l_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 l_ordered2(u32 v) {
+    const u32 mag = v & 0x7fff7fffu;
+    // 1 in a half that holds a NaN (magnitude above 0x7f80), by a saturating 16-bit subtraction
+    const l_u16x2 over = __builtin_elementwise_sub_sat(__builtin_bit_cast(l_u16x2, mag), __builtin_bit_cast(l_u16x2, 0x7f807f80u));
+    const l_u16x2 one = __builtin_elementwise_min(over, __builtin_bit_cast(l_u16x2, 0x00010001u));
+    v &= ~(__builtin_bit_cast(u32, one) << 15);            // NaNs become positive
+    const u32 neg = __builtin_bit_cast(u32, __builtin_bit_cast(l_s16x2, v) >> 15);   // 0xffff in a negative half
+    return v ^ (neg & 0x7fff7fffu);
+}
+__device__ __forceinline__ u32 l_unordered2(u32 t) {
+    const u32 neg = __builtin_bit_cast(u32, __builtin_bit_cast(l_s16x2, t) >> 15);
+    return t ^ (neg & 0x7fff7fffu);
+}
+__device__ __forceinline__ u32 l_pkmax_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(l_s16x2, a), __builtin_bit_cast(l_s16x2, b)));
+}
+__global__ __launch_bounds__(POOL3_THREADS) void pool3x3s1_slab_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int H, int W,
+                                                                       u32 cvec, u32 slabs) {
+    extern __shared__ uint4 pool3_tile[];                  // [H W][8 chunks of 8 channels], order-preserving integers
+    const u32 b = blockIdx.x / slabs, slab = blockIdx.x - b * slabs;
+    const u32 n = (u32)(H * W) * 8u;
+    const size_t base = (size_t)b * (size_t)(H * W) * cvec + slab * 8u;
+    for (u32 i = threadIdx.x; i < n; i += POOL3_THREADS) {
+        const uint4 v = x[base + (size_t)(i >> 3) * cvec + (i & 7u)];
+        pool3_tile[i] = make_uint4(l_ordered2(v.x), l_ordered2(v.y), l_ordered2(v.z), l_ordered2(v.w));
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += POOL3_THREADS) {
+        const int px = (int)(i >> 3), c = (int)(i & 7u);
+        const int h = px / W, w = px - h * W;
+        uint4 best = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);      // below every value
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                const int hi = h + dh, wi = w + dw;
+                const bool in = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W);
+                const uint4 v = pool3_tile[(in ? hi * W + wi : px) * 8 + c];               // outside the map: the centre again (no effect)
+                best = make_uint4(l_pkmax_i16(v.x, best.x), l_pkmax_i16(v.y, best.y), l_pkmax_i16(v.z, best.z), l_pkmax_i16(v.w, best.w));
+            }
+        y[base + (size_t)px * cvec + (u32)c] = make_uint4(l_unordered2(best.x), l_unordered2(best.y), l_unordered2(best.z), l_unordered2(best.w));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // L2Normalization: y = x * rsqrt(max(sum_c x^2, 1e-12)) * gamma[c]; one wave per pixel, float32 math.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma,
@@ -213,6 +272,15 @@ extern "C" int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias
     const long long total = (long long)B * Ho * Wo * (C / 8);
     if (total > 0x7fffffffLL || (long long)B * H * W * (C / 8) > 0x7fffffffLL) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) return SSDHIP_E_BADARG;
+    if (kernel == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && !bias && !relu && C % 64 == 0 && (long long)H * W * 128 <= 160 * 1024 && x != y) {
+        const size_t lds = (size_t)H * W * 128;
+        static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(pool3x3s1_slab_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (lds <= 64 * 1024 || big_lds) {
+            hipLaunchKernelGGL(pool3x3s1_slab_kernel, dim3((unsigned)(B * (C / 64))), dim3(POOL3_THREADS), lds, stream, static_cast<const uint4*>(x),
+                               static_cast<uint4*>(y), H, W, (u32)(C / 8), (u32)(C / 64));
+            return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+        }
+    }
     hipLaunchKernelGGL(bias_act_maxpool_kernel, dim3(grid_for((size_t)total, 256)), dim3(256), 0, stream,
                        static_cast<const uint4*>(x), static_cast<const uint4*>(bias), static_cast<uint4*>(y), B, H, W, (u32)(C / 8),
                        kernel, stride, pad, Ho, Wo, relu);

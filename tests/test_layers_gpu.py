@@ -36,7 +36,8 @@ def test_bias_act(env, shape):
 
 @pytest.mark.parametrize("shape,k,s,p,ceil", [((2, 64, 75, 75), 2, 2, 0, True), ((2, 64, 300, 300), 2, 2, 0, True),
                                               ((2, 512, 19, 19), 3, 1, 1, False), ((1, 32, 37, 37), 2, 2, 0, False),
-                                              ((2, 16, 5, 3), 2, 2, 0, True), ((1, 8, 4, 4), 3, 2, 1, True)])
+                                              ((2, 16, 5, 3), 2, 2, 0, True), ((1, 8, 4, 4), 3, 2, 1, True),
+                                              ((1, 64, 32, 32), 3, 1, 1, False), ((2, 128, 1, 5), 3, 1, 1, False), ((32, 512, 19, 19), 3, 1, 1, False)])
 def test_bias_act_maxpool(env, shape, k, s, p, ceil):
     torch, F, nat = env
     x = _fmap(torch, *shape, seed=2)
@@ -223,3 +224,26 @@ def test_decode_from_heads_equals_assemble_then_decode(env, fast):
                                                          [None, locs[1], None, locs[3], None, None])):
         got = layer.forward_from_heads(cs, ls, cb, lb, nbs, av, C)
         assert torch.equal(got, want)
+
+
+def test_pool5_slab_kernel_special_values(env):
+    """pool3x3s1_slab_kernel (csrc/ssdhip_layers.hip; MaxPooling2D(3, 1, 'same'), models/keras_ssd300.py:296) takes its maxima on an
+    order-preserving integer image of the bf16 values: negative values, infinities, NaNs of both signs and zeros of both signs against
+    max_pool2d (a NaN anywhere in the window gives NaN; the sign of a zero result is not compared)."""
+    torch, F, nat = env
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn((3, 64, 19, 19), generator=g, device="cuda") * 3).to(torch.bfloat16)
+    x[0, :, 3, 4] = float("nan")
+    x[0, 5, 10, 10] = float("inf")
+    x[1, :, 0, 0] = -float("inf")
+    x[1, 7, 18, 18] = float("nan")
+    x[2, :32] = -x[2, :32].abs()                                             # all-negative windows
+    x[2, 40] = 0.0
+    x[2, 40, ::2] = -0.0
+    neg_nan = torch.tensor([0xffc1 - 65536], dtype=torch.int16, device="cuda").view(torch.bfloat16)
+    x[1, 9, 5, 5] = neg_nan[0]
+    x = x.contiguous(memory_format=torch.channels_last)
+    want = F.max_pool2d(x.float(), 3, 1, 1)
+    got = nat.bias_act_maxpool(x, None, 3, 1, 1, False, relu=False).float()
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0))
