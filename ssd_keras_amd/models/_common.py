@@ -387,7 +387,7 @@ class SSDModel(nn.Module):
                     hit = next(iter(candidates))
                     SSDModel._conv_choice[key] = hit
                     return hit
-            best, hit = None, None
+            best, hit, times = None, None, {}
             # the library candidate goes last: when MIOpen falls back to its naive solver for a shape (tens of ms per call) the
             # single-call probe below drops it without paying for the bursts
             for name in sorted(candidates, key=lambda n: n == "miopen"):
@@ -410,8 +410,16 @@ class SSDModel(nn.Module):
                     b.record()
                     b.synchronize()
                     t = a.elapsed_time(b) if t is None else min(t, a.elapsed_time(b))
+                times[name] = t
                 if best is None or t < best:
                     best, hit = t, name
+            # Near-ties go to the deeper-pipelined form: a back-to-back burst is L2-warm and host-paced, and on fc6 / conv6_1 it has put
+            # the two-stage kernel a few per cent ahead of the three-stage one that is 10-25 % faster inside the step
+            # (profiles/r04s_step_timeline.json against r04n: fc6 142 vs 128 us, conv6_1 28 vs 22 us).
+            for name in ("halo", "igemm5", "igemm6"):
+                if name in times and times[name] <= 1.08 * best:
+                    hit = name
+                    break
             SSDModel._conv_choice[key] = hit
         return hit
 
