@@ -49,7 +49,16 @@ class L2Normalization(nn.Module):
         if (self.fused_inference and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and x.shape[1] % 8 == 0):
             from .. import _native as nat          # one pass in libssdhip (csrc/ssdhip_layers.hip) instead of seven kernels
-            return nat.l2_normalize(x, self.gamma)
+            g = self.gamma
+            if g.dtype != torch.float32:           # a bf16 model: the kernel's float32 gamma is converted once, not once per step
+                key = (g.data_ptr(), g._version)
+                hit = self.__dict__.get("_gamma32")
+                if hit is None or hit[0] != key:
+                    hit = (key, g.detach().float().contiguous())
+                    if not torch.cuda.is_current_stream_capturing():
+                        self.__dict__["_gamma32"] = hit
+                g = hit[1]
+            return nat.l2_normalize(x, g)
         if self.fused_inference and x.is_cuda and x.dim() == 4:
             from .. import _native as nat
             if nat.l2_normalize_supported(x):               # the float32 model, and the training step in either dtype
