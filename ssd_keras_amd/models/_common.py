@@ -416,10 +416,12 @@ class SSDModel(nn.Module):
             # Near-ties go to the deeper-pipelined form: a back-to-back burst is L2-warm and host-paced, and on fc6 / conv6_1 it has put
             # the two-stage kernel a few per cent ahead of the three-stage one that is 10-25 % faster inside the step
             # (profiles/r04s_step_timeline.json against r04n: fc6 142 vs 128 us, conv6_1 28 vs 22 us).
-            for name in ("halo", "igemm5", "igemm6"):
-                if name in times and times[name] <= 1.08 * best:
-                    hit = name
-                    break
+            # (plain convolutions only: among the pooled forms "halo" is the UNFUSED slab kernel + a pooling pass.)
+            if key and key[0] == "act":
+                for name in ("halo", "igemm6", "igemm5"):           # fc6 in the step: igemm6 128 us, igemm 142, igemm5 ~165 (r04n / r04s / r04zz)
+                    if name in times and times[name] <= 1.08 * best:
+                        hit = name
+                        break
             SSDModel._conv_choice[key] = hit
         return hit
 
