@@ -403,9 +403,9 @@ class SSDModel(nn.Module):
                     if a.elapsed_time(b) > 3.0 * best / 4.0:
                         continue
                 t = None
-                for _ in range(2):                       # best of two bursts of four: one noisy burst does not decide a layer
+                for _ in range(3):                       # best of three bursts of six: one noisy burst does not decide a layer
                     a.record()
-                    for _ in range(4):
+                    for _ in range(6):
                         fn()
                     b.record()
                     b.synchronize()
