@@ -486,6 +486,14 @@ int ssdhip_image_resize_u8(const void* x, void* y, int B, int H, int W, int Ho, 
 int ssdhip_image_hist_u8(const void* x, long long n_pixels, int C, int channel, unsigned int* hist_dev, void* stream);
 int ssdhip_image_lut_u8(const void* x, void* y, long long n_values, int C, int channel_mask, const void* table_dev, void* stream);
 
+/* 3x3 'same' convolution with any dilation on SMALL maps (H * W <= 384 pixels), one image per tile with its 64-channel slices resident in
+ * LDS and the dilated taps as per-lane addresses (csrc/ssdhip_convimg.hip).  Replaces Conv2D(1024, (3, 3), dilation_rate=(6, 6),
+ * activation='relu', padding='same') -- fc6, models/keras_ssd300.py:298 -- on the 19 x 19 map; same K order, hence the same bits, as
+ * ssdhip_conv2d_same_nhwc_bf16.  x [B, H, W, Cin] bf16, weight [Cout, 3, 3, Cin] bf16, bias [Cout] bf16 or NULL, y [B, H, W, Cout] bf16;
+ * Cin % 64 == 0, Cout % 128 == 0, 1 <= dilation <= 16.  SSDHIP_E_BADARG for any other geometry. */
+int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                                   int dilation, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

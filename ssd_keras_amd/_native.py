@@ -566,6 +566,35 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
+def conv3x3_image_supported(x, weight, dilation=1):
+    """Geometry of conv3x3_image: 3x3 filters, H * W <= 384 pixels, Cin % 64 == 0, Cout % 128 == 0, 1 <= dilation <= 16."""
+    b, cin, h, w = x.shape
+    cout, cin_w, kh, kw = weight.shape
+    return kh == 3 and kw == 3 and cin_w == cin and h * w <= 384 and cin % 64 == 0 and cout % 128 == 0 and 1 <= int(dilation) <= 16
+
+
+def conv3x3_image(x, weight, bias, dilation=1, relu=True):
+    """3x3 'same' convolution with any dilation on a small map, one image per tile (csrc/ssdhip_convimg.hip: fc6).  Layouts as
+    conv2d_same; bit-identical to it."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_convimg_bound", False):
+        lib.ssdhip_conv3x3_image_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_image_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+        lib._convimg_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or kh != 3 or kw != 3:
+        raise SsdHipError("weight must be bfloat16 (Cout, %d, 3, 3)" % cin)
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_image_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, int(dilation), int(bool(relu)),
+                                                current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_image_nhwc_bf16")
+    return y
+
+
 def conv_chain_pack(weight):
     """[Cout, Cin, k, k] bfloat16 (channels_last) filters in the fragment order `conv_chain` streams; None if the geometry is not supported."""
     torch = _torch()

@@ -1,0 +1,296 @@
+// ssdhip_convimg.hip -- 3x3 'same' convolution with ANY dilation on small maps (H W <= 384 pixels: fc6 of models/keras_ssd300.py:298,
+// Conv2D(1024, (3, 3), dilation_rate=(6, 6)) on the 19 x 19 x 512 map behind pool5) + bias + ReLU, gfx950, bf16 NHWC, float32 accumulation.
+//
+// Why its own kernel.  The slab kernel (ssdhip_convh.hip) turns a tap into ONE byte displacement by walking a padded position grid; with
+// dilation 6 that grid is 1.7 x the map.  The implicit-GEMM kernels (ssdhip_conv.hip) gather every tap's pixels again: 16 KB from L2 into
+// LDS per MFLOP against the slab kernel's 4.7 -- fc6 runs at a third of the MFMA peak there, bound by what a CU pulls from L2.
+// Here a tile is ONE IMAGE x 128 output channels:
+//   * the 64-channel slice of the WHOLE image sits in LDS (H W rows of 144 bytes: 128 data + 16 pad, double buffered; the pad makes the
+//     16-byte fragment reads of 32 consecutive pixels conflict-free without a swizzle term, as in ssdhip_conv64.hip);
+//   * a tap is a per-lane ADDRESS: pixel (h, w) reads row (h + d dh, w + d dw) of the slice, or the slice's ZERO ROW when that lies outside
+//     the map -- 9 taps x 3 pixel blocks = 27 address registers per lane, computed once; no border masks, no padded grid;
+//   * the filters of a (slice, tap) step stream through a three-stage ring of 16 KB stages, requested two steps ahead (slab kernel);
+//   * SSD300's fc6 at batch 32 is 32 images x 8 channel tiles = 256 tiles for 256 CUs; the 8 tiles of an image share an XCD (its L2 holds
+//     the image once).
+// Eight waves = 2 (64 output channels) x 4 (96 pixels = three 32-pixel MFMA blocks; 361 pixels pad to 384): six MFMAs per two filter and
+// three pixel fragments, 0.83 KB of LDS reads per MFMA (slab kernel: 1 KB).  One barrier per (slice, tap) step.
+// K order: slices outer, taps, 16-channel blocks -- the order of every other convolution kernel of the library, so the result is
+// bit-identical to theirs (tests/test_conv_gpu.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CI_THREADS = 512;
+constexpr int CI_PX = 384;                               // pixels of a tile (12 blocks of 32)
+constexpr int CI_ROW = 144;                              // bytes of a pixel row in LDS
+constexpr int CI_SLAB = (CI_PX + 1) * CI_ROW;            // + the zero row
+constexpr int CI_ZERO = CI_PX * CI_ROW;                  // offset of the zero row inside a slab buffer
+constexpr int CI_WST = 128 * 128;                        // a filter stage: [128 co][64 ci] bf16
+constexpr int CI_NW = 3;                                 // ring stages
+constexpr int CI_W0 = 2 * CI_SLAB;                       // LDS: slab 0 | slab 1 | ring | dump
+constexpr int CI_DUMP = CI_W0 + CI_NW * CI_WST;          // 1 KB that absorbs the dummy requests (every wave issues the same count per step)
+constexpr int CI_LDS = CI_DUMP + 1024;
+static_assert(CI_LDS <= 160 * 1024, "LDS budget");
+static_assert(CI_SLAB % 16 == 0, "slab buffers are 16-byte aligned");
+
+struct ConvImgParams {
+    const bf16_t* x;             // [B, H, W, Cin]
+    const bf16_t* w;             // [Cout, 3, 3, Cin]
+    const bf16_t* bias;          // [Cout] or null
+    bf16_t* y;                   // [B, H, W, Cout]
+    int B, H, W, Cin, Cout, dil, relu;
+    int n_cot;                   // Cout / 128
+    int xcd_map;                 // the channel tiles of an image on one XCD (needs n_cot == 8 or a tile count that is a multiple of 8 n_cot)
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 ci_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ci_f32x2 __attribute__((ext_vector_type(2)));
+typedef short ci_s16x2 __attribute__((ext_vector_type(2)));
+typedef u32 ci_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32 ci_pack2(float a, float b) {
+    const ci_f32x2 v = {a, b};
+    return __builtin_bit_cast(u32, __builtin_convertvector(v, ci_bf16x2));
+}
+__device__ __forceinline__ u32 ci_pkmax_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(ci_s16x2, a), __builtin_bit_cast(ci_s16x2, b)));
+}
+// one wave-wide 1 KiB LDS-DMA load: lane L writes 16 bytes at lds_dst + 16 L from base(rsrc) + voff (zeros if out of range)
+__device__ __forceinline__ void ci_bload(u32 voff, i32x4 rsrc, u32 lds_dst) {
+    u32 keep;
+    lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ i32x4 ci_rsrc(const void* base, u32 num_records) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    i32x4 r;
+    r.x = (int)(u32)a;
+    r.y = (int)((u32)(a >> 32) & 0xffffu);
+    r.z = (int)num_records;
+    r.w = 0x00020000;
+    return r;
+}
+#endif
+
+__global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[CI_LDS];
+    constexpr unsigned OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;             // 64 output channels x 96 pixels per wave
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int HW = p.H * p.W;
+
+    // ---- tile: image b, channel tile ct ---------------------------------------------------------------------------------------
+    int b, ct;
+    if (p.xcd_map) {                                     // blockIdx & 7 = the XCD (round-robin dispatch): an image's channel tiles share it
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        ct = j % p.n_cot;
+        b = xcd + 8 * (j / p.n_cot);
+    } else {
+        b = (int)blockIdx.x / p.n_cot;
+        ct = (int)blockIdx.x - b * p.n_cot;
+    }
+    if (b >= p.B) return;
+    const int co0 = ct * 128;
+    const int n_slices = p.Cin >> 6, n_steps = n_slices * 9;
+
+    // ---- zero rows, descriptors ---------------------------------------------------------------------------------------------------
+    if (tid < 2 * (CI_ROW / 4)) reinterpret_cast<u32*>(lds + (tid / (CI_ROW / 4)) * CI_SLAB + CI_ZERO)[tid % (CI_ROW / 4)] = 0u;
+    const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * p.Cin, (u32)((size_t)HW * p.Cin * 2));
+    const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * 9 * p.Cin, (u32)((size_t)128 * 9 * p.Cin * 2));
+
+    // ---- request plan.  Every wave issues exactly THREE LDS-DMA pieces per step, in this order: [two filter pieces of step i + 2 | one slab
+    //      piece of the next slice]; a request that has nothing to fetch goes out of range into the dump area.  So `s_waitcnt vmcnt(4)` at
+    //      the top of step i leaves the three requests of step i - 1 and the slab piece of step i - 2 in flight: the filters of step i
+    //      (issued at step i - 2) and every slab piece issued up to step i - 3 have landed -- a slice's pieces go out at its taps 0 .. 6
+    //      (9 HW / 64 <= 54 pieces, eight per tap), three steps and more ahead of the next slice's first step.  (Waiting for the previous
+    //      step's slab piece -- the first version -- exposed a memory round trip per step.)
+    //      slab: slot n = 64 piece + lane -> pixel n / 9, 16-byte chunk n % 9 (8 = the row's pad: not fetched).
+    //      filters of (slice s, tap t): [128 co][64 ci], piece = 8 rows; row r, chunk c at position c ^ ((r >> 1) & 7) --------------------
+    u32 wrel[2];                                         // byte offset of the lane's slot in filter piece 2 wave + i, (slice 0, tap 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + (lane >> 3);
+        const int j = (lane & 7) ^ ((row >> 1) & 7);
+        wrel[i] = (u32)((row * 9 * p.Cin) * 2 + j * 16);
+    }
+    // slab piece (t 8 + wave) of `slice` into buffer `buf` (or a dummy when the slice does not exist / the piece lies beyond the map)
+    auto issue_slab = [&](const int slice, const int t, const int buf) {
+        const int piece = t * 8 + wave, n = piece * 64 + lane;
+        const int px = n / 9, c = n - 9 * px;
+        const bool ok = (slice < n_slices) & (px < HW) & (c < 8);
+        const bool any = (slice < n_slices) & (piece * 64 < 9 * HW);          // wave-uniform: the piece holds at least one slot of the map
+        ci_bload(ok ? (u32)((px * p.Cin + slice * 64) * 2 + c * 16) : OOB, rx, any ? lds0 + buf * CI_SLAB + piece * 1024 : lds0 + CI_DUMP);
+    };
+    // filters of step `wstep` = (slice, tap) into ring stage `stage`
+    auto issue_filters = [&](const int wstep, const int stage) {
+        const bool wok = wstep < n_steps;
+        const int ws = wstep / 9, wt = wstep - 9 * ws;
+        const u32 wo = (u32)((wt * p.Cin + ws * 64) * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            ci_bload(wok ? wrel[i] + wo : OOB, rw, wok ? lds0 + CI_W0 + stage * CI_WST + (2 * wave + i) * 1024 : lds0 + CI_DUMP);
+    };
+
+    // ---- fragment addresses -----------------------------------------------------------------------------------------------------------
+    u32 abase[4];                                        // filter stage 0: row = channel, chunk (2 kk + khalf) ^ ((row >> 1) & 7); + 32 rows for the second block
+    {
+        const int row = wm * 64 + r31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) abase[kk] = (u32)(CI_W0 + row * 128 + (((2 * kk + khalf) ^ ((row >> 1) & 7)) << 4));
+    }
+    u32 baddr[9][3];                                     // current slab buffer: row of the tap's source pixel (or the zero row) + the lane's K half
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+        const int q = wn * 96 + pi * 32 + r31;
+        const int h = q / p.W, w = q - h * p.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h + p.dil * (t / 3 - 1), ww = w + p.dil * (t % 3 - 1);
+            const bool ok = (q < HW) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+            baddr[t][pi] = (u32)((ok ? (hh * p.W + ww) * CI_ROW : CI_ZERO) + khalf * 16);
+        }
+    }
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
+
+    // ---- prologue: the whole slab of slice 0 (its nine piece rounds), filters of steps 0 and 1 -------------------------------------
+#pragma unroll
+    for (int t = 0; t < 9; ++t) issue_slab(0, t, 0);
+    issue_filters(0, 0);
+    issue_filters(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- K loop: slices outer (runtime), the nine taps unrolled (the tap selects registers and ring stages at compile time) --------------
+    // Fragment reads run one 16-channel block ahead of the MFMAs through a two-slot register ring (the sched_barriers pin the order: hipcc
+    // left to itself sinks every read next to its use).  The PIXEL fragments of a step's first block are read before the step's barrier
+    // (the slab does not change inside a slice; behind a slice boundary they come from the new buffer, complete since three steps);
+    // the FILTER fragments only behind it.
+    bf16x8 fa[2][2], fb[2][3];
+    auto read_b = [&](const int t, const int kk, const int slot) {
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) fb[slot][pi] = *reinterpret_cast<const bf16x8*>(lds + baddr[t][pi] + kk * 32);
+    };
+    auto read_a = [&](const int t, const int kk, const int slot) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) fa[slot][ci] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + (t % CI_NW) * CI_WST + ci * (32 * 128));
+    };
+    read_b(0, 0, 0);
+    for (int s = 0; s < n_slices; ++s) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // the filters of this step (and the slab of this slice) have landed for this wave's share; the barrier makes that true for
+            // all waves and tells that everybody has finished the previous step (whose filter stage and, behind a slice boundary, whose
+            // slab buffer the requests below overwrite)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            read_a(t, 0, 0);
+            issue_filters(s * 9 + t + 2, (t + 2) % CI_NW);               // (9 s + t + 2) % 3 == (t + 2) % 3
+            issue_slab(s + 1, t, (s + 1) & 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < 3) { read_a(t, kk + 1, (kk + 1) & 1); read_b(t, kk + 1, (kk + 1) & 1); }
+                else if (t < 8) read_b(t + 1, 0, 0);                     // (t == 8: after the buffer flip below)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int pi = 0; pi < 3; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][ci], fb[kk & 1][pi], acc[ci][pi], 0, 0, 0);
+            }
+        }
+        // the next slice lives in the other slab buffer
+        const u32 flip = (s & 1) ? (u32)(-CI_SLAB) : (u32)CI_SLAB;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) baddr[t][pi] += flip;
+        read_b(0, 0, 0);                                 // the next slice's first pixel fragments (its slab is complete since taps 0 .. 6)
+    }
+
+    // ---- epilogue: bias, one rounding, ReLU on the rounded pair; 16-byte stores from the accumulator layout (ssdhip_conv64.hip) -----------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy requests of the last two steps
+    const u32 floor16 = p.relu ? 0u : 0x80008000u;
+    const size_t img = (size_t)HW * p.Cout * 2;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        float bv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
+                bv[4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
+            }
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) {
+            const int q = wn * 96 + pi * 32 + r31;
+            const u32 voff = (u32)((q * p.Cout + co0 + wm * 64 + ci * 32) * 2 + khalf * 16) | (q < HW ? 0u : OOB);
+            u32 lo[4], hi[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lo[g] = ci_pkmax_i16(ci_pack2(acc[ci][pi][4 * g] + bv[4 * g], acc[ci][pi][4 * g + 1] + bv[4 * g + 1]), floor16);
+                hi[g] = ci_pkmax_i16(ci_pack2(acc[ci][pi][4 * g + 2] + bv[4 * g + 2], acc[ci][pi][4 * g + 3] + bv[4 * g + 3]), floor16);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const auto sl = __builtin_amdgcn_permlane32_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+                const auto sh = __builtin_amdgcn_permlane32_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(ci_u32x4{sl[0], sh[0], sl[1], sh[1]}, ry, voff + pr * 32, 0, 0);
+            }
+        }
+    }
+#endif
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+// 3x3 'same' convolution (padding = dilation) of maps with H W <= 384 pixels, one image per tile: x [B, H, W, Cin] bf16, weight
+// [Cout, 3, 3, Cin] bf16, bias [Cout] bf16 or NULL, y [B, H, W, Cout] bf16; Cin % 64 == 0, Cout % 128 == 0, 1 <= dilation <= 16.
+// Replaces Conv2D(..., (3, 3), dilation_rate=d, padding='same', activation='relu') -- fc6, models/keras_ssd300.py:298 -- with the
+// K order (and hence the bits) of ssdhip_conv2d_same_nhwc_bf16.  SSDHIP_E_BADARG for other geometries (the caller keeps the
+// implicit-GEMM kernels for them).
+extern "C" int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                                              int Cout, int dilation, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SSDHIP_E_BADARG;
+    if ((Cin % 64) || (Cout % 128) || dilation < 1 || dilation > 16 || (long long)H * W > CI_PX) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    if ((long long)H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7ffff000LL || 128LL * 9 * Cin * 2 >= 0x7ffff000LL) return SSDHIP_E_BADARG;
+    ConvImgParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y);
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
+    p.n_cot = Cout / 128;
+    int grid = B * p.n_cot;
+    p.xcd_map = 0;
+    if (B % 8 == 0) p.xcd_map = 1;                       // b = xcd + 8 (j / n_cot) covers 0 .. B - 1 exactly when B is a multiple of 8
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 0) == hipSuccess;
+    (void)big_lds;
+    hipLaunchKernelGGL(conv_image_kernel, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

@@ -364,6 +364,15 @@ class SSDModel(nn.Module):
         return (conv.kernel_size == (3, 3) and conv.dilation == (1, 1) and conv.in_channels % 128 == 0
                 and conv.out_channels % 128 == 0 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
 
+    @staticmethod
+    def _image_ok(conv, x):
+        """csrc/ssdhip_convimg.hip: 3x3 'same' with any dilation, the whole map of an image (at most 384 pixels) resident in LDS, one
+        tile per (image, 128 output channels) -- offered where that gives at least half a chip's worth of tiles."""
+        import os
+        return (conv.kernel_size == (3, 3) and x.shape[2] * x.shape[3] <= 384 and conv.in_channels % 64 == 0
+                and conv.out_channels % 128 == 0 and 1 <= conv.dilation[0] <= 16
+                and x.shape[0] * (conv.out_channels // 128) >= 128 and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
+
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
         import os
@@ -418,7 +427,7 @@ class SSDModel(nn.Module):
             # (profiles/r04s_step_timeline.json against r04n: fc6 142 vs 128 us, conv6_1 28 vs 22 us).
             # (plain convolutions only: among the pooled forms "halo" is the UNFUSED slab kernel + a pooling pass.)
             if key and key[0] == "act":
-                for name in ("halo", "igemm6", "igemm5"):           # fc6 in the step: igemm6 128 us, igemm 142, igemm5 ~165 (r04n / r04s / r04zz)
+                for name in ("halo", "image", "igemm6", "igemm5"):  # fc6 in the step: igemm6 128 us, igemm 142, igemm5 ~165 (r04n / r04s / r04zz)
                     if name in times and times[name] <= 1.08 * best:
                         hit = name
                         break
@@ -446,6 +455,9 @@ class SSDModel(nn.Module):
                     cands["c64"] = lambda: nat.conv3x3_c64(x, conv.weight, conv.bias, relu=relu, pool=False)
                 if self._halo_ok(conv, x):
                     cands["halo"] = lambda: nat.conv2d_same(x, conv.weight, conv.bias, dilation=1, relu=relu, variant=7)
+                if self._image_ok(conv, x):
+                    # one image per tile, the dilated taps as per-lane LDS addresses (csrc/ssdhip_convimg.hip): fc6
+                    cands["image"] = lambda: nat.conv3x3_image(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu)
             elif self._igemm_general_ok(conv, x):
                 # the extra layers: small maps, one workgroup per CU at most -- the deeper LDS rings (loads three / two steps ahead)
                 # hide the L2 latency that the two-stage kernel exposes on every K-step
@@ -536,6 +548,8 @@ class SSDModel(nn.Module):
                 cands["c64"] = lambda xb, wb, bb: nat.conv3x3_c64(xb, wb, bb, relu=relu, pool=False)
             if self._halo_ok(conv, x):
                 cands["halo"] = lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=1, relu=relu, variant=7)
+            if self._image_ok(conv, x):
+                cands["image"] = lambda xb, wb, bb: nat.conv3x3_image(xb, wb, bb, dilation=d, relu=relu)
         elif self._igemm_general_ok(conv, x):
             cands = {nm: (lambda xb, wb, bb, v=v: nat.conv2d(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
                                                             relu=relu, variant=v))

@@ -540,3 +540,57 @@ def test_conv_chain_in_the_ssd300_model_equals_the_layer_by_layer_path():
     for a, b in zip(feats[3:], base[3:]):
         rms = b.float().pow(2).mean().sqrt().item()
         assert float((a.float() - b.float()).abs().max()) <= 3e-2 * rms + 2.0 ** -6 * float(b.float().abs().max())
+
+
+IMAGE_CASES = [  # B, H, W, Cin, Cout, dilation, bias, relu   (csrc/ssdhip_convimg.hip: one image per tile, H W <= 384, any dilation)
+    (32, 19, 19, 512, 1024, 6, True, True),      # fc6 (models/keras_ssd300.py:298): 256 tiles, the XCD-sharing tile map
+    (3, 19, 19, 128, 256, 6, True, True),        # the same geometry, a batch that is no multiple of 8 (plain tile map)
+    (2, 19, 19, 64, 128, 1, True, False),        # one slice, dilation 1, no ReLU
+    (8, 10, 10, 256, 256, 3, True, True),        # conv6-sized map
+    (2, 5, 7, 64, 128, 2, False, True),          # a non-square map narrower than the dilated taps reach, no bias
+    (1, 1, 1, 128, 128, 6, True, True),          # one pixel: eight of the nine taps are padding
+    (2, 16, 24, 192, 384, 4, True, True),        # exactly 384 pixels (54 slab pieces), three slices, three channel tiles
+    (16, 19, 19, 512, 512, 1, True, True),       # conv5_x shape, batch a multiple of 8 with four channel tiles
+]
+
+
+@pytest.mark.parametrize("case", IMAGE_CASES)
+def test_image_conv_equals_implicit_gemm(case):
+    """ssdhip_conv3x3_image_nhwc_bf16 against the implicit-GEMM kernel (variant 4) on the same operands: bit-identical (same K order:
+    slices, taps, 16-channel blocks), five launches each (a race between the LDS-DMA ring and the fragment reads would show up as a
+    run that differs), and within the convolution bar of the float32 reference."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, d, use_bias, relu = case
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + H * 7 + d)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if use_bias else None
+    assert nat.conv3x3_image_supported(x, wt, d)
+    base = nat.conv2d_same(x, wt, bias, dilation=d, relu=relu, variant=4)
+    for _ in range(5):
+        got = nat.conv3x3_image(x, wt, bias, dilation=d, relu=relu)
+        assert got.shape == base.shape
+        assert torch.equal(got.view(torch.int16), base.view(torch.int16))
+    want = F.conv2d(x.float(), wt.float(), bias.float() if use_bias else None, 1, d, d)
+    if relu:
+        want = want.clamp_min(0)
+    rms = want.pow(2).mean().sqrt().item()
+    assert int(((got.float() - want).abs() > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
+
+
+def test_image_conv_rejects_other_geometries():
+    import torch
+    from ssd_keras_amd import _native as nat
+    x = torch.zeros((1, 64, 20, 20), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros((128, 64, 3, 3), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert not nat.conv3x3_image_supported(x, w, 1)                       # 400 pixels
+    with pytest.raises(nat.SsdHipError):
+        nat.conv3x3_image(x, w, None, dilation=1)
+    x = torch.zeros((1, 64, 8, 8), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w64 = torch.zeros((64, 64, 3, 3), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv3x3_image(x, w64, None, dilation=1)                      # Cout % 128 != 0
+    with pytest.raises(nat.SsdHipError):
+        nat.conv3x3_image(x, w, None, dilation=17)
