@@ -39,9 +39,23 @@ constexpr int CI_WST = 128 * 128;                        // a filter stage: [128
 constexpr int CI_NW = 3;                                 // ring stages
 constexpr int CI_W0 = 2 * CI_SLAB;                       // LDS: slab 0 | slab 1 | ring | dump
 constexpr int CI_DUMP = CI_W0 + CI_NW * CI_WST;          // 1 KB that absorbs the dummy requests (every wave issues the same count per step)
-constexpr int CI_LDS = CI_DUMP + 1024;
+constexpr int CI_BIAS = CI_DUMP + 1024;                  // the tile's 128 bias values as float32
+constexpr int CI_LDS = CI_BIAS + 512;
 static_assert(CI_LDS <= 160 * 1024, "LDS budget");
 static_assert(CI_SLAB % 16 == 0, "slab buffers are 16-byte aligned");
+
+// In-kernel phase timers, profiling build only (tools/prof_build.sh): shader cycles of wave 0 in (prologue, wait + barrier, the rest of
+// the steps, epilogue), summed over workgroups; read back with ssdhip_profile_read_convimg.
+#ifdef SSDHIP_PROFILE
+__device__ unsigned long long g_profi[8];
+#define CI_PROF_DECL long long _pt = clock64(); long long _pa[4] = {0, 0, 0, 0};
+#define CI_PROF_MARK(i) { const long long _t = clock64(); _pa[i] += _t - _pt; _pt = _t; }
+#define CI_PROF_FLUSH if (tid == 0) { for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_profi[_i], (unsigned long long)_pa[_i]); atomicAdd(&g_profi[4], 1ull); }
+#else
+#define CI_PROF_DECL
+#define CI_PROF_MARK(i)
+#define CI_PROF_FLUSH
+#endif
 
 struct ConvImgParams {
     const bf16_t* x;             // [B, H, W, Cin]
@@ -108,8 +122,11 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     const int co0 = ct * 128;
     const int n_slices = p.Cin >> 6, n_steps = n_slices * 9;
 
+    CI_PROF_DECL
     // ---- zero rows, descriptors ---------------------------------------------------------------------------------------------------
     if (tid < 2 * (CI_ROW / 4)) reinterpret_cast<u32*>(lds + (tid / (CI_ROW / 4)) * CI_SLAB + CI_ZERO)[tid % (CI_ROW / 4)] = 0u;
+    // the bias of the tile's channels, fetched now and read from LDS in the epilogue (per-value global loads there cost 6 us per tile)
+    if (tid >= 128 && tid < 256) reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
     const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * p.Cin, (u32)((size_t)HW * p.Cin * 2));
     const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * 9 * p.Cin, (u32)((size_t)128 * 9 * p.Cin * 2));
 
@@ -137,13 +154,15 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         ci_bload(ok ? (u32)((px * p.Cin + slice * 64) * 2 + c * 16) : OOB, rx, any ? lds0 + buf * CI_SLAB + piece * 1024 : lds0 + CI_DUMP);
     };
     // filters of step `wstep` = (slice, tap) into ring stage `stage`
-    auto issue_filters = [&](const int wstep, const int stage) {
+    auto issue_filter_piece = [&](const int i, const int wstep, const int stage) {
         const bool wok = wstep < n_steps;
         const int ws = wstep / 9, wt = wstep - 9 * ws;
         const u32 wo = (u32)((wt * p.Cin + ws * 64) * 2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            ci_bload(wok ? wrel[i] + wo : OOB, rw, wok ? lds0 + CI_W0 + stage * CI_WST + (2 * wave + i) * 1024 : lds0 + CI_DUMP);
+        ci_bload(wok ? wrel[i] + wo : OOB, rw, wok ? lds0 + CI_W0 + stage * CI_WST + (2 * wave + i) * 1024 : lds0 + CI_DUMP);
+    };
+    auto issue_filters = [&](const int wstep, const int stage) {
+        issue_filter_piece(0, wstep, stage);
+        issue_filter_piece(1, wstep, stage);
     };
 
     // ---- fragment addresses -----------------------------------------------------------------------------------------------------------
@@ -183,9 +202,9 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 
     // ---- K loop: slices outer (runtime), the nine taps unrolled (the tap selects registers and ring stages at compile time) --------------
     // Fragment reads run one 16-channel block ahead of the MFMAs through a two-slot register ring (the sched_barriers pin the order: hipcc
-    // left to itself sinks every read next to its use).  The PIXEL fragments of a step's first block are read before the step's barrier
-    // (the slab does not change inside a slice; behind a slice boundary they come from the new buffer, complete since three steps);
-    // the FILTER fragments only behind it.
+    // left to itself sinks every read next to its use).  INSIDE a slice the pixel fragments of a step's first block are read before the
+    // step's barrier (the slab does not change); the filter fragments, and the first pixel fragments of a NEW slice, only behind it (the
+    // last pieces of a slab go out three steps before the slice begins: `vmcnt(4)` + that barrier are what makes them visible).
     bf16x8 fa[2][2], fb[2][3];
     auto read_b = [&](const int t, const int kk, const int slot) {
 #pragma unroll
@@ -195,18 +214,19 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci) fa[slot][ci] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + (t % CI_NW) * CI_WST + ci * (32 * 128));
     };
-    read_b(0, 0, 0);
+    CI_PROF_MARK(0)
     for (int s = 0; s < n_slices; ++s) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // the filters of this step (and the slab of this slice) have landed for this wave's share; the barrier makes that true for
             // all waves and tells that everybody has finished the previous step (whose filter stage and, behind a slice boundary, whose
             // slab buffer the requests below overwrite)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            CI_PROF_MARK(2)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // lgkmcnt: this wave's fragment reads of the previous step have RETURNED
+            __builtin_amdgcn_s_barrier();                                 // before anybody requests over the stage / buffer they came from
+            CI_PROF_MARK(1)
             read_a(t, 0, 0);
-            issue_filters(s * 9 + t + 2, (t + 2) % CI_NW);               // (9 s + t + 2) % 3 == (t + 2) % 3
-            issue_slab(s + 1, t, (s + 1) & 1);
+            if (t == 0) read_b(0, 0, 0);                                 // a new slice: its slab is complete and visible only behind this barrier
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -214,10 +234,17 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
                 else if (t < 8) read_b(t + 1, 0, 0);                     // (t == 8: after the buffer flip below)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
+                for (int pi = 0; pi < 3; ++pi) acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][0], fb[kk & 1][pi], acc[0][pi], 0, 0, 0);
+                // the step's three requests go out one at a time BETWEEN MFMA blocks (order: filters, filters, slab): an LDS-DMA instruction
+                // holds its wave for 60-120 cycles, and issued together behind the barrier they left the matrix pipe idle in both waves
+                // of the SIMD at once
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk == 0) issue_filter_piece(0, s * 9 + t + 2, (t + 2) % CI_NW);       // (9 s + t + 2) % 3 == (t + 2) % 3
+                if (kk == 1) issue_filter_piece(1, s * 9 + t + 2, (t + 2) % CI_NW);
+                if (kk == 2) issue_slab(s + 1, t, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int pi = 0; pi < 3; ++pi)
-                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][ci], fb[kk & 1][pi], acc[ci][pi], 0, 0, 0);
+                for (int pi = 0; pi < 3; ++pi) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
             }
         }
         // the next slice lives in the other slab buffer
@@ -226,10 +253,10 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int pi = 0; pi < 3; ++pi) baddr[t][pi] += flip;
-        read_b(0, 0, 0);                                 // the next slice's first pixel fragments (its slab is complete since taps 0 .. 6)
     }
 
     // ---- epilogue: bias, one rounding, ReLU on the rounded pair; 16-byte stores from the accumulator layout (ssdhip_conv64.hip) -----------
+    CI_PROF_MARK(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy requests of the last two steps
     const u32 floor16 = p.relu ? 0u : 0x80008000u;
     const size_t img = (size_t)HW * p.Cout * 2;
@@ -238,12 +265,10 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     for (int ci = 0; ci < 2; ++ci) {
         float bv[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ch = co0 + wm * 64 + ci * 32 + 8 * g + 4 * khalf + e;
-                bv[4 * g + e] = p.bias ? __uint_as_float((u32)p.bias[ch] << 16) : 0.f;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = *reinterpret_cast<const float4*>(lds + CI_BIAS + (wm * 64 + ci * 32 + 8 * g + 4 * khalf) * 4);
+            bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
+        }
 #pragma unroll
         for (int pi = 0; pi < 3; ++pi) {
             const int q = wn * 96 + pi * 32 + r31;
@@ -262,6 +287,8 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
             }
         }
     }
+    CI_PROF_MARK(3)
+    CI_PROF_FLUSH
 #endif
 }
 
@@ -294,3 +321,12 @@ extern "C" int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight,
     hipLaunchKernelGGL(conv_image_kernel, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
+
+#ifdef SSDHIP_PROFILE
+// profiling build only: out[0..3] = wave 0's cycles in (prologue, wait + barrier, steps, epilogue) summed over workgroups, out[4] = workgroups
+extern "C" int ssdhip_profile_read_convimg(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_profi), sizeof(g_profi)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_profi), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -580,6 +580,24 @@ def test_image_conv_equals_implicit_gemm(case):
     assert int(((got.float() - want).abs() > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
 
 
+def test_image_conv_race_screen():
+    """fc6 at batch 32 and conv5-sized tiles at batch 16: thirty launches each, every one bit-identical to the implicit-GEMM result (the
+    kernel's LDS-DMA rings are guarded by counted waits and one barrier per step; a missing guard shows up as an occasional stale
+    fragment -- one did during development, on exactly these shapes)."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    for B, H, W, Cin, Cout, d in ((32, 19, 19, 512, 1024, 6), (16, 19, 19, 512, 512, 1), (8, 10, 10, 256, 256, 3)):
+        g = torch.Generator(device="cuda").manual_seed(11)
+        x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+        wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+        bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+        base = nat.conv2d_same(x, wt, bias, dilation=d, relu=True, variant=4).view(torch.int16)
+        bad = 0
+        for _ in range(30):
+            bad += int((nat.conv3x3_image(x, wt, bias, dilation=d, relu=True).view(torch.int16) != base).sum().item())
+        assert bad == 0, (B, H, W, Cin, Cout, d, bad)
+
+
 def test_image_conv_rejects_other_geometries():
     import torch
     from ssd_keras_amd import _native as nat
