@@ -490,7 +490,8 @@ int ssdhip_image_lut_u8(const void* x, void* y, long long n_values, int C, int c
  * LDS and the dilated taps as per-lane addresses (csrc/ssdhip_convimg.hip).  Replaces Conv2D(1024, (3, 3), dilation_rate=(6, 6),
  * activation='relu', padding='same') -- fc6, models/keras_ssd300.py:298 -- on the 19 x 19 map; same K order, hence the same bits, as
  * ssdhip_conv2d_same_nhwc_bf16.  x [B, H, W, Cin] bf16, weight [Cout, 3, 3, Cin] bf16, bias [Cout] bf16 or NULL, y [B, H, W, Cout] bf16;
- * Cin % 64 == 0, Cout % 128 == 0, 1 <= dilation <= 16.  SSDHIP_E_BADARG for any other geometry. */
+ * Cin % 64 == 0, Cout % 64 == 0, 1 <= dilation <= 16.  SSDHIP_E_BADARG for any other geometry.  A tile is one image x 128 output channels
+ * (or x 64 where that is needed to fill the chip: conv5_x at batch 32). */
 int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
                                    int dilation, int relu, void* stream);
 

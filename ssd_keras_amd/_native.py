@@ -567,10 +567,10 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
 
 
 def conv3x3_image_supported(x, weight, dilation=1):
-    """Geometry of conv3x3_image: 3x3 filters, H * W <= 384 pixels, Cin % 64 == 0, Cout % 128 == 0, 1 <= dilation <= 16."""
+    """Geometry of conv3x3_image: 3x3 filters, H * W <= 384 pixels, Cin % 64 == 0, Cout % 64 == 0, 1 <= dilation <= 16."""
     b, cin, h, w = x.shape
     cout, cin_w, kh, kw = weight.shape
-    return kh == 3 and kw == 3 and cin_w == cin and h * w <= 384 and cin % 64 == 0 and cout % 128 == 0 and 1 <= int(dilation) <= 16
+    return kh == 3 and kw == 3 and cin_w == cin and h * w <= 384 and cin % 64 == 0 and cout % 64 == 0 and 1 <= int(dilation) <= 16
 
 
 def conv3x3_image(x, weight, bias, dilation=1, relu=True):

@@ -35,11 +35,11 @@ constexpr int CI_PX = 384;                               // pixels of a tile (12
 constexpr int CI_ROW = 144;                              // bytes of a pixel row in LDS
 constexpr int CI_SLAB = (CI_PX + 1) * CI_ROW;            // + the zero row
 constexpr int CI_ZERO = CI_PX * CI_ROW;                  // offset of the zero row inside a slab buffer
-constexpr int CI_WST = 128 * 128;                        // a filter stage: [128 co][64 ci] bf16
+constexpr int CI_WST = 128 * 128;                        // a filter stage: [BM co][64 ci] bf16 (BM = 128; the 64-channel form uses half of it)
 constexpr int CI_NW = 3;                                 // ring stages
 constexpr int CI_W0 = 2 * CI_SLAB;                       // LDS: slab 0 | slab 1 | ring | dump
 constexpr int CI_DUMP = CI_W0 + CI_NW * CI_WST;          // 1 KB that absorbs the dummy requests (every wave issues the same count per step)
-constexpr int CI_BIAS = CI_DUMP + 1024;                  // the tile's 128 bias values as float32
+constexpr int CI_BIAS = CI_DUMP + 1024;                  // the tile's bias values as float32
 constexpr int CI_LDS = CI_BIAS + 512;
 static_assert(CI_LDS <= 160 * 1024, "LDS budget");
 static_assert(CI_SLAB % 16 == 0, "slab buffers are 16-byte aligned");
@@ -63,7 +63,7 @@ struct ConvImgParams {
     const bf16_t* bias;          // [Cout] or null
     bf16_t* y;                   // [B, H, W, Cout]
     int B, H, W, Cin, Cout, dil, relu;
-    int n_cot;                   // Cout / 128
+    int n_cot;                   // Cout / BM
     int xcd_map;                 // the channel tiles of an image on one XCD (needs n_cot == 8 or a tile count that is a multiple of 8 n_cot)
 };
 
@@ -97,13 +97,19 @@ __device__ __forceinline__ i32x4 ci_rsrc(const void* base, u32 num_records) {
 }
 #endif
 
+// BM: output channels of a tile.  128: a wave owns 64 channels (two 32-channel MFMA blocks) x 96 pixels.  64: a wave owns ONE block x 96
+// pixels -- twice the tiles (conv5_x: 32 images x 8 = 256 instead of 128 for 256 CUs) for 1.33 KB of LDS reads per MFMA instead of 0.83.
+template <int BM>
 __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[CI_LDS];
     constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;             // 64 output channels x 96 pixels per wave
+    constexpr int NCB = BM / 64;                         // 32-channel MFMA blocks of a wave
+    constexpr int WCH = BM / 2;                          // output channels of a wave
+    constexpr int NFP = BM / 64;                         // filter pieces (8 rows x 128 B) a wave requests per step
+    const int wm = wave & 1, wn = wave >> 1;             // WCH output channels x 96 pixels per wave
     const int r31 = lane & 31, khalf = lane >> 5;
     const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int HW = p.H * p.W;
@@ -119,29 +125,29 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         ct = (int)blockIdx.x - b * p.n_cot;
     }
     if (b >= p.B) return;
-    const int co0 = ct * 128;
+    const int co0 = ct * BM;
     const int n_slices = p.Cin >> 6, n_steps = n_slices * 9;
 
     CI_PROF_DECL
     // ---- zero rows, descriptors ---------------------------------------------------------------------------------------------------
     if (tid < 2 * (CI_ROW / 4)) reinterpret_cast<u32*>(lds + (tid / (CI_ROW / 4)) * CI_SLAB + CI_ZERO)[tid % (CI_ROW / 4)] = 0u;
     // the bias of the tile's channels, fetched now and read from LDS in the epilogue (per-value global loads there cost 6 us per tile)
-    if (tid >= 128 && tid < 256) reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
+    if (tid >= 128 && tid < 128 + BM) reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
     const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * p.Cin, (u32)((size_t)HW * p.Cin * 2));
-    const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * 9 * p.Cin, (u32)((size_t)128 * 9 * p.Cin * 2));
+    const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * 9 * p.Cin, (u32)((size_t)BM * 9 * p.Cin * 2));
 
-    // ---- request plan.  Every wave issues exactly THREE LDS-DMA pieces per step, in this order: [two filter pieces of step i + 2 | one slab
-    //      piece of the next slice]; a request that has nothing to fetch goes out of range into the dump area.  So `s_waitcnt vmcnt(4)` at
-    //      the top of step i leaves the three requests of step i - 1 and the slab piece of step i - 2 in flight: the filters of step i
+    // ---- request plan.  Every wave issues exactly NFP + 1 LDS-DMA pieces per step, in this order: [NFP filter pieces of step i + 2 | one slab
+    //      piece of the next slice]; a request that has nothing to fetch goes out of range into the dump area.  So `s_waitcnt vmcnt(NFP + 2)`
+    //      at the top of step i leaves the requests of step i - 1 and the slab piece of step i - 2 in flight: the filters of step i
     //      (issued at step i - 2) and every slab piece issued up to step i - 3 have landed -- a slice's pieces go out at its taps 0 .. 6
     //      (9 HW / 64 <= 54 pieces, eight per tap), three steps and more ahead of the next slice's first step.  (Waiting for the previous
     //      step's slab piece -- the first version -- exposed a memory round trip per step.)
     //      slab: slot n = 64 piece + lane -> pixel n / 9, 16-byte chunk n % 9 (8 = the row's pad: not fetched).
-    //      filters of (slice s, tap t): [128 co][64 ci], piece = 8 rows; row r, chunk c at position c ^ ((r >> 1) & 7) --------------------
-    u32 wrel[2];                                         // byte offset of the lane's slot in filter piece 2 wave + i, (slice 0, tap 0)
+    //      filters of (slice s, tap t): [BM co][64 ci], piece = 8 rows; row r, chunk c at position c ^ ((r >> 1) & 7) ---------------------
+    u32 wrel[NFP];                                       // byte offset of the lane's slot in filter piece NFP wave + i, (slice 0, tap 0)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (2 * wave + i) * 8 + (lane >> 3);
+    for (int i = 0; i < NFP; ++i) {
+        const int row = (NFP * wave + i) * 8 + (lane >> 3);
         const int j = (lane & 7) ^ ((row >> 1) & 7);
         wrel[i] = (u32)((row * 9 * p.Cin) * 2 + j * 16);
     }
@@ -158,17 +164,17 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         const bool wok = wstep < n_steps;
         const int ws = wstep / 9, wt = wstep - 9 * ws;
         const u32 wo = (u32)((wt * p.Cin + ws * 64) * 2);
-        ci_bload(wok ? wrel[i] + wo : OOB, rw, wok ? lds0 + CI_W0 + stage * CI_WST + (2 * wave + i) * 1024 : lds0 + CI_DUMP);
+        ci_bload(wok ? wrel[i] + wo : OOB, rw, wok ? lds0 + CI_W0 + stage * CI_WST + (NFP * wave + i) * 1024 : lds0 + CI_DUMP);
     };
     auto issue_filters = [&](const int wstep, const int stage) {
-        issue_filter_piece(0, wstep, stage);
-        issue_filter_piece(1, wstep, stage);
+#pragma unroll
+        for (int i = 0; i < NFP; ++i) issue_filter_piece(i, wstep, stage);
     };
 
     // ---- fragment addresses -----------------------------------------------------------------------------------------------------------
     u32 abase[4];                                        // filter stage 0: row = channel, chunk (2 kk + khalf) ^ ((row >> 1) & 7); + 32 rows for the second block
     {
-        const int row = wm * 64 + r31;
+        const int row = wm * WCH + r31;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) abase[kk] = (u32)(CI_W0 + row * 128 + (((2 * kk + khalf) ^ ((row >> 1) & 7)) << 4));
     }
@@ -185,9 +191,9 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         }
     }
 
-    f32x16 acc[2][3];
+    f32x16 acc[NCB][3];
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
         for (int pi = 0; pi < 3; ++pi)
 #pragma unroll
@@ -205,14 +211,14 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     // left to itself sinks every read next to its use).  INSIDE a slice the pixel fragments of a step's first block are read before the
     // step's barrier (the slab does not change); the filter fragments, and the first pixel fragments of a NEW slice, only behind it (the
     // last pieces of a slab go out three steps before the slice begins: `vmcnt(4)` + that barrier are what makes them visible).
-    bf16x8 fa[2][2], fb[2][3];
+    bf16x8 fa[2][NCB], fb[2][3];
     auto read_b = [&](const int t, const int kk, const int slot) {
 #pragma unroll
         for (int pi = 0; pi < 3; ++pi) fb[slot][pi] = *reinterpret_cast<const bf16x8*>(lds + baddr[t][pi] + kk * 32);
     };
     auto read_a = [&](const int t, const int kk, const int slot) {
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci) fa[slot][ci] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + (t % CI_NW) * CI_WST + ci * (32 * 128));
+        for (int ci = 0; ci < NCB; ++ci) fa[slot][ci] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + (t % CI_NW) * CI_WST + ci * (32 * 128));
     };
     CI_PROF_MARK(0)
     for (int s = 0; s < n_slices; ++s) {
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
             // all waves and tells that everybody has finished the previous step (whose filter stage and, behind a slice boundary, whose
             // slab buffer the requests below overwrite)
             CI_PROF_MARK(2)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // lgkmcnt: this wave's fragment reads of the previous step have RETURNED
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NFP + 2) : "memory");   // lgkmcnt: this wave's fragment reads of the previous step have RETURNED
             __builtin_amdgcn_s_barrier();                                 // before anybody requests over the stage / buffer they came from
             CI_PROF_MARK(1)
             read_a(t, 0, 0);
@@ -235,16 +241,16 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pi = 0; pi < 3; ++pi) acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][0], fb[kk & 1][pi], acc[0][pi], 0, 0, 0);
-                // the step's three requests go out one at a time BETWEEN MFMA blocks (order: filters, filters, slab): an LDS-DMA instruction
-                // holds its wave for 60-120 cycles, and issued together behind the barrier they left the matrix pipe idle in both waves
-                // of the SIMD at once
+                // the step's requests go out one at a time BETWEEN MFMA blocks (order: filters, slab): an LDS-DMA instruction holds its wave
+                // for 60-120 cycles, and issued together behind the barrier they left the matrix pipe idle in both waves of the SIMD at once
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk == 0) issue_filter_piece(0, s * 9 + t + 2, (t + 2) % CI_NW);       // (9 s + t + 2) % 3 == (t + 2) % 3
-                if (kk == 1) issue_filter_piece(1, s * 9 + t + 2, (t + 2) % CI_NW);
-                if (kk == 2) issue_slab(s + 1, t, (s + 1) & 1);
+                if (kk < NFP) issue_filter_piece(kk, s * 9 + t + 2, (t + 2) % CI_NW);     // (9 s + t + 2) % 3 == (t + 2) % 3
+                if (kk == NFP) issue_slab(s + 1, t, (s + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NCB == 2) {
 #pragma unroll
-                for (int pi = 0; pi < 3; ++pi) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
+                    for (int pi = 0; pi < 3; ++pi) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
+                }
             }
         }
         // the next slice lives in the other slab buffer
@@ -262,17 +268,17 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     const size_t img = (size_t)HW * p.Cout * 2;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
+    for (int ci = 0; ci < NCB; ++ci) {
         float bv[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 t4 = *reinterpret_cast<const float4*>(lds + CI_BIAS + (wm * 64 + ci * 32 + 8 * g + 4 * khalf) * 4);
+            const float4 t4 = *reinterpret_cast<const float4*>(lds + CI_BIAS + (wm * WCH + ci * 32 + 8 * g + 4 * khalf) * 4);
             bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
         }
 #pragma unroll
         for (int pi = 0; pi < 3; ++pi) {
             const int q = wn * 96 + pi * 32 + r31;
-            const u32 voff = (u32)((q * p.Cout + co0 + wm * 64 + ci * 32) * 2 + khalf * 16) | (q < HW ? 0u : OOB);
+            const u32 voff = (u32)((q * p.Cout + co0 + wm * WCH + ci * 32) * 2 + khalf * 16) | (q < HW ? 0u : OOB);
             u32 lo[4], hi[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 using namespace ssdhip;
 
 // 3x3 'same' convolution (padding = dilation) of maps with H W <= 384 pixels, one image per tile: x [B, H, W, Cin] bf16, weight
-// [Cout, 3, 3, Cin] bf16, bias [Cout] bf16 or NULL, y [B, H, W, Cout] bf16; Cin % 64 == 0, Cout % 128 == 0, 1 <= dilation <= 16.
+// [Cout, 3, 3, Cin] bf16, bias [Cout] bf16 or NULL, y [B, H, W, Cout] bf16; Cin % 64 == 0, Cout % 64 == 0, 1 <= dilation <= 16.
 // Replaces Conv2D(..., (3, 3), dilation_rate=d, padding='same', activation='relu') -- fc6, models/keras_ssd300.py:298 -- with the
 // K order (and hence the bits) of ssdhip_conv2d_same_nhwc_bf16.  SSDHIP_E_BADARG for other geometries (the caller keeps the
 // implicit-GEMM kernels for them).
@@ -305,20 +311,22 @@ extern "C" int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight,
                                               int Cout, int dilation, int relu, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SSDHIP_E_BADARG;
-    if ((Cin % 64) || (Cout % 128) || dilation < 1 || dilation > 16 || (long long)H * W > CI_PX) return SSDHIP_E_BADARG;
+    if ((Cin % 64) || (Cout % 64) || dilation < 1 || dilation > 16 || (long long)H * W > CI_PX) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
     if ((long long)H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7ffff000LL || 128LL * 9 * Cin * 2 >= 0x7ffff000LL) return SSDHIP_E_BADARG;
     ConvImgParams p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
-    p.n_cot = Cout / 128;
-    int grid = B * p.n_cot;
-    p.xcd_map = 0;
-    if (B % 8 == 0) p.xcd_map = 1;                       // b = xcd + 8 (j / n_cot) covers 0 .. B - 1 exactly when B is a multiple of 8
-    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 0) == hipSuccess;
-    (void)big_lds;
-    hipLaunchKernelGGL(conv_image_kernel, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
+    // channel tile: 128 where that already gives three quarters of a chip's worth of tiles (fc6 at batch 32: 256), else 64 (conv5_x at
+    // batch 32: 256 tiles instead of 128).  SSDHIP_CONVIMG_BM forces one (A/B runs).
+    int bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
+    if (const char* e = getenv("SSDHIP_CONVIMG_BM")) { const int v = atoi(e); if (v == 64 || (v == 128 && (Cout % 128) == 0)) bm = v; }
+    p.n_cot = Cout / bm;
+    const int grid = B * p.n_cot;
+    p.xcd_map = (B % 8 == 0) ? 1 : 0;                    // b = xcd + 8 (j / n_cot) covers 0 .. B - 1 exactly when B is a multiple of 8
+    if (bm == 128) hipLaunchKernelGGL(conv_image_kernel<128>, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_image_kernel<64>, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -370,8 +370,8 @@ class SSDModel(nn.Module):
         tile per (image, 128 output channels) -- offered where that gives at least half a chip's worth of tiles."""
         import os
         return (conv.kernel_size == (3, 3) and x.shape[2] * x.shape[3] <= 384 and conv.in_channels % 64 == 0
-                and conv.out_channels % 128 == 0 and 1 <= conv.dilation[0] <= 16
-                and x.shape[0] * (conv.out_channels // 128) >= 128 and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
+                and conv.out_channels % 64 == 0 and 1 <= conv.dilation[0] <= 16
+                and x.shape[0] * (conv.out_channels // 64) >= 128 and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
 
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""

@@ -550,7 +550,8 @@ IMAGE_CASES = [  # B, H, W, Cin, Cout, dilation, bias, relu   (csrc/ssdhip_convi
     (2, 5, 7, 64, 128, 2, False, True),          # a non-square map narrower than the dilated taps reach, no bias
     (1, 1, 1, 128, 128, 6, True, True),          # one pixel: eight of the nine taps are padding
     (2, 16, 24, 192, 384, 4, True, True),        # exactly 384 pixels (54 slab pieces), three slices, three channel tiles
-    (16, 19, 19, 512, 512, 1, True, True),       # conv5_x shape, batch a multiple of 8 with four channel tiles
+    (16, 19, 19, 512, 512, 1, True, True),       # conv5_x shape, batch a multiple of 8: the 64-channel tile form (8 tiles per image)
+    (3, 7, 9, 128, 192, 2, True, True),          # Cout = 192: only the 64-channel form applies
 ]
 
 
@@ -607,8 +608,8 @@ def test_image_conv_rejects_other_geometries():
     with pytest.raises(nat.SsdHipError):
         nat.conv3x3_image(x, w, None, dilation=1)
     x = torch.zeros((1, 64, 8, 8), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w64 = torch.zeros((64, 64, 3, 3), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w32 = torch.zeros((32, 64, 3, 3), device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     with pytest.raises(nat.SsdHipError):
-        nat.conv3x3_image(x, w64, None, dilation=1)                      # Cout % 128 != 0
+        nat.conv3x3_image(x, w32, None, dilation=1)                      # Cout % 64 != 0
     with pytest.raises(nat.SsdHipError):
         nat.conv3x3_image(x, w, None, dilation=17)

@@ -9,7 +9,7 @@ import torch  # noqa: E402
 
 from ssd_keras_amd import _native as nat  # noqa: E402
 
-CASES = [("fc6", 32, 19, 19, 512, 1024, 6), ("conv5_1", 32, 19, 19, 512, 512, 1), ("small", 2, 5, 7, 64, 128, 2), ("10x10", 8, 10, 10, 256, 256, 3)]
+CASES = [("fc6", 32, 19, 19, 512, 1024, 6), ("conv5_1", 32, 19, 19, 512, 512, 1), ("ssd512_tail", 16, 16, 16, 512, 256, 1), ("small", 2, 5, 7, 64, 128, 2), ("10x10", 8, 10, 10, 256, 256, 3)]
 
 
 def timed(fn, reps=20):
