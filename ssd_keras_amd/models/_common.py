@@ -590,6 +590,10 @@ class SSDModel(nn.Module):
                     cands["halo"] = lambda: nat.bias_act_maxpool(
                         nat.conv2d_same(x, conv.weight, conv.bias, dilation=1, relu=True, variant=7), None, kernel, stride, pad,
                         ceil_mode, relu=False)
+                if self._image_ok(conv, x):              # conv5_3 -> pool5: the image-resident kernel + the pooling pass
+                    cands["image"] = lambda: nat.bias_act_maxpool(
+                        nat.conv3x3_image(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True), None, kernel, stride, pad,
+                        ceil_mode, relu=False)
                 if (kernel == 2 and stride == 2 and pad == 0 and (ceil_mode or x.shape[2] % 2 == 0) and (ceil_mode or x.shape[3] % 2 == 0)):
                     # pooling fused into the convolution's epilogue: the full-resolution activation is never written
                     cands["igemm_pool"] = lambda: nat.conv2d_same_pool2(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=True)
