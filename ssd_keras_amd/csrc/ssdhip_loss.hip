@@ -16,7 +16,7 @@
 //                     each finding the previous level's digit redundantly in every block.  No single-workgroup step, no list.
 //   L3 keep_kernel    the last digit and -- only if ties straddle the cut -- the flat-index limit (from per-block level-3
 //                     counts), then grid-stride over B*N: keep mask + per-image sum of the kept negative losses.
-//   L4 total_kernel   B threads: (pos_cls + neg_cls + alpha*loc) / max(1, n_pos) * B.
+//   L4 (folded into L3: the last keep block of an image to arrive): (pos_cls + neg_cls + alpha*loc) / max(1, n_pos) * B.
 // Backward = one kernel with the same LDS tiling writing d loss / d y_pred coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -74,7 +74,7 @@ static LossWs loss_ws_layout(int B, int N, int C) {
     w.tiles = (N + TA - 1) / TA;
     w.nblk = (int)(((long long)B * N + SELP_CHUNK - 1) / SELP_CHUNK);
     size_t o = 0;
-    w.hist = o;   o = lalign(o + (L1_SHARDS * L1_BINS + 2 * SEL_BINS) * sizeof(u32));   // first: one memset covers it
+    w.hist = o;   o = lalign(o + ((size_t)L1_SHARDS * L1_BINS + 2 * SEL_BINS + (size_t)B) * sizeof(u32));   // first: one zero-fill covers the bins and the B arrival counters of L3
     w.sums = o;   o = lalign(o + (size_t)(3 * B + 1) * sizeof(double));
     w.sel = o;    o = lalign(o + sizeof(SelectResult));
     w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restr
                                                             int B, int N, const u32* __restrict__ ghist, int nblk,
                                                             const unsigned short* __restrict__ bcol, SelectResult* __restrict__ res,
                                                             float* __restrict__ stats, unsigned char* __restrict__ keep,
-                                                            double* __restrict__ keep_part) {
+                                                            double* __restrict__ keep_part, u32* __restrict__ arrived,
+                                                            const double* __restrict__ sums, float alpha, float* __restrict__ loss) {
     __shared__ double red[LOSS_THREADS / 64];
     __shared__ u32 hist[SEL_BINS];
     __shared__ int sh_out[2];
@@ -405,20 +406,23 @@ __global__ __launch_bounds__(LOSS_THREADS) void keep_kernel(const float* __restr
     if (tid == 0) {
         double a = 0;
         for (int w = 0; w < LOSS_THREADS / 64; ++w) a += red[w];
-        keep_part[(size_t)b * KEEP_BLOCKS + blockIdx.x] = a;              // summed in a fixed order by L4
+        keep_part[(size_t)b * KEEP_BLOCKS + blockIdx.x] = a;              // summed in a fixed order below
+        // L4 folded in (round 4: one launch and its gap less): the LAST block of the image to arrive adds the image's partial sums in
+        // block order -- the order does not depend on who is last -- and writes the image's loss.  Release: the partial sum above is in L2
+        // before the counter moves; acquire: the last block reads the others' sums with device-scope loads.
+        __threadfence();
+        const u32 before = atomicAdd(&arrived[b], 1u);
+        if (before == gridDim.x - 1) {
+            __threadfence();
+            const float n_pos = (float)sums[3 * B];
+            double neg = 0.0;
+            for (u32 i = 0; i < gridDim.x; ++i)
+                neg += __hip_atomic_load(&keep_part[(size_t)b * KEEP_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float cls_loss = (float)sums[b] + (float)neg;               // class_loss = pos + neg (:200)
+            const float tot = (cls_loss + alpha * (float)sums[B + b]) / fmaxf(1.0f, n_pos);
+            loss[b] = tot * (float)B;                                         // :208-209
+        }
     }
-}
-
-__global__ void total_kernel(const double* __restrict__ sums, const double* __restrict__ keep_part, int keep_blocks, int B, float alpha,
-                             float* __restrict__ loss) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float n_pos = (float)sums[3 * B];
-    double neg = 0.0;
-    for (int i = 0; i < keep_blocks; ++i) neg += keep_part[(size_t)b * KEEP_BLOCKS + i];
-    const float cls = (float)sums[b] + (float)neg;                        // class_loss = pos + neg (:200)
-    const float tot = (cls + alpha * (float)sums[B + b]) / fmaxf(1.0f, n_pos);
-    loss[b] = tot * (float)B;                                             // :208-209
 }
 
 // ======================================================================================
@@ -489,7 +493,7 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     double* part = reinterpret_cast<double*>(base + lay.part);
     double* keep_part = reinterpret_cast<double*>(base + lay.keep_part);
     unsigned short* bcol = reinterpret_cast<unsigned short*>(base + lay.bcol);
-    if (zero_async(ghist, (L1_SHARDS * L1_BINS + 2 * SEL_BINS) * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins (sums are plain stores)
+    if (zero_async(ghist, ((size_t)L1_SHARDS * L1_BINS + 2 * SEL_BINS + (size_t)B) * sizeof(u32), stream) != hipSuccess) return SSDHIP_E_LAUNCH;    // the three levels' bins + L3's arrival counters (sums are plain stores)
 
     const int L = C + 12;
     const int TA = loss_tile(L);
@@ -508,9 +512,7 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     while (gx > 1 && gx * B > 512) --gx;
     if (gx > KEEP_BLOCKS) gx = KEEP_BLOCKS;
     hipLaunchKernelGGL(keep_kernel, dim3(gx, B), dim3(LOSS_THREADS), 0, stream, cls, neg, B, N, ghist, lay.nblk, bcol, sel, stats, keep_mask,
-                       keep_part);
-    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
-    hipLaunchKernelGGL(total_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sums, keep_part, gx, B, alpha, loss_per_item);
+                       keep_part, ghist + L1_SHARDS * L1_BINS + 2 * SEL_BINS, sums, alpha, loss_per_item);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     return SSDHIP_OK;
 }
