@@ -258,6 +258,7 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     b1v[cb][4 * g + e] = p.b1 ? __uint_as_float((u32)p.b1[cb * 32 + 8 * g + 4 * khalf + e] << 16) : 0.f;
+        // the lane's halo pixel in each block of 32: patch offset of its top-left tap, halo-row offset, (hr, hc)
         // gather offsets (bytes into the patch) of the lane's 16 k values relative to its pixel: k -> (kh, r = kw * 3 + ci)
         u32 kofs[2][8];
 #pragma unroll
@@ -661,205 +662,6 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-// =================================================================================================================================
-// Eight multiplying waves, no loader wave (round 4 experiment, NOT the default: see the launcher; the non-fused Cin = 64 layers).
-// The in-kernel timers (profiles/r04p_*) showed where the five-wave kernel above loses its time: with ONE multiplying wave per SIMD
-// every cycle of the epilogue and of the barrier is MFMA idle time (K loop 2 800 of a tile's 4 050 cycles).  The image-resident kernel
-// (ssdhip_convimg.hip) showed that two plain waves per SIMD reach ~90 % of the MFMA issue floor without any hand interleaving.  So:
-//   * 16 x 16-pixel tiles, eight waves = 2 (32 output channels, their 36 filter fragments in registers as above) x 4 (four tile rows =
-//     two row pairs x 16 columns = 64 pixels): two waves per SIMD, one wave's epilogue / waits overlap its partner's MFMAs;
-//   * no loader wave: every wave requests six of a halo's 46 LDS-DMA pieces, two tiles ahead, BETWEEN the MFMAs of its K loop.  The
-//     epilogue's four buffer stores sit in the same vmcnt queue; the counted wait at the top of a tile leaves everything YOUNGER than
-//     the halo it needs in flight (the previous two tiles' stores, the next halo's requests): a wave never waits for its own stores;
-//   * three halo buffers of 46 KB (18 x 18 pixels x 144 B), one barrier per tile.
-// Same K order (taps outer, 16-channel blocks inner), same epilogue arithmetic: bit-identical to the kernel above.
-constexpr int C8_THREADS = 512;
-constexpr int C8_HC = 18, C8_HPX = 18 * 18;                             // halo of a 16 x 16 tile
-constexpr int C8_NP = (9 * C8_HPX + 63) / 64;                           // 46 pieces of 1 KiB
-constexpr int C8_HB = C8_NP * 1024;
-constexpr int C8_NPW = (C8_NP + 7) / 8;                                 // pieces a wave requests per halo (6; the last two of wave 6, 7 are dummies)
-constexpr int C8_DUMP = 3 * C8_HB;                                      // dummy requests land here
-constexpr int C8_BIAS = C8_DUMP + 1024;
-constexpr int C8_LDS = C8_BIAS + 256;
-static_assert(C8_LDS <= 160 * 1024, "LDS budget");
-
-template <bool POOL>
-__global__ __launch_bounds__(C8_THREADS, 1) void conv64_eight_kernel(C64Params p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[C8_LDS];
-    constexpr unsigned OOB = 0x80000000u;
-    constexpr int HC = C8_HC, NPW = C8_NPW, NST = POOL ? 2 : 4;          // NST: buffer stores a wave issues per tile
-    const int G = (int)gridDim.x;
-    int slice = (int)blockIdx.x % p.n_slices, first = (int)blockIdx.x / p.n_slices;
-    const int stride = G / p.n_slices;
-    if (p.xcd_pairs) {
-        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        slice = j % p.n_slices;
-        first = xcd + 8 * (j / p.n_slices);
-    }
-    if (first >= p.tiles) return;
-    const int co0 = slice * 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;             // 32 output channels x 64 pixels (tile rows 4 wn .. 4 wn + 3) per wave
-    const int r31 = lane & 31, khalf = lane >> 5;
-    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const int xneg = (p.W + 1) * 128;                    // descriptor base one image row + one pixel before x (see conv64_body)
-    const i32x4 rx = c64_rsrc(reinterpret_cast<const unsigned char*>(p.x) - xneg, p.x_bytes + 2 * xneg);
-
-    auto tile_origin = [&](int tile, int& b, int& h0, int& w0) {
-        const int wt = tile % p.WT, r = tile / p.WT;
-        b = r / p.HT;
-        h0 = (r - b * p.HT) * 16;
-        w0 = wt * 16;
-    };
-    // ---- halo requests: piece k * 8 + wave, slot n = 64 piece + lane -> halo pixel n / 9, chunk n % 9 (8 = the row's pad) -----------------
-    int hrc[NPW];
-    u32 rel[NPW];
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-        const int piece = k * 8 + wave, n = piece * 64 + lane;
-        const int px = n / 9, c = n - 9 * px;
-        const int hr = px / HC, hc = px - hr * HC;
-        const bool data = (piece < C8_NP) & (c < 8) & (px < C8_HPX);
-        hrc[k] = data ? ((hr << 16) | (hc << 4) | c) : -1;
-        rel[k] = data ? (u32)((hr * p.W + hc) * 128 + c * 16) : OOB;
-    }
-    // one piece of the halo of `tile` into buffer `buf` (a dummy into the dump area when the tile does not exist / the piece is beyond 46)
-    auto issue_piece = [&](const int k, const int tile, const int buf) {
-        const int piece = k * 8 + wave;
-        const bool live = (tile < p.tiles) & (piece < C8_NP);
-        int b = 0, h0 = 0, w0 = 0;
-        if (tile < p.tiles) tile_origin(tile, b, h0, w0);
-        const int h = h0 - 1 + (hrc[k] >> 16), w = w0 - 1 + ((hrc[k] >> 4) & 0xfff);
-        const bool ok = live & (hrc[k] >= 0) & ((unsigned)h < (unsigned)p.H) & ((unsigned)w < (unsigned)p.W);
-        const u32 voff = ok ? (u32)(((b * p.H + h) * p.W + w) * 128 + (hrc[k] & 15) * 16 + xneg) : OOB;
-        c64_bload(voff, rx, live ? lds0 + buf * C8_HB + piece * 1024 : lds0 + C8_DUMP);
-    };
-
-    // ---- fragment addresses: lane -> pixel (row 4 wn + 2 (r31 >> 4) + pi, column r31 & 15) of the tile ----------------------------------
-    const int rp = 2 * wn + (r31 >> 4), col = r31 & 15;  // row pair of the tile, column
-    u32 bbase[2];
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) bbase[pi] = (u32)(((2 * rp + pi) * HC + col) * 144 + khalf * 16);
-    u32 ylane[2];
-    if constexpr (POOL) {
-        ylane[0] = ylane[1] = (u32)(((rp * p.Wo + (col >> 1)) * p.Cout) * 2 + khalf * 16);
-    } else {
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) ylane[pi] = (u32)((((2 * rp + pi) * p.W + col) * p.Cout) * 2 + khalf * 16);
-    }
-    bf16x8 wreg[36];
-    {
-        const bf16_t* wrow = p.w + (size_t)(co0 + wm * 32 + r31) * 576 + khalf * 8;
-#pragma unroll
-        for (int s = 0; s < 36; ++s) wreg[s] = *reinterpret_cast<const bf16x8*>(wrow + (s >> 2) * 64 + (s & 3) * 16);
-        if (wave == 0) reinterpret_cast<float*>(lds + C8_BIAS)[lane] = p.bias ? __uint_as_float((u32)p.bias[co0 + lane] << 16) : 0.f;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 36; ++s) asm volatile("" : "+v"(wreg[s]));
-
-    // ---- prologue: the halos of the first two tiles ------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) issue_piece(k, first, 0);
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) issue_piece(k, first + stride, 1);
-
-    int buf = 0, it = 0;
-    for (int tile = first; tile < p.tiles; tile += stride, ++it) {
-        // The halo of this tile has landed for this wave's share: requested two tiles ago, and everything this wave has issued SINCE --
-        // the stores of the previous two tiles, the requests of the next halo -- may still be in flight.  The first tiles of a
-        // workgroup have fewer stores behind them; their waits are simply stricter.
-        if (it >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW + 2 * NST) : "memory");
-        else if (it == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW + NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                    // ... for everybody's; and everybody is done with the buffer the requests below overwrite
-        const unsigned char* hb = lds + buf * C8_HB;
-        const int nbuf = buf == 0 ? 2 : buf - 1;         // buffer of tile + 2 stride = the one tile - stride used
-        f32x16 acc[2];
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[pi][v] = 0.f;
-        constexpr int RD = 3, RS = RD + 1;
-        bf16x8 fb0[RS], fb1[RS];
-        auto rd = [&](const int s, const int slot) {
-            const int t = s >> 2, kk = s & 3;
-            const int timm = ((t / 3) * HC + (t % 3)) * 144 + kk * 32;
-            fb0[slot] = *reinterpret_cast<const bf16x8*>(hb + bbase[0] + timm);
-            fb1[slot] = *reinterpret_cast<const bf16x8*>(hb + bbase[1] + timm);
-        };
-#pragma unroll
-        for (int s = 0; s < RD; ++s) rd(s, s);
-#pragma unroll
-        for (int s = 0; s < 36; ++s) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + RD < 36) rd(s + RD, (s + RD) % RS);
-            if (s % 6 == 2) issue_piece(s / 6, tile + 2 * stride, nbuf);             // six requests per tile, between the MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s], fb1[s % RS], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s], fb0[s % RS], acc[0], 0, 0, 0);
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-
-        // ---- epilogue (as conv64_body: straight from the accumulator layout) -------------------------------------------------------------------
-        float bv[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t4 = *reinterpret_cast<const float4*>(lds + C8_BIAS + (wm * 32 + 8 * g + 4 * khalf) * 4);
-            bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
-        }
-        int b, h0, w0;
-        tile_origin(tile, b, h0, w0);
-        const u32 floor16 = p.relu ? 0u : 0x80008000u;
-        if constexpr (POOL) {
-            const size_t img = (size_t)p.Ho * p.Wo * p.Cout * 2;
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
-            const u32 sbase = (u32)((((h0 >> 1) * p.Wo + (w0 >> 1)) * p.Cout + co0 + wm * 32) * 2);
-            const int hq = h0 + 2 * rp, wq = w0 + col;
-            const bool okp = (!(r31 & 1)) & (((h0 >> 1) + rp) < p.Ho) & ((wq >> 1) < p.Wo);
-            const u32 voff = ylane[0] | (okp ? 0u : OOB);
-            const bool has_below = hq + 1 < p.H, has_right = wq + 1 < p.W;
-            u32 lo[4], hi[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[0][4 * g + e];
-                    const float below = acc[1][4 * g + e];
-                    if (has_below) v = below > v ? below : v;
-                    const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
-                    if (has_right) v = right > v ? right : v;
-                    o[e] = v + bv[4 * g + e];
-                }
-                lo[g] = c64_pkmax_i16(c64_pack2(o[0], o[1]), floor16);
-                hi[g] = c64_pkmax_i16(c64_pack2(o[2], o[3]), floor16);
-            }
-            c64_store_runs(lo, hi, ry, voff, sbase);
-        } else {
-            const size_t img = (size_t)p.H * p.W * p.Cout * 2;
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
-            const u32 sbase = (u32)(((h0 * p.W + w0) * p.Cout + co0 + wm * 32) * 2);
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
-                const bool ok = ((h0 + 2 * rp + pi) < p.H) & ((w0 + col) < p.W);
-                const u32 voff = ylane[pi] | (ok ? 0u : OOB);
-                u32 lo[4], hi[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    lo[g] = c64_pkmax_i16(c64_pack2(acc[pi][4 * g] + bv[4 * g], acc[pi][4 * g + 1] + bv[4 * g + 1]), floor16);
-                    hi[g] = c64_pkmax_i16(c64_pack2(acc[pi][4 * g + 2] + bv[4 * g + 2], acc[pi][4 * g + 3] + bv[4 * g + 3]), floor16);
-                }
-                c64_store_runs(lo, hi, ry, voff, sbase);
-            }
-        }
-    }
-#endif
-}
-
 template <int CS, bool POOL, int NB, bool FRONT = false, bool WREG = false>
 __global__ __launch_bounds__(FRONT ? C64_FRONT_THREADS : C64_THREADS, 1) void conv64_kernel(C64Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -904,23 +706,11 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     G = (G / p.n_slices) * p.n_slices;
     if (G < p.n_slices) G = p.n_slices;
     { const char* e = getenv("SSDHIP_C64_XCD"); p.xcd_pairs = (p.n_slices > 1 && G % (8 * p.n_slices) == 0 && !(e && atoi(e) == 0)) ? 1 : 0; }
-    {   // the eight-wave kernel (16 x 16 tiles) only on request (SSDHIP_C64_EIGHT=1): bit-identical, measured 8 % SLOWER than the five-wave
-        // kernel on conv2_1 and conv1_2 + pool (profiles/r04v_c64_eight_waves_negative.txt) -- the two waves of a SIMD meet at the same
-        // barrier every tile, so one's epilogue does not overlap the other's MFMAs, and 16 x 16 tiles pad a 150 x 150 map by 14 %
-        const char* e = getenv("SSDHIP_C64_EIGHT");
-        if (e && atoi(e) == 1) {
-            C64Params q = p;
-            q.WT = (W + 15) / 16;
-            q.HT = (H + 15) / 16;
-            const long long t8 = (long long)B * q.HT * q.WT;
-            if (t8 <= 0x3fffffffLL) {
-                q.tiles = (int)t8;
-                if (pool) hipLaunchKernelGGL(conv64_eight_kernel<true>, dim3(G), dim3(C8_THREADS), 0, stream, q);
-                else hipLaunchKernelGGL(conv64_eight_kernel<false>, dim3(G), dim3(C8_THREADS), 0, stream, q);
-                return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
-            }
-        }
-    }
+    // (Round 4 tried these layers on EIGHT multiplying waves without a loader wave -- 16 x 16 tiles, every wave requesting a share of
+    //  the halo between its MFMAs, stores and requests in one counted vmcnt queue: 8 % slower (the two waves of a SIMD meet at the same
+    //  barrier every tile, so one's epilogue does not overlap the other's MFMAs; profiles/r04v_c64_eight_waves_negative.txt), and a
+    //  second visit showed a few hundred stale outputs per run: loads and stores do not retire in one order, a partial vmcnt over both
+    //  proves nothing about the loads.  Removed; the loader wave of this kernel exists for exactly that reason.)
     static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
 #define C64_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3, false, true>), dim3(G), dim3(C64_THREADS), 0, stream, p); \
                                     else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3>), dim3(G), dim3(C64_THREADS), 0, stream, p); } while (0)

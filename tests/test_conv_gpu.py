@@ -228,16 +228,13 @@ C64_CASES = [  # B, H, W, Cout
 ]
 
 
-@pytest.mark.parametrize("eight", ["1", "0"])
 @pytest.mark.parametrize("case", C64_CASES)
-def test_resident_weight_conv_c64(case, eight, monkeypatch):
-    """csrc/ssdhip_conv64.hip (persistent workgroups, filters resident in registers, activation halos; `eight`: the eight-wave kernel
-    on 16 x 16 tiles (an experiment kept for A/B runs) / the five-wave kernel with a loader wave (the default); SSDHIP_C64_EIGHT is read at every launch) == the implicit-GEMM
-    kernel bit for bit, with and without the fused pool, and within the convolution tolerance of the float32 reference."""
+def test_resident_weight_conv_c64(case):
+    """csrc/ssdhip_conv64.hip (persistent workgroups, filters resident in registers, activation halos from a loader wave) == the
+    implicit-GEMM kernel bit for bit, with and without the fused pool, and within the convolution tolerance of the float32 reference."""
     import torch
     import torch.nn.functional as F
     from ssd_keras_amd import _native as nat
-    monkeypatch.setenv("SSDHIP_C64_EIGHT", eight)
     B, H, W, Cout = case
     g = torch.Generator(device="cuda").manual_seed(hash(case) & 0xffff)
     x = torch.randn((B, H, W, 64), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
