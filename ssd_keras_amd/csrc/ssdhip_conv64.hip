@@ -708,9 +708,8 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     { const char* e = getenv("SSDHIP_C64_XCD"); p.xcd_pairs = (p.n_slices > 1 && G % (8 * p.n_slices) == 0 && !(e && atoi(e) == 0)) ? 1 : 0; }
     // (Round 4 tried these layers on EIGHT multiplying waves without a loader wave -- 16 x 16 tiles, every wave requesting a share of
     //  the halo between its MFMAs, stores and requests in one counted vmcnt queue: 8 % slower (the two waves of a SIMD meet at the same
-    //  barrier every tile, so one's epilogue does not overlap the other's MFMAs; profiles/r04v_c64_eight_waves_negative.txt), and a
-    //  second visit showed a few hundred stale outputs per run: loads and stores do not retire in one order, a partial vmcnt over both
-    //  proves nothing about the loads.  Removed; the loader wave of this kernel exists for exactly that reason.)
+    //  barrier every tile, so one's epilogue does not overlap the other's MFMAs; profiles/r04v_c64_eight_waves_negative.txt), and on a
+    //  second visit a few hundred stale outputs per run, cause not established in the GPU time that was left.  Removed.)
     static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
 #define C64_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3, false, true>), dim3(G), dim3(C64_THREADS), 0, stream, p); \
                                     else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3>), dim3(G), dim3(C64_THREADS), 0, stream, p); } while (0)
