@@ -5,20 +5,25 @@
 // 128-pixel x 64-channel tile (nine tap tiles of activations + nine weight tiles) for 72 MFMAs per wave, and pays nine
 // barriers: it runs at ~19 % of the MFMA peak there.  With Cin = 64 the WHOLE filter bank of a 64-channel output slice is
 // 9 x 64 x 64 x 2 B = 72 KB -- it fits in LDS next to the activations.  So:
-//   * persistent workgroups (one per CU): the 72 KB weight slice is loaded ONCE and stays resident;
+//   * persistent workgroups (one per CU): the weight slice is loaded ONCE and stays resident -- in LDS in the first version, since
+//     round 3 in the multiplying waves' REGISTERS (WREG: 36 fragments = 144 VGPRs per wave), which halves the LDS read traffic;
 //   * per tile only the activation HALO (the (2 RP + 2) x (CC + 2) pixels a 2 RP x CC tile reads through its nine taps,
-//     ~23 KB) comes in -- by LDS-DMA into the other half of a double buffer while the current tile is multiplied; the nine
-//     taps are nine constant byte displacements into that halo (rows are padded to 144 B so a displacement does not change
+//     ~23 KB) comes in -- by LDS-DMA from a dedicated LOADER wave, three tiles ahead, while the current tile is multiplied; the
+//     nine taps are nine constant byte displacements into that halo (rows are padded to 144 B so a displacement does not change
 //     the bank pattern: no swizzle term, every fragment address is base register + immediate);
 //   * image borders need no per-tap masks: out-of-image halo pixels are out-of-range buffer offsets, which the buffer unit
 //     turns into zeros in LDS;
-//   * ONE barrier per tile (9x fewer), 8 LDS-DMA loads per wave per tile (7x fewer), L2 -> LDS traffic 9x lower.
-// One wave per SIMD (the workgroup owns the CU's LDS), so the K loop is software pipelined by hand: the 36 (tap, k16) steps of
-// a tile are fully unrolled with the fragment reads running two steps ahead of the MFMAs through a three-slot register ring.
+//   * ONE barrier per tile (9x fewer), L2 -> LDS traffic 9x lower.
+// One multiplying wave per SIMD (the workgroup owns the CU's LDS), so the K loop is software pipelined by hand: the 36 (tap, k16)
+// steps of a tile are fully unrolled with the fragment reads running four steps ahead of the MFMAs through a register ring.
+// The epilogue (round 4) leaves from the accumulator layout: bias, one bf16 rounding, ReLU as v_pk_max_i16 on the rounded pair,
+// v_permlane32_swap to 16-byte runs, buffer stores -- no LDS transpose (with one wave per SIMD every epilogue cycle is MFMA idle
+// time: the in-kernel phase timers of profiles/r04p_* put the staged epilogue at 40 % of a tile).
 //
-// Tile geometry, epilogues and numerics are those of conv_igemm4_pool_kernel (ssdhip_conv.hip): 2-D tiles of RP row pairs x
-// CC columns; pooled epilogue = 2x2 max on the float32 accumulators (vertical in-lane, horizontal by DPP), then bias, ReLU, one
-// bf16 rounding.  Results are bit-identical to the implicit-GEMM kernel (same K order per output: taps outer, channels inner).
+// Tile geometry and numerics are those of conv_igemm4_pool_kernel (ssdhip_conv.hip): 2-D tiles of RP row pairs x CC columns;
+// pooled epilogue = 2x2 max on the float32 accumulators (vertical in-lane, horizontal by DPP), then bias, one bf16 rounding, ReLU.
+// Results are bit-identical to the implicit-GEMM kernel (same K order per output: taps outer, channels inner; rounding and ReLU
+// commute).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
