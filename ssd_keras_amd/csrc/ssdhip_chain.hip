@@ -33,7 +33,7 @@ typedef float cc_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CC_MAX_LAYERS = 8;
 constexpr int CC_THREADS = 512;
 constexpr int CC_LDS = 156 * 1024;
-constexpr int CC_PF = 8;                                 // filter fragments a wave keeps in flight
+[[maybe_unused]] constexpr int CC_PF = 8;                                 // filter fragments a wave keeps in flight
 
 struct ChainLayerDev {
     const uint4* wp;             // packed filters: [Cout / 32][k k][Cin / 16][64 lanes] x 16 bytes

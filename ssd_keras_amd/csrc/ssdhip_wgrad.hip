@@ -62,7 +62,7 @@ struct WgParams {
 };
 
 constexpr int WG_THREADS = 512;
-constexpr unsigned WG_OOB = 0x80000000u;
+[[maybe_unused]] constexpr unsigned WG_OOB = 0x80000000u;
 constexpr int wg_lds_bytes(int cos, int rb) { return 2 * (64 * rb + 32) * 64 + 4 * 1024 + cos * 4 * 64 * 64; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
