@@ -34,7 +34,7 @@ constexpr int CI_THREADS = 512;
 constexpr int CI_PX = 384;                               // pixels of a tile (12 blocks of 32)
 constexpr int CI_ROW = 144;                              // bytes of a pixel row in LDS
 constexpr int CI_SLAB = (CI_PX + 1) * CI_ROW;            // + the zero row
-constexpr int CI_ZERO = CI_PX * CI_ROW;                  // offset of the zero row inside a slab buffer
+[[maybe_unused]] constexpr int CI_ZERO = CI_PX * CI_ROW;                  // offset of the zero row inside a slab buffer
 constexpr int CI_WST = 128 * 128;                        // a filter stage: [BM co][64 ci] bf16 (BM = 128; the 64-channel form uses half of it)
 constexpr int CI_NW = 3;                                 // ring stages
 constexpr int CI_W0 = 2 * CI_SLAB;                       // LDS: slab 0 | slab 1 | ring | dump
