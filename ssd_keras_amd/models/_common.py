@@ -126,7 +126,13 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
         # (the deep 3x3 layers through the slab kernel, csrc/ssdhip_convh.hip: bit-identical and faster, r02o)
         halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0
                 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
-        gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
+        # (small maps -- conv5_x, fc6 with its dilation -- through the image-resident kernel, csrc/ssdhip_convimg.hip, where it fills the chip)
+        image = (k == 3 and gy.shape[2] * gy.shape[3] <= 384 and gy.shape[0] * (wt.shape[0] // 64) >= 128
+                 and nat.conv3x3_image_supported(gy, wt, dilation[0]) and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
+        if image:
+            gx = nat.conv3x3_image(gy, wt, None, dilation=dilation[0], relu=False)
+        else:
+            gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
     gw = None
     if (k == 3 and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1) and os.environ.get("SSDHIP_NO_OWN_WGRAD", "0") != "1"):
         # the weight gradient through libssdhip's MFMA kernel (csrc/ssdhip_wgrad.hip; float32, fixed summation order); None: geometry

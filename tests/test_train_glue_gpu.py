@@ -70,6 +70,10 @@ def test_data_gradient_through_the_forward_kernel(cin, cout, k, d, hw):
     err = (got - want).abs()
     bound = 2.0 ** -7 * want.abs() + 1e-2 * want.pow(2).mean().sqrt()
     assert bool((err <= bound).all()), float((err - bound).max())
+    if k == 3 and nat.conv3x3_image_supported(gy, wt, d):
+        # the form the training step takes on small maps at batch 32 (models/_common.py _conv_input_weight_grads): same bits
+        alt = nat.conv3x3_image(gy, wt, None, dilation=d, relu=False)
+        assert torch.equal(alt.view(torch.int16), nat.conv2d_same(gy, wt, None, dilation=d, relu=False).view(torch.int16))
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 37, 41), (2, 128, 30, 30), (2, 256, 75, 75), (1, 64, 1, 1), (2, 64, 2, 3)])
