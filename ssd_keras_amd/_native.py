@@ -595,8 +595,9 @@ def conv3x3_image(x, weight, bias, dilation=1, relu=True):
     return y
 
 
-def conv_chain_pack(weight):
-    """[Cout, Cin, k, k] bfloat16 (channels_last) filters in the fragment order `conv_chain` streams; None if the geometry is not supported."""
+def conv_chain_pack(weight, out=None):
+    """[Cout, Cin, k, k] bfloat16 (channels_last) filters in the fragment order `conv_chain` streams; None if the geometry is not supported.
+    `out`: an earlier result for the same geometry, re-packed IN PLACE (a captured HIP graph keeps reading that storage)."""
     torch = _torch()
     lib = load()
     _bind_chain(lib)
@@ -607,7 +608,9 @@ def conv_chain_pack(weight):
     if n == 0:
         return None
     wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-    packed = torch.empty((n,), dtype=torch.uint8, device=weight.device)
+    if out is not None and (out.numel() != n or out.dtype != torch.uint8 or out.device != weight.device):
+        raise SsdHipError("conv_chain_pack: `out` does not match this filter's packed size")
+    packed = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
         check(lib.ssdhip_conv_chain_pack_weight(_ptr(wt), _ptr(packed), kh, cin, cout, current_stream_ptr(weight.device)), "ssdhip_conv_chain_pack_weight")
     return packed

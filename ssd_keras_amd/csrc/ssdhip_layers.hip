@@ -274,11 +274,21 @@ extern "C" int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) return SSDHIP_E_BADARG;
     if (kernel == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && !bias && !relu && C % 64 == 0 && (long long)H * W * 128 <= 160 * 1024 && x != y) {
         const size_t lds = (size_t)H * W * 128;
-        static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(pool3x3s1_slab_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        // the attribute is per DEVICE: one process may drive several GPUs (state per device id: 0 unknown, 1 set, 2 refused)
+        static signed char big_lds_state[64] = {0};
+        int devid = 0;
+        bool big_lds = false;
+        if (lds > 64 * 1024 && hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64) {
+            if (big_lds_state[devid] == 0)
+                big_lds_state[devid] = hipFuncSetAttribute(reinterpret_cast<const void*>(pool3x3s1_slab_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 2;
+            big_lds = big_lds_state[devid] == 1;
+        }
         if (lds <= 64 * 1024 || big_lds) {
             hipLaunchKernelGGL(pool3x3s1_slab_kernel, dim3((unsigned)(B * (C / 64))), dim3(POOL3_THREADS), lds, stream, static_cast<const uint4*>(x),
                                static_cast<uint4*>(y), H, W, (u32)(C / 8), (u32)(C / 64));
-            return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+            if (hipGetLastError() == hipSuccess) return SSDHIP_OK;
+            // a refused launch falls through to the generic pooling kernel below
         }
     }
     hipLaunchKernelGGL(bias_act_maxpool_kernel, dim3(grid_for((size_t)total, 256)), dim3(256), 0, stream,

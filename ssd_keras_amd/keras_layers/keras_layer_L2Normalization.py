@@ -53,7 +53,11 @@ class L2Normalization(nn.Module):
             if g.dtype != torch.float32:           # a bf16 model: the kernel's float32 gamma is converted once, not once per step
                 key = (g.data_ptr(), g._version)
                 hit = self.__dict__.get("_gamma32")
-                if hit is None or hit[0] != key:
+                if hit is not None and hit[0] != key and hit[1].device == g.device and hit[1].shape == g.shape \
+                        and not torch.cuda.is_current_stream_capturing():
+                    self.refresh_cached_gamma()      # in place: a captured graph may be reading this storage
+                    hit = self.__dict__["_gamma32"]
+                elif hit is None or hit[0] != key:
                     hit = (key, g.detach().float().contiguous())
                     if not torch.cuda.is_current_stream_capturing():
                         self.__dict__["_gamma32"] = hit
@@ -66,6 +70,18 @@ class L2Normalization(nn.Module):
         xf = x.float()
         inv = torch.rsqrt(torch.clamp_min((xf * xf).sum(dim=1, keepdim=True), 1e-12))
         return (xf * inv * self.gamma.view(1, -1, 1, 1)).to(x.dtype)
+
+    def refresh_cached_gamma(self):
+        """Bring the cached float32 copy of gamma up to date IN ITS OWN STORAGE (a captured HIP graph keeps reading it)."""
+        hit = self.__dict__.get("_gamma32")
+        g = self.gamma
+        if hit is None or g is None:
+            return
+        key = (g.data_ptr(), g._version)
+        if hit[0] != key and hit[1].device == g.device and hit[1].shape == g.shape:
+            with torch.no_grad():
+                hit[1].copy_(g.detach())
+            self.__dict__["_gamma32"] = (key, hit[1])
 
     call = forward                                   # the Keras layer's method name (reference :61)
 

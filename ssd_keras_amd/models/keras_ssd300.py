@@ -104,32 +104,58 @@ class SSD300(_VGGBase):
         conv9_2 = ca(self.conv9_2, ca(self.conv9_1, conv8_2))
         return [conv6_2, conv7_2, conv8_2, conv9_2]
 
-    def _extras_tail_chain(self, conv6_2):
+    def _extras_tail_chain(self, conv6_2, _refresh_only=False):
         """conv7_1 ... conv9_2 (reference models/keras_ssd300.py:304-313) as ONE launch, one workgroup per image, the intermediate maps in
         LDS (csrc/ssdhip_chain.hip) on the fused bf16 inference path; None -> the caller runs the six layers one by one.  The filters are
         re-packed in MFMA fragment order once per set of weights (keyed on the parameters' versions)."""
         import os
-        if not self._fused(conv6_2) or os.environ.get("SSDHIP_NO_CHAIN", "0") == "1":
+        if not _refresh_only and (not self._fused(conv6_2) or os.environ.get("SSDHIP_NO_CHAIN", "0") == "1"):
             return None
-        convs = [self.conv7_1, self.conv7_2, self.conv8_1, self.conv8_2, self.conv9_1, self.conv9_2]
-        key = tuple((id(c.weight), c.weight.data_ptr(), c.weight._version, c.bias.data_ptr(), c.bias._version) for c in convs) + (str(conv6_2.device),)
+        convs = self._tail_convs()
+        key = self._tail_chain_key() + (str(conv6_2.device),)
         st = self.__dict__.get("_tail_chain")
         if st is None or st["key"] != key:
+            # the same geometry on the same device: re-packed IN PLACE (a captured HIP graph, GraphedInference, keeps reading these
+            # storages); anything else builds fresh tensors
+            old = st["layers"] if (st is not None and st["layers"] is not None and st["key"][-1] == key[-1]) else None
             layers = []
             with torch.no_grad():
                 for i, c in enumerate(convs):
                     wb = c.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-                    packed = nat.conv_chain_pack(wb)
+                    if old is not None:
+                        packed = nat.conv_chain_pack(wb, out=old[i]["packed"])
+                        bias = old[i]["bias"]
+                        bias.copy_(c.bias.detach())
+                    else:
+                        packed = nat.conv_chain_pack(wb)
+                        bias = c.bias.detach().to(torch.bfloat16).clone()
                     if packed is None:
                         layers = None
                         break
-                    layers.append(dict(packed=packed, bias=c.bias.detach().to(torch.bfloat16), k=c.kernel_size[0], stride=c.stride[0],
+                    layers.append(dict(packed=packed, bias=bias, k=c.kernel_size[0], stride=c.stride[0],
                                        pad=c.padding[0], cout=c.out_channels, relu=1, keep=bool(i & 1)))
             st = {"key": key, "layers": layers}
             self.__dict__["_tail_chain"] = st
-        if st["layers"] is None:
+        if st["layers"] is None or _refresh_only:
             return None
         return nat.conv_chain(conv6_2, st["layers"])
+
+    def _tail_convs(self):
+        return [self.conv7_1, self.conv7_2, self.conv8_1, self.conv8_2, self.conv9_1, self.conv9_2]
+
+    def _tail_chain_key(self):
+        return tuple((id(c.weight), c.weight.data_ptr(), c.weight._version, c.bias.data_ptr(), c.bias._version) for c in self._tail_convs())
+
+    def _derived_weights_key(self):
+        return super()._derived_weights_key() + self._tail_chain_key()
+
+    def _refresh_derived_weights(self):
+        """The fragment-packed conv7_1 ... conv9_2 filters beside the base class's caches, each re-built in its own storage."""
+        super()._refresh_derived_weights()
+        st = self.__dict__.get("_tail_chain")
+        if st is not None and st["layers"] is not None and st["key"][:-1] != self._tail_chain_key():
+            dev = st["layers"][0]["packed"].device
+            self._extras_tail_chain(torch.empty((0,), dtype=torch.bfloat16, device=dev), _refresh_only=True)
 
     def features(self, x):
         early = self.trunk_features(x)

@@ -218,9 +218,13 @@ class PreciseForward:
         self._calibrating = {}
         try:
             if str(images.device) not in self._side:
+                # a placeholder (every head on the main stream) for the calibration pass only: removed whatever happens, so that a
+                # failed calibration does not leave the measured stream choice switched off for good
                 self._side[str(images.device)] = (torch.cuda.current_stream(images.device), torch.cuda.current_stream(images.device))
-                self._forward(images)
-                del self._side[str(images.device)]
+                try:
+                    self._forward(images)
+                finally:
+                    del self._side[str(images.device)]
             else:
                 self._forward(images)
             amax = self._calibrating

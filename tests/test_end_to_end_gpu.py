@@ -235,3 +235,48 @@ def test_graphed_step_and_two_stream_heads_equal_the_plain_step():
         else:
             os.environ["SSDHIP_HEAD_OVERLAP"] = old
     assert int((plain_a[:, :, 0] > 0).sum()) > 0                 # the comparison is not between two empty outputs
+
+
+def test_graph_replay_follows_in_place_weight_updates():
+    """tensors DERIVED from parameters (the fragment-packed conv7_1 ... conv9_2 filters of the one-launch tail, the packed
+    predictor heads, the float32 copy of conv4_3_norm's gamma) are baked into a captured graph by address.  After an in-place update
+    of every parameter (load_state_dict) the next replay must equal the eager step on the new weights -- and differ from the old one."""
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = ssd_300((300, 300, 3), cfg["n_classes"], mode="inference", scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"],
+                    confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400).cuda()
+        m = m.to(memory_format=torch.channels_last).eval().to(torch.bfloat16)
+        with torch.no_grad():                                     # tamed heads: distinct confidences, finite boxes
+            for head in m.conf_heads:
+                head.weight.mul_(1e-2)
+                head.bias.view(-1, 21)[:, 0] = 4.0
+            for head in m.loc_heads:
+                head.weight.mul_(1e-2)
+        return m
+
+    model, other = make(21), make(22)
+    with torch.no_grad():
+        other.conv4_3_norm.gamma.mul_(0.5)                        # gamma must change too (its init is a constant)
+    images = torch.from_numpy(np.random.RandomState(9).randint(0, 256, size=(8, 300, 300, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        runner = model.graphed(images)
+        before = runner(images).clone()
+        assert torch.equal(before, model(images))
+        model.load_state_dict(other.state_dict())                 # in place: same storages, bumped versions
+        replayed = runner(images).clone()
+        eager_new = model(images)
+        want = other(images)
+    assert torch.equal(eager_new, want)
+    assert torch.equal(replayed, want), "the graph replayed stale derived weights"
+    assert not torch.equal(replayed, before)
+    # only the tail + the gamma changed: the narrowest form of the same question
+    with torch.no_grad():
+        for name in ("conv7_1", "conv8_2", "conv9_2"):
+            getattr(model, name).weight.mul_(-1.0)
+        model.conv4_3_norm.gamma.add_(1.0)
+        assert torch.equal(runner(images), model(images))

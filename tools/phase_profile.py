@@ -62,3 +62,11 @@ if __name__ == "__main__":
         with torch.no_grad():
             yp = model(imgs).float().cpu().numpy()
         run("random_init_model", yp)
+        with torch.no_grad():                        # bench.py's value_tamed_heads workload: distinct, unsaturated confidences
+            for head in model.conf_heads:
+                head.weight.mul_(1e-2)
+                head.bias.view(-1, 21)[:, 0] = 4.0
+            for head in model.loc_heads:
+                head.weight.mul_(1e-2)
+            yt = model(imgs).float().cpu().numpy()
+        run("tamed_heads_model", yt)
