@@ -27,6 +27,13 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-f
           "-Wno-unused-function"]
 
 
+# Per-file additions.  ssdhip_decode.hip: the 512-thread NMS kernel lives on 80 VGPRs (six waves per SIMD); LLVM's machine-LICM hoists
+# a dozen loop-invariant LDS addresses and constants out of its round loop and then SPILLS them at the top of every workgroup
+# (32-48 bytes per lane = 10-15 MB of scratch stores per launch, profiles/r04zz_decode_pmc_traffic.json).  Without that pass the
+# kernel has no scratch at all; the re-materialised address arithmetic is a handful of VALU instructions per round.
+EXTRA_CFLAGS = {"ssdhip_decode.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -53,7 +60,8 @@ def build(force=False, verbose=True):
     todo = [s for s in sources() if force or _newer([s] + hdrs, _obj_of(s))]
 
     def compile_one(src):
-        cmd = [hipcc] + CFLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", _obj_of(src)]
+        cmd = ([hipcc] + CFLAGS + EXTRA_CFLAGS.get(os.path.basename(src), []) +
+               ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", _obj_of(src)])
         if verbose:
             print("[ssd_keras_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -507,6 +507,7 @@ struct __attribute__((aligned(16))) FBox {
 struct NmsK {                    // wave-uniform constants of a launch
     double W, H, d, thr;
     float Wf, Hf, df, thr32, kE;
+    float thr_lo, thr_hi;        // POL_TF32: float32(thr) * (1 -+ 2^-20), the constants of the division-free pair test
     int fast_ok, no_nms;
 };
 
@@ -547,6 +548,24 @@ __device__ __forceinline__ FBox make_fbox(const float4 bx, u32 idx, const NmsK& 
 // supp: the pair is decided "b suppresses a"; und (POL_NUMPY64 only): the float32 filter cannot decide
 template <int POL>
 __device__ __forceinline__ void pair_test(const FBox& a, const FBox& b, const NmsK& k, bool& supp, bool& und) {
+    if (POL == POL_TF32) {
+        // fl(inter / uni) > thr  <=  inter >= fl(uni * c_hi),  c_hi = fl(thr (1 + 2^-20));   fl(inter / uni) <= thr  <=  inter <= fl(uni * c_lo),
+        // c_lo = fl(thr (1 - 2^-20))  (thr > 0; uni > 0 or +inf: inter <= either area in float32 as well, rounding is monotone; the
+        // roundings of the constant, of the product and of the quotient are each below 2^-23 relative, so the exact ratio is beyond
+        // thr (1 +- 2^-21)); what lies in between -- and every NaN -- takes the division.  inter and uni are the TF kernel's own float32
+        // values, except that the HEIGHT is not clamped: a negative one makes inter <= 0 and uni >= area_a + area_b > 0, which both
+        // tests read as "not suppressed", the right answer for an empty intersection (0 * inf = NaN: the division path, which clamps).
+        // 15 VALU instructions per 64 pairs (17 in rounds 2-4: three products, the second clamp).
+        const float ix0 = vmaxf(a.x0, b.x0), iy0 = vmaxf(a.y0, b.y0);
+        const float ix1 = vminf(a.x1, b.x1), iy1 = vminf(a.y1, b.y1);
+        const float iw = vmaxf(ix1 - ix0, 0.f), ih = iy1 - iy0;
+        const float inter = iw * ih;
+        const float uni = (a.area + b.area) - inter;
+        const bool yes = inter >= uni * k.thr_hi, no = inter <= uni * k.thr_lo;
+        supp = k.fast_ok && yes;
+        und = !k.fast_ok || !(yes || no);
+        return;
+    }
     if (POL == POL_NUMPY32) {
         const PxBox<float> pa = {a.x0, a.y0, a.x1, a.y1, a.area}, pb = {b.x0, b.y0, b.x1, b.y1, b.area};
         supp = !(iou_px<float>(pa, pb) <= k.thr32);
@@ -558,22 +577,13 @@ __device__ __forceinline__ void pair_test(const FBox& a, const FBox& b, const Nm
     const float iw = vmaxf(ix1 - ix0, 0.f), ih = vmaxf(iy1 - iy0, 0.f);
     const float inter = iw * ih;
     const float uni = (a.area + b.area) - inter;
-    if (POL == POL_NUMPY64) {
-        const float r = __builtin_fmaf(-k.thr32, uni, inter);
-        const float E = k.kE * vmaxf(a.sc, b.sc);
-        // the sign of R answers "IoU <= thr" only for a positive union (negative areas: border_pixels 'exclude', inverted boxes)
-        const bool dec = __builtin_fabsf(r) > E && uni > E;
-        supp = dec && r > 0.f;
-        und = !dec;
-    } else {
-        // fl(inter / uni) > thr  <=  inter >= fl(thr*uni) (1 + 2^-21);   fl(inter / uni) <= thr  <=  inter <= fl(thr*uni) (1 - 2^-21)
-        // (thr > 0, uni > 0 or +inf: the rounding of the product and of the quotient are each below 2^-23 relative); what lies in
-        // between -- and every NaN -- takes the division
-        const float hi = k.thr32 * uni;
-        const bool yes = inter >= hi * 1.00000048f, no = inter <= hi * 0.99999952f;
-        supp = k.fast_ok && yes;
-        und = !k.fast_ok || !(yes || no);
-    }
+    // POL_NUMPY64
+    const float r = __builtin_fmaf(-k.thr32, uni, inter);
+    const float E = k.kE * vmaxf(a.sc, b.sc);
+    // the sign of R answers "IoU <= thr" only for a positive union (negative areas: border_pixels 'exclude', inverted boxes)
+    const bool dec = __builtin_fabsf(r) > E && uni > E;
+    supp = dec && r > 0.f;
+    und = !dec;
 }
 
 // the exact evaluation of a pair the fast test left undecided
@@ -645,7 +655,7 @@ __device__ __forceinline__ void block_bitonic_desc_regs(u64 (&v)[PER], u64* xch)
                     const u32 olo = (u32)__shfl_xor((int)(u32)v[r], m), ohi = (u32)__shfl_xor((int)(u32)(v[r] >> 32), m);
                     const u64 o = ((u64)ohi << 32) | olo;
                     const bool take_max = low == desc;
-                    v[r] = take_max ? (o > v[r] ? o : v[r]) : (o < v[r] ? o : v[r]);
+                    v[r] = ((o > v[r]) == take_max) ? o : v[r];   // one 64-bit compare (keys are distinct; equal zero pads: either)
                 }
             } else {                                          // another wave: exchange through LDS
                 __syncthreads();
@@ -659,7 +669,7 @@ __device__ __forceinline__ void block_bitonic_desc_regs(u64 (&v)[PER], u64* xch)
                     const bool desc = ((e & kk) == 0);
                     const u64 o = xch[e ^ j];
                     const bool take_max = low == desc;
-                    v[r] = take_max ? (o > v[r] ? o : v[r]) : (o < v[r] ? o : v[r]);
+                    v[r] = ((o > v[r]) == take_max) ? o : v[r];
                 }
             }
         }
@@ -671,33 +681,47 @@ __device__ __forceinline__ void block_bitonic_desc_regs(u64 (&v)[PER], u64* xch)
 // and are mapped to the "consumed" key ~0).  The record count goes through an opaque scalar so that the loads are not hoisted
 // out of the round loop (the list is loop invariant; hoisting would keep 2 * KC registers alive through the NMS phases).
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-template <int T, int KC>
-__device__ __forceinline__ void load_keys_cached(const u64* keys, int n, int tid, u64 (&kc)[KC]) {
+template <int T, int KP>
+__device__ __forceinline__ void load_keys_cached(const u64* keys, int n, int tid, int first, u64 (&kc)[KP]) {
 #if defined(__HIP_DEVICE_COMPILE__)
     int nn = n;
     asm volatile("" : "+s"(nn));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(keys), 0, nn * 8, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < KC; ++u) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, tid * 8, u * T * 8, 0);
+    for (int u = 0; u < KP; ++u) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, tid * 8, (first + u) * T * 8, 0);
         const u64 key = ((u64)v.y << 32) | v.x;
         kc[u] = key ? key : ~0ull;
     }
 #endif
 }
 
+// A value every lane holds alike (read from LDS after a barrier) moved to scalar registers: the compiler cannot prove the uniformity
+// and would keep it in VGPRs -- 80 of them is all the 512-thread kernel has.
+__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 uni64(u64 v) {
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
+
 #ifndef SSDHIP_NMS_WAVES512
 #define SSDHIP_NMS_WAVES512 6      // minimum waves per SIMD the 512-thread variant is compiled for (tools/prof_build.sh sweeps it)
 #endif
-template <int POL, int T>
+// FULL = false (the 512-thread form): the kernel has no exact-selection fallback.  A class whose score histogram cannot deliver a chunk
+// (more than MAX_CHUNK near-equal scores in the bin at the cut and fewer than M / 4 above it -- not met once on any measured workload)
+// is handed back with kept_count = -1 and redone by a FULL launch with redo_only = 1, whose other workgroups return at once.  Inlined,
+// the fallback's five radix passes made the compiler park loop invariants in scratch at the top of EVERY workgroup: 48 bytes per lane,
+// 15.7 MB of scratch stores per launch -- the "1.39 x" HBM traffic of rounds 2-4 (profiles/r04zz_decode_pmc_traffic.json).
+template <int POL, int T, bool FULL>
 __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_kernel(DecodeParams p, const float4* __restrict__ boxes,
                                                const u64* __restrict__ cand, const int* __restrict__ cand_count,
                                                const int* __restrict__ work_order,
-                                               u64* __restrict__ kept, int* __restrict__ kept_count) {
+                                               u64* __restrict__ kept, int* __restrict__ kept_count, int redo_only) {
     constexpr int W = T / 64;
     // pairs tested per step in phase A / folded rows per step in phase B, and whether phase A prefetches the next step's
     // survivors: eight-wave workgroups trade unrolling (registers) for waves per SIMD
     constexpr int KC = KC_KEYS / T;
+    constexpr int KP = 9;                    // keys of one trip over the cached list (KC = 18 or 36: two or four trips)
+    static_assert(KC % KP == 0, "KC must be a multiple of the trip size");
     constexpr int UA = T >= 512 ? 2 : 4, UB = T >= 512 ? 2 : 4;
     constexpr bool PREFETCH = T < 512;
     // XCD-aware work mapping: hardware places block x on XCD x%8; give every XCD a contiguous range of
@@ -707,9 +731,14 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
     int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || work >= total_work) return;
     if (work_order) work = work_order[work];
+    if (redo_only && kept_count[work] != -1) return;
     const int b = work / p.G;
 
     __shared__ __attribute__((aligned(16))) u64 keybuf[MAX_CHUNK + 8];     // chunk keys, sorted in place
+    // the keys of the NEXT bins down (same histogram, same pass over the candidate list): a class that needs a second chunk -- one in
+    // two on distinct confidences -- takes it from LDS instead of reading, histogramming and filtering its candidate list again
+    __shared__ __attribute__((aligned(16))) u64 keybuf2[MAX_CHUNK + 8];
+    __shared__ int fill2;
     constexpr size_t SCRATCH = sizeof(FBox) * MAX_CHUNK > NMS_NBINS * sizeof(u32) ? sizeof(FBox) * MAX_CHUNK : NMS_NBINS * sizeof(u32);
     __shared__ __attribute__((aligned(16))) unsigned char scratch[SCRATCH];   // score histogram, then the chunk's boxes
     __shared__ __attribute__((aligned(16))) float4 cf4[POL == POL_NUMPY64 ? MAX_CHUNK : 1];    // normalised corners (exact fallback)
@@ -717,7 +746,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
     __shared__ __attribute__((aligned(16))) float4 kf4[POL == POL_NUMPY64 ? KEPT_LDS : 1];
     __shared__ u64 maskrow[64];
     __shared__ u64 supp_a[W];
-    __shared__ int red[260];
+    __shared__ int red[264];
     __shared__ int fill;
     u32* hist = reinterpret_cast<u32*>(scratch);
     FBox* cb = reinterpret_cast<FBox*>(scratch);
@@ -734,10 +763,17 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
     k.thr = p.iou_thresh;
     k.Wf = (float)p.img_w; k.Hf = (float)p.img_h; k.df = (float)k.d; k.thr32 = (float)p.iou_thresh;
     k.kE = p.filter_kE;
+    k.thr_lo = k.thr32 * 0.99999905f;
+    k.thr_hi = k.thr32 * 1.00000095f;
     k.fast_ok = p.fast_ok; k.no_nms = p.no_nms;
     const int cap_eff = min(p.cap_store, n);
+    if (!FULL && n > KC * T) {               // lists beyond the register-cached length (SSD512's dense classes): the FULL kernel's
+        if (tid == 0) kept_count[work] = -1; // eight-loads-at-a-time passes; their addresses would cost this kernel registers it lacks
+        return;
+    }
 
     int K = 0, consumed = 0;
+    int pending2 = 0;                        // keys of the second chunk waiting in keybuf2
     u64 upper = ~0ull;                       // keys >= upper are consumed; a real key is never all ones (its score field is a
     bool has_upper = false;                  // float key, whose all-ones value is a NaN that cannot pass the threshold)
     PROF_DECL
@@ -750,11 +786,20 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
         int m;
         u64 cutoff = 0;
         bool by_bin = false;
-        int bin_cut = 0;
-        // A candidate list of up to KC * T keys (every SSD300 class list) is read in ONE trip per pass (histogram, collection):
-        // all of a thread's loads are in flight together.  Longer lists (SSD512) take eight loads at a time.  (Keeping the keys
-        // in registers from the first pass to the second costs 72 VGPRs across the selection and drops a workgroup per CU.)
-        const bool cached = n <= KC * T;
+        int bin_cut = 0, bin_cut2 = 0, m2 = 0;
+        if (pending2) {                      // the bins right below the last chunk are already in LDS
+            m = pending2;
+            pending2 = 0;
+            for (int i = tid; i < MAX_CHUNK + 8; i += T) keybuf[i] = keybuf2[i];
+            __syncthreads();
+            PROF_MARK(0)
+            PROF_MARK(1)
+        } else {
+        // A candidate list of up to KC * T keys (every SSD300 class list) is read in trips of KP keys per thread and pass (histogram,
+        // collection): all of a trip's loads are in flight together.  Longer lists (SSD512) take eight loads at a time.  (One trip of
+        // KC keys, as in rounds 2-4, or keeping the keys in registers from the first pass to the second, spills: 2 KC registers
+        // against a budget of 80 at six waves per SIMD -- 15 MB of scratch stores per launch, profiles/r04zz_decode_pmc_traffic.json.)
+        const bool cached = !FULL || n <= KC * T;
         if (remaining <= MAX_CHUNK) {
             m = remaining;                   // take everything that is left
         } else {
@@ -762,11 +807,14 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
             for (int i = tid; i < NMS_NBINS; i += T) hist[i] = 0;
             __syncthreads();
             if (cached) {
-                u64 kc[KC];
-                load_keys_cached<T, KC>(keys, n, tid, kc);
+#pragma unroll 1
+                for (int part = 0; part < KC / KP; ++part) {
+                    u64 kc[KP];
+                    load_keys_cached<T, KP>(keys, n, tid, part * KP, kc);
 #pragma unroll
-                for (int u = 0; u < KC; ++u)
-                    if (kc[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(kc[u] >> IDX_BITS), p.thr_key)], 1u);
+                    for (int u = 0; u < KP; ++u)
+                        if (kc[u] < upper) atomicAdd(&hist[bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(kc[u] >> IDX_BITS), p.thr_key)], 1u);
+                }
             } else {
                 for (int i0 = tid; i0 < n; i0 += 8 * T) {
                     u64 k8[8];
@@ -778,31 +826,47 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
                 }
             }
             __syncthreads();
-            // highest bin d such that the bins above it hold <= MAX_CHUNK keys (and d included would not fit)
-            block_find_digit<NMS_NBINS / T>(hist, MAX_CHUNK + 1, red, red + 256);
-            bin_cut = red[256] + 1;
-            m = red[257];
+            // highest bin d such that the bins above it hold <= MAX_CHUNK keys (and d included would not fit); and the same question
+            // again for the bins below that cut: the second chunk
+            block_find_digit2<NMS_NBINS / T>(hist, MAX_CHUNK + 1, MAX_CHUNK + 1, red, red + 256, -1, remaining);
+            bin_cut = uni32(red[256]) + 1;
+            m = uni32(red[257]);
+            bin_cut2 = uni32(red[258]) + 1;
+            m2 = uni32(red[259]) - m;
             __syncthreads();
             if (m >= (M >> 2)) {
                 by_bin = true;
             } else {                         // one bin holds too many near-equal scores: exact selection of the M best
+                m2 = 0;
+                if (!FULL) {                 // (uniform: every thread leaves here)
+                    if (tid == 0) kept_count[work] = -1;
+                    return;
+                }
+#ifdef SSDHIP_PROFILE
+                if (tid == 0) { atomicAdd(&g_prof[15], 1ull); if (m == 0) atomicAdd(&g_prof[11], 1ull); }
+#endif
                 m = M;
-                cutoff = block_select_kth<32 + IDX_BITS, 12, T>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red);
+                if (FULL) cutoff = uni64(block_select_kth<32 + IDX_BITS, 12, T>([&](int i) { return keys[i]; }, n, upper, has_upper, M, hist, red));
             }
         }
         PROF_MARK(0)
-        for (int i = tid; i < MAX_CHUNK + 8; i += T) keybuf[i] = 0ull;     // unused sort slots hold 0 (below every key)
-        if (tid == 0) fill = 0;
+        for (int i = tid; i < MAX_CHUNK + 8; i += T) { keybuf[i] = 0ull; keybuf2[i] = 0ull; }     // unused sort slots hold 0 (below every key)
+        if (tid == 0) { fill = 0; fill2 = 0; }
         __syncthreads();
         if (cached) {
-            u64 kc[KC];
-            load_keys_cached<T, KC>(keys, n, tid, kc);
+#pragma unroll 1
+            for (int part = 0; part < KC / KP; ++part) {
+                u64 kc[KP];
+                load_keys_cached<T, KP>(keys, n, tid, part * KP, kc);
 #pragma unroll
-            for (int u = 0; u < KC; ++u) {
-                const u64 key = kc[u];
-                if (!(key < upper)) continue;
-                const bool take = by_bin ? (bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key) >= bin_cut) : (key >= cutoff);
-                if (take) keybuf[atomicAdd(&fill, 1)] = key;
+                for (int u = 0; u < KP; ++u) {
+                    const u64 key = kc[u];
+                    if (!(key < upper)) continue;
+                    const int bin = bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key);
+                    const bool take = by_bin ? (bin >= bin_cut) : (key >= cutoff);
+                    if (take) keybuf[atomicAdd(&fill, 1)] = key;
+                    else if (m2 > 0 && bin >= bin_cut2) keybuf2[atomicAdd(&fill2, 1)] = key;
+                }
             }
         } else {
             for (int i0 = tid; i0 < n; i0 += 8 * T) {
@@ -813,13 +877,17 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
                 for (int u = 0; u < 8; ++u) {
                     const u64 key = k8[u];
                     if (!(key < upper)) continue;
-                    const bool take = by_bin ? (bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key) >= bin_cut) : (key >= cutoff);
+                    const int bin = bin_of<NMS_BIN_SHIFT, NMS_NBINS>((u32)(key >> IDX_BITS), p.thr_key);
+                    const bool take = by_bin ? (bin >= bin_cut) : (key >= cutoff);
                     if (take) keybuf[atomicAdd(&fill, 1)] = key;
+                    else if (m2 > 0 && bin >= bin_cut2) keybuf2[atomicAdd(&fill2, 1)] = key;
                 }
             }
         }
+        pending2 = m2;
         __syncthreads();
         PROF_MARK(1)
+        }
         {
             constexpr int PER = MAX_CHUNK / T;
             u64 v[PER];
@@ -831,7 +899,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
             __syncthreads();
         }
         PROF_MARK(2)
-        upper = sorted[m - 1];
+        upper = uni64(sorted[m - 1]);
         has_upper = true;
         consumed += m;
         // stage the chunk's boxes (independent gathers, one latency exposure per round)
@@ -1475,10 +1543,12 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     const int nms_t = nms_env ? nms_env : (semantics == SSDHIP_SEM_KERAS ? 512 : 256);
 #define SSDHIP_LAUNCH_NMS(POL)                                                                                                            \
     do {                                                                                                                                  \
-        if (nms_t >= 512)                                                                                                                 \
-            hipLaunchKernelGGL((nms_kernel<POL, 512>), dim3(g4), dim3(512), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count); \
-        else                                                                                                                              \
-            hipLaunchKernelGGL((nms_kernel<POL, 256>), dim3(g4), dim3(256), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count); \
+        if (nms_t >= 512) {                                                                                                               \
+            hipLaunchKernelGGL((nms_kernel<POL, 512, false>), dim3(g4), dim3(512), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 0); \
+            hipLaunchKernelGGL((nms_kernel<POL, 256, true>), dim3(g4), dim3(256), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 1); \
+        } else {                                                                                                                          \
+            hipLaunchKernelGGL((nms_kernel<POL, 256, true>), dim3(g4), dim3(256), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 0); \
+        }                                                                                                                                 \
     } while (0)
     if (semantics == SSDHIP_SEM_KERAS) SSDHIP_LAUNCH_NMS(POL_TF32);
     else if (p.iou_f32) SSDHIP_LAUNCH_NMS(POL_NUMPY32);

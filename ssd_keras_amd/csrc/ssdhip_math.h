@@ -139,6 +139,26 @@ __device__ __forceinline__ u64 lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64u - lane));
 }
 
+// Inclusive suffix sum over the 64 lanes of a wave (lane l gets the sum of lanes l..63) as a butterfly: five ds_swizzle
+// exchanges (xor 1..16: an immediate pattern, NO address register -- __shfl_down costs one VGPR of lane addresses per distance,
+// which the compiler hoists out of every loop around the call and then spills in the 80-register NMS kernel) and one bpermute for xor 32.
+__device__ __forceinline__ int wave_suffix_sum(int v, int lane) {
+    int tot = v, suf = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SSDHIP_SWZ_STEP(D)                                                              \
+    {                                                                                   \
+        const int o = __builtin_amdgcn_ds_swizzle(tot, 0x1F | ((D) << 10));             \
+        if (!(lane & (D))) suf += o;                                                    \
+        tot += o;                                                                       \
+    }
+    SSDHIP_SWZ_STEP(1) SSDHIP_SWZ_STEP(2) SSDHIP_SWZ_STEP(4) SSDHIP_SWZ_STEP(8) SSDHIP_SWZ_STEP(16)
+#undef SSDHIP_SWZ_STEP
+    const int o32 = __shfl_xor(tot, 32);
+    if (lane < 32) suf += o32;
+#endif
+    return suf;
+}
+
 // ---------------------------------------------------------------------------------------
 // Radix-select helper: hist[] holds per-digit counts (blockDim.x * PER bins); find the digit d with
 //   #(digit > d) < want <= #(digit >= d)      (want >= 1, want <= total count)
@@ -152,11 +172,7 @@ __device__ __forceinline__ void block_find_digit(const u32* hist, int want, int*
     int s = 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) { local[j] = hist[tid * PER + j]; s += (int)local[j]; }
-    int suf = s;                                   // inclusive suffix sum over the lanes of this wave
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_down(suf, off);
-        if (lane + off < 64) suf += o;
-    }
+    const int suf = wave_suffix_sum(s, lane);      // inclusive suffix sum over the lanes of this wave
     if (lane == 0) wave_tot[wave] = suf;
     __syncthreads();
     int above = suf - s;
@@ -164,6 +180,39 @@ __device__ __forceinline__ void block_find_digit(const u32* hist, int want, int*
 #pragma unroll
     for (int j = PER - 1; j >= 0; --j) {
         if (above < want && want <= above + (int)local[j]) { out[0] = tid * PER + j; out[1] = above; }
+        above += (int)local[j];
+    }
+    __syncthreads();
+}
+
+// The same scan answering TWO questions from one read of the histogram: out[0..1] as block_find_digit(hist, want); then
+// out[2] = the digit d2 with #(digit > d2) < out[1] + want2 <= #(digit >= d2) and out[3] = #(digit > d2).  When fewer than
+// out[1] + want2 keys are counted at all, out[2..3] = (none2, above_none2).
+template <int PER>
+__device__ __forceinline__ void block_find_digit2(const u32* hist, int want, int want2, int* wave_tot, int* out, int none2, int above_none2) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    u32 local[PER];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { local[j] = hist[tid * PER + j]; s += (int)local[j]; }
+    const int suf = wave_suffix_sum(s, lane);
+    if (lane == 0) wave_tot[wave] = suf;
+    if (tid == 0) { out[2] = none2; out[3] = above_none2; }
+    __syncthreads();
+    int above0 = suf - s;
+    for (int w = wave + 1; w < nw; ++w) above0 += wave_tot[w];
+    int above = above0;
+#pragma unroll
+    for (int j = PER - 1; j >= 0; --j) {
+        if (above < want && want <= above + (int)local[j]) { out[0] = tid * PER + j; out[1] = above; }
+        above += (int)local[j];
+    }
+    __syncthreads();
+    const int w2 = out[1] + want2;
+    above = above0;
+#pragma unroll
+    for (int j = PER - 1; j >= 0; --j) {
+        if (above < w2 && w2 <= above + (int)local[j]) { out[2] = tid * PER + j; out[3] = above; }
         above += (int)local[j];
     }
     __syncthreads();

@@ -40,7 +40,8 @@ def run(name, y, img=300):
     B, N, L = y.shape
     G = L - 13
     nblk = max(g[12], 1)
-    print("== %s: nms blocks %d, consumed/blk %.0f, kept/blk %.1f" % (name, g[12], g[13] / nblk, g[14] / nblk))
+    print("== %s: nms blocks %d, consumed/blk %.0f, kept/blk %.1f, exact-select rounds %d (top bin alone overflows: %d)" % (
+        name, g[12], g[13] / nblk, g[14] / nblk, g[15], g[11]))
     print("  nms  kcycles/block: " + "  ".join("%s %.1f" % (n, g[i] / nblk / 1e3) for i, n in enumerate(NMS)) + "   total %.1f" % (g[:7].sum() / nblk / 1e3))
     nscan = ((N + 255) // 256) * B
     print("  scan kcycles/block: " + "  ".join("%s %.2f" % (n, g[16 + i] / nscan / 1e3) for i, n in enumerate(SCAN)))

@@ -23,7 +23,9 @@ def short(name):
     s = m.group(1)
     t = re.search(r"ssdhip::\w+<([^>]*)>", name)
     if t:
-        s += "<%s>" % t.group(1).split(",")[0].strip()
+        args = [a.strip() for a in t.group(1).split(",")]
+        # K4 is two launches per decode since round 5 (the 512-thread kernel + the redo launch of the FULL 256-thread one): keep them apart
+        s += "<%s>" % (", ".join(args) if s == "nms_kernel" else args[0])
     return s
 
 

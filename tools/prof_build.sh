@@ -10,7 +10,8 @@ SUF=${NAME:+_$NAME}
 mkdir -p $R/build/prof$SUF
 pids=()
 for f in $R/ssd_keras_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc -DSSDHIP_PROFILE "$@" \
+  X=""; [ "$(basename $f)" = "ssdhip_decode.hip" ] && X="-mllvm -disable-machine-licm"     # as ssd_keras_amd/build.py EXTRA_CFLAGS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc -DSSDHIP_PROFILE $X "$@" \
     -I $R/include -I $R/ssd_keras_amd/csrc -c $f -o $R/build/prof$SUF/$(basename $f .hip).o &
   pids+=($!)
 done
