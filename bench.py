@@ -359,6 +359,7 @@ def main():
             extra["ssd512_decode"] = bx.ssd512_decode_leg(dev, with_cpu)
             extra["conv_roofline_fp32"] = bx.fp32_forward_leg(dev, B)
             extra["conv_roofline_fp32x3"] = bx.fp32x3_forward_leg(dev, B, extra["conv_roofline_fp32"])
+            extra["other_models_forward"] = bx.other_models_forward_leg(dev)
             extra["evaluator"] = bx.evaluator_leg(dev, with_cpu)
             extra["augmentation"] = bx.augmentation_leg(dev, B, with_cpu)
         if args.train_steps > 0:
@@ -391,6 +392,51 @@ def main():
                                             "same stream; DecodeDetections reads the head outputs directly (no y_pred in HBM)"},
                 "value_tamed_heads": tamed, "roofline": roofline, "conv_roofline": conv, "cpu_baseline": cpu}
         line.update(extra)
+        # ---- scalars at the top level (the driver's record keeps scalar keys only) ----
+        def dig_any(obj, *path):
+            for k in path:
+                if not isinstance(obj, dict) or k not in obj:
+                    return None
+                obj = obj[k]
+            return obj
+
+        def dig(obj, *path):
+            for k in path:
+                if not isinstance(obj, dict) or k not in obj:
+                    return None
+                obj = obj[k]
+            return obj if isinstance(obj, (int, float, bool)) else None
+        flags = []
+
+        def flag(v):
+            if isinstance(v, dict) and "ok" in v:
+                flags.append(bool(v["ok"]))
+            elif isinstance(v, bool):
+                flags.append(v)
+            elif v is not None:
+                flags.append(False)                                      # an "error: ..." string is not green
+        if isinstance(cpu, dict):
+            flag(cpu.get("step_output_vs_layer_oracle"))
+            flag(cpu.get("hip_vs_port_on_the_sample"))
+        flag(dig_any(extra, "encoder", "cpu", "hip_matches_port"))
+        flag(dig_any(extra, "loss", "cpu", "hip_loss_within_1e-4_of_port"))
+        flag(dig_any(extra, "decode_sparse", "cpu", "hip_vs_port_on_the_sample"))
+        flag(dig_any(extra, "ssd512_decode", "sparse_bias7_conf0.01", "cpu", "hip_vs_port_on_the_sample"))
+        flag(dig_any(extra, "augmentation", "cpu", "hip_equals_port_on_the_sample"))
+        scal = {"value_reference_precision": dig(extra, "conv_roofline_fp32x3", "images_per_sec"),
+                "reference_precision_ms_per_step": dig(extra, "conv_roofline_fp32x3", "step_ms_fwd_plus_decode"),
+                "value_tamed_heads_img_s": dig(tamed, "value"), "decode_ms_in_step": round(decode_ms_in_step, 5),
+                "decode_ms_in_step_tamed": dig(tamed, "decode_ms_in_step"), "conv_frac": conv["frac"], "forward_ms": conv["forward_ms"],
+                "nms_kernel_us": round(1e3 * stage_ms["nms_kernel"], 2), "scan_kernel_us": round(1e3 * stage_ms["scan_kernel"], 2),
+                "nms_traffic_ratio": (traffic or {}).get("ratio_to_algorithmic_bytes") if dom == "nms_kernel" else None,
+                "train_step_ms": dig(extra, "train_step", "ms_per_step"), "train_images_per_sec": dig(extra, "train_step", "value"),
+                "loss_forward_ms": dig(extra, "loss", "fwd_ms"), "encoder_kernels_ms": dig(extra, "encoder", "gpu_ms_per_batch_kernels"),
+                "augment_batch_img_s": dig(extra, "augmentation", "augment_batch_images_per_sec"),
+                "ssd512_forward_img_s_batch8": dig(extra, "other_models_forward", "ssd512_voc_21_classes", "batch8", "images_per_sec"),
+                "ssd7_forward_img_s_batch8": dig(extra, "other_models_forward", "ssd7_300x300_5_classes", "batch8", "images_per_sec"),
+                "cpu_baseline_ms_per_img_1core": dig(cpu, "ms_per_img"),
+                "parity_all_green": (all(flags) if flags else None), "parity_flags_counted": len(flags)}
+        line.update({k: v for k, v in scal.items() if k not in line})
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -354,6 +354,44 @@ def fp32x3_forward_leg(dev, B, fp32_leg=None, reps=3):
 
 
 @_guard
+def other_models_forward_leg(dev, reps=5):
+    """SSD512 and SSD7 forward + DecodeDetections (mode='inference') at the README's batch 8 and at batch 32, beside the reference's
+    published whole-model figures (README.md:107-124: SSD512 25 FPS, SSD7 216 FPS at batch 8 on a GTX 1070 mobile -- other hardware,
+    Pascal VOC weights; here random-init weights on synthetic images, so the NMS works on the dense regime).  bf16 backbone, the
+    model's own fused path (models/_common.py); eager launches, events on the stream.  VERDICT r4 item 7."""
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models.keras_ssd512 import ssd_512
+    from ssd_keras_amd.models.keras_ssd7 import build_model
+    out = {}
+
+    def run(name, model, size, batches, ref_fps):
+        model = model.to(dev).to(memory_format=torch.channels_last).eval().to(torch.bfloat16)
+        res = {"reference_fps_batch8_gtx1070_mobile": ref_fps}
+        for b in batches:
+            images = torch.from_numpy(np.random.RandomState(b).randint(0, 256, size=(b, size, size, 3)).astype(np.float32)).to(dev)
+            with torch.cuda.device(dev), torch.no_grad():
+                for _ in range(3):
+                    y = model(images)
+                torch.cuda.synchronize()
+                ms = _events_ms(lambda: model(images), reps)
+            res["batch%d" % b] = {"ms_per_step": round(ms, 4), "images_per_sec": round(b / (ms * 1e-3), 1), "output": list(y.shape)}
+        out[name] = res
+
+    c5 = syn.SSD512_COCO
+    torch.manual_seed(5)
+    run("ssd512_voc_21_classes", ssd_512((512, 512, 3), 20, mode="inference", scales=[0.07, 0.15, 0.3, 0.45, 0.6, 0.75, 0.9, 1.05],
+                                         aspect_ratios_per_layer=c5["aspect_ratios_per_layer"], steps=c5["steps"], offsets=c5["offsets"],
+                                         confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400), 512, (8, 32), 25)
+    c7 = syn.SSD7_300
+    torch.manual_seed(7)
+    run("ssd7_300x300_5_classes", build_model((300, 300, 3), c7["n_classes"], mode="inference", scales=c7["scales"],
+                                              aspect_ratios_global=c7["aspect_ratios_global"], variances=c7["variances"],
+                                              normalize_coords=True, subtract_mean=127.5, divide_by_stddev=127.5,
+                                              confidence_thresh=0.5, iou_threshold=0.45, top_k=200, nms_max_output_size=400), 300, (8, 32), 216)
+    return out
+
+
+@_guard
 def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
     """BASELINE configs[2]/[3]: one SSD300 training step per rank = SSDInputEncoder (HIP) -> forward (bf16 autocast,
     fp32 master weights) -> SSDLoss (HIP, local hard-negative mining) -> backward -> RCCL gradient all-reduce (DDP,

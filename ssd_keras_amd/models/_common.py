@@ -19,6 +19,7 @@ from ..anchor_math import n_boxes_for
 from ..keras_layers.keras_layer_AnchorBoxes import AnchorBoxes
 from ..keras_layers.keras_layer_DecodeDetections import DecodeDetections
 from ..keras_layers.keras_layer_DecodeDetectionsFast import DecodeDetectionsFast
+from ..keras_layers.keras_layer_L2Normalization import L2Normalization
 
 
 def conv_out(n, k, s=1, p=0, d=1):
