@@ -424,7 +424,11 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
     # decay 1e-3 on the kernels only
     decay = [p for p in model.parameters() if p.dim() > 1]
     plain = [p for p in model.parameters() if p.dim() <= 1]
-    opt = torch.optim.SGD([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-7, momentum=0.9)
+    # keras.optimizers.SGD(lr, momentum=0.9) of ssd300_training.ipynb:169 as ONE launch over all parameters (ssd_keras_amd/optimizers.py;
+    # SSD_TRAIN_TORCH_SGD=1: the framework's optimizer, for A/B runs)
+    from ssd_keras_amd.optimizers import SGD as FusedSGD
+    opt_cls = torch.optim.SGD if os.environ.get("SSD_TRAIN_TORCH_SGD", "0") == "1" else FusedSGD
+    opt = opt_cls([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-7, momentum=0.9)
     enc = SSDInputEncoder(matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5, **cfg)
     gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=7 + rank)
     images = torch.from_numpy(np.random.RandomState(100 + rank).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)

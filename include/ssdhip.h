@@ -266,6 +266,9 @@ int ssdhip_l2_normalize_fwd(const void* x, const float* gamma, void* y, float* i
 int ssdhip_l2_normalize_bwd(const void* x, const void* dy, const float* gamma, const float* inv_norm, void* dx, float* dgamma_partial,
                             int n_waves, long long n_pixels, int C, int is_bf16, void* stream);
 int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
+/* Channel sums of a bf16 map alone (the bias gradient of a layer without activation: the predictor heads), as per-workgroup partial
+ * sums [n_blocks][C] like the two passes around it. */
+int ssdhip_channel_sums_nhwc_bf16(const void* gy, float* partial, long long n_pixels, int C, int n_blocks, void* stream);
 int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, void* out, float* partial, long long n_pixels, int C,
                                    int n_blocks, void* stream);
 
@@ -423,6 +426,11 @@ int ssdhip_conv_chain_nhwc_bf16(const void* x, int B, int H, int W, int C0, int 
  * Cin % 64 == 0 and (Cout % 128 == 0, W <= 190) or (Cout % 64 == 0, W <= 318); SSDHIP_E_BADARG otherwise.
  * ssdhip_conv3x3_wgrad_workspace_bytes returns 0 for an unsupported geometry. */
 size_t ssdhip_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+/* ssdhip_conv3x3_wgrad_bias_nhwc_bf16: the same, plus the layer's bias gradient db [Cout] float32 from bias_partial [bias_rows][Cout]
+ * (per-workgroup channel sums of dy as the backward passes of csrc/ssdhip_train.hip write them), its rows added in a fixed order by
+ * extra workgroups of the reduction launch; bias_partial == NULL: weight gradient only. */
+int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db,
+                                        int B, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
                                    size_t ws_bytes, void* stream);
 
@@ -494,6 +502,37 @@ int ssdhip_image_lut_u8(const void* x, void* y, long long n_values, int C, int c
  * (or x 64 where that is needed to fill the chip: conv5_x at batch 32). */
 int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
                                    int dilation, int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The parameter side of the training step (csrc/ssdhip_optim.hip): ONE launch over all parameters.  The reference trains float32
+ * weights with keras.optimizers.SGD(lr=0.001, momentum=0.9) (ssd300_training.ipynb:169-173); the MFMA kernels read bf16 copies.
+ *
+ * A table of descriptors in DEVICE memory names the tensors (the caller builds it once: the pointers are those of persistent buffers):
+ *   weights   src = float32 master filters [O][I][kh][kw] (contiguous; or [O][kh][kw][I] with src_channels_last = 1), KK = kh * kw <= 16;
+ *             cl  = bf16 [O][kh][kw][I] (channels_last: what the forward and the weight-gradient kernels read) or NULL;
+ *             tr  = bf16 [I][kh][kw][tr_ostride] with this tensor's O channels at offset tr_ooff and the taps FLIPPED -- the filters of
+ *                   the data gradient (a stride-1 'same' convolution of dL/dy), or NULL; tr_ostride / tr_ooff let the conf and loc
+ *                   heads of a source map share one packed tensor (as `cl` does through its pointer);
+ *             tile0 = index of the tensor's first 32 x 32 (O x I) tile in the launch (tiles are numbered tensor by tensor,
+ *                   ceil(O / 32) * ceil(I / 32) each); n_tiles = their total.
+ *   vectors   (descriptors n_weights .. n_weights + n_vectors - 1) src = float32 [O], cl = bf16 [O]; tile0 = index of its first
+ *             256-element block among the n_vector_blocks vector blocks.
+ * ssdhip_shadow_refresh      bf16 (round to nearest even) copies of every tensor of the table in the layouts above.
+ * ssdhip_sgd_momentum_step   torch.optim.SGD's update with momentum (dampening 0, no Nesterov) = Keras SGD's for a constant learning
+ *                            rate: src = parameter, cl = gradient, tr = momentum buffer, all float32 [O]; tile0 = index of the
+ *                            tensor's first 4096-element block, n_blocks their total; first_step: buf = grad (the buffer is written,
+ *                            not read).  g += weight_decay * p first when weight_decay != 0. */
+typedef struct ssdhip_shadow_desc {
+    const void* src;
+    void* cl;
+    void* tr;
+    int O, I, KK, tr_ostride, tr_ooff, tile0;
+    int src_channels_last;   /* weights: 0 = the master is [O][I][kh][kw], 1 = [O][kh][kw][I] (a channels_last nn.Conv2d weight) */
+    int reserved;
+} ssdhip_shadow_desc;
+int ssdhip_shadow_refresh(const ssdhip_shadow_desc* table_dev, int n_weights, int n_tiles, int n_vectors, int n_vector_blocks, void* stream);
+int ssdhip_sgd_momentum_step(const ssdhip_shadow_desc* table_dev, int n_tensors, int n_blocks, double lr, double momentum,
+                             double weight_decay, int first_step, void* stream);
 
 #ifdef __cplusplus
 }

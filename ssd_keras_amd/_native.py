@@ -461,13 +461,31 @@ def _train_lib():
         lib.ssdhip_maxpool_bwd_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 9 + [c_vp]
         lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16.restype = c_int
         lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp]
+        lib.ssdhip_channel_sums_nhwc_bf16.restype = c_int
+        lib.ssdhip_channel_sums_nhwc_bf16.argtypes = [c_vp, c_vp, c_ll, c_int, c_int, c_vp]
         lib._train_bound = True
     return lib
 
 
-def relu_bwd_bias(gy, y):
+def channel_sums_partial(gy):
+    """Per-workgroup channel sums of a bf16 NHWC map, float32 [n_blocks, C] (the bias gradient of a layer without activation is their
+    sum over axis 0: conv3x3_wgrad(..., bias_partial=...) adds them in its reduction launch); None: channel count not supported."""
+    torch = _torch()
+    lib = _train_lib()
+    gy, (b, h, w, c) = _nhwc_bf16(gy, "gy")
+    nb = lib.ssdhip_relu_bwd_bias_blocks(b * h * w, c)
+    if nb == 0:
+        return None
+    partial = torch.empty((nb, c), dtype=torch.float32, device=gy.device)
+    with torch.cuda.device(gy.device):
+        check(lib.ssdhip_channel_sums_nhwc_bf16(_ptr(gy), _ptr(partial), b * h * w, c, nb, current_stream_ptr(gy.device)), "ssdhip_channel_sums_nhwc_bf16")
+    return partial
+
+
+def relu_bwd_bias(gy, y, reduce=True):
     """Backward of `y = relu(conv + bias)` up to the convolution: returns (gy masked by y > 0, bias gradient float32 [C]) in one
-    pass (csrc/ssdhip_train.hip), or None when the channel count is not supported.  gy, y: (B, C, H, W) bf16 with NHWC memory."""
+    pass (csrc/ssdhip_train.hip), or None when the channel count is not supported.  gy, y: (B, C, H, W) bf16 with NHWC memory.
+    reduce=False: the second element is the [n_blocks, C] per-workgroup partial sums (the bias gradient is their sum over axis 0)."""
     torch = _torch()
     lib = _train_lib()
     gy, (b, h, w, c) = _nhwc_bf16(gy, "gy")
@@ -480,10 +498,10 @@ def relu_bwd_bias(gy, y):
     with torch.cuda.device(gy.device):
         rc = lib.ssdhip_relu_bwd_bias_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(out), _ptr(partial), b * h * w, c, nb, current_stream_ptr(gy.device))
     check(rc, "ssdhip_relu_bwd_bias_nhwc_bf16")
-    return out, partial.sum(dim=0)
+    return out, (partial.sum(dim=0) if reduce else partial)
 
 
-def maxpool2_relu_bwd_bias(y, gp):
+def maxpool2_relu_bwd_bias(y, gp, reduce=True):
     """Backward of `p = max_pool2d(y, 2, 2, ceil_mode=True)`, `y = relu(conv + bias)` up to the convolution in ONE pass: returns (the
     full-resolution gradient masked by y > 0, bias gradient float32 [C]), or None when the channel count is not supported.  y (B, C, H,
     W), gp (B, C, ceil(H/2), ceil(W/2)) bf16 with NHWC memory.  Bit-identical to maxpool_bwd followed by relu_bwd_bias."""
@@ -501,7 +519,83 @@ def maxpool2_relu_bwd_bias(y, gp):
     with torch.cuda.device(y.device):
         rc = lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16(_ptr(y), _ptr(gp), _ptr(out), _ptr(partial), b, h, w, c, nb, current_stream_ptr(y.device))
     check(rc, "ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16")
-    return out, partial.sum(dim=0)
+    return out, (partial.sum(dim=0) if reduce else partial)
+
+
+# ---- the parameter side of the training step (csrc/ssdhip_optim.hip) ------------------------------------------------------------
+SHADOW_DESC = [("src", "<u8"), ("cl", "<u8"), ("tr", "<u8"), ("O", "<i4"), ("I", "<i4"), ("KK", "<i4"), ("tr_ostride", "<i4"),
+               ("tr_ooff", "<i4"), ("tile0", "<i4"), ("src_channels_last", "<i4"), ("reserved", "<i4")]   # struct ssdhip_shadow_desc (include/ssdhip.h): 56 bytes
+
+
+def _optim_lib():
+    lib = load()
+    if not getattr(lib, "_optim_bound", False):
+        c_int, c_vp, c_d = ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+        lib.ssdhip_shadow_refresh.restype = c_int
+        lib.ssdhip_shadow_refresh.argtypes = [c_vp, c_int, c_int, c_int, c_int, c_vp]
+        lib.ssdhip_sgd_momentum_step.restype = c_int
+        lib.ssdhip_sgd_momentum_step.argtypes = [c_vp, c_int, c_int, c_d, c_d, c_d, c_int, c_vp]
+        lib._optim_bound = True
+    return lib
+
+
+def shadow_table(weights, vectors, device):
+    """The device table of ssdhip_shadow_refresh.  `weights`: (master float32 (O, I, kh, kw) contiguous, cl bf16 tensor or None,
+    tr bf16 tensor or None, tr_ostride, tr_ooff); `vectors`: (master float32 (n,), bf16 (n,)).  Returns (table tensor, n_weights,
+    n_tiles, n_vectors, n_vector_blocks); the caller keeps every tensor alive -- the table holds raw pointers."""
+    import numpy as np
+    torch = _torch()
+    tab = np.zeros((len(weights) + len(vectors),), dtype=np.dtype(SHADOW_DESC))
+    tiles = 0
+    for k, (w, cl, tr, ostride, ooff) in enumerate(weights):
+        o, i, kh, kw = w.shape
+        src_cl = 0 if w.is_contiguous() else 1
+        if w.dtype != torch.float32 or not (w.is_contiguous() or w.permute(0, 2, 3, 1).is_contiguous()) or kh * kw > 16:
+            raise SsdHipError("shadow_table: master filters must be float32 (O, I, kh, kw), contiguous or channels_last, at most 16 taps")
+        if cl is not None and (cl.dtype != torch.bfloat16 or tuple(cl.shape) != tuple(w.shape) or not cl.permute(0, 2, 3, 1).is_contiguous()):
+            raise SsdHipError("shadow_table: `cl` must be a bf16 tensor of the filters' shape in channels_last memory")
+        tab[k] = (w.data_ptr(), cl.data_ptr() if cl is not None else 0, tr.data_ptr() if tr is not None else 0, o, i, kh * kw,
+                  ostride, ooff, tiles, src_cl, 0)
+        tiles += -(-o // 32) * -(-i // 32)
+    vblocks = 0
+    for k, (v, dst) in enumerate(vectors):
+        if v.dtype != torch.float32 or dst.dtype != torch.bfloat16 or v.dim() != 1 or not v.is_contiguous() or not dst.is_contiguous():
+            raise SsdHipError("shadow_table: vectors are contiguous float32 (n,) -> bf16 (n,)")
+        tab[len(weights) + k] = (v.data_ptr(), dst.data_ptr(), 0, v.numel(), 0, 0, 0, 0, vblocks, 0, 0)
+        vblocks += -(-v.numel() // 256)
+    dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+    return dev_tab, len(weights), tiles, len(vectors), vblocks
+
+
+def shadow_refresh(table):
+    """bf16 copies (channels_last, and transposed with flipped taps) of every tensor of `table` (shadow_table's result): ONE launch."""
+    dev_tab, n_w, n_tiles, n_v, n_vb = table
+    lib = _optim_lib()
+    with _torch().cuda.device(dev_tab.device):
+        check(lib.ssdhip_shadow_refresh(_ptr(dev_tab), n_w, n_tiles, n_v, n_vb, current_stream_ptr(dev_tab.device)), "ssdhip_shadow_refresh")
+
+
+def sgd_table(params, grads, bufs, device):
+    """The device table of ssdhip_sgd_momentum_step over contiguous float32 tensors (parameter, gradient, momentum buffer)."""
+    import numpy as np
+    torch = _torch()
+    tab = np.zeros((len(params),), dtype=np.dtype(SHADOW_DESC))
+    blocks = 0
+    for k, (p, g, m) in enumerate(zip(params, grads, bufs)):
+        for t in (p, g, m):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel() or t.data_ptr() % 16:
+                raise SsdHipError("sgd_table: parameter, gradient and momentum buffer must be contiguous float32 of one size")
+        tab[k] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), 0, 0, 0, 0, blocks, 0, 0)
+        blocks += -(-p.numel() // 4096)
+    return torch.from_numpy(tab.view(np.uint8).copy()).to(device), len(params), blocks
+
+
+def sgd_momentum_step(table, lr, momentum, weight_decay=0.0, first_step=False):
+    dev_tab, n, blocks = table
+    lib = _optim_lib()
+    with _torch().cuda.device(dev_tab.device):
+        check(lib.ssdhip_sgd_momentum_step(_ptr(dev_tab), n, blocks, float(lr), float(momentum), float(weight_decay), 1 if first_step else 0,
+                                           current_stream_ptr(dev_tab.device)), "ssdhip_sgd_momentum_step")
 
 
 def maxpool_bwd(x, gy, kernel, stride, pad=0):
@@ -662,10 +756,12 @@ def conv_chain(x, layers):
     return outs
 
 
-def conv3x3_wgrad(x, dy):
+def conv3x3_wgrad(x, dy, bias_partial=None):
     """Weight gradient of a 3x3 'same' stride-1 convolution (csrc/ssdhip_wgrad.hip): x (B, Cin, H, W) and dy (B, Cout, H, W) bfloat16
     channels_last -> float32 (Cout, Cin, 3, 3) in channels_last memory format ([Cout, 3, 3, Cin] physical), or None when the
-    geometry is not supported (the caller falls back to the framework's convolution_backward)."""
+    geometry is not supported (the caller falls back to the framework's convolution_backward).  bias_partial: float32 [rows, Cout]
+    per-workgroup channel sums of dy (relu_bwd_bias(..., reduce=False) and friends): the result is then (dw, db), db float32 [Cout] =
+    their sum over axis 0, added by extra workgroups of the reduction launch."""
     torch = _torch()
     lib = load()
     if not getattr(lib, "_wgrad_bound", False):
@@ -673,6 +769,9 @@ def conv3x3_wgrad(x, dy):
         lib.ssdhip_conv3x3_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 5
         lib.ssdhip_conv3x3_wgrad_nhwc_bf16.restype = ctypes.c_int
         lib.ssdhip_conv3x3_wgrad_nhwc_bf16.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        lib.ssdhip_conv3x3_wgrad_bias_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_wgrad_bias_nhwc_bf16.argtypes = ([ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5 +
+                                                            [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])
         lib._wgrad_bound = True
     x, (b, h, w, cin) = _nhwc_bf16(x, "x")
     dy, (b2, h2, w2, cout) = _nhwc_bf16(dy, "dy")
@@ -683,6 +782,15 @@ def conv3x3_wgrad(x, dy):
         return None
     ws = workspaces.get(x.device, "wgrad", need)
     dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
+    if bias_partial is not None:
+        if (bias_partial.dtype != torch.float32 or bias_partial.dim() != 2 or bias_partial.shape[1] != cout or not bias_partial.is_contiguous()):
+            raise SsdHipError("bias_partial must be a contiguous float32 [rows, Cout] tensor")
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.ssdhip_conv3x3_wgrad_bias_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(bias_partial), int(bias_partial.shape[0]), _ptr(db),
+                                                         b, h, w, cin, cout, _ptr(ws), need, current_stream_ptr(x.device))
+        check(rc, "ssdhip_conv3x3_wgrad_bias_nhwc_bf16")
+        return dw.permute(0, 3, 1, 2), db
     with torch.cuda.device(x.device):
         rc = lib.ssdhip_conv3x3_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(dw), b, h, w, cin, cout, _ptr(ws), need, current_stream_ptr(x.device))
     check(rc, "ssdhip_conv3x3_wgrad_nhwc_bf16")

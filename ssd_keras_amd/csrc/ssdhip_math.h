@@ -143,8 +143,9 @@ __device__ __forceinline__ u64 lanemask_lt() {
 // exchanges (xor 1..16: an immediate pattern, NO address register -- __shfl_down costs one VGPR of lane addresses per distance,
 // which the compiler hoists out of every loop around the call and then spills in the 80-register NMS kernel) and one bpermute for xor 32.
 __device__ __forceinline__ int wave_suffix_sum(int v, int lane) {
-    int tot = v, suf = v;
+    int suf = v;
 #if defined(__HIP_DEVICE_COMPILE__)
+    int tot = v;
 #define SSDHIP_SWZ_STEP(D)                                                              \
     {                                                                                   \
         const int o = __builtin_amdgcn_ds_swizzle(tot, 0x1F | ((D) << 10));             \

@@ -1,0 +1,174 @@
+// ssdhip_optim.hip -- the parameter side of the TRAINING step on gfx950 (MI355X): one launch over ALL parameters instead of one or
+// two framework kernels per layer.
+//
+// The reference trains with keras.optimizers.SGD(lr=0.001, momentum=0.9) on float32 weights (ssd300_training.ipynb:169-173).  Here the
+// float32 master weights stay the optimizer's; what the MFMA kernels read are bf16 copies in the layouts they want:
+//   * the layer's filters [Cout][kh][kw][Cin] bf16 (channels_last) for the forward pass and the weight gradient,
+//   * the same filters transposed (Cin <-> Cout) with their taps flipped, [Cin][kh][kw][Cout], for the data gradient (a stride-1 'same'
+//     convolution of dL/dy with exactly those filters).
+// Round 4 built them per layer and per step with framework ops: a cast, a layout copy where a kernel wanted channels_last, torch.flip +
+// permute + contiguous in every backward, torch.cat for the packed predictor heads -- 52 copies, 19 flips, 15 concatenations, 24 fills:
+// ~0.8 ms and ~110 launches of an 11 ms step (profiles/r05h_train_step_timeline.json).
+//
+//   shadow_refresh_kernel   grid = tiles of 32 x 32 (Cout x Cin) filter taps over every weight tensor + a tail for the 1-D tensors
+//                           (biases, L2Normalization's gamma): float32 master -> bf16 through LDS, both layouts written as 64-byte runs.
+//   sgd_momentum_kernel     torch.optim.SGD's update (buf = momentum buf + g [+ wd p]; p -= lr buf; the first step's buf = g), every
+//                           parameter in one launch, float32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+__device__ __forceinline__ unsigned short opt_f2b(float f) {          // round to nearest even, NaN stays NaN (as c10::BFloat16)
+    const u32 u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+constexpr int SH_T = 32;                                  // tile edge (output x input channels)
+constexpr int SH_MAXKK = 16;                              // taps of a filter: 1 x 1, 3 x 3, 4 x 4 (SSD512's conv10_2)
+
+// One block = one (32 Cout x 32 Cin) tile of one weight tensor, or one 256-element run of a 1-D tensor.
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const ssdhip_shadow_desc* __restrict__ tab, int n_w, int n_tiles, int n_v) {
+    __shared__ unsigned short tile[SH_MAXKK * SH_T * (SH_T + 2)];
+    __shared__ int sh_which;
+    const int tid = threadIdx.x;
+    int blk = (int)blockIdx.x;
+    if (blk >= n_tiles) {                                 // ---- 1-D tensors: descriptors n_w .. n_w + n_v - 1, tile0 = first run
+        blk -= n_tiles;
+        if (tid == 0) {
+            int k = n_w;
+            while (k + 1 < n_w + n_v && tab[k + 1].tile0 <= blk) ++k;
+            sh_which = k;
+        }
+        __syncthreads();
+        const ssdhip_shadow_desc d = tab[sh_which];
+        const int i = (blk - d.tile0) * 256 + tid;
+        if (i < d.O) static_cast<unsigned short*>(d.cl)[i] = opt_f2b(static_cast<const float*>(d.src)[i]);
+        return;
+    }
+    if (tid == 0) {
+        int k = 0;
+        while (k + 1 < n_w && tab[k + 1].tile0 <= blk) ++k;
+        sh_which = k;
+    }
+    __syncthreads();
+    const ssdhip_shadow_desc d = tab[sh_which];
+    const int kk = d.KK;
+    const int ti = (d.I + SH_T - 1) / SH_T;
+    const int t = blk - d.tile0;
+    const int o0 = (t / ti) * SH_T, i0 = (t % ti) * SH_T;
+    const int no = min(SH_T, d.O - o0), ni = min(SH_T, d.I - i0);
+    const float* src = static_cast<const float*>(d.src);
+    const int run = ni * kk;
+    if (d.src_channels_last) {
+        // master [O][kk][I] float32 (a channels_last parameter): runs of ni values per (o, tap)
+        for (int e = tid; e < no * run; e += 256) {
+            const int o = e / run, j = e - o * run;
+            const int tap = j / ni, i = j - tap * ni;
+            tile[(tap * SH_T + o) * (SH_T + 2) + i] = opt_f2b(src[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i]);
+        }
+    } else {
+        // master [O][I][kk] float32: the tile's row o is the contiguous run [i0 .. i0 + ni) x kk
+        for (int e = tid; e < no * run; e += 256) {
+            const int o = e / run, j = e - o * run;
+            const int i = j / kk, tap = j - i * kk;
+            tile[(tap * SH_T + o) * (SH_T + 2) + i] = opt_f2b(src[((size_t)(o0 + o) * d.I + i0) * kk + j]);
+        }
+    }
+    __syncthreads();
+    // channels_last copy [O][kk][I]: runs of ni values
+    unsigned short* cl = static_cast<unsigned short*>(d.cl);
+    if (cl) {
+        for (int e = tid; e < no * kk * SH_T; e += 256) {
+            const int i = e & (SH_T - 1), r = e >> 5;
+            const int tap = r % kk, o = r / kk;
+            if (i < ni) cl[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i] = tile[(tap * SH_T + o) * (SH_T + 2) + i];
+        }
+    }
+    // transposed, taps flipped [I][kk][tr_ostride] at channel offset tr_ooff: runs of no values
+    unsigned short* tr = static_cast<unsigned short*>(d.tr);
+    if (tr) {
+        for (int e = tid; e < ni * kk * SH_T; e += 256) {
+            const int o = e & (SH_T - 1), r = e >> 5;
+            const int tap = r % kk, i = r / kk;
+            if (o < no) tr[((size_t)(i0 + i) * kk + (kk - 1 - tap)) * d.tr_ostride + d.tr_ooff + o0 + o] = tile[(tap * SH_T + o) * (SH_T + 2) + i];
+        }
+    }
+}
+
+// torch.optim.SGD (momentum, dampening 0, no Nesterov): four values per thread and step, every tensor of the table in one launch.
+// desc.src = the parameter, desc.cl = its gradient, desc.tr = its momentum buffer (all float32, desc.O elements); tile0 = first block.
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(const ssdhip_shadow_desc* __restrict__ tab, int n, float lr, float momentum,
+                                                           float weight_decay, int first_step) {
+    __shared__ int sh_which;
+    const int tid = threadIdx.x, blk = (int)blockIdx.x;
+    if (tid == 0) {
+        int lo = 0, hi = n - 1;                            // last descriptor with tile0 <= blk
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].tile0 <= blk) lo = mid; else hi = mid - 1;
+        }
+        sh_which = lo;
+    }
+    __syncthreads();
+    const ssdhip_shadow_desc d = tab[sh_which];
+    float* p = static_cast<float*>(const_cast<void*>(d.src));
+    const float* g = static_cast<const float*>(d.cl);
+    float* m = static_cast<float*>(d.tr);
+    const long long base = (long long)(blk - d.tile0) * 4096;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long i = base + (long long)u * 1024 + tid * 4;
+        if (i + 3 < d.O) {
+            const float4 pv = *reinterpret_cast<const float4*>(p + i), gv = *reinterpret_cast<const float4*>(g + i);
+            float4 mv = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(m + i);
+            float gg[4] = {gv.x, gv.y, gv.z, gv.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float gq = gg[q];
+                if (weight_decay != 0.f) gq = gq + weight_decay * pp[q];
+                mm[q] = first_step ? gq : momentum * mm[q] + gq;
+                pp[q] = pp[q] - lr * mm[q];
+            }
+            *reinterpret_cast<float4*>(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        } else {
+            for (long long j = i; j < d.O && j < i + 4; ++j) {
+                float gq = g[j];
+                if (weight_decay != 0.f) gq = gq + weight_decay * p[j];
+                const float mq = first_step ? gq : momentum * m[j] + gq;
+                m[j] = mq;
+                p[j] = p[j] - lr * mq;
+            }
+        }
+    }
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+extern "C" int ssdhip_shadow_refresh(const ssdhip_shadow_desc* table_dev, int n_weights, int n_tiles, int n_vectors, int n_vector_blocks,
+                                     void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!table_dev || n_weights < 0 || n_vectors < 0 || n_tiles < 0 || n_vector_blocks < 0 || (n_weights == 0) != (n_tiles == 0)
+        || (n_vectors == 0) != (n_vector_blocks == 0))
+        return SSDHIP_E_BADARG;
+    if (n_tiles + n_vector_blocks == 0) return SSDHIP_OK;
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)(n_tiles + n_vector_blocks)), dim3(256), 0, stream, table_dev, n_weights,
+                       n_tiles, n_vectors);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_sgd_momentum_step(const ssdhip_shadow_desc* table_dev, int n_tensors, int n_blocks, double lr, double momentum,
+                                        double weight_decay, int first_step, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!table_dev || n_tensors <= 0 || n_blocks <= 0) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, table_dev, n_tensors, (float)lr,
+                       (float)momentum, (float)weight_decay, first_step ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

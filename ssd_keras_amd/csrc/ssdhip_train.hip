@@ -29,6 +29,8 @@ __device__ __forceinline__ u32 tf2b(float f) {             // round to nearest e
 }
 
 // gy, y, out: [n_pixels][C] bf16 as uint4 (8 channels); partial: [gridDim.x][C] float32.  cvec = C / 8 divides 256.
+// MASK = false: no activation behind the layer (the packed predictor heads): channel sums of gy only, nothing written to `out`.
+template <bool MASK>
 __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const uint4* __restrict__ gy, const uint4* __restrict__ y,
                                                             uint4* __restrict__ out, float* __restrict__ partial, u32 n_pixels,
                                                             u32 cvec) {
@@ -38,19 +40,21 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const uint4* __restr
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (u32 px = blockIdx.x * ppb + pl; px < n_pixels; px += gridDim.x * ppb) {
         const size_t i = (size_t)px * cvec + cg;
-        const uint4 g = gy[i], v = y[i];
+        const uint4 g = gy[i];
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (MASK) v = y[i];
         const u32 gw[4] = {g.x, g.y, g.z, g.w}, vw[4] = {v.x, v.y, v.z, v.w};
         u32 o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // threshold_backward(grad, y, 0): zero where y <= 0 (a NaN activation lets the gradient through)
-            const u32 lo = (tb2f(vw[q] & 0xffffu) <= 0.f) ? 0u : (gw[q] & 0xffffu);
-            const u32 hi = (tb2f(vw[q] >> 16) <= 0.f) ? 0u : (gw[q] >> 16);
+            const u32 lo = (MASK && tb2f(vw[q] & 0xffffu) <= 0.f) ? 0u : (gw[q] & 0xffffu);
+            const u32 hi = (MASK && tb2f(vw[q] >> 16) <= 0.f) ? 0u : (gw[q] >> 16);
             o[q] = lo | (hi << 16);
             acc[2 * q] += tb2f(lo);
             acc[2 * q + 1] += tb2f(hi);
         }
-        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        if (MASK) out[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) red[tid * 8 + q] = acc[q];
@@ -197,8 +201,20 @@ extern "C" int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, voi
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!gy || !y || !out || !partial || n_pixels <= 0 || n_pixels > 0x7fffffffLL) return SSDHIP_E_BADARG;
     if (n_blocks <= 0 || n_blocks != ssdhip_relu_bwd_bias_blocks(n_pixels, C)) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy), static_cast<const uint4*>(y),
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy), static_cast<const uint4*>(y),
                        static_cast<uint4*>(out), partial, (u32)n_pixels, (u32)(C / 8));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// Channel sums of a bf16 map alone (the bias gradient of a layer WITHOUT activation: the packed predictor heads): partial [n_blocks][C]
+// float32 per-workgroup sums, n_blocks = ssdhip_relu_bwd_bias_blocks(n_pixels, C); the caller -- or the reduction launch of the layer's
+// weight gradient, ssdhip_conv3x3_wgrad_bias_nhwc_bf16 -- adds the rows in order.
+extern "C" int ssdhip_channel_sums_nhwc_bf16(const void* gy, float* partial, long long n_pixels, int C, int n_blocks, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!gy || !partial || n_pixels <= 0 || n_pixels > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if (n_blocks <= 0 || n_blocks != ssdhip_relu_bwd_bias_blocks(n_pixels, C)) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy), static_cast<const uint4*>(gy),
+                       static_cast<uint4*>(nullptr), partial, (u32)n_pixels, (u32)(C / 8));
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -334,9 +334,40 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 #endif
 }
 
-// out[i] = sum over the slots, in index order (float4 per thread)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out, int n4, int slots) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+// out[i] = sum over the slots, in index order (float4 per thread) -- blocks 0 .. rb1 - 1.  The blocks behind them (round 5) finish the
+// layer's BIAS gradient on the side: brows rows of per-workgroup channel sums [brows][4 bC4] (what the ReLU / pooling backward passes of
+// csrc/ssdhip_train.hip leave behind) -> bout [4 bC4].  A block owns 32 channels (8 float4 columns) x 32 row lanes; a lane adds rows
+// lane, lane + 32, ... in that order, the 32 lane sums are added in lane order: a fixed summation order, bit-reproducible, and no launch
+// of its own (the framework's `partial.sum(0)`: 30 launches, 0.31 ms of the step, profiles/r05i_train_step_timeline.json).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out, int n4, int slots,
+                                                           int rb1, const float4* __restrict__ bpart, float4* __restrict__ bout, int bC4,
+                                                           int brows) {
+    if ((int)blockIdx.x >= rb1) {
+        __shared__ float4 red[32][8];
+        const int col = (int)threadIdx.x & 7, rl = (int)threadIdx.x >> 3;
+        const int c4 = ((int)blockIdx.x - rb1) * 8 + col;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < bC4) {
+            for (int r0 = rl; r0 < brows; r0 += 32 * 4) {                  // four rows in flight per trip
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + 32 * u;
+                    v[u] = r < brows ? bpart[(size_t)r * bC4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+        }
+        red[rl][col] = s;
+        __syncthreads();
+        if (rl == 0 && c4 < bC4) {
+            for (int j = 1; j < 32; ++j) { const float4 v = red[j][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            bout[c4] = s;
+        }
+        return;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += rb1 * blockDim.x) {
         float4 s = part[i];
         for (int k = 1; k < slots; ++k) {
             const float4 v = part[(size_t)k * n4 + i];
@@ -388,11 +419,16 @@ extern "C" size_t ssdhip_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int 
 // stride-1 dilation-1 convolution y = conv(x, w): x [B, H, W, Cin] bf16, dy [B, H, W, Cout] bf16 (the gradient w.r.t. the convolution's
 // output, ReLU mask applied by the caller).  Cin % 64 == 0; Cout % 128 == 0 with W <= 190, or Cout % 64 == 0 with W <= 318.
 // Bit-reproducible run to run (fixed summation order).  SSDHIP_E_BADARG for other geometries (callers fall back to the framework).
-extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
-                                              size_t ws_bytes, void* stream_) {
+// ... and the layer's bias gradient with it: bias_partial [bias_rows][Cout] float32 per-workgroup channel sums of dy (as
+// ssdhip_relu_bwd_bias_nhwc_bf16 / ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16 / ssdhip_channel_sums_nhwc_bf16 write them) -> db [Cout]
+// float32, rows added in a fixed order by extra workgroups of the reduction launch.  bias_partial == NULL: weight gradient only.
+extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows,
+                                                   float* db, int B, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                                                   void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     WgPlan pl;
     if (!x || !dy || !dw || !wg_plan(B, H, W, Cin, Cout, pl)) return SSDHIP_E_BADARG;
+    if (bias_partial && (!db || bias_rows <= 0 || (((uintptr_t)bias_partial | (uintptr_t)db) & 15))) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) return SSDHIP_E_BADARG;
     if (!ws || ws_bytes < pl.ws_bytes || ((uintptr_t)ws & 15)) return SSDHIP_E_WORKSPACE;
     WgParams p;
@@ -425,7 +461,13 @@ extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, flo
     const int n4 = Cout * 9 * Cin / 4;
     int rb = (n4 + 255) / 256;
     if (rb > 2048) rb = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw),
-                       n4, pl.slots);
+    const int bC4 = bias_partial ? Cout / 4 : 0, rb2 = (bC4 + 7) / 8;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + rb2), dim3(256), 0, stream, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw),
+                       n4, pl.slots, rb, reinterpret_cast<const float4*>(bias_partial), reinterpret_cast<float4*>(db), bC4, bias_rows);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    return ssdhip_conv3x3_wgrad_bias_nhwc_bf16(x, dy, dw, nullptr, 0, nullptr, B, H, W, Cin, Cout, ws, ws_bytes, stream);
 }

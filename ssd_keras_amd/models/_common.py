@@ -81,13 +81,14 @@ class _ConvBiasActFn(torch.autograd.Function):
     gradient kernels) behind it.  `run` is the libssdhip thunk picked for this layer shape: (x_bf16, w_bf16, b_bf16) -> y."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu, wb=None, bb=None):
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu, wb=None, bb=None, wt=None):
         xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         if wb is None:                                   # no bf16 shadow of the parameters at hand: cast here
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             bb = bias.detach().to(torch.bfloat16) if bias is not None else None
         y = run(xb, wb, bb)
         ctx.save_for_backward(xb, wb, y if relu else None)
+        ctx.wt = wt                                      # the data gradient's filters, built with the shadows (None: built in backward)
         ctx.conf = (stride, padding, dilation, relu, weight.dtype, None if bias is None else bias.dtype, x.dtype)
         return y
 
@@ -96,25 +97,32 @@ class _ConvBiasActFn(torch.autograd.Function):
         xb, wb, y = ctx.saved_tensors
         stride, padding, dilation, relu, wdt, bdt, xdt = ctx.conf
         gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        gb = None
         want_gb = bdt is not None and ctx.needs_input_grad[2]
+        partial = None
         if relu:
-            # ReLU mask and bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the framework pair is the fallback
-            fused = nat.relu_bwd_bias(gy, y)
+            # ReLU mask and the per-workgroup channel sums of the bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the rows
+            # are added by the weight gradient's reduction launch where that is ours, by one framework reduction otherwise
+            fused = nat.relu_bwd_bias(gy, y, reduce=False)
             if fused is not None:
-                gy, gb32 = fused
-                gb = gb32.to(bdt) if want_gb else None
+                gy, partial = fused
             else:
                 gy = torch.ops.aten.threshold_backward(gy, y, 0)
-        if gb is None and want_gb:
-            gb = gy.sum(dim=(0, 2, 3), dtype=torch.float32).to(bdt)
-        gx, gw = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0])
-        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None
+        gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], ctx.wt,
+                                              partial if want_gb else None)
+        if want_gb:
+            if gb is None:
+                gb = partial.sum(dim=0) if partial is not None else gy.sum(dim=(0, 2, 3), dtype=torch.float32)
+            gb = gb.to(bdt)
+        else:
+            gb = None
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None, None
 
 
-def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
-    """dL/dx and dL/dw of a convolution from the (masked) dL/dy: the data gradient of a stride-1 'same' layer through the forward's MFMA
-    kernel, the rest through aten.convolution_backward (MIOpen)."""
+def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=None, bias_partial=None):
+    """dL/dx, dL/dw [and dL/db] of a convolution from the (masked) dL/dy: the data gradient of a stride-1 'same' layer through the
+    forward's MFMA kernel, the rest through aten.convolution_backward (MIOpen).  bias_partial: per-workgroup channel sums of gy
+    ([rows, Cout] float32); the third result is their ordered sum when the weight gradient's reduction launch could add them on the
+    side, None otherwise (the caller reduces them itself)."""
     gx = None
     k = wb.shape[2]
     same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
@@ -123,7 +131,8 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
     if need_x and same and os.environ.get("SSDHIP_NO_OWN_DGRAD", "0") != "1":
         # the data gradient of a stride-1 'same' convolution IS a 'same' convolution of dL/dy with the filters transposed
         # (Cin <-> Cout) and their taps flipped: the forward's MFMA kernel runs it, no bias, no activation
-        wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+        if wt is None:                                   # (the shadow set hands the transposed filters over: csrc/ssdhip_optim.hip)
+            wt = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
         # (the deep 3x3 layers through the slab kernel, csrc/ssdhip_convh.hip: bit-identical and faster, r02o)
         halo = (k == 3 and dilation[0] == 1 and wt.shape[0] % 128 == 0 and wt.shape[1] % 128 == 0
                 and os.environ.get("SSDHIP_NO_HALO", "0") != "1")
@@ -134,11 +143,16 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
             gx = nat.conv3x3_image(gy, wt, None, dilation=dilation[0], relu=False)
         else:
             gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
-    gw = None
+    gw, gb = None, None
     if (k == 3 and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1) and os.environ.get("SSDHIP_NO_OWN_WGRAD", "0") != "1"):
         # the weight gradient through libssdhip's MFMA kernel (csrc/ssdhip_wgrad.hip; float32, fixed summation order); None: geometry
         # not covered (3 input channels, predictor heads whose channel counts are not multiples of 64)
-        gw = nat.conv3x3_wgrad(xb, gy) if (xb.shape[1] % 64 == 0 and gy.shape[1] % 64 == 0) else None
+        if xb.shape[1] % 64 == 0 and gy.shape[1] % 64 == 0:
+            got = nat.conv3x3_wgrad(xb, gy, bias_partial=bias_partial)
+            if got is not None and bias_partial is not None:
+                gw, gb = got
+            else:
+                gw = got
     masks = [need_x and gx is None, gw is None, False]
     if masks[0] or masks[1]:
         gx_m, gw_m, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0],
@@ -147,7 +161,7 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x):
             gx = gx_m
         if gw is None:
             gw = gw_m
-    return gx, gw
+    return gx, gw, gb
 
 
 class _ConvBiasActPoolFn(torch.autograd.Function):
@@ -157,13 +171,14 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
     written -- then the convolution's gradients as in _ConvBiasActFn."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, run, stride, padding, dilation, wb=None, bb=None):
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, wb=None, bb=None, wt=None):
         xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             bb = bias.detach().to(torch.bfloat16) if bias is not None else None
         y = run(xb, wb, bb)
         p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
+        ctx.wt = wt
         ctx.save_for_backward(xb, wb, y)
         ctx.conf = (stride, padding, dilation, weight.dtype, None if bias is None else bias.dtype, x.dtype)
         return p
@@ -173,13 +188,18 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
         xb, wb, y = ctx.saved_tensors
         stride, padding, dilation, wdt, bdt, xdt = ctx.conf
         gp = gp.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        fused = nat.maxpool2_relu_bwd_bias(y, gp)
+        fused = nat.maxpool2_relu_bwd_bias(y, gp, reduce=False)
         if fused is None:
             raise RuntimeError("channel count not supported by the fused pooling backward (the forward checks it)")
-        gy, gb32 = fused
-        gb = gb32.to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
-        gx, gw = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0])
-        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None
+        gy, partial = fused
+        want_gb = bdt is not None and ctx.needs_input_grad[2]
+        gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], ctx.wt,
+                                              partial if want_gb else None)
+        if want_gb:
+            gb = (gb if gb is not None else partial.sum(dim=0)).to(bdt)
+        else:
+            gb = None
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None
 
 
 class _PackedHeadFn(torch.autograd.Function):
@@ -190,32 +210,29 @@ class _PackedHeadFn(torch.autograd.Function):
     (B, Cp, H, W) bf16 map; the caller slices conf / loc out of it (reference: models/keras_ssd300.py:322-335)."""
 
     @staticmethod
-    def forward(ctx, x, wc, bc, wl, bl, wcb, bcb, wlb, blb):
+    def forward(ctx, x, wc, bc, wl, bl, pw, pb, pwt):
+        """pw / pb / pwt: the packed bf16 filters [conf | loc | zero rows], biases and transposed / flipped filters of this source map,
+        kept up to date with the parameters by the model's shadow set (SSDModel._packed_head_shadow): nothing is concatenated here."""
         xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        nc, nl = wc.shape[0], wl.shape[0]
-        pad = (-(nc + nl)) % 128
-        parts_w = [wcb, wlb] + ([wcb.new_zeros((pad,) + tuple(wcb.shape[1:]))] if pad else [])
-        parts_b = [bcb, blb] + ([bcb.new_zeros((pad,))] if pad else [])
-        w = torch.cat(parts_w, dim=0).contiguous(memory_format=torch.channels_last)
-        y = nat.conv3x3_halo(xb, w, torch.cat(parts_b, dim=0), relu=False, pool=False)
-        ctx.save_for_backward(xb, w)
-        ctx.conf = (nc, nl, wc.dtype, bc.dtype, x.dtype)
+        y = nat.conv3x3_halo(xb, pw, pb, relu=False, pool=False)
+        ctx.save_for_backward(xb, pw, pwt)
+        ctx.conf = (wc.shape[0], wl.shape[0], wc.dtype, bc.dtype, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xb, w = ctx.saved_tensors
+        xb, w, wt = ctx.saved_tensors
         nc, nl, wdt, bdt, xdt = ctx.conf
         gyb = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         gx = None
         if ctx.needs_input_grad[0]:
-            wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
             gx = nat.conv2d_same(gyb, wt, None, dilation=1, relu=False, variant=7).to(xdt)
-        gw = nat.conv3x3_wgrad(xb, gyb)
-        if gw is None:
+        partial = nat.channel_sums_partial(gyb)              # per-workgroup channel sums; the weight gradient's reduction launch adds them
+        got = nat.conv3x3_wgrad(xb, gyb, bias_partial=partial)
+        if got is None:
             raise RuntimeError("packed predictor head: weight-gradient geometry not covered")
-        gb = gyb.float().sum(dim=(0, 2, 3))
-        return (gx, gw[:nc].to(wdt), gb[:nc].to(bdt), gw[nc:nc + nl].to(wdt), gb[nc:nc + nl].to(bdt), None, None, None, None)
+        gw, gb = got if partial is not None else (got, gyb.float().sum(dim=(0, 2, 3)))
+        return (gx, gw[:nc].to(wdt), gb[:nc].to(bdt), gw[nc:nc + nl].to(wdt), gb[nc:nc + nl].to(bdt), None, None, None)
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -499,8 +516,8 @@ class SSDModel(nn.Module):
         if self._fused_train(x, conv):
             run, _name = self._train_thunk(conv, x, relu)
             if run is not None:
-                wb, bb = self._bf16_shadow(conv)
-                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu, wb, bb)
+                wb, bb, wt = self._bf16_shadow(conv, with_transposed=True)
+                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu, wb, bb, wt)
         y = conv(x)
         return F.relu(y) if relu else y
 
@@ -510,19 +527,60 @@ class SSDModel(nn.Module):
         return (self.fused_training and x.is_cuda and torch.is_grad_enabled() and conv.bias is not None and conv.groups == 1
                 and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
 
-    def _bf16_shadow(self, conv):
-        """bf16 copies of a convolution's float32 master weight and bias for the libssdhip forward.  All shadows of the model are
-        refreshed together by ONE multi-tensor copy whenever a parameter changed (the optimizer's in-place update bumps
-        `_version`), instead of two cast kernels per layer per step."""
-        if conv.weight.dtype == torch.bfloat16:
-            return conv.weight.detach(), conv.bias.detach()
+    @staticmethod
+    def _own_dgrad_ok(conv):
+        """The data gradient of this layer runs on libssdhip's forward kernels with transposed / flipped filters (see
+        _conv_input_weight_grads): stride 1, 'same', k in (1, 3), channel counts multiples of 64."""
+        k = conv.kernel_size[0]
+        return (conv.stride == (1, 1) and conv.kernel_size[1] == k and k in (1, 3) and conv.dilation[0] == conv.dilation[1]
+                and conv.padding == (conv.dilation[0] * (k // 2),) * 2 and conv.groups == 1
+                and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+
+    def _shadow_build(self, device):
+        """bf16 copies of every convolution's float32 master weights in the layouts the MFMA kernels read (csrc/ssdhip_optim.hip):
+        channels_last filters, their transposed / tap-flipped twin where the layer's data gradient runs on our kernels, the bias; the
+        conf and loc heads of a source map as ROWS OF ONE packed tensor ([conf | loc | zero rows up to a multiple of 128]: what
+        _PackedHeadFn multiplies), so that nothing is concatenated, flipped or re-laid-out per step."""
+        convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m.bias is not None]
+        index = {id(c): i for i, c in enumerate(convs)}
+        cl, tr, bias, tr_arg = [None] * len(convs), [None] * len(convs), [None] * len(convs), [(0, 0)] * len(convs)
+        packs = {}
+        heads = list(zip(getattr(self, "conf_heads", []), getattr(self, "loc_heads", [])))
+        with torch.no_grad():
+            for l, (ch, lh) in enumerate(heads):
+                same = lambda c: (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1)
+                                  and c.dilation == (1, 1) and c.groups == 1 and c.bias is not None and id(c) in index)
+                if not (same(ch) and same(lh) and ch.in_channels == lh.in_channels and ch.in_channels % 128 == 0):
+                    continue
+                nc, nl, cin = ch.out_channels, lh.out_channels, ch.in_channels
+                cp = -(-(nc + nl) // 128) * 128
+                pw = torch.zeros((cp, cin, 3, 3), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+                pwt = torch.zeros((cin, cp, 3, 3), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+                pb = torch.zeros((cp,), dtype=torch.bfloat16, device=device)
+                packs[l] = (pw, pb, pwt, nc, nl)
+                for conv, lo, n in ((ch, 0, nc), (lh, nc, nl)):
+                    i = index[id(conv)]
+                    cl[i], bias[i], tr[i], tr_arg[i] = pw[lo:lo + n], pb[lo:lo + n], pwt, (cp, lo)
+            for i, c in enumerate(convs):
+                if cl[i] is not None:
+                    continue
+                cl[i] = torch.empty(tuple(c.weight.shape), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+                if cl[i].dim() == 4 and not cl[i].permute(0, 2, 3, 1).is_contiguous():          # size-1 dims can leave odd strides behind
+                    cl[i] = torch.empty(tuple(c.weight.permute(0, 2, 3, 1).shape), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)
+                bias[i] = torch.empty((c.out_channels,), dtype=torch.bfloat16, device=device)
+                if self._own_dgrad_ok(c):
+                    o, ci, kh, kw = c.weight.shape
+                    tr[i] = torch.empty((ci, kh, kw, o), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)   # (I, O, kh, kw) channels_last
+                    tr_arg[i] = (o, 0)
+        return {"device": device, "convs": convs, "index": index, "cl": cl, "tr": tr, "bias": bias, "tr_arg": tr_arg, "packs": packs,
+                "key": None, "table": None, "table_key": None}
+
+    def _shadow_state_fresh(self, conv):
+        """The shadow state with every bf16 copy up to date (ONE launch over all parameters when any of them changed: the optimizer's
+        in-place update bumps `_version`)."""
         st = self.__dict__.get("_shadow_state")
         if st is None or st["device"] != conv.weight.device:
-            convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m.bias is not None]
-            with torch.no_grad():
-                dst = [torch.empty_like(t, dtype=torch.bfloat16) for t in [c.weight for c in convs] + [c.bias for c in convs]]
-            st = {"device": conv.weight.device, "convs": convs, "dst": dst, "key": None,
-                  "index": {id(c): i for i, c in enumerate(convs)}, "n": len(convs)}
+            st = self._shadow_build(conv.weight.device)
             self.__dict__["_shadow_state"] = st
         # Inside raw_predictions the check runs once per forward pass (`_shadow_fresh`); a direct call of features() / conv_act()
         # checks every time.  The key holds the Parameter OBJECT, its storage and its version: an optimizer step bumps the version,
@@ -531,18 +589,44 @@ class SSDModel(nn.Module):
             src = [c.weight for c in st["convs"]] + [c.bias for c in st["convs"]]
             key = tuple((id(t), t.data_ptr(), t._version) for t in src)
             if key != st["key"]:
-                with torch.no_grad():
-                    torch._foreach_copy_(st["dst"], [t.detach() for t in src])
-                # Inside a stream capture the copy is only RECORDED (it runs at every replay): the shadows are not fresh for the next
+                tkey = tuple((id(t), t.data_ptr(), tuple(t.stride())) for t in src)
+                if st["table"] is None or st["table_key"] != tkey:             # the table holds raw pointers: rebuilt when a storage moved
+                    w = [(c.weight.detach(), st["cl"][i], st["tr"][i], st["tr_arg"][i][0], st["tr_arg"][i][1]) for i, c in enumerate(st["convs"])]
+                    v = [(c.bias.detach().contiguous(), st["bias"][i]) for i, c in enumerate(st["convs"])]
+                    if any(b.data_ptr() != c.bias.data_ptr() for (b, _), c in zip(v, st["convs"])):
+                        raise RuntimeError("a convolution bias is not a contiguous tensor")
+                    st["table"] = nat.shadow_table(w, v, st["device"])
+                    st["table_key"] = tkey
+                nat.shadow_refresh(st["table"])
+                # Inside a stream capture the refresh is only RECORDED (it runs at every replay): the shadows are not fresh for the next
                 # eager call, which must refresh them itself (tests/test_train_graph_gpu.py: the first eager step after a capture
                 # multiplied the previous step's filters, 1.3e-3 off on the loss).
                 if not torch.cuda.is_current_stream_capturing():
                     st["key"] = key
             self.__dict__["_shadow_fresh"] = True
+        return st
+
+    def _bf16_shadow(self, conv, with_transposed=False):
+        """bf16 copies of a convolution's float32 master weight (channels_last) and bias for the libssdhip kernels [+ the transposed,
+        tap-flipped filters of its data gradient, or None]; (None, None[, None]) for a convolution the shadow set does not hold."""
+        if conv.weight.dtype == torch.bfloat16:
+            return (conv.weight.detach(), conv.bias.detach(), None) if with_transposed else (conv.weight.detach(), conv.bias.detach())
+        st = self._shadow_state_fresh(conv)
         i = st["index"].get(id(conv))
         if i is None:
-            return None, None
-        return st["dst"][i], st["dst"][st["n"] + i]
+            return (None, None, None) if with_transposed else (None, None)
+        if with_transposed:
+            packed = st["tr_arg"][i][0] != conv.out_channels               # a head's rows live in its source map's packed tensor
+            return st["cl"][i], st["bias"][i], (None if packed else st["tr"][i])
+        return st["cl"][i], st["bias"][i]
+
+    def _packed_head_shadow(self, l):
+        """(packed filters (Cp, Cin, 3, 3) bf16 channels_last, packed bias (Cp,), transposed / flipped (Cin, Cp, 3, 3), n_conf, n_loc) of
+        predictor layer l, up to date; None when the heads of that source map are not packed."""
+        ch = self.conf_heads[l]
+        if ch.weight.dtype == torch.bfloat16:
+            return None
+        return self._shadow_state_fresh(ch)["packs"].get(l)
 
     def _train_thunk(self, conv, x, relu):
         """The libssdhip kernel for this layer as `(x_bf16, w_bf16, b_bf16) -> y`, or (None, None).  The variant is the one the
@@ -620,8 +704,8 @@ class SSDModel(nn.Module):
                 and 256 % (conv.out_channels // 8) == 0 and os.environ.get("SSDHIP_NO_FUSED_POOL_BWD", "0") != "1"):
             run, _name = self._train_thunk(conv, x, True)
             if run is not None:
-                wb, bb = self._bf16_shadow(conv)
-                return _ConvBiasActPoolFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, wb, bb)
+                wb, bb, wt = self._bf16_shadow(conv, with_transposed=True)
+                return _ConvBiasActPoolFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, wb, bb, wt)
         return self.max_pool(self.conv_act(conv, x, relu=True), kernel, stride, pad, ceil_mode=ceil_mode)
 
     def conv1_block_pool(self, c1, c2, x):
@@ -766,9 +850,8 @@ class SSDModel(nn.Module):
         for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads):
             # NCHW -> NHWC before the reshape so the channel axis splits as (box, class) like Keras (:363-383)
             if self._packed_train_head_ok(f, ch, lh):
-                wcb, bcb = self._bf16_shadow(ch)
-                wlb, blb = self._bf16_shadow(lh)
-                y = _PackedHeadFn.apply(f, ch.weight, ch.bias, lh.weight, lh.bias, wcb, bcb, wlb, blb).permute(0, 2, 3, 1)
+                pw, pb, pwt, _nc, _nl = self._packed_head_shadow(len(confs))
+                y = _PackedHeadFn.apply(f, ch.weight, ch.bias, lh.weight, lh.bias, pw, pb, pwt).permute(0, 2, 3, 1)
                 confs.append(y[..., :ch.out_channels].reshape(b, -1, self.n_classes))
                 locs.append(y[..., ch.out_channels:ch.out_channels + lh.out_channels].reshape(b, -1, 4))
                 continue
@@ -880,7 +963,7 @@ class SSDModel(nn.Module):
         import os
         return (self._fused_train(f, ch) and lh.bias is not None and self._packed_head_ok(ch, lh, f) and f.shape[1] % 128 == 0
                 and f.shape[3] <= 190 and os.environ.get("SSDHIP_NO_OWN_HEADS", "0") != "1"
-                and self._bf16_shadow(ch)[0] is not None and self._bf16_shadow(lh)[0] is not None)
+                and ch in self.conf_heads and self._packed_head_shadow(list(self.conf_heads).index(ch)) is not None)
 
     def _heads_grouped(self, feats):
         outs = nat.conv2d_same_group(list(feats), [self._packed_head_weight(l) for l in range(len(feats))], None, relu=False)

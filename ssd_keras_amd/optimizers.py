@@ -1,0 +1,86 @@
+"""`SGD` -- the optimizer of the reference's training notebooks, `keras.optimizers.SGD(lr=0.001, momentum=0.9, decay=0.0,
+nesterov=False)` (ssd300_training.ipynb:169), as a torch optimizer whose step is ONE libssdhip launch over every parameter
+(csrc/ssdhip_optim.hip, sgd_momentum_kernel) instead of the framework's dozen multi-tensor launches (0.34 ms of an 11 ms SSD300 step,
+profiles/r05h_train_step_timeline.json).
+
+Update rule: torch.optim.SGD's (`buf = momentum * buf + grad`, `p -= lr * buf`), which is Keras's (`v = momentum * v - lr * g`,
+`p += v`) for a constant learning rate; `weight_decay` adds `weight_decay * p` to the gradient first (Keras expresses the same thing as
+`kernel_regularizer=l2(5e-4)` on the loss, models/keras_ssd300.py:274: gradient `2 * 5e-4 * W`).  float32 parameters on a GPU with
+gradients of their own memory layout take the fused launch; anything else (CPU tensors, other dtypes, momentum 0) the plain tensor
+expressions below."""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nat
+
+
+def _bump_versions(tensors):
+    """What an in-place tensor op does to `_version`, for parameters a libssdhip kernel has just updated behind autograd's back."""
+    try:
+        torch._C._autograd._unsafe_set_version_counter(tuple(tensors), tuple(t._version + 1 for t in tensors))
+    except (AttributeError, TypeError):                      # an older framework: a multi-tensor no-op bumps them too
+        torch._foreach_add_(list(tensors), 0)
+
+
+class SGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=0.01, momentum=0.0, weight_decay=0.0, decay=0.0, nesterov=False):
+        if lr < 0.0 or momentum < 0.0 or weight_decay < 0.0:
+            raise ValueError("lr, momentum and weight_decay must be non-negative")
+        if decay != 0.0 or nesterov:
+            raise ValueError("the reference trains with decay=0.0, nesterov=False (ssd300_training.ipynb:169); neither is implemented")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._tables = {}
+
+    @staticmethod
+    def _dense(t):
+        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
+            fused, rest = [], []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                ok = (mom != 0.0 and p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse
+                      and self._dense(p) and tuple(g.stride()) == tuple(p.stride()) and p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0)
+                (fused if ok else rest).append(p)
+            by_dev = {}
+            for p in fused:
+                by_dev.setdefault(p.device, []).append(p)
+            for dev, ps in by_dev.items():
+                bufs = []
+                for p in ps:
+                    st = self.state[p]
+                    if "momentum_buffer" not in st:               # zeros: the first update is then buf = grad, as torch's clone(grad)
+                        st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    bufs.append(st["momentum_buffer"])
+                key = tuple((p.data_ptr(), p.grad.data_ptr(), b.data_ptr(), p.numel()) for p, b in zip(ps, bufs))
+                hit = self._tables.get((gi, dev))
+                if hit is None or hit[0] != key:                    # the table holds raw pointers: rebuilt when a gradient moved
+                    flat = lambda t: t.detach().as_strided((t.numel(),), (1,))
+                    hit = (key, nat.sgd_table([flat(p) for p in ps], [flat(p.grad) for p in ps], [flat(b) for b in bufs], dev))
+                    self._tables[(gi, dev)] = hit
+                nat.sgd_momentum_step(hit[1], lr, mom, wd)
+                _bump_versions(ps)                                  # caches keyed on `_version` (the bf16 shadows) must see the update
+            for p in rest:
+                g = p.grad
+                if wd != 0.0:
+                    g = g.add(p, alpha=wd)
+                if mom != 0.0:
+                    st = self.state[p]
+                    buf = st.get("momentum_buffer")
+                    if buf is None:
+                        buf = st["momentum_buffer"] = torch.clone(g).detach()
+                    else:
+                        buf.mul_(mom).add_(g)
+                    g = buf
+                p.add_(g, alpha=-lr)
+        return loss

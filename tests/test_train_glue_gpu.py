@@ -102,3 +102,75 @@ def test_fused_pool_relu_backward_equals_the_two_kernels(shape):
     ref = torch.ops.aten.threshold_backward(yf.grad.to(torch.bfloat16), y2, 0)
     got2, _ = nat.maxpool2_relu_bwd_bias(y2, gp)
     assert torch.equal(got2.float(), ref.float())                           # (-0 and +0 compare equal)
+
+
+@pytest.mark.parametrize("channels_last_master", [False, True])
+def test_shadow_refresh_builds_every_layout_in_one_launch(channels_last_master):
+    """csrc/ssdhip_optim.hip: the bf16 channels_last filters, the transposed / tap-flipped filters of the data gradient and the bf16
+    biases of many tensors from ONE launch == the framework expressions round 4 ran per layer (cast, contiguous(channels_last),
+    flip + permute), bit for bit -- including ragged channel counts (3, 84, 16), 1 x 1 and 4 x 4 filters and the conf / loc heads of a
+    source map as rows of one packed tensor."""
+    torch, nat = _t()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(64, 3, 3, 3), (128, 64, 3, 3), (1024, 1024, 1, 1), (256, 128, 4, 4), (96, 160, 3, 3), (84, 512, 3, 3), (16, 512, 3, 3)]
+    ws = [torch.randn(s, device="cuda", generator=g) for s in shapes]
+    ws[1].view(-1)[::101] = float("nan")
+    ws[2].view(-1)[5] = float("inf")
+    if channels_last_master:
+        ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
+    bs = [torch.randn((s[0],), device="cuda", generator=g) for s in shapes]
+    cl = [torch.empty(s, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last) for s in shapes]
+    cl = [c if c.permute(0, 2, 3, 1).is_contiguous() else torch.empty((s[0], s[2], s[3], s[1]), dtype=torch.bfloat16, device="cuda").permute(0, 3, 1, 2)
+          for c, s in zip(cl, shapes)]
+    tr = [torch.empty((s[1], s[2], s[3], s[0]), dtype=torch.bfloat16, device="cuda").permute(0, 3, 1, 2) for s in shapes]
+    # the last two are the conf / loc heads of one map: rows 0..83 and 84..99 of a packed (128, 512, 3, 3) tensor
+    pw = torch.zeros((128, 512, 3, 3), dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    pwt = torch.zeros((512, 128, 3, 3), dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    cl[5], cl[6] = pw[:84], pw[84:100]
+    weights = [(w, c, t, s[0], 0) for w, c, t, s in zip(ws[:5], cl[:5], tr[:5], shapes[:5])]
+    weights += [(ws[5], cl[5], pwt, 128, 0), (ws[6], cl[6], pwt, 128, 84)]
+    bdst = [torch.empty((s[0],), dtype=torch.bfloat16, device="cuda") for s in shapes]
+    table = nat.shadow_table(weights, list(zip(bs, bdst)), torch.device("cuda", 0))
+    nat.shadow_refresh(table)
+    torch.cuda.synchronize()
+    bits = lambda t: t.contiguous().view(torch.int16)
+    for i, w in enumerate(ws):
+        wb = w.to(torch.bfloat16)
+        assert torch.equal(bits(cl[i]), bits(wb)), shapes[i]
+        assert torch.equal(bits(bdst[i]), bits(bs[i].to(torch.bfloat16)))
+        if i < 5:
+            assert torch.equal(bits(tr[i]), bits(wb.flip(2, 3).permute(1, 0, 2, 3))), shapes[i]
+    packed = torch.cat([ws[5], ws[6], torch.zeros((28, 512, 3, 3), device="cuda")], dim=0).to(torch.bfloat16)
+    assert torch.equal(bits(pw), bits(packed))
+    assert torch.equal(bits(pwt), bits(packed.flip(2, 3).permute(1, 0, 2, 3)))
+
+
+def test_fused_sgd_momentum_step_follows_torch_sgd():
+    """ssd_keras_amd.optimizers.SGD (one launch over all parameters) against torch.optim.SGD on the same parameters and gradients
+    over five steps: within one float32 rounding per step (the framework's kernel contracts p + (-lr) buf into an FMA), ragged sizes,
+    channels_last parameters, weight decay in one group only; `_version` of every parameter moves (the bf16 shadows key on it)."""
+    torch, _ = _t()
+    from ssd_keras_amd.optimizers import SGD
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(64, 3, 3, 3), (7,), (512, 256, 3, 3), (1000003,), (33, 5)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11 + i)))
+                  for i, s in enumerate(shapes)]
+    a, b = mk(), mk()
+    with torch.no_grad():
+        for ps in (a, b):
+            ps[2].data = ps[2].data.contiguous(memory_format=torch.channels_last)
+    ours = SGD([{"params": a[:3], "weight_decay": 1e-3}, {"params": a[3:], "weight_decay": 0.0}], lr=1e-2, momentum=0.9)
+    ref = torch.optim.SGD([{"params": b[:3], "weight_decay": 1e-3}, {"params": b[3:], "weight_decay": 0.0}], lr=1e-2, momentum=0.9)
+    for step in range(5):
+        v0 = [p._version for p in a]
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, device="cuda", generator=g)
+            if pa.dim() == 4 and not pa.is_contiguous():
+                gr = gr.contiguous(memory_format=torch.channels_last)
+            pa.grad, pb.grad = gr.clone(memory_format=torch.preserve_format), gr.clone(memory_format=torch.preserve_format)
+        ours.step()
+        ref.step()
+        assert all(p._version > v for p, v in zip(a, v0))
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pa, pb, rtol=3e-7 * (step + 1), atol=1e-7 * (step + 1))
+            torch.testing.assert_close(ours.state[pa]["momentum_buffer"], ref.state[pb]["momentum_buffer"], rtol=1e-6, atol=1e-6)

@@ -100,10 +100,16 @@ def test_packed_head_node_matches_two_framework_convolutions(shape):
     ref = [t.grad.clone() for t in (x, wc, bc, wl, bl)]
     for t in (x, wc, bc, wl, bl):
         t.grad = None
-    bf = lambda t: t.detach().to(torch.bfloat16)
-    wcb = bf(wc).contiguous(memory_format=torch.channels_last)
-    wlb = bf(wl).contiguous(memory_format=torch.channels_last)
-    y = _PackedHeadFn.apply(x, wc, bc, wl, bl, wcb, bf(bc), wlb, bf(bl))
+    # the packed bf16 filters / biases / transposed-flipped filters as the model's shadow set builds them (csrc/ssdhip_optim.hip)
+    from ssd_keras_amd import _native as nat
+    cp = -(-(nc + nl) // 128) * 128
+    pw = torch.zeros((cp, Cin, 3, 3), dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    pwt = torch.zeros((Cin, cp, 3, 3), dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    pb = torch.zeros((cp,), dtype=torch.bfloat16, device="cuda")
+    table = nat.shadow_table([(wc.detach(), pw[:nc], pwt, cp, 0), (wl.detach(), pw[nc:nc + nl], pwt, cp, nc)],
+                             [(bc.detach(), pb[:nc]), (bl.detach(), pb[nc:nc + nl])], x.device)
+    nat.shadow_refresh(table)
+    y = _PackedHeadFn.apply(x, wc, bc, wl, bl, pw, pb, pwt)
     assert y.shape[0] == B and y.shape[1] % 128 == 0 and y.dtype == torch.bfloat16
     got = y[:, :nc + nl].float()
     rms = want.pow(2).mean().sqrt().item()
@@ -112,3 +118,27 @@ def test_packed_head_node_matches_two_framework_convolutions(shape):
     for name, t, r in zip(("x", "w conf", "b conf", "w loc", "b loc"), (x, wc, bc, wl, bl), ref):
         d = float((t.grad - r).norm() / (r.norm() + 1e-20))
         assert d <= 1e-2, "%s gradient %.3g of its norm away" % (name, d)
+
+
+@pytest.mark.parametrize("shape", [(4, 19, 19, 512, 512), (2, 38, 38, 256, 128), (1, 7, 9, 64, 64)])
+def test_weight_gradient_launch_also_finishes_the_bias_gradient(shape):
+    """ssdhip_conv3x3_wgrad_bias_nhwc_bf16: the per-workgroup channel sums the ReLU backward leaves behind are added by extra
+    workgroups of the weight gradient's reduction launch -- db within float32 summation-order noise of the framework's sum, the same
+    bits on every run, and dw bit-identical to the call without them."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(H * Cout)
+    x = torch.randn((B, Cin, H, W), generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.randn((B, Cout, H, W), generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((B, Cout, H, W), generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    masked, partial = nat.relu_bwd_bias(gy, y, reduce=False)
+    assert partial.dim() == 2 and partial.shape[1] == Cout
+    dw0 = nat.conv3x3_wgrad(x, masked)
+    dw1, db = nat.conv3x3_wgrad(x, masked, bias_partial=partial)
+    assert torch.equal(dw0, dw1)
+    torch.testing.assert_close(db, masked.float().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(db, partial.sum(dim=0), rtol=1e-5, atol=1e-4)
+    assert torch.equal(db, nat.conv3x3_wgrad(x, masked, bias_partial=partial)[1])
+    plain = nat.channel_sums_partial(gy)                                  # no activation: the predictor heads' form
+    torch.testing.assert_close(plain.sum(dim=0), gy.float().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
