@@ -519,9 +519,10 @@ int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void
  *             256-element block among the n_vector_blocks vector blocks.
  * ssdhip_shadow_refresh      bf16 (round to nearest even) copies of every tensor of the table in the layouts above.
  * ssdhip_sgd_momentum_step   torch.optim.SGD's update with momentum (dampening 0, no Nesterov) = Keras SGD's for a constant learning
- *                            rate: src = parameter, cl = gradient, tr = momentum buffer, all float32 [O]; tile0 = index of the
- *                            tensor's first 4096-element block, n_blocks their total; first_step: buf = grad (the buffer is written,
- *                            not read).  g += weight_decay * p first when weight_decay != 0. */
+ *                            rate, over n_tensors float32 tensors named by HOST arrays of device pointers (parameter, gradient,
+ *                            momentum buffer -- zeros before the first step -- and element count; 16-byte aligned): buf = momentum *
+ *                            buf + g, p -= lr * buf, g += weight_decay * p first when weight_decay != 0.  The table travels in the
+ *                            kernel arguments (80 tensors per launch): no upload, no host synchronisation. */
 typedef struct ssdhip_shadow_desc {
     const void* src;
     void* cl;
@@ -531,8 +532,8 @@ typedef struct ssdhip_shadow_desc {
     int reserved;
 } ssdhip_shadow_desc;
 int ssdhip_shadow_refresh(const ssdhip_shadow_desc* table_dev, int n_weights, int n_tiles, int n_vectors, int n_vector_blocks, void* stream);
-int ssdhip_sgd_momentum_step(const ssdhip_shadow_desc* table_dev, int n_tensors, int n_blocks, double lr, double momentum,
-                             double weight_decay, int first_step, void* stream);
+int ssdhip_sgd_momentum_step(int n_tensors, void* const* params_h, const void* const* grads_h, void* const* bufs_h,
+                             const long long* numel_h, double lr, double momentum, double weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

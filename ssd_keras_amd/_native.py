@@ -534,7 +534,7 @@ def _optim_lib():
         lib.ssdhip_shadow_refresh.restype = c_int
         lib.ssdhip_shadow_refresh.argtypes = [c_vp, c_int, c_int, c_int, c_int, c_vp]
         lib.ssdhip_sgd_momentum_step.restype = c_int
-        lib.ssdhip_sgd_momentum_step.argtypes = [c_vp, c_int, c_int, c_d, c_d, c_d, c_int, c_vp]
+        lib.ssdhip_sgd_momentum_step.argtypes = [c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_d, c_d, c_vp]
         lib._optim_bound = True
     return lib
 
@@ -576,26 +576,25 @@ def shadow_refresh(table):
 
 
 def sgd_table(params, grads, bufs, device):
-    """The device table of ssdhip_sgd_momentum_step over contiguous float32 tensors (parameter, gradient, momentum buffer)."""
-    import numpy as np
+    """The HOST table of ssdhip_sgd_momentum_step over dense float32 tensors (parameter, gradient, momentum buffer of one memory
+    layout each): ctypes arrays of device pointers and element counts.  It travels in the kernel arguments -- nothing is uploaded."""
     torch = _torch()
-    tab = np.zeros((len(params),), dtype=np.dtype(SHADOW_DESC))
-    blocks = 0
-    for k, (p, g, m) in enumerate(zip(params, grads, bufs)):
+    n = len(params)
+    for p, g, m in zip(params, grads, bufs):
         for t in (p, g, m):
-            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel() or t.data_ptr() % 16:
-                raise SsdHipError("sgd_table: parameter, gradient and momentum buffer must be contiguous float32 of one size")
-        tab[k] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel(), 0, 0, 0, 0, blocks, 0, 0)
-        blocks += -(-p.numel() // 4096)
-    return torch.from_numpy(tab.view(np.uint8).copy()).to(device), len(params), blocks
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel() or t.data_ptr() % 16 or t.device != device:
+                raise SsdHipError("sgd_table: parameter, gradient and momentum buffer must be dense float32 of one size on one device")
+    vp, ll = ctypes.c_void_p * n, ctypes.c_longlong * n
+    return (device, n, vp(*[p.data_ptr() for p in params]), vp(*[g.data_ptr() for g in grads]), vp(*[m.data_ptr() for m in bufs]),
+            ll(*[p.numel() for p in params]))
 
 
-def sgd_momentum_step(table, lr, momentum, weight_decay=0.0, first_step=False):
-    dev_tab, n, blocks = table
+def sgd_momentum_step(table, lr, momentum, weight_decay=0.0):
+    device, n, pp, gp, mp, nn = table
     lib = _optim_lib()
-    with _torch().cuda.device(dev_tab.device):
-        check(lib.ssdhip_sgd_momentum_step(_ptr(dev_tab), n, blocks, float(lr), float(momentum), float(weight_decay), 1 if first_step else 0,
-                                           current_stream_ptr(dev_tab.device)), "ssdhip_sgd_momentum_step")
+    with _torch().cuda.device(device):
+        check(lib.ssdhip_sgd_momentum_step(n, pp, gp, mp, nn, float(lr), float(momentum), float(weight_decay), current_stream_ptr(device)),
+              "ssdhip_sgd_momentum_step")
 
 
 def maxpool_bwd(x, gy, kernel, stride, pad=0):

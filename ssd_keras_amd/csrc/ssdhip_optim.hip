@@ -100,47 +100,53 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const ssdhip_shadow
     }
 }
 
-// torch.optim.SGD (momentum, dampening 0, no Nesterov): four values per thread and step, every tensor of the table in one launch.
-// desc.src = the parameter, desc.cl = its gradient, desc.tr = its momentum buffer (all float32, desc.O elements); tile0 = first block.
-__global__ __launch_bounds__(256) void sgd_momentum_kernel(const ssdhip_shadow_desc* __restrict__ tab, int n, float lr, float momentum,
-                                                           float weight_decay, int first_step) {
-    __shared__ int sh_which;
+// torch.optim.SGD (momentum, dampening 0, no Nesterov): four values per thread and step, up to SGD_CHUNK tensors per launch.  The
+// tensor table travels in the KERNEL ARGUMENTS: gradients are new tensors every step (zero_grad(set_to_none=True)), and a device-side
+// table would have to be re-uploaded -- a pageable host-to-device copy that blocks the host until the whole backward pass has drained
+// (measured: the step 0.3-0.5 ms SLOWER than with the framework's optimizer although the kernels took 250 us less).
+constexpr int SGD_CHUNK = 80;
+struct SgdArgs {
+    float* p[SGD_CHUNK];
+    const float* g[SGD_CHUNK];
+    float* m[SGD_CHUNK];
+    long long n[SGD_CHUNK];
+    int block0[SGD_CHUNK];                                 // first block of each tensor (4096 values per block)
+    int count;
+};
+
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(const SgdArgs a, float lr, float momentum, float weight_decay) {
     const int tid = threadIdx.x, blk = (int)blockIdx.x;
-    if (tid == 0) {
-        int lo = 0, hi = n - 1;                            // last descriptor with tile0 <= blk
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (tab[mid].tile0 <= blk) lo = mid; else hi = mid - 1;
-        }
-        sh_which = lo;
+    int lo = 0, hi = a.count - 1;                          // last tensor with block0 <= blk (uniform: scalar loads of the arguments)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.block0[mid] <= blk) lo = mid; else hi = mid - 1;
     }
-    __syncthreads();
-    const ssdhip_shadow_desc d = tab[sh_which];
-    float* p = static_cast<float*>(const_cast<void*>(d.src));
-    const float* g = static_cast<const float*>(d.cl);
-    float* m = static_cast<float*>(d.tr);
-    const long long base = (long long)(blk - d.tile0) * 4096;
+    float* p = a.p[lo];
+    const float* g = a.g[lo];
+    float* m = a.m[lo];
+    const long long n = a.n[lo];
+    const long long base = (long long)(blk - a.block0[lo]) * 4096;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const long long i = base + (long long)u * 1024 + tid * 4;
-        if (i + 3 < d.O) {
+        if (i + 3 < n) {
             const float4 pv = *reinterpret_cast<const float4*>(p + i), gv = *reinterpret_cast<const float4*>(g + i);
-            float4 mv = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(m + i);
+            const float4 mv = *reinterpret_cast<const float4*>(m + i);
             float gg[4] = {gv.x, gv.y, gv.z, gv.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float gq = gg[q];
                 if (weight_decay != 0.f) gq = gq + weight_decay * pp[q];
-                mm[q] = first_step ? gq : momentum * mm[q] + gq;
+                mm[q] = momentum * mm[q] + gq;
                 pp[q] = pp[q] - lr * mm[q];
             }
             *reinterpret_cast<float4*>(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
             *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
         } else {
-            for (long long j = i; j < d.O && j < i + 4; ++j) {
+            for (long long j = i; j < n && j < i + 4; ++j) {
                 float gq = g[j];
                 if (weight_decay != 0.f) gq = gq + weight_decay * p[j];
-                const float mq = first_step ? gq : momentum * m[j] + gq;
+                const float mq = momentum * m[j] + gq;
                 m[j] = mq;
                 p[j] = p[j] - lr * mq;
             }
@@ -164,11 +170,31 @@ extern "C" int ssdhip_shadow_refresh(const ssdhip_shadow_desc* table_dev, int n_
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
-extern "C" int ssdhip_sgd_momentum_step(const ssdhip_shadow_desc* table_dev, int n_tensors, int n_blocks, double lr, double momentum,
-                                        double weight_decay, int first_step, void* stream_) {
+extern "C" int ssdhip_sgd_momentum_step(int n_tensors, void* const* params_h, const void* const* grads_h, void* const* bufs_h,
+                                        const long long* numel_h, double lr, double momentum, double weight_decay, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!table_dev || n_tensors <= 0 || n_blocks <= 0) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, table_dev, n_tensors, (float)lr,
-                       (float)momentum, (float)weight_decay, first_step ? 1 : 0);
-    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    if (n_tensors <= 0 || !params_h || !grads_h || !bufs_h || !numel_h) return SSDHIP_E_BADARG;
+    for (int k = 0; k < n_tensors; ++k) {
+        if (!params_h[k] || !grads_h[k] || !bufs_h[k] || numel_h[k] <= 0) return SSDHIP_E_BADARG;
+        if (((uintptr_t)params_h[k] | (uintptr_t)grads_h[k] | (uintptr_t)bufs_h[k]) & 15) return SSDHIP_E_BADARG;
+        if ((numel_h[k] + 4095) / 4096 > 0x3fffffffLL) return SSDHIP_E_BADARG;
+    }
+    for (int k0 = 0; k0 < n_tensors; k0 += SGD_CHUNK) {
+        SgdArgs a;
+        a.count = n_tensors - k0 < SGD_CHUNK ? n_tensors - k0 : SGD_CHUNK;
+        long long blocks = 0;
+        for (int k = 0; k < SGD_CHUNK; ++k) {
+            const int src = k < a.count ? k0 + k : k0;     // (unused slots repeat the first tensor: never selected)
+            a.p[k] = static_cast<float*>(params_h[src]);
+            a.g[k] = static_cast<const float*>(grads_h[src]);
+            a.m[k] = static_cast<float*>(bufs_h[src]);
+            a.n[k] = numel_h[src];
+            a.block0[k] = (int)blocks;
+            if (k < a.count) blocks += (numel_h[src] + 4095) / 4096;
+            if (blocks > 0x7fffffffLL) return SSDHIP_E_BADARG;
+        }
+        hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (float)lr, (float)momentum, (float)weight_decay);
+        if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    }
+    return SSDHIP_OK;
 }

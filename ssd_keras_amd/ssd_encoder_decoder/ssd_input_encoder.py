@@ -177,9 +177,38 @@ class SSDInputEncoder:
         packed = np.empty(n_off + max(int(gt.shape[0]), 1) * 5, dtype=np.float64)
         packed[:n_off].view(np.int32)[:offsets.shape[0]] = offsets
         packed[n_off:n_off + gt.size] = gt.ravel()
-        packed_d = torch.from_numpy(packed).to(device)
+        packed_d = self._upload(packed, device)
         return self.encode_packed(packed_d[n_off:], packed_d[:n_off].view(torch.int32), int(gt.shape[0]), int(max_g), B, want_f32,
                                   want_f64, want_matches)
+
+    def _upload(self, packed, device):
+        """The packed labels -> HBM WITHOUT stalling the host.  `torch.from_numpy(a).to(device)` of a pageable array returns only when
+        the copy has run, and the copy queues behind everything the stream still holds: in a training loop that is a full device
+        synchronisation per step -- the host could not issue the next forward pass while the GPU finished the last backward (round 5:
+        ~0.5 ms of an 11 ms step).  A small ring of pinned staging buffers + an asynchronous copy instead; a slot is reused only after
+        its own copy has completed (an event per slot: four steps back, long done)."""
+        import os
+        import torch
+        if os.environ.get("SSDHIP_SYNC_UPLOAD", "0") == "1":               # the round-4 form, for A/B timing
+            return torch.from_numpy(packed).to(device)
+        ring = self.__dict__.setdefault('_pinned_ring', {}).setdefault(str(device), {'slots': [None] * 4, 'next': 0})
+        i = ring['next']
+        ring['next'] = (i + 1) % len(ring['slots'])
+        slot = ring['slots'][i]
+        n = int(packed.shape[0])
+        if slot is not None:
+            slot[1].synchronize()
+        if slot is None or slot[0].numel() < n:
+            slot = [torch.empty((max(n, 1024),), dtype=torch.float64).pin_memory(), None]
+        slot[0].numpy()[:n] = packed
+        out = torch.empty((n,), dtype=torch.float64, device=device)
+        with torch.cuda.device(device):
+            out.copy_(slot[0][:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        slot[1] = ev
+        ring['slots'][i] = slot
+        return out
 
     def encode_packed(self, gt_d, off_d, n_gt, max_gt_per_image, batch_size, want_f32=True, want_f64=False, want_matches=False):
         '''The encoder kernels on labels that are ALREADY on the GPU in CSR form (e.g. produced by a device-side input pipeline):
