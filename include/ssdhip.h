@@ -362,6 +362,19 @@ int ssdhip_conv2d_splitk_nhwc_bf16(const void* x, const void* weight, const void
 int ssdhip_conv2d_same_nhwc_bf16_variant(int variant, const void* x, const void* weight, const void* bias, void* y,
                                          int B, int H, int W, int Cin, int Cout, int kernel, int dilation, int relu, void* stream);
 
+/* The two entry points below from FLOAT32 head outputs whose bias the convolution has already added -- the packed conf + loc maps of the
+ * reference-precision path (ssdhip_conv2d_x3_nhwc_f16 with out_f32; models/precise.py): strides count float32 elements, no bias
+ * arrays.  The softmax is the float32 expression of the bf16 form. */
+int ssdhip_assemble_predictions_strided_f32(int n_layers, const void* const* conf_h, const void* const* loc_h, const int* n_anchors_h,
+                                            const int* n_boxes_h, const int* conf_stride_h, const int* loc_stride_h,
+                                            const float* anchors_var, int B, int N, int C, float* y_pred, void* stream);
+int ssdhip_decode_from_heads_f32(int n_layers, const void* const* conf_h, const void* const* loc_h, const int* n_anchors_h,
+                                 const int* n_boxes_h, const int* conf_stride_h, const int* loc_stride_h, const float* anchors_var,
+                                 int B, int N, int C, double conf_thresh, double iou_thresh, int top_k, int nms_cap, int class_agnostic,
+                                 int semantics, int coords, int normalize_coords, double img_height, double img_width, int border_pixels,
+                                 void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx, void* ws, size_t ws_bytes,
+                                 void* stream);
+
 /* DecodeDetections straight from the predictor heads: the arguments of ssdhip_assemble_predictions_strided_bf16
  * followed by those of ssdhip_decode_detections.  The [C+12]-float prediction rows are built in LDS (bias, softmax, anchors) and
  * decoded / thresholded at once; y_pred is never written.  Results are identical to assembling and then decoding. */

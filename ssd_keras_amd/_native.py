@@ -370,17 +370,21 @@ def _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_
     keep = []
     cp, lp, cbp, lbp, na, cs, ls = [], [], [], [], [], [], []
     nhwc = lambda t: t if t.permute(0, 2, 3, 1).is_contiguous() else t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    f32 = confs[0].dtype == torch.float32                    # the reference-precision path: float32 packed heads, bias already added
+    esz = 4 if f32 else 2
     for i in range(nl):
         cf = nhwc(confs[i])
-        if cf.dtype != torch.bfloat16 or not cf.is_cuda:
-            raise SsdHipError("the predictor head outputs must be bfloat16 CUDA tensors")
+        if cf.dtype != (torch.float32 if f32 else torch.bfloat16) or not cf.is_cuda:
+            raise SsdHipError("the predictor head outputs must be CUDA tensors, all bfloat16 or all float32")
+        if f32 and (locs[i] is not None or conf_biases[i] is not None or loc_biases[i] is not None):
+            raise SsdHipError("float32 head outputs are packed [conf | loc | padding] maps that carry their bias already")
         b, ch, h, w = cf.shape
         nc, nloc = n_boxes[i] * n_classes, n_boxes[i] * 4
         if locs[i] is None:                                  # packed heads
             if ch < nc + nloc:
                 raise SsdHipError("packed head %d has %d channels, expected >= %d" % (i, ch, nc + nloc))
             keep.append(cf)
-            cp.append(cf.data_ptr()); lp.append(cf.data_ptr() + 2 * nc); cs.append(ch); ls.append(ch)
+            cp.append(cf.data_ptr()); lp.append(cf.data_ptr() + esz * nc); cs.append(ch); ls.append(ch)
         else:
             lc = nhwc(locs[i])
             if lc.dtype != torch.bfloat16 or ch != nc or lc.shape[1] != nloc:
@@ -396,7 +400,10 @@ def _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_
         raise SsdHipError("anchors_var must be float32 (%d, 8)" % N)
     arr = lambda v: (ctypes.c_void_p * nl)(*v)
     iarr = lambda v: (ctypes.c_int * nl)(*[int(t) for t in v])
-    args = (nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes), iarr(cs), iarr(ls), _ptr(anchors_var))
+    if f32:
+        args = (nl, arr(cp), arr(lp), iarr(na), iarr(n_boxes), iarr(cs), iarr(ls), _ptr(anchors_var))
+    else:
+        args = (nl, arr(cp), arr(lp), arr(cbp), arr(lbp), iarr(na), iarr(n_boxes), iarr(cs), iarr(ls), _ptr(anchors_var))
     return args, keep, int(B), N
 
 
@@ -407,6 +414,16 @@ def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_
     lib = _layers_lib()
     args, keep, B, N = _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes)
     y = torch.empty((B, N, n_classes + 12), dtype=torch.float32, device=confs[0].device)
+    if confs[0].dtype == torch.float32:
+        if not getattr(lib, "_apf32_bound", False):
+            c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+            lib.ssdhip_assemble_predictions_strided_f32.restype = c_int
+            lib.ssdhip_assemble_predictions_strided_f32.argtypes = [c_int] + [c_vp] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
+            lib._apf32_bound = True
+        with torch.cuda.device(y.device):
+            rc = lib.ssdhip_assemble_predictions_strided_f32(*args, B, N, int(n_classes), _ptr(y), current_stream_ptr(y.device))
+        check(rc, "ssdhip_assemble_predictions_strided_f32")
+        return y
     with torch.cuda.device(y.device):
         rc = lib.ssdhip_assemble_predictions_strided_bf16(*args, B, N, int(n_classes), _ptr(y), current_stream_ptr(y.device))
     check(rc, "ssdhip_assemble_predictions_strided_bf16")
@@ -426,8 +443,13 @@ def decode_from_heads(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var
         lib.ssdhip_decode_from_heads.argtypes = ([c_int] + [c_vp] * 9 + [c_int, c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
                                                                        c_int, c_int, c_dbl, c_dbl, c_int, c_vp, c_int, c_int, c_vp, c_vp,
                                                                        c_vp, c_sz, c_vp])
+        lib.ssdhip_decode_from_heads_f32.restype = c_int
+        lib.ssdhip_decode_from_heads_f32.argtypes = ([c_int] + [c_vp] * 7 + [c_int, c_int, c_int, c_dbl, c_dbl, c_int, c_int, c_int, c_int,
+                                                                           c_int, c_int, c_dbl, c_dbl, c_int, c_vp, c_int, c_int, c_vp, c_vp,
+                                                                           c_vp, c_sz, c_vp])
         lib._dfh_bound = True
     args, keep, B, N = _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes)
+    fn = lib.ssdhip_decode_from_heads_f32 if confs[0].dtype == torch.float32 else lib.ssdhip_decode_from_heads
     dev = confs[0].device
     k = int(top_k) if top_k else 0
     cap = int(nms_cap) if nms_cap else 0
@@ -439,7 +461,7 @@ def decode_from_heads(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var
     count = torch.empty((B,), dtype=torch.int32, device=dev)
     aidx = torch.empty((B, out_rows), dtype=torch.int32, device=dev) if want_anchor_idx else None
     with torch.cuda.device(dev):
-        rc = lib.ssdhip_decode_from_heads(*args, B, N, int(n_classes), float(conf_thresh), float(iou_thresh), k, cap,
+        rc = fn(*args, B, N, int(n_classes), float(conf_thresh), float(iou_thresh), k, cap,
                                           int(bool(class_agnostic)), int(semantics), COORDS[coords], int(bool(normalize_coords)),
                                           float(img_height if img_height is not None else 1.0),
                                           float(img_width if img_width is not None else 1.0), BORDER[border_pixels], _ptr(out),

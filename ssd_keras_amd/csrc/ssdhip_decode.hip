@@ -1600,6 +1600,30 @@ extern "C" int ssdhip_decode_stages(int stages, const void* y_pred, int in_dtype
                       out_anchor_idx, ws, ws_bytes, stream);
 }
 
+static int decode_from_heads_any(int src_f32, int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                 const void* const* conf_bias_h, const void* const* loc_bias_h, const int* n_anchors_h,
+                                 const int* n_boxes_h, const int* conf_stride_h, const int* loc_stride_h, const float* anchors_var,
+                                 int B, int N, int C, double conf_thresh, double iou_thresh, int top_k, int nms_cap, int class_agnostic,
+                                 int semantics, int coords, int normalize_coords, double img_height, double img_width, int border_pixels,
+                                 void* out, int out_dtype, int out_rows, int* out_count, int* out_anchor_idx, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    if (!anchors_var) return SSDHIP_E_BADARG;
+    HeadParams hp;
+    HeadSource src;
+    src.hp = &hp; src.anchors_var = anchors_var; src.tiles = 0;
+    size_t tile_lds = 60 * 1024;
+#if defined(SSDHIP_PROFILE)
+    if (const char* e = getenv("SSDHIP_HEADS_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 120) tile_lds = (size_t)v * 1024; }   // tile sweep
+#endif
+    const int rc = head_fill_params(hp, n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h, conf_stride_h,
+                                    loc_stride_h, N, C, tile_lds, &src.tiles, src_f32);
+    if (rc != SSDHIP_OK) return rc;
+    if (hp.TA < 64) return SSDHIP_E_BADARG;          // C too large for a one-thread-per-row tile
+    return decode_run(&src, 7, nullptr, SSDHIP_F32, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,
+                      coords, normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
+                      out_anchor_idx, ws, ws_bytes, stream);
+}
+
 // DecodeDetections straight from the predictor heads (no y_pred): the arguments of ssdhip_assemble_predictions_strided_bf16
 // followed by those of ssdhip_decode_detections (in_dtype is implied: the rows are built in float32).
 extern "C" int ssdhip_decode_from_heads(int n_layers, const void* const* conf_h, const void* const* loc_h,
@@ -1610,19 +1634,21 @@ extern "C" int ssdhip_decode_from_heads(int n_layers, const void* const* conf_h,
                                         int semantics, int coords, int normalize_coords, double img_height, double img_width,
                                         int border_pixels, void* out, int out_dtype, int out_rows, int* out_count,
                                         int* out_anchor_idx, void* ws, size_t ws_bytes, void* stream) {
-    if (!anchors_var) return SSDHIP_E_BADARG;
-    HeadParams hp;
-    HeadSource src;
-    src.hp = &hp; src.anchors_var = anchors_var; src.tiles = 0;
-    size_t tile_lds = 60 * 1024;
-#if defined(SSDHIP_PROFILE)
-    if (const char* e = getenv("SSDHIP_HEADS_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 120) tile_lds = (size_t)v * 1024; }   // tile sweep
-#endif
-    const int rc = head_fill_params(hp, n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h, conf_stride_h,
-                                    loc_stride_h, N, C, tile_lds, &src.tiles);
-    if (rc != SSDHIP_OK) return rc;
-    if (hp.TA < 64) return SSDHIP_E_BADARG;          // C too large for a one-thread-per-row tile
-    return decode_run(&src, 7, nullptr, SSDHIP_F32, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics,
-                      coords, normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
-                      out_anchor_idx, ws, ws_bytes, stream);
+    return decode_from_heads_any(0, n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h, conf_stride_h, loc_stride_h,
+                                 anchors_var, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords,
+                                 normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
+                                 out_anchor_idx, ws, ws_bytes, stream);
+}
+
+// ... and from FLOAT32 head outputs that carry their bias already (the reference-precision path: ssdhip_conv2d_x3_nhwc_f16 with out_f32).
+extern "C" int ssdhip_decode_from_heads_f32(int n_layers, const void* const* conf_h, const void* const* loc_h, const int* n_anchors_h,
+                                            const int* n_boxes_h, const int* conf_stride_h, const int* loc_stride_h,
+                                            const float* anchors_var, int B, int N, int C, double conf_thresh, double iou_thresh,
+                                            int top_k, int nms_cap, int class_agnostic, int semantics, int coords, int normalize_coords,
+                                            double img_height, double img_width, int border_pixels, void* out, int out_dtype,
+                                            int out_rows, int* out_count, int* out_anchor_idx, void* ws, size_t ws_bytes, void* stream) {
+    return decode_from_heads_any(1, n_layers, conf_h, loc_h, nullptr, nullptr, n_anchors_h, n_boxes_h, conf_stride_h, loc_stride_h,
+                                 anchors_var, B, N, C, conf_thresh, iou_thresh, top_k, nms_cap, class_agnostic, semantics, coords,
+                                 normalize_coords, img_height, img_width, border_pixels, out, out_dtype, out_rows, out_count,
+                                 out_anchor_idx, ws, ws_bytes, stream);
 }

@@ -32,6 +32,8 @@ struct HeadParams {
     int tile_start[MAX_PRED_LAYERS + 1];          // first tile of layer l
     int anchor_off[MAX_PRED_LAYERS];
     int n_layers, N, C, TA;
+    int src_f32;                                  // the head outputs are float32 (the reference-precision path, models/precise.py): conf / loc
+                                                  // point at float32 values, strides count float32 elements, biases must be null
 };
 
 // LDS bytes of one tile: [TA][C+12] float rows + [TA][C] + [TA][4] bf16 logits
@@ -52,6 +54,60 @@ __device__ __forceinline__ void head_build_rows(const HeadParams& hp, const floa
     const int TA = hp.TA, C = hp.C, L = C + 12;
     hbf16_t* ll = cl + (size_t)TA * C;
     const int nb = hp.n_boxes[l];
+    if (hp.src_f32) {
+        // float32 head outputs (bias already added by the convolution): the values go straight into the float32 rows -- the same index
+        // walk as the bf16 packed form below, one element per thread and trip
+        const size_t px0 = (size_t)b * (hp.n_anchors[l] / nb);
+        {
+            const int step_a = nthreads / C, step_c = nthreads - step_a * C;
+            int c = tid % C, a = tid / C;
+            const int ga0 = a0 + a;
+            int pix = ga0 / nb, box = ga0 - pix * nb;
+            const float* src = reinterpret_cast<const float*>(hp.conf[l]) + px0 * hp.conf_stride[l];
+            const int cs = hp.conf_stride[l];
+            const int q0 = step_a / nb, r0 = step_a - q0 * nb, q1 = (step_a + 1) / nb, r1 = step_a + 1 - q1 * nb;
+            for (int i = tid; i < na * C; i += nthreads) {
+                rows[(size_t)a * L + c] = src[(size_t)pix * cs + box * C + c];
+                c += step_c;
+                const bool carry = c >= C;
+                c -= carry ? C : 0;
+                a += step_a + (carry ? 1 : 0);
+                box += carry ? r1 : r0;
+                pix += carry ? q1 : q0;
+                if (box >= nb) { box -= nb; ++pix; }
+            }
+        }
+        {
+            const int step_a = nthreads >> 2;
+            const int k = tid & 3;
+            int a = tid >> 2;
+            const int ga0 = a0 + a;
+            int pix = ga0 / nb, box = ga0 - pix * nb;
+            const float* src = reinterpret_cast<const float*>(hp.loc[l]) + px0 * hp.loc_stride[l];
+            const int ls = hp.loc_stride[l];
+            const int q0 = step_a / nb, r0 = step_a - q0 * nb;
+            for (int i = tid; i < na * 4; i += nthreads) {
+                rows[(size_t)a * L + C + k] = src[(size_t)pix * ls + box * 4 + k];
+                a += step_a;
+                box += r0;
+                pix += q0;
+                if (box >= nb) { box -= nb; ++pix; }
+            }
+        }
+        __syncthreads();
+        for (int a = tid; a < na; a += nthreads) {
+            float* r = rows + (size_t)a * L;
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, r[c]);
+            float sum = 0.f;
+            for (int c = 0; c < C; ++c) { const float e = expf(r[c] - mx); r[c] = e; sum += e; }
+            for (int c = 0; c < C; ++c) r[c] = r[c] / sum;
+            const float* av = anchors_var + (size_t)(hp.anchor_off[l] + a0 + a) * 8;
+            for (int k = 0; k < 8; ++k) r[C + 4 + k] = av[k];
+        }
+        __syncthreads();
+        return;
+    }
     if (hp.conf_stride[l] == nb * C && hp.loc_stride[l] == nb * 4) {                    // dense heads: contiguous spans
         const hbf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
         const hbf16_t* lsrc = hp.loc[l] + ((size_t)b * hp.n_anchors[l] + a0) * 4;
@@ -124,12 +180,16 @@ __device__ __forceinline__ void head_build_rows(const HeadParams& hp, const floa
 static inline int head_fill_params(HeadParams& hp, int n_layers, const void* const* conf_h, const void* const* loc_h,
                                    const void* const* conf_bias_h, const void* const* loc_bias_h, const int* n_anchors_h,
                                    const int* n_boxes_h, const int* conf_stride_h, const int* loc_stride_h, int N, int C,
-                                   size_t max_lds, int* tiles_out) {
+                                   size_t max_lds, int* tiles_out, int src_f32 = 0) {
     if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !conf_h || !loc_h || !n_anchors_h || !n_boxes_h || N <= 0 || C < 2 || C > 1024)
         return SSDHIP_E_BADARG;
     int TA = 256;
     while (TA > 32 && head_tile_lds(TA, C) > max_lds) TA >>= 1;
-    hp.n_layers = n_layers; hp.N = N; hp.C = C; hp.TA = TA;
+    hp.n_layers = n_layers; hp.N = N; hp.C = C; hp.TA = TA; hp.src_f32 = src_f32 ? 1 : 0;
+    if (src_f32 && (conf_bias_h || loc_bias_h)) {
+        for (int l = 0; l < n_layers; ++l)
+            if ((conf_bias_h && conf_bias_h[l]) || (loc_bias_h && loc_bias_h[l])) return SSDHIP_E_BADARG;   // float32 heads carry their bias already
+    }
     int off = 0, tiles = 0;
     for (int l = 0; l < MAX_PRED_LAYERS; ++l) {
         const bool on = l < n_layers;

@@ -519,6 +519,23 @@ extern "C" int ssdhip_assemble_predictions_strided_bf16(int n_layers, const void
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
+// The same from FLOAT32 head outputs whose bias the convolution has already added (the reference-precision path, models/precise.py:
+// the packed conf + loc maps of ssdhip_conv2d_x3_nhwc_f16 with out_f32): strides count float32 elements.
+extern "C" int ssdhip_assemble_predictions_strided_f32(int n_layers, const void* const* conf_h, const void* const* loc_h,
+                                                       const int* n_anchors_h, const int* n_boxes_h, const int* conf_stride_h,
+                                                       const int* loc_stride_h, const float* anchors_var, int B, int N, int C,
+                                                       float* y_pred, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!anchors_var || !y_pred || B <= 0) return SSDHIP_E_BADARG;
+    HeadParams hp;
+    int tiles = 0;
+    const int rc = head_fill_params(hp, n_layers, conf_h, loc_h, nullptr, nullptr, n_anchors_h, n_boxes_h, conf_stride_h, loc_stride_h,
+                                    N, C, 60 * 1024, &tiles, 1);
+    if (rc != SSDHIP_OK) return rc;
+    hipLaunchKernelGGL(head_kernel, dim3(tiles, B), dim3(256), head_tile_lds(hp.TA, C), stream, hp, anchors_var, y_pred);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,
                                                 const void* const* conf_bias_h, const void* const* loc_bias_h,
                                                 const int* n_anchors_h, const int* n_boxes_h, const float* anchors_var,

@@ -799,8 +799,7 @@ class SSDModel(nn.Module):
         decoded detections, which on the fused bf16 path come straight from the head outputs."""
         pf = self.__dict__.get("_precise")
         if (pf is not None and images.is_cuda and not torch.is_grad_enabled() and next(self.parameters()).dtype == torch.float32):
-            pred = pf(images)
-            return self.decoder(pred) if (decode and self.decoder is not None) else pred
+            return pf(images, decode=bool(decode and self.decoder is not None))
         self.__dict__["_shadow_fresh"] = False
         self.__dict__["_in_forward"] = True
         try:

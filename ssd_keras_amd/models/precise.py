@@ -48,6 +48,9 @@ class PreciseForward:
         self._calibrating = None                          # dict while `calibrate` walks the float32 framework model
         self._calibrated = False
         self.check_finite = check_finite
+        self._last_heads = None
+        import os
+        self._torch_assembly = os.environ.get("SSDHIP_X3_TORCH_ASSEMBLY", "0") == "1"    # the round-4 assembly in framework ops (A/B)
         # The two side streams of __call__ are PICKED: which hardware queues a process's streams share depends on how many were created
         # before, and a pair that shares one with the default stream (or with each other) loses the overlap -- 6.9 ms against 7.4 ms
         # with ordinary streams, 6.9 against 8.6 - 9.0 ms with high-priority ones, 8.3 ms inside bench.py against 7.1 ms alone
@@ -184,6 +187,20 @@ class PreciseForward:
         y = nat.conv2d_x3(s2, w, bias, oscale * s_in, stride=1, padding=1, dilation=1, relu=False, out_f32=True)   # (B, Cpad, h, w)
         return y.permute(0, 2, 3, 1)                      # NHWC view: the channel axis splits as (box, class) (:363-383)
 
+    def _assemble(self, ys, decode):
+        """The packed float32 head maps -> the prediction tensor (Reshape / Concatenate / softmax / AnchorBoxes, :363-419) in ONE
+        libssdhip launch -- or, with `decode`, straight into the model's DecodeDetections layer without a prediction tensor in HBM
+        (round 5; before: twelve reshaping copies, two concatenations, a softmax and an index_select, ~0.27 ms of the step)."""
+        m = self.model
+        maps = [y.permute(0, 3, 1, 2) for y in ys]        # (B, Cpad, h, w) channels_last: what the convolution wrote
+        sizes = [(y.shape[1], y.shape[2]) for y in ys]
+        anchors = m.anchors_and_variances(sizes, maps[0].device)
+        n_boxes = [pb.n_boxes for pb in m.priorboxes]
+        none = [None] * len(maps)
+        if decode:
+            return m.decoder.forward_from_heads(maps, none, none, none, n_boxes, anchors, m.n_classes)
+        return nat.assemble_predictions(maps, none, none, none, n_boxes, anchors, m.n_classes)
+
     def _streams(self, device):
         return self._side[str(device)]
 
@@ -245,7 +262,9 @@ class PreciseForward:
         return report
 
     @torch.no_grad()
-    def __call__(self, images):
+    def __call__(self, images, decode=False):
+        """The float32 prediction tensor; `decode=True`: the model's DecodeDetections(Fast) output computed straight from the head
+        maps (inference modes only)."""
         capturing = torch.cuda.is_current_stream_capturing()
         if not self._calibrated:
             if capturing:
@@ -255,14 +274,19 @@ class PreciseForward:
             if capturing:
                 raise RuntimeError("call PreciseForward once outside a stream capture first (it times its side streams)")
             self._pick_streams(images)
-        y = self._forward(images)
-        if self.check_finite and not capturing and not bool(torch.isfinite(y).all()):
-            raise FloatingPointError("PreciseForward: non-finite predictions -- an activation left the float16 pair range (|x| >= 65504 "
-                                     "after the calibrated per-layer divisors); re-run calibrate() on a batch like this one")
+        if decode and (self.model.decoder is None or self.model.n_classes > 81):
+            return self.model.decoder(self.__call__(images))
+        y = self._forward(images, decode=decode)
+        if self.check_finite and not capturing:
+            # (decode: the range guard looks at the head maps -- a poisoned layer shows there as it would in the predictions)
+            probe = self._last_heads if decode else [y]
+            if not all(bool(torch.isfinite(t).all()) for t in probe):
+                raise FloatingPointError("PreciseForward: non-finite predictions -- an activation left the float16 pair range (|x| >= "
+                                         "65504 after the calibrated per-layer divisors); re-run calibrate() on a batch like this one")
         return y
 
     @torch.no_grad()
-    def _forward(self, images):
+    def _forward(self, images, decode=False):
         m = self.model
         x = m.preprocess(images)                                              # float32, channels_last
         conv4_3, fc7 = self._vgg(x)
@@ -302,6 +326,12 @@ class PreciseForward:
             main.wait_stream(side1)
             main.wait_stream(side2)
         b = x.shape[0]
+        if self._calibrating is None and all(y.dtype == torch.float32 and y.is_cuda for y in ys) and not self._torch_assembly:
+            if not one_stream:
+                for y in ys:
+                    y.record_stream(main)
+            self._last_heads = ys if decode else None
+            return self._assemble(ys, decode)
         confs, locs, sizes = [], [], []
         for l, y in enumerate(ys):
             if not one_stream:
@@ -313,4 +343,6 @@ class PreciseForward:
         conf = torch.softmax(torch.cat(confs, dim=1), dim=-1)                  # 'mbox_conf_softmax' (:415)
         loc = torch.cat(locs, dim=1)
         anchors = m.anchors_and_variances(sizes, conf.device)
-        return torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+        pred = torch.cat([conf, loc, anchors.unsqueeze(0).expand(b, -1, -1)], dim=2)   # 'predictions' (:419)
+        self._last_heads = [pred] if decode else None
+        return m.decoder(pred) if decode else pred
