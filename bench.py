@@ -206,7 +206,7 @@ def main():
     with torch.no_grad():
         fwd_ms = event_ms(lambda: model.raw_predictions(images), 10)
     dom = max(("scan_kernel", "nms_kernel", "topk_kernel"), key=lambda k: stage_ms[k])
-    full_name = {"scan_kernel": "scan_kernel", "nms_kernel": "nms_kernel<POL_TF32, 512, false> (+ the redo launch of nms_kernel<POL_TF32, 256, true>: idle workgroups)", "topk_kernel": "topk_kernel<float>"}
+    full_name = {"scan_kernel": "scan_kernel", "nms_kernel": "nms_kernel<POL_TF32, 512, false> (+ the redo launch of nms_kernel<POL_TF32, 512, true>: idle workgroups)", "topk_kernel": "topk_kernel<float>"}
     achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
     traffic = None                                   # HBM bytes per launch of the dominant kernel from the committed PMC passes
     import glob

@@ -708,7 +708,8 @@ __device__ __forceinline__ u64 uni64(u64 v) {
 #endif
 // FULL = false (the 512-thread form): the kernel has no exact-selection fallback.  A class whose score histogram cannot deliver a chunk
 // (more than MAX_CHUNK near-equal scores in the bin at the cut and fewer than M / 4 above it -- not met once on any measured workload)
-// is handed back with kept_count = -1 and redone by a FULL launch with redo_only = 1, whose other workgroups return at once.  Inlined,
+// is handed back with kept_count = -1 and redone by a FULL launch (512 threads as well: the round-4 kernel, scratch and all -- it only
+// ever multiplies for the handed-back classes) with redo_only = 1, whose other workgroups return at once.  Inlined,
 // the fallback's five radix passes made the compiler park loop invariants in scratch at the top of EVERY workgroup: 48 bytes per lane,
 // 15.7 MB of scratch stores per launch -- the "1.39 x" HBM traffic of rounds 2-4 (profiles/r04zz_decode_pmc_traffic.json).
 template <int POL, int T, bool FULL>
@@ -1545,7 +1546,7 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     do {                                                                                                                                  \
         if (nms_t >= 512) {                                                                                                               \
             hipLaunchKernelGGL((nms_kernel<POL, 512, false>), dim3(g4), dim3(512), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 0); \
-            hipLaunchKernelGGL((nms_kernel<POL, 256, true>), dim3(g4), dim3(256), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 1); \
+            hipLaunchKernelGGL((nms_kernel<POL, 512, true>), dim3(g4), dim3(512), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 1); \
         } else {                                                                                                                          \
             hipLaunchKernelGGL((nms_kernel<POL, 256, true>), dim3(g4), dim3(256), 0, stream, p, boxes, cand, cand_count, order, kept, kept_count, 0); \
         }                                                                                                                                 \
