@@ -409,8 +409,8 @@ def main():
         flags = []
 
         def flag(v):
-            if isinstance(v, dict) and "ok" in v:
-                flags.append(bool(v["ok"]))
+            if isinstance(v, dict) and ("ok" in v or "equal" in v):
+                flags.append(bool(v.get("ok", v.get("equal"))))
             elif isinstance(v, bool):
                 flags.append(v)
             elif v is not None:
@@ -429,7 +429,7 @@ def main():
                 "decode_ms_in_step_tamed": dig(tamed, "decode_ms_in_step"), "conv_frac": conv["frac"], "forward_ms": conv["forward_ms"],
                 "nms_kernel_us": round(1e3 * stage_ms["nms_kernel"], 2), "scan_kernel_us": round(1e3 * stage_ms["scan_kernel"], 2),
                 "nms_traffic_ratio": (traffic or {}).get("ratio_to_algorithmic_bytes") if dom == "nms_kernel" else None,
-                "train_step_ms": dig(extra, "train_step", "ms_per_step"), "train_images_per_sec": dig(extra, "train_step", "value"),
+                "train_step_ms": dig(extra, "train_step", "ms_per_step"), "train_images_per_sec": dig(extra, "train_step", "images_per_sec"),
                 "loss_forward_ms": dig(extra, "loss", "fwd_ms"), "encoder_kernels_ms": dig(extra, "encoder", "gpu_ms_per_batch_kernels"),
                 "augment_batch_img_s": dig(extra, "augmentation", "augment_batch_images_per_sec"),
                 "ssd512_forward_img_s_batch8": dig(extra, "other_models_forward", "ssd512_voc_21_classes", "batch8", "images_per_sec"),
