@@ -548,6 +548,34 @@ int ssdhip_shadow_refresh(const ssdhip_shadow_desc* table_dev, int n_weights, in
 int ssdhip_sgd_momentum_step(int n_tensors, void* const* params_h, const void* const* grads_h, void* const* bufs_h,
                              const long long* numel_h, double lr, double momentum, double weight_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The decisions of the original-SSD augmentation chain for a whole batch in ONE launch (csrc/ssdhip_augment.hip): SSDExpand ->
+ * SSDRandomCrop -> RandomFlip -> ResizeRandomInterp of data_generator/data_augmentation_chain_original_ssd.py:208-280 (with
+ * object_detection_2d_patch_sampling_ops.py:24-339, object_detection_2d_geometric_ops.py:86-262 and the BoxFilter / ImageValidator of
+ * object_detection_2d_image_boxes_validation_utils.py:79-322), everything but the pixels.  One wave per image consumes the image's own
+ * NumPy MT19937 stream exactly as numpy.random does (uniform, randint, choice), so decisions, labels and the stream position afterwards
+ * are those of the reference chain called under the same generator state.
+ *   mt_state      [B][625] uint32: np.random.RandomState.get_state() -- 624 key words + the position -- of every image;
+ *   labels        [B][64][5] float64 rows (class_id, xmin, ymin, xmax, ymax), n_labels [B] <= 64 (int64 and float64 label arrays are
+ *                 both exact in float64);
+ *   geometry      [B][12] int32: expanded?, canvas top, left, height, width | cropped?, patch top, left, height, width | flipped?,
+ *                 interpolation mode -- what the gather launch (ssdhip_image_resize_gather_u8) needs;
+ *   labels_out    [B][64][5] float64 + n_labels_out [B]: the surviving boxes in the output image's coordinates;
+ *   mt_state_out  [B][625]: the generator states behind the chain. */
+typedef struct ssdhip_augment_params {
+    int img_height, img_width;                       /* size of the batch's images */
+    double expand_prob, expand_min_scale, expand_max_scale;
+    double crop_prob, crop_min_scale, crop_max_scale, crop_min_aspect_ratio, crop_max_aspect_ratio;
+    int n_trials, n_bounds;
+    double bound_cdf[8], bound_lower[8], bound_upper[8];   /* BoundGenerator: cumsum(weights) / its last element, (lower, upper] pairs */
+    double flip_prob;
+    int n_modes, interpolation_modes[8], out_height, out_width;
+    int max_rounds;                                  /* 0: 100 000 sampling rounds at most (the reference loops without a limit) */
+} ssdhip_augment_params;
+int ssdhip_ssd_augment_decide(const ssdhip_augment_params* params, int B, const unsigned int* mt_state, const double* labels,
+                              const int* n_labels, int* geometry, double* labels_out, int* n_labels_out, unsigned int* mt_state_out,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

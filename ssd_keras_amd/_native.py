@@ -1537,3 +1537,63 @@ def image_lut_u8(image, table, channel_mask):
                                      current_stream_ptr(image.device))
     check(rc, "ssdhip_image_lut_u8")
     return out
+
+
+# ---- the decisions of the original-SSD augmentation chain for a whole batch (csrc/ssdhip_augment.hip) ---------------------------------
+class _AugParams(ctypes.Structure):                  # struct ssdhip_augment_params (include/ssdhip.h)
+    _fields_ = [("img_height", ctypes.c_int), ("img_width", ctypes.c_int),
+                ("expand_prob", ctypes.c_double), ("expand_min_scale", ctypes.c_double), ("expand_max_scale", ctypes.c_double),
+                ("crop_prob", ctypes.c_double), ("crop_min_scale", ctypes.c_double), ("crop_max_scale", ctypes.c_double),
+                ("crop_min_aspect_ratio", ctypes.c_double), ("crop_max_aspect_ratio", ctypes.c_double),
+                ("n_trials", ctypes.c_int), ("n_bounds", ctypes.c_int),
+                ("bound_cdf", ctypes.c_double * 8), ("bound_lower", ctypes.c_double * 8), ("bound_upper", ctypes.c_double * 8),
+                ("flip_prob", ctypes.c_double),
+                ("n_modes", ctypes.c_int), ("interpolation_modes", ctypes.c_int * 8), ("out_height", ctypes.c_int), ("out_width", ctypes.c_int),
+                ("max_rounds", ctypes.c_int)]
+
+
+AUG_MAX_BOXES = 64
+
+
+def ssd_augment_decide(params, mt_states, labels, n_labels, device):
+    """`ssdhip_ssd_augment_decide`: params a dict of the fields of ssdhip_augment_params; mt_states (B, 625) uint32, labels (B, 64, 5)
+    float64, n_labels (B,) int32 NumPy arrays (ONE upload) -> NumPy (geometry (B, 12) int32, labels_out (B, 64, 5) float64, n_out (B,)
+    int32, mt_states_out (B, 625) uint32) (ONE download)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_aug_bound", False):
+        lib.ssdhip_ssd_augment_decide.restype = ctypes.c_int
+        lib.ssdhip_ssd_augment_decide.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8
+        lib._aug_bound = True
+    q = _AugParams()
+    for k, v in params.items():
+        if isinstance(v, (list, tuple)):
+            arr = getattr(q, k)
+            for i, e in enumerate(v):
+                arr[i] = e
+        else:
+            setattr(q, k, v)
+    B = int(mt_states.shape[0])
+    if mt_states.shape != (B, 625) or labels.shape != (B, AUG_MAX_BOXES, 5) or n_labels.shape != (B,):
+        raise SsdHipError("ssd_augment_decide: mt_states (B, 625), labels (B, 64, 5), n_labels (B,)")
+    # one packed upload: [labels f64 | mt u32 | n i32], one packed download: [labels_out f64 | mt_out u32 | geometry i32 | n_out i32]
+    nl, nm = B * AUG_MAX_BOXES * 5 * 8, B * 625 * 4
+    host = np.empty((nl + nm + B * 4,), dtype=np.uint8)
+    host[:nl] = np.ascontiguousarray(labels, dtype=np.float64).view(np.uint8).ravel()
+    host[nl:nl + nm] = np.ascontiguousarray(mt_states, dtype=np.uint32).view(np.uint8).ravel()
+    host[nl + nm:] = np.ascontiguousarray(n_labels, dtype=np.int32).view(np.uint8).ravel()
+    dev_in = torch.from_numpy(host).to(device)
+    no = nl + nm + B * 12 * 4 + B * 4
+    dev_out = torch.empty((no,), dtype=torch.uint8, device=device)
+    base_in, base_out = dev_in.data_ptr(), dev_out.data_ptr()
+    vp = ctypes.c_void_p
+    with torch.cuda.device(device):
+        rc = lib.ssdhip_ssd_augment_decide(ctypes.byref(q), B, vp(base_in + nl), vp(base_in), vp(base_in + nl + nm), vp(base_out + nl + nm),
+                                           vp(base_out), vp(base_out + nl + nm + B * 48), vp(base_out + nl), current_stream_ptr(device))
+    check(rc, "ssdhip_ssd_augment_decide")
+    out = dev_out.cpu().numpy()
+    lab_out = out[:nl].view(np.float64).reshape(B, AUG_MAX_BOXES, 5)
+    mt_out = out[nl:nl + nm].view(np.uint32).reshape(B, 625)
+    geo = out[nl + nm:nl + nm + B * 48].view(np.int32).reshape(B, 12)
+    n_out = out[nl + nm + B * 48:].view(np.int32)
+    return geo, lab_out, n_out, mt_out

@@ -1,0 +1,230 @@
+// ssdhip_augment.hip -- the DECISIONS of the original-SSD augmentation chain for a whole batch in one launch, gfx950 (MI355X).
+//
+// Replaces, for a device-resident batch, the per-image Python loop over (reference data_generator/)
+//   data_augmentation_chain_original_ssd.py:103-162  SSDExpand        (RandomPatch, prob 0.5, canvas 1-4 x the image)
+//   data_augmentation_chain_original_ssd.py:29-101   SSDRandomCrop    (RandomPatchInf: rounds of 50 candidate patches, IoU-validated)
+//   object_detection_2d_geometric_ops.py:202-262     RandomFlip, :86-148 ResizeRandomInterp + Resize's label arithmetic
+//   object_detection_2d_patch_sampling_ops.py:24-339 PatchCoordinateGenerator, CropPad (label shift, centre-point BoxFilter, clipping)
+//   object_detection_2d_image_boxes_validation_utils.py:79-322  BoxFilter / ImageValidator
+// i.e. everything of SSDDataAugmentation.__call__ (:208-280) behind the photometric part that is not a pixel operation.  Round 4 ran
+// it per image on the host with one GPU round trip per sampling round (733 images/s for a pipeline whose two pixel kernels take 0.4 ms
+// per batch of 32); here one WAVE per image walks the chain:
+//   * the random numbers are NumPy's: the image's MT19937 state (np.random.RandomState(seed).get_state(), after the photometric draws the
+//     host still makes) lives in LDS, and uniform / randint / choice consume it exactly as numpy/random/mtrand does (53-bit doubles from
+//     two words, masked rejection sampling for bounded integers, searchsorted over the normalised cumulative weights) -- the decisions,
+//     and the stream position afterwards, are those of the per-image chain under the same seed, bit for bit (tests/test_image_ops.py);
+//   * a candidate patch is validated by the lanes in parallel (lane = ground truth box, IoU in the reference's float64 expression) and the
+//     search stops at the first valid trial, which is where the reference's loop stops consuming random numbers;
+//   * the label arithmetic (shift, centre-point filter, clipping, mirroring, rounding to the network input, degenerate-box filter) runs in
+//     float64, exact for int64 and float64 label arrays alike.
+// Outputs per image: the geometry (canvas, crop window, flip, interpolation mode) the gather launch needs, the surviving labels, and the
+// generator state.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssdhip.h"
+#include "ssdhip_math.h"
+
+namespace ssdhip {
+
+constexpr int AUG_MAXG = 64;                              // ground truth boxes per image (one lane each)
+
+struct AugParams {
+    int H, W;                                             // the batch's image size
+    double exp_prob, exp_min, exp_max;                    // SSDExpand: RandomPatch(prob), PatchCoordinateGenerator(min_scale, max_scale, scale_uniformly)
+    double crop_prob, crop_min, crop_max, ar_min, ar_max; // SSDRandomCrop: RandomPatchInf(prob), generator scales / aspect ratios
+    int n_trials, n_bounds;
+    double cdf[8], lower[8], upper[8];                    // BoundGenerator: cumulative weights / cdf[-1] (as np.random.choice builds them), bounds
+    double flip_prob;
+    int n_modes, modes[8], out_h, out_w;                  // ResizeRandomInterp
+    int max_rounds;                                       // safety net of the crop loop (the reference loops without one)
+};
+
+struct Mt {                                               // numpy's rk_state: 624 key words in LDS, the position in a register
+    u32* key;
+    int pos;
+};
+
+__device__ __forceinline__ void mt_twist(u32* key, int lane) {
+    constexpr u32 UP = 0x80000000u, LO = 0x7fffffffu, MAG = 0x9908b0dfu;
+    for (int base = 0; base < 623; base += 64) {
+        const int i = base + lane;
+        u32 nv = 0u;
+        if (i < 623) {
+            const u32 y = (key[i] & UP) | (key[i + 1] & LO);
+            const u32 c = key[i < 227 ? i + 397 : i - 227];
+            nv = c ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        }
+        __syncthreads();                                  // every lane has read before any lane writes (one wave per block)
+        if (i < 623) key[i] = nv;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const u32 y = (key[623] & UP) | (key[0] & LO);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ u32 mt_u32(Mt& s, int lane) {
+    if (s.pos == 624) { mt_twist(s.key, lane); s.pos = 0; }
+    u32 y = s.key[s.pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+__device__ __forceinline__ double mt_double(Mt& s, int lane) {           // rk_double / random_sample
+    const u32 a = mt_u32(s, lane) >> 5, b = mt_u32(s, lane) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+__device__ __forceinline__ double mt_uniform(Mt& s, int lane, double lo, double hi) { return lo + (hi - lo) * mt_double(s, lane); }
+// np.random.randint(lo, hi) for int64 results: masked rejection sampling on 32-bit words (numpy/random/_bounded_integers: use_masked)
+__device__ __forceinline__ long long mt_randint(Mt& s, int lane, long long lo, long long hi) {
+    const unsigned long long rng = (unsigned long long)(hi - 1 - lo);
+    if (rng == 0ull) return lo;
+    unsigned long long mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+    if (rng == 0xffffffffull) return lo + (long long)mt_u32(s, lane);
+    if (rng > 0xffffffffull) {                                          // (never in this chain: extents are image sizes)
+        unsigned long long v;
+        do { const unsigned long long hi32 = mt_u32(s, lane), lo32 = mt_u32(s, lane); v = ((hi32 << 32) | lo32) & mask; } while (v > rng);
+        return lo + (long long)v;
+    }
+    u32 v;
+    do { v = mt_u32(s, lane) & (u32)mask; } while (v > (u32)rng);
+    return lo + (long long)v;
+}
+// PatchCoordinateGenerator._position (object_detection_2d_patch_sampling_ops.py:163-178)
+__device__ __forceinline__ int aug_position(Mt& s, int lane, int extent, int size) {
+    const int room = extent - size;
+    return (int)(room >= 0 ? mt_randint(s, lane, 0, (long long)room + 1) : mt_randint(s, lane, room, 1));
+}
+
+// one wave per image
+__global__ __launch_bounds__(64) void ssd_augment_decide_kernel(AugParams p, const u32* __restrict__ mt_in, const double* __restrict__ lab_in,
+                                                                const int* __restrict__ n_in, int* __restrict__ geo,
+                                                                double* __restrict__ lab_out, int* __restrict__ n_out,
+                                                                u32* __restrict__ mt_out) {
+    __shared__ u32 key[624];
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+    for (int i = lane; i < 624; i += 64) key[i] = mt_in[(size_t)b * 625 + i];
+    Mt s;
+    s.key = key;
+    s.pos = (int)mt_in[(size_t)b * 625 + 624];
+    __syncthreads();
+    const int n = n_in[b];
+    bool alive = lane < n;
+    double cls = 0.0, x0 = 0.0, y0 = 0.0, x1 = 0.0, y1 = 0.0;
+    if (alive) {
+        const double* r = lab_in + ((size_t)b * AUG_MAXG + lane) * 5;
+        cls = r[0]; x0 = r[1]; y0 = r[2]; x1 = r[3]; y1 = r[4];
+    }
+    int H = p.H, W = p.W;
+    int g[12] = {0, 0, 0, H, W, 0, 0, 0, H, W, 0, 0};
+
+    // ---- SSDExpand: RandomPatch(prob), one trial, no validator: the image on a canvas of 1 .. 4 times its size ----------------------
+    if (!(mt_uniform(s, lane, 0.0, 1.0) < (1.0 - p.exp_prob))) {
+        const double factor = mt_uniform(s, lane, p.exp_min, p.exp_max);
+        const int h = (int)(factor * (double)H), w = (int)(factor * (double)W);
+        const int top = aug_position(s, lane, H, h), left = aug_position(s, lane, W, w);
+        y0 -= (double)top; y1 -= (double)top; x0 -= (double)left; x1 -= (double)left;      // CropPad: labels -= (top, left); no filter, no clip
+        g[0] = 1; g[1] = top; g[2] = left; g[3] = h; g[4] = w;
+        H = h; W = w;
+    }
+    g[8] = H; g[9] = W;
+
+    // ---- SSDRandomCrop: RandomPatchInf -- rounds until a valid patch or the "leave it" draw -------------------------------------------
+    for (int round = 0; round < p.max_rounds; ++round) {
+        if (mt_uniform(s, lane, 0.0, 1.0) < (1.0 - p.crop_prob)) break;                    // unaltered
+        const double u = mt_double(s, lane);                                               // BoundGenerator: np.random.choice(n, p=weights)
+        int bi = 0;
+        while (bi < p.n_bounds - 1 && !(u < p.cdf[bi])) ++bi;                               // searchsorted(cdf, u, side='right')
+        const double lower = p.lower[bi], upper = p.upper[bi];
+        bool found = false;
+        for (int t = 0; t < p.n_trials && !found; ++t) {
+            const int h = (int)(mt_uniform(s, lane, p.crop_min, p.crop_max) * (double)H);
+            const int w = (int)(mt_uniform(s, lane, p.crop_min, p.crop_max) * (double)W);
+            const int top = aug_position(s, lane, H, h), left = aug_position(s, lane, W, w);
+            const double ar = (double)w / (double)h;
+            if (!(p.ar_min <= ar && ar <= p.ar_max)) continue;
+            // ImageValidator('iou', bounds, n_boxes_min = 1, border 'half'): iou(patch, box shifted into the patch's frame) in (lower, upper]
+            PxBox<double> im, bb;
+            im.x0 = 0.0; im.y0 = 0.0; im.x1 = (double)w; im.y1 = (double)h;
+            im.area = box_area<double>(im.x0, im.y0, im.x1, im.y1, 0.0);
+            bb.x0 = x0 - (double)left; bb.y0 = y0 - (double)top; bb.x1 = x1 - (double)left; bb.y1 = y1 - (double)top;
+            bb.area = box_area<double>(bb.x0, bb.y0, bb.x1, bb.y1, 0.0);
+            const double v = iou_px<double>(im, bb);
+            if (__ballot(alive && v > lower && v <= upper) == 0ull) continue;
+            // the cut: CropPad(clip_boxes=True, box_filter = centre point inside the patch)
+            x0 = bb.x0; y0 = bb.y0; x1 = bb.x1; y1 = bb.y1;
+            const double cy = (y0 + y1) / 2.0, cx = (x0 + x1) / 2.0;
+            alive = alive && cy >= 0.0 && cy <= (double)h - 1.0 && cx >= 0.0 && cx <= (double)w - 1.0;
+            const double ymax = (double)(h - 1), xmax = (double)(w - 1);
+            y0 = y0 < 0.0 ? 0.0 : (y0 > ymax ? ymax : y0); y1 = y1 < 0.0 ? 0.0 : (y1 > ymax ? ymax : y1);
+            x0 = x0 < 0.0 ? 0.0 : (x0 > xmax ? xmax : x0); x1 = x1 < 0.0 ? 0.0 : (x1 > xmax ? xmax : x1);
+            g[5] = 1; g[6] = top; g[7] = left; g[8] = h; g[9] = w;
+            H = h; W = w;
+            found = true;
+        }
+        if (found) break;
+    }
+
+    // ---- RandomFlip('horizontal', prob) ----------------------------------------------------------------------------------------------
+    if (!(mt_uniform(s, lane, 0.0, 1.0) < (1.0 - p.flip_prob))) {
+        const double nx0 = (double)W - x1, nx1 = (double)W - x0;
+        x0 = nx0; x1 = nx1;
+        g[10] = 1;
+    }
+
+    // ---- ResizeRandomInterp: mode = np.random.choice(modes); Resize's label arithmetic + the degenerate-box filter -----------------------
+    g[11] = p.modes[(int)mt_randint(s, lane, 0, p.n_modes)];
+    {
+        const double sy = (double)p.out_h / (double)H, sx = (double)p.out_w / (double)W;
+        y0 = __builtin_rint(y0 * sy); y1 = __builtin_rint(y1 * sy);
+        x0 = __builtin_rint(x0 * sx); x1 = __builtin_rint(x1 * sx);
+        alive = alive && x1 > x0 && y1 > y0;
+    }
+
+    const u64 keep = __ballot(alive);
+    if (alive) {
+        const int pos = __popcll(keep & lanemask_lt());
+        double* r = lab_out + ((size_t)b * AUG_MAXG + pos) * 5;
+        r[0] = cls; r[1] = x0; r[2] = y0; r[3] = x1; r[4] = y1;
+    }
+    if (lane == 0) {
+        n_out[b] = __popcll(keep);
+        for (int i = 0; i < 12; ++i) geo[(size_t)b * 12 + i] = g[i];
+        mt_out[(size_t)b * 625 + 624] = (u32)s.pos;
+    }
+    __syncthreads();
+    for (int i = lane; i < 624; i += 64) mt_out[(size_t)b * 625 + i] = key[i];
+}
+
+}  // namespace ssdhip
+
+using namespace ssdhip;
+
+extern "C" int ssdhip_ssd_augment_decide(const ssdhip_augment_params* q, int B, const unsigned int* mt_state, const double* labels,
+                                         const int* n_labels, int* geometry, double* labels_out, int* n_labels_out,
+                                         unsigned int* mt_state_out, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!q || B <= 0 || !mt_state || !labels || !n_labels || !geometry || !labels_out || !n_labels_out || !mt_state_out) return SSDHIP_E_BADARG;
+    if (q->img_height <= 0 || q->img_width <= 0 || q->out_height <= 0 || q->out_width <= 0) return SSDHIP_E_BADARG;
+    if (q->n_bounds < 1 || q->n_bounds > 8 || q->n_modes < 1 || q->n_modes > 8 || q->n_trials < 1) return SSDHIP_E_BADARG;
+    if (!(q->expand_min_scale >= 1.0) || !(q->expand_max_scale > q->expand_min_scale)) return SSDHIP_E_BADARG;       // a canvas, never a crop
+    if (!(q->crop_min_scale > 0.0) || !(q->crop_max_scale <= 1.0) || !(q->crop_max_scale > q->crop_min_scale)) return SSDHIP_E_BADARG;
+    AugParams p;
+    p.H = q->img_height; p.W = q->img_width;
+    p.exp_prob = q->expand_prob; p.exp_min = q->expand_min_scale; p.exp_max = q->expand_max_scale;
+    p.crop_prob = q->crop_prob; p.crop_min = q->crop_min_scale; p.crop_max = q->crop_max_scale;
+    p.ar_min = q->crop_min_aspect_ratio; p.ar_max = q->crop_max_aspect_ratio;
+    p.n_trials = q->n_trials; p.n_bounds = q->n_bounds;
+    for (int i = 0; i < 8; ++i) { p.cdf[i] = q->bound_cdf[i]; p.lower[i] = q->bound_lower[i]; p.upper[i] = q->bound_upper[i]; p.modes[i] = q->interpolation_modes[i]; }
+    p.flip_prob = q->flip_prob; p.n_modes = q->n_modes; p.out_h = q->out_height; p.out_w = q->out_width;
+    p.max_rounds = q->max_rounds > 0 ? q->max_rounds : 100000;
+    hipLaunchKernelGGL(ssd_augment_decide_kernel, dim3((unsigned)B), dim3(64), 0, stream, p, mt_state, labels, n_labels, geometry,
+                       labels_out, n_labels_out, mt_state_out);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

@@ -148,6 +148,16 @@ class GeoImage:
             res += [ii, ww]
         return res
 
+    def raw_taps(self):
+        """(ix, wx, iy, wy) of `taps`, unpadded: (out_w, tx) / (out_h, ty) with this image's own tap counts."""
+        out_h, out_w, interp = self.resized
+        al = _area_linear(len(self.ys), len(self.xs), out_h, out_w, interp)
+        res = []
+        for idx_map, n_dst in ((self.xs, out_w), (self.ys, out_h)):
+            i, w = axis_taps(len(idx_map), n_dst, interp, al)
+            res += [idx_map[i].astype(np.int32), w]
+        return res
+
     def n_taps(self):
         out_h, out_w, interp = self.resized
         al = _area_linear(len(self.ys), len(self.xs), out_h, out_w, interp)
@@ -161,12 +171,18 @@ def gather_batch(images, lazies):
     if len(sizes) != 1:
         raise ValueError("every image of a batch must end in the same size")
     out_h, out_w = sizes.pop()
-    n = max(l.n_taps() for l in lazies)
+    # every image's taps ONCE (round 4 built them twice: first to learn the tap count, then padded), written straight into the batch tables
+    raw = [l.raw_taps() for l in lazies]
+    n = max(max(r[0].shape[1], r[2].shape[1]) for r in raw)
     n = 1 if n <= 1 else (2 if n <= 2 else (4 if n <= 4 else (8 if n <= 8 else 16 if n <= 16 else n)))
-    tabs = [l.taps(n) for l in lazies]
+    b = len(lazies)
+    ix, wx = np.zeros((b, out_w, n), dtype=np.int32), np.zeros((b, out_w, n), dtype=np.float64)
+    iy, wy = np.zeros((b, out_h, n), dtype=np.int32), np.zeros((b, out_h, n), dtype=np.float64)
+    for k, (sx, vx, sy, vy) in enumerate(raw):
+        ix[k, :, :sx.shape[1]], wx[k, :, :sx.shape[1]] = sx, vx
+        iy[k, :, :sy.shape[1]], wy[k, :, :sy.shape[1]] = sy, vy
     bg = np.array([(l.background if l.background is not None else (0, 0, 0)) for l in lazies], dtype=np.uint8)
-    return nat.image_resize_gather_u8(images.contiguous(), out_h, out_w, np.stack([t[0] for t in tabs]), np.stack([t[1] for t in tabs]),
-                                      np.stack([t[2] for t in tabs]), np.stack([t[3] for t in tabs]), bg)
+    return nat.image_resize_gather_u8(images.contiguous(), out_h, out_w, ix, wx, iy, wy, bg)
 
 
 # ---- cv2.resize as separable taps ------------------------------------------------------------------------------------------------

@@ -132,15 +132,23 @@ class SSDDataAugmentation:
                 image, labels = transform(image, labels)
         return (image, labels, inverters[::-1]) if return_inverter else (image, labels)
 
-    def augment_batch(self, images, labels):
+    def augment_batch(self, images, labels, seeds=None):
         """The whole chain on a device-resident batch: images (B, H, W, 3) CUDA uint8, labels a list of B
         (n_i, 5) arrays -> ((B, img_height, img_width, 3) CUDA uint8 batch, list of B label arrays).  TWO launches for the pixels of
         the whole batch -- the photometric distortions (`ssdhip_image_program`, one program per image) and expansion + crop + flip +
         resize fused into one gather (`ssdhip_image_resize_gather_u8`: the geometric ops only record index maps, nothing but the final
         batch is materialised) -- and no PCIe traffic besides the tap tables.  The random draws, the label arithmetic and the box
         filtering are the per-image chain's own code in the per-image chain's order: with the same NumPy random state the result
-        equals calling the chain on image 0, 1, 2, ... (tests/test_image_ops.py)."""
+        equals calling the chain on image 0, 1, 2, ... (tests/test_image_ops.py).
+
+        `seeds` (round 5): one integer per image.  Image i is then augmented exactly as `np.random.seed(seeds[i]); chain(image_i,
+        labels_i)` would -- an independent stream per image is what lets the batch run in parallel: the host only makes each image's
+        photometric draws, and ONE launch (`ssdhip_ssd_augment_decide`, a wave per image consuming that image's MT19937 stream as NumPy
+        does) takes every other decision of the chain -- expansion, the crop search with its IoU validation, flip, interpolation mode --
+        and does the label arithmetic.  The global NumPy generator is left untouched."""
         import torch
+        if seeds is not None:
+            return self._augment_batch_seeded(images, labels, seeds)
         if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3):
             raise TypeError("augment_batch takes a (B, H, W, 3) CUDA uint8 batch")
         if len(labels) != images.shape[0]:
@@ -157,4 +165,101 @@ class SSDDataAugmentation:
             lazies.append(img)
             out_labels.append(lab)
         distorted = iop.run_batch(images, programs)
+        return iop.gather_batch(distorted, lazies), out_labels
+
+    def _seeded_params(self, h, w):
+        """The chain's configuration as ssdhip_augment_params fields, or None when an op is not in the original-SSD configuration the
+        kernel implements."""
+        ex, cr = self.expand.expand, self.random_crop.random_crop
+        eg, cg, bg = ex.patch_coord_generator, cr.patch_coord_generator, cr.bound_generator
+        val, bf = cr.image_validator, cr.box_filter
+        ok = (eg.must_match == 'h_w' and eg.scale_uniformly and ex.n_trials_max == 1 and ex.image_validator is None and ex.box_filter is None
+              and not ex.clip_boxes and all(v is None for v in (eg.patch_ymin, eg.patch_xmin, eg.patch_height, eg.patch_width))
+              and cg.must_match == 'h_w' and not cg.scale_uniformly
+              and all(v is None for v in (cg.patch_ymin, cg.patch_xmin, cg.patch_height, cg.patch_width))
+              and cr.clip_boxes and bg is not None and val is not None and val.overlap_criterion == 'iou' and val.n_boxes_min == 1
+              and val.border_pixels == 'half' and bf is not None and bf.check_overlap and not bf.check_min_area and not bf.check_degenerate
+              and bf.overlap_criterion == 'center_point' and len(bg.sample_space) <= 8
+              and self.random_flip.dim == 'horizontal' and len(self.resize.interpolation_modes) <= 8
+              and self.box_filter.check_degenerate and not self.box_filter.check_overlap and not self.box_filter.check_min_area
+              and eg.min_scale >= 1.0 and cg.max_scale <= 1.0)
+        if not ok:
+            return None
+        cdf = np.array(bg.weights, dtype=np.float64).cumsum()           # as np.random.choice(n, p=weights) builds it
+        cdf /= cdf[-1]
+        pad = lambda v, fill: list(v) + [fill] * (8 - len(v))
+        return dict(img_height=int(h), img_width=int(w), expand_prob=float(ex.prob), expand_min_scale=float(eg.min_scale),
+                    expand_max_scale=float(eg.max_scale), crop_prob=float(cr.prob), crop_min_scale=float(cg.min_scale),
+                    crop_max_scale=float(cg.max_scale), crop_min_aspect_ratio=float(cg.min_aspect_ratio),
+                    crop_max_aspect_ratio=float(cg.max_aspect_ratio), n_trials=int(max(1, cr.n_trials_max)), n_bounds=len(bg.sample_space),
+                    bound_cdf=pad(cdf.tolist(), 2.0), bound_lower=pad([float(b[0]) for b in bg.sample_space], 0.0),
+                    bound_upper=pad([float(b[1]) for b in bg.sample_space], 1.0), flip_prob=float(self.random_flip.prob),
+                    n_modes=len(self.resize.interpolation_modes), interpolation_modes=pad([int(m) for m in self.resize.interpolation_modes], 0),
+                    out_height=int(self.resize.height), out_width=int(self.resize.width), max_rounds=0)
+
+    def _augment_batch_seeded(self, images, labels, seeds):
+        import torch
+        from .. import _native as nat
+        if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3):
+            raise TypeError("augment_batch takes a (B, H, W, 3) CUDA uint8 batch")
+        B, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        if len(labels) != B or len(seeds) != B:
+            raise ValueError("one label array and one seed per image")
+        lf = self.labels_format
+        cols = [lf['class_id'], lf['xmin'], lf['ymin'], lf['xmax'], lf['ymax']]
+        arrs = [np.asarray(lab) for lab in labels]
+        params = self._seeded_params(h, w)
+        dtypes = {a.dtype for a in arrs}
+        fast = (params is not None and len(dtypes) == 1 and next(iter(dtypes)) in (np.dtype(np.int64), np.dtype(np.float64))
+                and all(a.ndim == 2 and a.shape[1] == 5 and a.shape[0] <= nat.AUG_MAX_BOXES for a in arrs) and sorted(cols) == [0, 1, 2, 3, 4])
+        saved = np.random.get_state()
+        try:
+            if not fast:                                 # anything the kernel does not cover: the per-image chain's own code, seeded per image
+                programs, lazies, out_labels = [], [], []
+                for t in (self.expand, self.random_crop, self.random_flip, self.resize):
+                    t.labels_format = self.labels_format
+                for lab, seed in zip(arrs, seeds):
+                    np.random.seed(int(seed))
+                    programs.append(self.photometric_distortions.draw())
+                    img = iop.GeoImage.of(h, w)
+                    for transform in (self.expand, self.random_crop, self.random_flip, self.resize):
+                        img, lab = transform(img, lab)
+                    lazies.append(img)
+                    out_labels.append(lab)
+                return iop.gather_batch(iop.run_batch(images, programs), lazies), out_labels
+            # ---- host: the photometric draws of every image under its own seed; the generator state behind them goes to the device ----
+            mt = np.empty((B, 625), dtype=np.uint32)
+            lab_in = np.zeros((B, nat.AUG_MAX_BOXES, 5), dtype=np.float64)
+            n_in = np.empty((B,), dtype=np.int32)
+            programs = []
+            for i in range(B):
+                np.random.seed(int(seeds[i]))
+                programs.append(self.photometric_distortions.draw())
+                st = np.random.get_state()
+                mt[i, :624] = st[1]
+                mt[i, 624] = st[2]
+                a = arrs[i]
+                n_in[i] = a.shape[0]
+                if a.shape[0]:
+                    lab_in[i, :a.shape[0]] = a[:, cols]
+        finally:
+            np.random.set_state(saved)
+        distorted = iop.run_batch(images, programs)
+        geo, lab_out, n_out, mt_out = nat.ssd_augment_decide(params, mt, lab_in, n_in, images.device)
+        self.__dict__["_last_generator_states"] = mt_out     # (B, 625): where each image's stream stands behind its chain (tests)
+        # ---- the recorded geometry of every image -> one gather launch; the labels back in the caller's column order and dtype ----------
+        dt = arrs[0].dtype
+        inv = np.argsort(cols)
+        lazies, out_labels = [], []
+        for i in range(B):
+            g = geo[i]
+            img = iop.GeoImage.of(h, w)
+            if g[0]:
+                img = img.window(int(g[1]), int(g[2]), int(g[3]), int(g[4]), self.expand.expand.background)
+            if g[5]:
+                img = img.window(int(g[6]), int(g[7]), int(g[8]), int(g[9]), self.random_crop.random_crop.background)
+            if g[10]:
+                img = img[:, ::-1]
+            lazies.append(img.resize(self.resize.height, self.resize.width, int(g[11])))
+            out_labels.append(np.ascontiguousarray(lab_out[i, :int(n_out[i])][:, inv]).astype(dt))
         return iop.gather_batch(distorted, lazies), out_labels

@@ -249,3 +249,47 @@ def test_augment_batch_equals_the_per_image_chain():
         for i in range(B):
             assert np.array_equal(g[i], want[i][0]), "seed %d image %d: %d pixels differ" % (seed, i, int((g[i] != want[i][0]).sum()))
             assert np.array_equal(got_lab[i], want[i][1]), (seed, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geometry", [(12, 120, 160, 64, "int64"), (32, 375, 500, 300, "int64"), (9, 96, 128, 48, "float64")])
+def test_augment_batch_with_seeds_equals_the_chain_under_each_seed(geometry):
+    """Round 5: `augment_batch(images, labels, seeds=s)` -- the host makes each image's photometric draws, ONE launch
+    (`ssdhip_ssd_augment_decide`, a wave per image consuming that image's NumPy MT19937 stream on the device) takes every other decision of
+    the chain and does the label arithmetic -- == `np.random.seed(s[i]); chain(image_i, labels_i)` of the per-image chain (reference
+    data_generator/data_augmentation_chain_original_ssd.py:208-280): pixels and labels bit for bit, and each image's generator ends in
+    the state the per-image chain leaves it in (the next draw is the same).  The global generator is not touched."""
+    import torch
+    from ssd_keras_amd.data_generator.data_augmentation_chain_original_ssd import SSDDataAugmentation
+    B, H, W, out, dt = geometry
+    rng = np.random.RandomState(7 + B)
+    batch = rng.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    labels = []
+    for i in range(B):
+        n = rng.randint(0 if i % 5 == 4 else 1, 7)
+        x0, y0 = rng.randint(0, W - W // 4, size=n), rng.randint(0, H - H // 4, size=n)
+        lab = np.stack([rng.randint(1, 21, size=n), x0, y0, x0 + rng.randint(W // 12, W // 4, size=n), y0 + rng.randint(H // 12, H // 4, size=n)],
+                       axis=1).reshape(n, 5)
+        labels.append(lab.astype(dt) + (0.25 if dt == "float64" else 0))
+    for trial in range(3):
+        seeds = rng.randint(0, 2 ** 31 - 1, size=B)
+        aug = SSDDataAugmentation(img_height=out, img_width=out)
+        want, nxt = [], []
+        for i in range(B):
+            np.random.seed(int(seeds[i]))
+            want.append(aug(batch[i], labels[i]))
+            nxt.append(np.random.uniform())
+        np.random.seed(12345)
+        before = np.random.get_state()
+        got_img, got_lab = aug.augment_batch(torch.from_numpy(batch).cuda(), labels, seeds=seeds)
+        after = np.random.get_state()
+        assert before[2] == after[2] and np.array_equal(before[1], after[1]), "the global generator must be left alone"
+        g = got_img.cpu().numpy()
+        states = aug._last_generator_states
+        for i in range(B):
+            assert got_lab[i].dtype == labels[i].dtype and got_lab[i].shape == want[i][1].shape, (trial, i, got_lab[i], want[i][1])
+            assert np.array_equal(got_lab[i], want[i][1]), (trial, i, got_lab[i], want[i][1])
+            assert np.array_equal(g[i], want[i][0]), "trial %d image %d: %d pixels differ" % (trial, i, int((g[i] != want[i][0]).sum()))
+            rs = np.random.RandomState()
+            rs.set_state(("MT19937", states[i, :624].copy(), int(states[i, 624]), 0, 0.0))
+            assert rs.uniform() == nxt[i], "image %d: the device left the stream elsewhere" % i

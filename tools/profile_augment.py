@@ -21,18 +21,20 @@ for _ in range(B):
     x0, y0 = rng.randint(0, 400, size=n), rng.randint(0, 280, size=n)
     labels.append(np.stack([rng.randint(1, 21, size=n), x0, y0, x0 + rng.randint(20, 100, size=n), y0 + rng.randint(20, 90, size=n)], axis=1))
 np.random.seed(1)
-aug.augment_batch(voc, labels)
+SEEDED = os.environ.get("SEEDED", "1") == "1"
+seeds = lambda: (np.random.randint(0, 2 ** 31 - 1, size=B) if SEEDED else None)
+aug.augment_batch(voc, labels, seeds=seeds())
 torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(5):
-    aug.augment_batch(voc, labels)
+    aug.augment_batch(voc, labels, seeds=seeds())
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
-print("augment_batch: %.2f ms per batch of %d = %.0f img/s" % (dt * 1e3, B, B / dt))
+print("augment_batch (%s): %.2f ms per batch of %d = %.0f img/s" % ("one seed per image, decisions on the device" if SEEDED else "global stream, per-image host loop", dt * 1e3, B, B / dt))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):
-    aug.augment_batch(voc, labels)
+    aug.augment_batch(voc, labels, seeds=seeds())
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
