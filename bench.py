@@ -423,6 +423,7 @@ def main():
         flag(dig_any(extra, "decode_sparse", "cpu", "hip_vs_port_on_the_sample"))
         flag(dig_any(extra, "ssd512_decode", "sparse_bias7_conf0.01", "cpu", "hip_vs_port_on_the_sample"))
         flag(dig_any(extra, "augmentation", "cpu", "hip_equals_port_on_the_sample"))
+        flag(dig_any(extra, "augmentation", "augment_batch_equals_the_per_image_chain_under_each_seed"))
         scal = {"value_reference_precision": dig(extra, "conv_roofline_fp32x3", "images_per_sec"),
                 "reference_precision_ms_per_step": dig(extra, "conv_roofline_fp32x3", "step_ms_fwd_plus_decode"),
                 "value_tamed_heads_img_s": dig(tamed, "value"), "decode_ms_in_step": round(decode_ms_in_step, 5),

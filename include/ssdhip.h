@@ -572,6 +572,12 @@ typedef struct ssdhip_augment_params {
     int n_modes, interpolation_modes[8], out_height, out_width;
     int max_rounds;                                  /* 0: 100 000 sampling rounds at most (the reference loops without a limit) */
 } ssdhip_augment_params;
+/* ssdhip_augment_taps: the tap tables of ssdhip_image_resize_gather_u8 for the batch, built on the device from `geometry` (as
+ * ssdhip_ssd_augment_decide leaves it): cv2.resize's source indices / float64 weights of each image's interpolation mode (0 nearest, 1
+ * linear, 2 cubic, 3 area, 4 Lanczos-4) composed with its flip, crop window and expansion canvas (-1: a canvas pixel).  ix / wx
+ * [B][out_w][n_taps], iy / wy [B][out_h][n_taps]; n_taps >= 8 and >= ceil(largest source / output extent ratio) + 1 (the area filter). */
+int ssdhip_augment_taps(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* ix_dev, double* wx_dev,
+                        int* iy_dev, double* wy_dev, void* stream);
 int ssdhip_ssd_augment_decide(const ssdhip_augment_params* params, int B, const unsigned int* mt_state, const double* labels,
                               const int* n_labels, int* geometry, double* labels_out, int* n_labels_out, unsigned int* mt_state_out,
                               void* stream);

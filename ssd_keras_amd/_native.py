@@ -1557,8 +1557,8 @@ AUG_MAX_BOXES = 64
 
 def ssd_augment_decide(params, mt_states, labels, n_labels, device):
     """`ssdhip_ssd_augment_decide`: params a dict of the fields of ssdhip_augment_params; mt_states (B, 625) uint32, labels (B, 64, 5)
-    float64, n_labels (B,) int32 NumPy arrays (ONE upload) -> NumPy (geometry (B, 12) int32, labels_out (B, 64, 5) float64, n_out (B,)
-    int32, mt_states_out (B, 625) uint32) (ONE download)."""
+    float64, n_labels (B,) int32 NumPy arrays (ONE upload) -> (geometry (B, 12) int32 CUDA tensor, fetch) where fetch() downloads
+    (geometry (B, 12) int32, labels_out (B, 64, 5) float64, n_out (B,) int32, mt_states_out (B, 625) uint32) as NumPy arrays."""
     torch = _torch()
     lib = load()
     if not getattr(lib, "_aug_bound", False):
@@ -1591,9 +1591,31 @@ def ssd_augment_decide(params, mt_states, labels, n_labels, device):
         rc = lib.ssdhip_ssd_augment_decide(ctypes.byref(q), B, vp(base_in + nl), vp(base_in), vp(base_in + nl + nm), vp(base_out + nl + nm),
                                            vp(base_out), vp(base_out + nl + nm + B * 48), vp(base_out + nl), current_stream_ptr(device))
     check(rc, "ssdhip_ssd_augment_decide")
-    out = dev_out.cpu().numpy()
-    lab_out = out[:nl].view(np.float64).reshape(B, AUG_MAX_BOXES, 5)
-    mt_out = out[nl:nl + nm].view(np.uint32).reshape(B, 625)
-    geo = out[nl + nm:nl + nm + B * 48].view(np.int32).reshape(B, 12)
-    n_out = out[nl + nm + B * 48:].view(np.int32)
-    return geo, lab_out, n_out, mt_out
+    geo_dev = dev_out[nl + nm:nl + nm + B * 48].view(torch.int32).view(B, 12)      # stays on the device for augment_taps
+
+    def fetch():
+        """(geometry, labels_out, n_out, mt_states_out) as NumPy arrays: ONE download (a host synchronisation: call it last)."""
+        out = dev_out.cpu().numpy()
+        return (out[nl + nm:nl + nm + B * 48].view(np.int32).reshape(B, 12), out[:nl].view(np.float64).reshape(B, AUG_MAX_BOXES, 5),
+                out[nl + nm + B * 48:].view(np.int32), out[nl:nl + nm].view(np.uint32).reshape(B, 625))
+    return geo_dev, fetch
+
+
+def augment_taps(geo_dev, H, W, out_h, out_w, n_taps):
+    """`ssdhip_augment_taps`: the gather launch's tap tables (ix, wx, iy, wy: CUDA tensors (B, out_w | out_h, n_taps)) built on the device
+    from the geometry ssd_augment_decide left there."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_augtaps_bound", False):
+        lib.ssdhip_augment_taps.restype = ctypes.c_int
+        lib.ssdhip_augment_taps.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 5
+        lib._augtaps_bound = True
+    B, dev = int(geo_dev.shape[0]), geo_dev.device
+    ix = torch.empty((B, out_w, n_taps), dtype=torch.int32, device=dev)
+    wx = torch.empty((B, out_w, n_taps), dtype=torch.float64, device=dev)
+    iy = torch.empty((B, out_h, n_taps), dtype=torch.int32, device=dev)
+    wy = torch.empty((B, out_h, n_taps), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ssdhip_augment_taps(_ptr(geo_dev), B, int(H), int(W), int(out_h), int(out_w), int(n_taps), _ptr(ix), _ptr(wx), _ptr(iy),
+                                      _ptr(wy), current_stream_ptr(dev)), "ssdhip_augment_taps")
+    return ix, wx, iy, wy

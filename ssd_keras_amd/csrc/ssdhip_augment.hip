@@ -202,6 +202,135 @@ __global__ __launch_bounds__(64) void ssd_augment_decide_kernel(AugParams p, con
     for (int i = lane; i < 624; i += 64) mt_out[(size_t)b * 625 + i] = key[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The tap tables of the gather launch (ssdhip_image_resize_gather_u8) built ON THE DEVICE from the decisions above: per image and axis,
+// cv2.resize's source indices and float64 weights for the drawn interpolation mode (data_generator/_image_ops.py axis_taps: the same
+// expressions in the same order -- nearest, bilinear, bicubic a = -0.75, the true area filter when both axes shrink and cv2's area-mode
+// bilinear variant otherwise, Lanczos-4 -- incl. NumPy's summation order where a row of weights is normalised), composed with the
+// recorded geometry (resize <- flip <- crop window <- expansion canvas; -1 = a canvas pixel, filled with the background colour).
+// Round 5: the host built these per image in NumPy and uploaded 1.8 MB per batch (2.5 ms of a 4.5 ms batch).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double aug_np_sum(const double* w, int n) {          // numpy's pairwise_sum for one contiguous row (n <= 64)
+    if (n < 8) {
+        double r = 0.0;                                                          // (-0.0 + w0 in NumPy; the weights are never -0.0)
+        for (int i = 0; i < n; ++i) r += w[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = w[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += w[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += w[i];
+    return res;
+}
+
+// grid (blocks over positions, 2 axes, B); axis 0 = columns (x), 1 = rows (y)
+__global__ __launch_bounds__(128) void aug_taps_kernel(const int* __restrict__ geo, int H, int W, int out_h, int out_w, int n_taps,
+                                                       int* __restrict__ ix, double* __restrict__ wx, int* __restrict__ iy,
+                                                       double* __restrict__ wy) {
+    const int b = (int)blockIdx.z, axis = (int)blockIdx.y;
+    const int n_dst = axis == 0 ? out_w : out_h;
+    const int i = (int)blockIdx.x * 128 + (int)threadIdx.x;
+    if (i >= n_dst) return;
+    const int* g = geo + (size_t)b * 12;
+    const int Hc = g[8], Wc = g[9], interp = g[11];
+    const int n_src = axis == 0 ? Wc : Hc;
+    const bool area_linear = interp == 3 && !(Wc >= out_w && Hc >= out_h);       // _area_linear
+    const double scale = (double)n_src / (double)n_dst;
+    int idx[64];
+    double w[64];
+    int T = 0;
+    if (interp == 3 && area_linear) {
+        double sxd = floor((double)i * scale);
+        float fx = (float)(((double)i + 1.0) - (sxd + 1.0) * (1.0 / scale));
+        fx = fx <= 0.f ? 0.f : fx - floorf(fx);
+        double fxd = (double)fx;
+        if (sxd >= (double)(n_src - 1)) { sxd = (double)(n_src - 1); fxd = 0.0; }
+        const long long s0 = (long long)sxd;
+        idx[0] = (int)(s0 < 0 ? 0 : (s0 > n_src - 1 ? n_src - 1 : s0));
+        idx[1] = (int)(s0 + 1 < 0 ? 0 : (s0 + 1 > n_src - 1 ? n_src - 1 : s0 + 1));
+        w[0] = 1.0 - fxd; w[1] = fxd;
+        T = 2;
+    } else if (interp == 0) {
+        const double f = floor((double)i * scale);
+        idx[0] = (int)(f < (double)(n_src - 1) ? f : (double)(n_src - 1));
+        w[0] = 1.0;
+        T = 1;
+    } else if (interp == 3 && scale >= 1.0) {
+        const double lo = (double)i * scale, hi = ((double)i + 1.0) * scale;
+        const long long first = (long long)floor(lo);
+        T = (int)ceil(scale) + 1;
+        T = T > 64 ? 64 : T;
+        for (int t = 0; t < T; ++t) {
+            const long long cell = first + t;
+            const double a = (double)cell + 1.0 < hi ? (double)cell + 1.0 : hi;   // np.minimum(cells + 1.0, hi)
+            const double c = (double)cell > lo ? (double)cell : lo;               // np.maximum(cells, lo)
+            const double d = a - c;
+            w[t] = d < 0.0 ? 0.0 : d;
+            idx[t] = (int)(cell < 0 ? 0 : (cell > n_src - 1 ? n_src - 1 : cell));
+        }
+        const double sum = aug_np_sum(w, T);
+        for (int t = 0; t < T; ++t) w[t] = w[t] / sum;
+    } else {
+        const double center = ((double)i + 0.5) * scale - 0.5;
+        const double base = floor(center);
+        const double frac = center - base;
+        int off0;
+        if (interp == 1 || interp == 3) {
+            off0 = 0; T = 2;
+            w[0] = 1.0 - frac; w[1] = frac;
+        } else if (interp == 2) {
+            off0 = -1; T = 4;
+            const double a = -0.75;
+            for (int t = 0; t < 4; ++t) {
+                const double d = fabs(frac - (double)(off0 + t));
+                const double near = ((a + 2) * d - (a + 3)) * d * d + 1;
+                const double far = ((a * d - 5 * a) * d + 8 * a) * d - 4 * a;
+                w[t] = d <= 1.0 ? near : (d < 2.0 ? far : 0.0);
+            }
+        } else {
+            off0 = -3; T = 8;
+            const double pi = 3.141592653589793;
+            for (int t = 0; t < 8; ++t) {
+                const double d = frac - (double)(off0 + t);
+                const bool inside = fabs(d) >= 1e-12 && fabs(d) < 4.0;
+                const double sf = inside ? d : 1.0;
+                const double val = 4 * sin(pi * sf) * sin(pi * sf / 4) / (pi * pi * sf * sf);
+                w[t] = inside ? val : (fabs(d) < 1e-12 ? 1.0 : 0.0);
+            }
+            const double sum = aug_np_sum(w, 8);
+            for (int t = 0; t < 8; ++t) w[t] = w[t] / sum;
+        }
+        for (int t = 0; t < T; ++t) {
+            const long long c = (long long)base + off0 + t;
+            idx[t] = (int)(c < 0 ? 0 : (c > n_src - 1 ? n_src - 1 : c));
+        }
+    }
+    // the recorded geometry: position j of the final (pre-resize) image <- flip <- crop window <- expansion canvas <- the image
+    int* oi = (axis == 0 ? ix : iy) + ((size_t)b * n_dst + i) * n_taps;
+    double* ow = (axis == 0 ? wx : wy) + ((size_t)b * n_dst + i) * n_taps;
+    for (int t = 0; t < n_taps; ++t) {
+        int src = 0;
+        double wt = 0.0;
+        if (t < T) {
+            int j = idx[t];
+            if (axis == 0 && g[10]) j = Wc - 1 - j;                               // RandomFlip('horizontal')
+            if (g[5]) j += axis == 0 ? g[7] : g[6];                               // the crop window's corner on the canvas
+            if (g[0]) {                                                           // the canvas: the image sits at (-top, -left)
+                j += axis == 0 ? g[2] : g[1];
+                if (j < 0 || j >= (axis == 0 ? W : H)) j = -1;
+            }
+            src = j;
+            wt = w[t];
+        }
+        oi[t] = src;
+        ow[t] = wt;
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -226,5 +355,17 @@ extern "C" int ssdhip_ssd_augment_decide(const ssdhip_augment_params* q, int B, 
     p.max_rounds = q->max_rounds > 0 ? q->max_rounds : 100000;
     hipLaunchKernelGGL(ssd_augment_decide_kernel, dim3((unsigned)B), dim3(64), 0, stream, p, mt_state, labels, n_labels, geometry,
                        labels_out, n_labels_out, mt_state_out);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_augment_taps(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* ix_dev,
+                                   double* wx_dev, int* iy_dev, double* wy_dev, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!geometry_dev || !ix_dev || !wx_dev || !iy_dev || !wy_dev || B <= 0 || B > 65535 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
+        return SSDHIP_E_BADARG;
+    if (n_taps < 8 || n_taps > 64) return SSDHIP_E_BADARG;                       // Lanczos-4 needs eight
+    const int n = out_h > out_w ? out_h : out_w;
+    hipLaunchKernelGGL(aug_taps_kernel, dim3((unsigned)((n + 127) / 128), 2, (unsigned)B), dim3(128), 0, stream, geometry_dev, H, W, out_h,
+                       out_w, n_taps, ix_dev, wx_dev, iy_dev, wy_dev);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -12,6 +12,7 @@ a CUDA batch: one draw sequence per image, one launch for all of them.
 from __future__ import annotations
 
 import inspect
+import os
 
 import numpy as np
 
@@ -245,11 +246,28 @@ class SSDDataAugmentation:
         finally:
             np.random.set_state(saved)
         distorted = iop.run_batch(images, programs)
-        geo, lab_out, n_out, mt_out = nat.ssd_augment_decide(params, mt, lab_in, n_in, images.device)
-        self.__dict__["_last_generator_states"] = mt_out     # (B, 625): where each image's stream stands behind its chain (tests)
-        # ---- the recorded geometry of every image -> one gather launch; the labels back in the caller's column order and dtype ----------
+        geo_dev, fetch = nat.ssd_augment_decide(params, mt, lab_in, n_in, images.device)
+        out_h, out_w = int(self.resize.height), int(self.resize.width)
+        # tap tables wide enough for the true area filter of the largest possible source (an expanded, uncropped image)
+        n_taps = max(8, int(np.ceil(float(self.expand.expand.patch_coord_generator.max_scale) * max(h / out_h, w / out_w))) + 1)
         dt = arrs[0].dtype
         inv = np.argsort(cols)
+        if n_taps <= 64 and os.environ.get("SSDHIP_AUG_HOST_TAPS", "0") != "1":
+            # ---- tap tables built on the device from the decisions, the gather launch behind them; the labels come back last (the only
+            #      host synchronisation of the call) ------------------------------------------------------------------------------------
+            ix, wx, iy, wy = nat.augment_taps(geo_dev, h, w, out_h, out_w, n_taps)
+            bg = self.__dict__.get("_bg_rows")
+            if bg is None or bg[0] != (B, str(images.device)):
+                row = np.array([int(v) for v in self.expand.expand.background], dtype=np.uint8)
+                bg = ((B, str(images.device)), nat.to_device(np.repeat(row[None], B, 0), device=images.device))
+                self.__dict__["_bg_rows"] = bg
+            out = nat.image_resize_gather_u8(distorted.contiguous(), out_h, out_w, ix, wx, iy, wy, bg[1])
+            geo, lab_out, n_out, mt_out = fetch()
+            self.__dict__["_last_generator_states"] = mt_out
+            return out, [np.ascontiguousarray(lab_out[i, :int(n_out[i])][:, inv]).astype(dt) for i in range(B)]
+        geo, lab_out, n_out, mt_out = fetch()
+        self.__dict__["_last_generator_states"] = mt_out     # (B, 625): where each image's stream stands behind its chain (tests)
+        # ---- the recorded geometry of every image -> one gather launch; the labels back in the caller's column order and dtype ----------
         lazies, out_labels = [], []
         for i in range(B):
             g = geo[i]
