@@ -159,3 +159,48 @@ def test_two_rank_batchnorm_buffers_stay_in_step(tmp_path):
     outs = [torch.load(os.path.join(str(tmp_path), "b%d.pt" % r)) for r in range(2)]
     assert outs[0]["bufs"].numel() > 0 and torch.equal(outs[0]["bufs"], outs[1]["bufs"])       # rank 0's running statistics everywhere
     assert torch.equal(outs[0]["grads"], outs[1]["grads"])
+
+
+def _worker_sgd(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env("gloo")
+    from ssd_keras_amd.optimizers import SGD
+    model = dp.data_parallel(_build(), bucket_cap_mb=1)
+    decay = [p for p in model.parameters() if p.dim() == 4]
+    plain = [p for p in model.parameters() if p.dim() != 4]
+    opt = SGD([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-8, momentum=0.9)
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(4, 64, 64, 3)).astype(np.float32))
+    lo, hi = dp.shard_range(4, rank, world)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        _loss(model(x[lo:hi])).backward()
+        opt.step()
+    torch.save(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), os.path.join(tmp, "p%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_training_steps_with_the_package_sgd_match_single_process(tmp_path):
+    """Round 5: `ssd_keras_amd.optimizers.SGD` (the reference's keras.optimizers.SGD(lr, momentum=0.9), ssd300_training.ipynb:169; on a GPU
+    one libssdhip launch, here its tensor-expression path) under DDP on two gloo ranks: three steps leave both ranks with the
+    parameters three single-process torch.optim.SGD steps on the whole batch produce."""
+    port = _free_port()
+    mp.spawn(_worker_sgd, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), "p%d.pt" % r)) for r in range(2))
+    assert torch.equal(a, b)
+    model = _build()
+    decay = [p for p in model.parameters() if p.dim() == 4]
+    plain = [p for p in model.parameters() if p.dim() != 4]
+    opt = torch.optim.SGD([{"params": decay, "weight_decay": 1e-3}, {"params": plain, "weight_decay": 0.0}], lr=1e-8, momentum=0.9)
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(4, 64, 64, 3)).astype(np.float32))
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        _loss(model(x)).backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    init = torch.cat([p.detach().reshape(-1) for p in _build().parameters()])
+    moved = (ref - init).abs()
+    assert float(moved.max()) > 1e-6                                      # the steps did something (tiny lr: raw 0..255 inputs)
+    d = ((a - init) - (ref - init)).abs()
+    assert float(d.max()) <= 1e-3 * float(moved.max()) + 1e-9, (float(d.max()), float(moved.max()))
