@@ -279,9 +279,11 @@ extern "C" int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias
         int devid = 0;
         bool big_lds = false;
         if (lds > 64 * 1024 && hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64) {
-            if (big_lds_state[devid] == 0)
+            if (big_lds_state[devid] == 0) {
                 big_lds_state[devid] = hipFuncSetAttribute(reinterpret_cast<const void*>(pool3x3s1_slab_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 2;
+                if (big_lds_state[devid] == 2) (void)hipGetLastError();   // a refusal must not surface as the next launch's error
+            }
             big_lds = big_lds_state[devid] == 1;
         }
         if (lds <= 64 * 1024 || big_lds) {

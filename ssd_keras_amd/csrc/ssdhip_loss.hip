@@ -79,7 +79,7 @@ static LossWs loss_ws_layout(int B, int N, int C) {
     w.sel = o;    o = lalign(o + sizeof(SelectResult));
     w.cls = o;    o = lalign(o + (size_t)B * N * sizeof(float));
     w.neg = o;    o = lalign(o + (size_t)B * N * sizeof(float));
-    w.part = o;   o = lalign(o + (size_t)4 * B * w.tiles * sizeof(double));
+    w.part = o;   o = lalign(o + (size_t)4 * B * ((N + 63) / 64) * sizeof(double));      // the streaming L1 writes per 64 anchors, the tiled one per TA >= 64
     w.keep_part = o; o = lalign(o + (size_t)B * KEEP_BLOCKS * sizeof(double));
     w.bcol = o;   o = lalign(o + (size_t)w.nblk * SEL_BINS * sizeof(unsigned short));
     w.total = o;
@@ -466,6 +466,244 @@ __global__ __launch_bounds__(LOSS_THREADS) void backward_kernel(const float* __r
     for (int i = tid; i < total; i += TA) grad[off + i] = yp[i];
 }
 
+
+// ======================================================================================
+// L1 and backward, streaming form (round 5).  The tiled kernels above move 74 MB (111 MB backward) at 2.6-3 TB/s: a workgroup loads
+// its tile with one 16-byte load in flight per thread, works, and leaves; the latency is covered only by the other workgroups of the
+// CU, and batching the loads through VGPRs made it worse (profiles/r01l_loss_copy_variants.txt).  Here every WAVE is a stream of its
+// own: tiles of 64 anchors (one per lane, whole [C+12]-rows) arrive in its private LDS double buffer by LDS-DMA (ssdhip_tile.h) while
+// it works on the previous tile -- no barrier inside the loop, a tile in flight per wave at all times.  A persistent grid: wave w
+// takes tiles w, w + W, w + 2W ... (neighbouring waves read neighbouring rows at the same time).  Needs 16-byte aligned tiles
+// (N (C+12) % 4 == 0, true for every reference geometry with an even number of anchors) and the tensors below 2 GiB; anything else
+// runs the tiled kernels.
+// ======================================================================================
+struct StreamPlan {
+    int ok, G, nw, grid, tiles64;     // G: 1 KiB loads per array and tile; nw: waves per workgroup
+    size_t lds;
+};
+
+static StreamPlan stream_plan(const void* y_true, const void* y_pred, int B, int N, int C, int extra_lds_per_stage) {
+    StreamPlan p = {0, 0, 0, 0, (N + 63) / 64, 0};
+    const int L = C + 12;
+    const long long bytes = (long long)B * N * L * 4;
+    if (bytes >= 0x7fffff00LL || ((long long)N * L) % 4 != 0 || N % 4 != 0) return p;
+    if (((uintptr_t)y_true | (uintptr_t)y_pred) & 15u) return p;
+    if (const char* e = getenv("SSDHIP_LOSS_STREAM")) { if (e[0] == '0') return p; }    // A/B switch: the tiled kernels
+    p.G = (64 * L * 4 + 1023) / 1024;
+    if (2 * p.G + 2 > 60) return p;                                     // vmcnt counts to 63
+    const size_t stage = (size_t)2 * p.G * 1024 + extra_lds_per_stage;
+    p.nw = 4;
+    while (p.nw > 1 && p.nw * 2 * stage > 150 * 1024) p.nw >>= 1;
+    if (p.nw * 2 * stage > 150 * 1024) return p;
+    p.lds = p.nw * 2 * stage;
+    const long long WT = (long long)B * p.tiles64;
+    int cus = 256;
+    long long grid = (WT + p.nw - 1) / p.nw;
+    if (grid > cus) grid = cus;
+    const long long per = (WT + grid * p.nw - 1) / (grid * p.nw);      // tiles per wave; then the smallest grid that still does it in `per`
+    grid = (WT + per * p.nw - 1) / (per * p.nw);
+    p.grid = (int)grid;
+    p.ok = 1;
+    return p;
+}
+
+static bool stream_big_lds(const void* fn, int which, size_t lds) {     // the > 64 KB opt-in is per device and per kernel
+    if (lds <= 64 * 1024) return true;
+    static int granted[2][64] = {{0}};                                  // bytes opted in so far; -1: refused
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return false;
+    int& g = granted[which][devid];
+    if (g >= 0 && (size_t)g < lds) {
+        // the dynamic part only: the kernel's static LDS comes out of the same 160 KB
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) g = (int)lds;
+        else { g = -1; (void)hipGetLastError(); }                       // a refusal must not surface as the next launch's error
+    }
+    return g >= 0 && (size_t)g >= lds;
+}
+
+// the wave's next tile -> stage `lds_dst`: G loads per array, always (a short last tile of an image and the lanes past its end write zeros)
+__device__ __forceinline__ void stream_issue(int t, int tiles64, int N, int L, int G, tile_i32x4 rt, tile_i32x4 rp, u32 lds_dst, int lane) {
+    const int b = t / tiles64, a0 = (t - b * tiles64) * 64;
+    const int na = min(64, N - a0);
+    const u32 tile_off = (u32)(((size_t)b * N + a0) * (size_t)L * 4);
+    const int nch = (na * L) >> 2;                                      // 16-byte chunks: na L % 4 == 0 (N L % 4 == 0, a0 = 64 i)
+    const u32 arr = (u32)G * 1024u;
+    for (int j = 0; j < G; ++j) {
+        const int c = j * 64 + lane;
+        const u32 voff = c < nch ? tile_off + (u32)c * 16u : TILE_OOB;
+        tile_dma16(voff, rt, lds_dst + (u32)j * 1024u);
+        tile_dma16(voff, rp, lds_dst + arr + (u32)j * 1024u);
+    }
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void anchor_stream_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
+                                                                     int B, int N, int C, int tiles64, int G,
+                                                                     float* __restrict__ cls_out, float* __restrict__ neg_out,
+                                                                     double* __restrict__ part, u32* __restrict__ ghist1) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    __shared__ u32 hist[L1_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = C + 12;
+    const u32 arr = (u32)G * 1024u, stage = 2u * arr;
+    unsigned char* mine = smem_raw + (size_t)wave * 2 * stage;
+    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + (u32)wave * 2u * stage;
+    const u32 total_bytes = (u32)((size_t)B * N * (size_t)L * 4);
+    const tile_i32x4 rt = tile_rsrc(y_true, total_bytes), rp = tile_rsrc(y_pred, total_bytes);
+    const int WT = B * tiles64, W = gridDim.x * nw, gw = blockIdx.x * nw + wave;
+    for (int i = tid; i < L1_BINS; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    if (gw < WT) stream_issue(gw, tiles64, N, L, G, rt, rp, lds0, lane);
+    int par = 0;
+    for (int t = gw; t < WT; t += W, par ^= 1) {
+        const bool more = t + W < WT;
+        if (more) stream_issue(t + W, tiles64, N, L, G, rt, rp, lds0 + (u32)(par ^ 1) * stage, lane);
+        tile_wait_vmcnt(more ? 2 * G : 0);                              // everything older than the tile just requested has landed
+        const int b = t / tiles64, ti = t - b * tiles64, a0 = ti * 64;
+        const int na = min(64, N - a0);
+        const float* tb = reinterpret_cast<const float*>(mine + (size_t)par * stage);
+        const float* qb = reinterpret_cast<const float*>(mine + (size_t)par * stage + arr);
+        double s_poscls = 0.0, s_loc = 0.0, s_npos = 0.0;
+        int nonzero = 0;
+        u32 bin = 0;
+        if (lane < na) {
+            const float* tr = tb + (size_t)lane * L;
+            const float* q = qb + (size_t)lane * L;
+            float cls = 0.f, pos = tr[1];
+            int c = 0;
+            for (; c + 4 <= C; c += 4) {                               // log_loss (:93-95); four classes' LDS reads in flight together
+                float tc[4], qc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { tc[u] = tr[c + u]; qc[u] = q[c + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c + u >= 1) pos = fmaxf(pos, tc[u]);            // positives = max(y_true[1:C]) (:140)
+                    if (tc[u] != 0.f) cls += tc[u] * logf(fmaxf(qc[u], 1e-15f));
+                }
+            }
+            for (; c < C; ++c) {
+                const float tc = tr[c];
+                if (c >= 1) pos = fmaxf(pos, tc);
+                if (tc != 0.f) cls += tc * logf(fmaxf(q[c], 1e-15f));
+            }
+            cls = -cls;
+            float loc = 0.f;
+            for (int k = 0; k < 4; ++k) {                               // smooth_L1_loss (:72-75)
+                const float d = tr[C + k] - q[C + k];
+                const float ad = fabsf(d);
+                loc += ad < 1.0f ? 0.5f * (d * d) : ad - 0.5f;
+            }
+            const float neg = cls * tr[0];                              // neg_class_loss_all (:150)
+            cls_out[(size_t)b * N + a0 + lane] = cls;
+            neg_out[(size_t)b * N + a0 + lane] = neg;
+            s_poscls = (double)(cls * pos);
+            s_loc = (double)(loc * pos);
+            s_npos = (double)pos;
+            nonzero = neg != 0.f;
+            bin = float_key(neg) >> 24;
+        }
+        hist_add_aggregated(hist, bin, lane < na);
+        s_poscls = wave_sum(s_poscls); s_loc = wave_sum(s_loc); s_npos = wave_sum(s_npos);
+        const double s_nz = wave_sum((double)nonzero);
+        if (lane == 0) {                                                // per-tile partial sums, reduced in a fixed order by L2
+            const size_t slot = (size_t)b * tiles64 + ti, plane = (size_t)B * tiles64;
+            part[slot] = s_poscls; part[plane + slot] = s_loc; part[2 * plane + slot] = s_npos; part[3 * plane + slot] = s_nz;
+        }
+    }
+    __syncthreads();
+    u32* gshard = ghist1 + (blockIdx.x & (L1_SHARDS - 1)) * L1_BINS;
+    for (int i = tid; i < L1_BINS; i += blockDim.x) {
+        const u32 c = hist[i];
+        if (c) atomicAdd(&gshard[i], c);
+    }
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void backward_stream_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
+                                                                       const unsigned char* __restrict__ keep,
+                                                                       const float* __restrict__ stats, const float* __restrict__ grad_out,
+                                                                       int B, int N, int C, int tiles64, int G, float alpha,
+                                                                       float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = C + 12;
+    const u32 arr = (u32)G * 1024u, stage = 2u * arr + 256u;            // + the tile's 64 keep bytes (a 4-byte DMA load on 16 lanes) and its image's grad_out
+    unsigned char* mine = smem_raw + (size_t)wave * 2 * stage;
+    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + (u32)wave * 2u * stage;
+    const u32 total_bytes = (u32)((size_t)B * N * (size_t)L * 4);
+    const tile_i32x4 rt = tile_rsrc(y_true, total_bytes), rp = tile_rsrc(y_pred, total_bytes), rk = tile_rsrc(keep, (u32)((size_t)B * N));
+    const tile_i32x4 rg = tile_rsrc(grad_out, (u32)B * 4u);
+    const int WT = B * tiles64, W = gridDim.x * nw, gw = blockIdx.x * nw + wave;
+    // No load of hipcc's own may follow the first DMA load: its s_waitcnt would drain ours with it (hipcc counts only what it issued).
+    // stats[0] is read -- and waited for, the empty asm pins that -- up here; grad_out[b] comes with the tile.
+    float n_pos = fmaxf(1.0f, stats[0]);
+    asm volatile("" : "+v"(n_pos) :: "memory");
+    auto issue = [&](int t, u32 dst) {
+        stream_issue(t, tiles64, N, L, G, rt, rp, dst, lane);
+        const int b = t / tiles64, a0 = (t - b * tiles64) * 64;
+        const int nk = (min(64, N - a0) + 3) >> 2;                     // N % 4 == 0: whole dwords inside the mask
+        // under an EXEC mask, not with out-of-range offsets: a lane past the end would write ZEROS at dst + 4 lane -- 256 bytes, over the
+        // other word here and into the next stage.  Both masks are never empty, so each instruction issues (vmcnt counts instructions).
+        if (lane < nk) tile_dma4((u32)((size_t)b * N + a0) + (u32)lane * 4u, rk, dst + 2u * arr);
+        if (lane == 0) tile_dma4((u32)b * 4u, rg, dst + 2u * arr + 128u);
+    };
+    if (gw < WT) issue(gw, lds0);
+    int par = 0;
+    for (int t = gw; t < WT; t += W, par ^= 1) {
+        const bool more = t + W < WT;
+        if (more) issue(t + W, lds0 + (u32)(par ^ 1) * stage);
+        tile_wait_vmcnt(more ? 2 * G + 2 : 0);
+        const int b = __builtin_amdgcn_readfirstlane(t / tiles64), ti = t - b * tiles64, a0 = ti * 64;
+        const int na = min(64, N - a0);
+        const float* tb = reinterpret_cast<const float*>(mine + (size_t)par * stage);
+        float* qb = reinterpret_cast<float*>(mine + (size_t)par * stage + arr);
+        const unsigned char* kb = mine + (size_t)par * stage + 2 * arr;
+        const float scale = *reinterpret_cast<const float*>(kb + 128) * (float)B / n_pos;    // the tiled kernel's order of operations
+        if (lane < na) {
+            const float* tr = tb + (size_t)lane * L;
+            float* q = qb + (size_t)lane * L;                          // overwritten with the gradient row
+            float pos = tr[1];
+            int c = 2;
+            for (; c + 4 <= C; c += 4) {                               // four LDS reads in flight together
+                float tc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tc[u] = tr[c + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pos = fmaxf(pos, tc[u]);
+            }
+            for (; c < C; ++c) pos = fmaxf(pos, tr[c]);
+            const float w_cls = (pos + (kb[lane] ? 1.0f : 0.0f)) * scale;
+            for (c = 0; c + 4 <= C; c += 4) {
+                float tc[4], pc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { tc[u] = tr[c + u]; pc[u] = q[c + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float g = 0.f;
+                    if (tc[u] != 0.f && pc[u] >= 1e-15f) g = -(tc[u] / pc[u]) * w_cls;       // a branch: few classes of few lanes divide
+                    q[c + u] = g;
+                }
+            }
+            for (; c < C; ++c) {
+                const float pc = q[c];
+                q[c] = (pc >= 1e-15f && tr[c] != 0.f) ? -(tr[c] / pc) * w_cls : 0.f;
+            }
+            const float w_loc = alpha * pos * scale;
+            for (int k = 0; k < 4; ++k) {
+                const float d = tr[C + k] - q[C + k];
+                const float dl = fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f);
+                q[C + k] = -dl * w_loc;
+            }
+            for (int k = 4; k < 12; ++k) q[C + k] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();                                // one wave: its LDS operations execute in order
+        const int nch = (na * L) >> 2;
+        float4* gdst = reinterpret_cast<float4*>(grad + ((size_t)b * N + a0) * (size_t)L);
+        const float4* gsrc = reinterpret_cast<const float4*>(qb);
+        for (int c = lane; c < nch; c += 64) gdst[c] = gsrc[c];
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -499,11 +737,19 @@ extern "C" int ssdhip_loss_forward(const float* y_true, const float* y_pred, int
     const int TA = loss_tile(L);
     const size_t lds = 2 * (((size_t)TA * L + 4 + 3) / 4 * 4) * sizeof(float) + 16;
     if (lds > 140 * 1024) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(anchor_kernel, dim3(lay.tiles, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, part, ghist);
+    const StreamPlan sp = stream_plan(y_true, y_pred, B, N, C, 0);
+    int part_tiles = lay.tiles;
+    if (sp.ok && stream_big_lds(reinterpret_cast<const void*>(anchor_stream_kernel), 0, sp.lds)) {
+        hipLaunchKernelGGL(anchor_stream_kernel, dim3(sp.grid), dim3(64 * sp.nw), sp.lds, stream, y_true, y_pred, B, N, C, sp.tiles64, sp.G,
+                           cls, neg, part, ghist);
+        part_tiles = sp.tiles64;
+    } else {
+        hipLaunchKernelGGL(anchor_kernel, dim3(lay.tiles, B), dim3(TA), lds, stream, y_true, y_pred, B, N, C, cls, neg, part, ghist);
+    }
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     const int total = B * N;
     hipLaunchKernelGGL(sel_pass2_kernel, dim3(lay.nblk), dim3(SELP_THREADS), 0, stream, neg, total, ghist, neg_pos_ratio, n_neg_min, part,
-                       lay.tiles, sums, B, sel, stats);
+                       part_tiles, sums, B, sel, stats);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     hipLaunchKernelGGL(sel_pass3_kernel, dim3(lay.nblk), dim3(SELP_THREADS), 0, stream, neg, total, ghist, sel, bcol);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
@@ -526,8 +772,15 @@ extern "C" int ssdhip_loss_backward(const float* y_true, const float* y_pred, co
     const int TA = loss_tile(L);
     const size_t lds = 2 * (((size_t)TA * L + 4 + 3) / 4 * 4) * sizeof(float) + 16;
     if (lds > 150 * 1024) return SSDHIP_E_BADARG;
-    hipLaunchKernelGGL(backward_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), lds, stream, y_true, y_pred, keep_mask, stats, grad_out,
-                       B, N, C, alpha, grad_y_pred);
+    const StreamPlan sp = stream_plan(y_true, y_pred, B, N, C, 256);
+    if (sp.ok && !((uintptr_t)grad_y_pred & 15u) && !((uintptr_t)keep_mask & 3u) &&
+        stream_big_lds(reinterpret_cast<const void*>(backward_stream_kernel), 1, sp.lds)) {
+        hipLaunchKernelGGL(backward_stream_kernel, dim3(sp.grid), dim3(64 * sp.nw), sp.lds, stream, y_true, y_pred, keep_mask, stats, grad_out,
+                           B, N, C, sp.tiles64, sp.G, alpha, grad_y_pred);
+    } else {
+        hipLaunchKernelGGL(backward_kernel, dim3((N + TA - 1) / TA, B), dim3(TA), lds, stream, y_true, y_pred, keep_mask, stats, grad_out,
+                           B, N, C, alpha, grad_y_pred);
+    }
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     return SSDHIP_OK;
 }

@@ -462,8 +462,17 @@ class SSDModel(nn.Module):
             SSDModel._conv_choice[key] = hit
         return hit
 
+    @staticmethod
+    def _gemm_1x1(conv, x, relu):
+        b, c, h, w = x.shape
+        x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, c)                 # a view of channels_last memory
+        w2 = conv.weight.reshape(conv.out_channels, c)
+        y2 = (torch._addmm_activation(conv.bias, x2, w2.t(), use_gelu=False) if relu else torch.addmm(conv.bias, x2, w2.t()))
+        return y2.view(b, h, w, conv.out_channels).permute(0, 3, 1, 2)
+
     def conv_act(self, conv, x, relu=True):
         if self._fused(x, conv):
+            import os
             k = conv.kernel_size[0]
             if (conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
                     and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.bias is not None):
@@ -486,6 +495,11 @@ class SSDModel(nn.Module):
                 if self._image_ok(conv, x):
                     # one image per tile, the dilated taps as per-lane LDS addresses (csrc/ssdhip_convimg.hip): fc6
                     cands["image"] = lambda: nat.conv3x3_image(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu)
+                if k == 1 and os.environ.get("SSDHIP_GEMM_1X1", "0") == "1":
+                    # a 1 x 1 layer on NHWC memory IS a plain GEMM ([B H W, Cin] x [Cin, Cout] + bias, ReLU).  Opt-in: the library's
+                    # (hipBLASLt through torch, bias / activation in its epilogue) was measured on fc7 and conv6_1 inside the step and is
+                    # no faster than the implicit-GEMM kernels (profiles/r05zd_library_gemm_for_1x1_layers_ab.txt: 2.119 / 2.112 / 2.119 ms)
+                    cands["gemm"] = lambda: self._gemm_1x1(conv, x, relu)
             elif self._igemm_general_ok(conv, x):
                 # the extra layers: small maps, one workgroup per CU at most -- the deeper LDS rings (loads three / two steps ahead)
                 # hide the L2 latency that the two-stage kernel exposes on every K-step

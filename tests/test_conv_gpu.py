@@ -613,3 +613,26 @@ def test_image_conv_rejects_other_geometries():
         nat.conv3x3_image(x, w32, None, dilation=1)                      # Cout % 64 != 0
     with pytest.raises(nat.SsdHipError):
         nat.conv3x3_image(x, w, None, dilation=17)
+
+
+@pytest.mark.parametrize("case", [(32, 19, 19, 1024, 1024, True), (32, 19, 19, 1024, 256, True), (2, 5, 7, 64, 128, False)])
+def test_library_gemm_form_of_1x1_layers(case):
+    """A 1 x 1 layer on NHWC memory as a plain GEMM through the library (SSDModel._gemm_1x1: fc7, conv6_1 where the autotune picks it)
+    vs the float32 reference, the same bar as the implicit-GEMM kernels -- and the result is a channels_last view like theirs."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd.models._common import SSDModel
+    B, H, W, Cin, Cout, relu = case
+    g = torch.Generator(device="cuda").manual_seed(91)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    conv = torch.nn.Conv2d(Cin, Cout, 1).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        got = SSDModel._gemm_1x1(conv, x, relu)
+        want = F.conv2d(x.float(), conv.weight.float(), conv.bias.float())
+        if relu:
+            want = torch.relu(want)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=torch.channels_last)
+    rms = want.pow(2).mean().sqrt().item()
+    err = (got.float() - want).abs()
+    bad = int((err > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item())
+    assert bad == 0, "%d of %d outputs off; max err %g (rms %g)" % (bad, err.numel(), err.max().item(), rms)

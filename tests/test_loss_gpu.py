@@ -113,6 +113,21 @@ def test_loss_is_bit_reproducible():
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("cfg,B", [("ssd300", 8), ("ssd512", 2), ("ssd7", 4), ("tiny", 3)])
+def test_streaming_kernels_equal_the_tiled_ones(cfg, B, monkeypatch):
+    """Round 5: L1 and the backward kernel stream 64-anchor tiles per wave by LDS-DMA where the rows are 16-byte aligned
+    (csrc/ssdhip_loss.hip); SSDHIP_LOSS_STREAM=0 keeps the tiled kernels.  Same arithmetic per anchor: the mask, the statistics
+    and the gradient agree to the bit, the loss to the order of the float64 partial sums."""
+    y_true, y_pred = _inputs(cfg, B, 51)
+    kw = dict(neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+    new = _run(y_true, y_pred, **kw)
+    monkeypatch.setenv("SSDHIP_LOSS_STREAM", "0")
+    old = _run(y_true, y_pred, **kw)
+    np.testing.assert_allclose(new[0], old[0], rtol=1e-6)
+    for u, v in zip(new[1:], old[1:]):
+        assert np.array_equal(u, v)
+
+
 def test_gradient_against_finite_differences():
     import torch
     from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
