@@ -4,9 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssdhip.h"
 #include "ssdhip_math.h"
+#include "ssdhip_tile.h"
 
 namespace ssdhip {
 
@@ -32,12 +34,17 @@ struct HeadParams {
     int tile_start[MAX_PRED_LAYERS + 1];          // first tile of layer l
     int anchor_off[MAX_PRED_LAYERS];
     int n_layers, N, C, TA;
+    int row_dma;                                  // packed bf16 heads: the tile's pixel rows by LDS-DMA (0 with SSDHIP_HEADS_DMA=0: the element-wise gather, A/B)
     int src_f32;                                  // the head outputs are float32 (the reference-precision path, models/precise.py): conf / loc
                                                   // point at float32 values, strides count float32 elements, biases must be null
 };
 
-// LDS bytes of one tile: [TA][C+12] float rows + [TA][C] + [TA][4] bf16 logits
-__host__ __device__ inline size_t head_tile_lds(int TA, int C) { return (size_t)TA * ((C + 12) * sizeof(float) + (C + 4) * sizeof(hbf16_t)); }
+// LDS bytes of one tile: [TA][C+12] float rows + the logits' staging area -- [TA][C] + [TA][4] bf16, or (packed heads, round 5) the
+// tile's whole pixel rows as LDS-DMA leaves them: up to TA / n_boxes + 2 rows of 16-byte chunks, the last load's idle lanes, the biases
+__host__ __device__ inline size_t head_stage_bytes(int TA, int C) {
+    return (size_t)TA * (C + 4) * sizeof(hbf16_t) + (size_t)16 * TA + (size_t)64 * (C + 4) + 1024;
+}
+__host__ __device__ inline size_t head_tile_lds(int TA, int C) { return (size_t)TA * (C + 12) * sizeof(float) + head_stage_bytes(TA, C); }
 
 // Which layer / anchors the tile `tile_id` of the launch covers.
 __device__ __forceinline__ void head_tile_of(const HeadParams& hp, int tile_id, int& l, int& a0, int& na) {
@@ -107,6 +114,103 @@ __device__ __forceinline__ void head_build_rows(const HeadParams& hp, const floa
         }
         __syncthreads();
         return;
+    }
+    // ---- packed bf16 heads, rows by LDS-DMA (round 5).  The element-wise gather below keeps ONE two-byte load in flight per thread
+    //      (25 dependent trips per tile) and the softmax loop read its bias from global memory per class: together the larger part of
+    //      scan_heads_kernel's 52 us.  A packed head's pixel row is [conf n_boxes C | loc n_boxes 4 | padding] bf16: the tile's pixel
+    //      rows come in as 16-byte chunks (tile_dma16: every load of the workgroup in flight at once, no registers), the biases are
+    //      staged in LDS once, the anchor's 8 template floats are requested before the wait. ----
+    {
+        const int stride = hp.conf_stride[l];
+        const int U = nb * (C + 4) * 2, cpr = (U + 15) >> 4, pitch = cpr * 16;
+        const int pix0 = a0 / nb, npx = (a0 + na - 1) / nb - pix0 + 1, nchunks = npx * cpr;
+        const size_t dma_area = (size_t)((nchunks + 63) >> 6) * 1024;
+        const size_t npix_l = (size_t)(hp.n_anchors[l] / nb);
+        const size_t src_bytes = (size_t)gridDim.y * npix_l * (size_t)stride * 2;
+        const bool dma = hp.row_dma && hp.loc[l] == hp.conf[l] + (size_t)nb * C && hp.loc_stride[l] == stride && !(stride & 7) && stride * 2 >= pitch &&
+                         !((uintptr_t)hp.conf[l] & 15) && dma_area + (size_t)U <= head_stage_bytes(TA, C) && src_bytes < 0x7fffff00ull &&
+                         !(nthreads & 63);
+        if (dma) {
+            unsigned char* st = reinterpret_cast<unsigned char*>(cl);
+            const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)st;
+            const tile_i32x4 rs = tile_rsrc(hp.conf[l], (u32)src_bytes);
+            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const u32 row0 = (u32)(((size_t)b * npix_l + pix0) * (size_t)stride * 2);
+            for (int q0 = wave * 64; q0 < nchunks; q0 += nthreads) {
+                const int q = q0 + lane, r = q / cpr, j = q - r * cpr;
+                tile_dma16(q < nchunks ? row0 + (u32)r * (u32)(stride * 2) + (u32)j * 16u : TILE_OOB, rs, lds0 + (u32)q0 * 16u);
+            }
+            hbf16_t* bs = reinterpret_cast<hbf16_t*>(st + dma_area);                     // [nb C] conf bias | [nb 4] loc bias
+            const bool has_cb = hp.conf_bias[l] != nullptr, has_lb = hp.loc_bias[l] != nullptr;
+            if (has_cb) for (int i = tid; i < nb * C; i += nthreads) bs[i] = hp.conf_bias[l][i];
+            if (has_lb) for (int i = tid; i < nb * 4; i += nthreads) bs[nb * C + i] = hp.loc_bias[l][i];
+            const bool av16 = !((uintptr_t)anchors_var & 15);
+            float4 av0 = make_float4(0.f, 0.f, 0.f, 0.f), av1 = av0;
+            if (av16 && tid < na) {
+                const float4* avp = reinterpret_cast<const float4*>(anchors_var + (size_t)(hp.anchor_off[l] + a0 + tid) * 8);
+                av0 = avp[0]; av1 = avp[1];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int a = tid; a < na; a += nthreads) {
+                const int ga = a0 + a, pix = ga / nb, box = ga - pix * nb;
+                const hbf16_t* prow = reinterpret_cast<const hbf16_t*>(st + (size_t)(pix - pix0) * pitch);
+                const hbf16_t* src = prow + box * C;
+                const hbf16_t* cb = bs + box * C;
+                float* r = rows + (size_t)a * L;
+                float mx = -INFINITY;
+                int c = 0;
+                for (; c + 4 <= C; c += 4) {                            // four classes' LDS reads in flight together
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float x = h_bf2f(src[c + u]);
+                        // the PyTorch path rounds conv + bias to bf16 before the float32 softmax: keep that rounding
+                        v[u] = has_cb ? h_bf2f(h_f2bf(x + h_bf2f(cb[c + u]))) : x;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { r[c + u] = v[u]; mx = fmaxf(mx, v[u]); }
+                }
+                for (; c < C; ++c) {
+                    const float x = h_bf2f(src[c]);
+                    const float v = has_cb ? h_bf2f(h_f2bf(x + h_bf2f(cb[c]))) : x;
+                    r[c] = v;
+                    mx = fmaxf(mx, v);
+                }
+                float sum = 0.f;
+                for (c = 0; c + 4 <= C; c += 4) {
+                    float e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = r[c + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { e[u] = expf(e[u] - mx); sum += e[u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r[c + u] = e[u];
+                }
+                for (; c < C; ++c) { const float e = expf(r[c] - mx); r[c] = e; sum += e; }
+                for (c = 0; c + 4 <= C; c += 4) {
+                    float e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = r[c + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r[c + u] = e[u] / sum;
+                }
+                for (; c < C; ++c) r[c] = r[c] / sum;
+                const hbf16_t* lsrc = prow + nb * C + box * 4;
+                const hbf16_t* lb = bs + nb * C + box * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[C + k] = has_lb ? h_bf2f(h_f2bf(h_bf2f(lsrc[k]) + h_bf2f(lb[k]))) : h_bf2f(lsrc[k]);
+                if (av16 && a == tid) {
+                    r[C + 4] = av0.x; r[C + 5] = av0.y; r[C + 6] = av0.z; r[C + 7] = av0.w;
+                    r[C + 8] = av1.x; r[C + 9] = av1.y; r[C + 10] = av1.z; r[C + 11] = av1.w;
+                } else {
+                    const float* av = anchors_var + (size_t)(hp.anchor_off[l] + a0 + a) * 8;
+                    for (int k = 0; k < 8; ++k) r[C + 4 + k] = av[k];
+                }
+            }
+            __syncthreads();
+            return;
+        }
     }
     if (hp.conf_stride[l] == nb * C && hp.loc_stride[l] == nb * 4) {                    // dense heads: contiguous spans
         const hbf16_t* csrc = hp.conf[l] + ((size_t)b * hp.n_anchors[l] + a0) * C;
@@ -186,6 +290,7 @@ static inline int head_fill_params(HeadParams& hp, int n_layers, const void* con
     int TA = 256;
     while (TA > 32 && head_tile_lds(TA, C) > max_lds) TA >>= 1;
     hp.n_layers = n_layers; hp.N = N; hp.C = C; hp.TA = TA; hp.src_f32 = src_f32 ? 1 : 0;
+    { const char* e = getenv("SSDHIP_HEADS_DMA"); hp.row_dma = !(e && e[0] == '0'); }
     if (src_f32 && (conf_bias_h || loc_bias_h)) {
         for (int l = 0; l < n_layers; ++l)
             if ((conf_bias_h && conf_bias_h[l]) || (loc_bias_h && loc_bias_h[l])) return SSDHIP_E_BADARG;   // float32 heads carry their bias already
