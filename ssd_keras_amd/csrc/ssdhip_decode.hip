@@ -80,6 +80,7 @@ struct DecodeParams {
     float filter_kE;            // POL_NUMPY64: |R32| > filter_kE * S decides a pair in float32 (inf: never)
     double iou_thresh, img_w, img_h;   // img_w/img_h = 1 when !normalize_coords
     int top_k, cap, cap_store, out_rows, sorted;
+    int no_dma;                 // scan_kernel: tile_copy_f32 instead of the LDS-DMA copy (SSDHIP_SCAN_DMA=0, A/B)
 };
 
 // monotone score-key -> histogram bin: 2^SHIFT float32 ulps per bin starting at the threshold, clamped to NB-1
@@ -246,8 +247,25 @@ __global__ __launch_bounds__(256) void scan_kernel(const float* __restrict__ y, 
     const int b = blockIdx.y;
     const int a0 = blockIdx.x * TA;
     const int na = min(TA, p.N - a0);
-    // ---- coalesced tile copy: rows [a0, a0+na) are one contiguous run of na*L floats ----
-    const float* tile = tile_copy_f32(reinterpret_cast<float*>(smem_raw), y + ((size_t)b * p.N + a0) * (size_t)p.L, na * p.L, threadIdx.x, TA);
+    // ---- coalesced tile copy: rows [a0, a0+na) are one contiguous run of na*L floats.  Where the runs are 16-byte aligned they come in by
+    //      LDS-DMA, every load of the workgroup in flight at once (round 5; tile_copy_f32 keeps one 16-byte load in flight per thread) ----
+    const float* tile;
+    const size_t total_bytes = (size_t)gridDim.y * p.N * (size_t)p.L * sizeof(float);
+    if (!((uintptr_t)y & 15) && !(((size_t)p.N * p.L) & 3) && !((TA * p.L) & 3) && total_bytes < 0x7fffff00ull && !(TA & 63) && !p.no_dma) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+        const tile_i32x4 rs = tile_rsrc(y, (u32)total_bytes);
+        const u32 off = (u32)(((size_t)b * p.N + a0) * (size_t)p.L * sizeof(float));
+        const int nch = (na * p.L + 3) >> 2;                       // the last chunk may run into the next rows (or read zeros past the end)
+        for (int q0 = wave * 64; q0 < nch; q0 += TA) {
+            const int q = q0 + lane;
+            tile_dma16(q < nch ? off + (u32)q * 16u : TILE_OOB, rs, lds0 + (u32)q0 * 16u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tile = reinterpret_cast<const float*>(smem_raw);
+    } else {
+        tile = tile_copy_f32(reinterpret_cast<float*>(smem_raw), y + ((size_t)b * p.N + a0) * (size_t)p.L, na * p.L, threadIdx.x, TA);
+    }
     int* wave_cnt = reinterpret_cast<int*>(smem_raw + (((size_t)TA * p.L + 4) * sizeof(float) + 15) / 16 * 16);
     __syncthreads();
     scan_tile_body(tile, wave_cnt, p, b, a0, na, boxes, cand, cand_count, cls_out);
@@ -1466,6 +1484,7 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
 
     DecodeParams p;
     p.B = B; p.N = N; p.C = C; p.L = C + 12; p.G = class_agnostic ? 1 : C - 1;
+    p.no_dma = 0;
     p.class_agnostic = class_agnostic ? 1 : 0;
     p.semantics = semantics; p.coords = coords; p.border = border_pixels;
     // dtype flow of the reference: float32 predictions stay float32 only on the 'corners' path (no convert_coordinates)
@@ -1514,7 +1533,9 @@ static int decode_run(const HeadSource* heads, int stages, const void* y_pred, i
     // K3: small tiles (<= 24 KiB of LDS) keep many workgroups in flight per CU to hide the load -> atomic -> store chain
     int TA = 256;
     while (TA > 64 && (size_t)TA * p.L * sizeof(float) > 24 * 1024) TA >>= 1;
-    const size_t k3_lds = align_up(((size_t)TA * p.L + 4) * sizeof(float), 16) + (size_t)(TA / 64) * p.G * sizeof(int);
+    size_t k3_lds = align_up(((size_t)TA * p.L + 4) * sizeof(float), 16) + (size_t)(TA / 64) * p.G * sizeof(int);
+    k3_lds = k3_lds > align_up((size_t)TA * p.L * sizeof(float), 1024) ? k3_lds : align_up((size_t)TA * p.L * sizeof(float), 1024);   // the DMA copy writes whole 1 KiB pieces
+    { const char* e = getenv("SSDHIP_SCAN_DMA"); p.no_dma = (e && e[0] == '0') ? 1 : 0; }                                            // A/B switch
     if (k3_lds > 160 * 1024) return SSDHIP_E_BADARG;
     if (heads) {
         const int HT = heads->hp->TA;                 // one thread per row of the head tile
