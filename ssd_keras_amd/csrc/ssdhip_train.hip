@@ -120,60 +120,73 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint4* __restric
 
 // y: [B,H,W,C] post-ReLU activation (the pooling's input), gp: [B,Ho,Wo,C] gradient of the pooled map (2x2 windows, stride 2, clipped to
 // the map: Ho = ceil(H/2), Wo = ceil(W/2)), out: [B,H,W,C] = dL/dy masked by y > 0, partial: [gridDim.x][C] float32 channel sums of out.
-// The thread layout and the summation order are relu_bwd_bias_kernel's.
+// One thread per WINDOW and 8 channels (round 5; one thread per pixel re-read its window's four activations and searched the maximum
+// four times over: 2.2 TB/s of HBM traffic at four times the load instructions): the four activations and the pooled gradient are five
+// 16-byte loads in flight together, the arg-max is found once, the four gradients leave as four stores.  The window scan order, the
+// first-maximum and NaN rules are max_pool2d's (as maxpool_bwd_kernel); the channel sums add a thread's pixels in that order.
 __global__ __launch_bounds__(256) void maxpool2_relu_bwd_bias_kernel(const uint4* __restrict__ y, const uint4* __restrict__ gp,
                                                                      uint4* __restrict__ out, float* __restrict__ partial, int H, int W,
-                                                                     int Ho, int Wo, u32 n_pixels, u32 cvec) {
+                                                                     int Ho, int Wo, u32 n_windows, u32 cvec) {
     __shared__ float red[256 * 8];
     const u32 tid = threadIdx.x;
-    const u32 cg = tid % cvec, pl = tid / cvec, ppb = 256u / cvec;
+    const u32 cg = tid % cvec, wl = tid / cvec, wpb = 256u / cvec;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (u32 px = blockIdx.x * ppb + pl; px < n_pixels; px += gridDim.x * ppb) {
-        const int w = (int)(px % (u32)W);
-        const u32 t = px / (u32)W;
-        const int h = (int)(t % (u32)H), b = (int)(t / (u32)H);
-        const int oh = h >> 1, ow = w >> 1;
-        const int h0 = 2 * oh, h1 = min(h0 + 2, H), w0 = 2 * ow, w1 = min(w0 + 2, W);
-        float best[8];
-        int arg[8];
+    const size_t rowp = (size_t)W * cvec;
+    for (u32 wn = blockIdx.x * wpb + wl; wn < n_windows; wn += gridDim.x * wpb) {
+        const int ow = (int)(wn % (u32)Wo);
+        const u32 t = wn / (u32)Wo;
+        const int oh = (int)(t % (u32)Ho), b = (int)(t / (u32)Ho);
+        const int h0 = 2 * oh, w0 = 2 * ow;
+        const bool ok[4] = {true, w0 + 1 < W, h0 + 1 < H, (w0 + 1 < W) && (h0 + 1 < H)};
+        const size_t p00 = ((size_t)(b * H + h0) * W + w0) * cvec + cg;
+        const size_t pos[4] = {p00, p00 + cvec, p00 + rowp, p00 + rowp + cvec};
+        uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { best[q] = -__builtin_inff(); arg[q] = -1; }
-        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
-        for (int hi = h0; hi < h1; ++hi)
-            for (int wi = w0; wi < w1; ++wi) {
-                const uint4 v = y[((size_t)(b * H + hi) * W + wi) * cvec + cg];
-                const u32 vw[4] = {v.x, v.y, v.z, v.w};
-                const int pos = hi * W + wi;
-                if (hi == h && wi == w) mine = v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float a = tb2f(vw[q] & 0xffffu), c = tb2f(vw[q] >> 16);
-                    if (a > best[2 * q] || a != a) { best[2 * q] = a; arg[2 * q] = pos; }          // max_pool2d: first maximum, NaN wins
-                    if (c > best[2 * q + 1] || c != c) { best[2 * q + 1] = c; arg[2 * q + 1] = pos; }
-                }
-            }
-        const uint4 g = gp[((size_t)(b * Ho + oh) * Wo + ow) * cvec + cg];
-        const u32 gw[4] = {g.x, g.y, g.z, g.w}, vw[4] = {mine.x, mine.y, mine.z, mine.w};
-        const int me = h * W + w;
-        u32 o[4];
+        for (int k = 0; k < 4; ++k) v[k] = ok[k] ? y[pos[k]] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 g = gp[(size_t)wn * cvec + cg];
+        const u32 gw[4] = {g.x, g.y, g.z, g.w};
+        u32 o[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // maxpool_bwd_kernel's value (0 + g, rounded: -0 becomes +0), then relu_bwd_bias_kernel's mask
-            const u32 plo = tf2b(arg[2 * q] == me ? 0.f + tb2f(gw[q] & 0xffffu) : 0.f);
-            const u32 phi = tf2b(arg[2 * q + 1] == me ? 0.f + tb2f(gw[q] >> 16) : 0.f);
-            const u32 lo = (tb2f(vw[q] & 0xffffu) <= 0.f) ? 0u : plo;
-            const u32 hi = (tb2f(vw[q] >> 16) <= 0.f) ? 0u : phi;
-            o[q] = lo | (hi << 16);
-            acc[2 * q] += tb2f(lo);
-            acc[2 * q + 1] += tb2f(hi);
+            float best0 = -__builtin_inff(), best1 = -__builtin_inff();
+            int arg0 = -1, arg1 = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 w = k == 0 ? (q == 0 ? v[0].x : q == 1 ? v[0].y : q == 2 ? v[0].z : v[0].w)
+                            : k == 1 ? (q == 0 ? v[1].x : q == 1 ? v[1].y : q == 2 ? v[1].z : v[1].w)
+                            : k == 2 ? (q == 0 ? v[2].x : q == 1 ? v[2].y : q == 2 ? v[2].z : v[2].w)
+                                     : (q == 0 ? v[3].x : q == 1 ? v[3].y : q == 2 ? v[3].z : v[3].w);
+                const float a = tb2f(w & 0xffffu), c = tb2f(w >> 16);
+                if (ok[k] && (a > best0 || a != a)) { best0 = a; arg0 = k; }          // max_pool2d: first maximum, NaN wins
+                if (ok[k] && (c > best1 || c != c)) { best1 = c; arg1 = k; }
+            }
+            // maxpool_bwd_kernel's value (0 + g, rounded: -0 becomes +0) where the pixel is the window's arg-max, then the ReLU mask
+            const u32 glo = tf2b(0.f + tb2f(gw[q] & 0xffffu)), ghi = tf2b(0.f + tb2f(gw[q] >> 16));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 w = k == 0 ? (q == 0 ? v[0].x : q == 1 ? v[0].y : q == 2 ? v[0].z : v[0].w)
+                            : k == 1 ? (q == 0 ? v[1].x : q == 1 ? v[1].y : q == 2 ? v[1].z : v[1].w)
+                            : k == 2 ? (q == 0 ? v[2].x : q == 1 ? v[2].y : q == 2 ? v[2].z : v[2].w)
+                                     : (q == 0 ? v[3].x : q == 1 ? v[3].y : q == 2 ? v[3].z : v[3].w);
+                const u32 lo = (arg0 != k || tb2f(w & 0xffffu) <= 0.f) ? 0u : glo;
+                const u32 hi = (arg1 != k || tb2f(w >> 16) <= 0.f) ? 0u : ghi;
+                o[k][q] = lo | (hi << 16);
+            }
         }
-        out[(size_t)px * cvec + cg] = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ok[k]) {
+                out[pos[k]] = make_uint4(o[k][0], o[k][1], o[k][2], o[k][3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += tb2f(o[k][q] & 0xffffu); acc[2 * q + 1] += tb2f(o[k][q] >> 16); }
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) red[tid * 8 + q] = acc[q];
     __syncthreads();
-    if (pl == 0) {
-        for (u32 j = 1; j < ppb; ++j)
+    if (wl == 0) {                                              // fixed order over the window lanes: reproducible sums
+        for (u32 j = 1; j < wpb; ++j)
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] += red[(j * cvec + cg) * 8 + q];
 #pragma unroll
@@ -227,8 +240,9 @@ extern "C" int ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16(const void* y, const void
     if (!y || !gp || !out || !partial || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
     const long long n = (long long)B * H * W;
     if (n > 0x7fffffffLL || n_blocks <= 0 || n_blocks != ssdhip_relu_bwd_bias_blocks(n, C)) return SSDHIP_E_BADARG;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     hipLaunchKernelGGL(maxpool2_relu_bwd_bias_kernel, dim3(n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(y),
-                       static_cast<const uint4*>(gp), static_cast<uint4*>(out), partial, H, W, (H + 1) / 2, (W + 1) / 2, (u32)n, (u32)(C / 8));
+                       static_cast<const uint4*>(gp), static_cast<uint4*>(out), partial, H, W, Ho, Wo, (u32)((long long)B * Ho * Wo), (u32)(C / 8));
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -79,8 +79,9 @@ def test_data_gradient_through_the_forward_kernel(cin, cout, k, d, hw):
 @pytest.mark.parametrize("shape", [(3, 64, 37, 41), (2, 128, 30, 30), (2, 256, 75, 75), (1, 64, 1, 1), (2, 64, 2, 3)])
 def test_fused_pool_relu_backward_equals_the_two_kernels(shape):
     """Conv2D(relu) -> MaxPooling2D(2, 2, 'same') backward in one pass (maxpool2_relu_bwd_bias_kernel) against maxpool_bwd followed by
-    relu_bwd_bias on the same tensors: masked gradient bit-identical, bias gradient bit-identical (same thread layout, same order);
-    and against PyTorch's max_pool2d backward + threshold_backward.  Ties (ReLU zeros fill whole windows), NaNs and odd map sizes."""
+    relu_bwd_bias on the same tensors: masked gradient bit-identical, bias gradient equal up to the order of the float32 sums (round 5:
+    one thread per window, not per pixel); and against PyTorch's max_pool2d backward + threshold_backward.  Ties (ReLU zeros fill whole
+    windows), NaNs and odd map sizes."""
     torch, nat = _t()
     import torch.nn.functional as F
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -94,7 +95,9 @@ def test_fused_pool_relu_backward_equals_the_two_kernels(shape):
     gx = nat.maxpool_bwd(y, gp, 2, 2, 0)
     want, wb = nat.relu_bwd_bias(gx, y)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
-    assert torch.equal(gb, wb)
+    fin = torch.isfinite(wb)
+    assert torch.equal(fin, torch.isfinite(gb))
+    assert torch.allclose(gb[fin], wb[fin], rtol=1e-5, atol=1e-5 * float(wb[fin].abs().max().clamp_min(1.0)))
     # and the framework's own backward ops on a NaN-free copy (bf16 gradient of a 2x2 window = one term: exact)
     y2 = torch.nan_to_num(y, nan=0.5)
     yf = y2.float().requires_grad_(True)
