@@ -118,6 +118,105 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint4* __restric
     }
 }
 
+// maxpool_bwd_kernel for kernel 3, stride 1, padding 1 (pool5: Ho = H, Wo = W).  A pixel lies in up to nine windows and the gather kernel
+// re-read each of them: 81 loads per thread.  Here the pixel's 5 x 5 neighbourhood is loaded ONCE (25 loads in flight together) and the nine
+// arg-max searches run on registers, in the gather kernel's order (windows by (oh, ow), a window's pixels by (row, column), first
+// maximum, a NaN wins), so the float32 sums and their one rounding are the same.
+__global__ __launch_bounds__(256) void maxpool3s1_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ gy, uint4* __restrict__ gx,
+                                                             int B, int H, int W, u32 cvec) {
+    const u32 total = (u32)B * H * W * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 cg = i % cvec;
+        u32 t = i / cvec;
+        const int w = t % W; t /= W;
+        const int h = t % H;
+        const int b = t / H;
+        bool okr[5], okc[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { okr[j] = (unsigned)(h + j - 2) < (unsigned)H; okc[j] = (unsigned)(w + j - 2) < (unsigned)W; }
+        uint4 nb[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                nb[r][c] = (okr[r] && okc[c]) ? x[((size_t)(b * H + h + r - 2) * W + (w + c - 2)) * cvec + cg] : make_uint4(0u, 0u, 0u, 0u);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh)
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                if (!(okr[dh + 2] && okc[dw + 2])) continue;                 // the window centred on (h + dh, w + dw)
+                const uint4 g = gy[((size_t)(b * H + h + dh) * W + (w + dw)) * cvec + cg];
+                const u32 gw[4] = {g.x, g.y, g.z, g.w};
+                const int me = (1 - dh) * 3 + (1 - dw);                      // this pixel's place in the window's scan
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float best0 = -__builtin_inff(), best1 = -__builtin_inff();
+                    int arg0 = -1, arg1 = -1;
+#pragma unroll
+                    for (int eh = -1; eh <= 1; ++eh)
+#pragma unroll
+                        for (int ew = -1; ew <= 1; ++ew) {
+                            const int r = dh + eh + 2, c = dw + ew + 2;
+                            const uint4 v = nb[r][c];
+                            const u32 wd = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+                            const float a = tb2f(wd & 0xffffu), cc = tb2f(wd >> 16);
+                            const bool ok = okr[r] && okc[c];
+                            if (ok && (a > best0 || a != a)) { best0 = a; arg0 = (eh + 1) * 3 + (ew + 1); }
+                            if (ok && (cc > best1 || cc != cc)) { best1 = cc; arg1 = (eh + 1) * 3 + (ew + 1); }
+                        }
+                    if (arg0 == me) acc[2 * q] += tb2f(gw[q] & 0xffffu);
+                    if (arg1 == me) acc[2 * q + 1] += tb2f(gw[q] >> 16);
+                }
+            }
+        gx[i] = make_uint4(tf2b(acc[0]) | (tf2b(acc[1]) << 16), tf2b(acc[2]) | (tf2b(acc[3]) << 16), tf2b(acc[4]) | (tf2b(acc[5]) << 16),
+                           tf2b(acc[6]) | (tf2b(acc[7]) << 16));
+    }
+}
+
+// maxpool_bwd_kernel for kernel 2, stride 2, no padding, windows clipped to the map (Ho = ceil(H/2), Wo = ceil(W/2): pool1 .. pool4): the windows
+// do not overlap, so one thread per WINDOW and 8 channels finds the arg-max once and writes the window's four gradients (0 + g rounded at
+// the arg-max, +0 elsewhere: the gather kernel's values) -- a quarter of its loads and searches.
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ gy, uint4* __restrict__ gx,
+                                                           int H, int W, int Ho, int Wo, u32 n_windows, u32 cvec) {
+    const size_t rowp = (size_t)W * cvec;
+    const u32 total = n_windows * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 cg = i % cvec, wn = i / cvec;
+        const int ow = (int)(wn % (u32)Wo);
+        const u32 t = wn / (u32)Wo;
+        const int oh = (int)(t % (u32)Ho), b = (int)(t / (u32)Ho);
+        const int h0 = 2 * oh, w0 = 2 * ow;
+        const bool ok[4] = {true, w0 + 1 < W, h0 + 1 < H, (w0 + 1 < W) && (h0 + 1 < H)};
+        const size_t p00 = ((size_t)(b * H + h0) * W + w0) * cvec + cg;
+        const size_t pos[4] = {p00, p00 + cvec, p00 + rowp, p00 + rowp + cvec};
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ok[k] ? x[pos[k]] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 g = gy[i];
+        const u32 gw[4] = {g.x, g.y, g.z, g.w};
+        u32 o[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float best0 = -__builtin_inff(), best1 = -__builtin_inff();
+            int arg0 = -1, arg1 = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 w = q == 0 ? v[k].x : q == 1 ? v[k].y : q == 2 ? v[k].z : v[k].w;
+                const float a = tb2f(w & 0xffffu), c = tb2f(w >> 16);
+                if (ok[k] && (a > best0 || a != a)) { best0 = a; arg0 = k; }          // max_pool2d: first maximum, NaN wins
+                if (ok[k] && (c > best1 || c != c)) { best1 = c; arg1 = k; }
+            }
+            const u32 glo = tf2b(0.f + tb2f(gw[q] & 0xffffu)), ghi = tf2b(0.f + tb2f(gw[q] >> 16));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][q] = (arg0 == k ? glo : 0u) | ((arg1 == k ? ghi : 0u) << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ok[k]) gx[pos[k]] = make_uint4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    }
+}
+
 // y: [B,H,W,C] post-ReLU activation (the pooling's input), gp: [B,Ho,Wo,C] gradient of the pooled map (2x2 windows, stride 2, clipped to
 // the map: Ho = ceil(H/2), Wo = ceil(W/2)), out: [B,H,W,C] = dL/dy masked by y > 0, partial: [gridDim.x][C] float32 channel sums of out.
 // One thread per WINDOW and 8 channels (round 5; one thread per pixel re-read its window's four activations and searched the maximum
@@ -412,6 +511,19 @@ extern "C" int ssdhip_maxpool_bwd_nhwc_bf16(const void* x, const void* gy, void*
     if (total > 0x7fffffffLL) return SSDHIP_E_BADARG;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
+    if (kernel == 2 && stride == 2 && pad == 0 && Ho == (H + 1) / 2 && Wo == (W + 1) / 2) {
+        const long long nwin = (long long)B * Ho * Wo;
+        long long wb = (nwin * (C / 8) + 255) / 256;
+        if (wb > 256 * 32) wb = 256 * 32;
+        hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)wb), dim3(256), 0, stream, static_cast<const uint4*>(x),
+                           static_cast<const uint4*>(gy), static_cast<uint4*>(gx), H, W, Ho, Wo, (u32)nwin, (u32)(C / 8));
+        return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    }
+    if (kernel == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W) {
+        hipLaunchKernelGGL(maxpool3s1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint4*>(x),
+                           static_cast<const uint4*>(gy), static_cast<uint4*>(gx), B, H, W, (u32)(C / 8));
+        return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint4*>(x),
                        static_cast<const uint4*>(gy), static_cast<uint4*>(gx), B, H, W, (u32)(C / 8), kernel, stride, pad, Ho, Wo);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;

@@ -139,8 +139,13 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
         # (small maps -- conv5_x, fc6 with its dilation -- through the image-resident kernel, csrc/ssdhip_convimg.hip, where it fills the chip)
         image = (k == 3 and gy.shape[2] * gy.shape[3] <= 384 and gy.shape[0] * (wt.shape[0] // 64) >= 128
                  and nat.conv3x3_image_supported(gy, wt, dilation[0]) and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
+        # (a 64-channel dL/dy -- conv1_2 -- through the resident-filter kernel of the Cin = 64 layers, csrc/ssdhip_conv64.hip: the same bits as
+        #  the implicit-GEMM kernel in half its time, 430 -> 215 us at 300 x 300 / batch 32)
+        c64 = (k == 3 and dilation[0] == 1 and wt.shape[1] == 64 and wt.shape[0] % 64 == 0 and os.environ.get("SSDHIP_NO_C64_DGRAD", "0") != "1")
         if image:
             gx = nat.conv3x3_image(gy, wt, None, dilation=dilation[0], relu=False)
+        elif c64:
+            gx = nat.conv3x3_c64(gy, wt, None, relu=False, pool=False)
         else:
             gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
     gw, gb = None, None

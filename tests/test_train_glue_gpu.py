@@ -70,6 +70,10 @@ def test_data_gradient_through_the_forward_kernel(cin, cout, k, d, hw):
     err = (got - want).abs()
     bound = 2.0 ** -7 * want.abs() + 1e-2 * want.pow(2).mean().sqrt()
     assert bool((err <= bound).all()), float((err - bound).max())
+    if k == 3 and d == 1 and cout == 64:
+        # a 64-channel dL/dy (conv1_2) takes the resident-filter kernel (csrc/ssdhip_conv64.hip): same bits
+        alt = nat.conv3x3_c64(gy, wt, None, relu=False, pool=False)
+        assert torch.equal(alt.view(torch.int16), nat.conv2d_same(gy, wt, None, dilation=d, relu=False).view(torch.int16))
     if k == 3 and nat.conv3x3_image_supported(gy, wt, d):
         # the form the training step takes on small maps at batch 32 (models/_common.py _conv_input_weight_grads): same bits
         alt = nat.conv3x3_image(gy, wt, None, dilation=d, relu=False)
