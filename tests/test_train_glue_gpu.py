@@ -39,7 +39,9 @@ def test_relu_backward_unsupported_channel_count_falls_back():
 
 
 @pytest.mark.parametrize("shape,k,s,p,ceil", [((2, 64, 75, 75), 2, 2, 0, True), ((2, 64, 38, 38), 2, 2, 0, True), ((3, 128, 19, 19), 3, 1, 1, False),
-                                              ((1, 8, 7, 5), 3, 2, 1, True), ((2, 16, 300, 300), 2, 2, 0, True)])
+                                              ((1, 8, 7, 5), 3, 2, 1, True), ((2, 16, 300, 300), 2, 2, 0, True),
+                                              # 3 x 3 / 1: channel counts and map sizes outside the per-image form (the neighbourhood kernel)
+                                              ((2, 24, 19, 19), 3, 1, 1, False), ((1, 32, 60, 60), 3, 1, 1, False), ((2, 512, 5, 3), 3, 1, 1, False)])
 def test_maxpool_backward_matches_pytorch(shape, k, s, p, ceil):
     torch, nat = _t()
     import torch.nn.functional as F
