@@ -64,19 +64,43 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const ssdhip_shadow
     const int no = min(SH_T, d.O - o0), ni = min(SH_T, d.I - i0);
     const float* src = static_cast<const float*>(d.src);
     const int run = ni * kk;
+    // (six loads in flight per thread and trip: one at a time, a tile of 9216 values was 36 dependent memory round trips per workgroup
+    //  and the launch ran at a third of the HBM rate)
+    constexpr int SH_U = 6;
+    const int n_el = no * run;
     if (d.src_channels_last) {
         // master [O][kk][I] float32 (a channels_last parameter): runs of ni values per (o, tap)
-        for (int e = tid; e < no * run; e += 256) {
-            const int o = e / run, j = e - o * run;
-            const int tap = j / ni, i = j - tap * ni;
-            tile[(tap * SH_T + o) * (SH_T + 2) + i] = opt_f2b(src[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i]);
+        for (int e0 = tid; e0 < n_el; e0 += 256 * SH_U) {
+            float v[SH_U];
+            int at[SH_U];
+#pragma unroll
+            for (int u = 0; u < SH_U; ++u) {
+                const int e = e0 + 256 * u, ec = e < n_el ? e : 0;
+                const int o = ec / run, j = ec - o * run;
+                const int tap = j / ni, i = j - tap * ni;
+                at[u] = e < n_el ? (tap * SH_T + o) * (SH_T + 2) + i : -1;
+                v[u] = src[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < SH_U; ++u)
+                if (at[u] >= 0) tile[at[u]] = opt_f2b(v[u]);
         }
     } else {
         // master [O][I][kk] float32: the tile's row o is the contiguous run [i0 .. i0 + ni) x kk
-        for (int e = tid; e < no * run; e += 256) {
-            const int o = e / run, j = e - o * run;
-            const int i = j / kk, tap = j - i * kk;
-            tile[(tap * SH_T + o) * (SH_T + 2) + i] = opt_f2b(src[((size_t)(o0 + o) * d.I + i0) * kk + j]);
+        for (int e0 = tid; e0 < n_el; e0 += 256 * SH_U) {
+            float v[SH_U];
+            int at[SH_U];
+#pragma unroll
+            for (int u = 0; u < SH_U; ++u) {
+                const int e = e0 + 256 * u, ec = e < n_el ? e : 0;
+                const int o = ec / run, j = ec - o * run;
+                const int i = j / kk, tap = j - i * kk;
+                at[u] = e < n_el ? (tap * SH_T + o) * (SH_T + 2) + i : -1;
+                v[u] = src[((size_t)(o0 + o) * d.I + i0) * kk + j];
+            }
+#pragma unroll
+            for (int u = 0; u < SH_U; ++u)
+                if (at[u] >= 0) tile[at[u]] = opt_f2b(v[u]);
         }
     }
     __syncthreads();

@@ -369,9 +369,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restr
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += rb1 * blockDim.x) {
         float4 s = part[i];
-        for (int k = 1; k < slots; ++k) {
-            const float4 v = part[(size_t)k * n4 + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int k = 1; k < slots; k += 8) {                            // eight slots' loads in flight together; added in slot order all the same
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k + u < slots ? part[(size_t)(k + u) * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k + u < slots) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
         out[i] = s;
     }
