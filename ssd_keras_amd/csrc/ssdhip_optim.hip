@@ -105,21 +105,46 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const ssdhip_shadow
     }
     __syncthreads();
     // channels_last copy [O][kk][I]: runs of ni values
+    // (four values = 8 bytes per store where the runs allow it: two-byte stores left the launch at 1.6 TB/s)
     unsigned short* cl = static_cast<unsigned short*>(d.cl);
     if (cl) {
-        for (int e = tid; e < no * kk * SH_T; e += 256) {
-            const int i = e & (SH_T - 1), r = e >> 5;
-            const int tap = r % kk, o = r / kk;
-            if (i < ni) cl[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i] = tile[(tap * SH_T + o) * (SH_T + 2) + i];
+        if (!(d.I & 3) && !((uintptr_t)cl & 7)) {                       // i0 is a multiple of 32, so ni % 4 == 0 as well
+            for (int e = tid; e < no * kk * (SH_T / 4); e += 256) {
+                const int i = (e & (SH_T / 4 - 1)) * 4, r = e >> 3;
+                const int tap = r % kk, o = r / kk;
+                if (i < ni) {
+                    const u32* t2 = reinterpret_cast<const u32*>(&tile[(tap * SH_T + o) * (SH_T + 2) + i]);   // rows are 68 bytes: 4-byte aligned
+                    *reinterpret_cast<uint2*>(&cl[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i]) = make_uint2(t2[0], t2[1]);
+                }
+            }
+        } else {
+            for (int e = tid; e < no * kk * SH_T; e += 256) {
+                const int i = e & (SH_T - 1), r = e >> 5;
+                const int tap = r % kk, o = r / kk;
+                if (i < ni) cl[((size_t)(o0 + o) * kk + tap) * d.I + i0 + i] = tile[(tap * SH_T + o) * (SH_T + 2) + i];
+            }
         }
     }
     // transposed, taps flipped [I][kk][tr_ostride] at channel offset tr_ooff: runs of no values
     unsigned short* tr = static_cast<unsigned short*>(d.tr);
     if (tr) {
-        for (int e = tid; e < ni * kk * SH_T; e += 256) {
-            const int o = e & (SH_T - 1), r = e >> 5;
-            const int tap = r % kk, i = r / kk;
-            if (o < no) tr[((size_t)(i0 + i) * kk + (kk - 1 - tap)) * d.tr_ostride + d.tr_ooff + o0 + o] = tile[(tap * SH_T + o) * (SH_T + 2) + i];
+        if (!(d.tr_ostride & 3) && !(d.tr_ooff & 3) && !(no & 3) && !((uintptr_t)tr & 7)) {
+            for (int e = tid; e < ni * kk * (SH_T / 4); e += 256) {
+                const int o = (e & (SH_T / 4 - 1)) * 4, r = e >> 3;
+                const int tap = r % kk, i = r / kk;
+                if (o < no) {
+                    const unsigned short* tp = &tile[(tap * SH_T + o) * (SH_T + 2) + i];
+                    const u32 a = tp[0], b = tp[SH_T + 2], c = tp[2 * (SH_T + 2)], e3 = tp[3 * (SH_T + 2)];
+                    *reinterpret_cast<uint2*>(&tr[((size_t)(i0 + i) * kk + (kk - 1 - tap)) * d.tr_ostride + d.tr_ooff + o0 + o]) =
+                        make_uint2(a | (b << 16), c | (e3 << 16));
+                }
+            }
+        } else {
+            for (int e = tid; e < ni * kk * SH_T; e += 256) {
+                const int o = e & (SH_T - 1), r = e >> 5;
+                const int tap = r % kk, i = r / kk;
+                if (o < no) tr[((size_t)(i0 + i) * kk + (kk - 1 - tap)) * d.tr_ostride + d.tr_ooff + o0 + o] = tile[(tap * SH_T + o) * (SH_T + 2) + i];
+            }
         }
     }
 }
