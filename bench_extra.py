@@ -556,10 +556,25 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        prof = None
+        if os.environ.get("SSD_TRAIN_HOST_PROFILE"):                      # tools aid: where the host spends the step (cProfile of the timed loop)
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t = time.perf_counter()
         for _ in range(steps):
             run()
+        issued = time.perf_counter() - t                                  # the host has issued every launch; the GPU may still be running
         torch.cuda.synchronize()
+        if prof is not None:
+            import io
+            import pstats
+            prof.disable()
+            buf = io.StringIO()
+            pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(45)
+            with open(os.environ["SSD_TRAIN_HOST_PROFILE"], "w") as fh:
+                fh.write("host issue time per step %.3f ms (of %.3f ms per step)\n" % (1e3 * issued / steps, 1e3 * (time.perf_counter() - t) / steps))
+                fh.write(buf.getvalue())
         if world > 1:
             torch.distributed.barrier()
         mine = time.perf_counter() - t
