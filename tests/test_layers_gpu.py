@@ -107,6 +107,10 @@ def test_preprocess(env):
     assert got.shape == want.shape and torch.equal(got, want)
     want2 = ((img.permute(0, 3, 1, 2) - 127.5) / 127.5).to(torch.bfloat16)
     assert torch.equal(nat.preprocess(img, [127.5] * 3, [127.5] * 3, None), want2)
+    # a pixel count off a multiple of four takes the one-pixel-per-thread kernel (the other: four pixels per thread, 16-byte loads)
+    odd = img[:1, :7, :5].contiguous()
+    assert torch.equal(nat.preprocess(odd, mean, None, swap),
+                       (odd.permute(0, 3, 1, 2) - torch.tensor(mean, device="cuda", dtype=torch.float32).view(1, -1, 1, 1))[:, swap].to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("which", ["ssd300", "ssd7", "ssd300-igemm"])
