@@ -269,6 +269,15 @@ int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
 /* Channel sums of a bf16 map alone (the bias gradient of a layer without activation: the predictor heads), as per-workgroup partial
  * sums [n_blocks][C] like the two passes around it. */
 int ssdhip_channel_sums_nhwc_bf16(const void* gy, float* partial, long long n_pixels, int C, int n_blocks, void* stream);
+
+/* The FIRST layer's backward in one pass (round 5): conv1_1 of the training graph (Conv2D(64, (3, 3), activation='relu', padding='same') on the
+ * 3-channel image, models/keras_ssd300.py:274) has no data gradient, so ReLU mask, bias gradient and weight gradient are one read of
+ * gy, y [B,H,W,64] bf16 (gradient of the post-ReLU output, that output) and x [B,H,W,3] bf16.  wpart [n_blocks][64][27] float32 with
+ * k = (kh*3 + kw)*3 + ci and bpart [n_blocks][64] float32 are per-workgroup partial sums: the caller adds the rows in order.
+ * n_blocks = ssdhip_conv1_1_bwd_blocks(B, H, W) (0: bad arguments). */
+int ssdhip_conv1_1_bwd_blocks(int B, int H, int W);
+int ssdhip_conv1_1_bwd_nhwc_bf16(const void* gy, const void* y, const void* x, float* wpart, float* bpart, int B, int H, int W, int n_blocks,
+                                 void* stream);
 int ssdhip_relu_bwd_bias_nhwc_bf16(const void* gy, const void* y, void* out, float* partial, long long n_pixels, int C,
                                    int n_blocks, void* stream);
 

@@ -485,6 +485,10 @@ def _train_lib():
         lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16.argtypes = [c_vp, c_vp, c_vp, c_vp] + [c_int] * 5 + [c_vp]
         lib.ssdhip_channel_sums_nhwc_bf16.restype = c_int
         lib.ssdhip_channel_sums_nhwc_bf16.argtypes = [c_vp, c_vp, c_ll, c_int, c_int, c_vp]
+        lib.ssdhip_conv1_1_bwd_blocks.restype = c_int
+        lib.ssdhip_conv1_1_bwd_blocks.argtypes = [c_int, c_int, c_int]
+        lib.ssdhip_conv1_1_bwd_nhwc_bf16.restype = c_int
+        lib.ssdhip_conv1_1_bwd_nhwc_bf16.argtypes = [c_vp] * 5 + [c_int] * 4 + [c_vp]
         lib._train_bound = True
     return lib
 
@@ -521,6 +525,31 @@ def relu_bwd_bias(gy, y, reduce=True):
         rc = lib.ssdhip_relu_bwd_bias_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(out), _ptr(partial), b * h * w, c, nb, current_stream_ptr(gy.device))
     check(rc, "ssdhip_relu_bwd_bias_nhwc_bf16")
     return out, (partial.sum(dim=0) if reduce else partial)
+
+
+def conv1_1_backward(gy, y, x):
+    """Backward of the FIRST layer, `y = relu(conv3x3(x) + bias)` with 3 input and 64 output channels and no data gradient, in one pass
+    (csrc/ssdhip_train.hip, conv1_1_bwd_kernel): returns (dL/dW float32 (64, 3, 3, 3), dL/db float32 (64,)).  gy, y: (B, 64, H, W) bf16
+    with NHWC memory (the gradient of the post-ReLU output, that output), x: (B, 3, H, W) bf16 with NHWC memory."""
+    torch = _torch()
+    lib = _train_lib()
+    gy, (b, h, w, c) = _nhwc_bf16(gy, "gy")
+    y, shp = _nhwc_bf16(y, "y")
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4:
+        raise SsdHipError("x must be a 4-D bfloat16 CUDA tensor")
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    bx, cx, hx, wx = x.shape
+    if c != 64 or shp != (b, h, w, c) or (bx, hx, wx, cx) != (b, h, w, 3):
+        raise SsdHipError("conv1_1_backward needs (B, 64, H, W) gradients / activations and a (B, 3, H, W) input")
+    nb = lib.ssdhip_conv1_1_bwd_blocks(b, h, w)
+    wpart = torch.empty((nb, 64, 27), dtype=torch.float32, device=gy.device)
+    bpart = torch.empty((nb, 64), dtype=torch.float32, device=gy.device)
+    with torch.cuda.device(gy.device):
+        rc = lib.ssdhip_conv1_1_bwd_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(x), _ptr(wpart), _ptr(bpart), b, h, w, nb, current_stream_ptr(gy.device))
+    check(rc, "ssdhip_conv1_1_bwd_nhwc_bf16")
+    gw = wpart.sum(dim=0).view(64, 3, 3, 3).permute(0, 3, 1, 2)           # k = (kh 3 + kw) 3 + ci  ->  (co, ci, kh, kw)
+    return gw, bpart.sum(dim=0)
 
 
 def maxpool2_relu_bwd_bias(y, gp, reduce=True):

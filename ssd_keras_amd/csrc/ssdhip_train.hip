@@ -355,6 +355,123 @@ __global__ __launch_bounds__(256) void maxpool2_relu_bwd_bias_kernel(const uint4
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The FIRST layer's backward in one pass (round 5): conv1_1 (3 -> 64 channels, 3 x 3 'same', ReLU; models/keras_ssd300.py:274) needs no
+// data gradient, so its masked output gradient is only ever summed -- into the bias gradient and into dW[co][kh][kw][ci] = sum over
+// pixels of g[p][co] x[p + tap][ci].  The three-launch form wrote the masked gradient (368 MB at 300 x 300 / batch 32) for MIOpen's weight
+// gradient to read back: 1.1 GB + 0.39 GB of traffic, ~390 us.  Here a tile of 64 pixels of one image row is masked in registers, laid
+// into LDS TRANSPOSED ([channel][pixel], so that an MFMA lane's eight consecutive K values -- pixels -- are one 16-byte read) next to
+// the tile's im2col patch [k = (kh 3 + kw) 3 + ci][pixel], and four waves accumulate D[64 channels][32 k] with
+// v_mfma_f32_32x32x16_bf16 over the pixels (K).  Reads gy + y + x once, writes per-workgroup partial sums (added in order by the caller).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 tr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float tr_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int C11B_PITCH = 144;                              // bytes per LDS row: 64 pixels + padding, 16-byte aligned
+
+__global__ __launch_bounds__(256) void conv1_1_bwd_kernel(const uint4* __restrict__ gy, const uint4* __restrict__ y,
+                                                          const unsigned short* __restrict__ x, float* __restrict__ wpart,
+                                                          float* __restrict__ bpart, int H, int W, int tiles_per_row, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char gT[64 * C11B_PITCH];       // masked gradient [channel][pixel] bf16
+    __shared__ __attribute__((aligned(16))) unsigned char pT[32 * C11B_PITCH];       // im2col patch   [k][pixel] bf16, rows 27 .. 31 zero
+    __shared__ unsigned short xs[3][66 * 3 + 2];                                     // the tile's three input rows, one pixel of halo each side
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 7, pp = tid >> 3;                   // 8 channels x one PAIR of pixels per thread
+    float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    tr_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = tid; i < 32 * C11B_PITCH / 4; i += 256) reinterpret_cast<u32*>(pT)[i] = 0u;
+    const int cohalf = wave & 1, pxhalf = wave >> 1;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tr = tile % tiles_per_row, rowid = tile / tiles_per_row;           // rowid = b H + h
+        const int h = rowid % H, w0 = tr * 64;
+        const int npx = min(64, W - w0);
+        // ---- loads: the pair's gradient and activation vectors, the three input rows ----
+        uint4 g[2], a[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int px = 2 * pp + e;
+            const bool ok = px < npx;
+            const size_t at = ((size_t)rowid * W + w0 + px) * 8 + cg;
+            g[e] = ok ? gy[at] : make_uint4(0u, 0u, 0u, 0u);
+            a[e] = ok ? y[at] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        for (int i = tid; i < 3 * 198; i += 256) {
+            const int r = i / 198, j = i - r * 198;
+            const int col = w0 - 1 + j / 3, row = h + r - 1;
+            unsigned short v = 0;
+            if ((unsigned)row < (unsigned)H && (unsigned)col < (unsigned)W)
+                v = x[((size_t)(rowid + r - 1) * W + col) * 3 + (j % 3)];            // rowid + r - 1 stays inside the image: row is
+            xs[r][j] = v;
+        }
+        // ---- ReLU mask (threshold_backward: zero where y <= 0, a NaN activation lets the gradient through), bias sums, transposed store ----
+        u32 m[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const u32 gw[4] = {g[e].x, g[e].y, g[e].z, g[e].w}, vw[4] = {a[e].x, a[e].y, a[e].z, a[e].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 lo = (tb2f(vw[q] & 0xffffu) <= 0.f) ? 0u : (gw[q] & 0xffffu);
+                const u32 hi = (tb2f(vw[q] >> 16) <= 0.f) ? 0u : (gw[q] >> 16);
+                m[e][q] = lo | (hi << 16);
+                bacc[2 * q] += tb2f(lo);
+                bacc[2 * q + 1] += tb2f(hi);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                         // channels cg 8 + 2 q and + 1: the pair's two pixels side by side in one word
+            *reinterpret_cast<u32*>(gT + (cg * 8 + 2 * q) * C11B_PITCH + pp * 4) = (m[0][q] & 0xffffu) | (m[1][q] << 16);
+            *reinterpret_cast<u32*>(gT + (cg * 8 + 2 * q + 1) * C11B_PITCH + pp * 4) = (m[0][q] >> 16) | (m[1][q] & 0xffff0000u);
+        }
+        __syncthreads();
+        // ---- im2col, transposed: pT[k][px] = xs[kh][(px + kw) 3 + ci] ----
+        for (int i = tid; i < 27 * 32; i += 256) {
+            const int k = i >> 5, q = i & 31;
+            const int kh = k / 9, rem = k - kh * 9;           // rem = kw 3 + ci
+            const u32 v0 = xs[kh][(2 * q) * 3 + rem], v1 = xs[kh][(2 * q + 1) * 3 + rem];
+            *reinterpret_cast<u32*>(pT + k * C11B_PITCH + q * 4) = v0 | (v1 << 16);
+        }
+        __syncthreads();
+        // ---- D[32 channels of this wave][32 k] += G[32][16 pixels] P[16 pixels][32]: two K-steps per wave and tile ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int px0 = (pxhalf * 2 + ks) * 16 + (lane >> 5) * 8;
+            const tr_bf16x8 fa = *reinterpret_cast<const tr_bf16x8*>(gT + (cohalf * 32 + (lane & 31)) * C11B_PITCH + px0 * 2);
+            const tr_bf16x8 fb = *reinterpret_cast<const tr_bf16x8*>(pT + (lane & 31) * C11B_PITCH + px0 * 2);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        __syncthreads();                                      // the next tile overwrites gT / pT / xs
+    }
+    // ---- the two pixel halves of a channel half are added through LDS; D row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column = lane & 31 ----
+    float* dsum = red;                                        // [2 channel halves][16][64 lanes]
+    if (pxhalf == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dsum[(cohalf * 16 + i) * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (pxhalf == 0) {
+        const int k = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = acc[i] + dsum[(cohalf * 16 + i) * 64 + lane];
+            const int co = cohalf * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (k < 27) wpart[((size_t)blockIdx.x * 64 + co) * 27 + k] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[tid * 8 + q] = bacc[q];
+    __syncthreads();
+    if (pp == 0) {                                            // fixed order over the pixel-pair lanes: reproducible sums
+        for (int j = 1; j < 32; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bacc[q] += red[(j * 8 + cg) * 8 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bpart[(size_t)blockIdx.x * 64 + cg * 8 + q] = bacc[q];
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -593,5 +710,26 @@ extern "C" int ssdhip_maxpool_bwd_nhwc_bf16(const void* x, const void* gy, void*
     }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint4*>(x),
                        static_cast<const uint4*>(gy), static_cast<uint4*>(gx), B, H, W, (u32)(C / 8), kernel, stride, pad, Ho, Wo);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// conv1_1's backward (3 -> 64 channels, 3 x 3 'same', ReLU, no data gradient) in one pass: gy, y [B,H,W,64] bf16 (the gradient of the
+// post-ReLU output and that output), x [B,H,W,3] bf16; wpart [n_blocks][64][27] float32 with k = (kh 3 + kw) 3 + ci, bpart
+// [n_blocks][64] float32: per-workgroup partial sums the caller adds in order.  n_blocks = ssdhip_conv1_1_bwd_blocks(B, H, W).
+extern "C" int ssdhip_conv1_1_bwd_blocks(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const long long tiles = (long long)B * H * ((W + 63) / 64);
+    return (int)(tiles < 1024 ? tiles : 1024);
+}
+
+extern "C" int ssdhip_conv1_1_bwd_nhwc_bf16(const void* gy, const void* y, const void* x, float* wpart, float* bpart, int B, int H, int W,
+                                            int n_blocks, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!gy || !y || !x || !wpart || !bpart || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    if ((((uintptr_t)gy | (uintptr_t)y) & 15) || ((uintptr_t)x & 1)) return SSDHIP_E_BADARG;
+    const long long tiles = (long long)B * H * ((W + 63) / 64);
+    if (tiles > 0x7fffffffLL || (long long)B * H * W > 0x3fffffffLL || n_blocks != ssdhip_conv1_1_bwd_blocks(B, H, W)) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(conv1_1_bwd_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy),
+                       static_cast<const uint4*>(y), static_cast<const unsigned short*>(x), wpart, bpart, H, W, (W + 63) / 64, (int)tiles);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -99,6 +99,13 @@ class _ConvBiasActFn(torch.autograd.Function):
         gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         want_gb = bdt is not None and ctx.needs_input_grad[2]
         partial = None
+        import os
+        if (relu and not ctx.needs_input_grad[0] and gy.is_cuda and tuple(wb.shape) == (64, 3, 3, 3) and stride == (1, 1)
+                and padding == (1, 1) and dilation == (1, 1) and os.environ.get("SSDHIP_NO_CONV1_1_BWD", "0") != "1"):
+            # the first layer: no data gradient, so the masked gradient is only ever summed -- ReLU mask, bias gradient and weight gradient
+            # in ONE pass that writes nothing but partial sums (csrc/ssdhip_train.hip, conv1_1_bwd_kernel)
+            gw, gb = nat.conv1_1_backward(gy, y, xb)
+            return None, gw.to(wdt), (gb.to(bdt) if want_gb else None), None, None, None, None, None, None, None, None
         if relu:
             # ReLU mask and the per-workgroup channel sums of the bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the rows
             # are added by the weight gradient's reduction launch where that is ours, by one framework reduction otherwise

@@ -183,3 +183,25 @@ def test_fused_sgd_momentum_step_follows_torch_sgd():
         for pa, pb in zip(a, b):
             torch.testing.assert_close(pa, pb, rtol=3e-7 * (step + 1), atol=1e-7 * (step + 1))
             torch.testing.assert_close(ours.state[pa]["momentum_buffer"], ref.state[pb]["momentum_buffer"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 300), (3, 37, 41), (1, 1, 1), (2, 5, 130), (1, 64, 64)])
+def test_first_layer_backward_in_one_pass(shape):
+    """conv1_1's backward (csrc/ssdhip_train.hip, conv1_1_bwd_kernel: ReLU mask + bias gradient + weight gradient from one read of the
+    gradient, the activation and the image) against the three-step form on the same tensors: relu_bwd_bias, then the float64
+    weight gradient of the masked gradient.  bf16 operands, float32 accumulation: 1e-3 of the gradient's scale; bias sums to 1e-5."""
+    torch, nat = _t()
+    b, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((b, 3, h, w), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.randn((b, 64, h, w), device="cuda", generator=g).clamp_min(0).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((b, 64, h, w), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if h * w > 4:
+        y.permute(0, 2, 3, 1).reshape(-1)[::97] = float("nan")             # a NaN activation lets the gradient through
+    gw, gb = nat.conv1_1_backward(gy, y, x)
+    masked, wb = nat.relu_bwd_bias(gy, y)
+    want_w = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 3, 3), masked.double(), stride=1, padding=1)
+    assert gw.shape == (64, 3, 3, 3) and gw.dtype == torch.float32 and gb.shape == (64,)
+    scale = float(want_w.abs().max().clamp_min(1e-6))
+    assert float((gw.double() - want_w).abs().max()) <= 1e-3 * scale
+    assert torch.allclose(gb, wb, rtol=1e-5, atol=1e-5 * float(wb.abs().max().clamp_min(1.0)))
