@@ -494,7 +494,7 @@ static StreamPlan stream_plan(const void* y_true, const void* y_pred, int B, int
     const size_t stage = (size_t)2 * p.G * 1024 + extra_lds_per_stage;
     p.nw = 4;
     while (p.nw > 1 && p.nw * 2 * stage > 150 * 1024) p.nw >>= 1;
-    if (p.nw < 2 || p.nw * 2 * stage > 150 * 1024) return p;            // rows too long for two streams per CU (COCO's 93 floats): the tiled kernels keep more waves in flight
+    if (p.nw < 4 || p.nw * 2 * stage > 150 * 1024) return p;            // rows too long for four streams per CU (C + 12 > 40 floats, e.g. COCO's 93): the tiled kernels keep more waves in flight there (not measured)
     p.lds = p.nw * 2 * stage;
     const long long WT = (long long)B * p.tiles64;
     int cus = 256;
