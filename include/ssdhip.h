@@ -270,6 +270,15 @@ int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
  * sums [n_blocks][C] like the two passes around it. */
 int ssdhip_channel_sums_nhwc_bf16(const void* gy, float* partial, long long n_pixels, int C, int n_blocks, void* stream);
 
+/* Backward of ssdhip_assemble_predictions_strided_bf16 for PACKED heads (the training step, round 5): the backward of the graph's
+ * Reshape + Concatenate + softmax + Concatenate (models/keras_ssd300.py:363-419) in one launch.  grad_pred, y_pred [B, N, C+12] float32
+ * (d loss / d predictions, and the predictions: the softmax probabilities are read from them); grad_heads[l]: the gradient of source map
+ * l's packed head output, [B, n_anchors[l] / n_boxes[l], stride[l]] bf16 with channels [conf n_boxes C | loc n_boxes 4 | padding], written
+ * whole (padding channels zero); host arrays of n_layers entries; stride[l] % 8 == 0, stride[l] >= n_boxes[l] (C + 4). */
+int ssdhip_assemble_predictions_backward_bf16(int n_layers, void* const* grad_heads, const int* n_anchors, const int* n_boxes,
+                                              const int* stride, const float* y_pred, const float* grad_pred, int B, int N, int C,
+                                              void* stream);
+
 /* The FIRST layer's backward in one pass (round 5): conv1_1 of the training graph (Conv2D(64, (3, 3), activation='relu', padding='same') on the
  * 3-channel image, models/keras_ssd300.py:274) has no data gradient, so ReLU mask, bias gradient and weight gradient are one read of
  * gy, y [B,H,W,64] bf16 (gradient of the post-ReLU output, that output) and x [B,H,W,3] bf16.  wpart [n_blocks][64][27] float32 with

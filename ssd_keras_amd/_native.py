@@ -407,6 +407,37 @@ def _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_
     return args, keep, int(B), N
 
 
+def assemble_predictions_backward(grad_pred, y_pred, packed_shapes, n_boxes, n_classes):
+    """Backward of `assemble_predictions` for PACKED bf16 heads (the training step): grad_pred, y_pred (B, N, C+12) float32 -> one
+    (B, Cp, h, w) bf16 gradient with NHWC memory per source map, channels [conf | loc | zero padding] (csrc/ssdhip_layers.hip,
+    head_grad_kernel: softmax backward, pass-through of the offsets, one rounding).  packed_shapes: the (B, Cp, h, w) of every map."""
+    torch = _torch()
+    lib = _layers_lib()
+    if not getattr(lib, "_apb_bound", False):
+        c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+        lib.ssdhip_assemble_predictions_backward_bf16.restype = c_int
+        lib.ssdhip_assemble_predictions_backward_bf16.argtypes = [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]
+        lib._apb_bound = True
+    require_cuda(grad_pred, "grad_pred")
+    if grad_pred.dtype != torch.float32 or y_pred.dtype != torch.float32 or grad_pred.shape != y_pred.shape or grad_pred.dim() != 3:
+        raise SsdHipError("grad_pred and y_pred must be float32 (B, N, C+12) tensors of one shape")
+    grad_pred, y_pred = grad_pred.contiguous(), y_pred.contiguous()
+    B, N, L = y_pred.shape
+    if L != n_classes + 12:
+        raise SsdHipError("y_pred has %d columns, expected %d" % (L, n_classes + 12))
+    nl = len(packed_shapes)
+    outs = [torch.empty((b, h, w, cp), dtype=torch.bfloat16, device=y_pred.device) for (b, cp, h, w) in packed_shapes]
+    ptrs = (ctypes.c_void_p * nl)(*[o.data_ptr() for o in outs])
+    na = (ctypes.c_int * nl)(*[int(h * w * nb) for (b, cp, h, w), nb in zip(packed_shapes, n_boxes)])
+    nbx = (ctypes.c_int * nl)(*[int(v) for v in n_boxes])
+    st = (ctypes.c_int * nl)(*[int(cp) for (b, cp, h, w) in packed_shapes])
+    with torch.cuda.device(y_pred.device):
+        rc = lib.ssdhip_assemble_predictions_backward_bf16(nl, ptrs, na, nbx, st, _ptr(y_pred), _ptr(grad_pred), B, N, int(n_classes),
+                                                           current_stream_ptr(y_pred.device))
+    check(rc, "ssdhip_assemble_predictions_backward_bf16")
+    return [o.permute(0, 3, 1, 2) for o in outs]
+
+
 def assemble_predictions(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_classes):
     """Per-layer NHWC conv outputs -> y_pred (B, N, C+12) float32 in one pass (softmax, biases, anchors, concatenation);
     see `_head_sources` for the accepted layer formats."""

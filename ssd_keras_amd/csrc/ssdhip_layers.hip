@@ -263,6 +263,58 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams hp, const float* _
     for (int i = tid; i < na * L; i += 256) dst[i] = rows[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the prediction assembly for the TRAINING step (round 5): d loss / d y_pred [B, N, C+12] float32 -> the gradient of every
+// source map's PACKED head output [B, h, w, Cp] bf16 ([conf n_boxes C | loc n_boxes 4 | zero padding]: what _PackedHeadFn returns and
+// its backward reads).  Per anchor: softmax backward on the class columns (dlogit_c = p_c (g_c - sum_k g_k p_k), p from the saved
+// y_pred), the four offset columns pass through, the anchor / variance columns have no producer; one rounding to bf16, as the
+// framework's cast of the float32 gradient.  Replaces the backward of Reshape + Concatenate + softmax + Concatenate
+// (models/keras_ssd300.py:363-419): ~15 framework launches (slices into zero-filled maps, concatenation splits, softmax backward).
+// grid (tiles, B); a tile = whole pixels of one layer (at most 128 anchors), both row tiles staged in LDS, the packed rows built in
+// LDS and stored as one contiguous run.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HG_TILE = 128;
+struct HeadGradParams {
+    bf16_t* out[MAX_PRED_LAYERS];
+    int n_anchors[MAX_PRED_LAYERS], n_boxes[MAX_PRED_LAYERS], stride[MAX_PRED_LAYERS], tile_start[MAX_PRED_LAYERS + 1],
+        anchor_off[MAX_PRED_LAYERS], tile_anchors[MAX_PRED_LAYERS];
+    int n_layers, N, C;
+};
+
+__global__ __launch_bounds__(HG_TILE) void head_grad_kernel(HeadGradParams hp, const float* __restrict__ y_pred, const float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, b = blockIdx.y, C = hp.C, L = C + 12;
+    int l = 0;
+    while (l + 1 < hp.n_layers && (int)blockIdx.x >= hp.tile_start[l + 1]) ++l;
+    const int nb = hp.n_boxes[l], ta = hp.tile_anchors[l];
+    const int a0 = ((int)blockIdx.x - hp.tile_start[l]) * ta, na = min(ta, hp.n_anchors[l] - a0);
+    const int pix0 = a0 / nb, npx = na / nb;                 // tiles hold whole pixels
+    const int rowb = hp.stride[l] * 2;
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const size_t half = ((size_t)HG_TILE * L + 4 + 3) / 4 * 4;
+    unsigned char* stage = smem_raw + 2 * half * sizeof(float);
+    const size_t off = ((size_t)b * hp.N + hp.anchor_off[l] + a0) * (size_t)L;
+    const float* yp = tile_copy_f32(lds, y_pred + off, na * L, tid, HG_TILE);
+    const float* gp = tile_copy_f32(lds + half, grad + off, na * L, tid, HG_TILE);
+    for (int i = tid; i < npx * rowb / 4; i += HG_TILE) reinterpret_cast<u32*>(stage)[i] = 0u;
+    __syncthreads();
+    if (tid < na) {
+        const int pix = tid / nb, box = tid - pix * nb;
+        const float* pr = yp + (size_t)tid * L;
+        const float* gr = gp + (size_t)tid * L;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot += gr[c] * pr[c];
+        bf16_t* row = reinterpret_cast<bf16_t*>(stage + (size_t)pix * rowb);
+        for (int c = 0; c < C; ++c) row[box * C + c] = (bf16_t)f2bf(pr[c] * (gr[c] - dot));
+        for (int k = 0; k < 4; ++k) row[nb * C + box * 4 + k] = (bf16_t)f2bf(gr[C + k]);
+    }
+    __syncthreads();
+    const size_t npix_l = (size_t)(hp.n_anchors[l] / nb);
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(hp.out[l]) + ((size_t)b * npix_l + pix0) * rowb);
+    const uint4* src = reinterpret_cast<const uint4*>(stage);
+    for (int i = tid; i < npx * rowb / 16; i += HG_TILE) dst[i] = src[i];
+}
+
 static inline int grid_for(size_t work_items, int per_block) {
     size_t g = (work_items + per_block - 1) / per_block;
     const size_t cap = 256 * 16;                 // 16 workgroups per CU: enough loads in flight, few tail blocks
@@ -571,4 +623,48 @@ extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const*
                                                 int B, int N, int C, float* y_pred, void* stream) {
     return ssdhip_assemble_predictions_strided_bf16(n_layers, conf_h, loc_h, conf_bias_h, loc_bias_h, n_anchors_h, n_boxes_h,
                                                     nullptr, nullptr, anchors_var, B, N, C, y_pred, stream);
+}
+
+// Backward of ssdhip_assemble_predictions_strided_bf16 for packed heads (the training step): grad_pred, y_pred [B, N, C+12] float32 (the
+// gradient of the loss with respect to the assembled predictions, and those predictions); grad_heads_h[l]: the gradient of source map
+// l's packed head output [B, n_anchors[l] / n_boxes[l], stride[l]] bf16 with channels [conf n_boxes C | loc n_boxes 4 | padding] --
+// written whole, padding channels zero.  stride[l] (elements per pixel) must be a multiple of 8 and hold n_boxes[l] (C + 4) values.
+extern "C" int ssdhip_assemble_predictions_backward_bf16(int n_layers, void* const* grad_heads_h, const int* n_anchors_h, const int* n_boxes_h,
+                                                         const int* stride_h, const float* y_pred, const float* grad_pred, int B, int N, int C,
+                                                         void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !grad_heads_h || !n_anchors_h || !n_boxes_h || !stride_h || !y_pred || !grad_pred ||
+        B <= 0 || B > 65535 || N <= 0 || C < 2)
+        return SSDHIP_E_BADARG;
+    HeadGradParams hp;
+    hp.n_layers = n_layers; hp.N = N; hp.C = C;
+    int off = 0, tiles = 0;
+    size_t max_stage = 0;
+    for (int l = 0; l < MAX_PRED_LAYERS; ++l) {
+        const bool on = l < n_layers;
+        hp.out[l] = on ? static_cast<bf16_t*>(grad_heads_h[l]) : nullptr;
+        hp.n_anchors[l] = on ? n_anchors_h[l] : 0;
+        hp.n_boxes[l] = on ? n_boxes_h[l] : 1;
+        hp.stride[l] = on ? stride_h[l] : 0;
+        hp.tile_start[l] = tiles;
+        hp.anchor_off[l] = off;
+        hp.tile_anchors[l] = 1;
+        if (on) {
+            const int nb = hp.n_boxes[l];
+            if (!hp.out[l] || ((uintptr_t)hp.out[l] & 15) || hp.n_anchors[l] <= 0 || nb <= 0 || nb > HG_TILE || hp.n_anchors[l] % nb ||
+                (hp.stride[l] & 7) || hp.stride[l] < nb * (C + 4))
+                return SSDHIP_E_BADARG;
+            hp.tile_anchors[l] = HG_TILE / nb * nb;
+            off += hp.n_anchors[l];
+            tiles += (hp.n_anchors[l] + hp.tile_anchors[l] - 1) / hp.tile_anchors[l];
+            const size_t st = (size_t)(hp.tile_anchors[l] / nb) * hp.stride[l] * 2;
+            max_stage = st > max_stage ? st : max_stage;
+        }
+    }
+    hp.tile_start[MAX_PRED_LAYERS] = tiles;
+    if (off != N) return SSDHIP_E_BADARG;
+    const size_t lds = 2 * (((size_t)HG_TILE * (C + 12) + 4 + 3) / 4 * 4) * sizeof(float) + max_stage + 16;
+    if (lds > 64 * 1024) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(head_grad_kernel, dim3(tiles, B), dim3(HG_TILE), lds, stream, hp, y_pred, grad_pred);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

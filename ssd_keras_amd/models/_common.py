@@ -247,6 +247,28 @@ class _PackedHeadFn(torch.autograd.Function):
         return (gx, gw[:nc].to(wdt), gb[:nc].to(bdt), gw[nc:nc + nl].to(wdt), gb[nc:nc + nl].to(bdt), None, None, None)
 
 
+class _AssembleTrainFn(torch.autograd.Function):
+    """Reshape + Concatenate + softmax + AnchorBoxes + Concatenate of the TRAINING step (models/keras_ssd300.py:363-419) as one autograd
+    node over the packed head maps: forward = ssdhip_assemble_predictions_strided_bf16 (the inference path's one-launch assembly),
+    backward = ssdhip_assemble_predictions_backward_bf16 (softmax backward and the scatter into the packed layout, one launch) --
+    instead of six slices, three concatenations, a softmax and an index_select forward and their ~15 kernels backward."""
+
+    @staticmethod
+    def forward(ctx, anchors, n_classes, n_boxes, *ys):
+        pred = nat.assemble_predictions([y.detach() for y in ys], [None] * len(ys), [None] * len(ys), [None] * len(ys), list(n_boxes),
+                                        anchors, n_classes)
+        ctx.save_for_backward(pred)
+        ctx.conf = (n_classes, tuple(n_boxes), tuple(tuple(y.shape) for y in ys))
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        (pred,) = ctx.saved_tensors
+        n_classes, n_boxes, shapes = ctx.conf
+        grads = nat.assemble_predictions_backward(g.float(), pred, shapes, n_boxes, n_classes)
+        return (None, None, None) + tuple(grads)
+
+
 class _MaxPoolFn(torch.autograd.Function):
     """max_pool2d of a bf16 NHWC map in the training step: libssdhip forward (one pass) and backward (gather, deterministic)."""
 
@@ -871,6 +893,16 @@ class SSDModel(nn.Module):
                 return self.decoder.forward_from_heads(*head_args)          # y_pred is never materialised
             pred = nat.assemble_predictions(*head_args)
             return self.decoder(pred) if (decode and self.decoder is not None) else pred
+        import os
+        if (torch.is_grad_enabled() and not decode and os.environ.get("SSDHIP_NO_TRAIN_ASSEMBLY", "0") != "1" and len(feats) <= 8
+                and self.n_classes <= 1024 and all(self._packed_train_head_ok(f, ch, lh) for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads))):
+            # every source map's heads are one packed libssdhip node: the assembly and its backward are one launch each
+            ys = []
+            for l, (f, ch, lh) in enumerate(zip(feats, self.conf_heads, self.loc_heads)):
+                pw, pb, pwt, _nc, _nl = self._packed_head_shadow(l)
+                ys.append(_PackedHeadFn.apply(f, ch.weight, ch.bias, lh.weight, lh.bias, pw, pb, pwt))
+            anchors = self.anchors_and_variances(sizes, x.device)
+            return _AssembleTrainFn.apply(anchors, self.n_classes, [pb_.n_boxes for pb_ in self.priorboxes], *ys)
         confs, locs = [], []
         for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads):
             # NCHW -> NHWC before the reshape so the channel axis splits as (box, class) like Keras (:363-383)

@@ -205,3 +205,35 @@ def test_first_layer_backward_in_one_pass(shape):
     scale = float(want_w.abs().max().clamp_min(1e-6))
     assert float((gw.double() - want_w).abs().max()) <= 1e-3 * scale
     assert torch.allclose(gb, wb, rtol=1e-5, atol=1e-5 * float(wb.abs().max().clamp_min(1.0)))
+
+
+def test_training_assembly_node_equals_the_framework_expression():
+    """_AssembleTrainFn (forward: the one-launch assembly; backward: ssdhip_assemble_predictions_backward_bf16) against the framework
+    expression it replaces -- slices of the packed maps, Reshape, Concatenate, softmax, Concatenate with the anchors -- forward to 2e-6,
+    the packed gradients to one bf16 rounding (padding channels exactly zero).  n_boxes 4 and 6, maps whose anchors do not fill a tile."""
+    torch, nat = _t()
+    from ssd_keras_amd.models._common import _AssembleTrainFn
+    g = torch.Generator(device="cuda").manual_seed(17)
+    B, C = 3, 21
+    geo = [(7, 9, 4, 128), (5, 5, 6, 256), (3, 2, 6, 256), (1, 1, 4, 128)]        # (h, w, n_boxes, packed channels)
+    ys = [(torch.randn((B, h, w, cp), device="cuda", generator=g) * 3).to(torch.bfloat16).permute(0, 3, 1, 2).requires_grad_(True) for h, w, nb, cp in geo]
+    N = sum(h * w * nb for h, w, nb, cp in geo)
+    anchors = torch.rand((N, 8), device="cuda", generator=g)
+    n_boxes = [nb for _, _, nb, _ in geo]
+    pred = _AssembleTrainFn.apply(anchors, C, n_boxes, *ys)
+    wgt = torch.randn(pred.shape, device="cuda", generator=g)
+    got = torch.autograd.grad((pred * wgt).sum(), ys)
+    refs = [y.detach().clone().requires_grad_(True) for y in ys]
+    confs, locs = [], []
+    for y, (h, w, nb, cp) in zip(refs, geo):
+        t = y.permute(0, 2, 3, 1)
+        confs.append(t[..., :nb * C].reshape(B, -1, C))
+        locs.append(t[..., nb * C:nb * (C + 4)].reshape(B, -1, 4))
+    want = torch.cat([torch.softmax(torch.cat(confs, 1).float(), -1), torch.cat(locs, 1).float(), anchors.unsqueeze(0).expand(B, -1, -1)], 2)
+    assert pred.shape == want.shape and torch.allclose(pred, want, rtol=2e-6, atol=2e-7)
+    ref = torch.autograd.grad((want * wgt).sum(), refs)
+    for a, b_, (h, w, nb, cp) in zip(got, ref, geo):
+        assert a.shape == b_.shape and a.dtype == torch.bfloat16
+        assert bool((a[:, nb * (C + 4):] == 0).all())
+        err = (a.float() - b_.float()).abs()
+        assert bool((err <= 2.0 ** -7 * b_.float().abs() + 1e-6).all()), float(err.max())
