@@ -796,6 +796,13 @@ class SSDModel(nn.Module):
                 and next(self.parameters()).dtype == torch.bfloat16):
             return nat.preprocess(x, self.subtract_mean, self.divide_by_stddev,
                                   list(self.swap_channels) if self.swap_channels else None)
+        if (nhwc and self.fused_training and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled()
+                and not x.requires_grad and self.img_channels <= 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and os.environ.get("SSDHIP_NO_TRAIN_PREPROCESS", "0") != "1"):
+            # the training step under bf16 autocast: the first convolution casts its input to bf16 anyway, and the images need no
+            # gradient -- the same one-launch kernel instead of a subtraction, an index_select and two layout / dtype copies
+            return nat.preprocess(x, self.subtract_mean, self.divide_by_stddev,
+                                  list(self.swap_channels) if self.swap_channels else None)
         if nhwc:
             x = x.permute(0, 3, 1, 2)                # NHWC storage == channels_last NCHW: no copy
         x = x.float()
