@@ -1,4 +1,4 @@
-"""Kernel timelines of bench steps in a rocprofv3 kernel trace (`*_kernel_trace.csv`): every kernel between one preprocess_kernel and
+"""Kernel timelines of bench steps in a rocprofv3 kernel trace (`*_kernel_trace.csv`): every kernel between one preprocess kernel and
 the next, with start offsets, durations and the hardware queue in microseconds.
 
 bench.py issues, in this order: eager warm-up steps, graph warm-ups, the TIMED steps (graph replays unless --graph 0), ten eager steps for
@@ -33,7 +33,7 @@ def main(trace, out, timed_steps=10):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r.get("Queue_Id", 0) or 0)))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "ssdhip::preprocess" in r[2]]          # preprocess_kernel / preprocess3_kernel (round 5)
     if len(starts) < 2:
         raise SystemExit("no complete step in the trace")
     steps = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if any("scan_heads_kernel" in r[2] for r in rows[a:b])
