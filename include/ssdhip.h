@@ -270,6 +270,14 @@ int ssdhip_relu_bwd_bias_blocks(long long n_pixels, int C);
  * sums [n_blocks][C] like the two passes around it. */
 int ssdhip_channel_sums_nhwc_bf16(const void* gy, float* partial, long long n_pixels, int C, int n_blocks, void* stream);
 
+/* Weight gradient of the 1x1 stride-1 layers (fc7, conv6_1 ... conv9_1: models/keras_ssd300.py:296-313 under model.fit_generator; round 5) as
+ * a GEMM over the pixels: dw [Cout][Cin] float32 from x [n_pixels][Cin] and dy [n_pixels][Cout] bf16 (NHWC maps read as matrices).
+ * Cin % 128 == 0 and Cout % 128 == 0 (ssdhip_conv1x1_wgrad_workspace_bytes returns 0 otherwise: the caller falls back to the
+ * framework).  Fixed summation order (bit-reproducible); bias_partial / bias_rows / db as ssdhip_conv3x3_wgrad_bias_nhwc_bf16. */
+size_t ssdhip_conv1x1_wgrad_workspace_bytes(long long n_pixels, int Cin, int Cout);
+int ssdhip_conv1x1_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db,
+                                        long long n_pixels, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
 /* Backward of ssdhip_assemble_predictions_strided_bf16 for PACKED heads (the training step, round 5): the backward of the graph's
  * Reshape + Concatenate + softmax + Concatenate (models/keras_ssd300.py:363-419) in one launch.  grad_pred, y_pred [B, N, C+12] float32
  * (d loss / d predictions, and the predictions: the softmax probabilities are read from them); grad_heads[l]: the gradient of source map

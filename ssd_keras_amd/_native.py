@@ -878,6 +878,42 @@ def conv3x3_wgrad(x, dy, bias_partial=None):
     return dw.permute(0, 3, 1, 2)
 
 
+def conv1x1_wgrad(x, dy, bias_partial=None):
+    """Weight gradient of a 1x1 stride-1 convolution as a pixel-contraction GEMM (csrc/ssdhip_wgrad.hip, conv1x1_wgrad_kernel):
+    x (B, Cin, H, W), dy (B, Cout, H, W) bfloat16 channels_last -> float32 (Cout, Cin, 1, 1), or None when the channel counts are not
+    multiples of 128 (the caller falls back to the framework).  bias_partial as in `conv3x3_wgrad`: the result is then (dw, db)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_wgrad1_bound", False):
+        lib.ssdhip_conv1x1_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        lib.ssdhip_conv1x1_wgrad_workspace_bytes.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+        lib.ssdhip_conv1x1_wgrad_bias_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv1x1_wgrad_bias_nhwc_bf16.argtypes = ([ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])
+        lib._wgrad1_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    dy, (b2, h2, w2, cout) = _nhwc_bf16(dy, "dy")
+    if (b2, h2, w2) != (b, h, w):
+        raise SsdHipError("x and dy must cover the same pixels")
+    need = int(lib.ssdhip_conv1x1_wgrad_workspace_bytes(b * h * w, cin, cout))
+    if need == 0:
+        return None
+    ws = workspaces.get(x.device, "wgrad", need)
+    dw = torch.empty((cout, 1, 1, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)     # channels_last strides, like the 3 x 3 form
+    db = None
+    rows = 0
+    if bias_partial is not None:
+        if (bias_partial.dtype != torch.float32 or bias_partial.dim() != 2 or bias_partial.shape[1] != cout or not bias_partial.is_contiguous()):
+            raise SsdHipError("bias_partial must be a contiguous float32 [rows, Cout] tensor")
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        rows = int(bias_partial.shape[0])
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv1x1_wgrad_bias_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(bias_partial), rows, _ptr(db), b * h * w, cin, cout,
+                                                     _ptr(ws), need, current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv1x1_wgrad_bias_nhwc_bf16")
+    return (dw, db) if bias_partial is not None else dw
+
+
 def conv3x3_halo_group(xs, weights, biases=None, relu=False, max_workgroups=0):
     """Several independent 3x3 'same' convolutions through the slab kernel in ONE launch (persistent workgroups, deepest problem
     first): the packed predictor heads.  xs[i] (B, Cin_i, H_i, W_i) bf16 NHWC memory, weights[i] (Cout_i, Cin_i, 3, 3) bf16

@@ -381,6 +381,104 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restr
     }
 }
 
+// ======================================================================================
+// Weight gradient of the 1 x 1 layers (fc7, conv6_1 ... conv9_1; round 5): dW[co][ci] = sum over pixels of dY[p][co] X[p][ci], a GEMM
+// whose K dimension -- the pixels -- is the slow index of BOTH NHWC operands.  A workgroup owns a 128 x 128 tile of dW over a range of
+// pixels: per step 64 pixels of dY and of X are loaded as 16-byte rows (eight loads in flight per thread, requested a step ahead), laid
+// into LDS TRANSPOSED ([channel][pixel]: a thread holds two neighbouring pixels of 8 channels and stores them side by side, so that an
+// MFMA lane's eight consecutive K values are one 16-byte read), and four waves (2 x 2 halves of the tile, four 32 x 32 accumulators
+// each) run 16 v_mfma_f32_32x32x16_bf16 per step.  Split over the pixels so that ~256-512 workgroups exist; the float32 partial tiles
+// are added in slot order by wgrad_reduce_kernel (bit-reproducible), which also adds the layer's bias partials.
+// ======================================================================================
+struct Wg1Params {
+    const bf16_t* x;             // [P][Cin]
+    const bf16_t* dy;            // [P][Cout]
+    float* part;                 // [slots][Cout][Cin]
+    int P, Cin, Cout, n_ci_tiles, n_tiles, steps_per_split, n_steps;
+};
+constexpr int WG1_PITCH = 144;   // bytes per LDS row: 64 pixels + padding, 16-byte aligned
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(Wg1Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char aT[128 * WG1_PITCH];   // dY tile [co][pixel]
+    __shared__ __attribute__((aligned(16))) unsigned char bT[128 * WG1_PITCH];   // X tile  [ci][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x % p.n_tiles, split = blockIdx.x / p.n_tiles;
+    const int co0 = (tile / p.n_ci_tiles) * 128, ci0 = (tile % p.n_ci_tiles) * 128;
+    const int s0 = split * p.steps_per_split, s1 = min(p.n_steps, s0 + p.steps_per_split);
+    const int cg = tid & 15, pp0 = tid >> 4;                 // 8 channels x the pixel pairs pp0 and pp0 + 16
+    const int cohalf = wave & 1, cihalf = wave >> 1;
+    wg_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    wg_u32x4 ra[4], rb[4];                                   // [unit u][pixel e]: unit u = pair pp0 + 16 u
+    auto request = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const long long px = (long long)step * 64 + 2 * (pp0 + 16 * u) + e;
+                const bool ok = px < p.P;
+                ra[2 * u + e] = ok ? *reinterpret_cast<const wg_u32x4*>(p.dy + px * p.Cout + co0 + cg * 8) : wg_u32x4{0u, 0u, 0u, 0u};
+                rb[2 * u + e] = ok ? *reinterpret_cast<const wg_u32x4*>(p.x + px * p.Cin + ci0 + cg * 8) : wg_u32x4{0u, 0u, 0u, 0u};
+            }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pp = pp0 + 16 * u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                    // channels cg 8 + 2 q and + 1: the pair's two pixels side by side in one word
+                const u32 a0 = ra[2 * u][q], a1 = ra[2 * u + 1][q], b0 = rb[2 * u][q], b1 = rb[2 * u + 1][q];
+                // the 16-byte chunk (8 pixels) of a row sits at chunk ^ (row / 8 & 7): rows 8 apart -- the sixteen channel groups of a
+                // store instruction -- would otherwise all hit one bank (row pitch 36 words: 8 rows = 288 words = 0 mod 32)
+                const int at = ((((pp >> 2) ^ (cg & 7)) << 2) | (pp & 3)) * 4;
+                *reinterpret_cast<u32*>(aT + (cg * 8 + 2 * q) * WG1_PITCH + at) = (a0 & 0xffffu) | (a1 << 16);
+                *reinterpret_cast<u32*>(aT + (cg * 8 + 2 * q + 1) * WG1_PITCH + at) = (a0 >> 16) | (a1 & 0xffff0000u);
+                *reinterpret_cast<u32*>(bT + (cg * 8 + 2 * q) * WG1_PITCH + at) = (b0 & 0xffffu) | (b1 << 16);
+                *reinterpret_cast<u32*>(bT + (cg * 8 + 2 * q + 1) * WG1_PITCH + at) = (b0 >> 16) | (b1 & 0xffff0000u);
+            }
+        }
+    };
+    if (s0 < s1) request(s0);
+    for (int step = s0; step < s1; ++step) {
+        stage();
+        __syncthreads();
+        if (step + 1 < s1) request(step + 1);                // in flight under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = 2 * ks + (lane >> 5);           // pixels 8 chunk .. + 7
+            wg_bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra_ = cohalf * 64 + i * 32 + (lane & 31), rb_ = cihalf * 64 + i * 32 + (lane & 31);
+                fa[i] = *reinterpret_cast<const wg_bf16x8*>(aT + ra_ * WG1_PITCH + ((chunk ^ ((ra_ >> 3) & 7)) << 4));
+                fb[i] = *reinterpret_cast<const wg_bf16x8*>(bT + rb_ * WG1_PITCH + ((chunk ^ ((rb_ >> 3) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                      // the next step's stage() overwrites the tiles
+    }
+    // D row (co) = (v & 3) + 8 (v >> 2) + 4 (lane >> 5), column (ci) = lane & 31
+    float* out = p.part + (size_t)split * p.Cout * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int co = co0 + cohalf * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                const int ci = ci0 + cihalf * 64 + j * 32 + (lane & 31);
+                out[(size_t)co * p.Cin + ci] = acc[i][j][v];
+            }
+}
+
 struct WgPlan {
     int cos, splits, slots, n_tiles, n_ci_tiles, n_blocks, blocks_per_split, HB;
     long long Q;
@@ -474,4 +572,49 @@ extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy
 extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
                                               size_t ws_bytes, void* stream) {
     return ssdhip_conv3x3_wgrad_bias_nhwc_bf16(x, dy, dw, nullptr, 0, nullptr, B, H, W, Cin, Cout, ws, ws_bytes, stream);
+}
+
+// Weight gradient (and, with bias_partial, the bias gradient) of a 1 x 1 stride-1 convolution (fc7, conv6_1 ... conv9_1 of
+// models/keras_ssd300.py:296-313): dw [Cout][Cin] float32 from x [P][Cin], dy [P][Cout] bf16 (P = B H W pixels).  Cin % 128 == 0,
+// Cout % 128 == 0.  Bit-reproducible (fixed summation order).  bias_partial / bias_rows / db as ssdhip_conv3x3_wgrad_bias_nhwc_bf16.
+static bool wg1_plan(long long P, int Cin, int Cout, int& splits, int& steps_per_split, int& n_steps) {
+    if (P <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 128) || (Cout % 128)) return false;
+    if (P * Cin * 2 >= 0x7ffff000LL || P * Cout * 2 >= 0x7ffff000LL) return false;
+    n_steps = (int)((P + 63) / 64);
+    const int tiles = (Cout / 128) * (Cin / 128);
+    int s = 512 / tiles;
+    if (s < 1) s = 1;
+    if (s > n_steps) s = n_steps;
+    while (s > 1 && (n_steps + s - 1) / s < 4) --s;                           // at least four steps per workgroup
+    steps_per_split = (n_steps + s - 1) / s;
+    splits = (n_steps + steps_per_split - 1) / steps_per_split;
+    return true;
+}
+
+extern "C" size_t ssdhip_conv1x1_wgrad_workspace_bytes(long long n_pixels, int Cin, int Cout) {
+    int s, sp, ns;
+    return wg1_plan(n_pixels, Cin, Cout, s, sp, ns) ? (size_t)s * Cout * Cin * sizeof(float) : 0;
+}
+
+extern "C" int ssdhip_conv1x1_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db,
+                                                   long long n_pixels, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int splits, sps, n_steps;
+    if (!x || !dy || !dw || !wg1_plan(n_pixels, Cin, Cout, splits, sps, n_steps)) return SSDHIP_E_BADARG;
+    if (bias_partial && (!db || bias_rows <= 0 || (((uintptr_t)bias_partial | (uintptr_t)db) & 15))) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) return SSDHIP_E_BADARG;
+    if (!ws || ws_bytes < (size_t)splits * Cout * Cin * sizeof(float) || ((uintptr_t)ws & 15)) return SSDHIP_E_WORKSPACE;
+    Wg1Params p;
+    p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.part = static_cast<float*>(ws);
+    p.P = (int)n_pixels; p.Cin = Cin; p.Cout = Cout;
+    p.n_ci_tiles = Cin / 128; p.n_tiles = (Cout / 128) * p.n_ci_tiles; p.steps_per_split = sps; p.n_steps = n_steps;
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(splits * p.n_tiles), dim3(256), 0, stream, p);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    const int n4 = Cout * Cin / 4;
+    int rb = (n4 + 255) / 256;
+    if (rb > 2048) rb = 2048;
+    const int bC4 = bias_partial ? Cout / 4 : 0, rb2 = (bC4 + 7) / 8;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + rb2), dim3(256), 0, stream, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw),
+                       n4, splits, rb, reinterpret_cast<const float4*>(bias_partial), reinterpret_cast<float4*>(db), bC4, bias_rows);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

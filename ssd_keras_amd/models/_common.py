@@ -165,6 +165,15 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
                 gw, gb = got
             else:
                 gw = got
+    if (gw is None and k == 1 and stride == (1, 1) and padding == (0, 0) and gy.is_cuda and xb.shape[1] % 128 == 0 and gy.shape[1] % 128 == 0
+            and os.environ.get("SSDHIP_NO_OWN_WGRAD", "0") != "1"):
+        # the 1 x 1 layers (fc7, conv6_1 ... conv9_1): the weight gradient is a GEMM over the pixels (csrc/ssdhip_wgrad.hip,
+        # conv1x1_wgrad_kernel; float32, fixed summation order), the bias partials ride in its reduction launch
+        got = nat.conv1x1_wgrad(xb, gy, bias_partial=bias_partial)
+        if got is not None and bias_partial is not None:
+            gw, gb = got
+        else:
+            gw = got
     masks = [need_x and gx is None, gw is None, False]
     if masks[0] or masks[1]:
         gx_m, gw_m, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, list(stride), list(padding), list(dilation), False, [0, 0],

@@ -36,6 +36,12 @@ class SGD(torch.optim.Optimizer):
     def _dense(t):
         return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
+    @staticmethod
+    def _same_order(g, p):
+        """The two tensors walk memory in the same order: equal strides on every dimension that has more than one entry (a 1 x 1 filter
+        is the same memory contiguous or channels_last; only the stride METADATA of its size-1 dimensions differs)."""
+        return tuple(g.shape) == tuple(p.shape) and all(a == b for a, b, n in zip(g.stride(), p.stride(), p.shape) if n != 1)
+
     def _plan(self, gi, group):
         """Which parameters of a group take the fused launch, and its device tables: rebuilt only when a gradient tensor moved (the
         tables hold raw pointers).  Everything per-parameter that can be decided once is decided here: the step itself is host-bound
@@ -47,7 +53,7 @@ class SGD(torch.optim.Optimizer):
             if g is None:
                 continue
             ok = (mom != 0.0 and p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse
-                  and self._dense(p) and tuple(g.stride()) == tuple(p.stride()) and p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0)
+                  and self._dense(p) and self._same_order(g, p) and p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0)
             if ok:
                 fused.setdefault(p.device, []).append(p)
             else:

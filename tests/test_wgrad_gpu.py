@@ -142,3 +142,25 @@ def test_weight_gradient_launch_also_finishes_the_bias_gradient(shape):
     assert torch.equal(db, nat.conv3x3_wgrad(x, masked, bias_partial=partial)[1])
     plain = nat.channel_sums_partial(gy)                                  # no activation: the predictor heads' form
     torch.testing.assert_close(plain.sum(dim=0), gy.float().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", [(32, 19, 19, 1024, 1024), (32, 19, 19, 1024, 256), (32, 10, 10, 512, 128), (2, 3, 3, 256, 128), (1, 1, 1, 128, 128)])
+def test_1x1_weight_gradient_as_a_gemm_over_the_pixels(case):
+    """csrc/ssdhip_wgrad.hip, conv1x1_wgrad_kernel (fc7, conv6_1 ... conv9_1) against the float64 weight gradient of the same bf16
+    tensors, with the bias partials riding in the reduction launch; bit-reproducible run to run; channel counts off 128 -> None."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    b, h, w, cin, cout = case
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x = torch.randn((b, cin, h, w), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((b, cout, h, w), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    part = nat.channel_sums_partial(dy)
+    gw, gb = nat.conv1x1_wgrad(x, dy, bias_partial=part)
+    want = torch.einsum("bohw,bihw->oi", dy.double(), x.double())
+    assert gw.shape == (cout, cin, 1, 1) and gw.dtype == torch.float32
+    scale = float(want.abs().max().clamp_min(1e-6))
+    assert float((gw.view(cout, cin).double() - want).abs().max()) <= 1e-3 * scale
+    assert torch.allclose(gb.double(), dy.double().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    gw2, gb2 = nat.conv1x1_wgrad(x, dy, bias_partial=part)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    assert nat.conv1x1_wgrad(x[:, :64], dy) is None
