@@ -911,8 +911,9 @@ class SSDModel(nn.Module):
             return self.decoder(pred) if (decode and self.decoder is not None) else pred
         import os
         if (torch.is_grad_enabled() and not decode and os.environ.get("SSDHIP_NO_TRAIN_ASSEMBLY", "0") != "1" and len(feats) <= 8
-                and self.n_classes <= 1024 and all(self._packed_train_head_ok(f, ch, lh) for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads))):
-            # every source map's heads are one packed libssdhip node: the assembly and its backward are one launch each
+                and self.n_classes <= 40 and all(self._packed_train_head_ok(f, ch, lh) for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads))):
+            # every source map's heads are one packed libssdhip node: the assembly and its backward are one launch each (the backward
+            # kernel stages two 128-anchor row tiles in 64 KB of LDS: up to 40 classes; COCO's 81 keep the framework expression below)
             ys = []
             for l, (f, ch, lh) in enumerate(zip(feats, self.conf_heads, self.loc_heads)):
                 pw, pb, pwt, _nc, _nl = self._packed_head_shadow(l)
