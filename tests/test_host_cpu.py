@@ -343,3 +343,21 @@ def test_all_core_cpu_baseline_helper_runs_and_agrees_with_the_port():
     want = sum(r.shape[0] for r in orc.decode_detections(y, **kw) if r.size)
     assert res["images"] == 3 and res["detections"] == want and res["value"] > 0 and 1 <= res["cores"] <= 3
     assert "error" in bx.cpu_decode_all_cores(y, dict(kw, no_such_argument=1), timeout_s=120)
+
+
+def test_fused_sgd_accepts_gradients_that_walk_memory_like_their_parameter():
+    """ssd_keras_amd.optimizers.SGD takes a gradient into its one-launch update when it has its parameter's memory order: strides are
+    compared only on dimensions with more than one entry -- a 1 x 1 filter is the same memory contiguous or channels_last, and a
+    float32 gradient that came with the other stride metadata (csrc/ssdhip_wgrad.hip's 1 x 1 form, round 5) used to fall out of the fused
+    launch into the framework's per-tensor arithmetic."""
+    import torch
+    from ssd_keras_amd.optimizers import SGD
+    p = torch.zeros((8, 1, 1, 4)).permute(0, 3, 1, 2)                                     # strides (4, 1, 4, 4): channels_last metadata
+    g = torch.zeros((8, 4, 1, 1))                                                         # strides (4, 1, 1, 1)
+    assert p.stride() != g.stride() and SGD._same_order(g, p) and SGD._same_order(p, g)
+    q = torch.zeros((8, 4, 3, 3)).contiguous(memory_format=torch.channels_last)
+    assert SGD._same_order(q.clone(memory_format=torch.preserve_format), q)
+    assert not SGD._same_order(torch.zeros((8, 4, 3, 3)), q)                              # a real layout difference
+    assert not SGD._same_order(torch.zeros((8, 4, 1, 2)), p)                              # another shape
+    b = torch.zeros((7,))
+    assert SGD._same_order(b.clone(), b)
