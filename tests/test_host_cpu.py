@@ -361,3 +361,28 @@ def test_fused_sgd_accepts_gradients_that_walk_memory_like_their_parameter():
     assert not SGD._same_order(torch.zeros((8, 4, 1, 2)), p)                              # another shape
     b = torch.zeros((7,))
     assert SGD._same_order(b.clone(), b)
+
+
+def test_step_timeline_tool_finds_steps_by_either_preprocess_kernel(tmp_path):
+    """tools/step_timeline.py delimits a bench step by the input-pipeline kernel: `preprocess_kernel` or, since round 5 (four pixels per
+    thread), `preprocess3_kernel` -- the tool missed every step of the first trace taken after the rename."""
+    import csv
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import step_timeline
+    rows, t = [], 1000
+    for step in range(12):
+        for name in ("void ssdhip::preprocess3_kernel(float4 const*)", "ssdhip::conv64_kernel<4>(ssdhip::C64Params)",
+                     "ssdhip::scan_heads_kernel(ssdhip::HeadParams)", "ssdhip::nms_kernel<2, 512, false>(ssdhip::DecodeParams)"):
+            rows.append({"Start_Timestamp": t, "End_Timestamp": t + 500, "Kernel_Name": name, "Queue_Id": 1})
+            t += 600
+    trace = tmp_path / "trace.csv"
+    with open(trace, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    out = tmp_path / "out.json"
+    step_timeline.main(str(trace), str(out))
+    got = json.load(open(out))
+    assert got["launches"] == 4 and "headline_eager" in got and "headline_timed" in got
