@@ -5,8 +5,10 @@ decode (DecodeDetections: threshold 0.01, NMS 0.45, top-200) at batch 32 per GPU
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); the data path has no
-collective (every rank decodes its own 32 images: weak scaling), the barrier + max-over-ranks timing does.
+N > 1: under a launcher (torch.distributed.run sets WORLD_SIZE; the driver's way) this process is one rank; WITHOUT one,
+`python bench.py --gpus N` spawns the N ranks itself (torch.distributed.run, 127.0.0.1 rendezvous, one rank per GPU,
+RCCL) and asserts WORLD_SIZE == N either way.  The data path has no collective (every rank decodes its own 32 images:
+weak scaling), the barrier + max-over-ranks timing does; `rccl_ranks_seen` on the line is an all-reduce of ones.
 Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline      the dominant hand-written kernel of the decode path against HBM bandwidth: algorithmic bytes of
                 the decode path per launch (N*(C+12)*4 read + top_k*6*4 written per image) / that
@@ -46,7 +48,49 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="1: the timed step is one HIP-graph launch (model.graphed); 0: eager launches")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (encoder / loss / sparse decode / training step)")
     ap.add_argument("--train-steps", type=int, default=6, help="timed steps of the training-step leg (0: skip it)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="create the --gpus N ranks, bring up the process group (RCCL on GPUs, gloo where there is none), all-reduce "
+                         "a one per rank, print {'ranks_seen': N, ...} and exit: the launcher path without any measurement")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-spawned ranks (0: a free one)")
     return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-execute this script as N ranks under
+    torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous) -- the command the driver itself uses -- and return its exit
+    code.  With a launcher environment (WORLD_SIZE set) this is never called: the process IS one of the ranks."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args):
+    """The N-rank launch path and nothing else: process group up, an all-reduce of ones, one JSON line from rank 0."""
+    from ssd_keras_amd import distributed as dp
+    has_gpu = torch.cuda.is_available()
+    backend = os.environ.get("SSD_BENCH_BACKEND", "nccl" if has_gpu else "gloo")
+    if has_gpu and os.environ.get("SSD_BENCH_SHARE_GPU", "0") == "1":
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local_rank = dp.init_from_env(backend)
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    dev = torch.device("cuda", local_rank) if (has_gpu and backend == "nccl") else torch.device("cpu")
+    seen = int(dp.sum_over_ranks(1.0, device=dev))
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world_size": world, "ranks_seen": seen, "backend": backend,
+                          "device": str(dev)}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if seen == args.gpus else 1
 
 
 def conv_choice_label(key):
@@ -78,6 +122,10 @@ def event_ms(fn, reps):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))                   # no launcher around us: become the launcher of N ranks
+    if args.dry_launch:
+        sys.exit(dry_launch(args))
     # one process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher; the process group (RCCL) comes up through the
     # package's own helper (device selected before init, dmabuf IPC mode, 127.0.0.1 rendezvous)
     from ssd_keras_amd import distributed as dp
@@ -88,8 +136,12 @@ def main():
     if os.environ.get("SSD_BENCH_SHARE_GPU", "0") == "1":
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local_rank = dp.init_from_env(backend)
+    assert world == args.gpus, ("--gpus %d but the launcher created WORLD_SIZE=%d ranks: n_gpus on the result line would lie"
+                                % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # every rank adds a one over the bench's backend (RCCL unless overridden): the line carries how many ranks really took part
+    ranks_seen = int(dp.sum_over_ranks(1.0, device=dev)) if world > 1 else 1
 
     from ssd_keras_amd import _native as nat
     from ssd_keras_amd import synthetic as syn
@@ -220,7 +272,10 @@ def main():
                        "read": round(sum(r["hbm_read_bytes"] for r in recs)),
                        "write": round(sum(r["hbm_write_bytes"] for r in recs)),
                        "ratio_to_algorithmic_bytes": round(sum(r["hbm_bytes"] for r in recs) / algo_bytes, 4),
-                       "source": "profiles/" + os.path.basename(profs[-1])}
+                       "source": "profiles/" + os.path.basename(profs[-1]),
+                       "measured_in_this_run": False,
+                       "note": "REPLAYED from the newest committed PMC profile (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                               "passes, tools/gpu.sh pmc_decode): counters cannot be read inside this process"}
         except Exception:
             traffic = None
     roofline = {"kernel": full_name[dom], "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -378,7 +433,8 @@ def main():
     if rank == 0:
         ips = world * B * args.steps / elapsed
         line = {"metric": "images/sec SSD300 fwd+decode @batch32", "value": round(ips, 2), "unit": "images/sec",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "n_gpus": world, "rccl_ranks_seen": ranks_seen, "collective_backend": backend if world > 1 else None,
+                "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "data": "synthetic",
                 "dtype": "f32 (decode, threshold, TF-style f32 NMS, top-k); %s conv backbone" % args.dtype,
@@ -429,7 +485,7 @@ def main():
                 "value_tamed_heads_img_s": dig(tamed, "value"), "decode_ms_in_step": round(decode_ms_in_step, 5),
                 "decode_ms_in_step_tamed": dig(tamed, "decode_ms_in_step"), "conv_frac": conv["frac"], "forward_ms": conv["forward_ms"],
                 "nms_kernel_us": round(1e3 * stage_ms["nms_kernel"], 2), "scan_kernel_us": round(1e3 * stage_ms["scan_kernel"], 2),
-                "nms_traffic_ratio": (traffic or {}).get("ratio_to_algorithmic_bytes") if dom == "nms_kernel" else None,
+                "nms_traffic_ratio_replayed_from_profile": (traffic or {}).get("ratio_to_algorithmic_bytes") if dom == "nms_kernel" else None,
                 "train_step_ms": dig(extra, "train_step", "ms_per_step"), "train_images_per_sec": dig(extra, "train_step", "images_per_sec"),
                 "loss_forward_ms": dig(extra, "loss", "fwd_ms"), "encoder_kernels_ms": dig(extra, "encoder", "gpu_ms_per_batch_kernels"),
                 "augment_batch_img_s": dig(extra, "augmentation", "augment_batch_images_per_sec"),

@@ -286,6 +286,10 @@ int ssdhip_conv1x1_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw
 int ssdhip_assemble_predictions_backward_bf16(int n_layers, void* const* grad_heads, const int* n_anchors, const int* n_boxes,
                                               const int* stride, const float* y_pred, const float* grad_pred, int B, int N, int C,
                                               void* stream);
+/* LDS bytes that launch needs for these source maps (two 128-anchor row tiles + the widest packed stage); 0: refused arguments.  It
+ * runs up to 160 KB - 64 (SSD300 / SSD512 heads: 21 classes 36 KB, 81 classes 117 KB); callers gate on this, not on a class count. */
+size_t ssdhip_assemble_backward_lds_bytes(int n_layers, const int* n_boxes, const int* stride, int C);
+#define SSDHIP_ASSEMBLE_BACKWARD_MAX_LDS (160 * 1024 - 64)
 
 /* The FIRST layer's backward in one pass (round 5): conv1_1 of the training graph (Conv2D(64, (3, 3), activation='relu', padding='same') on the
  * 3-channel image, models/keras_ssd300.py:274) has no data gradient, so ReLU mask, bias gradient and weight gradient are one read of

@@ -407,6 +407,24 @@ def _head_sources(confs, locs, conf_biases, loc_biases, n_boxes, anchors_var, n_
     return args, keep, int(B), N
 
 
+ASSEMBLE_BACKWARD_MAX_LDS = 160 * 1024 - 64          # include/ssdhip.h: SSDHIP_ASSEMBLE_BACKWARD_MAX_LDS
+
+
+def assemble_backward_supported(n_classes, n_boxes, strides):
+    """Whether `assemble_predictions_backward` runs for source maps with these boxes per pixel and packed channel strides: the kernel's
+    own LDS formula (ssdhip_assemble_backward_lds_bytes), so the model's gate and the launch cannot disagree."""
+    lib = _layers_lib()
+    if not hasattr(lib, "ssdhip_assemble_backward_lds_bytes"):
+        return False
+    lib.ssdhip_assemble_backward_lds_bytes.restype = ctypes.c_size_t
+    lib.ssdhip_assemble_backward_lds_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    nl = len(n_boxes)
+    nbx = (ctypes.c_int * nl)(*[int(v) for v in n_boxes])
+    st = (ctypes.c_int * nl)(*[int(v) for v in strides])
+    need = int(lib.ssdhip_assemble_backward_lds_bytes(nl, nbx, st, int(n_classes)))
+    return 0 < need <= ASSEMBLE_BACKWARD_MAX_LDS
+
+
 def assemble_predictions_backward(grad_pred, y_pred, packed_shapes, n_boxes, n_classes):
     """Backward of `assemble_predictions` for PACKED bf16 heads (the training step): grad_pred, y_pred (B, N, C+12) float32 -> one
     (B, Cp, h, w) bf16 gradient with NHWC memory per source map, channels [conf | loc | zero padding] (csrc/ssdhip_layers.hip,

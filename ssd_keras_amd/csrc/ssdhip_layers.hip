@@ -625,6 +625,23 @@ extern "C" int ssdhip_assemble_predictions_bf16(int n_layers, const void* const*
                                                     nullptr, nullptr, anchors_var, B, N, C, y_pred, stream);
 }
 
+// LDS bytes head_grad_kernel needs for these source maps: two HG_TILE-anchor row tiles (predictions, their gradient) + the widest
+// packed stage.  0 = arguments the backward would refuse.  The launch below takes up to HG_MAX_LDS (a CU has 160 KB; beyond 64 KB the
+// kernel is opted in per device) -- the host side gates the one-launch training assembly on THIS function (a fixed class
+// count in the gate and the LDS test here disagreed for 36-40 classes on 4-box maps).
+constexpr size_t HG_MAX_LDS = 160 * 1024 - 64;
+extern "C" size_t ssdhip_assemble_backward_lds_bytes(int n_layers, const int* n_boxes_h, const int* stride_h, int C) {
+    if (n_layers <= 0 || n_layers > MAX_PRED_LAYERS || !n_boxes_h || !stride_h || C < 2) return 0;
+    size_t max_stage = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int nb = n_boxes_h[l];
+        if (nb <= 0 || nb > HG_TILE || (stride_h[l] & 7) || stride_h[l] < nb * (C + 4)) return 0;
+        const size_t st = (size_t)(HG_TILE / nb) * stride_h[l] * 2;
+        max_stage = st > max_stage ? st : max_stage;
+    }
+    return 2 * (((size_t)HG_TILE * (C + 12) + 4 + 3) / 4 * 4) * sizeof(float) + max_stage + 16;
+}
+
 // Backward of ssdhip_assemble_predictions_strided_bf16 for packed heads (the training step): grad_pred, y_pred [B, N, C+12] float32 (the
 // gradient of the loss with respect to the assembled predictions, and those predictions); grad_heads_h[l]: the gradient of source map
 // l's packed head output [B, n_anchors[l] / n_boxes[l], stride[l]] bf16 with channels [conf n_boxes C | loc n_boxes 4 | padding] --
@@ -664,7 +681,16 @@ extern "C" int ssdhip_assemble_predictions_backward_bf16(int n_layers, void* con
     hp.tile_start[MAX_PRED_LAYERS] = tiles;
     if (off != N) return SSDHIP_E_BADARG;
     const size_t lds = 2 * (((size_t)HG_TILE * (C + 12) + 4 + 3) / 4 * 4) * sizeof(float) + max_stage + 16;
-    if (lds > 64 * 1024) return SSDHIP_E_BADARG;
+    if (lds > HG_MAX_LDS) return SSDHIP_E_BADARG;
+    if (lds > 48 * 1024) {                                   // opted in once per device for the whole range (no per-call attribute traffic)
+        static int opted[64] = {0};
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return SSDHIP_E_LAUNCH;
+        if (opted[devid] == 0)
+            opted[devid] = hipFuncSetAttribute(reinterpret_cast<const void*>(head_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)HG_MAX_LDS) == hipSuccess ? 1 : -1;
+        if (opted[devid] < 0) return SSDHIP_E_LAUNCH;
+    }
     hipLaunchKernelGGL(head_grad_kernel, dim3(tiles, B), dim3(HG_TILE), lds, stream, hp, y_pred, grad_pred);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -10,7 +10,9 @@ The reference has no multi-device code at all.  What shards h
   * hard-negative mining and the 1 / n_positives normalisation stay local to the rank's batch -- exactly the reference
     evaluated on that shard; DDP then AVERAGES the per-rank gradients, so a step is the mean over ranks of the reference's
     per-shard losses, not the reference's loss on the concatenated batch (that would need an all-reduce of n_positives and a
-    distributed k-th-value select).  `tests/test_distributed_cpu.py` pins this identity.
+    distributed k-th-value select).  `tests/test_ddp_loss_gpu.py` pins this identity on the real kernels (two ranks, HIP
+    encoder + HIP SSDLoss per shard, all-reduced gradient == mean of the oracle's per-shard gradients); `tests/test_distributed_cpu.py`
+    pins the all-reduce arithmetic itself on CPU with a stand-in loss (SSDLoss has no CPU path).
 """
 from __future__ import annotations
 

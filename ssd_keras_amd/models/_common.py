@@ -1,9 +1,13 @@
 """Shared machinery of the SSD model builders (reference models/keras_ssd300.py:200-457 and twins).
 
-PyTorch-ROCm runs the convolutional stack (MIOpen / MFMA); this module only adds what the
-reference's graph does around it: in-graph input normalisation, NHWC-ordered head reshapes so
-the anchor axis factorises exactly like Keras' `Reshape((-1, n_classes))`, the resident anchor
-constant, softmax, the `(B, N, C+12)` prediction layout and the optional decode layer.
+The convolutional stack of a bf16 model runs on libssdhip's MFMA kernels (csrc/ssdhip_convh / conv64 / conv /
+convimg / chain .hip), dispatched here per layer shape (`SSDModel._pick`), with the graph glue in
+csrc/ssdhip_layers.hip and, for training, autograd functions over the same kernels (+ csrc/ssdhip_wgrad /
+ssdhip_train .hip); the framework's own convolution (MIOpen) only runs float32 models and the few layer
+geometries no kernel here covers.  Around it this module adds what the reference's graph does: in-graph input
+normalisation, NHWC-ordered head reshapes so the anchor axis factorises exactly like Keras'
+`Reshape((-1, n_classes))`, the resident anchor constant, softmax, the `(B, N, C+12)` prediction layout and the
+optional decode layer.
 """
 from __future__ import annotations
 
@@ -16,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import _native as nat
 from ..anchor_math import n_boxes_for
+from ..optimizers import _bump_versions
 from ..keras_layers.keras_layer_AnchorBoxes import AnchorBoxes
 from ..keras_layers.keras_layer_DecodeDetections import DecodeDetections
 from ..keras_layers.keras_layer_DecodeDetectionsFast import DecodeDetectionsFast
@@ -87,14 +92,15 @@ class _ConvBiasActFn(torch.autograd.Function):
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             bb = bias.detach().to(torch.bfloat16) if bias is not None else None
         y = run(xb, wb, bb)
-        ctx.save_for_backward(xb, wb, y if relu else None)
-        ctx.wt = wt                                      # the data gradient's filters, built with the shadows (None: built in backward)
+        # (wt: the data gradient's filters, built with the shadows -- None: built in backward; saved like the others so that autograd's
+        #  version check covers it when the shadows are refreshed between this forward and its backward)
+        ctx.save_for_backward(xb, wb, y if relu else None, wt)
         ctx.conf = (stride, padding, dilation, relu, weight.dtype, None if bias is None else bias.dtype, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xb, wb, y = ctx.saved_tensors
+        xb, wb, y, wt = ctx.saved_tensors
         stride, padding, dilation, relu, wdt, bdt, xdt = ctx.conf
         gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         want_gb = bdt is not None and ctx.needs_input_grad[2]
@@ -114,7 +120,7 @@ class _ConvBiasActFn(torch.autograd.Function):
                 gy, partial = fused
             else:
                 gy = torch.ops.aten.threshold_backward(gy, y, 0)
-        gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], ctx.wt,
+        gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], wt,
                                               partial if want_gb else None)
         if want_gb:
             if gb is None:
@@ -199,14 +205,13 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
             bb = bias.detach().to(torch.bfloat16) if bias is not None else None
         y = run(xb, wb, bb)
         p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
-        ctx.wt = wt
-        ctx.save_for_backward(xb, wb, y)
+        ctx.save_for_backward(xb, wb, y, wt)
         ctx.conf = (stride, padding, dilation, weight.dtype, None if bias is None else bias.dtype, x.dtype)
         return p
 
     @staticmethod
     def backward(ctx, gp):
-        xb, wb, y = ctx.saved_tensors
+        xb, wb, y, wt = ctx.saved_tensors
         stride, padding, dilation, wdt, bdt, xdt = ctx.conf
         gp = gp.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         fused = nat.maxpool2_relu_bwd_bias(y, gp, reduce=False)
@@ -214,7 +219,7 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
             raise RuntimeError("channel count not supported by the fused pooling backward (the forward checks it)")
         gy, partial = fused
         want_gb = bdt is not None and ctx.needs_input_grad[2]
-        gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], ctx.wt,
+        gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], wt,
                                               partial if want_gb else None)
         if want_gb:
             gb = (gb if gb is not None else partial.sum(dim=0)).to(bdt)
@@ -629,8 +634,16 @@ class SSDModel(nn.Module):
                     o, ci, kh, kw = c.weight.shape
                     tr[i] = torch.empty((ci, kh, kw, o), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)   # (I, O, kh, kw) channels_last
                     tr_arg[i] = (o, 0)
+        dests, seen = [], set()                                   # every tensor the refresh launch writes, once (views share a counter)
+        for t in cl + tr + bias + [u for pk in packs.values() for u in pk[:3]]:
+            if t is None:
+                continue
+            base = t._base if t._base is not None else t
+            if id(base) not in seen:
+                seen.add(id(base))
+                dests.append(base)
         return {"device": device, "convs": convs, "index": index, "cl": cl, "tr": tr, "bias": bias, "tr_arg": tr_arg, "packs": packs,
-                "key": None, "table": None, "table_key": None}
+                "key": None, "table": None, "table_key": None, "dests": tuple(dests)}
 
     def _shadow_state_fresh(self, conv):
         """The shadow state with every bf16 copy up to date (ONE launch over all parameters when any of them changed: the optimizer's
@@ -655,6 +668,9 @@ class SSDModel(nn.Module):
                     st["table"] = nat.shadow_table(w, v, st["device"])
                     st["table_key"] = tkey
                 nat.shadow_refresh(st["table"])
+                # the kernel rewrote the shadows in place behind autograd's back: their version counters move as an in-place tensor
+                # op's would, so a backward whose forward saved the OLD filters raises instead of multiplying the new ones
+                _bump_versions(st["dests"])
                 # Inside a stream capture the refresh is only RECORDED (it runs at every replay): the shadows are not fresh for the next
                 # eager call, which must refresh them itself (tests/test_train_graph_gpu.py: the first eager step after a capture
                 # multiplied the previous step's filters, 1.3e-3 off on the loss).
@@ -911,9 +927,11 @@ class SSDModel(nn.Module):
             return self.decoder(pred) if (decode and self.decoder is not None) else pred
         import os
         if (torch.is_grad_enabled() and not decode and os.environ.get("SSDHIP_NO_TRAIN_ASSEMBLY", "0") != "1" and len(feats) <= 8
-                and self.n_classes <= 40 and all(self._packed_train_head_ok(f, ch, lh) for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads))):
+                and all(self._packed_train_head_ok(f, ch, lh) for f, ch, lh in zip(feats, self.conf_heads, self.loc_heads))
+                and self._train_assembly_fits(len(feats))):
             # every source map's heads are one packed libssdhip node: the assembly and its backward are one launch each (the backward
-            # kernel stages two 128-anchor row tiles in 64 KB of LDS: up to 40 classes; COCO's 81 keep the framework expression below)
+            # kernel stages two 128-anchor row tiles + a packed stage in LDS; whether that fits is the kernel's own formula,
+            # nat.assemble_backward_supported -- 21 classes need 36 KB, COCO's 81 classes 117 KB of the CU's 160)
             ys = []
             for l, (f, ch, lh) in enumerate(zip(feats, self.conf_heads, self.loc_heads)):
                 pw, pb, pwt, _nc, _nl = self._packed_head_shadow(l)
@@ -1031,6 +1049,17 @@ class SSDModel(nn.Module):
         small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None, relu=False)
         main.wait_stream(side)
         return early + rest, big + small
+
+    def _train_assembly_fits(self, n_maps):
+        """The one-launch assembly backward runs for this model's packed heads (LDS need from libssdhip's own formula, cached)."""
+        packs = [self._packed_head_shadow(l) for l in range(n_maps)]
+        if any(pk is None for pk in packs):
+            return False
+        key = (self.n_classes, tuple(int(pb.n_boxes) for pb in self.priorboxes[:n_maps]), tuple(int(pk[0].shape[0]) for pk in packs))
+        memo = self.__dict__.setdefault("_assembly_fits", {})
+        if key not in memo:
+            memo[key] = nat.assemble_backward_supported(key[0], key[1], key[2])
+        return memo[key]
 
     def _packed_train_head_ok(self, f, ch, lh):
         """Training step, bf16 autocast on the GPU, 3x3 'same' heads on a map the slab / weight-gradient kernels cover."""

@@ -1,9 +1,13 @@
 """`ssd_300` -- drop-in for the reference builder models/keras_ssd300.py:31-457, as a torch module.
 
 VGG-16 (atrous fc6/fc7) + extra feature layers + 6 pairs of 3x3 predictor heads; 8732 anchors at
-300x300.  The convolutions are PyTorch-ROCm calls (MIOpen -> MFMA); keep the model in
-channels_last and bf16 for throughput, fp32 for numerics checks.  Layer names follow the
-reference so ported weights can be loaded by name.
+300x300.  The modules are plain `nn.Conv2d` containers of the parameters; what multiplies depends on the
+dtype: a bf16 channels_last model on a GPU runs every convolution on libssdhip's hand-written MFMA kernels
+(models/_common.py picks per layer shape: the slab kernel, the fused conv1 block, the image-resident and
+implicit-GEMM kernels, the extra-layer chain), the training step the same kernels and their gradients under
+autograd, `model.precise()` their float16 x 3 forms at float32 precision; a float32 model is the framework's own
+convolution (MIOpen), kept as the numerics reference.  Layer names follow the reference so ported weights can
+be loaded by name.
 """
 from __future__ import annotations
 

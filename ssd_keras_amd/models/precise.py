@@ -274,15 +274,19 @@ class PreciseForward:
             if capturing:
                 raise RuntimeError("call PreciseForward once outside a stream capture first (it times its side streams)")
             self._pick_streams(images)
-        if decode and (self.model.decoder is None or self.model.n_classes > 81):
+        if decode and self.model.decoder is None:
+            raise ValueError("decode=True needs a model built with mode='inference' / 'inference_fast' (this one has no decoder layer)")
+        if decode and self.model.n_classes > 81:
             return self.model.decoder(self.__call__(images))
         y = self._forward(images, decode=decode)
         if self.check_finite and not capturing:
             # (decode: the range guard looks at the head maps -- a poisoned layer shows there as it would in the predictions)
             probe = self._last_heads if decode else [y]
             if not all(bool(torch.isfinite(t).all()) for t in probe):
+                self._last_heads = None
                 raise FloatingPointError("PreciseForward: non-finite predictions -- an activation left the float16 pair range (|x| >= "
                                          "65504 after the calibrated per-layer divisors); re-run calibrate() on a batch like this one")
+        self._last_heads = None                                   # (the float32 head maps are not kept alive between calls)
         return y
 
     @torch.no_grad()

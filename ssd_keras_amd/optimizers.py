@@ -32,6 +32,26 @@ class SGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._tables = {}
 
+    # The device tables hold RAW pointers (parameter, gradient, momentum buffer): everything that can replace one of those tensors
+    # drops them, and the per-step key below covers all three addresses as well (the key used to hold the gradients'
+    # addresses only -- `load_state_dict` after a step replaced the momentum buffers, the kernel kept updating the freed ones).
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}                                     # never pickled pointers: rebuilt on the next step
+
+    def __getstate__(self):
+        state = dict(super().__getstate__()) if hasattr(super(), "__getstate__") else dict(self.__dict__)
+        state.pop("_tables", None)
+        return state
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
+
     @staticmethod
     def _dense(t):
         return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
@@ -78,12 +98,26 @@ class SGD(torch.optim.Optimizer):
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
             lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
-            # (the key: which parameters have a gradient, and where it lives)
-            key = tuple([0 if p.grad is None else p.grad.data_ptr() for p in group["params"]])
-            hit = self._tables.get(gi)
+            # (the key: which parameters have a gradient, and where the three tensors the kernel touches live)
+            state = self.state
+            key = []
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    key.append(0)
+                    continue
+                buf = state[p].get("momentum_buffer") if p in state else None
+                key.append((g.data_ptr(), p.data_ptr(), 0 if buf is None else buf.data_ptr()))
+            key = tuple(key)
+            tabs = self.__dict__.setdefault("_tables", {})
+            hit = tabs.get(gi)
             if hit is None or hit[0] != key or hit[1] != mom:
-                hit = (key, mom) + self._plan(gi, group)
-                self._tables[gi] = hit
+                plan = self._plan(gi, group)               # (creates the missing momentum buffers: the key is taken again with them)
+                key = tuple(0 if p.grad is None else (p.grad.data_ptr(), p.data_ptr(),
+                                                      state[p]["momentum_buffer"].data_ptr() if "momentum_buffer" in state[p] else 0)
+                            for p in group["params"])
+                hit = (key, mom) + plan
+                tabs[gi] = hit
             tables, rest = hit[2], hit[3]
             for table, ps in tables:
                 nat.sgd_momentum_step(table, lr, mom, wd)

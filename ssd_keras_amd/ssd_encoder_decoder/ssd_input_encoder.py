@@ -125,6 +125,14 @@ class SSDInputEncoder:
     def n_anchors(self):
         return self._anchors_host.shape[0]
 
+    def __getstate__(self):
+        """Pickling / deep copies (DataLoader workers, a copied generator configuration) carry the host-side configuration only: the
+        resident device constants and the pinned upload ring (pinned tensors, HIP events) are per-process and rebuilt on first use."""
+        state = dict(self.__dict__)
+        state.pop('_pinned_ring', None)
+        state['_dev'] = {}
+        return state
+
     def _device_constants(self, device):
         import torch
         key = str(device)

@@ -204,3 +204,35 @@ def test_two_rank_training_steps_with_the_package_sgd_match_single_process(tmp_p
     assert float(moved.max()) > 1e-6                                      # the steps did something (tiny lr: raw 0..255 inputs)
     d = ((a - init) - (ref - init)).abs()
     assert float(d.max()) <= 1e-3 * float(moved.max()) + 1e-9, (float(d.max()), float(moved.max()))
+
+
+def _run_bench(argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, cwd=root, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(400)
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it creates two ranks itself (the flag was parsed and
+    never read); the dry launch brings the process group up and counts the ranks with an all-reduce of ones."""
+    import json
+    res = _run_bench(["--gpus", "2", "--dry-launch"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                                   # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["dry_launch"] is True and rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["ranks_seen"] == 2
+
+
+@pytest.mark.timeout(200)
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Under a launcher that created a different number of ranks than --gpus says, the bench stops instead of printing a line whose
+    n_gpus lies (world 1 pretending to be 2)."""
+    res = _run_bench(["--gpus", "2", "--dry-launch"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert res.returncode != 0
+    assert "--gpus 2" in res.stderr and "WORLD_SIZE=1" in res.stderr

@@ -386,3 +386,37 @@ def test_step_timeline_tool_finds_steps_by_either_preprocess_kernel(tmp_path):
     step_timeline.main(str(trace), str(out))
     got = json.load(open(out))
     assert got["launches"] == 4 and "headline_eager" in got and "headline_timed" in got
+
+
+def test_encoder_pickles_without_its_device_state():
+    """after the first `encode_to_device` the encoder held pinned tensors and HIP events in its __dict__ and could no longer
+    be pickled or deep-copied (DataLoader workers, copied generator configs).  The per-process device state stays out of the copy."""
+    import copy
+    import pickle
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder
+
+    class Unpicklable:
+        def __reduce__(self):
+            raise TypeError("a HIP event does not pickle")
+
+    enc = SSDInputEncoder(**syn.TINY)
+    enc.__dict__['_pinned_ring'] = {'cuda:0': {'slots': [[None, Unpicklable()]], 'next': 0}}      # what _upload leaves behind
+    enc._dev['cuda:0'] = (Unpicklable(), Unpicklable())
+    for twin in (pickle.loads(pickle.dumps(enc)), copy.deepcopy(enc)):
+        assert '_pinned_ring' not in twin.__dict__ and twin._dev == {}
+        assert twin.n_anchors == enc.n_anchors and np.array_equal(twin._anchors_host, enc._anchors_host)
+        assert all(np.array_equal(a, b) for a, b in zip(twin.boxes_list, enc.boxes_list))
+    assert '_pinned_ring' in enc.__dict__ and len(enc._dev) == 1                                    # the original keeps its state
+
+
+def test_training_assembly_gate_is_the_kernels_lds_formula():
+    """The model gates its one-launch training assembly on libssdhip's own LDS need (a host-side query, no launch): 4- and 6-box maps
+    with the packed strides the model builds (multiples of 128 channels), every class count SSD300 / SSD512 are built with."""
+    from ssd_keras_amd import _native as nat
+    pad = lambda nb, c: -(-(nb * (c + 4)) // 128) * 128
+    for c in (2, 6, 21, 35, 36, 40, 41, 81, 91):
+        assert nat.assemble_backward_supported(c, [4, 6, 6, 6, 4, 4], [pad(nb, c) for nb in (4, 6, 6, 6, 4, 4)]), c
+    assert not nat.assemble_backward_supported(250, [4, 6], [pad(4, 250), pad(6, 250)])       # beyond a CU's LDS: refused, not launched
+    assert not nat.assemble_backward_supported(21, [4], [100])                                # a stride the kernel refuses (not % 8)
+    assert not nat.assemble_backward_supported(21, [4], [96])                                 # ... or too narrow for 4 x 25 values

@@ -42,9 +42,12 @@ def _compare(y_true, y_pred, **kw):
         thr = stats[3]
         assert np.all(np.abs(parts["neg_all"][diff] - thr) <= 4e-7 * max(1.0, abs(thr))), "keep mask differs away from the cut"
         assert diff.sum() <= 4
-    else:
-        g_want = orc.ssd_loss_grad(y_true, y_pred, w, **kw)
-        np.testing.assert_allclose(grad, g_want, rtol=1e-4, atol=1e-6)
+    # an anchor's gradient row depends on its own keep bit and the item's n_positive only: compared on EVERY anchor whose mask
+    # agrees (all of them unless a knife-edge element flipped; VERDICT r5 weak 10 -- the comparison used to be skipped then)
+    g_want = orc.ssd_loss_grad(y_true, y_pred, w, **kw)
+    same = ~diff
+    assert same.sum() >= diff.size - 4
+    np.testing.assert_allclose(grad[same], g_want[same], rtol=1e-4, atol=1e-6)
     assert np.all(grad[:, :, -8:] == 0)
     return loss, stats
 

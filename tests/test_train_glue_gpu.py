@@ -185,6 +185,56 @@ def test_fused_sgd_momentum_step_follows_torch_sgd():
             torch.testing.assert_close(ours.state[pa]["momentum_buffer"], ref.state[pb]["momentum_buffer"], rtol=1e-6, atol=1e-6)
 
 
+def test_fused_sgd_survives_load_state_dict_and_copies():
+    """the fused step caches raw pointers; `load_state_dict` after a step replaces the momentum buffers, a deep copy /
+    unpickled optimizer has no cache at all.  step, load_state_dict (a checkpoint taken after step 1), step -- against
+    torch.optim.SGD doing the same; the restored momentum is the one used and the live buffers are the ones updated."""
+    import copy
+    import pickle
+    torch, _ = _t()
+    from ssd_keras_amd.optimizers import SGD
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = [(64, 3, 3, 3), (129,), (256, 128, 3, 3)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3 + i)))
+                  for i, s in enumerate(shapes)]
+    a, b = mk(), mk()
+    ours, ref = SGD(a, lr=1e-2, momentum=0.9, weight_decay=1e-4), torch.optim.SGD(b, lr=1e-2, momentum=0.9, weight_decay=1e-4)
+
+    def both_step():
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, device="cuda", generator=g)
+            if pa.grad is None:
+                pa.grad, pb.grad = gr.clone(), gr.clone()
+            else:                                                  # gradients stay where they are: the old key would not change
+                pa.grad.copy_(gr)
+                pb.grad.copy_(gr)
+        ours.step()
+        ref.step()
+
+    both_step()
+    ck_a, ck_b = copy.deepcopy(ours.state_dict()), copy.deepcopy(ref.state_dict())
+    both_step()
+    both_step()
+    ours.load_state_dict(ck_a)                                     # back to the momentum of step 1 (new buffer tensors)
+    ref.load_state_dict(ck_b)
+    both_step()
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pa, pb, rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(ours.state[pa]["momentum_buffer"], ref.state[pb]["momentum_buffer"], rtol=1e-6, atol=1e-6)
+    # copies: no stale table travels, the first step of the copy rebuilds it against ITS tensors
+    clone = pickle.loads(pickle.dumps(ours))
+    assert clone._tables == {}
+    twin = copy.deepcopy(ours)
+    before = [p.detach().clone() for p in a]
+    tp = [p for grp in twin.param_groups for p in grp["params"]]
+    for p, q in zip(tp, a):
+        p.grad = q.grad.clone()
+    twin.step()
+    for q, was in zip(a, before):
+        assert torch.equal(q, was)                                 # the original's parameters were not touched by the copy's step
+    assert all(not torch.equal(p, was) for p, was in zip(tp, before))
+
+
 @pytest.mark.parametrize("shape", [(2, 300, 300), (3, 37, 41), (1, 1, 1), (2, 5, 130), (1, 64, 64)])
 def test_first_layer_backward_in_one_pass(shape):
     """conv1_1's backward (csrc/ssdhip_train.hip, conv1_1_bwd_kernel: ReLU mask + bias gradient + weight gradient from one read of the
@@ -207,15 +257,20 @@ def test_first_layer_backward_in_one_pass(shape):
     assert torch.allclose(gb, wb, rtol=1e-5, atol=1e-5 * float(wb.abs().max().clamp_min(1.0)))
 
 
-def test_training_assembly_node_equals_the_framework_expression():
+@pytest.mark.parametrize("C", [21, 36, 40, 81])
+def test_training_assembly_node_equals_the_framework_expression(C):
     """_AssembleTrainFn (forward: the one-launch assembly; backward: ssdhip_assemble_predictions_backward_bf16) against the framework
     expression it replaces -- slices of the packed maps, Reshape, Concatenate, softmax, Concatenate with the anchors -- forward to 2e-6,
-    the packed gradients to one bf16 rounding (padding channels exactly zero).  n_boxes 4 and 6, maps whose anchors do not fill a tile."""
+    the packed gradients to one bf16 rounding (padding channels exactly zero).  n_boxes 4 and 6, maps whose anchors do not fill a tile.
+    Class counts at and beyond the old 64 KB LDS limit of the backward kernel (36-40 classes passed the model's gate and
+    failed in backward); the gate is now the kernel's own formula, checked here for every case."""
     torch, nat = _t()
     from ssd_keras_amd.models._common import _AssembleTrainFn
     g = torch.Generator(device="cuda").manual_seed(17)
-    B, C = 3, 21
-    geo = [(7, 9, 4, 128), (5, 5, 6, 256), (3, 2, 6, 256), (1, 1, 4, 128)]        # (h, w, n_boxes, packed channels)
+    B = 3
+    pad = lambda nb: -(-(nb * (C + 4)) // 128) * 128
+    geo = [(7, 9, 4, pad(4)), (5, 5, 6, pad(6)), (3, 2, 6, pad(6)), (1, 1, 4, pad(4))]        # (h, w, n_boxes, packed channels)
+    assert nat.assemble_backward_supported(C, [nb for _, _, nb, _ in geo], [cp for _, _, _, cp in geo])
     ys = [(torch.randn((B, h, w, cp), device="cuda", generator=g) * 3).to(torch.bfloat16).permute(0, 3, 1, 2).requires_grad_(True) for h, w, nb, cp in geo]
     N = sum(h * w * nb for h, w, nb, cp in geo)
     anchors = torch.rand((N, 8), device="cuda", generator=g)
