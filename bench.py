@@ -61,6 +61,10 @@ def self_spawn(args):
     code.  With a launcher environment (WORLD_SIZE set) this is never called: the process IS one of the ranks."""
     import socket
     import subprocess
+    if (torch.cuda.is_available() and torch.cuda.device_count() < args.gpus and os.environ.get("SSD_BENCH_SHARE_GPU", "0") != "1"):
+        print("bench.py: --gpus %d but this box has %d GPU(s) (one rank per GPU; SSD_BENCH_SHARE_GPU=1 SSD_BENCH_BACKEND=gloo puts every "
+              "rank on GPU 0 to exercise the launch path only)" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
     port = args.master_port
     if not port:
         with socket.socket() as sock:

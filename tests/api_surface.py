@@ -23,6 +23,8 @@ SURFACE = {
     "eval_utils/average_precision_evaluator.py": ["Evaluator.__init__", "Evaluator.__call__", "Evaluator.match_predictions",
                                                   "Evaluator.compute_precision_recall", "Evaluator.compute_average_precisions",
                                                   "Evaluator.compute_mean_average_precision"],
+    "eval_utils/coco_utils.py": ["get_coco_category_maps", "predict_all_to_json"],
+    "data_generator/object_detection_2d_misc_utils.py": ["apply_inverse_transforms"],
     "data_generator/object_detection_2d_image_boxes_validation_utils.py": ["BoundGenerator.__init__", "BoxFilter.__init__", "BoxFilter.__call__",
                                                                            "ImageValidator.__init__", "ImageValidator.__call__"],
     "data_generator/object_detection_2d_patch_sampling_ops.py": ["PatchCoordinateGenerator.__init__", "CropPad.__init__", "CropPad.__call__",

@@ -410,6 +410,61 @@ def gen_image_ops():
         del sys.modules[name]
 
 
+def gen_coco_utils():
+    """The reference's eval_utils/coco_utils.predict_all_to_json (:62-200) on the seeded cases of tests/coco_cases.py: a stand-in
+    generator / model around the REAL function, the real ConvertTo3Channels / RandomPadFixedAR / Resize (with the np_image-built cv2 of
+    gen_image_ops: only Resize's pixels go through it, and no pixel reaches the results file) and, for model_mode='training', the real
+    NumPy decode_detections.  Stored: the results file's text per case and how the function called the generator."""
+    import tempfile
+    import types
+    from oracle import np_image as npi
+    for name in [m for m in sys.modules if m == "cv2" or m.startswith("data_generator") or m.startswith("eval_utils")]:
+        del sys.modules[name]
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_RGB2HSV, cv2.COLOR_HSV2RGB, cv2.COLOR_RGB2GRAY = npi.COLOR_RGB2HSV, npi.COLOR_HSV2RGB, npi.COLOR_RGB2GRAY
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.INTER_LANCZOS4 = 0, 1, 2, 3, 4
+    cv2.BORDER_CONSTANT = 0
+    cv2.cvtColor = lambda image, code: npi.cvt_color(np.ascontiguousarray(image), code)
+    cv2.resize = lambda image, dsize=None, interpolation=1: npi.resize(np.ascontiguousarray(image), dsize, interpolation)
+    sys.modules["cv2"] = cv2
+    import eval_utils.coco_utils as ref_coco
+    from tests import coco_cases as cc
+    out = {"n_cases": np.array(len(cc.CASES))}
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, case in enumerate(cc.CASES):
+            res = cc.run(ref_coco, case, tmp)
+            out["c%02d_json" % i] = np.array(res["json"])
+            out["c%02d_error" % i] = np.array(res.get("error", ""))
+            if res.get("error"):
+                # the reference's 'pad' mode cannot run as written: :125 passes `clip_boxes`, which RandomPadFixedAR (:832) does not take;
+                # and with THAT keyword dropped (what average_precision_evaluator.py:325 does) CropPad turns `labels=None` into a 0-d
+                # array and indexes it (object_detection_2d_patch_sampling_ops.py:273, :325).  Both errors are recorded; the drop-in's
+                # 'pad' mode works and is tested through a round-trip property instead (tests/test_coco_utils.py).
+                real = ref_coco.RandomPadFixedAR
+                ref_coco.RandomPadFixedAR = lambda patch_aspect_ratio, clip_boxes=False: real(patch_aspect_ratio=patch_aspect_ratio)
+                try:
+                    cc.run(ref_coco, case, tmp)
+                    second = ""
+                except Exception as exc:                          # noqa: BLE001
+                    second = "%s: %s" % (type(exc).__name__, exc)
+                finally:
+                    ref_coco.RandomPadFixedAR = real
+                out["c%02d_error_without_clip_boxes_kwarg" % i] = np.array(second)
+            out["c%02d_generate_call" % i] = np.array(repr(res["generate_call"]))
+            out["c%02d_batches_seen" % i] = np.array(repr(res["batches_seen"]))
+            out["c%02d_case" % i] = np.array(repr(case))
+        ann = os.path.join(tmp, "ann.json")
+        import json
+        cats = [{"id": cid, "name": nm, "supercategory": "x"} for cid, nm in ((1, "person"), (2, "bicycle"), (4, "motorcycle"), (7, "train"), (90, "toothbrush"))]
+        with open(ann, "w") as f:
+            json.dump({"categories": cats, "images": [], "annotations": []}, f)
+        out["category_maps"] = np.array(repr(ref_coco.get_coco_category_maps(ann)))
+        out["category_file"] = np.array(open(ann).read())
+    save("coco_utils", **out)
+    for name in [m for m in sys.modules if m == "cv2" or m.startswith("data_generator") or m.startswith("eval_utils")]:
+        del sys.modules[name]
+
+
 def gen_api_surface():
     """The reference's call surface read from its SOURCE with `ast` (tests/api_surface.py): parameter names, order
     and defaults of every callable the package mirrors -- including the TensorFlow / Keras modules that cannot be imported here."""
@@ -580,7 +635,7 @@ def gen_decoder():
 
 if __name__ == "__main__":
     # box_filter / patch_sampling import the reference's real data_generator package; gen_evaluator stubs what is left of it
-    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_image_ops, gen_api_surface, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
+    gens = [gen_box_utils, gen_box_utils2, gen_box_filter, gen_patch_sampling, gen_image_ops, gen_coco_utils, gen_api_surface, gen_evaluator, gen_anchors, gen_encoder, gen_decoder]
     wanted = set(sys.argv[1:])
     for g in gens:
         if not wanted or g.__name__[4:] in wanted:
