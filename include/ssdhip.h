@@ -545,6 +545,13 @@ int ssdhip_image_lut_u8(const void* x, void* y, long long n_values, int C, int c
  * (or x 64 where that is needed to fill the chip: conv5_x at batch 32). */
 int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
                                    int dilation, int relu, void* stream);
+/* The same kernel family for k x k filters, k in {1, 3}, with stride and zero padding (round 6): fc7 = Conv2D(1024, (1, 1)) and
+ * conv6_1 = Conv2D(256, (1, 1)) (models/keras_ssd300.py:299, 301: a 1 x 1 layer is ONE step per 64-channel slice, the image's slice
+ * resident in LDS), conv6_2 = ZeroPadding2D(1) + Conv2D(512, (3, 3), strides=(2, 2), padding='valid') (:302-303: 19 x 19 -> 10 x 10,
+ * a 128-pixel tile form).  y [B, Ho, Wo, Cout] with Ho = (H + 2 padding - dilation (k - 1) - 1) / stride + 1; H * W <= 384,
+ * Ho * Wo <= 384, 1 <= stride <= 4, 0 <= padding <= dilation (k / 2); otherwise as above.  Bit-identical to ssdhip_conv2d_nhwc_bf16. */
+int ssdhip_conv2d_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                                  int ksize, int stride, int padding, int dilation, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The parameter side of the training step (csrc/ssdhip_optim.hip): ONE launch over all parameters.  The reference trains float32

@@ -788,6 +788,47 @@ def conv3x3_image(x, weight, bias, dilation=1, relu=True):
     return y
 
 
+def conv2d_image_supported(x, weight, stride=1, padding=0, dilation=1):
+    """Geometry of conv2d_image (csrc/ssdhip_convimg.hip, ssdhip_conv2d_image_nhwc_bf16): k x k filters with k in {1, 3}, at most 384
+    input and 384 output pixels per image, Cin % 64 == 0, Cout % 64 == 0, 1 <= stride <= 4, 1 <= dilation <= 16,
+    0 <= padding <= dilation (k // 2)."""
+    b, cin, h, w = x.shape
+    cout, cin_w, kh, kw = weight.shape
+    k, s, p, d = int(kh), int(stride), int(padding), int(dilation)
+    if kh != kw or k not in (1, 3) or cin_w != cin or cin % 64 or cout % 64 or h * w > 384:
+        return False
+    if not (1 <= s <= 4 and 1 <= d <= 16 and 0 <= p <= d * (k // 2)) or h + 2 * p < d * (k - 1) + 1 or w + 2 * p < d * (k - 1) + 1:
+        return False
+    ho, wo = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
+    return 1 <= ho * wo <= 384
+
+
+def conv2d_image(x, weight, bias, stride=1, padding=0, dilation=1, relu=True):
+    """k x k convolution (k in {1, 3}) with stride / zero padding / dilation on a small map, one image per tile with its 64-channel
+    slices resident in LDS (csrc/ssdhip_convimg.hip; round 6: fc7, conv6_1, conv6_2).  Layouts as conv2d; bit-identical to it."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_convimg2_bound", False):
+        lib.ssdhip_conv2d_image_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv2d_image_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 10 + [ctypes.c_void_p]
+        lib._convimg2_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or kh != kw or kh not in (1, 3):
+        raise SsdHipError("weight must be bfloat16 (Cout, %d, k, k) with k in (1, 3)" % cin)
+    k, s, p, d = int(kh), int(stride), int(padding), int(dilation)
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    ho, wo = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
+    if ho < 1 or wo < 1:
+        raise SsdHipError("the filter does not fit the padded map")
+    y = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv2d_image_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), b, h, w, cin, cout, k, s, p, d, int(bool(relu)),
+                                               current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv2d_image_nhwc_bf16")
+    return y
+
+
 def conv_chain_pack(weight, out=None):
     """[Cout, Cin, k, k] bfloat16 (channels_last) filters in the fragment order `conv_chain` streams; None if the geometry is not supported.
     `out`: an earlier result for the same geometry, re-packed IN PLACE (a captured HIP graph keeps reading that storage)."""

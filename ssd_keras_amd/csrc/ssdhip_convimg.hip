@@ -65,6 +65,7 @@ struct ConvImgParams {
     int B, H, W, Cin, Cout, dil, relu;
     int n_cot;                   // Cout / BM
     int xcd_map;                 // the channel tiles of an image on one XCD (needs n_cot == 8 or a tile count that is a multiple of 8 n_cot)
+    int Ho, Wo, stride, pad;     // output map, stride and zero padding (the 3x3 'same' form: Ho = H, Wo = W, stride 1, pad = dil)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -99,7 +100,11 @@ __device__ __forceinline__ i32x4 ci_rsrc(const void* base, u32 num_records) {
 
 // BM: output channels of a tile.  128: a wave owns 64 channels (two 32-channel MFMA blocks) x 96 pixels.  64: a wave owns ONE block x 96
 // pixels -- twice the tiles (conv5_x: 32 images x 8 = 256 instead of 128 for 256 CUs) for 1.33 KB of LDS reads per MFMA instead of 0.83.
-template <int BM>
+// KS: filter size, 3 (nine taps per 64-channel slice, any dilation / stride / padding: a tap is an address) or 1 (round 6: fc7, conv6_1 --
+// ONE step per slice; the implicit-GEMM form moved 2.5 x the bytes per FLOP of a 3x3 layer from L2 into LDS and ran fc7 at a quarter of the
+// peak).  NPB: 32-pixel MFMA blocks of a wave, 3 (output maps up to 384 pixels) or 1 (up to 128: the strided conv6_2, 19 x 19 -> 10 x 10,
+// would idle in three quarters of a 384-pixel tile).
+template <int BM, int KS, int NPB>
 __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[CI_LDS];
@@ -109,10 +114,12 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     constexpr int NCB = BM / 64;                         // 32-channel MFMA blocks of a wave
     constexpr int WCH = BM / 2;                          // output channels of a wave
     constexpr int NFP = BM / 64;                         // filter pieces (8 rows x 128 B) a wave requests per step
-    const int wm = wave & 1, wn = wave >> 1;             // WCH output channels x 96 pixels per wave
+    constexpr int NT = KS * KS;                          // taps = steps per slice
+
+    const int wm = wave & 1, wn = wave >> 1;             // WCH output channels x 32 NPB pixels per wave
     const int r31 = lane & 31, khalf = lane >> 5;
     const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const int HW = p.H * p.W;
+    const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
 
     // ---- tile: image b, channel tile ct ---------------------------------------------------------------------------------------
     int b, ct;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     }
     if (b >= p.B) return;
     const int co0 = ct * BM;
-    const int n_slices = p.Cin >> 6, n_steps = n_slices * 9;
+    const int n_slices = p.Cin >> 6, n_steps = n_slices * NT;
 
     CI_PROF_DECL
     // ---- zero rows, descriptors ---------------------------------------------------------------------------------------------------
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     // the bias of the tile's channels, fetched now and read from LDS in the epilogue (per-value global loads there cost 6 us per tile)
     if (tid >= 128 && tid < 128 + BM) reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
     const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * p.Cin, (u32)((size_t)HW * p.Cin * 2));
-    const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * 9 * p.Cin, (u32)((size_t)BM * 9 * p.Cin * 2));
+    const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * NT * p.Cin, (u32)((size_t)BM * NT * p.Cin * 2));
 
     // ---- request plan.  Every wave issues exactly NFP + 1 LDS-DMA pieces per step, in this order: [NFP filter pieces of step i + 2 | one slab
     //      piece of the next slice]; a request that has nothing to fetch goes out of range into the dump area.  So `s_waitcnt vmcnt(NFP + 2)`
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     for (int i = 0; i < NFP; ++i) {
         const int row = (NFP * wave + i) * 8 + (lane >> 3);
         const int j = (lane & 7) ^ ((row >> 1) & 7);
-        wrel[i] = (u32)((row * 9 * p.Cin) * 2 + j * 16);
+        wrel[i] = (u32)((row * NT * p.Cin) * 2 + j * 16);
     }
     // slab piece (t 8 + wave) of `slice` into buffer `buf` (or a dummy when the slice does not exist / the piece lies beyond the map)
     auto issue_slab = [&](const int slice, const int t, const int buf) {
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     // filters of step `wstep` = (slice, tap) into ring stage `stage`
     auto issue_filter_piece = [&](const int i, const int wstep, const int stage) {
         const bool wok = wstep < n_steps;
-        const int ws = wstep / 9, wt = wstep - 9 * ws;
+        const int ws = wstep / NT, wt = wstep - NT * ws;
         const u32 wo = (u32)((wt * p.Cin + ws * 64) * 2);
         ci_bload(wok ? wrel[i] + wo : OOB, rw, wok ? lds0 + CI_W0 + stage * CI_WST + (NFP * wave + i) * 1024 : lds0 + CI_DUMP);
     };
@@ -178,30 +185,30 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) abase[kk] = (u32)(CI_W0 + row * 128 + (((2 * kk + khalf) ^ ((row >> 1) & 7)) << 4));
     }
-    u32 baddr[9][3];                                     // current slab buffer: row of the tap's source pixel (or the zero row) + the lane's K half
+    u32 baddr[NT][NPB];                                  // current slab buffer: row of the tap's source pixel (or the zero row) + the lane's K half
 #pragma unroll
-    for (int pi = 0; pi < 3; ++pi) {
-        const int q = wn * 96 + pi * 32 + r31;
-        const int h = q / p.W, w = q - h * p.W;
+    for (int pi = 0; pi < NPB; ++pi) {
+        const int q = wn * (32 * NPB) + pi * 32 + r31;   // output pixel
+        const int h = q / p.Wo, w = q - h * p.Wo;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int hh = h + p.dil * (t / 3 - 1), ww = w + p.dil * (t % 3 - 1);
-            const bool ok = (q < HW) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+        for (int t = 0; t < NT; ++t) {
+            const int hh = h * p.stride - p.pad + p.dil * (t / KS), ww = w * p.stride - p.pad + p.dil * (t % KS);
+            const bool ok = (q < HWo) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
             baddr[t][pi] = (u32)((ok ? (hh * p.W + ww) * CI_ROW : CI_ZERO) + khalf * 16);
         }
     }
 
-    f32x16 acc[NCB][3];
+    f32x16 acc[NCB][NPB];
 #pragma unroll
     for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
-        for (int pi = 0; pi < 3; ++pi)
+        for (int pi = 0; pi < NPB; ++pi)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[ci][pi][v] = 0.f;
 
     // ---- prologue: the whole slab of slice 0 (its nine piece rounds), filters of steps 0 and 1 -------------------------------------
 #pragma unroll
-    for (int t = 0; t < 9; ++t) issue_slab(0, t, 0);
+    for (int t = 0; t < 7; ++t) issue_slab(0, t, 0);
     issue_filters(0, 0);
     issue_filters(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -211,61 +218,79 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     // left to itself sinks every read next to its use).  INSIDE a slice the pixel fragments of a step's first block are read before the
     // step's barrier (the slab does not change); the filter fragments, and the first pixel fragments of a NEW slice, only behind it (the
     // last pieces of a slab go out three steps before the slice begins: `vmcnt(4)` + that barrier are what makes them visible).
-    bf16x8 fa[2][NCB], fb[2][3];
+    bf16x8 fa[2][NCB], fb[2][NPB];
     auto read_b = [&](const int t, const int kk, const int slot) {
 #pragma unroll
-        for (int pi = 0; pi < 3; ++pi) fb[slot][pi] = *reinterpret_cast<const bf16x8*>(lds + baddr[t][pi] + kk * 32);
+        for (int pi = 0; pi < NPB; ++pi) fb[slot][pi] = *reinterpret_cast<const bf16x8*>(lds + baddr[t][pi] + kk * 32);
     };
-    auto read_a = [&](const int t, const int kk, const int slot) {
+    // `stage`: the ring stage of the step's filters -- (9 s + t) % 3 == t % 3 at compile time for 3x3, a running counter for 1x1
+    auto read_a = [&](const u32 stage_off, const int kk, const int slot) {
 #pragma unroll
-        for (int ci = 0; ci < NCB; ++ci) fa[slot][ci] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + (t % CI_NW) * CI_WST + ci * (32 * 128));
+        for (int ci = 0; ci < NCB; ++ci) fa[slot][ci] = *reinterpret_cast<const bf16x8*>(lds + abase[kk] + stage_off + ci * (32 * 128));
     };
     CI_PROF_MARK(0)
+    int stg = 0;                                         // (KS == 1) ring stage of the current step
     for (int s = 0; s < n_slices; ++s) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NT; ++t) {
             // the filters of this step (and the slab of this slice) have landed for this wave's share; the barrier makes that true for
             // all waves and tells that everybody has finished the previous step (whose filter stage and, behind a slice boundary, whose
-            // slab buffer the requests below overwrite)
+            // slab buffer the requests below overwrite).
+            // 3x3: a step requests [NFP filter pieces | one slab round]; NFP + 2 in flight = the previous step's + the slab round before.
+            // 1x1: a step requests [7 slab rounds of the NEXT slice | NFP filter pieces of step + 2]: everything but the previous step's
+            //      filter pieces (the most recent NFP requests) has to be here -- the slab of this slice was requested one step ago.
             CI_PROF_MARK(2)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NFP + 2) : "memory");   // lgkmcnt: this wave's fragment reads of the previous step have RETURNED
+            if constexpr (KS == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NFP + 2) : "memory");   // lgkmcnt: this wave's fragment reads of the previous step have RETURNED
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NFP) : "memory");
             __builtin_amdgcn_s_barrier();                                 // before anybody requests over the stage / buffer they came from
             CI_PROF_MARK(1)
-            read_a(t, 0, 0);
+            const u32 stage_off = (u32)((KS == 3 ? (t % CI_NW) : stg) * CI_WST);
+            const int stage_p2 = KS == 3 ? (t + 2) % CI_NW : (stg == 0 ? 2 : stg - 1);      // the stage of step + 2
+            read_a(stage_off, 0, 0);
             if (t == 0) read_b(0, 0, 0);                                 // a new slice: its slab is complete and visible only behind this barrier
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < 3) { read_a(t, kk + 1, (kk + 1) & 1); read_b(t, kk + 1, (kk + 1) & 1); }
-                else if (t < 8) read_b(t + 1, 0, 0);                     // (t == 8: after the buffer flip below)
+                if (kk < 3) { read_a(stage_off, kk + 1, (kk + 1) & 1); read_b(t, kk + 1, (kk + 1) & 1); }
+                else if (t < NT - 1) read_b(t + 1, 0, 0);                // (last tap of a slice: after the buffer flip below)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pi = 0; pi < 3; ++pi) acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][0], fb[kk & 1][pi], acc[0][pi], 0, 0, 0);
-                // the step's requests go out one at a time BETWEEN MFMA blocks (order: filters, slab): an LDS-DMA instruction holds its wave
+                for (int pi = 0; pi < NPB; ++pi) acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][0], fb[kk & 1][pi], acc[0][pi], 0, 0, 0);
+                // the step's requests go out a few at a time BETWEEN MFMA blocks: an LDS-DMA instruction holds its wave
                 // for 60-120 cycles, and issued together behind the barrier they left the matrix pipe idle in both waves of the SIMD at once
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < NFP) issue_filter_piece(kk, s * 9 + t + 2, (t + 2) % CI_NW);     // (9 s + t + 2) % 3 == (t + 2) % 3
-                if (kk == NFP) issue_slab(s + 1, t, (s + 1) & 1);
+                if constexpr (KS == 3) {                                 // order: filters, slab
+                    if (kk < NFP) issue_filter_piece(kk, s * NT + t + 2, stage_p2);
+                    if (kk == NFP) issue_slab(s + 1, t, (s + 1) & 1);
+                } else {                                                 // order: the seven slab rounds, then the filters
+                    if (kk < 3) { issue_slab(s + 1, 2 * kk, (s + 1) & 1); issue_slab(s + 1, 2 * kk + 1, (s + 1) & 1); }
+                    else {
+                        issue_slab(s + 1, 6, (s + 1) & 1);
+#pragma unroll
+                        for (int i = 0; i < NFP; ++i) issue_filter_piece(i, s + 2, stage_p2);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NCB == 2) {
 #pragma unroll
-                    for (int pi = 0; pi < 3; ++pi) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
+                    for (int pi = 0; pi < NPB; ++pi) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
                 }
             }
+            if constexpr (KS == 1) stg = stg == CI_NW - 1 ? 0 : stg + 1;
         }
         // the next slice lives in the other slab buffer
         const u32 flip = (s & 1) ? (u32)(-CI_SLAB) : (u32)CI_SLAB;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int pi = 0; pi < 3; ++pi) baddr[t][pi] += flip;
+            for (int pi = 0; pi < NPB; ++pi) baddr[t][pi] += flip;
     }
 
     // ---- epilogue: bias, one rounding, ReLU on the rounded pair; 16-byte stores from the accumulator layout (ssdhip_conv64.hip) -----------
     CI_PROF_MARK(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy requests of the last two steps
     const u32 floor16 = p.relu ? 0u : 0x80008000u;
-    const size_t img = (size_t)HW * p.Cout * 2;
+    const size_t img = (size_t)HWo * p.Cout * 2;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
 #pragma unroll
     for (int ci = 0; ci < NCB; ++ci) {
@@ -276,9 +301,9 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
             bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
         }
 #pragma unroll
-        for (int pi = 0; pi < 3; ++pi) {
-            const int q = wn * 96 + pi * 32 + r31;
-            const u32 voff = (u32)((q * p.Cout + co0 + wm * WCH + ci * 32) * 2 + khalf * 16) | (q < HW ? 0u : OOB);
+        for (int pi = 0; pi < NPB; ++pi) {
+            const int q = wn * (32 * NPB) + pi * 32 + r31;
+            const u32 voff = (u32)((q * p.Cout + co0 + wm * WCH + ci * 32) * 2 + khalf * 16) | (q < HWo ? 0u : OOB);
             u32 lo[4], hi[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -302,32 +327,56 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 
 using namespace ssdhip;
 
-// 3x3 'same' convolution (padding = dilation) of maps with H W <= 384 pixels, one image per tile: x [B, H, W, Cin] bf16, weight
-// [Cout, 3, 3, Cin] bf16, bias [Cout] bf16 or NULL, y [B, H, W, Cout] bf16; Cin % 64 == 0, Cout % 64 == 0, 1 <= dilation <= 16.
-// Replaces Conv2D(..., (3, 3), dilation_rate=d, padding='same', activation='relu') -- fc6, models/keras_ssd300.py:298 -- with the
-// K order (and hence the bits) of ssdhip_conv2d_same_nhwc_bf16.  SSDHIP_E_BADARG for other geometries (the caller keeps the
-// implicit-GEMM kernels for them).
-extern "C" int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
-                                              int Cout, int dilation, int relu, void* stream_) {
+// The general entry (round 6): k x k convolution, k in {1, 3}, of maps with H W <= 384 input pixels and at most 384 output pixels, one
+// image per tile: x [B, H, W, Cin] bf16, weight [Cout, k, k, Cin] bf16, bias [Cout] bf16 or NULL, y [B, Ho, Wo, Cout] bf16 with
+// Ho = (H + 2 padding - dilation (k - 1) - 1) / stride + 1 (Wo alike); Cin % 64 == 0, Cout % 64 == 0, 1 <= dilation <= 16,
+// 1 <= stride <= 4, 0 <= padding <= dilation (k / 2).  Replaces Conv2D(Cout, (k, k), strides, padding, dilation_rate, activation) of
+// models/keras_ssd300.py:298-313 -- fc6 (3x3, dilation 6), fc7 and conv6_1 (1x1), conv6_2 (ZeroPadding2D + 3x3 stride 2 'valid') --
+// with the K order (and hence the bits) of ssdhip_conv2d_nhwc_bf16.  SSDHIP_E_BADARG for other geometries.
+extern "C" int ssdhip_conv2d_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                                             int Cout, int ksize, int stride, int padding, int dilation, int relu, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SSDHIP_E_BADARG;
-    if ((Cin % 64) || (Cout % 64) || dilation < 1 || dilation > 16 || (long long)H * W > CI_PX) return SSDHIP_E_BADARG;
+    if ((ksize != 1 && ksize != 3) || stride < 1 || stride > 4 || dilation < 1 || dilation > 16 || padding < 0 ||
+        padding > dilation * (ksize / 2))
+        return SSDHIP_E_BADARG;
+    if ((Cin % 64) || (Cout % 64) || (long long)H * W > CI_PX) return SSDHIP_E_BADARG;
+    const int Ho = (H + 2 * padding - dilation * (ksize - 1) - 1) / stride + 1, Wo = (W + 2 * padding - dilation * (ksize - 1) - 1) / stride + 1;
+    if (H + 2 * padding < dilation * (ksize - 1) + 1 || W + 2 * padding < dilation * (ksize - 1) + 1 || Ho < 1 || Wo < 1 ||
+        (long long)Ho * Wo > CI_PX)
+        return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
     if ((long long)H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7ffff000LL || 128LL * 9 * Cin * 2 >= 0x7ffff000LL) return SSDHIP_E_BADARG;
     ConvImgParams p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
-    // channel tile: 128 where that already gives three quarters of a chip's worth of tiles (fc6 at batch 32: 256), else 64 (conv5_x at
-    // batch 32: 256 tiles instead of 128).  SSDHIP_CONVIMG_BM forces one (A/B runs).
+    p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = padding;
+    // channel tile: 128 where that already gives three quarters of a chip's worth of tiles (fc6 / fc7 at batch 32: 256), else 64 (conv5_x,
+    // conv6_1, conv6_2 at batch 32: 256 / 128 / 256 tiles).  SSDHIP_CONVIMG_BM forces one (A/B runs).
     int bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
     if (const char* e = getenv("SSDHIP_CONVIMG_BM")) { const int v = atoi(e); if (v == 64 || (v == 128 && (Cout % 128) == 0)) bm = v; }
     p.n_cot = Cout / bm;
-    const int grid = B * p.n_cot;
+    const dim3 grid((unsigned)(B * p.n_cot)), block(CI_THREADS);
     p.xcd_map = (B % 8 == 0) ? 1 : 0;                    // b = xcd + 8 (j / n_cot) covers 0 .. B - 1 exactly when B is a multiple of 8
-    if (bm == 128) hipLaunchKernelGGL(conv_image_kernel<128>, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL(conv_image_kernel<64>, dim3((unsigned)grid), dim3(CI_THREADS), 0, stream, p);
+    const bool small = Ho * Wo <= 128;                   // one 32-pixel block per wave
+#define CI_LAUNCH(BM_, KS_, NPB_) hipLaunchKernelGGL((conv_image_kernel<BM_, KS_, NPB_>), grid, block, 0, stream, p)
+    if (ksize == 3) {
+        if (bm == 128) { if (small) CI_LAUNCH(128, 3, 1); else CI_LAUNCH(128, 3, 3); }
+        else { if (small) CI_LAUNCH(64, 3, 1); else CI_LAUNCH(64, 3, 3); }
+    } else {
+        if (bm == 128) { if (small) CI_LAUNCH(128, 1, 1); else CI_LAUNCH(128, 1, 3); }
+        else { if (small) CI_LAUNCH(64, 1, 1); else CI_LAUNCH(64, 1, 3); }
+    }
+#undef CI_LAUNCH
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// 3x3 'same' convolution (padding = dilation) of maps with H W <= 384 pixels: the round-4 entry, now the general one at stride 1 and
+// padding = dilation (fc6, conv5_x; the data gradient of the same layers in the training step).
+extern "C" int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin,
+                                              int Cout, int dilation, int relu, void* stream_) {
+    return ssdhip_conv2d_image_nhwc_bf16(x, weight, bias, y, B, H, W, Cin, Cout, 3, 1, dilation, dilation, relu, stream_);
 }
 
 #ifdef SSDHIP_PROFILE

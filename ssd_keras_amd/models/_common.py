@@ -155,8 +155,14 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
         # (a 64-channel dL/dy -- conv1_2 -- through the resident-filter kernel of the Cin = 64 layers, csrc/ssdhip_conv64.hip: the same bits as
         #  the implicit-GEMM kernel in half its time, 430 -> 215 us at 300 x 300 / batch 32)
         c64 = (k == 3 and dilation[0] == 1 and wt.shape[1] == 64 and wt.shape[0] % 64 == 0 and os.environ.get("SSDHIP_NO_C64_DGRAD", "0") != "1")
+        # (round 6: the 1 x 1 layers on small maps -- fc7, conv6_1 -- through the same kernel's one-step-per-slice form)
+        image1 = (k == 1 and gy.shape[2] * gy.shape[3] <= 384 and gy.shape[0] * (wt.shape[0] // 64) >= 128
+                  and nat.conv2d_image_supported(gy, wt) and os.environ.get("SSDHIP_IMAGE2", "1") != "0"
+                  and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
         if image:
             gx = nat.conv3x3_image(gy, wt, None, dilation=dilation[0], relu=False)
+        elif image1:
+            gx = nat.conv2d_image(gy, wt, None, relu=False)
         elif c64:
             gx = nat.conv3x3_c64(gy, wt, None, relu=False, pool=False)
         else:
@@ -447,6 +453,20 @@ class SSDModel(nn.Module):
                 and conv.out_channels % 64 == 0 and 1 <= conv.dilation[0] <= 16
                 and x.shape[0] * (conv.out_channels // 64) >= 128 and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
 
+    @staticmethod
+    def _image2_ok(conv, x):
+        """Round 6, csrc/ssdhip_convimg.hip's general form: 1 x 1 layers (fc7, conv6_1: one step per 64-channel slice of the resident
+        image) and strided / partially padded 3 x 3 layers (conv6_2) on maps of at most 384 pixels, where one image x 64 output channels
+        per tile gives at least half a chip's worth of tiles."""
+        import os
+        k = conv.kernel_size[0]
+        if (os.environ.get("SSDHIP_IMAGE2", "1") == "0" or os.environ.get("SSDHIP_NO_IMAGE", "0") == "1" or conv.kernel_size[1] != k
+                or conv.stride[0] != conv.stride[1] or conv.dilation[0] != conv.dilation[1] or not isinstance(conv.padding, tuple)
+                or conv.padding[0] != conv.padding[1] or conv.groups != 1 or conv.padding_mode != 'zeros'):
+            return False
+        return (x.shape[0] * (conv.out_channels // 64) >= 128
+                and nat.conv2d_image_supported(x, conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0]))
+
     def _pick(self, key, candidates):
         """candidates: {name: thunk}; returns the name of the fastest (timed once per key with events)."""
         import os
@@ -543,6 +563,14 @@ class SSDModel(nn.Module):
                 if self._image_ok(conv, x):
                     # one image per tile, the dilated taps as per-lane LDS addresses (csrc/ssdhip_convimg.hip): fc6
                     cands["image"] = lambda: nat.conv3x3_image(x, conv.weight, conv.bias, dilation=conv.dilation[0], relu=relu)
+                if k == 1 and self._image2_ok(conv, x):
+                    # round 6: a 1 x 1 layer with the image's 64-channel slices resident in LDS, one step per slice (fc7 41 -> ~17 us,
+                    # conv6_1 23 -> ~10 us: the implicit-GEMM tiles move 2.5 x the bytes per FLOP from L2).  Taken without a timing
+                    # run, like the split-K form below: a back-to-back burst of these kernels is L2-warm and host-paced.
+                    cands["image"] = lambda: nat.conv2d_image(x, conv.weight, conv.bias, relu=relu)
+                    if (os.environ.get("SSDHIP_CONV", "auto") in ("auto", "auto_miopen") and not os.environ.get("SSDHIP_PREFER")
+                            and x.shape[0] >= 16):
+                        return cands["image"]()
                 if k == 1 and os.environ.get("SSDHIP_GEMM_1X1", "0") == "1":
                     # a 1 x 1 layer on NHWC memory IS a plain GEMM ([B H W, Cin] x [Cin, Cout] + bias, ReLU).  Opt-in: the library's
                     # (hipBLASLt through torch, bias / activation in its epilogue) was measured on fc7 and conv6_1 inside the step and is
@@ -565,6 +593,14 @@ class SSDModel(nn.Module):
                     # these layers cost the latency of their K loop, not arithmetic
                     cands["halo"] = lambda: nat.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
                                                        dilation=1, relu=relu, variant=7)
+                if self._image2_ok(conv, x):
+                    # round 6: conv6_2 (19 x 19 -> 10 x 10, stride 2) with the image resident in LDS, the strided taps as addresses, one
+                    # (image, 64 channels) tile of 128 pixels per workgroup: 256 tiles at batch 32 instead of a split-K launch + its reduction
+                    cands["image"] = lambda: nat.conv2d_image(x, conv.weight, conv.bias, stride=conv.stride[0], padding=conv.padding[0],
+                                                              dilation=conv.dilation[0], relu=relu)
+                    if (os.environ.get("SSDHIP_CONV", "auto") in ("auto", "auto_miopen") and not os.environ.get("SSDHIP_PREFER")
+                            and x.shape[0] >= 16):
+                        return cands["image"]()
             import os
             if ("splitk" in cands and self._splitk_measured_regime(x) and os.environ.get("SSDHIP_NO_SPLITK", "0") != "1"
                     and os.environ.get("SSDHIP_CONV", "auto") in ("auto", "auto_miopen") and not os.environ.get("SSDHIP_PREFER")):
@@ -718,10 +754,15 @@ class SSDModel(nn.Module):
                 cands["halo"] = lambda xb, wb, bb: nat.conv2d_same(xb, wb, bb, dilation=1, relu=relu, variant=7)
             if self._image_ok(conv, x):
                 cands["image"] = lambda xb, wb, bb: nat.conv3x3_image(xb, wb, bb, dilation=d, relu=relu)
+            if k == 1 and self._image2_ok(conv, x):
+                cands["image"] = lambda xb, wb, bb: nat.conv2d_image(xb, wb, bb, relu=relu)
         elif self._igemm_general_ok(conv, x):
             cands = {nm: (lambda xb, wb, bb, v=v: nat.conv2d(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
                                                             relu=relu, variant=v))
                      for nm, v in (("igemm", None), ("igemm5", 5), ("igemm6", 6))}
+            if self._image2_ok(conv, x):
+                cands["image"] = lambda xb, wb, bb: nat.conv2d_image(xb, wb, bb, stride=conv.stride[0], padding=conv.padding[0], dilation=d,
+                                                                     relu=relu)
         else:
             return None, None
         import os

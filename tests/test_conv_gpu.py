@@ -581,6 +581,84 @@ def test_image_conv_equals_implicit_gemm(case):
     assert int(((got.float() - want).abs() > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
 
 
+IMAGE2_CASES = [  # B, H, W, Cin, Cout, k, stride, padding, dilation, bias, relu   (round 6: ssdhip_conv2d_image_nhwc_bf16)
+    (32, 19, 19, 1024, 1024, 1, 1, 0, 1, True, True),    # fc7 (models/keras_ssd300.py:299): 256 tiles of 128 channels, 16 one-tap slices
+    (32, 19, 19, 1024, 256, 1, 1, 0, 1, True, True),     # conv6_1 (:301): 128 tiles of 64 channels
+    (32, 19, 19, 256, 512, 3, 2, 1, 1, True, True),      # conv6_2 (:302-303): 19 x 19 -> 10 x 10, the 128-pixel tile form
+    (3, 19, 19, 128, 192, 1, 1, 0, 1, True, False),      # 1x1, two slices (fewer than the ring has stages), Cout = 192, no ReLU, plain tile map
+    (2, 7, 9, 64, 64, 1, 1, 0, 1, False, True),          # 1x1, ONE slice, no bias, a 63-pixel map on the one-block tile
+    (8, 16, 24, 192, 128, 1, 1, 0, 1, True, True),       # 1x1 on exactly 384 pixels (54 slab pieces per slice: all seven rounds)
+    (5, 10, 10, 512, 128, 1, 1, 0, 1, True, True),       # conv7_1 geometry (1x1 on 10 x 10), eight slices on the one-block tile
+    (4, 10, 10, 128, 256, 3, 2, 1, 1, True, True),       # conv7_2: 10 x 10 -> 5 x 5
+    (4, 5, 5, 128, 256, 3, 1, 0, 1, True, True),         # conv8_2: 'valid', 5 x 5 -> 3 x 3
+    (2, 3, 3, 128, 256, 3, 1, 0, 1, True, True),         # conv9_2: 'valid', 3 x 3 -> 1 x 1
+    (2, 19, 19, 64, 128, 3, 1, 2, 2, True, True),        # 'same' through the general entry (dilation 2, padding 2)
+    (2, 18, 20, 128, 64, 3, 3, 1, 1, True, True),        # stride 3 on a non-square map
+    (3, 19, 19, 64, 128, 1, 2, 0, 1, True, True),        # a strided 1x1
+    (2, 17, 17, 128, 128, 3, 1, 1, 6, True, True),       # padding smaller than the dilated reach: 17 x 17 -> 7 x 7
+]
+
+
+@pytest.mark.parametrize("case", IMAGE2_CASES)
+def test_general_image_conv_equals_implicit_gemm(case):
+    """ssdhip_conv2d_image_nhwc_bf16 (1x1 layers: one step per slice with the next slice's seven slab rounds inside it; strided /
+    partially padded 3x3 layers: taps as addresses, 128- and 384-pixel tiles) against the implicit-GEMM kernel on the same operands:
+    bit-identical over five launches, and within the convolution bar of the float32 reference."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout, k, stride, pad, d, use_bias, relu = case
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + H * 7 + d + 17 * k + stride)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if use_bias else None
+    assert nat.conv2d_image_supported(x, wt, stride, pad, d)
+    base = nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=d, relu=relu)
+    for _ in range(5):
+        got = nat.conv2d_image(x, wt, bias, stride=stride, padding=pad, dilation=d, relu=relu)
+        assert got.shape == base.shape
+        assert torch.equal(got.view(torch.int16), base.view(torch.int16))
+    want = F.conv2d(x.float(), wt.float(), bias.float() if use_bias else None, stride, pad, d)
+    if relu:
+        want = want.clamp_min(0)
+    rms = want.pow(2).mean().sqrt().item()
+    assert int(((got.float() - want).abs() > want.abs() * 2.0 ** -7 + 1e-2 * rms).sum().item()) == 0
+
+
+def test_general_image_conv_race_screen():
+    """fc7, conv6_1 and conv6_2 at batch 32: thirty launches each, every one bit-identical to the implicit-GEMM result (the 1x1 form
+    waits for a slab requested ONE step earlier: a wrong count shows up as stale rows)."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    for B, H, W, Cin, Cout, k, stride, pad in ((32, 19, 19, 1024, 1024, 1, 1, 0), (32, 19, 19, 1024, 256, 1, 1, 0), (32, 19, 19, 256, 512, 3, 2, 1)):
+        g = torch.Generator(device="cuda").manual_seed(13)
+        x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+        wt = (torch.randn((Cout, k, k, Cin), generator=g, device="cuda") / (k * k * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+        bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+        base = nat.conv2d(x, wt, bias, stride=stride, padding=pad, dilation=1, relu=True).view(torch.int16)
+        bad = 0
+        for _ in range(30):
+            bad += int((nat.conv2d_image(x, wt, bias, stride=stride, padding=pad, dilation=1, relu=True).view(torch.int16) != base).sum().item())
+        assert bad == 0, (B, H, W, Cin, Cout, k, bad)
+
+
+def test_general_image_conv_rejects_other_geometries():
+    import torch
+    from ssd_keras_amd import _native as nat
+    mk = lambda *shape: torch.zeros(shape, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert not nat.conv2d_image_supported(mk(1, 64, 20, 20), mk(64, 64, 1, 1))                # 400 pixels
+    assert not nat.conv2d_image_supported(mk(1, 64, 8, 8), mk(64, 64, 5, 5), 1, 2, 1)         # 5 x 5 filters
+    assert not nat.conv2d_image_supported(mk(1, 64, 8, 8), mk(64, 64, 1, 1), 1, 1, 1)         # padding on a 1 x 1 layer
+    assert not nat.conv2d_image_supported(mk(1, 64, 8, 8), mk(64, 64, 3, 3), 5, 1, 1)         # stride 5
+    assert not nat.conv2d_image_supported(mk(1, 64, 2, 2), mk(64, 64, 3, 3), 1, 0, 1)         # the filter does not fit
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d_image(mk(1, 64, 20, 20), mk(64, 64, 1, 1), None)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d_image(mk(1, 64, 8, 8), mk(64, 64, 1, 1), None, padding=1)
+    with pytest.raises(nat.SsdHipError):
+        nat.conv2d_image(mk(1, 64, 8, 8), mk(32, 64, 1, 1), None)                            # Cout % 64 != 0
+
+
 def test_image_conv_race_screen():
     """fc6 at batch 32 and conv5-sized tiles at batch 16: thirty launches each, every one bit-identical to the implicit-GEMM result (the
     kernel's LDS-DMA rings are guarded by counted waits and one barrier per step; a missing guard shows up as an occasional stale
