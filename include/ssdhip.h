@@ -214,6 +214,15 @@ int ssdhip_match_predictions(const float* pred, const int* pred_image, int P, co
                              const unsigned char* gt_neutral, int n_images, int G, double matching_iou_threshold,
                              int border_pixels, int* order, int* true_pos, int* false_pos, int* cum_true_pos,
                              int* cum_false_pos, void* ws, size_t ws_bytes, void* stream);
+/* The whole class loop of Evaluator.match_predictions (:601-725) in ONE call (round 6).  The predictions of all classes concatenated
+ * slot by slot (slot = position in the caller's class list): pred_segment [P] = slot * n_images + image index, pred_class [P] = slot,
+ * class_start [n_slots+1] (device) the slots' stretches; the ground truth as CSR over the n_slots * n_images segments (gt_offsets
+ * [n_segments+1]).  Outputs [P] in the concatenated order, every slot's stretch sorted as above; the cumulative sums restart per slot.
+ * n_slots <= 128, P < 2^25; workspace from ssdhip_match_predictions_workspace_bytes(P, G). */
+int ssdhip_match_predictions_multi(const float* pred, const int* pred_segment, const int* pred_class, int P, const double* gt_boxes,
+                                   const int* gt_offsets, const unsigned char* gt_neutral, int n_segments, int G, const int* class_start,
+                                   int n_slots, double matching_iou_threshold, int border_pixels, int* order, int* true_pos,
+                                   int* false_pos, int* cum_true_pos, int* cum_false_pos, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Graph glue between the convolutions (bf16 activations, NHWC = torch channels_last; C % 8 == 0; pointers

@@ -1528,6 +1528,41 @@ def match_predictions_class(pred, pred_image, gt_boxes, gt_offsets, gt_neutral, 
     return tuple(outs)
 
 
+def match_predictions_all(pred, pred_segment, pred_class, class_start, gt_boxes, gt_offsets, gt_neutral, matching_iou_threshold,
+                          border_pixels):
+    """Every class of Evaluator.match_predictions in ONE call (ssdhip_match_predictions_multi).  CUDA tensors: pred (P,5) float32
+    [conf, xmin, ymin, xmax, ymax] with the classes' predictions concatenated slot by slot, pred_segment (P,) int32 = slot * n_images +
+    image index, pred_class (P,) int32 = slot, class_start (n_slots + 1,) int32, gt_boxes (G,4) float64 and gt_offsets
+    (n_slots * n_images + 1,) int32 CSR over the segments, gt_neutral (G,) uint8 or None.  Returns ONE CUDA int32 tensor (5, P): rows
+    order, true_pos, false_pos, cum_true_pos, cum_false_pos (every slot's stretch sorted by descending confidence)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_eval_multi_bound", False):
+        c_int, c_vp, c_dbl, c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_size_t
+        lib.ssdhip_match_predictions_workspace_bytes.restype = c_sz
+        lib.ssdhip_match_predictions_workspace_bytes.argtypes = [c_int, c_int]
+        lib.ssdhip_match_predictions_multi.restype = c_int
+        lib.ssdhip_match_predictions_multi.argtypes = [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_dbl, c_int,
+                                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]
+        lib._eval_multi_bound = True
+    require_cuda(pred, "pred")
+    dev = pred.device
+    P, G = int(pred.shape[0]), int(gt_boxes.shape[0])
+    n_segments, n_slots = int(gt_offsets.shape[0]) - 1, int(class_start.shape[0]) - 1
+    out = torch.zeros((5, P), dtype=torch.int32, device=dev)
+    if P == 0:
+        return out
+    ws = workspaces.get(dev, "match_predictions", lib.ssdhip_match_predictions_workspace_bytes(P, G))
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_match_predictions_multi(_ptr(pred), _ptr(pred_segment), _ptr(pred_class), P, _ptr(gt_boxes) if G else None,
+                                                _ptr(gt_offsets), _ptr(gt_neutral) if gt_neutral is not None else None, n_segments, G,
+                                                _ptr(class_start), n_slots, float(matching_iou_threshold), BORDER[border_pixels],
+                                                *[ctypes.c_void_p(out[i].data_ptr()) for i in range(5)], _ptr(ws), ws.numel(),
+                                                current_stream_ptr(dev))
+    check(rc, "ssdhip_match_predictions_multi")
+    return out
+
+
 def box_filter(boxes, box_image, image_hw, check_overlap, check_min_area, check_degenerate, criterion, lower, upper, min_area,
                border_pixels):
     """Batched BoxFilter: boxes (G,4) float64 corners, box_image (G,) int32, image_hw (n_images,2) float64 -> CUDA uint8 keep mask."""

@@ -40,15 +40,25 @@ struct EvmParams {
 // key: larger = earlier in the reference's order (confidence descending; ties: lower original index first)
 __device__ __forceinline__ u64 evm_key(float conf, int p) { return ((u64)float_key(conf) << 32) | (u64)(0xffffffffu - (u32)p); }
 
+// All classes in one pass (round 6): the predictions lie class by class (slot 0 first), `pred_class[p]` is the slot.  One 64-bit key
+// still orders everything: [127 - slot : 7 | confidence bits : 32 | inverted index : 25] sorted descending = slot ascending, inside a
+// slot confidence descending, ties by the lower index -- each slot's stretch of the sorted array is that class's
+// argsort(-confidence, kind='mergesort').  Up to 128 slots and 2^25 predictions per call.
+constexpr int EVM_MULTI_IDX_BITS = 25;
+__device__ __forceinline__ u64 evm_key_multi(float conf, int p, int slot) {
+    return ((u64)(127u - (u32)slot) << 57) | ((u64)float_key(conf) << EVM_MULTI_IDX_BITS) | (u64)(((1u << EVM_MULTI_IDX_BITS) - 1u) - (u32)p);
+}
+
 __global__ __launch_bounds__(EVM_THREADS) void evm_target_kernel(EvmParams q, const float* __restrict__ pred,
-                                                                 const int* __restrict__ pred_image, const double* __restrict__ gt,
+                                                                 const int* __restrict__ pred_image, const int* __restrict__ pred_class,
+                                                                 const double* __restrict__ gt,
                                                                  const int* __restrict__ gt_off, const unsigned char* __restrict__ neutral,
                                                                  u64* __restrict__ keys, int* __restrict__ idx, int* __restrict__ target,
                                                                  u64* __restrict__ winner) {
     const int p = blockIdx.x * EVM_THREADS + threadIdx.x;
     if (p >= q.P) return;
     const float* r = pred + (size_t)p * 5;
-    const u64 key = evm_key(r[0], p);
+    const u64 key = pred_class ? evm_key_multi(r[0], p, pred_class[p]) : evm_key(r[0], p);
     keys[p] = key;
     idx[p] = p;
     const int img = pred_image[p];
@@ -93,8 +103,20 @@ __global__ __launch_bounds__(EVM_THREADS) void evm_assign_kernel(int P, const u6
     fp[s] = is_fp;
 }
 
+// cumulative counts of the all-classes call: the chip-wide running sums minus what the earlier slots contributed
+__global__ __launch_bounds__(EVM_THREADS) void evm_segment_cum_kernel(int P, const u64* __restrict__ sorted_keys, const int* __restrict__ class_start,
+                                                                      const int* __restrict__ run_tp, const int* __restrict__ run_fp,
+                                                                      int* __restrict__ cum_tp, int* __restrict__ cum_fp) {
+    const int s = blockIdx.x * EVM_THREADS + threadIdx.x;
+    if (s >= P) return;
+    const int slot = 127 - (int)(sorted_keys[s] >> 57);
+    const int base = class_start[slot];
+    cum_tp[s] = run_tp[s] - (base > 0 ? run_tp[base - 1] : 0);
+    cum_fp[s] = run_fp[s] - (base > 0 ? run_fp[base - 1] : 0);
+}
+
 struct EvmWs {
-    size_t keys, keys_sorted, idx, target, winner, tmp, tmp_bytes, total;
+    size_t keys, keys_sorted, idx, target, winner, run_tp, run_fp, tmp, tmp_bytes, total;
 };
 
 static inline size_t evm_align(size_t v) { return (v + 255) / 256 * 256; }
@@ -112,6 +134,8 @@ static EvmWs evm_layout(int P, int G) {
     w.idx = o;         o = evm_align(o + p * sizeof(int));
     w.target = o;      o = evm_align(o + p * sizeof(int));
     w.winner = o;      o = evm_align(o + g * sizeof(u64));
+    w.run_tp = o;      o = evm_align(o + p * sizeof(int));
+    w.run_fp = o;      o = evm_align(o + p * sizeof(int));
     w.tmp = o;
     w.tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
     const size_t floor_bytes = p * 32 + (1u << 20);    // never below a generous bound (the size query needs a device to answer)
@@ -154,8 +178,8 @@ extern "C" int ssdhip_match_predictions(const float* pred, const int* pred_image
     EvmParams q;
     q.P = P; q.n_images = n_images; q.G = G; q.border = border_pixels; q.thr = matching_iou_threshold;
     const int blocks = (P + EVM_THREADS - 1) / EVM_THREADS;
-    hipLaunchKernelGGL(evm_target_kernel, dim3(blocks), dim3(EVM_THREADS), 0, stream, q, pred, pred_image, gt_boxes, gt_offsets, gt_neutral,
-                       keys, idx, target, winner);
+    hipLaunchKernelGGL(evm_target_kernel, dim3(blocks), dim3(EVM_THREADS), 0, stream, q, pred, pred_image, (const int*)nullptr, gt_boxes,
+                       gt_offsets, gt_neutral, keys, idx, target, winner);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     if (rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys, keys_sorted, idx, order, (size_t)P, 0, 64, stream) != hipSuccess)
         return SSDHIP_E_LAUNCH;
@@ -169,4 +193,57 @@ extern "C" int ssdhip_match_predictions(const float* pred, const int* pred_image
     if (rocprim::inclusive_scan(tmp, tmp_bytes, false_pos, cum_false_pos, (size_t)P, rocprim::plus<int>(), stream) != hipSuccess)
         return SSDHIP_E_LAUNCH;
     return SSDHIP_OK;
+}
+
+// Evaluator.match_predictions for ALL classes in one call (round 6; eval_utils/average_precision_evaluator.py:604-725 is the body of a
+// loop over the classes, :601).  The predictions of every class concatenated slot by slot (slot = position in the caller's class list):
+// pred [P,5] float32 [conf, xmin, ymin, xmax, ymax], pred_segment [P] = slot * n_images + image index, pred_class [P] = slot,
+// class_start [n_slots + 1] (device): slot c owns [class_start[c], class_start[c+1]).  Ground truth as CSR over the n_slots * n_images
+// segments: gt_offsets [n_segments + 1], gt_boxes [G,4] float64, gt_neutral [G] or NULL.  Outputs [P] in the concatenated order, each
+// slot's stretch sorted by descending confidence: order (index into the concatenated input), true / false positive flags and their
+// PER-SLOT running sums.  Same arithmetic per prediction as ssdhip_match_predictions; n_slots <= 128, P < 2^25.
+extern "C" int ssdhip_match_predictions_multi(const float* pred, const int* pred_segment, const int* pred_class, int P,
+                                              const double* gt_boxes, const int* gt_offsets, const unsigned char* gt_neutral, int n_segments,
+                                              int G, const int* class_start, int n_slots, double matching_iou_threshold, int border_pixels,
+                                              int* order, int* true_pos, int* false_pos, int* cum_true_pos, int* cum_false_pos, void* ws,
+                                              size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0 || G < 0 || n_segments < 0 || n_slots < 1 || n_slots > 128 || border_pixels < 0 || border_pixels > 2) return SSDHIP_E_BADARG;
+    if (P >= (1 << EVM_MULTI_IDX_BITS)) return SSDHIP_E_BADARG;
+    if (P == 0) return SSDHIP_OK;
+    if (!pred || !pred_segment || !pred_class || !gt_offsets || !class_start || !order || !true_pos || !false_pos || !cum_true_pos ||
+        !cum_false_pos)
+        return SSDHIP_E_BADARG;
+    if (G > 0 && !gt_boxes) return SSDHIP_E_BADARG;
+    const EvmWs lay = evm_layout(P, G);
+    if (!ws || ws_bytes < lay.total) return SSDHIP_E_WORKSPACE;
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    u64* keys = reinterpret_cast<u64*>(base + lay.keys);
+    u64* keys_sorted = reinterpret_cast<u64*>(base + lay.keys_sorted);
+    int* idx = reinterpret_cast<int*>(base + lay.idx);
+    int* target = reinterpret_cast<int*>(base + lay.target);
+    u64* winner = reinterpret_cast<u64*>(base + lay.winner);
+    int* run_tp = reinterpret_cast<int*>(base + lay.run_tp);
+    int* run_fp = reinterpret_cast<int*>(base + lay.run_fp);
+    void* tmp = base + lay.tmp;
+    size_t tmp_bytes = lay.tmp_bytes;
+    if (zero_async(winner, (size_t)(G > 0 ? G : 1) * sizeof(u64), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    EvmParams q;
+    q.P = P; q.n_images = n_segments; q.G = G; q.border = border_pixels; q.thr = matching_iou_threshold;
+    const int blocks = (P + EVM_THREADS - 1) / EVM_THREADS;
+    hipLaunchKernelGGL(evm_target_kernel, dim3(blocks), dim3(EVM_THREADS), 0, stream, q, pred, pred_segment, pred_class, gt_boxes, gt_offsets,
+                       gt_neutral, keys, idx, target, winner);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    if (rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys, keys_sorted, idx, order, (size_t)P, 0, 64, stream) != hipSuccess)
+        return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(evm_assign_kernel, dim3(blocks), dim3(EVM_THREADS), 0, stream, P, keys_sorted, order, target, winner, true_pos,
+                       false_pos);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    tmp_bytes = lay.tmp_bytes;
+    if (rocprim::inclusive_scan(tmp, tmp_bytes, true_pos, run_tp, (size_t)P, rocprim::plus<int>(), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    tmp_bytes = lay.tmp_bytes;
+    if (rocprim::inclusive_scan(tmp, tmp_bytes, false_pos, run_fp, (size_t)P, rocprim::plus<int>(), stream) != hipSuccess) return SSDHIP_E_LAUNCH;
+    hipLaunchKernelGGL(evm_segment_cum_kernel, dim3(blocks), dim3(EVM_THREADS), 0, stream, P, keys_sorted, class_start, run_tp, run_fp,
+                       cum_true_pos, cum_false_pos);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

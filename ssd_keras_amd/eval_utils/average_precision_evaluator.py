@@ -180,45 +180,121 @@ class Evaluator:
             raise ValueError("There are no prediction results. You must run `predict_on_dataset()` before calling this method.")
         if border_pixels not in nat.BORDER:
             raise ValueError("`border_pixels` must be one of 'half', 'include' and 'exclude'")
-        gf = self.gt_format
-        cols = [gf['xmin'], gf['ymin'], gf['xmax'], gf['ymax']]
-        image_ids = [str(v) for v in self.data_generator.image_ids]
-        index_of = {image_id: i for i, image_id in enumerate(image_ids)}
-        neutral = self.data_generator.eval_neutral if (ignore_neutral_boxes and self.data_generator.eval_neutral is not None) else None
-        gt_cat, gt_img, neutral_cat = self._concat_ground_truth(self.data_generator.labels, neutral)
-        n_images = len(image_ids)
-
+        import torch
+        n_classes = self.n_classes
+        packed = self._packed_predictions()                     # every class's predictions on the device, packed ONCE per results object
+        gt = self._packed_ground_truth(ignore_neutral_boxes)    # ... and the ground truth as CSR over (class, image), once per labels object
+        P = int(packed["pred"].shape[0])
+        starts = packed["starts_host"]
+        if verbose:
+            for class_id in range(1, n_classes + 1):
+                if starts[class_id] == starts[class_id - 1]:
+                    print("No predictions for class {}/{}".format(class_id, n_classes))
+            print("Matching predictions to ground truth, classes 1-{} in one launch sequence.".format(n_classes))
+            sys.stdout.flush()
+        if P:
+            # ONE call for all classes (csrc/ssdhip_eval.hip, ssdhip_match_predictions_multi) and ONE download of the five result rows
+            res = nat.match_predictions_all(packed["pred"], packed["segment"], packed["slot"], packed["starts"], gt["boxes"], gt["offsets"],
+                                            gt["neutral"], matching_iou_threshold, border_pixels).cpu().numpy().astype(np.int64)
+        else:
+            res = np.zeros((5, 0), dtype=np.int64)
         true_positives, false_positives = [[]], [[]]
         cumulative_true_positives, cumulative_false_positives = [[]], [[]]
-        for class_id in range(1, self.n_classes + 1):
-            predictions = self.prediction_results[class_id]
-            P = len(predictions)
-            if P == 0:
-                if verbose:
-                    print("No predictions for class {}/{}".format(class_id, self.n_classes))
-                empty = np.zeros(0, dtype=np.int64)
-                for lst in (true_positives, false_positives, cumulative_true_positives, cumulative_false_positives):
-                    lst.append(empty.copy())
-                continue
-            gt_boxes, offsets, gt_neutral = self._class_ground_truth(gt_cat, gt_img, neutral_cat, n_images, class_id, gf['class_id'], cols)
-            columns = list(zip(*predictions))                                 # (image ids, conf, xmin, ymin, xmax, ymax)
-            pred = np.stack([np.asarray(col, dtype=np.float32) for col in columns[1:6]], axis=1)   # 'f4' like the reference (:629-634)
-            pred_image = np.fromiter((index_of[str(v)] for v in columns[0]), dtype=np.int32, count=P)
-            if verbose:
-                print("Matching predictions to ground truth, class {}/{}.".format(class_id, self.n_classes))
-                sys.stdout.flush()
-            _order, tp, fp, ctp, cfp = nat.match_predictions_class(pred, pred_image, gt_boxes, offsets, gt_neutral, matching_iou_threshold,
-                                                                   border_pixels)
-            true_positives.append(tp.cpu().numpy().astype(np.int64))
-            false_positives.append(fp.cpu().numpy().astype(np.int64))
-            cumulative_true_positives.append(ctp.cpu().numpy().astype(np.int64))
-            cumulative_false_positives.append(cfp.cpu().numpy().astype(np.int64))
+        for class_id in range(1, n_classes + 1):
+            lo, hi = int(starts[class_id - 1]), int(starts[class_id])
+            true_positives.append(res[1, lo:hi].copy())
+            false_positives.append(res[2, lo:hi].copy())
+            cumulative_true_positives.append(res[3, lo:hi].copy())
+            cumulative_false_positives.append(res[4, lo:hi].copy())
         self.true_positives = true_positives
         self.false_positives = false_positives
         self.cumulative_true_positives = cumulative_true_positives
         self.cumulative_false_positives = cumulative_false_positives
         if ret:
             return true_positives, false_positives, cumulative_true_positives, cumulative_false_positives
+
+    # ---- packing: the reference keeps predictions as per-class Python lists of tuples and labels as a list of arrays; walking them
+    #      is host work that dwarfs the matching itself (94 k predictions: ~70 ms of tuple handling for ~1 ms of kernels).  Both are
+    #      packed once per OBJECT and kept on the device: a second evaluation of the same results (another IoU threshold, another border
+    #      mode) only launches.  The cache keys on the identity of `prediction_results` / `labels` and on the per-class lengths: whoever
+    #      edits those lists IN PLACE without changing a length calls `forget_packed_inputs()`. --------------------------------------------
+    def forget_packed_inputs(self):
+        """Drop the device copies of the predictions and the ground truth (rebuilt by the next `match_predictions`)."""
+        for name in ("_packed_pred_memo", "_packed_gt_memo", "_image_index_memo"):
+            self.__dict__.pop(name, None)
+
+    def _image_index(self):
+        ids = self.data_generator.image_ids
+        memo = self.__dict__.get("_image_index_memo")
+        if memo is None or memo[0] is not ids or memo[1] != len(ids):
+            memo = (ids, len(ids), {str(v): i for i, v in enumerate(ids)})
+            self.__dict__["_image_index_memo"] = memo
+        return memo[2]
+
+    def _packed_predictions(self):
+        import torch
+        results = self.prediction_results
+        sig = (id(results), tuple(len(r) for r in results), id(self.data_generator.image_ids))
+        memo = self.__dict__.get("_packed_pred_memo")
+        if memo is not None and memo["sig"] == sig and memo["results"] is results:
+            return memo
+        n_classes = self.n_classes
+        n_images = len(self.data_generator.image_ids)
+        index_of = self._image_index()
+        counts = np.array([len(results[c]) for c in range(1, n_classes + 1)], dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        P = int(starts[-1])
+        pred = np.empty((P, 5), dtype=np.float32)                 # 'f4' like the reference's structured array (:629-634)
+        image = np.empty((P,), dtype=np.int64)
+        for c in range(1, n_classes + 1):
+            rows = results[c]
+            if not rows:
+                continue
+            lo, hi = int(starts[c - 1]), int(starts[c])
+            columns = list(zip(*rows))                            # (image ids, conf, xmin, ymin, xmax, ymax)
+            for j in range(5):
+                pred[lo:hi, j] = columns[j + 1]
+            image[lo:hi] = [index_of[str(v)] for v in columns[0]]
+        slot = np.repeat(np.arange(n_classes, dtype=np.int64), counts)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        memo = {"sig": sig, "results": results, "starts_host": starts,
+                "pred": nat.to_device(pred, device=dev, dtype=torch.float32),
+                "segment": nat.to_device((slot * n_images + image).astype(np.int32), device=dev, dtype=torch.int32),
+                "slot": nat.to_device(slot.astype(np.int32), device=dev, dtype=torch.int32),
+                "starts": nat.to_device(starts.astype(np.int32), device=dev, dtype=torch.int32)}
+        self.__dict__["_packed_pred_memo"] = memo
+        return memo
+
+    def _packed_ground_truth(self, ignore_neutral_boxes):
+        import torch
+        labels = self.data_generator.labels
+        neutral = self.data_generator.eval_neutral if (ignore_neutral_boxes and self.data_generator.eval_neutral is not None) else None
+        gf = self.gt_format
+        sig = (id(labels), len(labels), id(neutral), self.n_classes, tuple(sorted(gf.items())))
+        memo = self.__dict__.get("_packed_gt_memo")
+        if memo is not None and memo["sig"] == sig and memo["labels"] is labels:
+            return memo
+        cols = [gf['xmin'], gf['ymin'], gf['xmax'], gf['ymax']]
+        n_images, n_classes = len(labels), self.n_classes
+        gt_cat, gt_img, neutral_cat = self._concat_ground_truth(labels, neutral)
+        if gt_cat.shape[0]:
+            cls = gt_cat[:, gf['class_id']].astype(np.int64)
+            keep = (cls >= 1) & (cls <= n_classes)                # rows of other classes are never looked at (the reference masks per class)
+            seg = (cls - 1) * n_images + gt_img
+            order = np.argsort(np.where(keep, seg, n_classes * n_images), kind='stable')[:int(keep.sum())]   # image order inside a segment
+            boxes = gt_cat[order][:, cols].astype(np.float64)
+            per_segment = np.bincount(seg[order], minlength=n_classes * n_images)
+            flags = neutral_cat[order].astype(np.uint8) if neutral_cat is not None else None
+        else:
+            boxes, per_segment, flags = np.zeros((0, 4)), np.zeros(n_classes * n_images, dtype=np.int64), None
+        offsets = np.concatenate([[0], np.cumsum(per_segment)]).astype(np.int32)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        memo = {"sig": sig, "labels": labels,
+                "boxes": nat.to_device(np.ascontiguousarray(boxes), device=dev, dtype=torch.float64),
+                "offsets": nat.to_device(offsets, device=dev, dtype=torch.int32),
+                "neutral": nat.to_device(flags, device=dev, dtype=torch.uint8) if flags is not None else None}
+        self.__dict__["_packed_gt_memo"] = memo
+        return memo
 
     @staticmethod
     def _concat_ground_truth(labels, neutral):

@@ -324,7 +324,7 @@ class GraphedInference:
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         had = model.__dict__.get("_head_overlap")
-        model.__dict__["_head_overlap"] = os.environ.get("SSDHIP_GRAPH_HEAD_OVERLAP", "3")   # two streams inside the graph: explicit dependencies, no allocator subtleties
+        model.__dict__["_head_overlap"] = os.environ.get("SSDHIP_GRAPH_HEAD_OVERLAP", "4")   # two streams inside the graph: explicit dependencies, no allocator subtleties
         try:
             with torch.cuda.stream(self.stream), torch.no_grad():
                 for _ in range(max(1, warmup)):

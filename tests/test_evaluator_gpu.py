@@ -108,3 +108,51 @@ def test_evaluator_errors():
     ev.compute_precision_recall(verbose=False)
     with pytest.raises(ValueError):
         ev.compute_average_precisions(mode="trapezoid")
+
+
+def test_packed_inputs_are_reused_and_follow_their_sources():
+    """Round 6: all classes in one call, predictions / ground truth packed once per object.  A second evaluation at another threshold
+    and border mode reuses the device copies and still equals the oracle; new result lists (or forget_packed_inputs after an in-place
+    edit) are re-packed."""
+    rng = np.random.RandomState(5)
+    n_images, n_classes = 300, 5
+    labels, neutral, image_ids = [], [], []
+    preds = [[] for _ in range(n_classes + 1)]
+    for i in range(n_images):
+        image_ids.append("%06d" % i)
+        g = int(rng.randint(0, 5))
+        cls = rng.randint(1, n_classes + 1, size=g)
+        x0, y0 = rng.randint(0, 300, size=g), rng.randint(0, 200, size=g)
+        lab = np.stack([cls, x0, y0, x0 + rng.randint(8, 90, size=g), y0 + rng.randint(8, 90, size=g)], axis=1).astype(np.int64)
+        labels.append(lab)
+        neutral.append(rng.uniform(size=g) < 0.2)
+        for b in lab:
+            for _ in range(int(rng.randint(0, 3))):
+                j = rng.normal(0, 4, size=4)
+                preds[int(b[0])].append((image_ids[-1], float(np.round(rng.uniform(0.05, 1), 2)), float(b[1] + j[0]), float(b[2] + j[1]),
+                                         float(b[3] + j[2]), float(b[4] + j[3])))
+        for _ in range(int(rng.randint(0, 6))):
+            c = int(rng.randint(1, n_classes))                                # the last class gets no random false positives
+            x, y = rng.uniform(0, 300, size=2)
+            preds[c].append((image_ids[-1], float(np.round(rng.uniform(0.05, 0.5), 2)), float(x), float(y), float(x + 30), float(y + 40)))
+    ev = _evaluator(labels, neutral, image_ids, preds, n_classes=n_classes)
+    for thr, bp, ignore in ((0.5, "include", True), (0.3, "half", True), (0.5, "exclude", False)):
+        got = ev.match_predictions(ignore_neutral_boxes=ignore, matching_iou_threshold=thr, border_pixels=bp, verbose=False, ret=True)
+        want = orc.evaluator_match_predictions(preds, labels, image_ids, neutral, n_classes, ignore_neutral_boxes=ignore,
+                                               matching_iou_threshold=thr, border_pixels=bp)
+        for g, w in zip(got, want):
+            for c in range(1, n_classes + 1):
+                assert np.array_equal(g[c], w[c]), (thr, bp, c)
+    first = ev.__dict__["_packed_pred_memo"]
+    ev.match_predictions(verbose=False)
+    assert ev.__dict__["_packed_pred_memo"] is first                           # same results object: no re-packing
+    # an in-place edit that keeps every length: invisible to the cache until told
+    preds[1][0] = (preds[1][0][0], 0.999) + tuple(preds[1][0][2:])
+    ev.forget_packed_inputs()
+    got = ev.match_predictions(verbose=False, ret=True)
+    want = orc.evaluator_match_predictions(preds, labels, image_ids, neutral, n_classes)
+    assert all(np.array_equal(got[0][c], want[0][c]) and np.array_equal(got[2][c], want[2][c]) for c in range(1, n_classes + 1))
+    # a new results object is packed again by itself
+    ev.prediction_results = [list(rows) for rows in preds]
+    ev.match_predictions(verbose=False)
+    assert ev.__dict__["_packed_pred_memo"] is not first
