@@ -484,6 +484,7 @@ def main():
         flag(dig_any(extra, "ssd512_decode", "sparse_bias7_conf0.01", "cpu", "hip_vs_port_on_the_sample"))
         flag(dig_any(extra, "augmentation", "cpu", "hip_equals_port_on_the_sample"))
         flag(dig_any(extra, "augmentation", "augment_batch_equals_the_per_image_chain_under_each_seed"))
+        flag(dig_any(extra, "augmentation", "augment_batch_global_stream_equals_the_per_image_chain"))
         scal = {"value_reference_precision": dig(extra, "conv_roofline_fp32x3", "images_per_sec"),
                 "reference_precision_ms_per_step": dig(extra, "conv_roofline_fp32x3", "step_ms_fwd_plus_decode"),
                 "value_tamed_heads_img_s": dig(tamed, "value"), "decode_ms_in_step": round(decode_ms_in_step, 5),
@@ -493,6 +494,8 @@ def main():
                 "train_step_ms": dig(extra, "train_step", "ms_per_step"), "train_images_per_sec": dig(extra, "train_step", "images_per_sec"),
                 "loss_forward_ms": dig(extra, "loss", "fwd_ms"), "encoder_kernels_ms": dig(extra, "encoder", "gpu_ms_per_batch_kernels"),
                 "augment_batch_img_s": dig(extra, "augmentation", "augment_batch_images_per_sec"),
+                "augment_batch_global_stream_img_s": dig(extra, "augmentation", "augment_batch_global_stream_images_per_sec"),
+                "evaluator_ms": dig(extra, "evaluator", "gpu_ms_total"),
                 "ssd512_forward_img_s_batch8": dig(extra, "other_models_forward", "ssd512_voc_21_classes", "batch8", "images_per_sec"),
                 "ssd7_forward_img_s_batch8": dig(extra, "other_models_forward", "ssd7_300x300_5_classes", "batch8", "images_per_sec"),
                 "cpu_baseline_ms_per_img_1core": dig(cpu, "ms_per_img"),

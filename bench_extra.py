@@ -660,8 +660,27 @@ def augmentation_leg(dev, B, with_cpu=True):
             # round 5: one seed per image -- the host makes the photometric draws, ONE launch (a wave per image on that image's NumPy
             # MT19937 stream) takes every other decision of the chain, a second builds the tap tables, the gather launch does the pixels
             dt = timed(lambda: aug.augment_batch(batch, labels, seeds=np.random.randint(0, 2 ** 31 - 1, size=B)), 10)
-            # the round-4 form: ONE global stream, the chain's decisions per image on the host (a GPU round trip per sampling round)
-            dt_host = timed(lambda: aug.augment_batch(batch, labels), 3)
+            # round 6: ONE global np.random stream across the batch (the reference's generator semantics), decided on the device by a
+            # single wave walking the images in order, photometric draws included (ssdhip_ssd_augment_decide_stream)
+            dt_stream = timed(lambda: aug.augment_batch(batch, labels), 10)
+            # parity of that path on this batch: == the per-image chain on the same stream (first 4 images + the stream's end)
+            np.random.seed(123)
+            s_img, s_lab = aug.augment_batch(batch, labels)
+            s_next = np.random.uniform()
+            s_img = s_img.cpu().numpy()
+            np.random.seed(123)
+            same_stream = True
+            for i in range(B):
+                wi, wl = aug(host[i], labels[i])
+                if i < 4:
+                    same_stream = same_stream and np.array_equal(wi, s_img[i]) and np.array_equal(wl, s_lab[i])
+            same_stream = same_stream and np.random.uniform() == s_next
+            # the round-4 form of the same semantics: the chain's decisions per image on the host (a GPU round trip per sampling round)
+            os.environ["SSDHIP_AUG_HOST_STREAM"] = "1"
+            try:
+                dt_host = timed(lambda: aug.augment_batch(batch, labels), 3)
+            finally:
+                os.environ.pop("SSDHIP_AUG_HOST_STREAM", None)
             # parity on this batch: image i == the per-image chain under np.random.seed(seed_i), bit for bit (sample of 4 images)
             seeds = np.random.randint(0, 2 ** 31 - 1, size=B)
             got_img, got_lab = aug.augment_batch(batch, labels, seeds=seeds)
@@ -675,12 +694,17 @@ def augmentation_leg(dev, B, with_cpu=True):
         leg["augment_batch_ms_per_batch_wall"] = round(1e3 * dt, 3)
         leg["augment_batch_images_per_sec"] = round(B / dt, 1)
         leg["augment_batch_equals_the_per_image_chain_under_each_seed"] = bool(same)
-        leg["augment_batch_global_stream_images_per_sec"] = round(B / dt_host, 1)
+        leg["augment_batch_global_stream_images_per_sec"] = round(B / dt_stream, 1)
+        leg["augment_batch_global_stream_ms_per_batch_wall"] = round(1e3 * dt_stream, 3)
+        leg["augment_batch_global_stream_equals_the_per_image_chain"] = bool(same_stream)
+        leg["augment_batch_global_stream_host_decisions_images_per_sec"] = round(B / dt_host, 1)
         leg["augment_batch_note"] = ("seeds= : the host makes each image's photometric draws; ssdhip_ssd_augment_decide (a wave per image on "
                                      "that image's NumPy MT19937 stream) takes the chain's other decisions and does the label arithmetic, "
                                      "ssdhip_augment_taps builds the tap tables, one gather launch the pixels; wall clock incl. the label "
-                                     "download.  Without seeds (one global stream, as the reference's generator loop) the decisions stay "
-                                     "on the host, per image: the round-4 figure beside it")
+                                     "download.  Without seeds (ONE global stream across the batch: the reference's generator loop, "
+                                     "object_detection_2d_data_generator.py:1050-1089) a single wave walks the images in order on that stream "
+                                     "and takes every decision incl. the photometric ones (ssdhip_ssd_augment_decide_stream), np.random "
+                                     "continues behind the batch: `global_stream`; the same semantics decided on the host: `host_decisions`")
     except Exception as exc:                                                  # noqa: BLE001 -- a companion figure
         leg["augment_batch_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:160])
     if with_cpu:

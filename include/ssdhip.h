@@ -627,6 +627,21 @@ int ssdhip_augment_taps(const int* geometry_dev, int B, int H, int W, int out_h,
 int ssdhip_ssd_augment_decide(const ssdhip_augment_params* params, int B, const unsigned int* mt_state, const double* labels,
                               const int* n_labels, int* geometry, double* labels_out, int* n_labels_out, unsigned int* mt_state_out,
                               void* stream);
+/* Round 6: the same decisions on ONE generator for the whole batch -- the reference's own semantics: its generator loop
+ * (data_generator/object_detection_2d_data_generator.py:1050-1089) calls SSDDataAugmentation (data_augmentation_chain_original_ssd.py:
+ * 208-280) image after image on the global np.random stream.  One wave walks the images in order and ALSO takes the photometric decisions
+ * (SSDPhotometricDistortions :146-208), written as the per-image programs of ssdhip_image_program: programs_ops [B][16] int32,
+ * programs_args [B][16] float64.  mt_state / mt_state_out [625]: np.random.get_state() before the batch / the state to put back after it.
+ * photo: probability and uniform range of RandomBrightness, RandomContrast, RandomSaturation, RandomHue (in this order);
+ * RandomChannelSwap's probability must be 0 (the original-SSD configuration). */
+typedef struct ssdhip_augment_photo {
+    double prob[4], lower[4], upper[4];
+    double swap_prob;
+} ssdhip_augment_photo;
+int ssdhip_ssd_augment_decide_stream(const ssdhip_augment_params* params, const ssdhip_augment_photo* photo, int B,
+                                     const unsigned int* mt_state, const double* labels, const int* n_labels, int* programs_ops,
+                                     double* programs_args, int* geometry, double* labels_out, int* n_labels_out,
+                                     unsigned int* mt_state_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1791,6 +1791,67 @@ def ssd_augment_decide(params, mt_states, labels, n_labels, device):
     return geo_dev, fetch
 
 
+class _AugPhoto(ctypes.Structure):
+    _fields_ = [("prob", ctypes.c_double * 4), ("lower", ctypes.c_double * 4), ("upper", ctypes.c_double * 4), ("swap_prob", ctypes.c_double)]
+
+
+def ssd_augment_decide_stream(params, photo, mt_state, labels, n_labels, device):
+    """`ssdhip_ssd_augment_decide_stream`: the whole batch on ONE generator stream, photometric decisions included (round 6).  params as
+    ssd_augment_decide; photo = dict(prob, lower, upper: four values each for brightness / contrast / saturation / hue, swap_prob);
+    mt_state (625,) uint32 (np.random.get_state(): the 624 key words + the position), labels (B, 64, 5) float64, n_labels (B,) int32.
+    Returns (ops (B, 16) int32 and args (B, 16) float64 CUDA tensors = the programs of image_program, geometry (B, 12) int32 CUDA tensor,
+    fetch) where fetch() downloads (geometry, labels_out, n_out, mt_state_out (625,)) as NumPy arrays."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_augs_bound", False):
+        lib.ssdhip_ssd_augment_decide_stream.restype = ctypes.c_int
+        lib.ssdhip_ssd_augment_decide_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
+        lib._augs_bound = True
+    q = _AugParams()
+    for k, v in params.items():
+        if isinstance(v, (list, tuple)):
+            arr = getattr(q, k)
+            for i, e in enumerate(v):
+                arr[i] = e
+        else:
+            setattr(q, k, v)
+    ph = _AugPhoto()
+    for i in range(4):
+        ph.prob[i], ph.lower[i], ph.upper[i] = float(photo["prob"][i]), float(photo["lower"][i]), float(photo["upper"][i])
+    ph.swap_prob = float(photo["swap_prob"])
+    B = int(labels.shape[0])
+    if mt_state.shape != (625,) or labels.shape != (B, AUG_MAX_BOXES, 5) or n_labels.shape != (B,):
+        raise SsdHipError("ssd_augment_decide_stream: mt_state (625,), labels (B, 64, 5), n_labels (B,)")
+    # one packed upload: [labels f64 | mt u32 (625, padded to 632) | n i32];
+    # one packed download: [labels_out f64 | args f64 | mt_out u32 (632) | geometry i32 | ops i32 | n_out i32]
+    nl, nm = B * AUG_MAX_BOXES * 5 * 8, 632 * 4
+    host = np.zeros((nl + nm + B * 4,), dtype=np.uint8)
+    host[:nl] = np.ascontiguousarray(labels, dtype=np.float64).view(np.uint8).ravel()
+    host[nl:nl + 625 * 4] = np.ascontiguousarray(mt_state, dtype=np.uint32).view(np.uint8).ravel()
+    host[nl + nm:] = np.ascontiguousarray(n_labels, dtype=np.int32).view(np.uint8).ravel()
+    dev_in = torch.from_numpy(host).to(device)
+    na = B * IMG_PROG * 8
+    o_args, o_mt, o_geo, o_ops, o_n = nl, nl + na, nl + na + nm, nl + na + nm + B * 48, nl + na + nm + B * 48 + B * IMG_PROG * 4
+    dev_out = torch.empty((o_n + B * 4,), dtype=torch.uint8, device=device)
+    base_in, base_out = dev_in.data_ptr(), dev_out.data_ptr()
+    vp = ctypes.c_void_p
+    with torch.cuda.device(device):
+        rc = lib.ssdhip_ssd_augment_decide_stream(ctypes.byref(q), ctypes.byref(ph), B, vp(base_in + nl), vp(base_in), vp(base_in + nl + nm),
+                                                  vp(base_out + o_ops), vp(base_out + o_args), vp(base_out + o_geo), vp(base_out),
+                                                  vp(base_out + o_n), vp(base_out + o_mt), current_stream_ptr(device))
+    check(rc, "ssdhip_ssd_augment_decide_stream")
+    geo_dev = dev_out[o_geo:o_geo + B * 48].view(torch.int32).view(B, 12)
+    ops_dev = dev_out[o_ops:o_ops + B * IMG_PROG * 4].view(torch.int32).view(B, IMG_PROG)
+    args_dev = dev_out[o_args:o_args + na].view(torch.float64).view(B, IMG_PROG)
+
+    def fetch():
+        """(geometry, labels_out, n_out, mt_state_out) as NumPy arrays: ONE download (a host synchronisation: call it last)."""
+        out = dev_out.cpu().numpy()
+        return (out[o_geo:o_geo + B * 48].view(np.int32).reshape(B, 12), out[:nl].view(np.float64).reshape(B, AUG_MAX_BOXES, 5),
+                out[o_n:].view(np.int32), out[o_mt:o_mt + 625 * 4].view(np.uint32).copy())
+    return ops_dev, args_dev, geo_dev, fetch
+
+
 def augment_taps(geo_dev, H, W, out_h, out_w, n_taps):
     """`ssdhip_augment_taps`: the gather launch's tap tables (ix, wx, iy, wy: CUDA tensors (B, out_w | out_h, n_taps)) built on the device
     from the geometry ssd_augment_decide left there."""

@@ -43,6 +43,11 @@ struct AugParams {
 struct Mt {                                               // numpy's rk_state: 624 key words in LDS, the position in a register
     u32* key;
     int pos;
+    // Round 6: a window of 64 TEMPERED outputs in a register, lane i = output `base + i`.  A draw is then one v_readlane with a scalar
+    // index instead of a dependent LDS round trip + the tempering ALU chain -- the batch-serial walk of ssd_augment_stream_kernel is a
+    // chain of ~100-cycle draws otherwise (1.2 ms for a batch of 32).  base < 0: no window loaded.
+    u32 win;
+    int base;
 };
 
 __device__ __forceinline__ void mt_twist(u32* key, int lane) {
@@ -67,17 +72,24 @@ __device__ __forceinline__ void mt_twist(u32* key, int lane) {
 }
 
 __device__ __forceinline__ u32 mt_u32(Mt& s, int lane) {
-    if (s.pos == 624) { mt_twist(s.key, lane); s.pos = 0; }
-    u32 y = s.key[s.pos++];
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
+    if (s.pos == 624) { mt_twist(s.key, lane); s.pos = 0; s.base = -1; }
+    if (s.base < 0 || s.pos - s.base >= 64) {            // (the position only moves forward inside a block of 624)
+        s.base = s.pos;
+        const int i = s.pos + lane;
+        u32 y = s.key[i < 624 ? i : 623];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        s.win = y;
+    }
+    const int k = __builtin_amdgcn_readfirstlane(s.pos - s.base);
+    ++s.pos;
+    return (u32)__builtin_amdgcn_readlane((int)s.win, k);
 }
 __device__ __forceinline__ double mt_double(Mt& s, int lane) {           // rk_double / random_sample
     const u32 a = mt_u32(s, lane) >> 5, b = mt_u32(s, lane) >> 6;
-    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);   // (x 2^-53: exact, the same double as NumPy's division)
 }
 __device__ __forceinline__ double mt_uniform(Mt& s, int lane, double lo, double hi) { return lo + (hi - lo) * mt_double(s, lane); }
 // np.random.randint(lo, hi) for int64 results: masked rejection sampling on 32-bit words (numpy/random/_bounded_integers: use_masked)
@@ -102,18 +114,11 @@ __device__ __forceinline__ int aug_position(Mt& s, int lane, int extent, int siz
     return (int)(room >= 0 ? mt_randint(s, lane, 0, (long long)room + 1) : mt_randint(s, lane, room, 1));
 }
 
-// one wave per image
-__global__ __launch_bounds__(64) void ssd_augment_decide_kernel(AugParams p, const u32* __restrict__ mt_in, const double* __restrict__ lab_in,
-                                                                const int* __restrict__ n_in, int* __restrict__ geo,
-                                                                double* __restrict__ lab_out, int* __restrict__ n_out,
-                                                                u32* __restrict__ mt_out) {
-    __shared__ u32 key[624];
-    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
-    for (int i = lane; i < 624; i += 64) key[i] = mt_in[(size_t)b * 625 + i];
-    Mt s;
-    s.key = key;
-    s.pos = (int)mt_in[(size_t)b * 625 + 624];
-    __syncthreads();
+// The geometric decisions of ONE image (SSDExpand, SSDRandomCrop, RandomFlip, ResizeRandomInterp + the label arithmetic) by one wave on
+// the generator state `s`: what SSDDataAugmentation.__call__ does behind the photometric part (:208-280).
+__device__ __forceinline__ void aug_decide_image(const AugParams& p, Mt& s, const int lane, const int b, const double* __restrict__ lab_in,
+                                                 const int* __restrict__ n_in, int* __restrict__ geo, double* __restrict__ lab_out,
+                                                 int* __restrict__ n_out) {
     const int n = n_in[b];
     bool alive = lane < n;
     double cls = 0.0, x0 = 0.0, y0 = 0.0, x1 = 0.0, y1 = 0.0;
@@ -196,10 +201,85 @@ __global__ __launch_bounds__(64) void ssd_augment_decide_kernel(AugParams p, con
     if (lane == 0) {
         n_out[b] = __popcll(keep);
         for (int i = 0; i < 12; ++i) geo[(size_t)b * 12 + i] = g[i];
-        mt_out[(size_t)b * 625 + 624] = (u32)s.pos;
     }
+}
+
+// one wave per image, every image on its OWN generator state (augment_batch(seeds=...), round 5)
+__global__ __launch_bounds__(64) void ssd_augment_decide_kernel(AugParams p, const u32* __restrict__ mt_in, const double* __restrict__ lab_in,
+                                                                const int* __restrict__ n_in, int* __restrict__ geo,
+                                                                double* __restrict__ lab_out, int* __restrict__ n_out,
+                                                                u32* __restrict__ mt_out) {
+    __shared__ u32 key[624];
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+    for (int i = lane; i < 624; i += 64) key[i] = mt_in[(size_t)b * 625 + i];
+    Mt s;
+    s.key = key;
+    s.pos = (int)mt_in[(size_t)b * 625 + 624];
+    s.base = -1; s.win = 0u;
+    __syncthreads();
+    aug_decide_image(p, s, lane, b, lab_in, n_in, geo, lab_out, n_out);
+    if (lane == 0) mt_out[(size_t)b * 625 + 624] = (u32)s.pos;
     __syncthreads();
     for (int i = lane; i < 624; i += 64) mt_out[(size_t)b * 625 + i] = key[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the reference's OWN contract -- ONE generator for the whole batch.  Its generator loop calls the chain image after image on the
+// global np.random stream (object_detection_2d_data_generator.py:1050-1089 -> data_augmentation_chain_original_ssd.py:208-280), so the
+// draws of image i + 1 start where image i's ended: inherently serial, and cheap (a few dozen draws per image).  ONE wave walks the batch
+// in order on that one stream and takes EVERY decision, the photometric ones included (SSDPhotometricDistortions :146-208: which of the
+// two sequences, and per op "does it fire" + its parameter), writing them as the per-image programs ssdhip_image_program runs; the
+// geometric half is aug_decide_image.  Out: the programs, the geometry, the labels and the generator state behind the LAST image, which
+// the host writes back into np.random -- the stream continues exactly as if the reference's loop had run.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct AugPhoto {                                         // RandomBrightness / Contrast / Saturation / Hue: prob, uniform(lo, hi); swap: prob 0
+    double prob[4], lo[4], hi[4], swap_prob;
+};
+constexpr int AUG_PROG = 16;                              // steps of a program (include/ssdhip.h: SSDHIP_IMG_PROG)
+enum { OP_END = 0, OP_TO_F32 = 1, OP_TO_U8 = 2, OP_BRIGHTNESS = 3, OP_CONTRAST = 4, OP_SATURATION = 5, OP_HUE = 6, OP_RGB2HSV = 7, OP_HSV2RGB = 8 };
+
+__global__ __launch_bounds__(64) void ssd_augment_stream_kernel(AugParams p, AugPhoto ph, int B, const u32* __restrict__ mt_in,
+                                                                const double* __restrict__ lab_in, const int* __restrict__ n_in,
+                                                                int* __restrict__ prog_ops, double* __restrict__ prog_args,
+                                                                int* __restrict__ geo, double* __restrict__ lab_out, int* __restrict__ n_out,
+                                                                u32* __restrict__ mt_out) {
+    __shared__ u32 key[624];
+    const int lane = (int)threadIdx.x;
+    for (int i = lane; i < 624; i += 64) key[i] = mt_in[i];
+    Mt s;
+    s.key = key;
+    s.pos = (int)mt_in[624];
+    s.base = -1; s.win = 0u;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        // ---- SSDPhotometricDistortions.__call__: `if np.random.choice(2)` picks the sequence, every random op draws uniform(0, 1) and,
+        //      when it fires (>= 1 - prob), its parameter; RandomChannelSwap(prob 0) draws and never fires ---------------------------------
+        int ops[AUG_PROG];
+        double args[AUG_PROG];
+        int k = 0;
+        auto push = [&](int op, double a) { ops[k] = op; args[k] = a; ++k; };
+        auto maybe = [&](int which, int op) {            // RandomX.draw(): the firing draw, then uniform(lower, upper)
+            if (mt_uniform(s, lane, 0.0, 1.0) >= (1.0 - ph.prob[which])) push(op, mt_uniform(s, lane, ph.lo[which], ph.hi[which]));
+        };
+        const bool contrast_first = mt_randint(s, lane, 0, 2) != 0;
+        push(OP_TO_F32, 0.0);
+        maybe(0, OP_BRIGHTNESS);
+        if (contrast_first) maybe(1, OP_CONTRAST);
+        push(OP_TO_U8, 0.0); push(OP_RGB2HSV, 0.0); push(OP_TO_F32, 0.0);
+        maybe(2, OP_SATURATION);
+        maybe(3, OP_HUE);
+        push(OP_TO_U8, 0.0); push(OP_HSV2RGB, 0.0);
+        if (!contrast_first) { push(OP_TO_F32, 0.0); maybe(1, OP_CONTRAST); push(OP_TO_U8, 0.0); }
+        (void)mt_uniform(s, lane, 0.0, 1.0);             // RandomChannelSwap(prob = 0.0): uniform(0, 1) >= 1.0 never holds
+        for (; k < AUG_PROG; ) push(OP_END, 0.0);
+        if (lane == 0)
+            for (int i = 0; i < AUG_PROG; ++i) { prog_ops[(size_t)b * AUG_PROG + i] = ops[i]; prog_args[(size_t)b * AUG_PROG + i] = args[i]; }
+        // ---- the geometric half on the same stream ------------------------------------------------------------------------------------
+        aug_decide_image(p, s, lane, b, lab_in, n_in, geo, lab_out, n_out);
+    }
+    if (lane == 0) mt_out[624] = (u32)s.pos;
+    __syncthreads();
+    for (int i = lane; i < 624; i += 64) mt_out[i] = key[i];
 }
 
 
@@ -335,16 +415,53 @@ __global__ __launch_bounds__(128) void aug_taps_kernel(const int* __restrict__ g
 
 using namespace ssdhip;
 
+static int aug_params_from(const ssdhip_augment_params* q, AugParams& p);
+
+// The whole batch on ONE generator stream, photometric decisions included (round 6; the reference's own generator semantics).
+// mt_state / mt_state_out [625]; programs_ops [B][16] int32 + programs_args [B][16] float64: the per-image programs of
+// ssdhip_image_program; the rest as ssdhip_ssd_augment_decide.  photo: probabilities and uniform ranges of RandomBrightness,
+// RandomContrast, RandomSaturation, RandomHue (in that order); RandomChannelSwap must have probability 0 (SSDPhotometricDistortions).
+extern "C" int ssdhip_ssd_augment_decide_stream(const ssdhip_augment_params* q, const ssdhip_augment_photo* photo, int B,
+                                                const unsigned int* mt_state, const double* labels, const int* n_labels, int* programs_ops,
+                                                double* programs_args, int* geometry, double* labels_out, int* n_labels_out,
+                                                unsigned int* mt_state_out, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!q || !photo || B <= 0 || !mt_state || !labels || !n_labels || !programs_ops || !programs_args || !geometry || !labels_out ||
+        !n_labels_out || !mt_state_out)
+        return SSDHIP_E_BADARG;
+    if (photo->swap_prob != 0.0) return SSDHIP_E_BADARG;
+    AugParams p;
+    const int rc = aug_params_from(q, p);
+    if (rc != SSDHIP_OK) return rc;
+    AugPhoto ph;
+    for (int i = 0; i < 4; ++i) {
+        if (!(photo->prob[i] >= 0.0 && photo->prob[i] <= 1.0)) return SSDHIP_E_BADARG;
+        ph.prob[i] = photo->prob[i]; ph.lo[i] = photo->lower[i]; ph.hi[i] = photo->upper[i];
+    }
+    ph.swap_prob = 0.0;
+    hipLaunchKernelGGL(ssd_augment_stream_kernel, dim3(1), dim3(64), 0, stream, p, ph, B, mt_state, labels, n_labels, programs_ops,
+                       programs_args, geometry, labels_out, n_labels_out, mt_state_out);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 extern "C" int ssdhip_ssd_augment_decide(const ssdhip_augment_params* q, int B, const unsigned int* mt_state, const double* labels,
                                          const int* n_labels, int* geometry, double* labels_out, int* n_labels_out,
                                          unsigned int* mt_state_out, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!q || B <= 0 || !mt_state || !labels || !n_labels || !geometry || !labels_out || !n_labels_out || !mt_state_out) return SSDHIP_E_BADARG;
+    AugParams p;
+    const int rc = aug_params_from(q, p);
+    if (rc != SSDHIP_OK) return rc;
+    hipLaunchKernelGGL(ssd_augment_decide_kernel, dim3((unsigned)B), dim3(64), 0, stream, p, mt_state, labels, n_labels, geometry,
+                       labels_out, n_labels_out, mt_state_out);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+static int aug_params_from(const ssdhip_augment_params* q, AugParams& p) {
     if (q->img_height <= 0 || q->img_width <= 0 || q->out_height <= 0 || q->out_width <= 0) return SSDHIP_E_BADARG;
     if (q->n_bounds < 1 || q->n_bounds > 8 || q->n_modes < 1 || q->n_modes > 8 || q->n_trials < 1) return SSDHIP_E_BADARG;
     if (!(q->expand_min_scale >= 1.0) || !(q->expand_max_scale > q->expand_min_scale)) return SSDHIP_E_BADARG;       // a canvas, never a crop
     if (!(q->crop_min_scale > 0.0) || !(q->crop_max_scale <= 1.0) || !(q->crop_max_scale > q->crop_min_scale)) return SSDHIP_E_BADARG;
-    AugParams p;
     p.H = q->img_height; p.W = q->img_width;
     p.exp_prob = q->expand_prob; p.exp_min = q->expand_min_scale; p.exp_max = q->expand_max_scale;
     p.crop_prob = q->crop_prob; p.crop_min = q->crop_min_scale; p.crop_max = q->crop_max_scale;
@@ -353,9 +470,7 @@ extern "C" int ssdhip_ssd_augment_decide(const ssdhip_augment_params* q, int B, 
     for (int i = 0; i < 8; ++i) { p.cdf[i] = q->bound_cdf[i]; p.lower[i] = q->bound_lower[i]; p.upper[i] = q->bound_upper[i]; p.modes[i] = q->interpolation_modes[i]; }
     p.flip_prob = q->flip_prob; p.n_modes = q->n_modes; p.out_h = q->out_height; p.out_w = q->out_width;
     p.max_rounds = q->max_rounds > 0 ? q->max_rounds : 100000;
-    hipLaunchKernelGGL(ssd_augment_decide_kernel, dim3((unsigned)B), dim3(64), 0, stream, p, mt_state, labels, n_labels, geometry,
-                       labels_out, n_labels_out, mt_state_out);
-    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+    return SSDHIP_OK;
 }
 
 extern "C" int ssdhip_augment_taps(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* ix_dev,

@@ -154,6 +154,14 @@ class SSDDataAugmentation:
             raise TypeError("augment_batch takes a (B, H, W, 3) CUDA uint8 batch")
         if len(labels) != images.shape[0]:
             raise ValueError("one label array per image")
+        if os.environ.get("SSDHIP_AUG_HOST_STREAM", "0") != "1":
+            # Round 6: the reference's own semantics -- ONE global np.random stream across the batch -- decided on the device: a single wave
+            # walks the images in order on that stream (ssdhip_ssd_augment_decide_stream: photometric AND geometric decisions, label
+            # arithmetic), the pixel launches are the seeded path's, and the generator state behind the last image goes back into
+            # np.random.  None: a configuration / label layout the kernel does not cover -> the host loop below.
+            done = self._augment_batch_seeded(images, labels, None)
+            if done is not None:
+                return done
         for t in (self.expand, self.random_crop, self.random_flip, self.resize):
             t.labels_format = self.labels_format
         h, w = int(images.shape[1]), int(images.shape[2])
@@ -204,7 +212,8 @@ class SSDDataAugmentation:
         if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3):
             raise TypeError("augment_batch takes a (B, H, W, 3) CUDA uint8 batch")
         B, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
-        if len(labels) != B or len(seeds) != B:
+        stream_mode = seeds is None                      # one global generator for the whole batch (the reference's contract)
+        if len(labels) != B or (not stream_mode and len(seeds) != B):
             raise ValueError("one label array and one seed per image")
         lf = self.labels_format
         cols = [lf['class_id'], lf['xmin'], lf['ymin'], lf['xmax'], lf['ymax']]
@@ -213,6 +222,24 @@ class SSDDataAugmentation:
         dtypes = {a.dtype for a in arrs}
         fast = (params is not None and len(dtypes) == 1 and next(iter(dtypes)) in (np.dtype(np.int64), np.dtype(np.float64))
                 and all(a.ndim == 2 and a.shape[1] == 5 and a.shape[0] <= nat.AUG_MAX_BOXES for a in arrs) and sorted(cols) == [0, 1, 2, 3, 4])
+        if stream_mode:
+            photo = self._photo_params()
+            state = np.random.get_state()
+            if not fast or photo is None or state[0] != 'MT19937' or B == 0:
+                return None
+            lab_in = np.zeros((B, nat.AUG_MAX_BOXES, 5), dtype=np.float64)
+            n_in = np.empty((B,), dtype=np.int32)
+            for i, a in enumerate(arrs):
+                n_in[i] = a.shape[0]
+                if a.shape[0]:
+                    lab_in[i, :a.shape[0]] = a[:, cols]
+            mt = np.empty((625,), dtype=np.uint32)
+            mt[:624], mt[624] = state[1], state[2]
+            ops_dev, args_dev, geo_dev, fetch = nat.ssd_augment_decide_stream(params, photo, mt, lab_in, n_in, images.device)
+            distorted = nat.image_program(images.contiguous(), ops_dev, args_dev, torch.uint8)     # both sequences end in 'to_u8'
+            out, out_labels, mt_out = self._gather_from_decisions(images, distorted, geo_dev, fetch, arrs[0].dtype, cols, B, h, w)
+            np.random.set_state((state[0], mt_out[:624], int(mt_out[624]), state[3], state[4]))    # the stream goes on behind the batch
+            return out, out_labels
         saved = np.random.get_state()
         try:
             if not fast:                                 # anything the kernel does not cover: the per-image chain's own code, seeded per image
@@ -247,10 +274,28 @@ class SSDDataAugmentation:
             np.random.set_state(saved)
         distorted = iop.run_batch(images, programs)
         geo_dev, fetch = nat.ssd_augment_decide(params, mt, lab_in, n_in, images.device)
+        out, out_labels, mt_out = self._gather_from_decisions(images, distorted, geo_dev, fetch, arrs[0].dtype, cols, B, h, w)
+        self.__dict__["_last_generator_states"] = mt_out     # (B, 625): where each image's stream stands behind its chain (tests)
+        return out, out_labels
+
+    def _photo_params(self):
+        """SSDPhotometricDistortions' configuration as the fields of ssdhip_augment_photo, or None when it is not the original-SSD one
+        (RandomChannelSwap must never fire: the device walk only consumes its firing draw)."""
+        pd = self.photometric_distortions
+        ops = (pd.random_brightness, pd.random_contrast, pd.random_saturation)
+        if pd.random_channel_swap.prob != 0.0 or not all(0.0 <= o.prob <= 1.0 for o in ops + (pd.random_hue,)):
+            return None
+        return dict(prob=[float(o.prob) for o in ops] + [float(pd.random_hue.prob)],
+                    lower=[float(o.lower) for o in ops] + [-float(pd.random_hue.max_delta)],
+                    upper=[float(o.upper) for o in ops] + [float(pd.random_hue.max_delta)], swap_prob=0.0)
+
+    def _gather_from_decisions(self, images, distorted, geo_dev, fetch, dt, cols, B, h, w):
+        """The pixel half behind the device-side decisions: tap tables built on the device from `geo_dev`, ONE gather launch, then the one
+        download of the call (labels, geometry, generator state).  Returns (batch, labels, generator state(s))."""
+        from .. import _native as nat
         out_h, out_w = int(self.resize.height), int(self.resize.width)
         # tap tables wide enough for the true area filter of the largest possible source (an expanded, uncropped image)
         n_taps = max(8, int(np.ceil(float(self.expand.expand.patch_coord_generator.max_scale) * max(h / out_h, w / out_w))) + 1)
-        dt = arrs[0].dtype
         inv = np.argsort(cols)
         if n_taps <= 64 and os.environ.get("SSDHIP_AUG_HOST_TAPS", "0") != "1":
             # ---- tap tables built on the device from the decisions, the gather launch behind them; the labels come back last (the only
@@ -263,10 +308,8 @@ class SSDDataAugmentation:
                 self.__dict__["_bg_rows"] = bg
             out = nat.image_resize_gather_u8(distorted.contiguous(), out_h, out_w, ix, wx, iy, wy, bg[1])
             geo, lab_out, n_out, mt_out = fetch()
-            self.__dict__["_last_generator_states"] = mt_out
-            return out, [np.ascontiguousarray(lab_out[i, :int(n_out[i])][:, inv]).astype(dt) for i in range(B)]
+            return out, [np.ascontiguousarray(lab_out[i, :int(n_out[i])][:, inv]).astype(dt) for i in range(B)], mt_out
         geo, lab_out, n_out, mt_out = fetch()
-        self.__dict__["_last_generator_states"] = mt_out     # (B, 625): where each image's stream stands behind its chain (tests)
         # ---- the recorded geometry of every image -> one gather launch; the labels back in the caller's column order and dtype ----------
         lazies, out_labels = [], []
         for i in range(B):
@@ -280,4 +323,4 @@ class SSDDataAugmentation:
                 img = img[:, ::-1]
             lazies.append(img.resize(self.resize.height, self.resize.width, int(g[11])))
             out_labels.append(np.ascontiguousarray(lab_out[i, :int(n_out[i])][:, inv]).astype(dt))
-        return iop.gather_batch(distorted, lazies), out_labels
+        return iop.gather_batch(distorted, lazies), out_labels, mt_out

@@ -293,3 +293,86 @@ def test_augment_batch_with_seeds_equals_the_chain_under_each_seed(geometry):
             rs = np.random.RandomState()
             rs.set_state(("MT19937", states[i, :624].copy(), int(states[i, 624]), 0, 0.0))
             assert rs.uniform() == nxt[i], "image %d: the device left the stream elsewhere" % i
+
+
+@pytest.mark.gpu
+def test_augment_batch_global_stream_on_the_device_equals_the_reference_chain():
+    """Round 6: `augment_batch(images, labels)` WITHOUT seeds keeps the reference's contract -- one global np.random
+    stream across the batch (object_detection_2d_data_generator.py:1050-1089 -> data_augmentation_chain_original_ssd.py:208-280) -- with
+    every decision, photometric ones included, taken by one wave on the device (ssdhip_ssd_augment_decide_stream).
+    (a) the ten `ssd_augmentation` cases of the reference-generated fixture, each as a batch of one under the case's seed: pixels,
+        labels and the three random numbers that follow, bit for bit against the REAL reference's outputs;
+    (b) a VOC-sized batch of 32 and a second batch behind it: == the per-image host loop (SSDHIP_AUG_HOST_STREAM=1) and == the
+        per-image chain, pixels, labels and the FULL generator state (np.random.get_state()) after each batch; int64 and float64 labels;
+    (c) a generator position on the twist boundary (624) and right behind a twist."""
+    import os
+    import torch
+    from ssd_keras_amd.data_generator.data_augmentation_chain_original_ssd import SSDDataAugmentation
+    z = util.load("image_ops")
+    n = 0
+    for i, case in enumerate(ic.CASES):
+        if case["op"] != "ssd_augmentation":
+            continue
+        img, labels = ic.make_inputs(case["seed"], case["n_boxes"], size=(40, 52))
+        aug = SSDDataAugmentation(img_height=case["out"][0], img_width=case["out"][1])
+        np.random.seed(case["seed"])
+        got_img, got_lab = aug.augment_batch(torch.from_numpy(np.ascontiguousarray(img)[None]).cuda(), [labels])
+        probe = np.random.uniform(0, 1, size=3)
+        pre = "i%03d_" % i
+        assert np.array_equal(got_img[0].cpu().numpy(), z[pre + "image"]), case
+        assert np.array_equal(got_lab[0], z[pre + "labels"]) and got_lab[0].dtype == z[pre + "labels"].dtype, case
+        assert np.array_equal(probe, z[pre + "probe"]), case
+        n += 1
+    assert n == 10
+
+    def states_equal(a, b):
+        return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+    for dt in (np.int64, np.float64):
+        rng = np.random.RandomState(77)
+        B, H, W = 32, 375, 500
+        batches = [rng.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8) for _ in range(2)]
+        labels = []
+        for _ in range(2):
+            cur = []
+            for k in range(B):
+                g = rng.randint(0 if k % 7 == 6 else 1, 8)
+                x0, y0 = rng.randint(0, W - 60, size=g), rng.randint(0, H - 60, size=g)
+                cur.append(np.stack([rng.randint(1, 21, size=g), x0, y0, x0 + rng.randint(10, 60, size=g), y0 + rng.randint(10, 60, size=g)],
+                                    axis=1).astype(dt))
+            labels.append(cur)
+        aug = SSDDataAugmentation(img_height=300, img_width=300)
+        np.random.seed(5)
+        want, want_states = [], []
+        for bi in range(2):
+            want.append([aug(batches[bi][k], labels[bi][k]) for k in range(B)])
+            want_states.append(np.random.get_state())
+        for host in ("0", "1"):
+            os.environ["SSDHIP_AUG_HOST_STREAM"] = host
+            try:
+                np.random.seed(5)
+                for bi in range(2):
+                    got_img, got_lab = aug.augment_batch(torch.from_numpy(batches[bi]).cuda(), labels[bi])
+                    assert states_equal(np.random.get_state(), want_states[bi]), (dt, host, bi)
+                    g = got_img.cpu().numpy()
+                    for k in range(B):
+                        assert np.array_equal(g[k], want[bi][k][0]), (dt, host, bi, k, int((g[k] != want[bi][k][0]).sum()))
+                        assert np.array_equal(got_lab[k], want[bi][k][1]) and got_lab[k].dtype == want[bi][k][1].dtype, (dt, host, bi, k)
+            finally:
+                os.environ.pop("SSDHIP_AUG_HOST_STREAM", None)
+
+    # (c) the generator's position at 624 (every word of the block consumed: the next draw twists) and at 2
+    small = np.random.RandomState(3).randint(0, 256, size=(5, 60, 80, 3)).astype(np.uint8)
+    small_lab = [np.array([[3, 10, 12, 50, 44], [7, 30, 20, 70, 55]], dtype=np.int64) for _ in range(5)]
+    aug = SSDDataAugmentation(img_height=48, img_width=48)
+    for burn in (312, 313):                                 # 312 doubles = 624 words -> pos 624; one more double -> pos 2 of the next block
+        np.random.seed(11)
+        np.random.random_sample(burn)
+        assert np.random.get_state()[2] == (624 if burn == 312 else 2)
+        want = [aug(small[k], small_lab[k]) for k in range(5)]
+        want_state = np.random.get_state()
+        np.random.seed(11)
+        np.random.random_sample(burn)
+        got_img, got_lab = aug.augment_batch(torch.from_numpy(small).cuda(), small_lab)
+        assert states_equal(np.random.get_state(), want_state), burn
+        assert all(np.array_equal(got_img[k].cpu().numpy(), want[k][0]) and np.array_equal(got_lab[k], want[k][1]) for k in range(5)), burn
