@@ -543,6 +543,18 @@ int ssdhip_image_program(const void* x, int in_dtype, void* y, int out_dtype, in
                          const int* ops_dev, const double* args_dev, void* stream);
 int ssdhip_image_resize_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, const int* ix_dev, const double* wx_dev,
                            int nx, const int* iy_dev, const double* wy_dev, int ny, void* stream);
+/* cv2.resize on 8-bit images with OpenCV's own arithmetic (round 6; data_generator/object_detection_2d_geometric_ops.py:70-72 calls
+ * cv2.resize -> imgproc/resize.cpp): `kind` 0 nearest, 1 linear (11-bit fixed-point coefficients, the two-stage vertical rounding),
+ * 2 cubic / Lanczos-4 (fixed point, (sum + 2^21) >> 22), 3 area (float32 tables, cvRound), 4 fast area (block sum * (1.f / area)),
+ * 5 fast area 2 x 2 ((sum + 2) >> 2), 6 copy; the tables hold the shorts / float32 weights / ones as float64 values.
+ * ssdhip_image_resize_cv_u8: one plan for the batch, ix / wx [Wo][nx], iy / wy [Ho][ny].  ssdhip_image_resize_gather_cv_u8: a plan per
+ * image, plan [B][4] = kind, area, taps per column, taps per row; tables [B][Wo][nx] / [B][Ho][ny], nx, ny >= 2; index -1 reads
+ * background [B][C] (the augmentation chain's expansion canvas). */
+int ssdhip_image_resize_cv_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, int kind, int area, const int* ix_dev,
+                              const double* wx_dev, int nx, const int* iy_dev, const double* wy_dev, int ny, void* stream);
+int ssdhip_image_resize_gather_cv_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, const int* plan_dev,
+                                     const int* ix_dev, const double* wx_dev, int nx, const int* iy_dev, const double* wy_dev, int ny,
+                                     const void* background_dev, void* stream);
 int ssdhip_image_hist_u8(const void* x, long long n_pixels, int C, int channel, unsigned int* hist_dev, void* stream);
 int ssdhip_image_lut_u8(const void* x, void* y, long long n_values, int C, int channel_mask, const void* table_dev, void* stream);
 
@@ -624,6 +636,11 @@ typedef struct ssdhip_augment_params {
  * [B][out_w][n_taps], iy / wy [B][out_h][n_taps]; n_taps >= 8 and >= ceil(largest source / output extent ratio) + 1 (the area filter). */
 int ssdhip_augment_taps(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* ix_dev, double* wx_dev,
                         int* iy_dev, double* wy_dev, void* stream);
+/* ssdhip_augment_plans (round 6): as ssdhip_augment_taps, with cv2.resize's own 8-bit arithmetic: plan [B][4] = kind, area, taps per
+ * column, taps per row and the tables of ssdhip_image_resize_gather_cv_u8 (fixed-point shorts / float32 area weights / ones as float64
+ * values); n_taps >= 8 and >= ceil(largest source / output extent ratio) + 2. */
+int ssdhip_augment_plans(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* plan_dev, int* ix_dev,
+                         double* wx_dev, int* iy_dev, double* wy_dev, void* stream);
 int ssdhip_ssd_augment_decide(const ssdhip_augment_params* params, int B, const unsigned int* mt_state, const double* labels,
                               const int* n_labels, int* geometry, double* labels_out, int* n_labels_out, unsigned int* mt_state_out,
                               void* stream);

@@ -5,9 +5,10 @@ object_detection_2d_geometric_ops.py:70-72 (cv2.resize).
 PARITY UNPINNED for these primitives: OpenCV (opencv-python, the reference's un-pinned dependency, README.md:143-150) is not installed
 here and the reference holds no image fixtures.  The 8-bit colour conversions, the LUT and the histogram equalisation follow the
 algorithms of OpenCV's imgproc sources as published (fixed-point tables of color_hsv / color_yuv, equalizeHist's scale-and-round);
-`resize` is the documented sampling geometry (pixel centres, src = (dst + 0.5) * scale - 0.5, replicated border) with float64
-weights and ONE rounding at the end -- OpenCV's own 8-bit paths use 11-bit fixed-point weights, so a real cv2 result can differ from
-this one by one grey level.  What IS pinned with these primitives standing in for cv2: everything the reference itself does around
+`resize` (round 6) follows imgproc/resize.cpp's 8-bit arithmetic itself: 11-bit fixed-point coefficients, int32 rows, the two-stage
+vertical rounding of the linear path and the `(... + (1 << 21)) >> 22` of the cubic / Lanczos ones, ResizeAreaFast / ResizeArea for
+shrinking INTER_AREA (the block comment in front of the resize functions lists every rule and the two that stay platform-defined in
+OpenCV itself).  What IS pinned with these primitives standing in for cv2: everything the reference itself does around
 them (tests/golden/make_golden.py gen_image_ops: the real reference classes run with a cv2 stub built on this module -- dtype
 conversions, NumPy arithmetic and clipping, the order of random draws, label arithmetic)."""
 import numpy as np
@@ -151,86 +152,280 @@ def equalize_hist(plane):
     return tab[plane]
 
 
-# ---- resize: separable resampling with per-output-coordinate taps --------------------------------------------------------------
-def _cubic_w(t, a=-0.75):
-    t = np.abs(t)
-    return np.where(t <= 1, ((a + 2) * t - (a + 3)) * t * t + 1, np.where(t < 2, ((a * t - 5 * a) * t + 8 * a) * t - 4 * a, 0.0))
+# ---- cv2.resize for 8-bit images, with the ARITHMETIC of OpenCV's imgproc/resize.cpp (3.4 / 4.x, the C++ reference paths) -----------
+# Round 6.  cv::resize on CV_8U is not "weights x pixels, one rounding":
+#   * INTER_LINEAR / INTER_CUBIC / INTER_LANCZOS4 (and INTER_AREA when an axis grows: `area_mode`) use 11-bit FIXED-POINT coefficients
+#     (INTER_RESIZE_COEF_BITS = 11): per output column / row the float32 kernel values are rounded to `short`
+#     (saturate_cast<short>(coeff * 2048), cvRound = nearest-even), HResize* accumulates uchar x short products in int32 rows, and
+#     VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>> computes
+#         dst = uchar(( ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 ) >> 2)
+#     (the two-stage form its SIMD twin _mm_mulhi_epi16 dictates), VResizeCubic / VResizeLanczos4
+#         dst = saturate_cast<uchar>((S0 b0 + S1 b1 + ... + (1 << 21)) >> 22);
+#   * horizontally the linear kernel resets (sx, fx) at the borders (sx < 0 -> (0, 0); sx >= width - 1 -> (width - 1, 0)), vertically
+#     the ROWS are clamped and the coefficients kept; cubic / Lanczos clamp their tap indices on both axes;
+#   * INTER_AREA with both scales >= 1: integer scales -> ResizeAreaFast (sum of the block, saturate_cast<uchar>(sum * (1.f / area)),
+#     the 2 x 2 block as (sum + 2) >> 2); otherwise ResizeArea with computeResizeAreaTab's float32 alpha / beta tables accumulated in
+#     float32 in table order and saturate_cast<uchar> (cvRound) at the end;
+#   * INTER_LINEAR at exactly 2 x 2 shrinking IS the fast area path; equal sizes are a copy; INTER_NEAREST takes
+#     min(floor(dst * (1 / (dst_size / src_size))), src - 1).
+# What remains of the reservation in the module docstring: OpenCV's SIMD builds run the cubic vertical pass in float32 (identical except
+# on exact ties of the last rounding), and interpolateLanczos4 calls the platform's sin / cos -- here `det_sincos`, a fixed Horner chain
+# shared with the product (within 1 ulp of libm's; the float32 cast and the 11-bit rounding absorb that except on measure-zero ties).
+INTER_RESIZE_COEF_BITS = 11
+INTER_RESIZE_COEF_SCALE = 1 << INTER_RESIZE_COEF_BITS
+KIND_NEAREST, KIND_LINEAR, KIND_KERNEL, KIND_AREA, KIND_AREA_FAST, KIND_AREA_FAST2, KIND_COPY = 0, 1, 2, 3, 4, 5, 6
+_F32 = np.float32
+_CV_PI = 3.1415926535897932384626433832795
 
 
-def _lanczos_w(t, a=4):
-    t = np.asarray(t, dtype=np.float64)
-    out = np.where(np.abs(t) < 1e-12, 1.0, 0.0)
-    nzm = (np.abs(t) >= 1e-12) & (np.abs(t) < a)
-    tt = np.where(nzm, t, 1.0)
-    val = a * np.sin(np.pi * tt) * np.sin(np.pi * tt / a) / (np.pi * np.pi * tt * tt)
-    return np.where(nzm, val, out)
+def _sat_short(v):
+    """saturate_cast<short>(float): cvRound (nearest, ties to even), clamped."""
+    return np.clip(np.rint(np.asarray(v, dtype=np.float64)), -32768, 32767).astype(np.int64)
 
 
-def resize_taps(n_src, n_dst, interp, area_linear=False):
-    """(index [n_dst, T] int32, weight [n_dst, T] float64) of one axis: dst[i] = sum_t weight[i, t] * src[index[i, t]].
-    `area_linear`: INTER_AREA when NOT both axes shrink -- OpenCV's resize() then emulates it "using some variant of bilinear" on BOTH
-    axes (imgproc/resize.cpp, 3.x / 4.x: `area_mode`): sx = floor(dx scale), fx = (float)((dx + 1) - (sx + 1) / scale), fx <= 0 -> 0 else
-    its fractional part; taps (sx, sx + 1) with weights (1 - fx, fx), clamped at the last pixel."""
-    scale = n_src / n_dst
-    i = np.arange(n_dst, dtype=np.float64)
-    if interp == INTER_AREA and area_linear:
-        sx = np.floor(i * scale)
-        fx = ((i + 1) - (sx + 1) * (1.0 / scale)).astype(np.float32)
-        fx = np.where(fx <= 0, np.float32(0), fx - np.floor(fx)).astype(np.float64)
-        last = sx >= n_src - 1
-        sx = np.where(last, n_src - 1, sx).astype(np.int64)
-        fx = np.where(last, 0.0, fx)
-        idx = np.clip(np.stack([sx, sx + 1], axis=1), 0, n_src - 1).astype(np.int32)
-        return idx, np.stack([1.0 - fx, fx], axis=1)
-    if interp == INTER_NEAREST:
-        idx = np.minimum(np.floor(i * scale), n_src - 1).astype(np.int32)[:, None]
-        return idx, np.ones((n_dst, 1))
-    if interp == INTER_AREA and scale >= 1:
-        # box filter: the overlap of [i * scale, (i + 1) * scale) with each source cell, normalised
-        lo, hi = i * scale, (i + 1) * scale
-        first = np.floor(lo).astype(np.int64)
-        T = int(np.ceil(scale)) + 1
-        idx = first[:, None] + np.arange(T)[None, :]
-        w = np.clip(np.minimum(idx + 1.0, hi[:, None]) - np.maximum(idx.astype(np.float64), lo[:, None]), 0.0, None)
-        w = w / w.sum(axis=1, keepdims=True)
-        return np.clip(idx, 0, n_src - 1).astype(np.int32), w
-    center = (i + 0.5) * scale - 0.5
-    base = np.floor(center)
-    frac = center - base
-    if interp in (INTER_LINEAR, INTER_AREA):                                # (AREA when enlarging: the linear kernel)
+def _inv_scales(n_src, n_dst):
+    inv = float(n_dst) / float(n_src)                     # inv_scale_x = (double)dsize.width / ssize.width
+    return inv, 1.0 / inv                                 # scale_x = 1. / inv_scale_x
+
+
+def cv_interpolate_cubic(x):
+    """interpolateCubic (imgproc/resize.cpp), float32 operation by operation; x float32 array -> (n, 4) float32."""
+    x = np.asarray(x, dtype=_F32)
+    A = _F32(-0.75)
+    x1 = x + _F32(1)
+    c0 = ((A * x1 - _F32(5) * A) * x1 + _F32(8) * A) * x1 - _F32(4) * A
+    c1 = ((A + _F32(2)) * x - (A + _F32(3))) * x * x + _F32(1)
+    y = _F32(1) - x
+    c2 = ((A + _F32(2)) * y - (A + _F32(3))) * y * y + _F32(1)
+    c3 = _F32(1) - c0 - c1 - c2
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(_F32)
+
+
+def det_sincos(y):
+    """sin and cos of y in [-pi, -3 pi / 4] (interpolateLanczos4's y0) as a fixed chain of float64 +, -, *: t = y + pi in [0, pi / 4],
+    sin y = -sin t, cos y = -cos t, Taylor polynomials of degree 23 / 22 by Horner.  Same bits on every host and on the GPU."""
+    y = np.asarray(y, dtype=np.float64)
+    t = y + _CV_PI
+    t2 = t * t
+    s = np.full_like(t2, 1.0 / 25852016738884976640000.0)            # 1 / 23!
+    for k in (21, 19, 17, 15, 13, 11, 9, 7, 5, 3, 1):
+        s = s * t2
+        s = _SIN_C[k] - s
+    s = s * t
+    c = np.full_like(t2, 1.0 / 1124000727777607680000.0)             # 1 / 22!
+    for k in (20, 18, 16, 14, 12, 10, 8, 6, 4, 2, 0):
+        c = c * t2
+        c = _COS_C[k] - c
+    return -s, -c
+
+
+def _fact(n):
+    r = 1
+    for i in range(2, n + 1):
+        r *= i
+    return r
+
+
+# alternating Taylor coefficients written so that every Horner step is `c_k - acc * t^2`: sin t = t (1/1! - t2 (1/3! - t2 (1/5! - ...)))
+_SIN_C = {k: 1.0 / _fact(k) for k in range(1, 23, 2)}
+_COS_C = {k: 1.0 / _fact(k) for k in range(0, 22, 2)}
+
+
+def cv_interpolate_lanczos4(x):
+    """interpolateLanczos4 (imgproc/resize.cpp); x float32 array -> (n, 8) float32."""
+    x = np.asarray(x, dtype=_F32).reshape(-1)
+    s45 = 0.70710678118654752440084436210485
+    cs = np.array([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]], dtype=np.float64)
+    out = np.zeros((x.shape[0], 8), dtype=_F32)
+    tiny = x < np.finfo(_F32).eps                           # x < FLT_EPSILON: the centre tap alone
+    out[tiny, 3] = 1
+    xs = x[~tiny]
+    if xs.size:
+        x3 = xs + _F32(3)                                   # float32: (x + 3)
+        y0 = -(x3.astype(np.float64)) * _CV_PI * 0.25
+        s0, c0 = det_sincos(y0)
+        co = np.empty((xs.shape[0], 8), dtype=_F32)
+        for i in range(8):
+            y = -((x3 - _F32(i)).astype(np.float64)) * _CV_PI * 0.25        # -(x + 3 - i) * CV_PI * 0.25, the difference in float32
+            co[:, i] = ((cs[i, 0] * s0 + cs[i, 1] * c0) / (y * y)).astype(_F32)
+        total = np.zeros(xs.shape[0], dtype=_F32)
+        for i in range(8):
+            total = total + co[:, i]                        # float sum, in tap order
+        total = _F32(1) / total
+        out[~tiny] = co * total[:, None]
+    return out
+
+
+def cv_coords(n_src, n_dst, area_mode):
+    """(sx int64, fx float32) of every destination coordinate, before any border handling (resize.cpp: the dx / dy loops)."""
+    inv, scale = _inv_scales(n_src, n_dst)
+    d = np.arange(n_dst, dtype=np.float64)
+    if not area_mode:
+        fx = ((d + 0.5) * scale - 0.5).astype(_F32)
+        sx = np.floor(fx).astype(np.int64)
+        fx = (fx - sx.astype(_F32)).astype(_F32)
+    else:
+        sx = np.floor(d * scale).astype(np.int64)
+        fx = ((d + 1) - (sx + 1) * inv).astype(_F32)
+        fx = np.where(fx <= 0, _F32(0), fx - np.floor(fx)).astype(_F32)
+    return sx, fx
+
+
+def cv_fixed_axis(n_src, n_dst, interp, area_mode, horizontal):
+    """Tap indices (n_dst, k) and the `short` coefficients (n_dst, k) of one axis for the fixed-point paths."""
+    sx, fx = cv_coords(n_src, n_dst, area_mode)
+    if interp in (INTER_LINEAR, INTER_AREA):
+        if horizontal:                                      # only the x loop resets the pair at the borders
+            lo, hi = sx < 0, sx >= n_src - 1
+            fx = np.where(lo | hi, _F32(0), fx).astype(_F32)
+            sx = np.where(lo, 0, np.where(hi, n_src - 1, sx))
+        coef = np.stack([_F32(1) - fx, fx], axis=1)
         offs = np.array([0, 1])
-        w = np.stack([1.0 - frac, frac], axis=1)
     elif interp == INTER_CUBIC:
-        offs = np.array([-1, 0, 1, 2])
-        w = _cubic_w(frac[:, None] - offs[None, :])
+        coef, offs = cv_interpolate_cubic(fx), np.array([-1, 0, 1, 2])
     elif interp == INTER_LANCZOS4:
-        offs = np.arange(-3, 5)
-        w = _lanczos_w(frac[:, None] - offs[None, :])
-        w = w / w.sum(axis=1, keepdims=True)
+        coef, offs = cv_interpolate_lanczos4(fx), np.arange(-3, 5)
     else:
         raise ValueError("interpolation mode %r" % (interp,))
-    idx = np.clip(base[:, None].astype(np.int64) + offs[None, :], 0, n_src - 1).astype(np.int32)
-    return idx, w
+    idx = np.clip(sx[:, None] + offs[None, :], 0, n_src - 1).astype(np.int32)
+    return idx, _sat_short(coef.astype(_F32) * _F32(INTER_RESIZE_COEF_SCALE))
+
+
+def cv_area_tab(n_src, n_dst):
+    """computeResizeAreaTab as padded per-destination taps: (index (n_dst, T) int32, alpha (n_dst, T) float32, zero beyond a row's
+    own entries -- adding `pixel * 0.f` leaves a float32 sum unchanged)."""
+    _, scale = _inv_scales(n_src, n_dst)
+    rows = []
+    for dx in range(n_dst):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, n_src - fsx1)
+        sx1, sx2 = int(np.ceil(fsx1)), int(np.floor(fsx2))
+        sx2 = min(sx2, n_src - 1)
+        sx1 = min(sx1, sx2)
+        ent = []
+        if sx1 - fsx1 > 1e-3:
+            ent.append((sx1 - 1, _F32((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            ent.append((sx, _F32(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            ent.append((sx2, _F32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+        rows.append(ent)
+    T = max(1, max(len(r) for r in rows))
+    idx = np.zeros((n_dst, T), dtype=np.int32)
+    alpha = np.zeros((n_dst, T), dtype=_F32)
+    for d, ent in enumerate(rows):
+        for k, (si, a) in enumerate(ent):
+            idx[d, k], alpha[d, k] = si, a
+        if ent:
+            idx[d, len(ent):] = ent[-1][0]
+    return idx, alpha
+
+
+def cv_resize_plan(src_h, src_w, dst_h, dst_w, interp):
+    """What cv::resize does for these sizes: (kind, ix, wx, iy, wy, area).  ix / iy (n_dst, T) source indices, wx / wy the table
+    values as float64 (shorts for the fixed-point kinds, float32 alphas for the area filter, ones otherwise)."""
+    interp = int(interp)
+    ones = lambda i: np.ones(i.shape, dtype=np.float64)
+    if (src_h, src_w) == (dst_h, dst_w):
+        iy, ix = np.arange(dst_h, dtype=np.int32)[:, None], np.arange(dst_w, dtype=np.int32)[:, None]
+        return KIND_COPY, ix, ones(ix), iy, ones(iy), 1
+    if interp == INTER_NEAREST:
+        res = []
+        for n_src, n_dst in ((src_w, dst_w), (src_h, dst_h)):
+            _, scale = _inv_scales(n_src, n_dst)
+            i = np.minimum(np.floor(np.arange(n_dst, dtype=np.float64) * scale), n_src - 1).astype(np.int32)[:, None]
+            res += [i, ones(i)]
+        return (KIND_NEAREST,) + tuple(res) + (1,)
+    _, scale_x = _inv_scales(src_w, dst_w)
+    _, scale_y = _inv_scales(src_h, dst_h)
+    iscale_x, iscale_y = int(np.rint(scale_x)), int(np.rint(scale_y))             # saturate_cast<int>(double) = cvRound
+    eps = np.finfo(np.float64).eps
+    fast = abs(scale_x - iscale_x) < eps and abs(scale_y - iscale_y) < eps
+    if interp == INTER_LINEAR and fast and iscale_x == 2 and iscale_y == 2:
+        interp = INTER_AREA
+    if interp == INTER_AREA and scale_x >= 1 and scale_y >= 1:
+        if fast:
+            ix = (np.arange(dst_w)[:, None] * iscale_x + np.arange(iscale_x)[None, :]).astype(np.int32)
+            iy = (np.arange(dst_h)[:, None] * iscale_y + np.arange(iscale_y)[None, :]).astype(np.int32)
+            kind = KIND_AREA_FAST2 if (iscale_x, iscale_y) == (2, 2) else KIND_AREA_FAST
+            return kind, ix, ones(ix), iy, ones(iy), iscale_x * iscale_y
+        ix, ax = cv_area_tab(src_w, dst_w)
+        iy, ay = cv_area_tab(src_h, dst_h)
+        return KIND_AREA, ix, ax.astype(np.float64), iy, ay.astype(np.float64), 1
+    area_mode = interp == INTER_AREA
+    ix, cx = cv_fixed_axis(src_w, dst_w, interp, area_mode, True)
+    iy, cy = cv_fixed_axis(src_h, dst_h, interp, area_mode, False)
+    kind = KIND_LINEAR if interp in (INTER_LINEAR, INTER_AREA) else KIND_KERNEL
+    return kind, ix, cx.astype(np.float64), iy, cy.astype(np.float64), 1
+
+
+def cv_apply_plan(src, plan, background=None):
+    """The pixel arithmetic of a plan on src (H, W, C) uint8 -> (dst_h, dst_w, C) uint8.  Index -1 (the augmentation's canvas) reads
+    `background` (C,)."""
+    kind, ix, wx, iy, wy, area = plan
+    C = src.shape[2]
+
+    def rows_of(j):                                         # the source rows of vertical tap j, gathered at horizontal tap k: (Ho, Wo, C)
+        def at(k):
+            r, c = iy[:, j], ix[:, k]
+            v = src[np.clip(r, 0, None)][:, np.clip(c, 0, None)].astype(np.int64)
+            if background is not None:
+                hole = (r[:, None] < 0) | (c[None, :] < 0)
+                v = np.where(hole[:, :, None], np.asarray(background, dtype=np.int64)[None, None, :], v)
+            return v
+        return at
+
+    if kind in (KIND_NEAREST, KIND_COPY):
+        return rows_of(0)(0).astype(np.uint8)
+    if kind == KIND_LINEAR:
+        a, b = wx.astype(np.int64), wy.astype(np.int64)
+        S = []
+        for j in range(2):
+            at = rows_of(j)
+            S.append(at(0) * a[None, :, 0, None] + at(1) * a[None, :, 1, None])          # HResizeLinear: int32 row
+        v = ((b[:, 0, None, None] * (S[0] >> 4)) >> 16) + ((b[:, 1, None, None] * (S[1] >> 4)) >> 16)
+        return (((v + 2) >> 2) & 0xff).astype(np.uint8)                                   # uchar(...): a plain cast
+    if kind == KIND_KERNEL:
+        a, b = wx.astype(np.int64), wy.astype(np.int64)
+        acc = np.zeros((iy.shape[0], ix.shape[0], C), dtype=np.int64)
+        for j in range(iy.shape[1]):
+            at = rows_of(j)
+            row = np.zeros_like(acc)
+            for k in range(ix.shape[1]):
+                row = row + at(k) * a[None, :, k, None]
+            acc = acc + row * b[:, j, None, None]
+        acc = ((acc + (1 << 31)) & 0xffffffff) - (1 << 31)                                # int arithmetic wraps at 32 bits
+        return np.clip((acc + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    if kind == KIND_AREA:
+        a, b = wx.astype(_F32), wy.astype(_F32)
+        total = None
+        for j in range(iy.shape[1]):
+            at = rows_of(j)
+            buf = np.zeros((iy.shape[0], ix.shape[0], C), dtype=_F32)
+            for k in range(ix.shape[1]):
+                buf = buf + at(k).astype(_F32) * a[None, :, k, None]                       # buf[dx] += S[sx] * alpha
+            term = b[:, j, None, None] * buf
+            total = term if total is None else total + term                               # sum[dx] = beta * buf  /  += beta * buf
+        return np.clip(np.rint(total.astype(np.float64)), 0, 255).astype(np.uint8)        # saturate_cast<uchar>(float): cvRound
+    total = np.zeros((iy.shape[0], ix.shape[0], C), dtype=np.int64)
+    for j in range(iy.shape[1]):
+        at = rows_of(j)
+        for k in range(ix.shape[1]):
+            total = total + at(k)
+    if kind == KIND_AREA_FAST2:
+        return ((total + 2) >> 2).astype(np.uint8)
+    scale = _F32(1.0) / _F32(area)                                                         # scale = 1.f / (scale_x * scale_y)
+    return np.clip(np.rint((total.astype(_F32) * scale).astype(np.float64)), 0, 255).astype(np.uint8)
 
 
 def resize(img, dsize, interpolation=INTER_LINEAR):
-    """cv2.resize(img, dsize=(width, height), interpolation) for 8-bit images [H, W] / [H, W, C] (see the module docstring)."""
+    """cv2.resize(img, dsize=(width, height), interpolation) for 8-bit images [H, W] / [H, W, C] (see the block comment above)."""
     if img.dtype != np.uint8:
         raise TypeError("resize: 8-bit images")
     wo, ho = int(dsize[0]), int(dsize[1])
     src = img if img.ndim == 3 else img[:, :, None]
-    al = int(interpolation) == INTER_AREA and not (src.shape[1] >= wo and src.shape[0] >= ho)     # cv2: the box filter only if BOTH axes shrink
-    ix, wx = resize_taps(src.shape[1], wo, int(interpolation), al)
-    iy, wy = resize_taps(src.shape[0], ho, int(interpolation), al)
-    srcd = src.astype(np.float64)
-    acc = np.zeros((ho, wo, src.shape[2]))
-    for j in range(iy.shape[1]):                                            # rows outer, columns inner: the kernel's order
-        rows = srcd[iy[:, j]]                                               # [ho, W, C]
-        racc = np.zeros((ho, wo, src.shape[2]))
-        for t in range(ix.shape[1]):
-            racc = racc + wx[None, :, t, None] * rows[:, ix[:, t]]
-        acc = acc + wy[:, j, None, None] * racc
-    out = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    out = cv_apply_plan(src, cv_resize_plan(src.shape[0], src.shape[1], ho, wo, interpolation))
     return out if img.ndim == 3 else out[:, :, 0]
 
 

@@ -1696,6 +1696,73 @@ def image_resize_gather_u8(images, out_h, out_w, ix, wx, iy, wy, background):
     return out
 
 
+def image_resize_cv_u8(images, out_h, out_w, kind, area, ix, wx, iy, wy):
+    """ssdhip_image_resize_cv_u8 (cv2.resize's own 8-bit arithmetic): images (B, H, W, C) CUDA uint8; one plan for the batch
+    (data_generator/_image_ops.resize_plan): `kind`, `area`, ix / wx (out_w, nx), iy / wy (out_h, ny)."""
+    torch = _torch()
+    lib = _image_lib()
+    if not getattr(lib, "_resize_cv_bound", False):
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.ssdhip_image_resize_cv_u8.restype = ci
+        lib.ssdhip_image_resize_cv_u8.argtypes = [vp, vp] + [ci] * 8 + [vp, vp, ci, vp, vp, ci, vp]
+        lib._resize_cv_bound = True
+    require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 4 or not images.is_contiguous():
+        raise SsdHipError("images must be a contiguous (B, H, W, C) uint8 tensor")
+    b, h, w, c = images.shape
+    dev = images.device
+    ix = to_device(ix, device=dev, dtype=torch.int32).contiguous()
+    wx = to_device(wx, device=dev, dtype=torch.float64).contiguous()
+    iy = to_device(iy, device=dev, dtype=torch.int32).contiguous()
+    wy = to_device(wy, device=dev, dtype=torch.float64).contiguous()
+    if ix.shape != wx.shape or iy.shape != wy.shape or ix.shape[0] != out_w or iy.shape[0] != out_h:
+        raise SsdHipError("tap tables must be (out_w, nx) and (out_h, ny)")
+    out = torch.empty((b, out_h, out_w, c), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_image_resize_cv_u8(_ptr(images), _ptr(out), b, h, w, out_h, out_w, c, int(kind), int(area), _ptr(ix), _ptr(wx),
+                                           int(ix.shape[1]), _ptr(iy), _ptr(wy), int(iy.shape[1]), current_stream_ptr(dev))
+    check(rc, "ssdhip_image_resize_cv_u8")
+    return out
+
+
+def image_resize_gather_cv_u8(images, out_h, out_w, plans, ix, wx, iy, wy, background):
+    """ssdhip_image_resize_gather_cv_u8: images (B, H, W, C) CUDA uint8; plans (B, 4) int32 [kind, area, taps per column, taps per row];
+    per-image tables ix / wx (B, out_w, nx), iy / wy (B, out_h, ny) (index -1 = background), background (B, C) uint8."""
+    torch = _torch()
+    lib = _image_lib()
+    if not getattr(lib, "_gather_cv_bound", False):
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.ssdhip_image_resize_gather_cv_u8.restype = ci
+        lib.ssdhip_image_resize_gather_cv_u8.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, vp, ci, vp, vp, ci, vp, vp]
+        lib._gather_cv_bound = True
+    require_cuda(images, "images")
+    if images.dtype != torch.uint8 or images.dim() != 4 or not images.is_contiguous():
+        raise SsdHipError("images must be a contiguous (B, H, W, C) uint8 tensor")
+    b, h, w, c = images.shape
+    dev = images.device
+    plans = to_device(plans, device=dev, dtype=torch.int32).contiguous()
+    ix = to_device(ix, device=dev, dtype=torch.int32).contiguous()
+    wx = to_device(wx, device=dev, dtype=torch.float64).contiguous()
+    iy = to_device(iy, device=dev, dtype=torch.int32).contiguous()
+    wy = to_device(wy, device=dev, dtype=torch.float64).contiguous()
+    bg = to_device(background, device=dev, dtype=torch.uint8).contiguous()
+    if ix.shape[2] < 2:                                        # (the entry point wants room for the linear kernel's two taps)
+        pad = lambda t: torch.cat([t, torch.zeros_like(t)], dim=2)
+        ix, wx = pad(ix), pad(wx)
+    if iy.shape[2] < 2:
+        pad = lambda t: torch.cat([t, torch.zeros_like(t)], dim=2)
+        iy, wy = pad(iy), pad(wy)
+    if (ix.shape != wx.shape or iy.shape != wy.shape or tuple(ix.shape[:2]) != (b, out_w) or tuple(iy.shape[:2]) != (b, out_h)
+            or tuple(bg.shape) != (b, c) or tuple(plans.shape) != (b, 4)):
+        raise SsdHipError("plans must be (B, 4), tap tables (B, out_w, nx) / (B, out_h, ny), background (B, C)")
+    out = torch.empty((b, out_h, out_w, c), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_image_resize_gather_cv_u8(_ptr(images), _ptr(out), b, h, w, out_h, out_w, c, _ptr(plans), _ptr(ix), _ptr(wx),
+                                                  int(ix.shape[2]), _ptr(iy), _ptr(wy), int(iy.shape[2]), _ptr(bg), current_stream_ptr(dev))
+    check(rc, "ssdhip_image_resize_gather_cv_u8")
+    return out
+
+
 def image_hist_u8(image, channel):
     """256-bin histogram (CUDA int64 tensor) of one channel of an (..., C) uint8 CUDA image."""
     torch = _torch()
@@ -1850,6 +1917,28 @@ def ssd_augment_decide_stream(params, photo, mt_state, labels, n_labels, device)
         return (out[o_geo:o_geo + B * 48].view(np.int32).reshape(B, 12), out[:nl].view(np.float64).reshape(B, AUG_MAX_BOXES, 5),
                 out[o_n:].view(np.int32), out[o_mt:o_mt + 625 * 4].view(np.uint32).copy())
     return ops_dev, args_dev, geo_dev, fetch
+
+
+def augment_plans(geo_dev, H, W, out_h, out_w, n_taps):
+    """`ssdhip_augment_plans`: the gather launch's per-image plans (plans (B, 4) int32, ix, wx, iy, wy: CUDA tensors
+    (B, out_w | out_h, n_taps)) with cv2.resize's own arithmetic, built on the device from the geometry the decision kernels left there."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_augplans_bound", False):
+        lib.ssdhip_augment_plans.restype = ctypes.c_int
+        lib.ssdhip_augment_plans.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 6
+        lib._augplans_bound = True
+    B, dev = int(geo_dev.shape[0]), geo_dev.device
+    plans = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    ix = torch.empty((B, out_w, n_taps), dtype=torch.int32, device=dev)
+    wx = torch.empty((B, out_w, n_taps), dtype=torch.float64, device=dev)
+    iy = torch.empty((B, out_h, n_taps), dtype=torch.int32, device=dev)
+    wy = torch.empty((B, out_h, n_taps), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.ssdhip_augment_plans(_ptr(geo_dev), B, int(H), int(W), int(out_h), int(out_w), int(n_taps), _ptr(plans), _ptr(ix), _ptr(wx),
+                                      _ptr(iy), _ptr(wy), current_stream_ptr(dev))
+    check(rc, "ssdhip_augment_plans")
+    return plans, ix, wx, iy, wy
 
 
 def augment_taps(geo_dev, H, W, out_h, out_w, n_taps):

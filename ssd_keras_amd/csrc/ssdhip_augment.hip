@@ -411,6 +411,176 @@ __global__ __launch_bounds__(128) void aug_taps_kernel(const int* __restrict__ g
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the gather launch's PLANS with cv2.resize's own 8-bit arithmetic (ssdhip_image_resize_gather_cv_u8), built on the device from
+// the decisions: per image the dispatch of cv::resize (copy / nearest / fixed-point linear, cubic, Lanczos-4 / area-mode bilinear /
+// ResizeArea / ResizeAreaFast) and per axis the tap indices + table values of data_generator/_image_ops.py resize_plan -- the same
+// float32 / float64 operations in the same order (this file is compiled without contraction), Lanczos' sine and cosine by the same
+// fixed Horner chain -- composed with the recorded geometry as aug_taps_kernel does.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+enum { PK_NEAREST = 0, PK_LINEAR = 1, PK_KERNEL = 2, PK_AREA = 3, PK_AREA_FAST = 4, PK_AREA_FAST2 = 5, PK_COPY = 6 };
+__device__ const double AUG_SIN_C[12] = {1.0, 0.16666666666666666, 0.008333333333333333, 0.0001984126984126984, 2.7557319223985893e-06, 2.505210838544172e-08, 1.6059043836821613e-10, 7.647163731819816e-13, 2.8114572543455206e-15, 8.22063524662433e-18, 1.9572941063391263e-20, 3.8681701706306835e-23};       // 1 / (2 k + 1)!
+__device__ const double AUG_COS_C[12] = {1.0, 0.5, 0.041666666666666664, 0.001388888888888889, 2.48015873015873e-05, 2.755731922398589e-07, 2.08767569878681e-09, 1.1470745597729725e-11, 4.779477332387385e-14, 1.5619206968586225e-16, 4.110317623312165e-19, 8.896791392450574e-22};       // 1 / (2 k)!
+
+__device__ __forceinline__ void aug_sincos_near_minus_pi(double y, double& sn, double& cs) {   // _image_ops.sincos_near_minus_pi
+    const double t = y + 3.1415926535897932384626433832795;
+    const double t2 = t * t;
+    double s = AUG_SIN_C[11];
+    for (int k = 10; k >= 0; --k) s = AUG_SIN_C[k] - s * t2;
+    double c = AUG_COS_C[11];
+    for (int k = 10; k >= 0; --k) c = AUG_COS_C[k] - c * t2;
+    sn = -(s * t);
+    cs = -c;
+}
+__device__ __forceinline__ double aug_to_short(float coef) {                  // saturate_cast<short>(coef * 2048): nearest-even, clamped
+    const double r = __builtin_rint((double)(coef * 2048.f));
+    return r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+}
+
+struct AugPlan { int kind, area, tx, ty, interp, area_mode; };
+__device__ __forceinline__ AugPlan aug_plan_of(int Hc, int Wc, int out_h, int out_w, int interp, int n_taps) {
+    AugPlan q;
+    q.area = 1; q.tx = 1; q.ty = 1; q.interp = interp; q.area_mode = 0;
+    if (Hc == out_h && Wc == out_w) { q.kind = PK_COPY; return q; }
+    if (interp == 0) { q.kind = PK_NEAREST; return q; }
+    const double scale_x = 1.0 / ((double)out_w / (double)Wc), scale_y = 1.0 / ((double)out_h / (double)Hc);
+    const int isx = (int)__builtin_rint(scale_x), isy = (int)__builtin_rint(scale_y);
+    const double eps = 2.220446049250313e-16;
+    const bool fast = fabs(scale_x - (double)isx) < eps && fabs(scale_y - (double)isy) < eps;
+    if (interp == 1 && fast && isx == 2 && isy == 2) interp = 3;
+    if (interp == 3 && scale_x >= 1.0 && scale_y >= 1.0) {
+        if (fast) { q.kind = (isx == 2 && isy == 2) ? PK_AREA_FAST2 : PK_AREA_FAST; q.area = isx * isy; q.tx = isx; q.ty = isy; }
+        else {
+            q.kind = PK_AREA;
+            const int bx = (int)ceil(scale_x) + 2, by = (int)ceil(scale_y) + 2;
+            q.tx = bx < n_taps ? bx : n_taps; q.ty = by < n_taps ? by : n_taps;
+        }
+        q.interp = 3;
+        return q;
+    }
+    q.interp = interp;
+    q.area_mode = interp == 3;
+    if (interp == 1 || interp == 3) { q.kind = PK_LINEAR; q.tx = q.ty = 2; }
+    else { q.kind = PK_KERNEL; q.tx = q.ty = interp == 2 ? 4 : 8; }
+    return q;
+}
+
+// grid (blocks over positions, 2 axes, B); axis 0 = columns (x), 1 = rows (y); plan [B][4] = kind, area, taps per column, taps per row
+__global__ __launch_bounds__(128) void aug_plan_kernel(const int* __restrict__ geo, int H, int W, int out_h, int out_w, int n_taps,
+                                                       int* __restrict__ plan, int* __restrict__ ix, double* __restrict__ wx,
+                                                       int* __restrict__ iy, double* __restrict__ wy) {
+    const int b = (int)blockIdx.z, axis = (int)blockIdx.y;
+    const int n_dst = axis == 0 ? out_w : out_h;
+    const int i = (int)blockIdx.x * 128 + (int)threadIdx.x;
+    const int* g = geo + (size_t)b * 12;
+    const int Hc = g[8], Wc = g[9];
+    const AugPlan q = aug_plan_of(Hc, Wc, out_h, out_w, g[11], n_taps);
+    if (axis == 0 && i == 0) { plan[b * 4] = q.kind; plan[b * 4 + 1] = q.area; plan[b * 4 + 2] = q.tx; plan[b * 4 + 3] = q.ty; }
+    if (i >= n_dst) return;
+    const int n_src = axis == 0 ? Wc : Hc;
+    const double inv = (double)n_dst / (double)n_src, scale = 1.0 / inv;
+    int idx[64];
+    double w[64];
+    int T = 1;
+    if (q.kind == PK_COPY) { idx[0] = i; w[0] = 1.0; }
+    else if (q.kind == PK_NEAREST) {
+        const double f = floor((double)i * scale);
+        idx[0] = (int)(f < (double)(n_src - 1) ? f : (double)(n_src - 1));
+        w[0] = 1.0;
+    } else if (q.kind == PK_AREA_FAST || q.kind == PK_AREA_FAST2) {
+        const int is = axis == 0 ? q.tx : q.ty;
+        T = is > 64 ? 64 : is;
+        for (int t = 0; t < T; ++t) { idx[t] = i * is + t; w[t] = 1.0; }
+    } else if (q.kind == PK_AREA) {                                         // computeResizeAreaTab, the entries of destination i
+        const double f1 = (double)i * scale, f2 = f1 + scale;
+        const double room = (double)n_src - f1;
+        const double cell = scale < room ? scale : room;
+        long long s2 = (long long)floor(f2), s1 = (long long)ceil(f1);
+        s2 = s2 < n_src - 1 ? s2 : n_src - 1;
+        s1 = s1 < s2 ? s1 : s2;
+        T = 0;
+        if ((double)s1 - f1 > 1e-3) { idx[T] = (int)(s1 - 1); w[T] = (double)(float)(((double)s1 - f1) / cell); ++T; }
+        for (long long sx = s1; sx < s2 && T < 63; ++sx) { idx[T] = (int)sx; w[T] = (double)(float)(1.0 / cell); ++T; }
+        if (f2 - (double)s2 > 1e-3) {
+            double m = f2 - (double)s2;
+            m = m < 1.0 ? m : 1.0;
+            m = m < cell ? m : cell;
+            idx[T] = (int)s2; w[T] = (double)(float)(m / cell); ++T;
+        }
+        if (T == 0) { idx[0] = 0; w[0] = 0.0; T = 1; }
+        for (int t = 0; t < T; ++t) idx[t] = idx[t] < 0 ? 0 : (idx[t] > n_src - 1 ? n_src - 1 : idx[t]);
+    } else {
+        long long sx;
+        float fx;
+        if (q.area_mode) {
+            sx = (long long)floor((double)i * scale);
+            fx = (float)(((double)i + 1.0) - ((double)sx + 1.0) * inv);
+            fx = fx <= 0.f ? 0.f : fx - floorf(fx);
+        } else {
+            fx = (float)(((double)i + 0.5) * scale - 0.5);
+            const float fl = floorf(fx);
+            sx = (long long)fl;
+            fx = fx - fl;
+        }
+        int off0;
+        float co[8];
+        if (q.kind == PK_LINEAR) {
+            if (axis == 0) {                                                // only the x loop resets the pair at the borders
+                if (sx < 0) { sx = 0; fx = 0.f; }
+                else if (sx >= n_src - 1) { sx = n_src - 1; fx = 0.f; }
+            }
+            off0 = 0; T = 2;
+            co[0] = 1.f - fx; co[1] = fx;
+        } else if (q.interp == 2) {                                         // interpolateCubic, A = -0.75, float32 operation by operation
+            off0 = -1; T = 4;
+            const float A = -0.75f, u = fx + 1.f, v = 1.f - fx;
+            co[0] = ((A * u - 5.f * A) * u + 8.f * A) * u - 4.f * A;
+            co[1] = ((A + 2.f) * fx - (A + 3.f)) * fx * fx + 1.f;
+            co[2] = ((A + 2.f) * v - (A + 3.f)) * v * v + 1.f;
+            co[3] = 1.f - co[0] - co[1] - co[2];
+        } else {                                                            // interpolateLanczos4
+            off0 = -3; T = 8;
+            if (fx < 1.1920928955078125e-07f) {
+                for (int t = 0; t < 8; ++t) co[t] = 0.f;
+                co[3] = 1.f;
+            } else {
+                const double r = 0.70710678118654752440084436210485;
+                const double cs[8][2] = {{1, 0}, {-r, -r}, {0, 1}, {r, -r}, {-1, 0}, {r, r}, {0, -1}, {-r, r}};
+                const float x3 = fx + 3.f;
+                double s0, c0;
+                aug_sincos_near_minus_pi(-((double)x3) * 3.1415926535897932384626433832795 * 0.25, s0, c0);
+                float total = 0.f;
+                for (int t = 0; t < 8; ++t) {
+                    const double y = -((double)(x3 - (float)t)) * 3.1415926535897932384626433832795 * 0.25;
+                    co[t] = (float)((cs[t][0] * s0 + cs[t][1] * c0) / (y * y));
+                }
+                for (int t = 0; t < 8; ++t) total = total + co[t];
+                total = 1.f / total;
+                for (int t = 0; t < 8; ++t) co[t] = co[t] * total;
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            const long long c = sx + off0 + t;
+            idx[t] = (int)(c < 0 ? 0 : (c > n_src - 1 ? n_src - 1 : c));
+            w[t] = aug_to_short(co[t]);
+        }
+    }
+    // the recorded geometry: position j of the final (pre-resize) image <- flip <- crop window <- expansion canvas <- the image
+    int* oi = (axis == 0 ? ix : iy) + ((size_t)b * n_dst + i) * n_taps;
+    double* ow = (axis == 0 ? wx : wy) + ((size_t)b * n_dst + i) * n_taps;
+    for (int t = 0; t < n_taps; ++t) {
+        int j = idx[t < T ? t : T - 1];
+        if (axis == 0 && g[10]) j = Wc - 1 - j;                                   // RandomFlip('horizontal')
+        if (g[5]) j += axis == 0 ? g[7] : g[6];                                   // the crop window's corner on the canvas
+        if (g[0]) {                                                               // the canvas: the image sits at (-top, -left)
+            j += axis == 0 ? g[2] : g[1];
+            if (j < 0 || j >= (axis == 0 ? W : H)) j = -1;
+        }
+        oi[t] = j;
+        ow[t] = t < T ? w[t] : 0.0;
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -471,6 +641,19 @@ static int aug_params_from(const ssdhip_augment_params* q, AugParams& p) {
     p.flip_prob = q->flip_prob; p.n_modes = q->n_modes; p.out_h = q->out_height; p.out_w = q->out_width;
     p.max_rounds = q->max_rounds > 0 ? q->max_rounds : 100000;
     return SSDHIP_OK;
+}
+
+extern "C" int ssdhip_augment_plans(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* plan_dev,
+                                    int* ix_dev, double* wx_dev, int* iy_dev, double* wy_dev, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!geometry_dev || !plan_dev || !ix_dev || !wx_dev || !iy_dev || !wy_dev || B <= 0 || B > 65535 || H <= 0 || W <= 0 || out_h <= 0 ||
+        out_w <= 0)
+        return SSDHIP_E_BADARG;
+    if (n_taps < 8 || n_taps > 64) return SSDHIP_E_BADARG;                       // Lanczos-4 needs eight
+    const int n = out_h > out_w ? out_h : out_w;
+    hipLaunchKernelGGL(aug_plan_kernel, dim3((unsigned)((n + 127) / 128), 2, (unsigned)B), dim3(128), 0, stream, geometry_dev, H, W, out_h,
+                       out_w, n_taps, plan_dev, ix_dev, wx_dev, iy_dev, wy_dev);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
 extern "C" int ssdhip_augment_taps(const int* geometry_dev, int B, int H, int W, int out_h, int out_w, int n_taps, int* ix_dev,

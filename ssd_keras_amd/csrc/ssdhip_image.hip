@@ -332,6 +332,97 @@ __global__ __launch_bounds__(256) void resize_gather_kernel(const unsigned char*
     y[((size_t)b * Ho + yo) * Wo * C + v] = (unsigned char)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// cv2.resize on 8-bit images with OpenCV's OWN arithmetic (round 6; imgproc/resize.cpp, the C++ reference paths -- the kernels above
+// resample with float64 weights and one rounding, one grey level off here and there).  The host (data_generator/_image_ops.py
+// resize_plan) or the device (csrc/ssdhip_augment.hip) builds the plan: `kind`, tap indices, and the tables as float64 values that hold
+// 11-bit fixed-point shorts / float32 area weights / ones exactly.  Per output value, rows j outer, columns k inner:
+//   COPY / NEAREST   the single tap
+//   LINEAR           S_j = p[j][0] a0 + p[j][1] a1 (int32);  uchar((((b0 (S_0 >> 4)) >> 16) + ((b1 (S_1 >> 4)) >> 16) + 2) >> 2)
+//                    (VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>: the two-stage form of its mulhi SIMD twin)
+//   KERNEL           cubic / Lanczos-4: S_j = sum_k p a_k, saturate((sum_j S_j b_j + (1 << 21)) >> 22), int32 (wrapping) arithmetic
+//   AREA             ResizeArea: buf_j = sum_k float(p) alpha_k, total = sum_j beta_j buf_j, all float32 in table order, cvRound, saturate
+//   AREA_FAST / 2    ResizeAreaFast: the block's integer sum; saturate(cvRound(float(sum) * (1.f / area))); 2 x 2: (sum + 2) >> 2
+// Unused taps of a padded row carry weight 0 and a valid index (a float32 sum is unchanged by + p * 0.f).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+enum { CV_NEAREST = 0, CV_LINEAR = 1, CV_KERNEL = 2, CV_AREA = 3, CV_AREA_FAST = 4, CV_AREA_FAST2 = 5, CV_COPY = 6 };
+
+template <typename Px>
+__device__ __forceinline__ unsigned char cv_resample(const int kind, const int area, const int nx, const int ny, const double* __restrict__ wx,
+                                                     const double* __restrict__ wy, Px px) {
+    if (kind == CV_NEAREST || kind == CV_COPY) return (unsigned char)px(0, 0);
+    if (kind == CV_LINEAR) {
+        const int a0 = (int)wx[0], a1 = (int)wx[1], b0 = (int)wy[0], b1 = (int)wy[1];
+        const int s0 = px(0, 0) * a0 + px(0, 1) * a1, s1 = px(1, 0) * a0 + px(1, 1) * a1;
+        return (unsigned char)((((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2);
+    }
+    if (kind == CV_KERNEL) {
+        unsigned int acc = 0u;                                        // unsigned: the wrap-around of the reference's int arithmetic, defined
+        for (int j = 0; j < ny; ++j) {
+            unsigned int row = 0u;
+            for (int k = 0; k < nx; ++k) row += (unsigned int)(px(j, k) * (int)wx[k]);
+            acc += row * (unsigned int)(int)wy[j];
+        }
+        const int v = ((int)(acc + (1u << 21))) >> 22;
+        return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+    if (kind == CV_AREA) {
+        float total = 0.f;
+        for (int j = 0; j < ny; ++j) {
+            float buf = 0.f;
+            for (int k = 0; k < nx; ++k) buf = buf + (float)px(j, k) * (float)wx[k];
+            const float term = (float)wy[j] * buf;
+            total = j == 0 ? term : total + term;
+        }
+        const float r = rintf(total);
+        return (unsigned char)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+    }
+    int sum = 0;
+    for (int j = 0; j < ny; ++j)
+        for (int k = 0; k < nx; ++k) sum += px(j, k);
+    if (kind == CV_AREA_FAST2) return (unsigned char)((sum + 2) >> 2);
+    const float r = rintf((float)sum * (1.f / (float)area));
+    return (unsigned char)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+
+// one plan for the whole batch: grid (blocks over Wo C, Ho, B); ix / wx [Wo][nx], iy / wy [Ho][ny]
+__global__ __launch_bounds__(256) void resize_cv_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ y, int H, int W,
+                                                        int Ho, int Wo, int C, int kind, int area, const int* __restrict__ ix,
+                                                        const double* __restrict__ wx, int nx, const int* __restrict__ iy,
+                                                        const double* __restrict__ wy, int ny) {
+    const int v = (int)blockIdx.x * 256 + (int)threadIdx.x, yo = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (v >= Wo * C) return;
+    const int xo = v / C, ch = v - xo * C;
+    const unsigned char* src = x + (size_t)b * H * W * C;
+    const int* ixr = ix + (size_t)xo * nx;
+    const int* iyr = iy + (size_t)yo * ny;
+    auto px = [&](int j, int k) -> int { return (int)src[((size_t)iyr[j] * W + ixr[k]) * C + ch]; };
+    y[((size_t)b * Ho + yo) * Wo * C + v] = cv_resample(kind, area, nx, ny, wx + (size_t)xo * nx, wy + (size_t)yo * ny, px);
+}
+
+// every image its own plan (the augmentation chain's gather launch): plan [B][4] = kind, area, taps per column, taps per row (<= nx, ny =
+// the tables' strides); ix / wx [B][Wo][nx], iy / wy [B][Ho][ny]; index -1 = the expansion canvas -> background [B][C]
+__global__ __launch_bounds__(256) void resize_gather_cv_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ y, int H,
+                                                               int W, int Ho, int Wo, int C, const int* __restrict__ plan,
+                                                               const int* __restrict__ ix, const double* __restrict__ wx, int nx,
+                                                               const int* __restrict__ iy, const double* __restrict__ wy, int ny,
+                                                               const unsigned char* __restrict__ background) {
+    const int v = (int)blockIdx.x * 256 + (int)threadIdx.x, yo = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (v >= Wo * C) return;
+    const int xo = v / C, ch = v - xo * C;
+    const int kind = plan[b * 4], area = plan[b * 4 + 1], tx = plan[b * 4 + 2], ty = plan[b * 4 + 3];
+    const int bg = (int)background[b * C + ch];
+    const int* ixb = ix + ((size_t)b * Wo + xo) * nx;
+    const int* iyb = iy + ((size_t)b * Ho + yo) * ny;
+    const unsigned char* src = x + (size_t)b * H * W * C;
+    auto px = [&](int j, int k) -> int {
+        const int sy = iyb[j], sx = ixb[k];
+        return (sy < 0 || sx < 0) ? bg : (int)src[((size_t)sy * W + sx) * C + ch];
+    };
+    y[((size_t)b * Ho + yo) * Wo * C + v] = cv_resample(kind, area, tx < nx ? tx : nx, ty < ny ? ty : ny, wx + ((size_t)b * Wo + xo) * nx,
+                                                        wy + ((size_t)b * Ho + yo) * ny, px);
+}
+
 __global__ __launch_bounds__(256) void hist_u8_kernel(const unsigned char* __restrict__ x, long long n_pixels, int C, int channel,
                                                       unsigned int* __restrict__ hist) {
     __shared__ unsigned int h[256];
@@ -406,6 +497,34 @@ extern "C" int ssdhip_image_resize_gather_u8(const void* x, void* y, int B, int 
     hipLaunchKernelGGL(resize_gather_kernel, dim3((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)B), dim3(256), 0, stream,
                        static_cast<const unsigned char*>(x), static_cast<unsigned char*>(y), H, W, Ho, Wo, C, ix_dev, wx_dev, nx, iy_dev, wy_dev, ny,
                        static_cast<const unsigned char*>(background_dev));
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_image_resize_cv_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, int kind, int area,
+                                         const int* ix_dev, const double* wx_dev, int nx, const int* iy_dev, const double* wy_dev, int ny,
+                                         void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || !ix_dev || !wx_dev || !iy_dev || !wy_dev) return SSDHIP_E_BADARG;
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || Ho <= 0 || Ho > 65535 || Wo <= 0 || C <= 0 || C > 4 || nx <= 0 || ny <= 0 || nx > 64 ||
+        ny > 64 || kind < 0 || kind > CV_COPY || area < 1)
+        return SSDHIP_E_BADARG;
+    if ((kind == CV_LINEAR && (nx != 2 || ny != 2)) || ((kind == CV_NEAREST || kind == CV_COPY) && (nx != 1 || ny != 1))) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(resize_cv_kernel, dim3((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)B), dim3(256), 0, stream,
+                       static_cast<const unsigned char*>(x), static_cast<unsigned char*>(y), H, W, Ho, Wo, C, kind, area, ix_dev, wx_dev, nx,
+                       iy_dev, wy_dev, ny);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_image_resize_gather_cv_u8(const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, const int* plan_dev,
+                                                const int* ix_dev, const double* wx_dev, int nx, const int* iy_dev, const double* wy_dev,
+                                                int ny, const void* background_dev, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || !plan_dev || !ix_dev || !wx_dev || !iy_dev || !wy_dev || !background_dev) return SSDHIP_E_BADARG;
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || Ho <= 0 || Ho > 65535 || Wo <= 0 || C <= 0 || C > 4 || nx < 2 || ny < 2 || nx > 64 || ny > 64)
+        return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(resize_gather_cv_kernel, dim3((unsigned)((Wo * C + 255) / 256), (unsigned)Ho, (unsigned)B), dim3(256), 0, stream,
+                       static_cast<const unsigned char*>(x), static_cast<unsigned char*>(y), H, W, Ho, Wo, C, plan_dev, ix_dev, wx_dev, nx,
+                       iy_dev, wy_dev, ny, static_cast<const unsigned char*>(background_dev));
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

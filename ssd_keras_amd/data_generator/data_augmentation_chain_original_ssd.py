@@ -137,7 +137,7 @@ class SSDDataAugmentation:
         """The whole chain on a device-resident batch: images (B, H, W, 3) CUDA uint8, labels a list of B
         (n_i, 5) arrays -> ((B, img_height, img_width, 3) CUDA uint8 batch, list of B label arrays).  TWO launches for the pixels of
         the whole batch -- the photometric distortions (`ssdhip_image_program`, one program per image) and expansion + crop + flip +
-        resize fused into one gather (`ssdhip_image_resize_gather_u8`: the geometric ops only record index maps, nothing but the final
+        resize fused into one gather (`ssdhip_image_resize_gather_cv_u8`: the geometric ops only record index maps, nothing but the final
         batch is materialised) -- and no PCIe traffic besides the tap tables.  The random draws, the label arithmetic and the box
         filtering are the per-image chain's own code in the per-image chain's order: with the same NumPy random state the result
         equals calling the chain on image 0, 1, 2, ... (tests/test_image_ops.py).
@@ -295,18 +295,18 @@ class SSDDataAugmentation:
         from .. import _native as nat
         out_h, out_w = int(self.resize.height), int(self.resize.width)
         # tap tables wide enough for the true area filter of the largest possible source (an expanded, uncropped image)
-        n_taps = max(8, int(np.ceil(float(self.expand.expand.patch_coord_generator.max_scale) * max(h / out_h, w / out_w))) + 1)
+        n_taps = max(8, int(np.ceil(float(self.expand.expand.patch_coord_generator.max_scale) * max(h / out_h, w / out_w))) + 2)
         inv = np.argsort(cols)
         if n_taps <= 64 and os.environ.get("SSDHIP_AUG_HOST_TAPS", "0") != "1":
             # ---- tap tables built on the device from the decisions, the gather launch behind them; the labels come back last (the only
             #      host synchronisation of the call) ------------------------------------------------------------------------------------
-            ix, wx, iy, wy = nat.augment_taps(geo_dev, h, w, out_h, out_w, n_taps)
+            plans, ix, wx, iy, wy = nat.augment_plans(geo_dev, h, w, out_h, out_w, n_taps)
             bg = self.__dict__.get("_bg_rows")
             if bg is None or bg[0] != (B, str(images.device)):
                 row = np.array([int(v) for v in self.expand.expand.background], dtype=np.uint8)
                 bg = ((B, str(images.device)), nat.to_device(np.repeat(row[None], B, 0), device=images.device))
                 self.__dict__["_bg_rows"] = bg
-            out = nat.image_resize_gather_u8(distorted.contiguous(), out_h, out_w, ix, wx, iy, wy, bg[1])
+            out = nat.image_resize_gather_cv_u8(distorted.contiguous(), out_h, out_w, plans, ix, wx, iy, wy, bg[1])
             geo, lab_out, n_out, mt_out = fetch()
             return out, [np.ascontiguousarray(lab_out[i, :int(n_out[i])][:, inv]).astype(dt) for i in range(B)], mt_out
         geo, lab_out, n_out, mt_out = fetch()

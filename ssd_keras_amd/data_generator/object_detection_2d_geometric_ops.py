@@ -2,9 +2,11 @@
 (`Resize`, `ResizeRandomInterp`, `Flip`, `RandomFlip`).
 
 The label arithmetic, the inverters, the random draws and the return conventions are the reference's; the resampling itself
-(`cv2.resize`, :70-72) runs on the GPU as separable taps (csrc/ssdhip_image.hip, `_image_ops.axis_taps`): one kernel for the five
-OpenCV interpolation modes the chain draws from (nearest, linear, cubic, area, Lanczos-4), float64 weights, one rounding -- OpenCV's
-8-bit paths use 11-bit fixed-point weights, so a real cv2 result can differ by one grey level (no OpenCV here to pin against).
+(`cv2.resize`, :70-72) runs on the GPU with the arithmetic of OpenCV's imgproc/resize.cpp for 8-bit images (round 6;
+csrc/ssdhip_image.hip, plans built by `_image_ops.resize_plan`): cv::resize's dispatch over the five interpolation modes the chain draws
+from -- 11-bit fixed-point coefficients with the two-stage vertical rounding (linear) or `(sum + 2^21) >> 22` (cubic, Lanczos-4), the
+area-mode bilinear variant, ResizeArea / ResizeAreaFast, nearest, copy -- checked against cases worked out by hand from that source
+(tests/resize_hand_cases.py; no OpenCV binary exists here to pin against).
 `Translate`, `Scale`, `Rotate` and their random forms (cv2.warpAffine; the satellite / constant-input-size chains) are not provided."""
 from __future__ import annotations
 

@@ -65,56 +65,72 @@ def test_call_surface_equals_the_reference():
 
 
 def test_host_tables_against_hand_computed_cases():
-    """The product's tap / table builders (`_image_ops.axis_taps`, `equalize_table`) against values worked out BY HAND from the
-    published definitions (OpenCV's sampling geometry src = (dst + 0.5) scale - 0.5 with replicated borders, the a = -0.75 cubic
-    kernel, the Lanczos-4 kernel, the box filter, equalizeHist's scale) -- not against oracle/np_image.py, whose builders are their twins
-    (VERDICT r3 weak #2 (iii): comparing the two with each other pinned nothing)."""
+    """cv2.resize's 8-bit arithmetic (round 6) against cases worked out BY HAND from imgproc/resize.cpp
+    (tests/resize_hand_cases.py: every expected pixel and coefficient derived in a comment there) -- the oracle's `resize`, and the
+    PRODUCT's plans (`_image_ops.resize_plan`: dispatch, tap indices, fixed-point shorts, area tables) evaluated by the pixel rule.
+    Then the product's equalizeHist table against a hand-computed histogram."""
+    from oracle import np_image as npi
     from ssd_keras_amd.data_generator import _image_ops as iop
-    # nearest, 6 -> 4: floor(dst 1.5) = 0, 1, 3, 4
-    i, w = iop.axis_taps(6, 4, iop.INTER_NEAREST)
-    assert i.dtype == np.int32 and i[:, 0].tolist() == [0, 1, 3, 4] and np.array_equal(w, np.ones((4, 1)))
-    # linear, 4 -> 2: centres 0.5 and 2.5 -> taps (0, 1) and (2, 3) with weights (0.5, 0.5)
-    i, w = iop.axis_taps(4, 2, iop.INTER_LINEAR)
-    assert i.tolist() == [[0, 1], [2, 3]] and np.array_equal(w, [[0.5, 0.5], [0.5, 0.5]])
-    # linear, 2 -> 4 (enlarging): centres -0.25, 0.25, 0.75, 1.25; the first / last taps are clamped to the border pixel
-    i, w = iop.axis_taps(2, 4, iop.INTER_LINEAR)
-    assert i.tolist() == [[0, 0], [0, 1], [0, 1], [1, 1]]
-    assert np.allclose(w, [[0.25, 0.75], [0.75, 0.25], [0.25, 0.75], [0.75, 0.25]], rtol=0, atol=1e-15)
-    # cubic (a = -0.75), 8 -> 4: every centre falls half way between two pixels: weights (-3/32, 19/32, 19/32, -3/32)
-    i, w = iop.axis_taps(8, 4, iop.INTER_CUBIC)
-    assert i.tolist() == [[0, 0, 1, 2], [1, 2, 3, 4], [3, 4, 5, 6], [5, 6, 7, 7]]
-    assert np.allclose(w, np.tile([-0.09375, 0.59375, 0.59375, -0.09375], (4, 1)), rtol=0, atol=1e-15)
-    # cubic, same size: fraction 0 -> the pixel itself
-    i, w = iop.axis_taps(5, 5, iop.INTER_CUBIC)
-    assert np.allclose(w, np.tile([0.0, 1.0, 0.0, 0.0], (5, 1)), rtol=0, atol=1e-15) and i[:, 1].tolist() == [0, 1, 2, 3, 4]
-    # Lanczos-4, same size: the delta; 8 -> 4: symmetric in the two centre taps, weights sum to one, outer lobes as the closed form gives
-    i, w = iop.axis_taps(7, 7, iop.INTER_LANCZOS4)
-    assert np.allclose(w[:, 3], 1.0) and np.allclose(np.delete(w, 3, axis=1), 0.0)
-    i, w = iop.axis_taps(16, 8, iop.INTER_LANCZOS4)
-    lz = lambda t: 4 * np.sin(np.pi * t) * np.sin(np.pi * t / 4) / (np.pi ** 2 * t ** 2)
-    row = np.array([lz(t) for t in (3.5, 2.5, 1.5, 0.5, 0.5, 1.5, 2.5, 3.5)])
-    assert np.allclose(w[3], row / row.sum(), rtol=1e-12) and i[3].tolist() == [3, 4, 5, 6, 7, 8, 9, 10]
-    # area, 4 -> 2: the box filter over two pixels; 3 -> 2: cells [0, 1.5) and [1.5, 3): weights (1, 0.5) / 1.5 and (0.5, 1) / 1.5
-    i, w = iop.axis_taps(4, 2, iop.INTER_AREA)
-    assert np.allclose(w[:, :2], 0.5) and np.allclose(w[:, 2:], 0.0) and i[:, :2].tolist() == [[0, 1], [2, 3]]
-    i, w = iop.axis_taps(3, 2, iop.INTER_AREA)
-    assert np.allclose(w[0, :2], [2 / 3, 1 / 3]) and np.allclose(w[1, :2], [1 / 3, 2 / 3]) and i[0, :2].tolist() == [0, 1] and i[1, :2].tolist() == [1, 2]
-    # area when NOT both axes shrink (cv2's `area_mode` bilinear variant): an integer enlargement replicates pixels, 2 -> 4: a a b b;
-    # 3 -> 4: sx = 0, 0, 1, 2 and fx = frac(1 - 4/3 <= 0 -> 0), 2 - 4/3 = 2/3, 3 - 8/3 = 1/3, last pixel -> 0
-    i, w = iop.axis_taps(2, 4, iop.INTER_AREA, area_linear=True)
-    assert (i[:, 0] * (w[:, 0] == 1)).tolist() == [0, 0, 1, 1] and np.array_equal(w, [[1, 0]] * 4)
-    i, w = iop.axis_taps(3, 4, iop.INTER_AREA, area_linear=True)
-    assert i[:, 0].tolist() == [0, 0, 1, 2] and np.allclose(w[:, 1], [0.0, 2 / 3, 1 / 3, 0.0], rtol=0, atol=1e-6)
-    for interp in range(5):                               # structural: indices inside the image, weights sum to one
-        for n_src, n_dst in ((20, 30), (48, 13), (300, 1), (5, 64), (1000, 300)):
-            i, w = iop.axis_taps(n_src, n_dst, interp)
-            assert i.dtype == np.int32 and np.all(i >= 0) and np.all(i < n_src) and np.allclose(w.sum(axis=1), 1.0)
+    from tests import resize_hand_cases as hc
+    for name, src, dsize, interp, want in hc.CASES:
+        assert np.array_equal(npi.resize(src, dsize, interp), want), name
+        plan = iop.resize_plan(src.shape[0], src.shape[1], dsize[1], dsize[0], interp)
+        assert plan[1].dtype == np.int32 and plan[3].dtype == np.int32
+        assert np.array_equal(npi.cv_apply_plan(src[:, :, None], plan)[:, :, 0], want), name
+    for n_src, n_dst, interp, horizontal, idx, coef in hc.TABLES:
+        i, c = iop.fixed_axis(n_src, n_dst, interp, False, horizontal)
+        if idx is not None:
+            assert i.tolist() == idx, (n_src, n_dst, interp, horizontal)
+        if isinstance(coef, dict):
+            for row, values in coef.items():
+                assert c[row].tolist() == values
+        else:
+            assert c.tolist() == coef, (n_src, n_dst, interp, horizontal)
+    # the dispatch: which of cv::resize's paths a geometry takes
+    kinds = lambda sh, sw, dh, dw, m: iop.resize_plan(sh, sw, dh, dw, m)[0]
+    assert kinds(10, 10, 10, 10, 2) == iop.KIND_COPY and kinds(10, 10, 5, 5, 1) == iop.KIND_AREA_FAST2
+    assert kinds(12, 12, 4, 4, 3) == iop.KIND_AREA_FAST and iop.resize_plan(12, 12, 4, 4, 3)[5] == 9
+    assert kinds(12, 12, 4, 4, 1) == iop.KIND_LINEAR                      # INTER_LINEAR is the area path only at exactly 2 x 2
+    assert kinds(375, 500, 300, 300, 3) == iop.KIND_AREA and kinds(375, 500, 300, 600, 3) == iop.KIND_LINEAR     # one axis grows: area-mode bilinear
+    assert kinds(20, 20, 30, 30, 4) == iop.KIND_KERNEL and iop.resize_plan(20, 20, 30, 30, 4)[1].shape[1] == 8
+    assert kinds(49, 49, 1, 1, 3) == iop.KIND_AREA                        # 1 / (1 / 49) is not 49 in float64: the `fast` test fails as in OpenCV
+    for interp in range(5):                                               # structural: indices inside the image; fixed-point rows sum to ~2048
+        for sh, sw, dh, dw in ((20, 20, 30, 30), (48, 48, 13, 13), (300, 300, 1, 1), (5, 5, 64, 64), (1000, 1000, 300, 300)):
+            kind, ix, wx, iy, wy, area = iop.resize_plan(sh, sw, dh, dw, interp)
+            assert np.all(ix >= 0) and np.all(ix < sw) and np.all(iy >= 0) and np.all(iy < sh)
+            if kind in (iop.KIND_LINEAR, iop.KIND_KERNEL):
+                assert np.all(np.abs(wx.sum(axis=1) - 2048) <= 4) and np.all(np.abs(wy.sum(axis=1) - 2048) <= 4)
+            if kind == iop.KIND_AREA:
+                assert np.allclose(wx.sum(axis=1), 1.0, atol=1e-6) and np.allclose(wy.sum(axis=1), 1.0, atol=1e-6)
+    # Lanczos' sine / cosine chain (shared with the device build of the tables): within an ulp or two of the C library's
+    y = np.linspace(-np.pi, -0.75 * np.pi, 2001)
+    sn, cs = iop.sincos_near_minus_pi(y)
+    assert np.abs(sn - np.sin(y)).max() <= 4e-16 and np.abs(cs - np.cos(y)).max() <= 4e-16
+    on, oc = npi.det_sincos(y)
+    assert np.array_equal(sn, on) and np.array_equal(cs, oc)
     # equalizeHist: 4 pixels of value 10, 4 of 20, 8 of 30 -> lut[10] = 0, lut[20] = round(4 * 255 / 12) = 85, lut[30] = 255, below 10 -> 0
     hist = np.zeros(256, dtype=np.int64)
     hist[10], hist[20], hist[30] = 4, 4, 8
     lut = iop.equalize_table(hist)
     assert lut.dtype == np.uint8 and lut[10] == 0 and lut[20] == 85 and lut[30] == 255 and lut[5] == 0 and lut[25] == 85
     assert np.array_equal(iop.equalize_table(np.bincount([7] * 9, minlength=256)), np.arange(256))      # a constant plane is left alone
+
+
+def test_product_plans_equal_the_oracles():
+    """The product's plan builder and the oracle's are written separately (vectorised / per destination): same kind, indices and table
+    values on a sweep of geometries, every interpolation mode."""
+    from oracle import np_image as npi
+    from ssd_keras_amd.data_generator import _image_ops as iop
+    rng = np.random.RandomState(9)
+    geos = [(23, 37, 23, 50), (23, 37, 15, 13), (40, 48, 20, 24), (40, 48, 10, 16), (30, 30, 10, 10), (23, 37, 46, 74), (375, 500, 300, 300),
+            (12, 46, 36, 46), (33, 45, 20, 20), (7, 3, 2, 9), (301, 299, 300, 300), (1, 1, 5, 5), (9, 1, 3, 4)]
+    geos += [tuple(int(v) for v in rng.randint(1, 400, size=4)) for _ in range(40)]
+    for sh, sw, dh, dw in geos:
+        for interp in range(5):
+            a, b = iop.resize_plan(sh, sw, dh, dw, interp), npi.cv_resize_plan(sh, sw, dh, dw, interp)
+            assert a[0] == b[0] and a[5] == b[5], (sh, sw, dh, dw, interp)
+            for u, v in zip(a[1:5], b[1:5]):
+                assert u.shape == v.shape and np.array_equal(u, v), (sh, sw, dh, dw, interp)
 
 
 def test_oracle_colour_conversions_have_the_documented_properties():
@@ -155,20 +171,13 @@ def test_host_logic_matches_reference(monkeypatch):
         assert out.dtype == out_dtype, (out.dtype, out_dtype)
         return out
 
-    def fake_resize(images, out_h, out_w, ix, wx, iy, wy):
-        src = images.numpy().astype(np.float64)
-        acc = np.zeros((src.shape[0], out_h, out_w, src.shape[3]))
-        for j in range(iy.shape[1]):
-            rows = src[:, iy[:, j]]
-            racc = np.zeros_like(acc)
-            for t in range(ix.shape[1]):
-                racc = racc + wx[None, None, :, t, None] * rows[:, :, ix[:, t]]
-            acc = acc + wy[None, :, j, None, None] * racc
-        return torch.from_numpy(np.clip(np.rint(acc), 0, 255).astype(np.uint8))
+    def fake_resize(images, out_h, out_w, kind, area, ix, wx, iy, wy):
+        plan = (kind, ix, wx, iy, wy, area)
+        return torch.from_numpy(np.stack([npi.cv_apply_plan(img, plan) for img in images.numpy()]))
 
     monkeypatch.setattr(nat, "to_device", lambda a, device=None, dtype=None: torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a)
     monkeypatch.setattr(nat, "image_program", fake_program)
-    monkeypatch.setattr(nat, "image_resize_u8", fake_resize)
+    monkeypatch.setattr(nat, "image_resize_cv_u8", fake_resize)
     monkeypatch.setattr(nat, "image_hist_u8", lambda image, channel: torch.from_numpy(
         np.bincount(image.numpy()[..., channel].reshape(-1), minlength=256).astype(np.int64)))
     monkeypatch.setattr(nat, "image_lut_u8", lambda image, table, mask: torch.from_numpy(np.where(
@@ -218,6 +227,17 @@ def test_gamma_and_batched_resize():
     big = rng.randint(0, 256, size=(2, 375, 500, 3)).astype(np.uint8)          # a VOC-sized image down to the network input
     got = iop.resize(torch.from_numpy(big).cuda(), 300, 300, 3).cpu().numpy()
     assert np.array_equal(got[1], npi.resize(big[1], (300, 300), 3))
+    # every path of cv::resize's dispatch through the kernel: fast area (2 x 2, 3 x 3, 4 x 1), true area, area-mode bilinear, the
+    # fixed-point kernels shrinking and enlarging, nearest, copy -- and the hand-computed cases of tests/resize_hand_cases.py
+    from tests import resize_hand_cases as hc
+    src = rng.randint(0, 256, size=(3, 48, 60, 3)).astype(np.uint8)
+    for out_h, out_w in ((24, 30), (16, 20), (48, 15), (31, 47), (48, 90), (96, 120), (100, 33), (48, 60), (7, 5)):
+        for interp in range(5):
+            got = iop.resize(torch.from_numpy(src).cuda(), out_h, out_w, interp).cpu().numpy()
+            want = np.stack([npi.resize(src[i], (out_w, out_h), interp) for i in range(src.shape[0])])
+            assert np.array_equal(got, want), (out_h, out_w, interp, int((got != want).sum()))
+    for name, img, dsize, interp, want in hc.CASES:
+        assert np.array_equal(iop.resize(img, dsize[1], dsize[0], interp), want), name
 
 
 @pytest.mark.gpu
