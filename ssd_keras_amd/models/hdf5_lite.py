@@ -1,0 +1,469 @@
+"""A pure-Python reader (and writer) for the HDF5 subset Keras weight files use -- SURVEY section 8f row 2: the reference ships its
+trained weights as `.h5` files written by `model.save_weights()` / `model.save()` (README.md:60-90, ssd300_training.ipynb:120-140) and
+h5py is not installed where this package runs.
+
+What `h5py.File(path, 'w')` with its default `libver='earliest'` writes, and what this module reads (HDF5 File Format Specification
+version 1.1 / 2.0, the "old style" structures):
+  * superblock version 0 or 1 (8-byte offsets and lengths), the root group's symbol table entry in it;
+  * groups as symbol tables: object header message 0x0011 -> a version-1 B-tree of group nodes ("TREE", node type 0, any depth) whose
+    leaves are symbol table nodes ("SNOD") and a local heap ("HEAP") with the link names;
+  * version-1 object headers with continuation blocks (message 0x0010); messages used: dataspace 0x0001 (versions 1, 2), datatype
+    0x0003 (fixed-point, floating-point, fixed-length string; variable-length strings are recognised and returned as None), data
+    layout 0x0008 (version 3 contiguous / compact; versions 1, 2 contiguous), attribute 0x000C (versions 1, 2, 3);
+  * datasets: contiguous or compact, little- or big-endian integers / floats of 1, 2, 4, 8 bytes, fixed-length strings.
+Not read (a clear HDF5FormatError instead): version-2 object headers / "new style" groups (libver='latest'), chunked or filtered
+datasets, superblock versions 2 and 3.  Keras never writes those for weights (`create_dataset(name, shape, dtype)` without chunks).
+
+`write()` produces files of exactly that subset (superblock 0, symbol table nodes under a B-tree of group nodes -- with the library's
+default K = 4 or, by default, one node per group with the superblock's "group leaf node K" set large enough, which the format allows --,
+contiguous little-endian datasets, version-1 attribute messages):
+`save_keras_weights_h5` uses it so that this package can hand weights back in the reference's container.
+
+PARITY NOTE: no HDF5 library and no real Keras weight file exist in this environment.  The reader is written from the published
+format specification and is tested against files produced by this module's own writer plus hand-assembled byte strings
+(tests/test_host_cpu.py) -- self-consistency, not an interoperability proof.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class HDF5FormatError(ValueError):
+    """The file is not HDF5, is damaged, or uses a structure outside the subset described in the module docstring."""
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# reading
+# ------------------------------------------------------------------------------------------------------------------------------------------
+class _Buf:
+    def __init__(self, data):
+        self.d = data
+
+    def u(self, off, size):
+        if off < 0 or off + size > len(self.d):
+            raise HDF5FormatError("read of %d bytes at %d beyond the end of the file (%d bytes)" % (size, off, len(self.d)))
+        return int.from_bytes(self.d[off:off + size], "little")
+
+    def raw(self, off, size):
+        if off < 0 or off + size > len(self.d):
+            raise HDF5FormatError("read of %d bytes at %d beyond the end of the file (%d bytes)" % (size, off, len(self.d)))
+        return self.d[off:off + size]
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+def _parse_datatype(b, off):
+    """-> (numpy dtype or None for an unsupported / variable-length type, element size, bytes consumed)."""
+    cls_ver = b.u(off, 1)
+    cls, bits0 = cls_ver & 0x0F, b.u(off + 1, 1)
+    size = b.u(off + 4, 4)
+    order = ">" if (bits0 & 1) else "<"
+    if cls == 0:                                             # fixed-point: properties bit offset (2), precision (2)
+        signed = bool(bits0 & 0x08)
+        if size not in (1, 2, 4, 8):
+            return None, size, 12
+        return np.dtype("%s%s%d" % (order, "i" if signed else "u", size)), size, 12
+    if cls == 1:                                             # floating-point: 12 bytes of properties
+        if size not in (2, 4, 8):
+            return None, size, 20
+        return np.dtype("%sf%d" % (order, size)), size, 20
+    if cls == 3:                                             # fixed-length string, no properties
+        return np.dtype("S%d" % size), size, 8
+    if cls == 9:                                             # variable-length: the base type follows; data live in the global heap
+        _, _, used = _parse_datatype(b, off + 8)
+        return None, size, 8 + used
+    return None, size, 8
+
+
+def _parse_dataspace(b, off):
+    """-> (shape tuple, bytes consumed)."""
+    version = b.u(off, 1)
+    rank, flags = b.u(off + 1, 1), b.u(off + 2, 1)
+    if version == 1:
+        p = off + 8
+    elif version == 2:
+        if b.u(off + 3, 1) == 2:                             # null dataspace
+            return None, 4
+        p = off + 4
+    else:
+        raise HDF5FormatError("dataspace message version %d" % version)
+    shape = tuple(b.u(p + 8 * i, 8) for i in range(rank))
+    used = (p - off) + 8 * rank * (2 if (flags & 1) else 1)
+    return shape, used
+
+
+def _decode(raw, dtype, shape):
+    count = int(np.prod(shape)) if shape else 1
+    arr = np.frombuffer(raw, dtype=dtype, count=count)
+    arr = arr.reshape(shape) if shape else arr.reshape(())
+    if dtype.kind in "iuf" and dtype.byteorder == ">":
+        arr = arr.astype(dtype.newbyteorder("<"))
+    return np.array(arr)                                      # an owning, writable copy
+
+
+class Node:
+    """A group or a dataset of the file.  Groups: `keys()`, `node[name]` (paths with '/' walk nested groups), `attrs` (dict of NumPy
+    values).  Datasets: `read()` -> NumPy array, `shape`, `dtype`, `attrs`."""
+
+    def __init__(self, f, header_addr, name):
+        self._f, self.name = f, name
+        self.attrs = {}
+        self._btree = self._heap = None
+        self._shape = self._dtype = self._layout = None
+        self._parse_header(header_addr)
+
+    # -- object header, version 1 --------------------------------------------------------------------------------------------------------
+    def _parse_header(self, addr):
+        b = self._f.b
+        if b.raw(addr, 4) == b"OHDR":
+            raise HDF5FormatError("object '%s' has a version-2 object header (file written with libver='latest'): not supported" % self.name)
+        if b.u(addr, 1) != 1:
+            raise HDF5FormatError("object header version %d at %d" % (b.u(addr, 1), addr))
+        n_msgs, size = b.u(addr + 2, 2), b.u(addr + 8, 4)
+        blocks = [(addr + 16, size)]
+        seen = 0
+        while blocks and seen < n_msgs:
+            p, left = blocks.pop(0)
+            end = p + left
+            while p + 8 <= end and seen < n_msgs:
+                mtype, msize, _flags = b.u(p, 2), b.u(p + 2, 2), b.u(p + 4, 1)
+                body = p + 8
+                seen += 1
+                if mtype == 0x0010:
+                    blocks.append((b.u(body, 8), b.u(body + 8, 8)))
+                else:
+                    self._message(mtype, body, msize)
+                p = body + msize
+
+    def _message(self, mtype, off, size):
+        b = self._f.b
+        if mtype == 0x0011:
+            self._btree, self._heap = b.u(off, 8), b.u(off + 8, 8)
+        elif mtype == 0x0001:
+            self._shape = _parse_dataspace(b, off)[0]
+        elif mtype == 0x0003:
+            self._dtype = _parse_datatype(b, off)[0]
+        elif mtype == 0x0008:
+            version = b.u(off, 1)
+            if version == 3:
+                cls = b.u(off + 1, 1)
+                if cls == 1:
+                    self._layout = ("contiguous", b.u(off + 2, 8), b.u(off + 10, 8))
+                elif cls == 0:
+                    n = b.u(off + 2, 2)
+                    self._layout = ("compact", off + 4, n)
+                else:
+                    self._layout = ("chunked", 0, 0)
+            elif version in (1, 2):
+                rank, cls = b.u(off + 1, 1), b.u(off + 2, 1)
+                if cls == 1:
+                    self._layout = ("contiguous", b.u(off + 8, 8), None)
+                elif cls == 0:
+                    p = off + 8 + 4 * rank
+                    self._layout = ("compact", p + 4, b.u(p, 4))
+                else:
+                    self._layout = ("chunked", 0, 0)
+            else:
+                raise HDF5FormatError("data layout message version %d" % version)
+        elif mtype == 0x000C:
+            self._attribute(off)
+
+    def _attribute(self, off):
+        b = self._f.b
+        version = b.u(off, 1)
+        name_size, dt_size, ds_size = b.u(off + 2, 2), b.u(off + 4, 2), b.u(off + 6, 2)
+        if version == 1:
+            p = off + 8
+            step = _pad8
+        elif version in (2, 3):
+            p = off + 8 + (1 if version == 3 else 0)
+            step = lambda n: n
+        else:
+            raise HDF5FormatError("attribute message version %d" % version)
+        name = b.raw(p, name_size).split(b"\x00", 1)[0].decode("utf-8", "replace")
+        p += step(name_size)
+        dtype, elem, _ = _parse_datatype(b, p)
+        p += step(dt_size)
+        shape = _parse_dataspace(b, p)[0]
+        p += step(ds_size)
+        if dtype is None or shape is None:
+            self.attrs[name] = None                              # variable-length strings etc.: present, not decoded
+            return
+        count = int(np.prod(shape)) if shape else 1
+        self.attrs[name] = _decode(b.raw(p, count * elem), dtype, shape)
+
+    # -- groups ------------------------------------------------------------------------------------------------------------------------------
+    @property
+    def is_group(self):
+        return self._btree is not None
+
+    def _links(self):
+        if not self.is_group:
+            raise HDF5FormatError("'%s' is a dataset, not a group" % self.name)
+        b = self._f.b
+        if b.raw(self._heap, 4) != b"HEAP":
+            raise HDF5FormatError("local heap signature missing at %d" % self._heap)
+        heap_data = b.u(self._heap + 24, 8)
+        out = {}
+
+        def walk(addr, depth):
+            if depth > 64:
+                raise HDF5FormatError("group B-tree deeper than 64 levels")
+            if b.raw(addr, 4) != b"TREE":
+                raise HDF5FormatError("B-tree signature missing at %d" % addr)
+            if b.u(addr + 4, 1) != 0:
+                raise HDF5FormatError("B-tree node type %d in a group" % b.u(addr + 4, 1))
+            level, used = b.u(addr + 5, 1), b.u(addr + 6, 2)
+            p = addr + 24
+            for i in range(used):
+                child = b.u(p + 8 + 16 * i, 8)                   # key, child, key, child, ..., key
+                if level > 0:
+                    walk(child, depth + 1)
+                    continue
+                if b.raw(child, 4) != b"SNOD":
+                    raise HDF5FormatError("symbol table node signature missing at %d" % child)
+                for k in range(b.u(child + 6, 2)):
+                    e = child + 8 + 40 * k
+                    name_off, header = b.u(e, 8), b.u(e + 8, 8)
+                    q = heap_data + name_off
+                    end = self._f.b.d.find(b"\x00", q)
+                    out[self._f.b.d[q:end].decode("utf-8", "replace")] = header
+
+        walk(self._btree, 0)
+        return out
+
+    def keys(self):
+        return sorted(self._links())
+
+    def __contains__(self, name):
+        try:
+            self[name]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, path):
+        node = self
+        for part in [p for p in path.split("/") if p]:
+            links = node._links()
+            if part not in links:
+                raise KeyError("'%s' not in group '%s'" % (part, node.name))
+            node = Node(self._f, links[part], (node.name.rstrip("/") + "/" + part))
+        return node
+
+    # -- datasets ----------------------------------------------------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def read(self):
+        if self.is_group:
+            raise HDF5FormatError("'%s' is a group" % self.name)
+        if self._dtype is None or self._shape is None or self._layout is None:
+            raise HDF5FormatError("dataset '%s': unsupported datatype or missing dataspace / layout message" % self.name)
+        kind, addr, size = self._layout
+        if kind == "chunked":
+            raise HDF5FormatError("dataset '%s' is chunked (or filtered): not supported -- Keras writes weights contiguously" % self.name)
+        count = int(np.prod(self._shape)) if self._shape else 1
+        need = count * self._dtype.itemsize
+        if need == 0:
+            return np.zeros(self._shape, dtype=self._dtype)
+        if addr == UNDEF:
+            raise HDF5FormatError("dataset '%s' has no storage allocated" % self.name)
+        return _decode(self._f.b.raw(addr, need), self._dtype, self._shape)
+
+
+class File:
+    """`File(path_or_bytes)`: `.root` is the root group; `f[path]`, `f.attrs`, `f.keys()` forward to it."""
+
+    def __init__(self, source):
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            data = bytes(source)
+        else:
+            with open(source, "rb") as fh:
+                data = fh.read()
+        self.b = _Buf(data)
+        base = -1
+        for start in [0] + [512 << i for i in range(24)]:       # the superblock sits at 0 or at 512, 1024, 2048, ...
+            if start + 8 <= len(data) and data[start:start + 8] == SIGNATURE:
+                base = start
+                break
+        if base < 0:
+            raise HDF5FormatError("no HDF5 signature: not an HDF5 file")
+        version = self.b.u(base + 8, 1)
+        if version not in (0, 1):
+            raise HDF5FormatError("superblock version %d (libver='latest' file): only versions 0 and 1 are supported" % version)
+        if self.b.u(base + 13, 1) != 8 or self.b.u(base + 14, 1) != 8:
+            raise HDF5FormatError("offsets / lengths of %d / %d bytes: only 8 / 8 is supported" % (self.b.u(base + 13, 1), self.b.u(base + 14, 1)))
+        p = base + 24 + (4 if version == 1 else 0)
+        if self.b.u(p, 8) != 0 or base != 0:
+            raise HDF5FormatError("a non-zero base address (user block) is not supported")
+        root_entry = p + 32
+        self.root = Node(self, self.b.u(root_entry + 8, 8), "/")
+
+    def __getitem__(self, path):
+        return self.root[path]
+
+    def __contains__(self, path):
+        return path in self.root
+
+    def keys(self):
+        return self.root.keys()
+
+    @property
+    def attrs(self):
+        return self.root.attrs
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# writing (the same subset)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _dtype_message(dt):
+    dt = np.dtype(dt)
+    if dt.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0, 0, 0, dt.itemsize)                     # class 3, version 1; null-terminated ASCII
+    if dt.kind == "f":
+        bits = dt.itemsize * 8
+        exp_bits, man_bits, bias = {2: (5, 10, 15), 4: (8, 23, 127), 8: (11, 52, 1023)}[dt.itemsize]
+        # byte order little (bit 0 = 0), mantissa normalisation 2 (implied leading bit: bits 4-5 = 2), sign location = the top bit
+        return (struct.pack("<BBBBI", 0x11, 0x20, bits - 1, 0, dt.itemsize) +
+                struct.pack("<HHBBBBI", 0, bits, man_bits, exp_bits, 0, man_bits, bias))
+    if dt.kind in "iu":
+        bits0 = 0x08 if dt.kind == "i" else 0x00
+        return struct.pack("<BBBBI", 0x10, bits0, 0, 0, dt.itemsize) + struct.pack("<HH", 0, dt.itemsize * 8)
+    raise TypeError("cannot write dtype %s" % dt)
+
+
+def _dataspace_message(shape):
+    return struct.pack("<BBBB4x", 1, len(shape), 0, 0) + b"".join(struct.pack("<Q", int(n)) for n in shape)
+
+
+def _norm(a):
+    a = np.asarray(a)
+    if a.dtype.kind == "U":
+        a = np.char.encode(a, "utf-8")
+    if a.dtype.kind in "iuf" and a.dtype.byteorder == ">":
+        a = a.astype(a.dtype.newbyteorder("<"))
+    if a.dtype.kind == "O":
+        raise TypeError("object arrays cannot be written")
+    return np.asarray(a, order="C")                           # (ascontiguousarray would turn a scalar into a one-element vector)
+
+
+def _message(mtype, body):
+    body = body + b"\x00" * (_pad8(len(body)) - len(body))
+    return struct.pack("<HHB3x", mtype, len(body), 0) + body
+
+
+def _attr_message(name, value):
+    a = _norm(value)
+    nm = name.encode("utf-8") + b"\x00"
+    dt, ds = _dtype_message(a.dtype), _dataspace_message(a.shape)
+    pad = lambda x: x + b"\x00" * (_pad8(len(x)) - len(x))
+    return _message(0x000C, struct.pack("<BxHHH", 1, len(nm), len(dt), len(ds)) + pad(nm) + pad(dt) + pad(ds) + a.tobytes())
+
+
+def _object_header(messages):
+    body = b"".join(messages)
+    return struct.pack("<BxHII4x", 1, len(messages), 1, len(body)) + body
+
+
+class _Writer:
+    def __init__(self):
+        self.chunks = []
+        self.pos = 96                                         # behind the superblock
+
+    def place(self, data):
+        addr = self.pos
+        data = data + b"\x00" * (_pad8(len(data)) - len(data))
+        self.chunks.append(data)
+        self.pos += len(data)
+        return addr
+
+    def dataset(self, arr, attrs):
+        a = _norm(arr)
+        data_addr = self.place(a.tobytes()) if a.size else UNDEF
+        msgs = [_message(0x0001, _dataspace_message(a.shape)), _message(0x0003, _dtype_message(a.dtype)),
+                _message(0x0008, struct.pack("<BBQQ", 3, 1, data_addr, a.nbytes))]
+        msgs += [_attr_message(k, v) for k, v in attrs.items()]
+        return self.place(_object_header(msgs))
+
+    def group(self, node):
+        """node: {'attrs': {...}, 'groups': {name: node}, 'datasets': {name: array | (array, attrs)}} -> (header address, btree, heap)."""
+        children = {}
+        for name, sub in node.get("groups", {}).items():
+            children[name] = self.group(sub)[0]
+        for name, ds in node.get("datasets", {}).items():
+            arr, attrs = ds if isinstance(ds, tuple) else (ds, {})
+            children[name] = self.dataset(arr, attrs)
+        names = sorted(children, key=lambda s: s.encode("utf-8"))
+        heap_data, offsets = bytearray(b"\x00" * 8), {}
+        for name in names:
+            offsets[name] = len(heap_data)
+            raw = name.encode("utf-8") + b"\x00"
+            heap_data += raw + b"\x00" * (_pad8(len(raw)) - len(raw))
+        heap_data_addr = self.place(bytes(heap_data))
+        heap = self.place(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, heap_data_addr))
+        # symbol table nodes of at most 2 K links each (sorted by name), a B-tree of group nodes over them: level 0 nodes hold up to
+        # 2 K' children (K' = 16, "group internal node K"), further levels as needed; key i + 1 = heap offset of the largest name
+        # below child i, key 0 = the empty string at offset 0
+        per = 2 * self.leaf_k
+        leaves = []                                               # (address, offset of the largest name)
+        for i in range(0, max(len(names), 1), per):
+            part = names[i:i + per]
+            snod = b"SNOD" + struct.pack("<BxH", 1, len(part))
+            for name in part:
+                snod += struct.pack("<QQII16x", offsets[name], children[name], 0, 0)
+            snod += b"\x00" * (40 * (per - len(part)))
+            if part:
+                leaves.append((self.place(snod), offsets[part[-1]]))
+        level, nodes = 0, leaves
+        while True:
+            parents = []
+            for i in range(0, max(len(nodes), 1), 32):
+                part = nodes[i:i + 32]
+                tree = b"TREE" + struct.pack("<BBHQQ", 0, level, len(part), UNDEF, UNDEF) + struct.pack("<Q", 0)
+                for addr, key in part:
+                    tree += struct.pack("<QQ", addr, key)
+                tree += b"\x00" * (24 + 8 + 16 * 32 - len(tree))   # room for 2 K' children and 2 K' + 1 keys
+                parents.append((self.place(tree), part[-1][1] if part else 0))
+            if len(parents) == 1:
+                btree = parents[0][0]
+                break
+            level, nodes = level + 1, parents
+        msgs = [_message(0x0011, struct.pack("<QQ", btree, heap))] + [_attr_message(k, v) for k, v in node.get("attrs", {}).items()]
+        return self.place(_object_header(msgs)), btree, heap
+
+
+def _max_children(node):
+    n = len(node.get("groups", {})) + len(node.get("datasets", {}))
+    return max([n] + [_max_children(sub) for sub in node.get("groups", {}).values()])
+
+
+def write(path, root, leaf_k=None):
+    """Write `root` = {'attrs': {name: array-like}, 'groups': {name: <same>}, 'datasets': {name: array or (array, attrs)}} as an HDF5
+    file of the subset described in the module docstring.  Attribute values: numbers, fixed-length byte strings (np.bytes_ arrays;
+    str arrays are encoded as UTF-8 bytes).  `leaf_k`: the superblock's "group leaf node K" (a symbol table node holds 2 K links);
+    None = large enough for one node per group, 4 = the HDF5 library's default (several nodes under a B-tree, as a real file has)."""
+    w = _Writer()
+    w.leaf_k = int(leaf_k) if leaf_k else max(4, (_max_children(root) + 1) // 2)
+    if w.leaf_k > 0x7FFF:
+        raise ValueError("too many links in one group")
+    header, btree, heap = w.group(root)
+    sb = (SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, w.leaf_k, 16, 0) +
+          struct.pack("<QQQQ", 0, UNDEF, w.pos, UNDEF) + struct.pack("<QQII", 0, header, 1, 0) + struct.pack("<QQ", btree, heap))
+    assert len(sb) == 96
+    with open(path, "wb") as fh:
+        fh.write(sb)
+        for c in w.chunks:
+            fh.write(c)

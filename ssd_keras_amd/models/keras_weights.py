@@ -8,8 +8,9 @@ torch's is OIHW; BatchNormalization stores `gamma, beta, moving_mean, moving_var
 
 `keras_layer_map(model)` gives name -> list of (parameter/buffer, to_torch, to_keras) in Keras' `weight_names` order;
 `load_keras_weights(model, source)` takes a `{layer_name: [arrays in Keras order]}` dict, the path of an `.npz` container
-(keys "<layer>/<index>": `save_keras_weights_npz`, or `NPZ_CONVERSION` run once next to the Keras file -- no h5py on this side) or the
-path of a Keras `.h5` weight file (needs h5py, which is not installed in every environment: ImportError says so);
+(keys "<layer>/<index>": `save_keras_weights_npz`, or `NPZ_CONVERSION` run once next to the Keras file) or the path of a Keras `.h5`
+weight file -- read with h5py where it is installed, otherwise with this package's own reader of the HDF5 subset Keras writes
+(models/hdf5_lite.py, round 6; `save_keras_weights_h5` writes the same container);
 `export_keras_weights(model)` is the inverse (dict).  `by_name` semantics as in Keras: layers missing from the source keep
 their initialisation, layers whose shapes do not match raise ValueError.
 """
@@ -53,12 +54,43 @@ def keras_layer_map(model):
     return m
 
 
+def _strings(values):
+    return [v.decode("utf-8") if isinstance(v, bytes) else str(v) for v in np.asarray(values).reshape(-1).tolist()]
+
+
+def _chunked_attr(attrs, name):
+    """Keras splits attributes beyond HDF5's 64 KB header limit into `name0`, `name1`, ... (saving.py: save_attributes_to_hdf5_group)."""
+    if name in attrs and attrs[name] is not None:
+        return _strings(attrs[name])
+    out, i = [], 0
+    while "%s%d" % (name, i) in attrs:
+        out += _strings(attrs["%s%d" % (name, i)])
+        i += 1
+    if not out and "%s0" % name not in attrs:
+        raise KeyError("attribute '%s' not found" % name)
+    return out
+
+
+def _read_h5_lite(path):
+    """The same walk over a Keras weight file with this package's own HDF5 reader (models/hdf5_lite.py: the "old style" subset
+    h5py's default libver writes; no HDF5 library needed)."""
+    from . import hdf5_lite
+    f = hdf5_lite.File(path)
+    g = f["model_weights"] if "model_weights" in f else f.root
+    out = {}
+    for name in _chunked_attr(g.attrs, "layer_names"):
+        layer = g[name]
+        weight_names = _chunked_attr(layer.attrs, "weight_names")
+        if weight_names:
+            out[name] = [layer[w].read() for w in weight_names]
+    return out
+
+
 def _read_h5(path):
     try:
         import h5py
-    except ImportError as e:                                     # pragma: no cover - depends on the environment
-        raise ImportError("reading Keras .h5 weight files needs h5py, which is not installed here; pass a "
-                          "{layer_name: [arrays]} dict instead (e.g. from np.load of a converted file)") from e
+    except ImportError:                                          # the usual case where this package runs: its own reader
+        return _read_h5_lite(path)
     out = {}
     with h5py.File(path, "r") as f:
         g = f["model_weights"] if "model_weights" in f else f
@@ -83,6 +115,27 @@ np.savez(sys.argv[2], **out)
 """
 
 
+def save_keras_weights_h5(source, path, backend="tensorflow", keras_version="2.2.4"):
+    """Write a `{layer_name: [arrays in Keras order]}` dict (or a model: its export_keras_weights) as a Keras weight FILE -- the layout
+    `model.save_weights(path)` produces (keras/engine/saving.py save_weights_to_hdf5_group): root attributes `layer_names`, `backend`,
+    `keras_version`; one group per layer with the attribute `weight_names` = ["<layer>/kernel:0", "<layer>/bias:0", ...] and the arrays
+    as datasets under those paths -- through this package's HDF5 writer (models/hdf5_lite.py; no h5py).  Weight names follow Keras 2:
+    Conv2D kernel / bias, BatchNormalization gamma / beta / moving_mean / moving_variance, L2Normalization gamma."""
+    from . import hdf5_lite
+    weights = source if isinstance(source, dict) else export_keras_weights(source)
+    conv, bn = ("kernel:0", "bias:0"), ("gamma:0", "beta:0", "moving_mean:0", "moving_variance:0")
+    groups = {}
+    for name, arrays in weights.items():
+        labels = bn if len(arrays) == 4 else (("gamma:0",) if (len(arrays) == 1 and np.asarray(arrays[0]).ndim == 1) else conv[:len(arrays)])
+        names = ["%s/%s" % (name, lab) for lab in labels]
+        groups[name] = {"attrs": {"weight_names": np.array([n.encode("utf-8") for n in names])},
+                        "groups": {name: {"datasets": {lab: np.asarray(a, dtype=np.float32) for lab, a in zip(labels, arrays)}}}}
+    root = {"attrs": {"layer_names": np.array([n.encode("utf-8") for n in weights]), "backend": np.bytes_(backend.encode("utf-8")),
+                      "keras_version": np.bytes_(keras_version.encode("utf-8"))},
+            "groups": groups}
+    hdf5_lite.write(path, root)
+
+
 def save_keras_weights_npz(source, path):
     """Write a `{layer_name: [arrays in Keras order]}` dict (or a model: its export_keras_weights) as the h5py-free container:
     an .npz whose keys are "<layer name>/<index in Keras' weight_names order>" -- what NPZ_CONVERSION produces from a Keras .h5."""
@@ -103,7 +156,7 @@ def _read_npz(path):
 
 def load_keras_weights(model, source, by_name=True, strict_shapes=True):
     """Load Keras-layout weights into `model` (in place).  `source`: a `{layer_name: [arrays]}` dict, the path of an .npz
-    container (save_keras_weights_npz / NPZ_CONVERSION; no h5py needed) or of a Keras .h5 weight file (needs h5py).
+    container (save_keras_weights_npz / NPZ_CONVERSION) or of a Keras .h5 weight file (h5py if installed, else models/hdf5_lite.py).
     Returns (loaded layer names, model layers absent from the source)."""
     if isinstance(source, str):
         weights = _read_npz(source) if source.endswith(".npz") else _read_h5(source)

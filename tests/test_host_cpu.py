@@ -420,3 +420,102 @@ def test_training_assembly_gate_is_the_kernels_lds_formula():
     assert not nat.assemble_backward_supported(250, [4, 6], [pad(4, 250), pad(6, 250)])       # beyond a CU's LDS: refused, not launched
     assert not nat.assemble_backward_supported(21, [4], [100])                                # a stride the kernel refuses (not % 8)
     assert not nat.assemble_backward_supported(21, [4], [96])                                 # ... or too narrow for 4 x 25 values
+
+
+def test_keras_h5_weight_files_without_h5py(tmp_path):
+    """SURVEY 8f row 2 / VERDICT r5 item 9: a Keras `.h5` weight file read WITHOUT an HDF5 library (models/hdf5_lite.py: superblock 0,
+    symbol-table groups under version-1 B-trees, local heaps, version-1 object headers with fixed-string attributes, contiguous
+    datasets -- what h5py's default libver writes for `model.save_weights`).  No HDF5 library and no real Keras file exist here, so this
+    is SELF-CONSISTENCY: (a) the writer's bytes carry the structures of the published format at their documented offsets; (b) an SSD300's
+    weighted layers go file -> fresh model bit for bit, with the library-default node size (several symbol table nodes, a B-tree
+    over them) and through `model.save()`'s `model_weights` sub-group; (c) reader paths the writer does not produce: big-endian data,
+    a version-3 attribute message, 80 links under a two-level B-tree, a continuation block."""
+    import struct
+    import torch
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models import hdf5_lite as h5
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.models.keras_weights import export_keras_weights, load_keras_weights, save_keras_weights_h5
+    cfg = syn.SSD300_VOC
+    mk = lambda seed: (torch.manual_seed(seed), ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"],
+                                                       aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"],
+                                                       offsets=cfg["offsets"]))[1]
+    a = mk(1)
+    path = str(tmp_path / "weights.h5")
+    save_keras_weights_h5(a, path)
+    raw = open(path, "rb").read()
+    # (a) the published layout: signature, superblock version 0, 8-byte offsets / lengths, end-of-file address, the root entry's header
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n" and raw[8] == 0 and raw[13] == 8 and raw[14] == 8
+    assert struct.unpack_from("<Q", raw, 40)[0] == len(raw)
+    root_header = struct.unpack_from("<Q", raw, 64)[0]
+    assert raw[root_header] == 1                                                  # a version-1 object header
+    btree, heap = struct.unpack_from("<QQ", raw, 80)
+    assert raw[btree:btree + 4] == b"TREE" and raw[heap:heap + 4] == b"HEAP"
+    f = h5.File(path)
+    names = [n.decode() for n in f.attrs["layer_names"]]
+    assert len(names) == len(export_keras_weights(a)) >= 35 and "conv4_3_norm" in names and f.attrs["backend"].item() == b"tensorflow"
+    assert [w.decode() for w in f["conv1_1"].attrs["weight_names"]] == ["conv1_1/kernel:0", "conv1_1/bias:0"]
+    k = f["conv1_1/conv1_1/kernel:0"]
+    assert k.shape == (3, 3, 3, 64) and k.dtype == np.dtype("<f4")                # HWIO, as Keras stores a Conv2D kernel
+    # (b) file -> fresh model
+    want = export_keras_weights(a)
+    for variant in ("plain", "library_k", "model_save"):
+        p2 = str(tmp_path / (variant + ".h5"))
+        if variant == "plain":
+            p2 = path
+        elif variant == "library_k":
+            root = {"attrs": {"layer_names": np.array([n.encode() for n in want])},
+                    "groups": {n: {"attrs": {"weight_names": np.array([("%s/w%d" % (n, i)).encode() for i in range(len(arrs))])},
+                                   "groups": {n: {"datasets": {"w%d" % i: arr for i, arr in enumerate(arrs)}}}} for n, arrs in want.items()}}
+            h5.write(p2, root, leaf_k=4)                                          # ~36 links: five symbol table nodes under one B-tree node
+        else:
+            inner = {"attrs": {"layer_names": np.array([n.encode() for n in want])},
+                     "groups": {n: {"attrs": {"weight_names": np.array([("%s/w%d" % (n, i)).encode() for i in range(len(arrs))])},
+                                    "groups": {n: {"datasets": {"w%d" % i: arr for i, arr in enumerate(arrs)}}}} for n, arrs in want.items()}}
+            h5.write(p2, {"groups": {"model_weights": inner, "optimizer_weights": {}}, "attrs": {"keras_version": np.bytes_(b"2.2.4")}})
+        b = mk(2)
+        loaded, missing = load_keras_weights(b, p2)
+        assert sorted(loaded) == sorted(want) and missing == []
+        got = export_keras_weights(b)
+        assert all(np.array_equal(x, y) for n in want for x, y in zip(got[n], want[n])), variant
+    # (c) 80 links with K = 1: forty symbol table nodes, two level-0 B-tree nodes, one level-1 node
+    many = {"datasets": {"d%03d" % i: np.full((2,), i, np.int16) for i in range(80)}}
+    p3 = str(tmp_path / "many.h5")
+    h5.write(p3, many, leaf_k=1)
+    f3 = h5.File(p3)
+    assert f3.keys() == ["d%03d" % i for i in range(80)] and all(int(f3["d%03d" % i].read()[1]) == i for i in (0, 1, 39, 40, 79))
+    top = struct.unpack_from("<Q", open(p3, "rb").read(), 80)[0]
+    assert open(p3, "rb").read()[top + 5] == 1                                     # the root's B-tree node is a level-1 node
+    # big-endian float data + datatype; a version-3 attribute; a continuation block -- patched / assembled by hand
+    p4 = str(tmp_path / "be.h5")
+    h5.write(p4, {"datasets": {"x": np.array([1.5, -2.25, 3.0], np.float32)}})
+    buf = bytearray(open(p4, "rb").read())
+    pos = bytes(buf).find(np.array([1.5, -2.25, 3.0], "<f4").tobytes())
+    buf[pos:pos + 12] = np.array([1.5, -2.25, 3.0], ">f4").tobytes()
+    dt = bytes(buf).find(bytes([0x11, 0x20, 31, 0, 4, 0, 0, 0]))
+    buf[dt + 1] |= 1                                                               # byte order bit: big-endian
+    assert np.array_equal(h5.File(bytes(buf))["x"].read(), np.array([1.5, -2.25, 3.0], np.float32))
+    # an object header whose attribute sits in a continuation block, the attribute in version 3 (no padding, a character-set byte)
+    dt_msg, ds_msg = h5._dtype_message(np.dtype("<i4")), h5._dataspace_message((2,))
+    att3 = struct.pack("<BBHHHB", 3, 0, 2, len(dt_msg), len(ds_msg), 0) + b"n\x00" + dt_msg + ds_msg + np.array([7, -9], "<i4").tobytes()
+    cont_block = h5._message(0x000C, att3)
+    base = bytearray(open(p4, "rb").read())
+    cont_addr = len(base)
+    base += cont_block
+    # the root header: rewrite it behind everything with a continuation message added
+    root_header = struct.unpack_from("<Q", base, 64)[0]
+    n_msgs, size = struct.unpack_from("<H", base, root_header + 2)[0], struct.unpack_from("<I", base, root_header + 8)[0]
+    msgs = bytes(base[root_header + 16:root_header + 16 + size]) + h5._message(0x0010, struct.pack("<QQ", cont_addr, len(cont_block)))
+    new_header = struct.pack("<BxHII4x", 1, n_msgs + 2, 1, len(msgs)) + msgs
+    struct.pack_into("<Q", base, 64, len(base))
+    base += new_header
+    struct.pack_into("<Q", base, 40, len(base))
+    f5 = h5.File(bytes(base))
+    assert np.array_equal(f5.attrs["n"], [7, -9]) and f5.keys() == ["x"]
+    # errors are specific
+    with pytest.raises(h5.HDF5FormatError, match="not an HDF5 file"):
+        h5.File(b"PK\x03\x04" + b"\x00" * 64)
+    v2 = bytearray(open(p4, "rb").read())
+    v2[8] = 2
+    with pytest.raises(h5.HDF5FormatError, match="superblock version 2"):
+        h5.File(bytes(v2))
