@@ -994,29 +994,44 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
             const u64 sall = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(sall_v >> 32)) << 32) |
                              (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)sall_v);      // scalar: the skips below are s_cbranch
             PROF_MARK(4)
-            // ---- phase B: in-batch pairs i > j.  Row j (lanes j+1..nb-1) and row nb-1-j (lanes nb-j..nb-1) together fill
-            //      nb-1 lanes: folded row f handles rows f and nb-1-f in one step.  Bit i of maskrow[j] = "j suppresses i". ----
-            const int nfold = (nb + 1) >> 1;
+            // ---- round 6: the rest of the batch runs on the candidates phase A left ALIVE, renumbered densely (order kept).  On real
+            //      score distributions two thirds of a batch die against the earlier survivors: their rows of the in-batch matrix are
+            //      never read and nothing they could suppress matters either, so the triangle shrinks from nb (nb - 1) / 2 pairs to
+            //      na (na - 1) / 2 (na ~ nb / 3: a ninth), and the resolve walks na lanes.  `dl` = the batch lane of the candidate with
+            //      dense rank `lane`: every lane pushes its own index to its rank (alive first, dead behind them) through the LDS
+            //      crossbar -- no memory, no barrier.
+            const u64 nbmask = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+            const u64 live0 = nbmask & ~sall;                                       // scalar
+            const int na = __popcll(live0);
+            int dl;
+            {
+                const bool mine = (live0 >> lane) & 1ull;
+                const int below = __popcll(live0 & lanemask_lt());                  // alive lanes below this one
+                const int dest = mine ? below : na + (lane - below);                // a bijection of the 64 lanes
+                dl = __builtin_amdgcn_ds_permute(dest << 2, lane);
+            }
+            // ---- phase B: pairs i > j among the na alive candidates.  Row j (lanes j+1..na-1) and row na-1-j (lanes na-j..na-1)
+            //      together fill na-1 lanes: folded row f handles rows f and na-1-f in one step.  Bit i of maskrow[j] = "j suppresses i",
+            //      i and j DENSE ranks. ----
+            const int nfold = (na + 1) >> 1;
             for (int f0 = wave * UB; f0 < nfold; f0 += UB * W) {     // UB folded rows per step: their LDS reads overlap
                 bool s4[UB], un4[UB], act4[UB];
                 int ii4[UB], jj4[UB];
                 FBox bi[UB], bj[UB];
-                bool any_live = false;
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int f = f0 + u;
-                    const int jA = f, jB = nb - 1 - f;
+                    const int jA = f, jB = na - 1 - f;
                     const bool row = f < nfold;
-                    const bool deadA = !row || ((sall >> (jA & 63)) & 1ull), deadB = !row || ((sall >> (jB & 63)) & 1ull) || jB == jA;
-                    const bool isA = lane > jA && lane < nb;
-                    const bool isB = lane < f;                               // pair (nb - f + lane, jB)
-                    ii4[u] = isA ? lane : (isB ? nb - f + lane : 0);
-                    jj4[u] = row ? (isA ? jA : jB) : 0;
-                    ii4[u] = row ? ii4[u] : 0;
-                    act4[u] = !k.no_nms && ((isA && !deadA) || (isB && !deadB));
-                    any_live |= !(deadA && deadB);
+                    const bool isA = lane > jA && lane < na;
+                    const bool isB = lane < f && jB != jA;                   // pair (na - f + lane, jB)
+                    const int id = isA ? lane : (isB ? na - f + lane : 0);   // dense rank of the suppressed side
+                    const int jd = row ? (isA ? jA : jB) : 0;                // ... of the suppressing side (one of two values per step)
+                    ii4[u] = __builtin_amdgcn_ds_bpermute((row ? id : 0) << 2, dl);      // -> batch lanes
+                    jj4[u] = __builtin_amdgcn_ds_bpermute(jd << 2, dl);
+                    act4[u] = !k.no_nms && row && (isA || isB);
                 }
-                if (any_live && !k.no_nms) {
+                if (!k.no_nms) {
 #pragma unroll
                     for (int u = 0; u < UB; ++u) { bi[u] = cb[base + ii4[u]]; bj[u] = cb[base + jj4[u]]; }
 #pragma unroll
@@ -1041,11 +1056,10 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
                 for (int u = 0; u < UB; ++u) {
                     const int f = f0 + u;
                     if (f >= nfold) break;
-                    const int jA = f, jB = nb - 1 - f;
-                    const bool deadA = (sall >> jA) & 1ull, deadB = ((sall >> jB) & 1ull) || jB == jA;
+                    const int jA = f, jB = na - 1 - f;
                     const u64 ball = __ballot(act4[u] && s4[u]);
-                    const u64 rowA = deadA ? 0ull : (ball & ~((2ull << jA) - 1ull));
-                    const u64 rowB = (deadB || f == 0) ? 0ull : ((ball & ((1ull << f) - 1ull)) << (nb - f));
+                    const u64 rowA = ball & ~((2ull << jA) - 1ull);
+                    const u64 rowB = (jB == jA || f == 0) ? 0ull : ((ball & ((1ull << f) - 1ull)) << (na - f));
                     if (lane == 0) {
                         maskrow[jA] = rowA;
                         if (jB != jA) maskrow[jB] = rowB;
@@ -1054,13 +1068,12 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
             }
             __syncthreads();
             PROF_MARK(5)
-            // resolve.  Candidates are taken in order; a candidate is kept iff no earlier KEPT candidate suppresses it.
+            // resolve, in dense ranks.  Candidates are taken in order; a candidate is kept iff no earlier KEPT candidate suppresses it.
             // Only lanes whose row is non-zero can change anything, so the scalar loop visits just those ("conflict
             // lanes"); everything still alive at the end is kept.  Rows sit one per lane and are fetched by readlane.
-            const u64 myrow = valid ? maskrow[lane] : 0ull;
+            const u64 myrow = lane < na ? maskrow[lane] : 0ull;
             const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
-            u64 alive = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) & ~sall;
-            alive = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(alive >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)alive);
+            u64 alive = na == 64 ? ~0ull : ((1ull << na) - 1ull);
             const u64 cmask = __ballot(myrow != 0ull);
             u64 pending = alive & cmask;
             while (pending) {
@@ -1074,17 +1087,21 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
                 alive &= ~(1ull << (63 - __clzll((long long)alive)));
                 --cnt;
             }
-            if (wave == 0 && ((alive >> lane) & 1ull)) {
+            const bool keep_me = (alive >> lane) & 1ull;   // lane = dense rank; its candidate sits at batch lane dl
+            if (wave == 0 && keep_me) {
                 const int pos = K + __popcll(alive & lanemask_lt());
-                kept_out[pos] = sorted[base + lane];
+                kept_out[pos] = sorted[base + dl];
                 if (pos < KEPT_LDS) {
-                    kb[pos] = cb[base + lane];
-                    if (POL == POL_NUMPY64) kf4[pos] = me4;
+                    kb[pos] = cb[base + dl];
+                    if (POL == POL_NUMPY64) kf4[pos] = cf4[base + dl];
                 }
             }
             K += cnt;
             // NumPy flows: a kept box whose area is NaN makes every later IoU NaN ("not <= thr"): nothing after it can survive
-            if (POL != POL_TF32 && !k.no_nms && (alive & __ballot(valid && me.area != me.area))) finished = true;
+            if (POL != POL_TF32 && !k.no_nms) {
+                const float a_me = keep_me ? cb[base + dl].area : 0.f;
+                if (__ballot(keep_me && a_me != a_me)) finished = true;
+            }
             __syncthreads();
             PROF_MARK(6)
         }
