@@ -573,6 +573,12 @@ int ssdhip_conv3x3_image_nhwc_bf16(const void* x, const void* weight, const void
  * Ho * Wo <= 384, 1 <= stride <= 4, 0 <= padding <= dilation (k / 2); otherwise as above.  Bit-identical to ssdhip_conv2d_nhwc_bf16. */
 int ssdhip_conv2d_image_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W, int Cin, int Cout,
                                   int ksize, int stride, int padding, int dilation, int relu, void* stream);
+/* ... and its reference-precision form (models/precise.py; the float32 graph of models/keras_ssd300.py:274-335 on the float16 MFMA rate):
+ * x [B, H, W, 2 C] float16 (hi | lo), weight [Cout, k, k, 3 C] float16 (w hi | w lo | w hi), bias float32 or NULL, y the next layer's
+ * pairs [B, Ho, Wo, 2 Cout] float16 or (out_f32) [B, Ho, Wo, Cout] float32; acc * oscale + bias, activation on float32.  Bit-identical
+ * to ssdhip_conv2d_x3_nhwc_f16 (same K order). */
+int ssdhip_conv2d_image_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C, int Cout,
+                                    int ksize, int stride, int padding, int dilation, int relu, int out_f32, float oscale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The parameter side of the training step (csrc/ssdhip_optim.hip): ONE launch over all parameters.  The reference trains float32

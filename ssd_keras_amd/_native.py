@@ -1181,8 +1181,10 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
     c = c2 // 2
     if slab64 and not (int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and cout % 128 == 0):
         raise SsdHipError("slab64 filters are for a 3x3 'same' convolution with Cout % 128 == 0")
+    image_first = (os.environ.get("SSDHIP_X3_IMAGE", "1") == "2" and not pool and not slab64 and h * w <= 384 and c % 64 == 0
+                   and b * (cout // 64) >= 128)                              # (A/B aid: conv5_x on the image kernel instead of the slab kernel)
     if (int(kh) == 3 and int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and (c % 128 == 0 or slab64) and cout % 128 == 0
-            and (slab64 or os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1")):
+            and (slab64 or os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1") and not image_first):
         # the slab kernel (csrc/ssdhip_convh.hip): the deep 3x3 layers and the packed heads; it writes split pairs, merged here when
         # the caller wants float32
         if not getattr(lib, "_x3h_bound", False):
@@ -1197,6 +1199,22 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
         return x3_merge(y2) if out_f32 else y2
     y = (torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x2.device) if out_f32 else
          torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device)).permute(0, 3, 1, 2)
+    if (not pool and not slab64 and int(kh) in (1, 3) and h * w <= 384 and ho * wo <= 384 and c % 64 == 0 and cout % 64 == 0
+            and b * (cout // 64) >= 128 and 1 <= int(stride) <= 4 and 1 <= int(dilation) <= 16
+            and 0 <= int(padding) <= int(dilation) * (int(kh) // 2) and os.environ.get("SSDHIP_X3_IMAGE", "1") != "0"
+            and hasattr(lib, "ssdhip_conv2d_image_x3_nhwc_f16")):
+        # round 6: small maps (fc6, fc7, conv6_x) with the image's slices resident in LDS (csrc/ssdhip_convimg.hip, X3): the
+        # implicit-GEMM form below gathers every tap's pixels again and moves 2.5-3.5 x the bytes per FLOP from L2
+        if not getattr(lib, "_x3img_bound", False):
+            lib.ssdhip_conv2d_image_x3_nhwc_f16.restype = ctypes.c_int
+            lib.ssdhip_conv2d_image_x3_nhwc_f16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 11 + [ctypes.c_float, ctypes.c_void_p]
+            lib._x3img_bound = True
+        with torch.cuda.device(x2.device):
+            rc = lib.ssdhip_conv2d_image_x3_nhwc_f16(_ptr(x2), _ptr(packed_weight), _ptr(bias), _ptr(y), b, h, w, c, cout, int(kh),
+                                                     int(stride), int(padding), int(dilation), int(bool(relu)), int(bool(out_f32)),
+                                                     ctypes.c_float(float(oscale)), current_stream_ptr(x2.device))
+        check(rc, "ssdhip_conv2d_image_x3_nhwc_f16")
+        return y
     with torch.cuda.device(x2.device):
         rc = lib.ssdhip_conv2d_x3_nhwc_f16(_ptr(x2), _ptr(packed_weight), _ptr(bias), _ptr(y), b, h, w, c2 // 2, cout, int(kh), int(stride),
                                            int(padding), int(dilation), int(bool(relu)), int(bool(pool)), int(bool(out_f32)),

@@ -66,6 +66,12 @@ struct ConvImgParams {
     int n_cot;                   // Cout / BM
     int xcd_map;                 // the channel tiles of an image on one XCD (needs n_cot == 8 or a tile count that is a multiple of 8 n_cot)
     int Ho, Wo, stride, pad;     // output map, stride and zero padding (the 3x3 'same' form: Ho = H, Wo = W, stride 1, pad = dil)
+    // X3 (the reference-precision form, models/precise.py): x rows hold xC = 2 C float16 channels [hi | lo], the K loop walks Cin = 3 C
+    // filter channels [w hi | w lo | w hi] and slice j reads x slice j < xslices ? j : j - xslices (hi, hi, lo); float32 bias, the
+    // accumulator scaled by oscale, the activated float32 value split into the next layer's pair (or written as float32)
+    int xC, xslices, out_f32;
+    const float* bias32;
+    float oscale;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -104,7 +110,15 @@ __device__ __forceinline__ i32x4 ci_rsrc(const void* base, u32 num_records) {
 // ONE step per slice; the implicit-GEMM form moved 2.5 x the bytes per FLOP of a 3x3 layer from L2 into LDS and ran fc7 at a quarter of the
 // peak).  NPB: 32-pixel MFMA blocks of a wave, 3 (output maps up to 384 pixels) or 1 (up to 128: the strided conv6_2, 19 x 19 -> 10 x 10,
 // would idle in three quarters of a 384-pixel tile).
-template <int BM, int KS, int NPB>
+typedef _Float16 ci_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32 ci_split2(float a, float b, u32& lo_out) {          // hi = fl16(v), lo = fl16(v - hi), two values per word
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+    lo_out = (u32)__builtin_bit_cast(unsigned short, la) | ((u32)__builtin_bit_cast(unsigned short, lb) << 16);
+    return (u32)__builtin_bit_cast(unsigned short, ha) | ((u32)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+template <int BM, int KS, int NPB, bool X3 = false>
 __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[CI_LDS];
@@ -139,8 +153,12 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     // ---- zero rows, descriptors ---------------------------------------------------------------------------------------------------
     if (tid < 2 * (CI_ROW / 4)) reinterpret_cast<u32*>(lds + (tid / (CI_ROW / 4)) * CI_SLAB + CI_ZERO)[tid % (CI_ROW / 4)] = 0u;
     // the bias of the tile's channels, fetched now and read from LDS in the epilogue (per-value global loads there cost 6 us per tile)
-    if (tid >= 128 && tid < 128 + BM) reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
-    const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * p.Cin, (u32)((size_t)HW * p.Cin * 2));
+    if (tid >= 128 && tid < 128 + BM) {
+        if constexpr (X3) reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias32 ? p.bias32[co0 + tid - 128] : 0.f;
+        else reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
+    }
+    const int XC = X3 ? p.xC : p.Cin;                    // channels of an x row
+    const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * XC, (u32)((size_t)HW * XC * 2));
     const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * NT * p.Cin, (u32)((size_t)BM * NT * p.Cin * 2));
 
     // ---- request plan.  Every wave issues exactly NFP + 1 LDS-DMA pieces per step, in this order: [NFP filter pieces of step i + 2 | one slab
@@ -164,7 +182,8 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         const int px = n / 9, c = n - 9 * px;
         const bool ok = (slice < n_slices) & (px < HW) & (c < 8);
         const bool any = (slice < n_slices) & (piece * 64 < 9 * HW);          // wave-uniform: the piece holds at least one slot of the map
-        ci_bload(ok ? (u32)((px * p.Cin + slice * 64) * 2 + c * 16) : OOB, rx, any ? lds0 + buf * CI_SLAB + piece * 1024 : lds0 + CI_DUMP);
+        const int xs = (X3 && slice >= p.xslices) ? slice - p.xslices : slice;      // X3: the x slice this K slice multiplies (hi, hi, lo)
+        ci_bload(ok ? (u32)((px * XC + xs * 64) * 2 + c * 16) : OOB, rx, any ? lds0 + buf * CI_SLAB + piece * 1024 : lds0 + CI_DUMP);
     };
     // filters of step `wstep` = (slice, tap) into ring stage `stage`
     auto issue_filter_piece = [&](const int i, const int wstep, const int stage) {
@@ -255,7 +274,10 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
                 else if (t < NT - 1) read_b(t + 1, 0, 0);                // (last tap of a slice: after the buffer flip below)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pi = 0; pi < NPB; ++pi) acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][0], fb[kk & 1][pi], acc[0][pi], 0, 0, 0);
+                for (int pi = 0; pi < NPB; ++pi) {
+                    if constexpr (X3) acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ci_f16x8, fa[kk & 1][0]), __builtin_bit_cast(ci_f16x8, fb[kk & 1][pi]), acc[0][pi], 0, 0, 0);
+                    else acc[0][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][0], fb[kk & 1][pi], acc[0][pi], 0, 0, 0);
+                }
                 // the step's requests go out a few at a time BETWEEN MFMA blocks: an LDS-DMA instruction holds its wave
                 // for 60-120 cycles, and issued together behind the barrier they left the matrix pipe idle in both waves of the SIMD at once
                 __builtin_amdgcn_sched_barrier(0);
@@ -273,7 +295,10 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NCB == 2) {
 #pragma unroll
-                    for (int pi = 0; pi < NPB; ++pi) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
+                    for (int pi = 0; pi < NPB; ++pi) {
+                        if constexpr (X3) acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ci_f16x8, fa[kk & 1][1]), __builtin_bit_cast(ci_f16x8, fb[kk & 1][pi]), acc[1][pi], 0, 0, 0);
+                        else acc[1][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][1], fb[kk & 1][pi], acc[1][pi], 0, 0, 0);
+                    }
                 }
             }
             if constexpr (KS == 1) stg = stg == CI_NW - 1 ? 0 : stg + 1;
@@ -289,6 +314,43 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     // ---- epilogue: bias, one rounding, ReLU on the rounded pair; 16-byte stores from the accumulator layout (ssdhip_conv64.hip) -----------
     CI_PROF_MARK(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy requests of the last two steps
+    if constexpr (X3) {
+        // ---- reference-precision epilogue: float32 straight from the registers (a lane holds 4 consecutive channels of a pixel per
+        //      accumulator quad): scale, float32 bias, activation on float32, then the next layer's (hi, lo) pair or the float32 value ----
+#pragma unroll
+        for (int ci = 0; ci < NCB; ++ci)
+#pragma unroll
+            for (int pi = 0; pi < NPB; ++pi) {
+                const int q = wn * (32 * NPB) + pi * 32 + r31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chl = wm * WCH + ci * 32 + 8 * g + 4 * khalf;         // channel inside the tile
+                    const float4 b4 = *reinterpret_cast<const float4*>(lds + CI_BIAS + chl * 4);
+                    const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[ci][pi][4 * g + e] * p.oscale + bv[e];
+                        if (p.relu) t = t > 0.f ? t : (t != t ? t : 0.f);
+                        v[e] = t;
+                    }
+                    if (q >= HWo) continue;
+                    const size_t pix = (size_t)b * HWo + q;
+                    if (p.out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + pix * p.Cout + co0 + chl) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        u32 l0, l1;
+                        const u32 h0 = ci_split2(v[0], v[1], l0), h1 = ci_split2(v[2], v[3], l1);
+                        bf16_t* row = p.y + pix * (2 * p.Cout) + co0 + chl;
+                        *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(row + p.Cout) = make_uint2(l0, l1);
+                    }
+                }
+            }
+        CI_PROF_MARK(3)
+        CI_PROF_FLUSH
+        return;
+    }
     const u32 floor16 = p.relu ? 0u : 0x80008000u;
     const size_t img = (size_t)HWo * p.Cout * 2;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
@@ -352,6 +414,7 @@ extern "C" int ssdhip_conv2d_image_nhwc_bf16(const void* x, const void* weight, 
     p.y = static_cast<bf16_t*>(y);
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
     p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = padding;
+    p.xC = Cin; p.xslices = Cin / 64; p.out_f32 = 0; p.bias32 = nullptr; p.oscale = 1.f;
     // channel tile: 128 where that already gives three quarters of a chip's worth of tiles (fc6 / fc7 at batch 32: 256), else 64 (conv5_x,
     // conv6_1, conv6_2 at batch 32: 256 / 128 / 256 tiles).  SSDHIP_CONVIMG_BM forces one (A/B runs).
     int bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
@@ -369,6 +432,49 @@ extern "C" int ssdhip_conv2d_image_nhwc_bf16(const void* x, const void* weight, 
         else { if (small) CI_LAUNCH(64, 1, 1); else CI_LAUNCH(64, 1, 3); }
     }
 #undef CI_LAUNCH
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// The reference-precision (X3) form of the same kernel (round 6; models/precise.py): x [B, H, W, 2 C] float16 = [hi | lo], weight
+// [Cout, k, k, 3 C] float16 = [w hi | w lo | w hi] (x3_pack_weight), bias float32 [Cout] or NULL, y [B, Ho, Wo, 2 Cout] float16 pairs
+// or, with out_f32, [B, Ho, Wo, Cout] float32.  One K loop over 3 C channels, float32 accumulation, the K order of
+// ssdhip_conv2d_x3_nhwc_f16 (bit-identical to it).  C % 64 == 0, Cout % 64 == 0; geometry limits as ssdhip_conv2d_image_nhwc_bf16.
+extern "C" int ssdhip_conv2d_image_x3_nhwc_f16(const void* x, const void* weight, const float* bias, void* y, int B, int H, int W, int C,
+                                               int Cout, int ksize, int stride, int padding, int dilation, int relu, int out_f32,
+                                               float oscale, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return SSDHIP_E_BADARG;
+    if ((ksize != 1 && ksize != 3) || stride < 1 || stride > 4 || dilation < 1 || dilation > 16 || padding < 0 ||
+        padding > dilation * (ksize / 2))
+        return SSDHIP_E_BADARG;
+    if ((C % 64) || (Cout % 64) || (long long)H * W > CI_PX) return SSDHIP_E_BADARG;
+    const int Ho = (H + 2 * padding - dilation * (ksize - 1) - 1) / stride + 1, Wo = (W + 2 * padding - dilation * (ksize - 1) - 1) / stride + 1;
+    if (H + 2 * padding < dilation * (ksize - 1) + 1 || W + 2 * padding < dilation * (ksize - 1) + 1 || Ho < 1 || Wo < 1 ||
+        (long long)Ho * Wo > CI_PX)
+        return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 3)) return SSDHIP_E_BADARG;
+    if ((long long)H * W * 3 * (C > Cout ? C : Cout) * 4 >= 0x7ffff000LL || 128LL * 9 * 3 * C * 2 >= 0x7ffff000LL) return SSDHIP_E_BADARG;
+    ConvImgParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
+    p.y = static_cast<bf16_t*>(y);
+    p.B = B; p.H = H; p.W = W; p.Cin = 3 * C; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
+    p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = padding;
+    p.xC = 2 * C; p.xslices = C / 64; p.out_f32 = out_f32 ? 1 : 0; p.bias32 = bias; p.oscale = oscale;
+    int bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
+    if (const char* e = getenv("SSDHIP_CONVIMG_BM")) { const int v = atoi(e); if (v == 64 || (v == 128 && (Cout % 128) == 0)) bm = v; }
+    p.n_cot = Cout / bm;
+    const dim3 grid((unsigned)(B * p.n_cot)), block(CI_THREADS);
+    p.xcd_map = (B % 8 == 0) ? 1 : 0;
+    const bool small = Ho * Wo <= 128;
+#define CI_LAUNCH3(BM_, KS_, NPB_) hipLaunchKernelGGL((conv_image_kernel<BM_, KS_, NPB_, true>), grid, block, 0, stream, p)
+    if (ksize == 3) {
+        if (bm == 128) { if (small) CI_LAUNCH3(128, 3, 1); else CI_LAUNCH3(128, 3, 3); }
+        else { if (small) CI_LAUNCH3(64, 3, 1); else CI_LAUNCH3(64, 3, 3); }
+    } else {
+        if (bm == 128) { if (small) CI_LAUNCH3(128, 1, 1); else CI_LAUNCH3(128, 1, 3); }
+        else { if (small) CI_LAUNCH3(64, 1, 1); else CI_LAUNCH3(64, 1, 3); }
+    }
+#undef CI_LAUNCH3
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -70,6 +70,51 @@ def test_x3_convolution_is_float32_grade(case, out_f32, halo, monkeypatch):
     assert e_x3 <= 8.0 * e_fw + 1e-6 and e_x3 <= 3e-5
 
 
+IMAGE_X3_CASES = [  # B, H, W, C, Cout, k, stride, pad, dil, relu   (round 6: ssdhip_conv2d_image_x3_nhwc_f16; batches that fill >= 128 tiles)
+    (8, 19, 19, 512, 1024, 3, 1, 6, 6, True),        # fc6: dilation 6, 128 tiles of 128 channels... at batch 8: the 64-channel tile form
+    (16, 19, 19, 1024, 1024, 1, 1, 0, 1, True),      # fc7: 1x1, 48 one-step slices
+    (32, 19, 19, 1024, 256, 1, 1, 0, 1, True),       # conv6_1
+    (32, 19, 19, 256, 512, 3, 2, 1, 1, True),        # conv6_2: stride 2 on the 128-pixel tile
+    (32, 10, 10, 128, 256, 3, 2, 1, 1, False),       # conv7_2 geometry, no activation
+    (24, 19, 19, 512, 512, 3, 1, 1, 1, True),        # conv5_x geometry through the implicit-GEMM switch (the slab kernel off)
+]
+
+
+@pytest.mark.parametrize("case", IMAGE_X3_CASES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_x3_image_kernel_equals_the_implicit_gemm_form(case, out_f32, monkeypatch):
+    """Round 6: the reference-precision form of the image-resident kernel (csrc/ssdhip_convimg.hip, X3) against the implicit-GEMM X3
+    kernel on the same operands -- the same K order, hence the same bits, three launches each -- and float32-grade against a float64
+    convolution (the bar of test_x3_convolution_is_float32_grade)."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, C, Cout, k, stride, pad, dil, relu = case
+    monkeypatch.setenv("SSDHIP_X3_NO_HALO", "1")
+    g = torch.Generator(device="cuda").manual_seed((hash(case) & 0xffff) + 3)
+    x = (torch.randn((B, C, H, W), generator=g, device="cuda") * 30).relu().contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, C, k, k), generator=g, device="cuda") * (2.0 / (k * k * C)) ** 0.5
+    bias = torch.randn((Cout,), generator=g, device="cuda")
+    pw, oscale = nat.x3_pack_weight(w)
+    x2 = nat.x3_split(x)
+    kw = dict(stride=stride, padding=pad, dilation=dil, relu=relu, pool=False, out_f32=out_f32)
+    monkeypatch.setenv("SSDHIP_X3_IMAGE", "0")
+    base = nat.conv2d_x3(x2, pw, bias, oscale, **kw)
+    monkeypatch.setenv("SSDHIP_X3_IMAGE", "1")
+    for _ in range(3):
+        got = nat.conv2d_x3(x2, pw, bias, oscale, **kw)
+        assert got.shape == base.shape and got.dtype == base.dtype
+        assert torch.equal(got.view(torch.int32 if out_f32 else torch.int16), base.view(torch.int32 if out_f32 else torch.int16))
+    if not out_f32:
+        c = got.shape[1] // 2
+        got = got[:, :c].double() + got[:, c:].double()
+    want = F.conv2d(x.double(), w.double(), bias.double(), stride, pad, dil)
+    if relu:
+        want = torch.relu(want)
+    bound = 2.0 ** -20 * F.conv2d(x.double().abs(), w.double().abs(), None, stride, pad, dil) + 1e-6
+    assert bool(((got.double() - want).abs() <= bound).all())
+
+
 def test_x3_split_merge_and_first_layer_kernels():
     """ssdhip_x3_split_nhwc / ssdhip_x3_merge_nhwc against the PyTorch formulation (bit for bit), and ssdhip_conv1_1_x3_nhwc (the
     3-channel first layer in float32 vector arithmetic) against a float64 convolution."""
