@@ -386,6 +386,10 @@ int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight, const flo
  *                         NULL, y [B,H,W,128] float16 = [hi | lo]. */
 int ssdhip_x3_split_nhwc(const float* x, void* y, long long n_pixels, int C, void* stream);
 int ssdhip_x3_merge_nhwc(const void* x, float* y, long long n_pixels, int C, void* stream);
+/* MaxPooling2D on a pair map without leaving the pair representation (round 6; pool4 / pool5 of models/keras_ssd300.py:287, 296 in the
+ * reference-precision path): x [B, H, W, 2 C] float16 -> y [B, Ho, Wo, 2 C], the pair of the window's largest hi + lo; windows clipped
+ * to the map (Keras 'same' / ceil mode: the caller passes Ho, Wo). */
+int ssdhip_x3_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int kernel, int stride, int pad, int Ho, int Wo, void* stream);
 int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const float* bias, void* y, int B, int H, int W, int relu, void* stream);
 
 size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,

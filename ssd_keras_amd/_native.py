@@ -1095,6 +1095,34 @@ def x3_merge(y2):
     return out
 
 
+def x3_maxpool(y2, kernel, stride, padding=0, ceil_mode=False):
+    """MaxPooling2D on a float16 (B, 2C, H, W) channels_last pair map -> the pair map of the windows' largest values
+    (ssdhip_x3_maxpool_nhwc; torch.nn.functional.max_pool2d's output size and clipped windows)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_x3pool_bound", False):
+        lib.ssdhip_x3_maxpool_nhwc.restype = ctypes.c_int
+        lib.ssdhip_x3_maxpool_nhwc.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 9 + [ctypes.c_void_p]
+        lib._x3pool_bound = True
+    b, c2, h, w = y2.shape
+    if not (y2.is_cuda and y2.dtype == torch.float16 and (c2 // 2) % 8 == 0 and c2 % 2 == 0 and _nhwc_ok(y2)):
+        raise SsdHipError("x3_maxpool takes a float16 (B, 2 C, H, W) channels_last pair map with C % 8 == 0")
+    k, s, p = int(kernel), int(stride), int(padding)
+
+    def out(n):
+        v = n + 2 * p - k
+        o = (-(-v // s) if ceil_mode else v // s) + 1
+        if ceil_mode and (o - 1) * s >= n + p:               # torch: the last window must start inside the map or its left padding
+            o -= 1
+        return o
+    ho, wo = out(h), out(w)
+    y = torch.empty((b, ho, wo, c2), dtype=torch.float16, device=y2.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(y2.device):
+        rc = lib.ssdhip_x3_maxpool_nhwc(_ptr(y2), _ptr(y), b, h, w, c2 // 2, k, s, p, ho, wo, current_stream_ptr(y2.device))
+    check(rc, "ssdhip_x3_maxpool_nhwc")
+    return y
+
+
 def conv1_1_x3(x, weight, bias, relu=True):
     """conv1_1 of the reference-precision path: float32 (B, 3, H, W) channels_last images, float32 (64, 3, 3, 3) filters -> the split
     float16 (B, 128, H, W) map (ssdhip_conv1_1_x3_nhwc)."""
@@ -1181,8 +1209,10 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
     c = c2 // 2
     if slab64 and not (int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and cout % 128 == 0):
         raise SsdHipError("slab64 filters are for a 3x3 'same' convolution with Cout % 128 == 0")
-    image_first = (os.environ.get("SSDHIP_X3_IMAGE", "1") == "2" and not pool and not slab64 and h * w <= 384 and c % 64 == 0
-                   and b * (cout // 64) >= 128)                              # (A/B aid: conv5_x on the image kernel instead of the slab kernel)
+    # round 6: small maps take the image-resident kernel AHEAD of the slab kernel too (conv5_x: 6.72 -> 6.57 ms per step, r06n);
+    # SSDHIP_X3_IMAGE = 0: never, 1: only where the slab kernel does not apply
+    image_first = (os.environ.get("SSDHIP_X3_IMAGE", "2") == "2" and not pool and not slab64 and h * w <= 384 and c % 64 == 0
+                   and b * (cout // 64) >= 128)
     if (int(kh) == 3 and int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and (c % 128 == 0 or slab64) and cout % 128 == 0
             and (slab64 or os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1") and not image_first):
         # the slab kernel (csrc/ssdhip_convh.hip): the deep 3x3 layers and the packed heads; it writes split pairs, merged here when
@@ -1201,7 +1231,7 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
          torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device)).permute(0, 3, 1, 2)
     if (not pool and not slab64 and int(kh) in (1, 3) and h * w <= 384 and ho * wo <= 384 and c % 64 == 0 and cout % 64 == 0
             and b * (cout // 64) >= 128 and 1 <= int(stride) <= 4 and 1 <= int(dilation) <= 16
-            and 0 <= int(padding) <= int(dilation) * (int(kh) // 2) and os.environ.get("SSDHIP_X3_IMAGE", "1") != "0"
+            and 0 <= int(padding) <= int(dilation) * (int(kh) // 2) and os.environ.get("SSDHIP_X3_IMAGE", "2") != "0"
             and hasattr(lib, "ssdhip_conv2d_image_x3_nhwc_f16")):
         # round 6: small maps (fc6, fc7, conv6_x) with the image's slices resident in LDS (csrc/ssdhip_convimg.hip, X3): the
         # implicit-GEMM form below gathers every tap's pixels again and moves 2.5-3.5 x the bytes per FLOP from L2

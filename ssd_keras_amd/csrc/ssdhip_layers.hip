@@ -539,6 +539,63 @@ extern "C" int ssdhip_x3_split_nhwc(const float* x, void* y, long long n_pixels,
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
+namespace ssdhip {
+// MaxPooling2D on (hi, lo) float16 pair maps (round 6): the pair of the window's largest VALUE, without leaving the pair representation
+// (before: merge to float32, the framework's pooling, split again -- three passes and 4-byte values through HBM).  hi + lo is exact in
+// float32 (22 significant bits), so the comparison is the float32 pooling's; NaNs win as in the framework's kernel.  One thread per
+// (output pixel, 8 channels); x [B, H, W, 2 C] = [hi | lo], windows k x k, stride s, padding p, clipped to the map.
+__global__ __launch_bounds__(256) void x3_maxpool_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int B, int H, int W, u32 cvec,
+                                                         int k, int s, int p, int Ho, int Wo) {
+    const u32 total = (u32)B * Ho * Wo * cvec;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const u32 cg = i % cvec;
+        u32 t = i / cvec;
+        const int wo = t % Wo; t /= Wo;
+        const int ho = t % Ho;
+        const int b = t / Ho;
+        const int h0 = max(ho * s - p, 0), h1 = min(ho * s - p + k, H);
+        const int w0 = max(wo * s - p, 0), w1 = min(wo * s - p + k, W);
+        float best[8];
+        u32 bh[8], bl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -__builtin_inff(); bh[e] = 0xfc00u; bl[e] = 0u; }   // (-inf, 0): an empty window's pair
+        for (int hi = h0; hi < h1; ++hi)
+            for (int wi = w0; wi < w1; ++wi) {
+                const size_t row = ((size_t)(b * H + hi) * W + wi) * (2 * cvec);
+                const uint4 vh = x[row + cg], vl = x[row + cvec + cg];
+                const u32 wh[4] = {vh.x, vh.y, vh.z, vh.w}, wl[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const u32 h16 = half ? (wh[q] >> 16) : (wh[q] & 0xffffu), l16 = half ? (wl[q] >> 16) : (wl[q] & 0xffffu);
+                        const float v = l_h2f(h16) + l_h2f(l16);
+                        const int e = 2 * q + half;
+                        if (v > best[e] || v != v) { best[e] = v; bh[e] = h16; bl[e] = l16; }
+                    }
+            }
+        const size_t orow = ((size_t)(b * Ho + ho) * Wo + wo) * (2 * cvec);
+        y[orow + cg] = make_uint4(bh[0] | (bh[1] << 16), bh[2] | (bh[3] << 16), bh[4] | (bh[5] << 16), bh[6] | (bh[7] << 16));
+        y[orow + cvec + cg] = make_uint4(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16), bl[4] | (bl[5] << 16), bl[6] | (bl[7] << 16));
+    }
+}
+}  // namespace ssdhip
+
+// MaxPooling2D(k, strides = s, zero... 'same' / ceil-mode windows clipped to the map) of a pair map: x [B, H, W, 2 C] float16 -> y
+// [B, Ho, Wo, 2 C]; Ho, Wo given by the caller (models/keras_ssd300.py:287 pool4 = (2, 2) 'same', :296 pool5 = (3, 3) / 1 'same').
+extern "C" int ssdhip_x3_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int kernel, int stride, int pad, int Ho, int Wo,
+                                      void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || kernel < 1 || stride < 1 || pad < 0 || pad >= kernel || Ho <= 0 || Wo <= 0)
+        return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    if ((long long)B * Ho * Wo * (C / 8) > 0x7fffffffLL || (long long)B * H * W * (C / 4) > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    if ((Ho - 1) * stride - pad >= H || (Wo - 1) * stride - pad >= W) return SSDHIP_E_BADARG;          // every window meets the map
+    hipLaunchKernelGGL(ssdhip::x3_maxpool_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8), 256)), dim3(256), 0, stream,
+                       static_cast<const uint4*>(x), static_cast<uint4*>(y), B, H, W, (u32)(C / 8), kernel, stride, pad, Ho, Wo);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
 extern "C" int ssdhip_x3_merge_nhwc(const void* x, float* y, long long n_pixels, int C, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !y || n_pixels <= 0 || C <= 0 || (C & 7) || n_pixels * (C / 8) > 0x7fffffffLL) return SSDHIP_E_BADARG;

@@ -140,6 +140,17 @@ class PreciseForward:
         return y, s_out
 
     @staticmethod
+    def _pool(t, kernel, stride, padding, ceil_mode):
+        """MaxPooling2D of an activation in either representation: pair maps through libssdhip, float32 maps (calibration, layers
+        the kernels do not cover) through the framework."""
+        if t.dtype == torch.float16 and (t.shape[1] // 2) % 8 == 0:
+            return nat.x3_maxpool(t, kernel, stride, padding, ceil_mode)
+        if t.dtype == torch.float16:
+            t = nat.x3_merge(t)
+            return nat.x3_split(F.max_pool2d(t, kernel, stride, padding, ceil_mode=ceil_mode).contiguous(memory_format=torch.channels_last))
+        return F.max_pool2d(t, kernel, stride, padding, ceil_mode=ceil_mode)
+
+    @staticmethod
     def _same3(conv):
         return conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
 
@@ -163,10 +174,12 @@ class PreciseForward:
         a = c(m.conv1_2, a, pool=True)                                     # MaxPooling2D(2, 2, 'same') fused (:275-276)
         a = c(m.conv2_2, c(m.conv2_1, a), pool=True)
         a = c(m.conv3_3, c(m.conv3_2, c(m.conv3_1, a)), pool=True)
-        conv4_3 = c(m.conv4_3, c(m.conv4_2, c(m.conv4_1, a)), out_f32=True)          # (float32 map / s, s)
-        a = (F.max_pool2d(conv4_3[0], 2, 2, ceil_mode=True), conv4_3[1])              # pooling commutes with the positive divisor
-        conv5_3 = c(m.conv5_3, c(m.conv5_2, c(m.conv5_1, a)), out_f32=True)
-        a = (F.max_pool2d(conv5_3[0], 3, 1, 1), conv5_3[1])
+        # round 6: conv4_3 / conv5_3 stay PAIR maps and pool4 / pool5 select pairs (ssdhip_x3_maxpool_nhwc) -- before: a float32 map
+        # out of the convolution, the framework's float32 pooling, a split pass (0.25 ms of glue per step, twice the bytes)
+        conv4_3 = c(m.conv4_3, c(m.conv4_2, c(m.conv4_1, a)))                        # (pair map / s, s)
+        a = (self._pool(conv4_3[0], 2, 2, 0, True), conv4_3[1])                      # pooling commutes with the positive divisor
+        conv5_3 = c(m.conv5_3, c(m.conv5_2, c(m.conv5_1, a)))
+        a = (self._pool(conv5_3[0], 3, 1, 1, False), conv5_3[1])
         fc7 = c(m.fc7, c(m.fc6, a))
         return conv4_3, fc7
 

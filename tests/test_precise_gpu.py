@@ -141,6 +141,36 @@ def test_x3_split_merge_and_first_layer_kernels():
     assert float((got - want).abs().max() / want.abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("geo", [(3, 38, 38, 512, 2, 2, 0, True), (2, 19, 19, 512, 3, 1, 1, False), (2, 75, 75, 64, 2, 2, 0, True),
+                                 (1, 5, 7, 8, 3, 2, 1, False), (2, 9, 9, 16, 2, 2, 0, False)])
+def test_x3_maxpool_selects_the_pair_of_the_largest_value(geo):
+    """ssdhip_x3_maxpool_nhwc (round 6: pool4 / pool5 of the reference-precision path on pair maps): merged, the pooled pair map IS the
+    framework's float32 max-pool of the merged input -- the same values, bit for bit -- for 'same' / ceil-mode and padded windows; NaNs
+    win as in the framework."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    B, H, W, C, k, s, p, ceil = geo
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H)
+    v = (torch.randn((B, C, H, W), generator=g, device="cuda") * 50).contiguous(memory_format=torch.channels_last)
+    v[0, 0, 0, 0] = float("nan")
+    v[:, 1] = 0.0                                             # ties between equal values
+    pairs = nat.x3_split(v)
+    merged = nat.x3_merge(pairs)
+    got = nat.x3_maxpool(pairs, k, s, p, ceil_mode=ceil)
+    want = F.max_pool2d(merged, k, s, p, ceil_mode=ceil)
+    assert got.dtype == torch.float16 and got.shape == (B, 2 * C, want.shape[2], want.shape[3])
+    gm = nat.x3_merge(got)
+    assert torch.equal(torch.isnan(gm), torch.isnan(want)) and torch.equal(torch.nan_to_num(gm), torch.nan_to_num(want))
+    # ... and the pairs themselves are INPUT pairs (selected, never re-split): where the pooled value is unique in its window, the
+    # output pair is that element's pair -- checked through the pair halves' own pooling on a map without ties or NaNs
+    clean = (torch.randn((B, C, H, W), generator=g, device="cuda") * 50).contiguous(memory_format=torch.channels_last)
+    pc = nat.x3_split(clean)
+    out = nat.x3_maxpool(pc, k, s, p, ceil_mode=ceil)
+    hi_in, hi_out = pc[:, :C].float(), out[:, :C].float()
+    assert torch.equal(hi_out, F.max_pool2d(hi_in, k, s, p, ceil_mode=ceil))        # hi = fl16(value) is monotone in the value
+
+
 def test_precise_forward_reproduces_the_float32_model():
     import torch
     from ssd_keras_amd.models.keras_ssd300 import ssd_300
