@@ -247,6 +247,10 @@ int ssdhip_bias_act_nhwc_bf16(const void* x, const void* bias, void* y, long lon
 int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias, void* y, int B, int H, int W, int C,
                                       int kernel, int stride, int pad, int Ho, int Wo, int relu, void* stream);
 int ssdhip_l2_normalize_nhwc_bf16(const void* x, const float* gamma, void* y, long long n_pixels, int C, void* stream);
+/* pool4 + conv4_3_norm in one pass (round 6): MaxPooling2D((2, 2), strides (2, 2), 'same') and L2Normalization of the same 512-channel map
+ * (models/keras_ssd300.py:287, 316): x [B, H, W, 512] bf16 -> y_pool [B, ceil(H/2), ceil(W/2), 512], y_norm [B, H, W, 512]; bit-identical
+ * to the two separate calls. */
+int ssdhip_pool2_l2_normalize_nhwc_bf16(const void* x, const float* gamma, void* y_pool, void* y_norm, int B, int H, int W, int C, void* stream);
 int ssdhip_preprocess_nhwc_f32_to_bf16(const float* images, void* out, long long n_pixels, int channels,
                                        const float* mean_h, const float* divide_h, const int* swap_h, void* stream);
 int ssdhip_assemble_predictions_bf16(int n_layers, const void* const* conf_h, const void* const* loc_h,

@@ -269,6 +269,25 @@ def l2_normalize(x, gamma):
     return y
 
 
+def pool2_l2_normalize(x, gamma):
+    """MaxPooling2D(2, 2, 'same') AND L2Normalization of the same (B, 512, H, W) bf16 channels_last map in one pass
+    (ssdhip_pool2_l2_normalize_nhwc_bf16): returns (pooled (B, 512, ceil(H/2), ceil(W/2)), normalised (B, 512, H, W))."""
+    torch = _torch()
+    lib = _layers_lib()
+    if not getattr(lib, "_p2l2_bound", False):
+        lib.ssdhip_pool2_l2_normalize_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_pool2_l2_normalize_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        lib._p2l2_bound = True
+    x, (b, h, w, c) = _nhwc_bf16(x, "x")
+    g = gamma.detach().float().contiguous()
+    pooled = torch.empty((b, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    normed = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_pool2_l2_normalize_nhwc_bf16(_ptr(x), _ptr(g), _ptr(pooled), _ptr(normed), b, h, w, c, current_stream_ptr(x.device))
+    check(rc, "ssdhip_pool2_l2_normalize_nhwc_bf16")
+    return pooled, normed
+
+
 def _l2_bind(lib):
     if not getattr(lib, "_l2_bound", False):
         c_int, c_vp, c_ll = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong

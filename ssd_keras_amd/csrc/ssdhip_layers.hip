@@ -205,6 +205,66 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const uint4* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pool4 + conv4_3_norm in ONE pass (round 6): MaxPooling2D(2, 2, 'same') and L2Normalization both read the conv4_3 map
+// (models/keras_ssd300.py:287 and :316); as two kernels the 47 MB map crossed HBM twice (15.9 + 21 us at batch 32).  One wave per
+// 2 x 2 window, lane = 8 of the 512 channels: the window's four pixels are read once, their maximum goes to the pooled map, each
+// pixel's normalised row (the arithmetic of l2norm_kernel, operation for operation) to the normalised map.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool2_l2norm_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma, uint4* __restrict__ y_pool,
+                                                           uint4* __restrict__ y_norm, int B, int H, int W, int Ho, int Wo) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256u) >> 6;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = gamma[lane * 8 + e];
+    const u32 total = (u32)B * Ho * Wo;
+    for (u32 o = wave; o < total; o += nwaves) {
+        const int wo = o % Wo;
+        const int ho = (o / Wo) % Ho;
+        const int b = o / (Wo * Ho);
+        uint4 v[4];
+        bool in[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = 2 * ho + (q >> 1), w = 2 * wo + (q & 1);
+            in[q] = h < H && w < W;
+            v[q] = in[q] ? x[((size_t)(b * H + h) * W + w) * 64 + lane] : make_uint4(0, 0, 0, 0);
+        }
+        uint4 best = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);      // -inf
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (in[q]) best = bfmax8(v[q], best);
+        y_pool[(size_t)o * 64 + lane] = best;
+        float ss[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const float a = bf2f(w4[t] & 0xffffu), c = bf2f(w4[t] >> 16); acc += a * a; acc += c * c; }
+            ss[q] = acc;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ss[q] += __shfl_xor(ss[q], off);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!in[q]) continue;
+            const float inv = rsqrtf(fmaxf(ss[q], 1e-12f));
+            const u32 w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            u32 r[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                r[t] = f2bf((bf2f(w4[t] & 0xffffu) * inv) * g[2 * t]) | (f2bf((bf2f(w4[t] >> 16) * inv) * g[2 * t + 1]) << 16);
+            const int h = 2 * ho + (q >> 1), w = 2 * wo + (q & 1);
+            y_norm[((size_t)(b * H + h) * W + w) * 64 + lane] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Input pipeline: out[b,h,w,c'] = bf16((img[b,h,w,swap[c']] - mean[swap[c']]) * scale[swap[c']]), img float32 NHWC.
 // ---------------------------------------------------------------------------------------------------------------
 struct PreParams { float mean[4]; float scale[4]; int swap[4]; int has_scale; };
@@ -370,6 +430,21 @@ extern "C" int ssdhip_bias_act_maxpool_nhwc_bf16(const void* x, const void* bias
     hipLaunchKernelGGL(bias_act_maxpool_kernel, dim3(grid_for((size_t)total, 256)), dim3(256), 0, stream,
                        static_cast<const uint4*>(x), static_cast<const uint4*>(bias), static_cast<uint4*>(y), B, H, W, (u32)(C / 8),
                        kernel, stride, pad, Ho, Wo, relu);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// MaxPooling2D(pool_size=(2, 2), strides=(2, 2), padding='same') + L2Normalization of the SAME 512-channel map in one pass (pool4 and
+// conv4_3_norm, models/keras_ssd300.py:287, 316): x [B, H, W, 512] bf16 -> y_pool [B, ceil(H / 2), ceil(W / 2), 512], y_norm [B, H, W, 512];
+// bit-identical to ssdhip_bias_act_maxpool_nhwc_bf16 (no bias, no activation) and ssdhip_l2_normalize_nhwc_bf16.
+extern "C" int ssdhip_pool2_l2_normalize_nhwc_bf16(const void* x, const float* gamma, void* y_pool, void* y_norm, int B, int H, int W, int C,
+                                                   void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !gamma || !y_pool || !y_norm || B <= 0 || H <= 0 || W <= 0 || C != 512) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y_pool | (uintptr_t)y_norm) & 15) return SSDHIP_E_BADARG;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    if ((long long)B * H * W * 64 > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(pool2_l2norm_kernel, dim3(grid_for((size_t)B * Ho * Wo, 4)), dim3(256), 0, stream, static_cast<const uint4*>(x), gamma,
+                       static_cast<uint4*>(y_pool), static_cast<uint4*>(y_norm), B, H, W, Ho, Wo);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -49,20 +49,7 @@ class L2Normalization(nn.Module):
         if (self.fused_inference and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and x.shape[1] % 8 == 0):
             from .. import _native as nat          # one pass in libssdhip (csrc/ssdhip_layers.hip) instead of seven kernels
-            g = self.gamma
-            if g.dtype != torch.float32:           # a bf16 model: the kernel's float32 gamma is converted once, not once per step
-                key = (g.data_ptr(), g._version)
-                hit = self.__dict__.get("_gamma32")
-                if hit is not None and hit[0] != key and hit[1].device == g.device and hit[1].shape == g.shape \
-                        and not torch.cuda.is_current_stream_capturing():
-                    self.refresh_cached_gamma()      # in place: a captured graph may be reading this storage
-                    hit = self.__dict__["_gamma32"]
-                elif hit is None or hit[0] != key:
-                    hit = (key, g.detach().float().contiguous())
-                    if not torch.cuda.is_current_stream_capturing():
-                        self.__dict__["_gamma32"] = hit
-                g = hit[1]
-            return nat.l2_normalize(x, g)
+            return nat.l2_normalize(x, self.gamma_float32())
         if self.fused_inference and x.is_cuda and x.dim() == 4:
             from .. import _native as nat
             if nat.l2_normalize_supported(x):               # the float32 model, and the training step in either dtype
@@ -70,6 +57,24 @@ class L2Normalization(nn.Module):
         xf = x.float()
         inv = torch.rsqrt(torch.clamp_min((xf * xf).sum(dim=1, keepdim=True), 1e-12))
         return (xf * inv * self.gamma.view(1, -1, 1, 1)).to(x.dtype)
+
+    def gamma_float32(self):
+        """gamma as the float32 tensor the kernels read: itself for a float32 model, a cached copy for a bf16 one (converted once, not
+        once per step; refreshed in its own storage when gamma changed -- a captured graph may be reading it)."""
+        g = self.gamma
+        if g.dtype == torch.float32:
+            return g
+        key = (g.data_ptr(), g._version)
+        hit = self.__dict__.get("_gamma32")
+        if hit is not None and hit[0] != key and hit[1].device == g.device and hit[1].shape == g.shape \
+                and not torch.cuda.is_current_stream_capturing():
+            self.refresh_cached_gamma()
+            hit = self.__dict__["_gamma32"]
+        elif hit is None or hit[0] != key:
+            hit = (key, g.detach().float().contiguous())
+            if not torch.cuda.is_current_stream_capturing():
+                self.__dict__["_gamma32"] = hit
+        return hit[1]
 
     def refresh_cached_gamma(self):
         """Bring the cached float32 copy of gamma up to date IN ITS OWN STORAGE (a captured HIP graph keeps reading it)."""

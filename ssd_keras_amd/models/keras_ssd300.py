@@ -43,15 +43,30 @@ class _VGGBase(SSDModel):
         x = cap(self.conv3_3, ca(self.conv3_2, ca(self.conv3_1, x)), 2, 2, ceil_mode=True)
         return ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x)))
 
-    def _vgg_from_conv4_3(self, conv4_3):
+    def _vgg_from_pool4(self, x):
         ca, cap = self.conv_act, self.conv_act_pool
-        x = self.max_pool(conv4_3, 2, 2, ceil_mode=True)
         x = cap(self.conv5_3, ca(self.conv5_2, ca(self.conv5_1, x)), 3, 1, pad=1)
         return ca(self.fc7, ca(self.fc6, x))
+
+    def _vgg_from_conv4_3(self, conv4_3):
+        return self._vgg_from_pool4(self.max_pool(conv4_3, 2, 2, ceil_mode=True))
 
     def _vgg(self, x):
         conv4_3 = self._vgg_to_conv4_3(x)
         return conv4_3, self._vgg_from_conv4_3(conv4_3)
+
+    def _trunk(self, x):
+        """[conv4_3_norm, fc7].  Fused bf16 inference (round 6): pool4 and conv4_3_norm are ONE pass over the conv4_3 map
+        (csrc/ssdhip_layers.hip, pool2_l2norm_kernel: 15.9 + 21 -> ~24 us at batch 32, bit-identical to the two passes)."""
+        import os
+        conv4_3 = self._vgg_to_conv4_3(x)
+        norm = self.conv4_3_norm
+        if (self._fused(conv4_3) and conv4_3.shape[1] == 512 and norm.fused_inference and norm.gamma is not None
+                and not torch.is_grad_enabled() and os.environ.get("SSDHIP_NO_POOL_NORM", "0") != "1"):
+            from .. import _native as nat
+            pooled, normed = nat.pool2_l2_normalize(conv4_3, norm.gamma_float32())
+            return [normed, self._vgg_from_pool4(pooled)]
+        return [norm(conv4_3), self._vgg_from_conv4_3(conv4_3)]
 
     @staticmethod
     def _vgg_sizes(n):
@@ -87,8 +102,7 @@ class SSD300(_VGGBase):
     def trunk_features(self, x):
         """The two source maps the VGG trunk yields (conv4_3 after L2Normalization, fc7): their predictor heads do not depend on
         the extra layers, which `extra_features` derives from fc7."""
-        conv4_3, fc7 = self._vgg(x)
-        return [self.conv4_3_norm(conv4_3), fc7]
+        return self._trunk(x)
 
     def extra_features(self, fc7):
         return self.extra_features_tail(self.extra_features_front(fc7))

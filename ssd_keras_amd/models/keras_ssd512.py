@@ -38,8 +38,7 @@ class SSD512(_VGGBase):
     def trunk_features(self, x):
         """The two source maps the VGG trunk yields (conv4_3 after L2Normalization, fc7): their predictor heads do not depend on
         the extra layers, which `extra_features` derives from fc7."""
-        conv4_3, fc7 = self._vgg(x)
-        return [self.conv4_3_norm(conv4_3), fc7]
+        return self._trunk(x)
 
     def extra_features(self, fc7):
         ca = self.conv_act

@@ -251,3 +251,42 @@ def test_pool5_slab_kernel_special_values(env):
     got = nat.bias_act_maxpool(x, None, 3, 1, 1, False, relu=False).float()
     assert torch.equal(torch.isnan(got), torch.isnan(want))
     assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0))
+
+
+@pytest.mark.parametrize("geo", [(32, 38, 38), (3, 37, 41), (2, 64, 64), (1, 1, 1), (2, 2, 5)])
+def test_pool4_and_conv4_3_norm_in_one_pass(geo):
+    """Round 6: ssdhip_pool2_l2_normalize_nhwc_bf16 -- MaxPooling2D(2, 2, 'same') and L2Normalization of the same 512-channel map in one
+    pass (models/keras_ssd300.py:287, 316) -- is BIT-identical to the two separate launches it replaces (odd maps: windows clipped at the
+    bottom / right; NaNs; all-zero pixels under the 1e-12 clamp)."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W = geo
+    g = torch.Generator(device="cuda").manual_seed(H * 100 + W)
+    x = (torch.randn((B, H, W, 512), generator=g, device="cuda") * 3).relu().to(torch.bfloat16)
+    x[0, 0, 0, :] = 0                                        # a pixel of zeros: the clamp
+    if H * W > 1:
+        x[-1, -1, -1, 5] = float("nan")
+    x = x.permute(0, 3, 1, 2)
+    gamma = torch.rand((512,), generator=g, device="cuda") * 30
+    pooled, normed = nat.pool2_l2_normalize(x, gamma)
+    want_pool = nat.bias_act_maxpool(x, None, 2, 2, 0, True, relu=False)
+    want_norm = nat.l2_normalize(x, gamma)
+    assert pooled.shape == want_pool.shape and normed.shape == want_norm.shape
+    assert torch.equal(pooled.contiguous().view(torch.int16), want_pool.contiguous().view(torch.int16))
+    assert torch.equal(normed.contiguous().view(torch.int16), want_norm.contiguous().view(torch.int16))
+
+
+def test_ssd300_forward_is_unchanged_by_the_fused_pool4_norm(monkeypatch):
+    import torch
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(3)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"], aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"],
+                    steps=cfg["steps"], offsets=cfg["offsets"]).cuda().to(memory_format=torch.channels_last).to(torch.bfloat16).eval()
+    images = torch.from_numpy(np.random.RandomState(0).randint(0, 256, size=(2, 300, 300, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        a = model(images).clone()
+        monkeypatch.setenv("SSDHIP_NO_POOL_NORM", "1")
+        b = model(images).clone()
+    assert torch.equal(a, b)
