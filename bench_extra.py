@@ -361,9 +361,11 @@ def fp32x3_forward_leg(dev, B, fp32_leg=None, reps=3):
            "vs_framework_float32": {"max_abs_diff_class_probabilities": float(d[:, :, :C][finite[:, :, :C]].max().item()),
                                     "max_rel_diff_offsets": float(rel[:, :, C:][finite[:, :, C:]].max().item()),
                                     "non_finite_in_either": int((~finite).sum().item())},
-           "note": "3x3 'same' convolutions with 128-multiple channels on the slab kernel (csrc/ssdhip_convh.hip, X3), the rest on the "
-                   "implicit-GEMM kernel (csrc/ssdhip_conv.hip, X3), conv1_1 (K = 27) float32 vector arithmetic (ssdhip_conv1_1_x3_nhwc); "
-                   "pool4 / pool5 / L2Normalization in float32 PyTorch; Reshape / Concatenate / softmax / AnchorBoxes + DecodeDetections in one libssdhip pipeline straight from the float32 head maps; parity flags on tamed heads "
+           "note": "3x3 'same' convolutions with 128-multiple channels on the slab kernel (csrc/ssdhip_convh.hip, X3); round 6: small maps "
+                   "(conv5_x, fc6, fc7, conv6_x) on the image-resident kernel's X3 form (csrc/ssdhip_convimg.hip), pool4 / pool5 on pair "
+                   "maps (ssdhip_x3_maxpool_nhwc); the rest on the implicit-GEMM kernel (csrc/ssdhip_conv.hip, X3), conv1_1 (K = 27) float32 "
+                   "vector arithmetic (ssdhip_conv1_1_x3_nhwc), L2Normalization in float32; Reshape / Concatenate / softmax / AnchorBoxes + "
+                   "DecodeDetections in one libssdhip pipeline straight from the float32 head maps; parity flags on tamed heads "
                    "(filters x 1e-3, background bias 4: an unsaturated softmax)"}
     if isinstance(fp32_leg, dict) and fp32_leg.get("images_per_sec"):
         out["speedup_over_miopen_float32"] = round(out["images_per_sec"] / fp32_leg["images_per_sec"], 3)
