@@ -741,7 +741,10 @@ __global__ __launch_bounds__(T, (T >= 512 ? SSDHIP_NMS_WAVES512 : 3)) void nms_k
     constexpr int KC = KC_KEYS / T;
     constexpr int KP = 9;                    // keys of one trip over the cached list (KC = 18 or 36: two or four trips)
     static_assert(KC % KP == 0, "KC must be a multiple of the trip size");
-    constexpr int UA = T >= 512 ? 2 : 4, UB = T >= 512 ? 2 : 4;
+    // (round 6: with the dense phase B the 512-thread kernel has room for four survivor records per phase-A step again -- 80 VGPRs, no
+    //  scratch; tamed heads 82.7 -> 80.2 us, SSD512 sparse 81.4 -> 78.0, r06v.  The float64-fallback policy keeps two: four spill 14
+    //  registers there.  One per step with a prefetch, or two with one, are 5-15 % SLOWER: more, shorter steps.)
+    constexpr int UA = T >= 512 ? (POL == POL_NUMPY64 ? 2 : 4) : 4, UB = T >= 512 ? 2 : 4;
     constexpr bool PREFETCH = T < 512;
     // XCD-aware work mapping: hardware places block x on XCD x%8; give every XCD a contiguous range of
     // (image, class) work items so that all classes of an image share one L2.
