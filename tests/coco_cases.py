@@ -71,7 +71,7 @@ class Generator:
 
     def generate(self, batch_size=32, shuffle=True, transformations=[], label_encoder=None, returns={'processed_images', 'encoded_labels'},
                  keep_images_without_gt=False, degenerate_box_handling='remove'):
-        self.calls.append(dict(batch_size=batch_size, shuffle=shuffle, label_encoder=label_encoder, returns=set(returns),
+        self.calls.append(dict(batch_size=batch_size, shuffle=shuffle, label_encoder=label_encoder, returns=sorted(returns),            # (sorted: a set's repr depends on the hash seed)
                                keep_images_without_gt=keep_images_without_gt,
                                transformations=[type(t).__name__ for t in transformations]))
         current = 0
