@@ -311,8 +311,15 @@ def main():
     choices = {}
     for key, name in SSDModel._conv_choice.items():          # which kernel the per-shape autotune kept for each convolution
         choices[conv_choice_label(key)] = name
+    # the chip does not hold its nominal clock with every SIMD issuing MFMAs: 2.39 GHz with one workgroup resident, 1.75-1.90 GHz under a full
+    # MFMA load (tools/micro/memtime_vs_mfma.hip, profiles/r04q2_clock64_is_shader_cycles_and_full_load_clock.txt) -- the fraction against the
+    # peak THAT clock allows (midpoint 1.825 GHz) beside the one against the nominal 2.5 PF/s
+    sustained_peak = MFMA_PEAK_TFLOPS[args.dtype] * (1.825 / 2.39) if args.dtype == "bf16" else None
     conv = {"bound": "mfma", "forward_ms": round(fwd_ms, 4), "achieved": round(conv_tflops, 2),
             "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(conv_tflops / MFMA_PEAK_TFLOPS[args.dtype], 5),
+            "frac_at_sustained_clock": round(conv_tflops / sustained_peak, 5) if sustained_peak else None,
+            "sustained_clock_note": "peak x 1.825 / 2.39 GHz: the shader clock under a full MFMA load, REPLAYED from "
+                                    "profiles/r04q2_clock64_is_shader_cycles_and_full_load_clock.txt (1.75-1.90 GHz), not measured by this run",
             "note": "per layer shape the fastest of libssdhip's MFMA kernels, timed once (kernel_per_layer): the slab kernel "
                     "(csrc/ssdhip_convh.hip: halo / halo_pool / halo_grouped), the fused conv1_1 + conv1_2 + pool1 kernel "
                     "(conv1_block), the resident-weight kernel (c64), the implicit-GEMM kernels (igemm*); %s; 62.747 GFLOP/img "
@@ -504,7 +511,7 @@ def main():
         scal = {"value_reference_precision": dig(extra, "conv_roofline_fp32x3", "images_per_sec"),
                 "reference_precision_ms_per_step": dig(extra, "conv_roofline_fp32x3", "step_ms_fwd_plus_decode"),
                 "value_tamed_heads_img_s": dig(tamed, "value"), "decode_ms_in_step": round(decode_ms_in_step, 5),
-                "decode_ms_in_step_tamed": dig(tamed, "decode_ms_in_step"), "conv_frac": conv["frac"], "forward_ms": conv["forward_ms"],
+                "decode_ms_in_step_tamed": dig(tamed, "decode_ms_in_step"), "conv_frac": conv["frac"], "conv_frac_at_sustained_clock": conv["frac_at_sustained_clock"], "forward_ms": conv["forward_ms"],
                 "nms_kernel_us": round(1e3 * stage_ms["nms_kernel"], 2), "scan_kernel_us": round(1e3 * stage_ms["scan_kernel"], 2),
                 "nms_traffic_ratio_replayed_from_profile": (traffic or {}).get("ratio_to_algorithmic_bytes") if dom == "nms_kernel" else None,
                 "train_step_ms": dig(extra, "train_step", "ms_per_step"), "train_images_per_sec": dig(extra, "train_step", "images_per_sec"),
