@@ -1039,17 +1039,29 @@ class SSDModel(nn.Module):
             # balance moved: first the front of the extra layers (conv6_1, conv6_2: split-K launches that want the whole chip), THEN
             # the two trunk heads on the second stream capped so that one CU per image stays free, beside the tail and the small heads
             front = self.extra_features_front(early[1])
+            # Round 6: conv6_2 exists BEFORE the fork, so its head rides in the capped launch with the two trunk heads instead of leading
+            # the small launch behind the chain.  In units of 72 K-steps the capped launch is then 112 fc7 items x 2 + 192 conv4_3 items
+            # + 32 conv6_2 items = 448 = exactly two per workgroup at 224 workgroups in the kernel's snake order (at 216 sixteen
+            # workgroups draw an fc7 item AND a conv6_2 item: 132 us instead of 102), and 224 + the chain's 32 = the chip's 256 CUs.
+            # Same box, alternating, 3 x 30 steps: 1.935 -> 1.926 ms per step (profiles/r06y_ab_head_split.txt).
+            n_big = n_early + 1 if (os.environ.get("SSDHIP_HEAD_SPLIT", "3") == "3" and self._halo_heads_ok([front])
+                                    and self._fused_head_ok(front, self.conf_heads[n_early])
+                                    and self._packed_head_ok(self.conf_heads[n_early], self.loc_heads[n_early], front)) else n_early
+            big_maps = list(early) + ([front] if n_big > n_early else [])
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                big = nat.conv3x3_halo_group(list(early), [self._packed_head_weight(l, 128) for l in range(n_early)], None, relu=False,
-                                             max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "216")))
+                big = nat.conv3x3_halo_group(big_maps, [self._packed_head_weight(l, 128) for l in range(n_big)], None, relu=False,
+                                             max_workgroups=int(os.environ.get("SSDHIP_HEAD_WGS", "224" if n_big > n_early else "216")))
             rest = self.extra_features_tail(front)
             check_rest(rest)
-            if self._halo_heads_ok(rest):
-                small = nat.conv3x3_halo_group(list(rest), [self._packed_head_weight(n_early + l, 128) for l in range(len(rest))], None,
+            later = rest[n_big - n_early:]                    # the maps whose heads are still to come
+            if not later:
+                small = []
+            elif self._halo_heads_ok(later):
+                small = nat.conv3x3_halo_group(list(later), [self._packed_head_weight(n_big + l, 128) for l in range(len(later))], None,
                                                relu=False)
             else:
-                small = nat.conv2d_same_group(list(rest), [self._packed_head_weight(n_early + l) for l in range(len(rest))], None,
+                small = nat.conv2d_same_group(list(later), [self._packed_head_weight(n_big + l) for l in range(len(later))], None,
                                               relu=False)
             main.wait_stream(side)
             return early + rest, big + small
