@@ -1023,8 +1023,12 @@ class SSDModel(nn.Module):
         main = torch.cuda.current_stream(x.device)
         side = self.__dict__.get("_side_stream")
         if side is None or side.device != x.device:
-            # high priority: when both streams have workgroups pending, the dispatcher serves this one first
-            side = torch.cuda.Stream(device=x.device, priority=-1)
+            # An ORDINARY stream since round 6 (rounds 2-5: priority -1, "served first when both streams have workgroups pending" --
+            # schedule 4 has no such moment: the capped launch leaves the chain its CUs).  Same box, 6 x 60 steps alternating: 2.0068 ms
+            # (ordinary) vs 2.0072 ms (high priority); but once a process has USED a high-priority stream, every later HIP graph with
+            # parallel branches replays slower on this runtime -- the reference-precision step 6.5 -> 7.6-7.9 ms, slower than its eager
+            # form, which is what bench.py's second graph measured in rounds 5-6 (profiles/r06z_graphs_after_a_high_priority_stream.txt).
+            side = torch.cuda.Stream(device=x.device, priority=int(os.environ.get("SSDHIP_SIDE_PRIORITY", "0")))
             self.__dict__["_side_stream"] = side
 
         def check_rest(rest):
