@@ -291,6 +291,20 @@ size_t ssdhip_conv1x1_wgrad_workspace_bytes(long long n_pixels, int Cin, int Cou
 int ssdhip_conv1x1_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db,
                                         long long n_pixels, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
+/* Weight gradient of the 3x3 layers of ANY stride / padding / dilation (round 6: fc6 with dilation 6, the stride-2 conv6_2 / conv7_2
+ * behind ZeroPadding2D, the 'valid' conv8_2 / conv9_2: models/keras_ssd300.py:294, 299-313 under model.fit_generator; replaces the
+ * framework's aten.convolution_backward -- MIOpen -- for them): dw [Cout][3][3][Cin] float32 from x [B,H,W,Cin] and dy [B,Ho,Wo,Cout] bf16,
+ * Ho = (H + 2 padding - 2 dilation - 1) / stride + 1.  Cin % 128 == 0, Cout % 128 == 0 (the workspace query returns 0 otherwise).
+ * Fixed summation order (bit-reproducible); bias_partial / bias_rows / db as ssdhip_conv3x3_wgrad_bias_nhwc_bf16. */
+size_t ssdhip_conv3x3_taps_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int padding, int dilation);
+int ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db,
+                                             int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int padding, int dilation,
+                                             void* ws, size_t ws_bytes, void* stream);
+/* First half of the DATA gradient of a strided or 'valid' 3x3 convolution (same layers): z [B,H,W,C] = zeros with gy [B,Ho,Wo,C] at
+ * (offset + stride i, offset + stride j), offset = 1 - padding; the 3x3 'same' convolution of z with the transposed, tap-flipped
+ * filters (any forward entry of this header) is d loss / d input. */
+int ssdhip_embed_strided_nhwc_bf16(const void* gy, void* z, int B, int Ho, int Wo, int C, int H, int W, int stride, int offset, void* stream);
+
 /* Backward of ssdhip_assemble_predictions_strided_bf16 for PACKED heads (the training step, round 5): the backward of the graph's
  * Reshape + Concatenate + softmax + Concatenate (models/keras_ssd300.py:363-419) in one launch.  grad_pred, y_pred [B, N, C+12] float32
  * (d loss / d predictions, and the predictions: the softmax probabilities are read from them); grad_heads[l]: the gradient of source map

@@ -992,6 +992,63 @@ def conv1x1_wgrad(x, dy, bias_partial=None):
     return (dw, db) if bias_partial is not None else dw
 
 
+def conv3x3_taps_wgrad(x, dy, stride=1, padding=1, dilation=1, bias_partial=None):
+    """Weight gradient of a 3x3 convolution of any stride / padding / dilation (csrc/ssdhip_wgrad.hip, conv_taps_wgrad_kernel: fc6's
+    dilation 6, the stride-2 conv6_2 / conv7_2, the 'valid' conv8_2 / conv9_2): x (B, Cin, H, W), dy (B, Cout, Ho, Wo) bfloat16
+    channels_last -> float32 (Cout, Cin, 3, 3) in channels_last memory, or None when the channel counts are not multiples of 128 or dy's
+    size is not the convolution's output size (the caller falls back to the framework).  bias_partial as in `conv3x3_wgrad`: the result is
+    then (dw, db)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_wgradt_bound", False):
+        lib.ssdhip_conv3x3_taps_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        lib.ssdhip_conv3x3_taps_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 10
+        lib.ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16.argtypes = ([ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 10
+                                                                  + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])
+        lib._wgradt_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    dy, (b2, ho, wo, cout) = _nhwc_bf16(dy, "dy")
+    if b2 != b:
+        raise SsdHipError("x and dy must have the same batch size")
+    geom = (b, h, w, cin, ho, wo, cout, int(stride), int(padding), int(dilation))
+    need = int(lib.ssdhip_conv3x3_taps_wgrad_workspace_bytes(*geom))
+    if need == 0:
+        return None
+    ws = workspaces.get(x.device, "wgrad", need)
+    dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    db = None
+    rows = 0
+    if bias_partial is not None:
+        if (bias_partial.dtype != torch.float32 or bias_partial.dim() != 2 or bias_partial.shape[1] != cout or not bias_partial.is_contiguous()):
+            raise SsdHipError("bias_partial must be a contiguous float32 [rows, Cout] tensor")
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        rows = int(bias_partial.shape[0])
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(dw), _ptr(bias_partial), rows, _ptr(db), *geom, _ptr(ws), need,
+                                                          current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16")
+    return (dw, db) if bias_partial is not None else dw
+
+
+def embed_strided(gy, h, w, stride, offset):
+    """gy (B, C, Ho, Wo) bfloat16 channels_last -> z (B, C, h, w): zeros with gy at (offset + stride i, offset + stride j)
+    (csrc/ssdhip_train.hip, embed_strided_kernel).  The 3x3 'same' convolution of z with the transposed, tap-flipped filters is the data
+    gradient of the 3x3 convolution with that stride and padding 1 - offset."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_embed_bound", False):
+        lib.ssdhip_embed_strided_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_embed_strided_nhwc_bf16.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 8 + [ctypes.c_void_p]
+        lib._embed_bound = True
+    gy, (b, ho, wo, c) = _nhwc_bf16(gy, "gy")
+    z = torch.empty((b, int(h), int(w), c), dtype=torch.bfloat16, device=gy.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(gy.device):
+        rc = lib.ssdhip_embed_strided_nhwc_bf16(_ptr(gy), _ptr(z), b, ho, wo, c, int(h), int(w), int(stride), int(offset), current_stream_ptr(gy.device))
+    check(rc, "ssdhip_embed_strided_nhwc_bf16")
+    return z
+
+
 def conv3x3_halo_group(xs, weights, biases=None, relu=False, max_workgroups=0):
     """Several independent 3x3 'same' convolutions through the slab kernel in ONE launch (persistent workgroups, deepest problem
     first): the packed predictor heads.  xs[i] (B, Cin_i, H_i, W_i) bf16 NHWC memory, weights[i] (Cout_i, Cin_i, 3, 3) bf16

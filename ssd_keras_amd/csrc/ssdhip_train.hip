@@ -472,6 +472,23 @@ __global__ __launch_bounds__(256) void conv1_1_bwd_kernel(const uint4* __restric
     }
 }
 
+// z[b, off + s i, off + s j, :] = gy[b, i, j, :], zeros everywhere else (one thread per 16 bytes of z): the data gradient of a strided or
+// 'valid' 3 x 3 convolution is the 3 x 3 'same' convolution of THIS map with the transposed, tap-flipped filters (see the entry point).
+__global__ __launch_bounds__(256) void embed_strided_kernel(const uint4* __restrict__ gy, uint4* __restrict__ z, u32 n, int H, int W, int Ho, int Wo,
+                                                            u32 cvec, int stride, int off) {
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const u32 c = i % cvec, px = i / cvec;
+        const u32 w = px % (u32)W, r = px / (u32)W, h = r % (u32)H, b = r / (u32)H;
+        const int hh = (int)h - off, ww = (int)w - off;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (hh >= 0 && ww >= 0 && hh % stride == 0 && ww % stride == 0) {
+            const int ho = hh / stride, wo = ww / stride;
+            if (ho < Ho && wo < Wo) v = gy[(((size_t)b * Ho + ho) * Wo + wo) * cvec + c];
+        }
+        z[i] = v;
+    }
+}
+
 }  // namespace ssdhip
 
 using namespace ssdhip;
@@ -731,5 +748,25 @@ extern "C" int ssdhip_conv1_1_bwd_nhwc_bf16(const void* gy, const void* y, const
     if (tiles > 0x7fffffffLL || (long long)B * H * W > 0x3fffffffLL || n_blocks != ssdhip_conv1_1_bwd_blocks(B, H, W)) return SSDHIP_E_BADARG;
     hipLaunchKernelGGL(conv1_1_bwd_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy),
                        static_cast<const uint4*>(y), static_cast<const unsigned short*>(x), wpart, bpart, H, W, (W + 63) / 64, (int)tiles);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// The data gradient of a 3 x 3 convolution with stride s and padding pad (dilation 1) through a 3 x 3 'same' convolution (round 6:
+// conv6_2 / conv7_2 -- stride 2 behind ZeroPadding2D -- and the 'valid' conv8_2 / conv9_2, models/keras_ssd300.py:299-313):
+// dX[r] = sum_k dY[(r + pad - k) / s] w[k] = sum_k' Z[r + k' - 1] w[2 - k'] with Z[s i + 1 - pad] = dY[i] and zeros elsewhere.  This
+// entry builds Z: gy [B, Ho, Wo, C] bf16 -> z [B, H, W, C] bf16 (the convolution's INPUT size), offset = 1 - pad in {0, 1}; the caller
+// then runs its forward kernel on z with the transposed, tap-flipped filters.  C % 8 == 0.
+extern "C" int ssdhip_embed_strided_nhwc_bf16(const void* gy, void* z, int B, int Ho, int Wo, int C, int H, int W, int stride, int offset,
+                                              void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!gy || !z || B <= 0 || Ho <= 0 || Wo <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || stride < 1 || offset < 0) return SSDHIP_E_BADARG;
+    if (offset + (long long)stride * (Ho - 1) >= H + 1 || offset + (long long)stride * (Wo - 1) >= W + 1) return SSDHIP_E_BADARG;   // (a last tap row may fall off: pad > 0)
+    if ((((uintptr_t)gy | (uintptr_t)z) & 15)) return SSDHIP_E_BADARG;
+    const long long n = (long long)B * H * W * (C / 8);
+    if (n > 0x7fffffffLL) return SSDHIP_E_BADARG;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embed_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint4*>(gy), static_cast<uint4*>(z), (u32)n,
+                       H, W, Ho, Wo, (u32)(C / 8), stride, offset);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -479,6 +479,132 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(Wg1Params p) {
             }
 }
 
+// ======================================================================================
+// Weight gradient of the 3 x 3 layers the position-grid kernel above does not cover (round 6: fc6 with its dilation 6, the stride-2
+// conv6_2 / conv7_2 behind their ZeroPadding2D, the 'valid' conv8_2 / conv9_2 -- models/keras_ssd300.py:294, 299-313):
+//     dW[co][kh][kw][ci] = sum over output pixels (b, ho, wo) of dY[b, ho, wo, co] X[b, ho s + kh d - pad, wo s + kw d - pad, ci]
+// as the pixel-contraction GEMM of the 1 x 1 form with the X rows GATHERED per tap: a workgroup owns 128 output channels x 128 input
+// channels x the three taps of ONE filter row over a range of output pixels.  Per step of 64 pixels the dY rows come in once and the X
+// rows of the three taps beside them (16-byte rows, sixteen loads in flight per thread, requested a step ahead; a tap that falls outside
+// the image is a row of zeros), all four tiles go into LDS transposed as above, and four waves run 3 x 16 MFMAs -- the dY fragments are
+// read once for the three taps.  Any stride / dilation / padding: the address arithmetic is per pixel and per tap, nothing else knows.
+// Split over the pixels, partial tiles added in slot order by wgrad_reduce_kernel with the bias partials (bit-reproducible).
+// ======================================================================================
+struct WgTParams {
+    const bf16_t* x;             // [B, H, W, Cin]
+    const bf16_t* dy;            // [B, Ho, Wo, Cout]
+    float* part;                 // [slots][Cout][9][Cin]
+    int P;                       // output pixels B Ho Wo
+    int H, W, Ho, Wo, Cin, Cout, stride, pad, dil;
+    int n_ci_tiles, n_tiles;     // Cin / 128; (Cout / 128) n_ci_tiles 3
+    int steps_per_split, n_steps;
+};
+
+__global__ __launch_bounds__(256) void conv_taps_wgrad_kernel(WgTParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char aT[128 * WG1_PITCH];       // dY tile [co][pixel]
+    __shared__ __attribute__((aligned(16))) unsigned char bT[3][128 * WG1_PITCH];    // X tiles [kw][ci][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x % p.n_tiles, split = blockIdx.x / p.n_tiles;
+    const int kh = tile % 3, t2 = tile / 3;                 // the three filter rows of a (co, ci) tile are neighbours: they share dY and most X rows in L2
+    const int co0 = (t2 / p.n_ci_tiles) * 128, ci0 = (t2 % p.n_ci_tiles) * 128;
+    const int s0 = split * p.steps_per_split, s1 = min(p.n_steps, s0 + p.steps_per_split);
+    const int cg = tid & 15, pp0 = tid >> 4;
+    const int cohalf = wave & 1, cihalf = wave >> 1;
+    wg_f32x16 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][i][j][v] = 0.f;
+    wg_u32x4 ra[4], rb[3][4];
+    const u32 howo = (u32)(p.Ho * p.Wo);
+    auto request = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const u32 px = (u32)step * 64u + 2u * (u32)(pp0 + 16 * u) + (u32)e;
+                const bool ok = px < (u32)p.P;
+                const u32 b = px / howo, r = px - b * howo, ho = r / (u32)p.Wo, wo = r - ho * (u32)p.Wo;
+                ra[2 * u + e] = ok ? *reinterpret_cast<const wg_u32x4*>(p.dy + (size_t)px * p.Cout + co0 + cg * 8) : wg_u32x4{0u, 0u, 0u, 0u};
+                const int hi = (int)ho * p.stride + kh * p.dil - p.pad;
+                const bool okh = ok && hi >= 0 && hi < p.H;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int wi = (int)wo * p.stride + t * p.dil - p.pad;
+                    const bool okx = okh && wi >= 0 && wi < p.W;
+                    rb[t][2 * u + e] = okx ? *reinterpret_cast<const wg_u32x4*>(p.x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + cg * 8)
+                                           : wg_u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pp = pp0 + 16 * u;
+            const int at = ((((pp >> 2) ^ (cg & 7)) << 2) | (pp & 3)) * 4;     // (the chunk swizzle of conv1x1_wgrad_kernel)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 a0 = ra[2 * u][q], a1 = ra[2 * u + 1][q];
+                *reinterpret_cast<u32*>(aT + (cg * 8 + 2 * q) * WG1_PITCH + at) = (a0 & 0xffffu) | (a1 << 16);
+                *reinterpret_cast<u32*>(aT + (cg * 8 + 2 * q + 1) * WG1_PITCH + at) = (a0 >> 16) | (a1 & 0xffff0000u);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const u32 b0 = rb[t][2 * u][q], b1 = rb[t][2 * u + 1][q];
+                    *reinterpret_cast<u32*>(bT[t] + (cg * 8 + 2 * q) * WG1_PITCH + at) = (b0 & 0xffffu) | (b1 << 16);
+                    *reinterpret_cast<u32*>(bT[t] + (cg * 8 + 2 * q + 1) * WG1_PITCH + at) = (b0 >> 16) | (b1 & 0xffff0000u);
+                }
+            }
+        }
+    };
+    if (s0 < s1) request(s0);
+    for (int step = s0; step < s1; ++step) {
+        stage();
+        __syncthreads();
+        if (step + 1 < s1) request(step + 1);                // in flight under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = 2 * ks + (lane >> 5);
+            wg_bf16x8 fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra_ = cohalf * 64 + i * 32 + (lane & 31);
+                fa[i] = *reinterpret_cast<const wg_bf16x8*>(aT + ra_ * WG1_PITCH + ((chunk ^ ((ra_ >> 3) & 7)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                wg_bf16x8 fb[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int rb_ = cihalf * 64 + j * 32 + (lane & 31);
+                    fb[j] = *reinterpret_cast<const wg_bf16x8*>(bT[t] + rb_ * WG1_PITCH + ((chunk ^ ((rb_ >> 3) & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                      // the next step's stage() overwrites the tiles
+    }
+    float* out = p.part + (size_t)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int co = co0 + cohalf * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                    const int ci = ci0 + cihalf * 64 + j * 32 + (lane & 31);
+                    out[((size_t)co * 9 + kh * 3 + t) * p.Cin + ci] = acc[t][i][j][v];
+                }
+}
+
 struct WgPlan {
     int cos, splits, slots, n_tiles, n_ci_tiles, n_blocks, blocks_per_split, HB;
     long long Q;
@@ -611,6 +737,61 @@ extern "C" int ssdhip_conv1x1_wgrad_bias_nhwc_bf16(const void* x, const void* dy
     hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(splits * p.n_tiles), dim3(256), 0, stream, p);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
     const int n4 = Cout * Cin / 4;
+    int rb = (n4 + 255) / 256;
+    if (rb > 2048) rb = 2048;
+    const int bC4 = bias_partial ? Cout / 4 : 0, rb2 = (bC4 + 7) / 8;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + rb2), dim3(256), 0, stream, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw),
+                       n4, splits, rb, reinterpret_cast<const float4*>(bias_partial), reinterpret_cast<float4*>(db), bC4, bias_rows);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// Weight gradient (and, with bias_partial, the bias gradient) of a 3 x 3 convolution of ANY stride / padding / dilation (fc6: dilation 6;
+// conv6_2, conv7_2: stride 2 behind ZeroPadding2D; conv8_2, conv9_2: 'valid' -- models/keras_ssd300.py:294, 299-313):
+// dw [Cout][3][3][Cin] float32 (the channels_last layout of a [Cout, Cin, 3, 3] gradient) from x [B, H, W, Cin] and dy
+// [B, Ho, Wo, Cout] bf16, Ho = (H + 2 pad - 2 dilation - 1) / stride + 1 (likewise Wo; anything else is SSDHIP_E_BADARG).
+// Cin % 128 == 0, Cout % 128 == 0.  Bit-reproducible (fixed summation order).  bias_partial / bias_rows / db as
+// ssdhip_conv3x3_wgrad_bias_nhwc_bf16.
+static bool wgt_plan(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int pad, int dil, int& splits, int& steps_per_split,
+                     int& n_steps) {
+    if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 128) || (Cout % 128)) return false;
+    if (stride < 1 || pad < 0 || dil < 1) return false;
+    if (H + 2 * pad - 2 * dil - 1 < 0 || W + 2 * pad - 2 * dil - 1 < 0) return false;
+    if (Ho != (H + 2 * pad - 2 * dil - 1) / stride + 1 || Wo != (W + 2 * pad - 2 * dil - 1) / stride + 1) return false;
+    const long long P = (long long)B * Ho * Wo;
+    if ((long long)B * H * W * Cin * 2 >= 0x7ffff000LL || P * Cout * 2 >= 0x7ffff000LL || P >= 0x7fffff00LL) return false;
+    n_steps = (int)((P + 63) / 64);
+    const int tiles = (Cout / 128) * (Cin / 128) * 3;
+    int s = 512 / tiles;
+    if (s < 1) s = 1;
+    if (s > n_steps) s = n_steps;
+    while (s > 1 && (n_steps + s - 1) / s < 4) --s;                           // at least four steps per workgroup
+    steps_per_split = (n_steps + s - 1) / s;
+    splits = (n_steps + steps_per_split - 1) / steps_per_split;
+    return true;
+}
+
+extern "C" size_t ssdhip_conv3x3_taps_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int padding,
+                                                            int dilation) {
+    int s, sp, ns;
+    return wgt_plan(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, s, sp, ns) ? (size_t)s * Cout * 9 * Cin * sizeof(float) : 0;
+}
+
+extern "C" int ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows,
+                                                        float* db, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
+                                                        int padding, int dilation, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int splits, sps, n_steps;
+    if (!x || !dy || !dw || !wgt_plan(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, splits, sps, n_steps)) return SSDHIP_E_BADARG;
+    if (bias_partial && (!db || bias_rows <= 0 || (((uintptr_t)bias_partial | (uintptr_t)db) & 15))) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) return SSDHIP_E_BADARG;
+    if (!ws || ws_bytes < (size_t)splits * Cout * 9 * Cin * sizeof(float) || ((uintptr_t)ws & 15)) return SSDHIP_E_WORKSPACE;
+    WgTParams p;
+    p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.part = static_cast<float*>(ws);
+    p.P = B * Ho * Wo; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.pad = padding; p.dil = dilation;
+    p.n_ci_tiles = Cin / 128; p.n_tiles = (Cout / 128) * p.n_ci_tiles * 3; p.steps_per_split = sps; p.n_steps = n_steps;
+    hipLaunchKernelGGL(conv_taps_wgrad_kernel, dim3(splits * p.n_tiles), dim3(256), 0, stream, p);
+    if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
+    const int n4 = Cout * 9 * Cin / 4;
     int rb = (n4 + 255) / 256;
     if (rb > 2048) rb = 2048;
     const int bC4 = bias_partial ? Cout / 4 : 0, rb2 = (bC4 + 7) / 8;

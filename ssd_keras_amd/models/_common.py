@@ -141,7 +141,16 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
     same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
             and wb.shape[0] % 64 == 0 and wb.shape[1] % 64 == 0 and k in (1, 3))
     import os
-    if need_x and same and os.environ.get("SSDHIP_NO_OWN_DGRAD", "0") != "1":
+    own_taps = os.environ.get("SSDHIP_NO_TAPS_BWD", "0") != "1"
+    # (round 6) a strided or 'valid' 3 x 3 layer (conv6_2 / conv7_2: stride 2 behind ZeroPadding2D; conv8_2 / conv9_2: no padding):
+    # dX[r] = sum_k dY[(r + pad - k) / s] w[k] is the 3 x 3 'same' convolution of Z -- zeros with dY at (1 - pad + s i) -- with the same
+    # transposed, tap-flipped filters: one embedding launch (csrc/ssdhip_train.hip), then the branch below as for a 'same' layer
+    embedded = (need_x and not same and own_taps and k == 3 and dilation == (1, 1) and stride[0] == stride[1] and padding[0] == padding[1]
+                and padding[0] in (0, 1) and wb.shape[0] % 64 == 0 and wb.shape[1] % 64 == 0 and gy.is_cuda
+                and os.environ.get("SSDHIP_NO_OWN_DGRAD", "0") != "1")
+    if embedded:
+        gy_full, gy = gy, nat.embed_strided(gy, xb.shape[2], xb.shape[3], stride[0], 1 - padding[0])
+    if need_x and (same or embedded) and os.environ.get("SSDHIP_NO_OWN_DGRAD", "0") != "1":
         # the data gradient of a stride-1 'same' convolution IS a 'same' convolution of dL/dy with the filters transposed
         # (Cin <-> Cout) and their taps flipped: the forward's MFMA kernel runs it, no bias, no activation
         if wt is None:                                   # (the shadow set hands the transposed filters over: csrc/ssdhip_optim.hip)
@@ -167,6 +176,8 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
             gx = nat.conv3x3_c64(gy, wt, None, relu=False, pool=False)
         else:
             gx = nat.conv2d_same(gy, wt, None, dilation=dilation[0], relu=False, variant=7 if halo else None)
+    if embedded:
+        gy = gy_full
     gw, gb = None, None
     if (k == 3 and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1) and os.environ.get("SSDHIP_NO_OWN_WGRAD", "0") != "1"):
         # the weight gradient through libssdhip's MFMA kernel (csrc/ssdhip_wgrad.hip; float32, fixed summation order); None: geometry
@@ -182,6 +193,15 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
         # the 1 x 1 layers (fc7, conv6_1 ... conv9_1): the weight gradient is a GEMM over the pixels (csrc/ssdhip_wgrad.hip,
         # conv1x1_wgrad_kernel; float32, fixed summation order), the bias partials ride in its reduction launch
         got = nat.conv1x1_wgrad(xb, gy, bias_partial=bias_partial)
+        if got is not None and bias_partial is not None:
+            gw, gb = got
+        else:
+            gw = got
+    if (gw is None and k == 3 and own_taps and gy.is_cuda and stride[0] == stride[1] and padding[0] == padding[1] and dilation[0] == dilation[1]
+            and xb.shape[1] % 128 == 0 and gy.shape[1] % 128 == 0 and os.environ.get("SSDHIP_NO_OWN_WGRAD", "0") != "1"):
+        # (round 6) the other 3 x 3 layers -- fc6's dilation, the strided and the 'valid' extras -- through the tap-gathered pixel GEMM
+        # (csrc/ssdhip_wgrad.hip, conv_taps_wgrad_kernel): with it the training step holds no framework convolution
+        got = nat.conv3x3_taps_wgrad(xb, gy, stride[0], padding[0], dilation[0], bias_partial=bias_partial)
         if got is not None and bias_partial is not None:
             gw, gb = got
         else:

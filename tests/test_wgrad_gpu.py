@@ -164,3 +164,86 @@ def test_1x1_weight_gradient_as_a_gemm_over_the_pixels(case):
     gw2, gb2 = nat.conv1x1_wgrad(x, dy, bias_partial=part)
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
     assert nat.conv1x1_wgrad(x[:, :64], dy) is None
+
+
+def _double_conv_grads(x, w, gy, stride, padding, dilation):
+    """d/dx, d/dw of conv2d(x, w) . gy in float64 through unfold (no library convolution involved)."""
+    import torch
+    import torch.nn.functional as F
+    x64 = x.double().contiguous().requires_grad_(True)
+    w64 = w.double().contiguous().requires_grad_(True)
+    b, cin, h, wd = x.shape
+    cout = w.shape[0]
+    cols = F.unfold(x64, 3, dilation=dilation, padding=padding, stride=stride)            # [B, Cin 9, Ho Wo]
+    y = (w64.view(cout, -1) @ cols).view(b, cout, gy.shape[2], gy.shape[3])
+    (y * gy.double()).sum().backward()
+    return x64.grad, w64.grad
+
+
+TAP_CASES = [  # B, H, W, Cin, Cout, stride, padding, dilation
+    (32, 19, 19, 512, 1024, 1, 6, 6),      # fc6
+    (32, 19, 19, 256, 512, 2, 1, 1),       # conv6_2
+    (32, 10, 10, 128, 256, 2, 1, 1),       # conv7_2
+    (32, 5, 5, 128, 256, 1, 0, 1),         # conv8_2
+    (32, 3, 3, 128, 256, 1, 0, 1),         # conv9_2
+    (3, 7, 9, 128, 128, 2, 1, 1),
+    (2, 8, 6, 128, 128, 3, 0, 1),
+    (1, 9, 9, 128, 128, 1, 2, 2),
+    (5, 6, 7, 256, 128, 2, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", TAP_CASES)
+def test_3x3_weight_gradient_with_gathered_taps(case):
+    """csrc/ssdhip_wgrad.hip, conv_taps_wgrad_kernel (fc6's dilation, the strided and the 'valid' extras) against the float64 weight
+    gradient of the same bf16 tensors, bias partials in the reduction launch; bit-reproducible; unsupported geometry -> None."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    b, h, w, cin, cout, s, p, d = case
+    ho, wo = (h + 2 * p - 2 * d - 1) // s + 1, (w + 2 * p - 2 * d - 1) // s + 1
+    g = torch.Generator(device="cuda").manual_seed(29)
+    x = torch.randn((b, cin, h, w), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((b, cout, ho, wo), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    part = nat.channel_sums_partial(dy)
+    gw, gb = nat.conv3x3_taps_wgrad(x, dy, s, p, d, bias_partial=part)
+    wdummy = torch.zeros((cout, cin, 3, 3), device="cuda")
+    _, want = _double_conv_grads(x, wdummy, dy, s, p, d)
+    assert gw.shape == (cout, cin, 3, 3) and gw.dtype == torch.float32 and gw.permute(0, 2, 3, 1).is_contiguous()
+    scale = float(want.abs().max().clamp_min(1e-6))
+    assert float((gw.double() - want).abs().max()) <= 1e-3 * scale
+    assert torch.allclose(gb.double(), dy.double().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    gw2, gb2 = nat.conv3x3_taps_wgrad(x, dy, s, p, d, bias_partial=part)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    assert nat.conv3x3_taps_wgrad(x[:, :64], dy, s, p, d) is None
+    if ho > 1:
+        assert nat.conv3x3_taps_wgrad(x, dy[:, :, :-1], s, p, d) is None            # not this convolution's output size
+
+
+@pytest.mark.parametrize("case", [c for c in TAP_CASES if c[7] == 1 and c[6] in (0, 1)])
+def test_strided_and_valid_layers_backward_without_the_framework(case):
+    """models/_common.py, _conv_input_weight_grads on the stride-2 / 'valid' 3 x 3 layers: data gradient = embed_strided + the forward's
+    'same' kernel on the transposed, flipped filters; weight gradient = the tap-gathered kernel -- against float64, and no
+    aten.convolution_backward in the trace."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    from ssd_keras_amd.models import _common as cm
+    b, h, w, cin, cout, s, p, d = case
+    ho, wo = (h + 2 * p - 3) // s + 1, (w + 2 * p - 3) // s + 1
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x = torch.randn((b, cin, h, w), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((b, cout, ho, wo), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    z = nat.embed_strided(dy, h, w, s, 1 - p)
+    want_z = torch.zeros((b, cout, h, w), device="cuda", dtype=torch.bfloat16)
+    want_z[:, :, 1 - p::s, 1 - p::s][:, :, :ho, :wo] = dy
+    assert torch.equal(z, want_z)
+    part = nat.channel_sums_partial(dy)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        gx, gw, gb = cm._conv_input_weight_grads(dy, x, wt, (s, s), (p, p), (1, 1), True, None, part)
+    assert not any("convolution_backward" in e.key for e in prof.key_averages())
+    want_x, want_w = _double_conv_grads(x, wt, dy, s, p, d)
+    assert gx.shape == x.shape and gb is not None
+    sx = float(want_x.abs().max().clamp_min(1e-6))
+    assert float((gx.double() - want_x).abs().max()) <= 2.0 ** -7 * sx                  # one bf16 rounding of the result
+    sw = float(want_w.abs().max().clamp_min(1e-6))
+    assert float((gw.double() - want_w).abs().max()) <= 1e-3 * sw
