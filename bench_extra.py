@@ -475,6 +475,9 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
     # hooks inside a capture could not be exercised on this single-GPU box.
     graph = None
     how = "eager"
+    # Round 6: the one-launch SGD (ssd_keras_amd/optimizers.py) is captured with the rest -- the step is ONE graph launch + the encoder
+    # (SSD_TRAIN_GRAPH_OPT=0, or the framework's optimizer: the update is issued eagerly after each replay as in rounds 3-5)
+    opt_in_graph = os.environ.get("SSD_TRAIN_GRAPH_OPT", "1") == "1" and opt_cls is FusedSGD
 
     def capture():
         nonlocal graph
@@ -510,7 +513,9 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y_pred = ddp(images)
             loss_static = lf.compute_loss(y_static, y_pred.float()).mean()
-            loss_static.backward()                        # writes the .grad tensors allocated here: the eager opt.step() reads them
+            loss_static.backward()                        # writes the .grad tensors allocated here: opt.step() reads them
+            if opt_in_graph:
+                opt.step()
         torch.cuda.synchronize()
         graph = (g, y_static, loss_static)
 
@@ -519,7 +524,8 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         y_true, _, _ = enc.encode_to_device(gt, device=dev)
         y_static.copy_(y_true)
         g.replay()
-        opt.step()
+        if not opt_in_graph:
+            opt.step()
         last["loss"] = loss_static.detach()
         if trace is not None:
             trace.append(("graph", round(float(loss_static), 4)))
@@ -544,14 +550,19 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         # zero_async, profiles/r04l_loss_graph_memset_node.txt), but the framework's remaining backward kernels (MIOpen weight gradients
         # of the predictor heads / extra layers) still do, and their gradients go to inf on the fourth replay
         # (profiles/r04m_graph_rounds_after_zero_kernel.txt).  The step is GPU-bound: eager costs 0.5 %.
-        safe_graph = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") == "0"
+        # Round 6: the backward pass holds no framework convolution any more (models/_common.py, _conv_input_weight_grads: the dilated /
+        # strided / 'valid' 3 x 3 layers have their own kernels), hence no memset node: the whole step replays under the runtime's
+        # defaults (tests/test_train_graph_gpu.py); with SSDHIP_NO_TAPS_BWD=1 or SSDHIP_NO_OWN_WGRAD=1 (MIOpen back in) only with packet capture off.
+        miopen_back = any(os.environ.get(k, "0") == "1" for k in ("SSDHIP_NO_TAPS_BWD", "SSDHIP_NO_OWN_WGRAD", "SSDHIP_NO_OWN_DGRAD"))
+        safe_graph = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") == "0" or not miopen_back
         if world == 1 and os.environ.get("SSD_TRAIN_GRAPH", "1" if safe_graph else "0") == "1":
             try:
                 capture()
                 for _ in range(2):
                     graph_step()
                 torch.cuda.synchronize()
-                run, how = graph_step, "hipGraph replay (forward + loss + backward captured once) + eager SGD step"
+                run, how = graph_step, ("ONE hipGraph replay per step (forward + SSDLoss + backward + SGD captured once); the encoder eager"
+                                        if opt_in_graph else "hipGraph replay (forward + loss + backward captured once) + eager SGD step")
             except Exception as exc:                                          # noqa: BLE001 -- fall back to the eager step
                 how = "eager (graph capture failed: %s: %s)" % (type(exc).__name__, str(exc)[:120])
                 torch.cuda.synchronize()

@@ -300,6 +300,10 @@ size_t ssdhip_conv3x3_taps_wgrad_workspace_bytes(int B, int H, int W, int Cin, i
 int ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db,
                                              int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int padding, int dilation,
                                              void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum over the rows of partial [rows][C] float32 in a fixed order (C % 4 == 0): finishes the per-workgroup partial sums the
+ * backward passes of this header leave behind where no weight-gradient reduction launch is at hand to take them along (conv1_1, L2Normalization's
+ * gamma).  A kernel, not a library reduction: no memset node in a captured training step. */
+int ssdhip_row_sums_f32(const float* partial, int rows, int C, float* out, void* stream);
 /* First half of the DATA gradient of a strided or 'valid' 3x3 convolution (same layers): z [B,H,W,C] = zeros with gy [B,Ho,Wo,C] at
  * (offset + stride i, offset + stride j), offset = 1 - padding; the 3x3 'same' convolution of z with the transposed, tap-flipped
  * filters (any forward entry of this header) is d loss / d input. */

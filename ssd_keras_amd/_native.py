@@ -353,7 +353,7 @@ def l2_normalize_bwd(x, dy, gamma, inv):
         rc = lib.ssdhip_l2_normalize_bwd(_ptr(x), _ptr(dy), _ptr(g), _ptr(inv), _ptr(dx), _ptr(part), n_waves, n_px, c, is_bf16,
                                          current_stream_ptr(x.device))
     check(rc, "ssdhip_l2_normalize_bwd")
-    return dx, part.sum(dim=0)
+    return dx, row_sums(part)
 
 
 def preprocess(images, mean=None, divide=None, swap=None):
@@ -592,7 +592,7 @@ def relu_bwd_bias(gy, y, reduce=True):
     with torch.cuda.device(gy.device):
         rc = lib.ssdhip_relu_bwd_bias_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(out), _ptr(partial), b * h * w, c, nb, current_stream_ptr(gy.device))
     check(rc, "ssdhip_relu_bwd_bias_nhwc_bf16")
-    return out, (partial.sum(dim=0) if reduce else partial)
+    return out, (row_sums(partial) if reduce else partial)
 
 
 def conv1_1_backward(gy, y, x):
@@ -616,8 +616,8 @@ def conv1_1_backward(gy, y, x):
     with torch.cuda.device(gy.device):
         rc = lib.ssdhip_conv1_1_bwd_nhwc_bf16(_ptr(gy), _ptr(y), _ptr(x), _ptr(wpart), _ptr(bpart), b, h, w, nb, current_stream_ptr(gy.device))
     check(rc, "ssdhip_conv1_1_bwd_nhwc_bf16")
-    gw = wpart.sum(dim=0).view(64, 3, 3, 3).permute(0, 3, 1, 2)           # k = (kh 3 + kw) 3 + ci  ->  (co, ci, kh, kw)
-    return gw, bpart.sum(dim=0)
+    gw = row_sums(wpart).view(64, 3, 3, 3).permute(0, 3, 1, 2)            # k = (kh 3 + kw) 3 + ci  ->  (co, ci, kh, kw)
+    return gw, row_sums(bpart)
 
 
 def maxpool2_relu_bwd_bias(y, gp, reduce=True):
@@ -638,7 +638,7 @@ def maxpool2_relu_bwd_bias(y, gp, reduce=True):
     with torch.cuda.device(y.device):
         rc = lib.ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16(_ptr(y), _ptr(gp), _ptr(out), _ptr(partial), b, h, w, c, nb, current_stream_ptr(y.device))
     check(rc, "ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16")
-    return out, (partial.sum(dim=0) if reduce else partial)
+    return out, (row_sums(partial) if reduce else partial)
 
 
 # ---- the parameter side of the training step (csrc/ssdhip_optim.hip) ------------------------------------------------------------
@@ -990,6 +990,29 @@ def conv1x1_wgrad(x, dy, bias_partial=None):
                                                      _ptr(ws), need, current_stream_ptr(x.device))
     check(rc, "ssdhip_conv1x1_wgrad_bias_nhwc_bf16")
     return (dw, db) if bias_partial is not None else dw
+
+
+def row_sums(partial):
+    """partial [rows, C] float32 (C % 4 == 0) -> [C]: the rows added in a fixed order by a libssdhip launch (csrc/ssdhip_wgrad.hip,
+    ssdhip_row_sums_f32).  `partial.sum(0)` in the framework zeroes its semaphores with a memset node, which a replayed HIP graph
+    of the training step does not honour on this runtime."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_rowsums_bound", False):
+        lib.ssdhip_row_sums_f32.restype = ctypes.c_int
+        lib.ssdhip_row_sums_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib._rowsums_bound = True
+    if not partial.is_cuda or partial.dtype != torch.float32 or partial.dim() < 2 or not partial.is_contiguous():
+        raise SsdHipError("row_sums needs a contiguous float32 CUDA tensor [rows, ...]")
+    rows = int(partial.shape[0])
+    c = partial.numel() // max(rows, 1)
+    if rows == 0 or c % 4:
+        return partial.sum(dim=0)
+    out = torch.empty(partial.shape[1:], dtype=torch.float32, device=partial.device)
+    with torch.cuda.device(partial.device):
+        rc = lib.ssdhip_row_sums_f32(_ptr(partial), rows, c, _ptr(out), current_stream_ptr(partial.device))
+    check(rc, "ssdhip_row_sums_f32")
+    return out
 
 
 def conv3x3_taps_wgrad(x, dy, stride=1, padding=1, dilation=1, bias_partial=None):

@@ -799,3 +799,16 @@ extern "C" int ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(const void* x, const voi
                        n4, splits, rb, reinterpret_cast<const float4*>(bias_partial), reinterpret_cast<float4*>(db), bC4, bias_rows);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
+
+// out[c] = sum over the rows of partial [rows][C] float32, rows added in a fixed order (the bias half of wgrad_reduce_kernel on its own):
+// the per-workgroup partial sums of conv1_1_bwd_kernel and l2norm_bwd_kernel.  Round 6: these were `partial.sum(0)` in the framework,
+// whose reduction zeroes its semaphores with a MEMSET node -- the one thing that kept the training step from replaying as a HIP graph
+// under the runtime's defaults (profiles/r06zd_train_graph_conv1_1_gradient.txt).  C % 4 == 0.
+extern "C" int ssdhip_row_sums_f32(const float* partial, int rows, int C, float* out, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!partial || !out || rows <= 0 || C <= 0 || (C % 4) || (((uintptr_t)partial | (uintptr_t)out) & 15)) return SSDHIP_E_BADARG;
+    const int bC4 = C / 4, rb2 = (bC4 + 7) / 8;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, stream, static_cast<const float4*>(nullptr), static_cast<float4*>(nullptr), 0, 0, 0,
+                       reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(out), bC4, rows);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

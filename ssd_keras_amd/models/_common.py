@@ -124,7 +124,7 @@ class _ConvBiasActFn(torch.autograd.Function):
                                               partial if want_gb else None)
         if want_gb:
             if gb is None:
-                gb = partial.sum(dim=0) if partial is not None else gy.sum(dim=(0, 2, 3), dtype=torch.float32)
+                gb = nat.row_sums(partial) if partial is not None else gy.sum(dim=(0, 2, 3), dtype=torch.float32)
             gb = gb.to(bdt)
         else:
             gb = None
@@ -248,7 +248,7 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
         gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], wt,
                                               partial if want_gb else None)
         if want_gb:
-            gb = (gb if gb is not None else partial.sum(dim=0)).to(bdt)
+            gb = (gb if gb is not None else nat.row_sums(partial)).to(bdt)
         else:
             gb = None
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None
@@ -650,9 +650,13 @@ class SSDModel(nn.Module):
         """The data gradient of this layer runs on libssdhip's forward kernels with transposed / flipped filters (see
         _conv_input_weight_grads): stride 1, 'same', k in (1, 3), channel counts multiples of 64."""
         k = conv.kernel_size[0]
-        return (conv.stride == (1, 1) and conv.kernel_size[1] == k and k in (1, 3) and conv.dilation[0] == conv.dilation[1]
-                and conv.padding == (conv.dilation[0] * (k // 2),) * 2 and conv.groups == 1
-                and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+        if conv.groups != 1 or conv.kernel_size[1] != k or conv.in_channels % 64 or conv.out_channels % 64:
+            return False
+        if (k == 3 and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+                and conv.padding[0] in (0, 1) and isinstance(conv.padding, tuple)):
+            return True                                  # (round 6) strided / 'valid' 3 x 3: embedding launch + the 'same' kernel
+        return (conv.stride == (1, 1) and k in (1, 3) and conv.dilation[0] == conv.dilation[1]
+                and conv.padding == (conv.dilation[0] * (k // 2),) * 2)
 
     def _shadow_build(self, device):
         """bf16 copies of every convolution's float32 master weights in the layouts the MFMA kernels read (csrc/ssdhip_optim.hip):

@@ -53,3 +53,19 @@ def test_whole_step_replay_equals_eager_on_the_same_weights_across_synchronizes(
         assert worst <= 5e-2, "round %d: %s" % (i, line)
         losses.append(lg)
     assert len(set(losses)) == 6 and losses[-1] < losses[0], "the weights move every round and the loss descends: %s" % line
+
+
+def test_whole_step_with_its_optimizer_as_one_graph_under_the_default_runtime():
+    """Round 6: no framework convolution is left in the backward pass (the dilated / strided / 'valid' 3 x 3 layers have their own
+    weight- and data-gradient kernels), so no memset node either: forward + SSDLoss + backward + the one-launch SGD step replay as ONE
+    graph with the runtime's defaults -- per round the replay agrees with an eager forward + backward on the same weights."""
+    out = _run("debug_graph_rounds.py", DBG_LR="1e-8", DBG_ROUNDS=6, DBG_FUSED_SGD=1, DBG_OPT_IN_GRAPH=1)
+    line = [l for l in out.splitlines() if l.startswith("ROUNDS")][-1]
+    rounds = [tuple(float(v) for v in r.split("/")) for r in line.split("|")[1].split()]
+    assert len(rounds) == 6
+    losses = []
+    for i, (le, lg, worst) in enumerate(rounds):
+        assert abs(lg - le) <= 1e-4 * abs(le), "round %d: %s" % (i, line)
+        assert worst <= 5e-2, "round %d: %s" % (i, line)
+        losses.append(lg)
+    assert len(set(losses)) == 6 and losses[-1] < losses[0], "the weights move every round and the loss descends: %s" % line

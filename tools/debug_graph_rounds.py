@@ -4,6 +4,8 @@ synchronize.  Prints per round: eager loss, replayed loss, worst relative gradie
   DBG_SYNC=0        no synchronize between rounds          DBG_EAGER_BETWEEN=0  no eager forward / backward between the replays
   DBG_FUSED=0       framework autograd only                DBG_TORCHLOSS=1      a plain tensor loss instead of SSDLoss
   DBG_ZERO_WS=1     re-zero every libssdhip workspace before each replay        SSDHIP_NO_OWN_WGRAD / _DGRAD = 1
+  DBG_FUSED_SGD=1   ssd_keras_amd.optimizers.SGD (one launch)                   DBG_OPT_IN_GRAPH=1   the optimizer step is captured too
+                                                                                (round 6: the whole step as ONE graph)
 """
 import os
 import sys
@@ -33,7 +35,12 @@ with torch.no_grad():
         head.bias.view(-1, cfg["n_classes"] + 1)[:, 0] = 4.0
     for head in model.loc_heads:
         head.weight.mul_(1e-2)
-opt = torch.optim.SGD(model.parameters(), lr=float(E("DBG_LR", "1e-7")), momentum=0.9)
+if E("DBG_FUSED_SGD", "0") == "1":
+    from ssd_keras_amd.optimizers import SGD as _SGD
+else:
+    _SGD = torch.optim.SGD
+opt = _SGD(model.parameters(), lr=float(E("DBG_LR", "1e-7")), momentum=0.9)
+OPT_IN_GRAPH = E("DBG_OPT_IN_GRAPH", "0") == "1"
 enc = SSDInputEncoder(matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5, **cfg)
 gt = syn.make_ground_truth(B, cfg["n_classes"], 300, 300, max_boxes=8, seed=7)
 images = torch.from_numpy(np.random.RandomState(100).randint(0, 256, size=(B, 300, 300, 3)).astype(np.float32)).to(dev)
@@ -89,6 +96,8 @@ with torch.cuda.device(dev):
     opt.zero_grad(set_to_none=True)
     with torch.cuda.graph(g):
         loss_static = fwd_bwd()
+        if OPT_IN_GRAPH:
+            opt.step()
     torch.cuda.synchronize()
     watched = [p for p in model.parameters() if p.grad is not None]
     graph_grads = [p.grad for p in watched]
@@ -112,8 +121,13 @@ with torch.cuda.device(dev):
         worst = float("nan")
         if eager_grads is not None:
             worst = 0.0
+            names = {id(p): n for n, p in model.named_parameters()}
             for p, ge in zip(watched, eager_grads):
-                worst = max(worst, float((p.grad.float() - ge.float()).norm()) / (float(ge.float().norm()) + 1e-20))
+                rel = float((p.grad.float() - ge.float()).norm()) / (float(ge.float().norm()) + 1e-20)
+                if E("DBG_WORST", "0") == "1" and not rel <= 5e-2:
+                    print("ROUND", rnd, "gradient of", names.get(id(p)), tuple(p.shape), "rel %.3g  |eager| %.3g  |graph| %.3g" % (
+                        rel, float(ge.float().norm()), float(p.grad.float().norm())), flush=True)
+                worst = max(worst, rel)
         if E("DBG_TRACE", "0") == "1" and eager_grads is not None:
             first = None
             for i, ((n, tg_), (_, te)) in enumerate(zip(graph_trace, eager_trace)):
@@ -122,7 +136,13 @@ with torch.cuda.device(dev):
                     first = "%d:%s diff %.3g of max %.3g" % (i, n, d, float(te.abs().max()))
                     break
             print("ROUND", rnd, "first differing traced output:", first, "| shadow error after the replay %.3g" % shadow_error(), flush=True)
-        opt.step()
+        if not OPT_IN_GRAPH:
+            opt.step()
+        else:
+            # the replayed update does not pass through Python: tell the version-keyed caches (the bf16 weight shadows of the EAGER
+            # comparison forward; the graph's own forward holds its refresh launch) that the parameters moved
+            from ssd_keras_amd.optimizers import _bump_versions
+            _bump_versions([p for p in model.parameters()])
         if E("DBG_SYNC", "1") == "1":
             torch.cuda.synchronize()
         out.append("%.4f/%.4f/%.3g" % (le, lg, worst))
