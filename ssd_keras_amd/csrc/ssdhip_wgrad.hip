@@ -95,7 +95,9 @@ struct WgTrack {
 
 // ABL (profiling build only, wrong results by construction -- each bit removes one cost): 1 no requests inside the block loop, 2 no
 // fragment reads, 8 no MFMAs, 16 no wait / barrier per block.
-template <int COS, int RB, int ABL = 0>
+// DIL (round 6: fc6, dilation 6): the same grid with DIL dummy columns per row and DIL dummy rows per image, tap (kh, kw) at displacement
+// ((kh - 1) (W + DIL) + (kw - 1)) DIL -- 58 % of fc6's positions are real (19 x 19 of 25 x 25), which still beats gathering the taps.
+template <int COS, int RB, int ABL = 0, int DIL = 1>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = 64 * RB;                           // rows of the X ring (+ 32 guard rows mirroring rows 0..31)
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     const int wm = COS == 4 ? (wave >> 1) & 1 : 0;       // 64-channel half of the output channels
     const int kg = COS == 4 ? 0 : (wave >> 1) & 1;       // COS = 2: which two K-steps of a block
     const int tg = wave >> 2;                            // tap group: 0 = taps 0..4, 1 = taps 5..8 (waves w and w + 4 share a SIMD)
-    const int H = p.H, W = p.W, W1 = W + 1, H1 = H + 1;
+    const int H = p.H, W = p.W, W1 = W + DIL, H1 = H + DIL;
 
     // workgroup -> (tile, split): the tiles of one split (the same positions) share an XCD's L2 (ids are dealt round robin)
     const int id = (int)blockIdx.x, xcd = id & 7, slot_id = id >> 3;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     wg_u32x4 fx[5];                                      // X fragments of the group's taps: ONE set -- a tap's registers are refilled for
                                                          // the next K-step as soon as its two MFMAs have issued
     // ring row of position (64 (block) - W1 - 1) of the CURRENT block, i.e. of tap (0, 0) of the block's first position
-    int ubase = 64 * p.HB - W1 - 1;                      // >= 0 because 64 HB >= W + 2
+    int ubase = 64 * p.HB - DIL * (W1 + 1);              // >= 0 because 64 HB >= DIL (W1 + 1)
     int rslot = 0;                                       // dY ring slot of the current block
     auto read_a = [&](auto setc, const int ds, const int kk) {
         constexpr int S = decltype(setc)::value;
@@ -224,13 +226,13 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgParams p) {
     // the address of filter row kh of K-step (ub, kk): the row's first ring row is wrapped in SCALAR arithmetic; the lanes' rows (+ lp <= 7,
     // + kw <= 2, + 8 for the second read) run at most 17 rows past it, into the guard rows that mirror the ring's first 32
     auto row_addr = [&](const int ub, const int kk, const int kh) {
-        int rs = ub + kk * 16 + kh * W1;
+        int rs = ub + kk * 16 + kh * DIL * W1;
         rs = rs >= R ? rs - R : rs;
         return x_lane + (u32)(rs * 64);
     };
     auto read_tap = [&](const int slot, const u32 a, const int kw) {
         if constexpr (ABL & 2) { asm volatile("" : "+v"(fx[slot]) : "v"(a)); return; }
-        const wg_u32x2 lo = wg_tr_read(ldsp, a + kw * 64), hi = wg_tr_read(ldsp, a + kw * 64 + 512);
+        const wg_u32x2 lo = wg_tr_read(ldsp, a + kw * DIL * 64), hi = wg_tr_read(ldsp, a + kw * DIL * 64 + 512);
         fx[slot] = wg_u32x4{lo.x, lo.y, hi.x, hi.y};
     };
     auto mfma_tap = [&](auto setc, const int slot) {
@@ -611,12 +613,13 @@ struct WgPlan {
     size_t ws_bytes;
 };
 
-static bool wg_plan(int B, int H, int W, int Cin, int Cout, WgPlan& pl) {
+static bool wg_plan(int B, int H, int W, int Cin, int Cout, WgPlan& pl, int dil = 1) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64)) return false;
+    if (dil != 1 && !(dil == 6 && Cout % 128 == 0)) return false;            // the dilated form is instantiated for fc6 only
     pl.cos = (Cout % 128) ? 2 : 4;
-    pl.HB = (W + 2 + 63) / 64;
+    pl.HB = (dil * (W + dil + 1) + 63) / 64;                                  // the taps reach dil rows + dil columns either way
     if (pl.HB > (pl.cos == 4 ? 3 : 5)) return false;                          // ring blocks: 2 HB + 4 <= 10 | 14
-    pl.Q = (long long)B * (H + 1) * (W + 1);
+    pl.Q = (long long)B * (H + dil) * (W + dil);
     if (pl.Q > 0x3fffff00LL) return false;
     if ((long long)B * H * W * Cin * 2 >= 0x7ffff000LL || (long long)B * H * W * Cout * 2 >= 0x7ffff000LL) return false;   // 31-bit byte offsets
     pl.n_blocks = (int)((pl.Q + 63) / 64);
@@ -650,12 +653,11 @@ extern "C" size_t ssdhip_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int 
 // ... and the layer's bias gradient with it: bias_partial [bias_rows][Cout] float32 per-workgroup channel sums of dy (as
 // ssdhip_relu_bwd_bias_nhwc_bf16 / ssdhip_maxpool2_relu_bwd_bias_nhwc_bf16 / ssdhip_channel_sums_nhwc_bf16 write them) -> db [Cout]
 // float32, rows added in a fixed order by extra workgroups of the reduction launch.  bias_partial == NULL: weight gradient only.
-extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows,
-                                                   float* db, int B, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
-                                                   void* stream_) {
+static int wg_grid_launch(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows, float* db, int B, int H, int W,
+                          int Cin, int Cout, int dil, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     WgPlan pl;
-    if (!x || !dy || !dw || !wg_plan(B, H, W, Cin, Cout, pl)) return SSDHIP_E_BADARG;
+    if (!x || !dy || !dw || !wg_plan(B, H, W, Cin, Cout, pl, dil)) return SSDHIP_E_BADARG;
     if (bias_partial && (!db || bias_rows <= 0 || (((uintptr_t)bias_partial | (uintptr_t)db) & 15))) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) return SSDHIP_E_BADARG;
     if (!ws || ws_bytes < pl.ws_bytes || ((uintptr_t)ws & 15)) return SSDHIP_E_WORKSPACE;
@@ -664,7 +666,7 @@ extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.Q = (int)pl.Q; p.n_blocks = pl.n_blocks; p.n_ci_tiles = pl.n_ci_tiles; p.n_tiles = pl.n_tiles;
     p.blocks_per_split = pl.blocks_per_split; p.HB = pl.HB;
-    p.step_h = 64 / (W + 1); p.step_w = 64 % (W + 1);
+    p.step_h = 64 / (W + dil); p.step_w = 64 % (W + dil);
     p.x_bytes = (int)((long long)B * H * W * Cin * 2); p.dy_bytes = (int)((long long)B * H * W * Cout * 2);
     const dim3 grid(pl.splits * pl.n_tiles), block(WG_THREADS);
     int abl = 0;
@@ -683,6 +685,7 @@ extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy
     }
 #endif
     if (abl) {}
+    else if (dil == 6) hipLaunchKernelGGL((conv_wgrad_kernel<4, 10, 0, 6>), grid, block, 0, stream, p);
     else if (pl.cos == 4) hipLaunchKernelGGL((conv_wgrad_kernel<4, 10>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<2, 14>), grid, block, 0, stream, p);
     if (hipGetLastError() != hipSuccess) return SSDHIP_E_LAUNCH;
@@ -693,6 +696,12 @@ extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb + rb2), dim3(256), 0, stream, reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw),
                        n4, pl.slots, rb, reinterpret_cast<const float4*>(bias_partial), reinterpret_cast<float4*>(db), bC4, bias_rows);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_conv3x3_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows,
+                                                   float* db, int B, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                                                   void* stream) {
+    return wg_grid_launch(x, dy, dw, bias_partial, bias_rows, db, B, H, W, Cin, Cout, 1, ws, ws_bytes, stream);
 }
 
 extern "C" int ssdhip_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, void* ws,
@@ -770,10 +779,19 @@ static bool wgt_plan(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int
     return true;
 }
 
+// (a dilated 'same' layer the position-grid kernel is instantiated for -- fc6 -- goes there: 175 us against 250 us with gathered taps)
+static bool wgt_on_grid(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int pad, int dil, WgPlan& pl) {
+    return stride == 1 && dil > 1 && pad == dil && Ho == H && Wo == W && wg_plan(B, H, W, Cin, Cout, pl, dil);
+}
+
 extern "C" size_t ssdhip_conv3x3_taps_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int padding,
                                                             int dilation) {
     int s, sp, ns;
-    return wgt_plan(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, s, sp, ns) ? (size_t)s * Cout * 9 * Cin * sizeof(float) : 0;
+    if (!wgt_plan(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, s, sp, ns)) return 0;
+    WgPlan pl;
+    const size_t gather = (size_t)s * Cout * 9 * Cin * sizeof(float);
+    if (wgt_on_grid(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, pl)) return pl.ws_bytes > gather ? pl.ws_bytes : gather;
+    return gather;
 }
 
 extern "C" int ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(const void* x, const void* dy, float* dw, const float* bias_partial, int bias_rows,
@@ -782,6 +800,9 @@ extern "C" int ssdhip_conv3x3_taps_wgrad_bias_nhwc_bf16(const void* x, const voi
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int splits, sps, n_steps;
     if (!x || !dy || !dw || !wgt_plan(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, splits, sps, n_steps)) return SSDHIP_E_BADARG;
+    WgPlan pl;
+    if (wgt_on_grid(B, H, W, Cin, Ho, Wo, Cout, stride, padding, dilation, pl) && !getenv("SSDHIP_WGRAD_GATHER_ONLY"))
+        return wg_grid_launch(x, dy, dw, bias_partial, bias_rows, db, B, H, W, Cin, Cout, dilation, ws, ws_bytes, stream_);
     if (bias_partial && (!db || bias_rows <= 0 || (((uintptr_t)bias_partial | (uintptr_t)db) & 15))) return SSDHIP_E_BADARG;
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) return SSDHIP_E_BADARG;
     if (!ws || ws_bytes < (size_t)splits * Cout * 9 * Cin * sizeof(float) || ((uintptr_t)ws & 15)) return SSDHIP_E_WORKSPACE;

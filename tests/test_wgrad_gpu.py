@@ -193,12 +193,15 @@ TAP_CASES = [  # B, H, W, Cin, Cout, stride, padding, dilation
 ]
 
 
-@pytest.mark.parametrize("case", TAP_CASES)
-def test_3x3_weight_gradient_with_gathered_taps(case):
+@pytest.mark.parametrize("case", TAP_CASES + [TAP_CASES[0] + ("gather",), (2, 19, 19, 128, 128, 1, 6, 6), (3, 5, 4, 128, 256, 1, 6, 6)])
+def test_3x3_weight_gradient_with_gathered_taps(case, monkeypatch):
     """csrc/ssdhip_wgrad.hip, conv_taps_wgrad_kernel (fc6's dilation, the strided and the 'valid' extras) against the float64 weight
     gradient of the same bf16 tensors, bias partials in the reduction launch; bit-reproducible; unsupported geometry -> None."""
     import torch
     from ssd_keras_amd import _native as nat
+    if len(case) == 9:                                  # fc6's geometry goes to the dilated position-grid kernel: keep the gather kernel covered on it too
+        monkeypatch.setenv("SSDHIP_WGRAD_GATHER_ONLY", "1")
+        case = case[:8]
     b, h, w, cin, cout, s, p, d = case
     ho, wo = (h + 2 * p - 2 * d - 1) // s + 1, (w + 2 * p - 2 * d - 1) // s + 1
     g = torch.Generator(device="cuda").manual_seed(29)
