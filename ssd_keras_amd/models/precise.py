@@ -45,8 +45,11 @@ class PreciseForward:
         self._packed = {}
         self._side = {}
         self._scale = {}                                  # id(conv) -> power-of-two divisor of the layer's stored output
-        self._calibrating = None                          # dict while `calibrate` walks the float32 framework model
+        self._calibrating = None                          # dict while `calibrate` records the layers' largest magnitudes
         self._calibrated = False
+        self._headroom = 4.0
+        import os as _os
+        self._framework_calibration = _os.environ.get("SSDHIP_X3_FRAMEWORK_CALIBRATION", "0") == "1"   # rounds 3-5: MIOpen float32 walk
         self.check_finite = check_finite
         self._last_heads = None
         import os
@@ -115,8 +118,41 @@ class PreciseForward:
             return act
         return nat.x3_split(t.contiguous(memory_format=torch.channels_last)), sc
 
+    PROBE = 2.0 ** 14                                     # calibration probe: the layer's output divided by this cannot leave float16
+
+    def _divisor(self, amax):
+        import math
+        if not math.isfinite(amax) or amax <= 65504.0 / self._headroom:
+            return 1.0
+        return 2.0 ** math.ceil(math.log2(amax / self.LIMIT))
+
     def conv(self, conv, act, relu=True, pool=False, out_f32=False):
-        if self._calibrating is not None:                 # the float32 framework convolution on true values, magnitudes recorded
+        if self._calibrating is not None and self._supported(conv) and act[0].is_cuda and not self._framework_calibration:
+            # Round 6: the layer calibrates ITSELF.  Pass 1 runs the X3 kernel with the output divided by 2^14 (nothing a float32 network
+            # on 0..255 images produces leaves float16 there; what underflows is far below the range question) and reads the largest
+            # magnitude; the divisor is chosen from it as before; the normal path below is pass 2 and hands the next layer exactly the
+            # map a calibrated forward would.  (Rounds 3-5 walked the float32 FRAMEWORK model layer by layer: MIOpen serves float32
+            # NHWC convolutions from its naive kernel, 85-450 ms per layer -- the first call of model.precise() took 25 s.)
+            x2, s_in = self._as_pair(act)
+            w, oscale, _b = self._conv_filters(conv)
+            import math
+            probe = self.PROBE
+            for _ in range(6):                            # (a probe that overflows all the same is repeated with its square: 2^28, 2^56, ...)
+                b_try = (conv.bias.detach().float() / probe).contiguous() if conv.bias is not None else None
+                y = nat.conv2d_x3(x2, w, b_try, oscale * s_in / probe, stride=conv.stride[0], padding=conv.padding[0],
+                                  dilation=conv.dilation[0], relu=relu, pool=pool, out_f32=True)
+                amax = float(y.abs().max()) * probe
+                del y
+                if math.isfinite(amax) or probe > 1e30:
+                    break
+                probe = probe * probe
+            self._calibrating[id(conv)] = amax
+            sc = self._divisor(amax)
+            if sc != 1.0:
+                self._scale[id(conv)] = sc
+            else:
+                self._scale.pop(id(conv), None)
+        elif self._calibrating is not None:               # the float32 framework convolution on true values, magnitudes recorded
             y = F.conv2d(self._true(act), conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
             y = torch.relu(y) if relu else y
             if pool:
@@ -163,7 +199,8 @@ class PreciseForward:
         if self._calibrating is not None:
             y = torch.relu(F.conv2d(x, c11.weight, c11.bias, c11.stride, c11.padding))
             self._calibrating[id(c11)] = float(y.abs().max())
-            a = (y.contiguous(memory_format=torch.channels_last), 1.0)
+            s11 = 1.0 if self._framework_calibration else self._divisor(self._calibrating[id(c11)])   # (the next layer's probe takes pairs)
+            a = ((y / s11 if s11 != 1.0 else y).contiguous(memory_format=torch.channels_last), s11)
         elif (c11.in_channels == 3 and c11.out_channels == 64 and self._same3(c11) and x.is_cuda
                 and x.permute(0, 2, 3, 1).is_contiguous() and self._scale.get(id(c11), 1.0) == 1.0):
             a = (nat.conv1_1_x3(x, c11.weight, c11.bias, relu=True), 1.0)
@@ -191,7 +228,7 @@ class PreciseForward:
         ch, lh = m.conf_heads[l], m.loc_heads[l]
         if not (self._same3(ch) and self._same3(lh)):
             raise RuntimeError("predictor heads must be 3x3 'same' convolutions")
-        if self._calibrating is not None:
+        if self._calibrating is not None and (self._framework_calibration or not act[0].is_cuda):
             x = self._true(act)
             y = torch.cat([F.conv2d(x, ch.weight, ch.bias, 1, 1), F.conv2d(x, lh.weight, lh.bias, 1, 1)], dim=1)
             return y.permute(0, 2, 3, 1)
@@ -239,12 +276,16 @@ class PreciseForward:
 
     @torch.no_grad()
     def calibrate(self, images, headroom=4.0):
-        """Choose the per-layer power-of-two divisors from the float32 framework model's activations on `images` (run once, layer by
-        layer: ~30 ms at batch 32): a map whose largest magnitude exceeds 65504 / headroom is stored divided by the power of two that
-        brings it to <= LIMIT.  Returns {layer name: (largest magnitude, divisor)}."""
+        """Choose the per-layer power-of-two divisors from the layers' activations on `images`: a map whose largest magnitude exceeds
+        65504 / headroom is stored divided by the power of two that brings it to <= LIMIT.  Each layer is probed by its own X3 kernel
+        with a 2^14 divisor, then run for real (`conv`): two forwards' worth of kernels, no framework convolution (round 6; the float32
+        framework walk of rounds 3-5 -- SSDHIP_X3_FRAMEWORK_CALIBRATION=1 -- took 25 s on MIOpen's naive NHWC kernels).  Returns
+        {layer name: (largest magnitude, divisor)}."""
         import math
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("calibrate outside a stream capture")
+        self._headroom = float(headroom)
+        self._scale = {}
         self._calibrating = {}
         try:
             if str(images.device) not in self._side:

@@ -251,6 +251,15 @@ def test_precise_forward_activations_beyond_the_float16_range():
     report = pf.calibrate(images)
     big = {k: v for k, v in report.items() if v[1] != 1.0}
     assert "conv3_1" in big and "conv3_3" in big and max(v[0] for v in report.values()) > 65504.0, report
+    # round 6: the layers calibrate themselves (a 2^14 probe pass of their own kernel); the float32 framework walk of rounds 3-5 sees the
+    # same magnitudes and picks the same divisors
+    walk = PreciseForward(m32)
+    walk._framework_calibration = True
+    report_walk = walk.calibrate(images)
+    assert set(report_walk) == set(report)
+    for name, (amax, div) in report.items():
+        assert abs(amax - report_walk[name][0]) <= 1e-3 * report_walk[name][0] + 1e-6, (name, amax, report_walk[name])
+        assert div == report_walk[name][1], (name, div, report_walk[name])
     px3 = pf(images)
     d_conf = float((px3[:, :, :21] - p32[:, :, :21]).abs().max())
     d_loc = float((px3[:, :, 21:25] - p32[:, :, 21:25]).abs().max())
