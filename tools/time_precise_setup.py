@@ -1,5 +1,7 @@
+"""What a user pays for `model.precise()`: the call itself, the FIRST forward (filter packing, the divisor calibration, the side-stream
+pick) and the second one.  `bench` as argv[1]: with torch.backends.cudnn.benchmark on.  GPU box."""
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ssd_keras_amd import synthetic as syn
 from ssd_keras_amd.models.keras_ssd300 import ssd_300
