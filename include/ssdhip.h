@@ -412,6 +412,10 @@ int ssdhip_x3_merge_nhwc(const void* x, float* y, long long n_pixels, int C, voi
  * reference-precision path): x [B, H, W, 2 C] float16 -> y [B, Ho, Wo, 2 C], the pair of the window's largest hi + lo; windows clipped
  * to the map (Keras 'same' / ceil mode: the caller passes Ho, Wo). */
 int ssdhip_x3_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int kernel, int stride, int pad, int Ho, int Wo, void* stream);
+/* L2Normalization (keras_layers/keras_layer_L2Normalization.py:62-70, conv4_3_norm of models/keras_ssd300.py:316) on a pair map: x, y
+ * [n_pixels][2 C] float16 = [hi | lo], true input (hi + lo) * scale, output stored with divisor 1; C % 8 == 0.  The float32 result of
+ * ssdhip_l2_normalize_fwd on the merged map, re-split -- one pass instead of merge + normalise + split (round 6). */
+int ssdhip_x3_l2_normalize_nhwc(const void* x, const float* gamma, void* y, long long n_pixels, int C, float scale, void* stream);
 int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const float* bias, void* y, int B, int H, int W, int relu, void* stream);
 
 size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,

@@ -1222,6 +1222,30 @@ def x3_maxpool(y2, kernel, stride, padding=0, ceil_mode=False):
     return y
 
 
+def x3_l2_normalize(y2, gamma, scale=1.0):
+    """L2Normalization of a float16 (B, 2C, H, W) channels_last pair map whose true values are (hi + lo) * scale -> the pair map of
+    gamma * x / max(||x||_2, 1e-6) over the channel axis, stored with divisor 1 (ssdhip_x3_l2_normalize_nhwc: the float32 result of
+    l2_normalize on the merged map, re-split)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_x3norm_bound", False):
+        lib.ssdhip_x3_l2_normalize_nhwc.restype = ctypes.c_int
+        lib.ssdhip_x3_l2_normalize_nhwc.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        lib._x3norm_bound = True
+    b, c2, h, w = y2.shape
+    if not (y2.is_cuda and y2.dtype == torch.float16 and (c2 // 2) % 8 == 0 and c2 % 2 == 0 and _nhwc_ok(y2)):
+        raise SsdHipError("x3_l2_normalize takes a float16 (B, 2 C, H, W) channels_last pair map with C % 8 == 0")
+    g = gamma.detach()
+    if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != c2 // 2 or g.device != y2.device:
+        raise SsdHipError("gamma must be a contiguous float32 tensor of C elements on the map's device")
+    y = torch.empty((b, h, w, c2), dtype=torch.float16, device=y2.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(y2.device):
+        rc = lib.ssdhip_x3_l2_normalize_nhwc(_ptr(y2), _ptr(g), _ptr(y), b * h * w, c2 // 2, ctypes.c_float(float(scale)),
+                                             current_stream_ptr(y2.device))
+    check(rc, "ssdhip_x3_l2_normalize_nhwc")
+    return y
+
+
 def conv1_1_x3(x, weight, bias, relu=True):
     """conv1_1 of the reference-precision path: float32 (B, 3, H, W) channels_last images, float32 (64, 3, 3, 3) filters -> the split
     float16 (B, 128, H, W) map (ssdhip_conv1_1_x3_nhwc)."""
@@ -1311,7 +1335,7 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
     # round 6: small maps take the image-resident kernel AHEAD of the slab kernel too (conv5_x: 6.72 -> 6.57 ms per step, r06n);
     # SSDHIP_X3_IMAGE = 0: never, 1: only where the slab kernel does not apply
     image_first = (os.environ.get("SSDHIP_X3_IMAGE", "2") == "2" and not pool and not slab64 and h * w <= 384 and c % 64 == 0
-                   and b * (cout // 64) >= 128)
+                   and b * (cout // 64) >= int(os.environ.get("SSDHIP_X3_IMAGE_MIN_TILES", "128")))
     if (int(kh) == 3 and int(stride) == 1 and int(padding) == 1 and int(dilation) == 1 and (c % 128 == 0 or slab64) and cout % 128 == 0
             and (slab64 or os.environ.get("SSDHIP_X3_NO_HALO", "0") != "1") and not image_first):
         # the slab kernel (csrc/ssdhip_convh.hip): the deep 3x3 layers and the packed heads; it writes split pairs, merged here when

@@ -603,6 +603,46 @@ __global__ __launch_bounds__(256, 4) void conv1_1_x3_kernel(const float* __restr
     }
 }
 
+// L2Normalization (keras_layers/keras_layer_L2Normalization.py:62-70) of a PAIR map (round 6): x, y [n_pixels][2 C] float16 = [hi | lo];
+// the true activation is (hi + lo) * scale.  One wave per pixel, the arithmetic of l2norm_fwd_kernel on the float32 sums hi + lo (what
+// x3_merge would hand it): ss = sum v^2 in lane-strided order + butterfly, inv = rsqrt(max(scale^2 ss, 1e-12)), out = ((v scale) inv)
+// gamma, re-split.  Replaces merge -> float32 normalisation -> split (three passes over the conv4_3 map on the reference-precision
+// step's critical path: 32 + 46 + 34 us).
+__global__ __launch_bounds__(256) void x3_l2norm_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma, uint4* __restrict__ y,
+                                                        u32 n_pixels, u32 cvec, float scale) {
+    const u32 lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (u32 px = wave; px < n_pixels; px += nwaves) {
+        float ss = 0.f;
+        for (u32 j = lane; j < cvec; j += 64u) {
+            const uint4 h = x[(size_t)px * (2 * cvec) + j], l = x[(size_t)px * (2 * cvec) + cvec + j];
+            const u32 hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = (l_h2f(hw[q] & 0xffffu) + l_h2f(lw[q] & 0xffffu)) * scale, b = (l_h2f(hw[q] >> 16) + l_h2f(lw[q] >> 16)) * scale;
+                ss += a * a;
+                ss += b * b;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        for (u32 j = lane; j < cvec; j += 64u) {
+            const uint4 h = x[(size_t)px * (2 * cvec) + j], l = x[(size_t)px * (2 * cvec) + cvec + j];
+            const u32 hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = (l_h2f(hw[q] & 0xffffu) + l_h2f(lw[q] & 0xffffu)) * scale, b = (l_h2f(hw[q] >> 16) + l_h2f(lw[q] >> 16)) * scale;
+                o[2 * q] = (a * inv) * gamma[j * 8 + 2 * q];
+                o[2 * q + 1] = (b * inv) * gamma[j * 8 + 2 * q + 1];
+            }
+            u32 l0, l1, l2, l3;
+            const u32 h0 = l_split2(o[0], o[1], l0), h1 = l_split2(o[2], o[3], l1), h2 = l_split2(o[4], o[5], l2), h3 = l_split2(o[6], o[7], l3);
+            y[(size_t)px * (2 * cvec) + j] = make_uint4(h0, h1, h2, h3);
+            y[(size_t)px * (2 * cvec) + cvec + j] = make_uint4(l0, l1, l2, l3);
+        }
+    }
+}
+
 }  // namespace ssdhip
 
 extern "C" int ssdhip_x3_split_nhwc(const float* x, void* y, long long n_pixels, int C, void* stream_) {
@@ -824,5 +864,19 @@ extern "C" int ssdhip_assemble_predictions_backward_bf16(int n_layers, void* con
         if (opted[devid] < 0) return SSDHIP_E_LAUNCH;
     }
     hipLaunchKernelGGL(head_grad_kernel, dim3(tiles, B), dim3(HG_TILE), lds, stream, hp, y_pred, grad_pred);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// L2Normalization of a pair map: x, y [n_pixels][2 C] float16 = [hi | lo] (x3_split's layout), gamma [C] float32; the true input is
+// (hi + lo) * scale (the layer's power-of-two divisor), the output is stored with divisor 1.  C % 8 == 0.  The float32 result of
+// ssdhip_l2_normalize_fwd on the merged map, re-split.
+extern "C" int ssdhip_x3_l2_normalize_nhwc(const void* x, const float* gamma, void* y, long long n_pixels, int C, float scale, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !gamma || !y || n_pixels <= 0 || n_pixels > 0x7fffffffLL || C <= 0 || (C & 7) || !(scale > 0.f)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    long long blocks = (n_pixels + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(x3_l2norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint4*>(x), gamma, static_cast<uint4*>(y),
+                       (u32)n_pixels, (u32)(C / 8), scale);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -26,6 +26,8 @@ decoded detections in the inference modes) computed here.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -364,9 +366,22 @@ class PreciseForward:
         ys = [None] * n_heads
         with torch.cuda.stream(side1):
             side1.wait_event(trunk)
-            norm = m.conv4_3_norm(self._true(conv4_3))                        # L2Normalization on the true float32 map (:316)
-            ys[0] = self._head(0, (norm.contiguous(memory_format=torch.channels_last), 1.0))
-            ys[1] = self._head(1, fc7)
+            fc7_first = os.environ.get("SSDHIP_X3_FC7_HEAD_FIRST", "0") == "1"
+            if fc7_first:
+                ys[1] = self._head(1, fc7)
+            nl = m.conv4_3_norm
+            if nl.gamma is None:
+                nl.build(conv4_3[0].shape[1] // 2 if conv4_3[0].dtype == torch.float16 else conv4_3[0].shape[1], x.device)
+            if (conv4_3[0].dtype == torch.float16 and conv4_3[0].is_cuda and nl.gamma.dtype == torch.float32 and nl.gamma.is_contiguous()
+                    and os.environ.get("SSDHIP_X3_NO_PAIR_NORM", "0") != "1"):
+                # round 6: L2Normalization on the pair map itself (one pass; before: merge -> float32 normalisation -> split, 111 us
+                # in front of the conv4_3 head on this stream)
+                ys[0] = self._head(0, (nat.x3_l2_normalize(conv4_3[0], nl.gamma, conv4_3[1]), 1.0))
+            else:
+                norm = nl(self._true(conv4_3))                                   # L2Normalization on the true float32 map (:316)
+                ys[0] = self._head(0, (norm.contiguous(memory_format=torch.channels_last), 1.0))
+            if not fc7_first:
+                ys[1] = self._head(1, fc7)
         if not one_stream:
             conv4_3[0].record_stream(side1)
             fc7[0].record_stream(side1)

@@ -297,3 +297,24 @@ def test_model_precise_is_the_forward_path():
     with torch.no_grad():
         det = inf.precise()(images)
     assert det.shape == (2, 200, 6) and bool(torch.isfinite(det).all())
+
+
+@pytest.mark.parametrize("shape,scale", [((2, 512, 38, 38), 1.0), ((1, 64, 5, 7), 4096.0), ((3, 8, 3, 3), 0.25)])
+def test_l2_normalization_on_the_pair_map(shape, scale):
+    """csrc/ssdhip_layers.hip, x3_l2norm_kernel (conv4_3_norm of the reference-precision step): the pair map of gamma x / max(||x||, 1e-6)
+    from the pair map of x / scale -- against the float64 formula of keras_layer_L2Normalization.py:62-70, float32-grade, an all-zero
+    pixel included (the 1e-12 clamp)."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(41)
+    b, c, h, w = shape
+    x = (torch.randn(shape, device="cuda", generator=g) * 37.0 * scale).contiguous(memory_format=torch.channels_last)
+    x[0, :, 0, 0] = 0.0
+    gamma = (torch.rand((c,), device="cuda", generator=g) * 20.0 + 1.0)
+    pair = nat.x3_split((x / scale).contiguous(memory_format=torch.channels_last))
+    got = nat.x3_merge(nat.x3_l2_normalize(pair, gamma, scale)).double()
+    xt = nat.x3_merge(pair).double() * scale                                  # what the pair map holds
+    norm = torch.sqrt(torch.clamp_min((xt * xt).sum(dim=1, keepdim=True), 1e-12))
+    want = xt / norm * gamma.double().view(1, -1, 1, 1)
+    assert bool(torch.isfinite(got).all()) and float(got[0, :, 0, 0].abs().max()) == 0.0
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
