@@ -1353,7 +1353,8 @@ def conv2d_x3(x2, packed_weight, bias, oscale, stride=1, padding=0, dilation=1, 
     y = (torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x2.device) if out_f32 else
          torch.empty((b, ho, wo, 2 * cout), dtype=torch.float16, device=x2.device)).permute(0, 3, 1, 2)
     if (not pool and not slab64 and int(kh) in (1, 3) and h * w <= 384 and ho * wo <= 384 and c % 64 == 0 and cout % 64 == 0
-            and b * (cout // 64) >= 128 and 1 <= int(stride) <= 4 and 1 <= int(dilation) <= 16
+            and b * (cout // 64) >= (int(os.environ.get("SSDHIP_X3_IMAGE1_MIN_TILES", "128")) if int(kh) == 1 else 128)
+            and 1 <= int(stride) <= 4 and 1 <= int(dilation) <= 16
             and 0 <= int(padding) <= int(dilation) * (int(kh) // 2) and os.environ.get("SSDHIP_X3_IMAGE", "2") != "0"
             and hasattr(lib, "ssdhip_conv2d_image_x3_nhwc_f16")):
         # round 6: small maps (fc6, fc7, conv6_x) with the image's slices resident in LDS (csrc/ssdhip_convimg.hip, X3): the

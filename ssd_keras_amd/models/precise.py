@@ -366,7 +366,7 @@ class PreciseForward:
         ys = [None] * n_heads
         with torch.cuda.stream(side1):
             side1.wait_event(trunk)
-            fc7_first = os.environ.get("SSDHIP_X3_FC7_HEAD_FIRST", "0") == "1"
+            fc7_first = os.environ.get("SSDHIP_X3_FC7_HEAD_FIRST", "1") == "1"
             if fc7_first:
                 ys[1] = self._head(1, fc7)
             nl = m.conv4_3_norm
@@ -390,11 +390,14 @@ class PreciseForward:
             x2 = self.conv(getattr(m, b), self.conv(getattr(m, a), x2))       # main stream
             ready = torch.cuda.Event()
             ready.record(main)
-            with torch.cuda.stream(side2):
-                side2.wait_event(ready)
+            # (round 6: the small heads ALTERNATE between the two side streams -- on one stream the 3 x 3 and 1 x 1 maps' heads, ~75 us of
+            #  weight streaming each, queued behind one another at the very end of the step)
+            hs = side1 if (k & 1) and os.environ.get("SSDHIP_X3_HEADS_ALTERNATE", "1") == "1" else side2
+            with torch.cuda.stream(hs):
+                hs.wait_event(ready)
                 ys[2 + k] = self._head(2 + k, x2)
             if not one_stream:
-                x2[0].record_stream(side2)
+                x2[0].record_stream(hs)
         if not one_stream:
             main.wait_stream(side1)
             main.wait_stream(side2)
