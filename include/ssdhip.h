@@ -498,6 +498,17 @@ int ssdhip_conv_chain_pack_weight(const void* weight, void* packed, int k, int C
 int ssdhip_conv_chain_nhwc_bf16(const void* x, int B, int H, int W, int C0, int n_layers, const void* const* packed_h,
                                 const void* const* bias_h, void* const* y_h, const int* k_h, const int* stride_h, const int* pad_h,
                                 const int* cout_h, const int* relu_h, void* stream);
+/* The same chain at the reference's precision (round 6; the float32 Keras graph of models/keras_ssd300.py:304-313 on the float16 x 3 MFMA
+ * path): x [B, H, W, 2 C0] float16 = [hi | lo] pairs; layer i computes act(mul_i * conv(x, w_i) + bias_i) in float32 -- three float16
+ * products per K-step, mul_i = oscale_i * (divisor of its input) / (divisor of its output), bias_i float32 already divided by the output
+ * divisor -- and re-splits; y_h[i] != NULL: [B, H_i, W_i, 2 Cout_i] pairs.  packed_h[i]: the layer's [Cout, k, k, 3 Cin] float16 filters
+ * ([w hi | w lo | w hi], as for ssdhip_conv2d_x3_nhwc_f16) re-ordered by ssdhip_conv_chain_x3_pack_weight.  The first layer must be
+ * 1 x 1 / stride 1 / no padding (it reads x from global memory); Cin_i % 64 == 0, Cout_i % 32 == 0; the later maps must fit the CU's LDS. */
+size_t ssdhip_conv_chain_x3_packed_bytes(int k, int Cin, int Cout);
+int ssdhip_conv_chain_x3_pack_weight(const void* weight_x3, void* packed, int k, int Cin, int Cout, void* stream);
+int ssdhip_conv_chain_x3_nhwc_f16(const void* x, int B, int H, int W, int C0, int n_layers, const void* const* packed_h,
+                                  const float* const* bias_h, void* const* y_h, const int* k_h, const int* stride_h, const int* pad_h,
+                                  const int* cout_h, const int* relu_h, const float* mul_h, void* stream);
 
 /* Weight gradient of a 3x3 'same' stride-1 dilation-1 convolution of the training graph -- what the TensorFlow graph behind
  * model.fit_generator computes for every Conv2D of models/keras_ssd300.py:274-296 (ssd300_training.ipynb:171-173):

@@ -915,6 +915,79 @@ def conv_chain(x, layers):
     return outs
 
 
+def _bind_chain_x3(lib):
+    if not getattr(lib, "_chainx3_bound", False):
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.ssdhip_conv_chain_x3_packed_bytes.restype = ctypes.c_size_t
+        lib.ssdhip_conv_chain_x3_packed_bytes.argtypes = [ci, ci, ci]
+        lib.ssdhip_conv_chain_x3_pack_weight.restype = ci
+        lib.ssdhip_conv_chain_x3_pack_weight.argtypes = [vp, vp, ci, ci, ci, vp]
+        lib.ssdhip_conv_chain_x3_nhwc_f16.restype = ci
+        lib.ssdhip_conv_chain_x3_nhwc_f16.argtypes = [vp, ci, ci, ci, ci, ci] + [vp] * 9 + [vp]
+        lib._chainx3_bound = True
+
+
+def conv_chain_x3_pack(packed_weight, out=None):
+    """x3_pack_weight's (Cout, 3 Cin, k, k) float16 channels_last filters in the fragment order `conv_chain_x3` streams; None if the
+    geometry is not supported.  `out`: an earlier result for the same geometry, re-packed in place."""
+    torch = _torch()
+    lib = load()
+    _bind_chain_x3(lib)
+    cout, c3, kh, kw = packed_weight.shape
+    if packed_weight.dtype != torch.float16 or kh != kw or c3 % 3 or not packed_weight.permute(0, 2, 3, 1).is_contiguous():
+        raise SsdHipError("conv_chain_x3_pack takes x3_pack_weight's (Cout, 3 Cin, k, k) float16 channels_last filters")
+    n = int(lib.ssdhip_conv_chain_x3_packed_bytes(kh, c3 // 3, cout))
+    if n == 0:
+        return None
+    if out is not None and (out.numel() != n or out.dtype != torch.uint8 or out.device != packed_weight.device):
+        raise SsdHipError("conv_chain_x3_pack: `out` does not match this filter's packed size")
+    packed = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=packed_weight.device)
+    with torch.cuda.device(packed_weight.device):
+        check(lib.ssdhip_conv_chain_x3_pack_weight(_ptr(packed_weight), _ptr(packed), kh, c3 // 3, cout, current_stream_ptr(packed_weight.device)),
+              "ssdhip_conv_chain_x3_pack_weight")
+    return packed
+
+
+def conv_chain_x3(x2, layers):
+    """The chain of small convolutions at the reference's precision in one launch (csrc/ssdhip_chain.hip, conv_chain_x3_kernel).  x2
+    (B, 2 C0, H, W) float16 channels_last pair map; `layers`: dicts {packed (conv_chain_x3_pack), bias (float32, divided by the layer's
+    output divisor, or None), k, stride, pad, cout, relu, mul (oscale * input divisor / output divisor), keep}; returns the kept
+    layers' pair maps (B, 2 Cout, Ho, Wo), or None when the chain does not fit (the caller runs the layers one by one)."""
+    torch = _torch()
+    lib = load()
+    _bind_chain_x3(lib)
+    if not (x2.is_cuda and x2.dtype == torch.float16 and x2.dim() == 4 and x2.shape[1] % 2 == 0 and _nhwc_ok(x2)):
+        raise SsdHipError("conv_chain_x3 takes a float16 (B, 2 C, H, W) channels_last pair map")
+    b, c2, h, w = x2.shape
+    n = len(layers)
+    outs, ys = [], []
+    hh, ww = h, w
+    for l in layers:
+        hh = (hh + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        ww = (ww + 2 * l["pad"] - l["k"]) // l["stride"] + 1
+        if hh < 1 or ww < 1:
+            return None
+        if l.get("bias") is not None and (l["bias"].dtype != torch.float32 or not l["bias"].is_contiguous()):
+            raise SsdHipError("conv_chain_x3: bias must be contiguous float32")
+        if l.get("keep", False):
+            y = torch.empty((b, hh, ww, 2 * l["cout"]), dtype=torch.float16, device=x2.device).permute(0, 3, 1, 2)
+            outs.append(y)
+            ys.append(y)
+        else:
+            ys.append(None)
+    parr = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    iarr = lambda key: (ctypes.c_int * n)(*[int(l[key]) for l in layers])
+    farr = (ctypes.c_float * n)(*[float(l["mul"]) for l in layers])
+    with torch.cuda.device(x2.device):
+        rc = lib.ssdhip_conv_chain_x3_nhwc_f16(_ptr(x2), b, h, w, c2 // 2, n, parr([l["packed"] for l in layers]),
+                                               parr([l.get("bias") for l in layers]), parr(ys), iarr("k"), iarr("stride"), iarr("pad"),
+                                               iarr("cout"), iarr("relu"), farr, current_stream_ptr(x2.device))
+    if rc == -1:                                          # SSDHIP_E_BADARG: the chain does not fit this kernel
+        return None
+    check(rc, "ssdhip_conv_chain_x3_nhwc_f16")
+    return outs
+
+
 def conv3x3_wgrad(x, dy, bias_partial=None):
     """Weight gradient of a 3x3 'same' stride-1 convolution (csrc/ssdhip_wgrad.hip): x (B, Cin, H, W) and dy (B, Cout, H, W) bfloat16
     channels_last -> float32 (Cout, Cin, 3, 3) in channels_last memory format ([Cout, 3, 3, Cin] physical), or None when the

@@ -166,6 +166,175 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
 #endif
 }
 
+// ======================================================================================
+// The same chain at the reference's precision (round 6; models/precise.py): activations are float16 (hi, lo) PAIR maps, filters float16
+// pairs of the float32 filters / oscale, three float16 MFMAs per K-step -- w_hi x_hi, w_hi x_lo, w_lo x_hi -- into three float32
+// accumulators (three independent chains through the matrix pipe), the epilogue mul * sum + bias in float32, ReLU, re-split.  One
+// workgroup per image as above.  Differences: the FIRST layer (a 1 x 1 layer: conv7_1) reads its pixels straight from global memory --
+// conv6_2's 10 x 10 x 512 map is 205 KB as pairs, more than a CU's LDS -- and every later map (53 KB and below) lives in LDS as
+// [pixel][hi C | lo C] rows; filter fragments stream as (hi, lo) twins, four K-steps in flight per wave (the register budget of 2
+// waves per SIMD: 32 ring + 64 pixel-operand + 48 accumulator registers).  Replaces six launches of 22-102 us each on the
+// reference-precision step's critical path.
+// ======================================================================================
+typedef _Float16 cc_f16x8 __attribute__((ext_vector_type(8)));
+[[maybe_unused]] constexpr int CX_PF = 4;
+
+struct ChainX3LayerDev {
+    const uint4* wp;             // packed filters: [Cout / 32][k k][Cin / 16][2 = hi, lo][64 lanes] x 16 bytes
+    const float* bias;           // [Cout] float32, already divided by the layer's output divisor, or null
+    unsigned short* y;           // [B, Hout, Wout, 2 Cout] float16 pairs or null
+    float mul;                   // oscale * s_in / s_out
+    int k, stride, pad, Cin, Cout, relu;
+    int Hin, Win, Hout, Wout;
+    int in_off, out_off;         // LDS byte offsets of the input / output map (rows of 4 C + 16 bytes); layer 0 reads global memory
+};
+struct ChainX3Params {
+    const unsigned short* x;     // [B, H, W, 2 C0] float16 pairs
+    int n_layers, zero_off;
+    ChainX3LayerDev L[CC_MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(CC_THREADS) void conv_chain_x3_kernel(ChainX3Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[CC_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, khalf = lane >> 5;
+    const int b = (int)blockIdx.x;
+    for (int i = tid; i < 66; i += CC_THREADS) *reinterpret_cast<uint4*>(lds + p.zero_off + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    for (int li = 0; li < p.n_layers; ++li) {
+        const ChainX3LayerDev& l = p.L[li];
+        const int c16n = l.Cin >> 4;                     // 16-channel blocks per tap (a multiple of 4)
+        const int taps = l.k * l.k, kt = taps * c16n;
+        const int bpt = c16n >> 2;                       // blocks of four K-steps per tap
+        const int nblk = l.Cout >> 5, npix = l.Hout * l.Wout, mblk = (npix + 31) >> 5;
+        const int out_stride = l.Cout * 4 + 16;
+        // (two instantiations of the tile loop: layer 0's pixel rows are GLOBAL memory, the others' LDS -- one generic pointer would make
+        //  every read a flat load)
+        auto tiles = [&](auto from_global) {
+        constexpr bool GLOBAL = decltype(from_global)::value;
+        const int in_stride = GLOBAL ? l.Cin * 4 : l.Cin * 4 + 16;
+        const unsigned char* const gbase = reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * l.Hin * l.Win * (l.Cin * 4);
+        for (int t = wave; t < nblk * mblk; t += CC_THREADS / 64) {
+            const int nb = t % nblk, mb = t / nblk;
+            const int pix = mb * 32 + r31;
+            const bool live = pix < npix;
+            const int ho = live ? pix / l.Wout : 0, wo = live ? pix - ho * l.Wout : 0;
+            const int hi0 = ho * l.stride - l.pad, wi0 = wo * l.stride - l.pad;
+            const uint4* wsrc = l.wp + (size_t)nb * kt * 128 + lane;
+            cc_f32x16 a_hh, a_hl, a_lh;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { a_hh[v] = 0.f; a_hl[v] = 0.f; a_lh[v] = 0.f; }
+            uint4 rh[CX_PF], rl[CX_PF];
+#pragma unroll
+            for (int j = 0; j < CX_PF; ++j) { rh[j] = wsrc[(size_t)j * 128]; rl[j] = wsrc[(size_t)j * 128 + 64]; }
+            uint4 bh[2][CX_PF], bl[2][CX_PF];
+            // the lane's pixel row of K-block kb (one tap, 64 channels), or the row of zeros (padding tap / lane without a pixel / behind the end)
+            auto read_block = [&](auto hc, const int kb) {
+                constexpr int HB = decltype(hc)::value;
+                const int tap = (kb >> 2) / bpt, cb = (kb >> 2) - tap * bpt;
+                const int kh = tap / l.k, kw = tap - kh * l.k;
+                const int hi = hi0 + kh, wi = wi0 + kw;
+                const bool ok = live & ((unsigned)hi < (unsigned)l.Hin) & ((unsigned)wi < (unsigned)l.Win) & (kb < kt);
+                if constexpr (GLOBAL) {
+                    // (a 1 x 1 layer without padding: only lanes without a pixel and reads behind the end are not `ok` -- they re-read the
+                    //  image's first row, their products are never stored / the step multiplies the clamped last filter fragment into
+                    //  nothing that is kept: kb >= kt only happens in the skipped half of the last double block)
+                    const unsigned char* row = gbase + (size_t)(ok ? hi * l.Win + wi : 0) * in_stride + (kb < kt ? cb * 128 : 0) + khalf * 16;
+#pragma unroll
+                    for (int j = 0; j < CX_PF; ++j) {
+                        bh[HB][j] = *reinterpret_cast<const uint4*>(row + j * 32);
+                        bl[HB][j] = *reinterpret_cast<const uint4*>(row + l.Cin * 2 + j * 32);
+                    }
+                } else {
+                    const unsigned char* row = lds + (ok ? l.in_off + (hi * l.Win + wi) * in_stride + cb * 128 + khalf * 16 : p.zero_off + khalf * 16);
+                    const int step = ok ? 32 : 0, lo = ok ? l.Cin * 2 : 0;
+#pragma unroll
+                    for (int j = 0; j < CX_PF; ++j) {
+                        bh[HB][j] = *reinterpret_cast<const uint4*>(row + j * step);
+                        bl[HB][j] = *reinterpret_cast<const uint4*>(row + lo + j * step);
+                    }
+                }
+            };
+            auto mul_block = [&](auto hc, const int kb) {
+                constexpr int HB = decltype(hc)::value;
+#pragma unroll
+                for (int j = 0; j < CX_PF; ++j) {
+                    const uint4 wh = rh[j], wl = rl[j];
+                    const int kn = kb + CX_PF + j;
+                    const size_t o = (size_t)(kn < kt ? kn : kt - 1) * 128;
+                    rh[j] = wsrc[o];
+                    rl[j] = wsrc[o + 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    a_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cc_f16x8, wh), __builtin_bit_cast(cc_f16x8, bh[HB][j]), a_hh, 0, 0, 0);
+                    a_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cc_f16x8, wh), __builtin_bit_cast(cc_f16x8, bl[HB][j]), a_hl, 0, 0, 0);
+                    a_lh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cc_f16x8, wl), __builtin_bit_cast(cc_f16x8, bh[HB][j]), a_lh, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
+            read_block(H0{}, 0);
+            for (int kb = 0; kb < kt; kb += 2 * CX_PF) {
+                read_block(H1{}, kb + CX_PF);
+                mul_block(H0{}, kb);
+                if (kb + CX_PF < kt) {
+                    read_block(H0{}, kb + 2 * CX_PF);
+                    mul_block(H1{}, kb + CX_PF);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = nb * 32 + 8 * g + 4 * khalf;
+                    unsigned short hs[4], ls[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = (a_hh[4 * g + e] + (a_hl[4 * g + e] + a_lh[4 * g + e])) * l.mul;
+                        if (l.bias) v += l.bias[c + e];
+                        v = l.relu ? (v > 0.f ? v : (v != v ? v : 0.f)) : v;
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)h);
+                        hs[e] = __builtin_bit_cast(unsigned short, h);
+                        ls[e] = __builtin_bit_cast(unsigned short, lo);
+                    }
+                    const uint2 ph = make_uint2((u32)hs[0] | ((u32)hs[1] << 16), (u32)hs[2] | ((u32)hs[3] << 16));
+                    const uint2 pl = make_uint2((u32)ls[0] | ((u32)ls[1] << 16), (u32)ls[2] | ((u32)ls[3] << 16));
+                    unsigned char* orow = lds + l.out_off + pix * out_stride;
+                    *reinterpret_cast<uint2*>(orow + c * 2) = ph;
+                    *reinterpret_cast<uint2*>(orow + l.Cout * 2 + c * 2) = pl;
+                    if (l.y) {
+                        unsigned short* yrow = l.y + ((size_t)b * npix + pix) * (2 * l.Cout);
+                        *reinterpret_cast<uint2*>(yrow + c) = ph;
+                        *reinterpret_cast<uint2*>(yrow + l.Cout + c) = pl;
+                    }
+                }
+            }
+        }
+        };
+        if (li == 0) tiles(std::true_type{}); else tiles(std::false_type{});
+        __syncthreads();
+    }
+#endif
+}
+
+// x3 [Cout][taps][3 Cin] float16 = [w hi | w lo | w hi] (what x3_pack_weight builds) -> fragment twins:
+// packed[(((nb T + tap) (Cin / 16) + c16) 2 + part) 64 + lane] (16 bytes) = part(w)[nb 32 + (lane & 31)][tap][c16 16 + (lane >> 5) 8 .. + 7]
+__global__ __launch_bounds__(256) void chain_x3_pack_kernel(const uint4* __restrict__ w, uint4* __restrict__ packed, int taps, int Cin, int Cout) {
+    const int c16n = Cin >> 4;
+    const size_t n = (size_t)(Cout >> 5) * taps * c16n * 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
+        size_t r = i >> 7;
+        const int c16 = (int)(r % c16n); r /= c16n;
+        const int tap = (int)(r % taps);
+        const int nb = (int)(r / taps);
+        const int co = nb * 32 + (lane & 31);
+        packed[i] = w[((size_t)co * taps + tap) * (3 * Cin >> 3) + (size_t)part * (Cin >> 3) + c16 * 2 + (lane >> 5)];
+    }
+}
+
 // packed[((nb T + tap) (Cin / 16) + c16) 64 + lane] (16 bytes) = w[nb 32 + (lane & 31)][tap][c16 16 + (lane >> 5) 8 .. + 7]
 __global__ __launch_bounds__(256) void chain_pack_kernel(const uint4* __restrict__ w, uint4* __restrict__ packed, int taps, int Cin, int Cout) {
     const int c16n = Cin >> 4;
@@ -246,5 +415,72 @@ extern "C" int ssdhip_conv_chain_nhwc_bf16(const void* x, int B, int H, int W, i
     }
     for (int i = n_layers; i < CC_MAX_LAYERS; ++i) p.L[i] = p.L[0];
     hipLaunchKernelGGL(conv_chain_kernel, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// ---- the chain at the reference's precision (float16 pairs, three products; see conv_chain_x3_kernel) -------------------------------------
+extern "C" size_t ssdhip_conv_chain_x3_packed_bytes(int k, int Cin, int Cout) {
+    if (k <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 32)) return 0;
+    return (size_t)Cout * k * k * Cin * 4;
+}
+
+// weight_x3 [Cout, k, k, 3 Cin] float16 = [w hi | w lo | w hi] (ssdhip_conv2d_x3_nhwc_f16's filter layout) -> the fragment twins the chain streams
+extern "C" int ssdhip_conv_chain_x3_pack_weight(const void* weight_x3, void* packed, int k, int Cin, int Cout, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!weight_x3 || !packed || !ssdhip_conv_chain_x3_packed_bytes(k, Cin, Cout)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)weight_x3 | (uintptr_t)packed) & 15) return SSDHIP_E_BADARG;
+    hipLaunchKernelGGL(chain_x3_pack_kernel, dim3(256), dim3(256), 0, stream, static_cast<const uint4*>(weight_x3), static_cast<uint4*>(packed), k * k,
+                       Cin, Cout);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// n_layers (<= 8) convolutions applied one after the other to the pair map x [B, H, W, 2 C0] float16 = [hi | lo]; layer i computes
+// act(mul_i * (w_i * x) + bias_i) in float32 -- mul_i = oscale_i * (divisor of its input) / (divisor of its output), bias_i float32 already
+// divided by the output divisor -- and re-splits; y_i [B, H_i, W_i, 2 Cout_i] pairs are written where y_h[i] is not null.  The first layer
+// must be 1 x 1, stride 1, no padding (it reads x from global memory; the later maps must fit the CU's LDS as pairs).  Cin_i % 64 == 0,
+// Cout_i % 32 == 0.  SSDHIP_E_BADARG: the chain does not fit (callers run the layers one by one).
+extern "C" int ssdhip_conv_chain_x3_nhwc_f16(const void* x, int B, int H, int W, int C0, int n_layers, const void* const* packed_h,
+                                             const float* const* bias_h, void* const* y_h, const int* k_h, const int* stride_h, const int* pad_h,
+                                             const int* cout_h, const int* relu_h, const float* mul_h, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || B <= 0 || H <= 0 || W <= 0 || n_layers < 1 || n_layers > CC_MAX_LAYERS || !packed_h || !y_h || !k_h || !stride_h || !pad_h || !cout_h ||
+        !mul_h)
+        return SSDHIP_E_BADARG;
+    if (k_h[0] != 1 || stride_h[0] != 1 || pad_h[0] != 0 || ((uintptr_t)x & 15)) return SSDHIP_E_BADARG;
+    ChainX3Params p;
+    p.x = static_cast<const unsigned short*>(x);
+    p.n_layers = n_layers;
+    int h = H, w = W, c = C0;
+    size_t need[2] = {0, 0};
+    int hs[CC_MAX_LAYERS + 1], wsz[CC_MAX_LAYERS + 1], cs[CC_MAX_LAYERS + 1];
+    hs[0] = h; wsz[0] = w; cs[0] = c;
+    for (int i = 0; i < n_layers; ++i) {
+        const int k = k_h[i], s = stride_h[i], pd = pad_h[i], co = cout_h[i];
+        if (k < 1 || k > 7 || s < 1 || pd < 0 || !ssdhip_conv_chain_x3_packed_bytes(k, c, co) || !packed_h[i] || !(mul_h[i] > 0.f)) return SSDHIP_E_BADARG;
+        if (h + 2 * pd < k || w + 2 * pd < k) return SSDHIP_E_BADARG;
+        if (((uintptr_t)packed_h[i] & 15) || (bias_h && bias_h[i] && ((uintptr_t)bias_h[i] & 3)) || (y_h[i] && ((uintptr_t)y_h[i] & 7))) return SSDHIP_E_BADARG;
+        h = (h + 2 * pd - k) / s + 1; w = (w + 2 * pd - k) / s + 1; c = co;
+        hs[i + 1] = h; wsz[i + 1] = w; cs[i + 1] = c;
+    }
+    for (int i = 1; i <= n_layers; ++i) {                 // map 0 stays in global memory
+        const size_t bytes = (size_t)hs[i] * wsz[i] * (cs[i] * 4 + 16);
+        if (bytes > need[i & 1]) need[i & 1] = bytes;
+    }
+    const size_t off1 = (need[0] + 15) / 16 * 16, zoff = off1 + (need[1] + 15) / 16 * 16;
+    if (zoff + 66 * 16 > (size_t)CC_LDS) return SSDHIP_E_BADARG;
+    p.zero_off = (int)zoff;
+    for (int i = 0; i < n_layers; ++i) {
+        ChainX3LayerDev& l = p.L[i];
+        l.wp = static_cast<const uint4*>(packed_h[i]);
+        l.bias = bias_h ? bias_h[i] : nullptr;
+        l.y = static_cast<unsigned short*>(y_h[i]);
+        l.mul = mul_h[i];
+        l.k = k_h[i]; l.stride = stride_h[i]; l.pad = pad_h[i]; l.Cin = cs[i]; l.Cout = cs[i + 1]; l.relu = relu_h ? relu_h[i] : 1;
+        l.Hin = hs[i]; l.Win = wsz[i]; l.Hout = hs[i + 1]; l.Wout = wsz[i + 1];
+        l.in_off = (i & 1) ? (int)off1 : 0;
+        l.out_off = (i & 1) ? 0 : (int)off1;
+    }
+    for (int i = n_layers; i < CC_MAX_LAYERS; ++i) p.L[i] = p.L[0];
+    hipLaunchKernelGGL(conv_chain_x3_kernel, dim3(B), dim3(CC_THREADS), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

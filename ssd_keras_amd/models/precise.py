@@ -222,6 +222,32 @@ class PreciseForward:
         fc7 = c(m.fc7, c(m.fc6, a))
         return conv4_3, fc7
 
+    def _extras_chain(self, act, convs):
+        """The 1x1 / 3x3 pairs behind conv6_2 (conv7_1 ... conv9_2, reference models/keras_ssd300.py:304-313) as ONE launch with the
+        intermediate pair maps in LDS; returns the (pair map, divisor) of every second layer, or None -> the caller runs them one by
+        one (calibration, a layer the kernel does not cover, maps that do not fit)."""
+        if self._calibrating is not None or not convs or os.environ.get("SSDHIP_X3_NO_CHAIN", "0") == "1":
+            return None
+        t, s_in = act
+        if t.dtype != torch.float16 or not t.is_cuda:
+            return None
+        layers = []
+        for i, conv in enumerate(convs):
+            if not self._supported(conv) or conv.dilation != (1, 1) or conv.bias is None:
+                return None
+            w, oscale, bias = self._conv_filters(conv)
+            packed = self._pack(("chain", id(conv)), [conv.weight], lambda w=w: nat.conv_chain_x3_pack(w))
+            if packed is None:
+                return None
+            s_out = self._scale.get(id(conv), 1.0)
+            layers.append({"packed": packed, "bias": bias, "k": conv.kernel_size[0], "stride": conv.stride[0], "pad": conv.padding[0],
+                           "cout": conv.out_channels, "relu": 1, "mul": oscale * s_in / s_out, "keep": bool(i & 1)})
+            s_in = s_out
+        outs = nat.conv_chain_x3(t, layers)
+        if outs is None:
+            return None
+        return [(o, self._scale.get(id(c), 1.0)) for o, c in zip(outs, convs[1::2])]
+
     _EXTRA_NAMES = [("conv6_1", "conv6_2"), ("conv7_1", "conv7_2"), ("conv8_1", "conv8_2"), ("conv9_1", "conv9_2"), ("conv10_1", "conv10_2")]
 
     def _head(self, l, act):
@@ -385,9 +411,7 @@ class PreciseForward:
         if not one_stream:
             conv4_3[0].record_stream(side1)
             fc7[0].record_stream(side1)
-        x2 = fc7
-        for k, (a, b) in enumerate(names):
-            x2 = self.conv(getattr(m, b), self.conv(getattr(m, a), x2))       # main stream
+        def small_head(k, act):
             ready = torch.cuda.Event()
             ready.record(main)
             # (round 6: the small heads ALTERNATE between the two side streams -- on one stream the 3 x 3 and 1 x 1 maps' heads, ~75 us of
@@ -395,9 +419,21 @@ class PreciseForward:
             hs = side1 if (k & 1) and os.environ.get("SSDHIP_X3_HEADS_ALTERNATE", "1") == "1" else side2
             with torch.cuda.stream(hs):
                 hs.wait_event(ready)
-                ys[2 + k] = self._head(2 + k, x2)
+                ys[2 + k] = self._head(2 + k, act)
             if not one_stream:
-                x2[0].record_stream(hs)
+                act[0].record_stream(hs)
+
+        x2 = fc7
+        for k, (a, b) in enumerate(names):
+            if k == 1:
+                # round 6: conv7_1 ... conv9_2 in ONE launch (csrc/ssdhip_chain.hip, conv_chain_x3_kernel; six launches of 22-102 us before)
+                tail = self._extras_chain(x2, [getattr(m, n) for pair in names[1:] for n in pair])
+                if tail is not None:
+                    for kk, act in enumerate(tail, start=1):
+                        small_head(kk, act)
+                    break
+            x2 = self.conv(getattr(m, b), self.conv(getattr(m, a), x2))       # main stream
+            small_head(k, x2)
         if not one_stream:
             main.wait_stream(side1)
             main.wait_stream(side2)

@@ -318,3 +318,43 @@ def test_l2_normalization_on_the_pair_map(shape, scale):
     want = xt / norm * gamma.double().view(1, -1, 1, 1)
     assert bool(torch.isfinite(got).all()) and float(got[0, :, 0, 0].abs().max()) == 0.0
     assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_extras_chain_at_reference_precision_equals_the_layers_one_by_one():
+    """csrc/ssdhip_chain.hip, conv_chain_x3_kernel: conv7_1 ... conv9_2 of a float32 SSD300 in one launch against the same six layers
+    through ssdhip_conv2d_x3 one by one (float32-grade: the three products are summed in another order) and against float64; with
+    per-layer divisors; a chain whose first layer is not 1 x 1 -> None."""
+    import torch
+    import torch.nn.functional as F
+    from ssd_keras_amd import _native as nat
+    from ssd_keras_amd.models.precise import PreciseForward
+    m32 = _tamed_float32_ssd300(19)
+    for prm in m32.parameters():
+        prm.requires_grad_(False)
+    pf = PreciseForward(m32)
+    g = torch.Generator(device="cuda").manual_seed(43)
+    x = (torch.rand((3, 512, 10, 10), device="cuda", generator=g) * 50.0).contiguous(memory_format=torch.channels_last)
+    convs = [m32.conv7_1, m32.conv7_2, m32.conv8_1, m32.conv8_2, m32.conv9_1, m32.conv9_2]
+    for divisors in ({}, {id(m32.conv7_2): 4.0, id(m32.conv8_1): 0.5}):
+        pf._scale = dict(divisors)
+        pf._packed = {}
+        pf._calibrated = True
+        act = (nat.x3_split(x / 2.0), 2.0)
+        tail = pf._extras_chain(act, convs)
+        assert tail is not None and len(tail) == 3
+        one = act
+        ref = x.double()
+        singles, refs = [], []
+        for i, conv in enumerate(convs):
+            one = pf.conv(conv, one)
+            ref = torch.relu(F.conv2d(ref, conv.weight.double(), conv.bias.double(), conv.stride, conv.padding))
+            if i & 1:
+                singles.append(one)
+                refs.append(ref)
+        for (got, sg), (want, sw), r64 in zip(tail, singles, refs):
+            assert sg == sw and got.shape == want.shape and got.dtype == torch.float16
+            a, b = nat.x3_merge(got).double() * sg, nat.x3_merge(want).double() * sw
+            scale = float(r64.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-6 * scale
+            assert float((a - r64).abs().max()) <= 4e-6 * scale
+    assert pf._extras_chain(act, convs[1:]) is None                       # a 3 x 3 first layer: the caller runs the layers one by one
