@@ -417,6 +417,12 @@ int ssdhip_x3_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, i
  * ssdhip_l2_normalize_fwd on the merged map, re-split -- one pass instead of merge + normalise + split (round 6). */
 int ssdhip_x3_l2_normalize_nhwc(const void* x, const float* gamma, void* y, long long n_pixels, int C, float scale, void* stream);
 int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const float* bias, void* y, int B, int H, int W, int relu, void* stream);
+/* ... with the graph's input Lambdas in front (models/keras_ssd300.py:254-264: mean subtraction, stddev division, channel swap): images
+ * [B,H,W,3] float32 as the generator hands them over, mean_h / divide_h / swap_h HOST arrays of three entries or NULL; conv1_1 reads
+ * (images[swap[c]] - mean[swap[c]]) / divide[swap[c]], the framework's float32 expression bit for bit (round 6: three passes over the
+ * batch less in the reference-precision step). */
+int ssdhip_conv1_1_x3_pre_nhwc(const float* images, const float* weight, const float* bias, void* y, int B, int H, int W, int relu,
+                               const float* mean_h, const float* divide_h, const int* swap_h, void* stream);
 
 size_t ssdhip_conv2d_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kernel, int stride, int pad, int dilation,
                                             int ksplit);

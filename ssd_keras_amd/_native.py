@@ -1336,6 +1336,32 @@ def conv1_1_x3(x, weight, bias, relu=True):
     return y
 
 
+def conv1_1_x3_pre(images, weight, bias, mean=None, divide=None, swap=None, relu=True):
+    """conv1_1 of the reference-precision path straight from the generator's float32 (B, H, W, 3) images: the graph's input Lambdas (mean
+    subtraction, stddev division, channel swap) are applied while the kernel stages its input (ssdhip_conv1_1_x3_pre_nhwc) -> the split
+    float16 (B, 128, H, W) map."""
+    torch = _torch()
+    lib = _x3_glue(load())
+    if not getattr(lib, "_c11pre_bound", False):
+        lib.ssdhip_conv1_1_x3_pre_nhwc.restype = ctypes.c_int
+        lib.ssdhip_conv1_1_x3_pre_nhwc.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4
+        lib._c11pre_bound = True
+    if not (images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[3] == 3 and images.is_contiguous()
+            and tuple(weight.shape) == (64, 3, 3, 3)):
+        raise SsdHipError("conv1_1_x3_pre takes contiguous float32 (B, H, W, 3) images and (64, 3, 3, 3) filters")
+    b, h, w, _ = images.shape
+    wk = weight.detach().float().permute(0, 2, 3, 1).contiguous()          # (co, kh, kw, ci)
+    bk = bias.detach().float().contiguous() if bias is not None else None
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(t) for t in v]) if v is not None else None
+    i3 = (ctypes.c_int * 3)(*[int(t) for t in swap]) if swap is not None else None
+    y = torch.empty((b, h, w, 128), dtype=torch.float16, device=images.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(images.device):
+        rc = lib.ssdhip_conv1_1_x3_pre_nhwc(_ptr(images), _ptr(wk), _ptr(bk), _ptr(y), b, h, w, int(bool(relu)), f3(mean), f3(divide), i3,
+                                            current_stream_ptr(images.device))
+    check(rc, "ssdhip_conv1_1_x3_pre_nhwc")
+    return y
+
+
 def x3_split(v):
     """float32 (B, C, H, W) in channels_last memory -> float16 (B, 2C, H, W) channels_last = [hi | lo], hi = fl16(v), lo = fl16(v - hi):
     the activation layout of conv2d_x3."""

@@ -517,8 +517,17 @@ __global__ __launch_bounds__(256) void x3_merge_kernel(const uint4* __restrict__
 constexpr int C11_PX = 4;
 constexpr int C11_TILE = 32 * C11_PX;                    // pixels per tile
 constexpr int C11_RUN = (C11_TILE + 2) * 3;              // floats of one staged run: pixels p0 - 1 .. p0 + TILE of one filter row
+// PRE (round 6): the graph's input Lambdas (identity / mean subtraction / stddev division / channel swap, models/keras_ssd300.py:254-264)
+// applied while the tile's input runs are staged -- out[c] = (x[swap[c]] - mean[swap[c]]) / div[swap[c]], the framework's float32
+// operations in its order, zeros stay zeros outside the image -- instead of three framework passes over the batch (52 us of the step).
+struct C11Pre {
+    float mean[3], div[3];
+    int swap[3];
+    int on, has_div;
+};
+template <bool PRE>
 __global__ __launch_bounds__(256, 4) void conv1_1_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         uint4* __restrict__ y, int H, int W, u32 n_pixels, int relu) {
+                                                         uint4* __restrict__ y, int H, int W, u32 n_pixels, int relu, C11Pre pre) {
     __shared__ __attribute__((aligned(16))) float wl[27 * 64];
     __shared__ float bl[64];
     __shared__ float sx[3][C11_RUN + 2];
@@ -533,7 +542,17 @@ __global__ __launch_bounds__(256, 4) void conv1_1_x3_kernel(const float* __restr
         for (int i = threadIdx.x; i < 3 * C11_RUN; i += 256) {
             const int r = i / C11_RUN, k = i - r * C11_RUN;
             const long long g = ((long long)p0 - 1 + (long long)(r - 1) * W) * 3 + k;
-            sx[r][k] = (g >= 0 && g < n_floats) ? x[g] : 0.f;
+            if constexpr (PRE) {
+                const int c = k % 3, sc = c == 0 ? pre.swap[0] : (c == 1 ? pre.swap[1] : pre.swap[2]);
+                float v = 0.f;
+                if (g >= 0 && g < n_floats) {
+                    v = x[g - c + sc] - (sc == 0 ? pre.mean[0] : (sc == 1 ? pre.mean[1] : pre.mean[2]));
+                    if (pre.has_div) v = v / (sc == 0 ? pre.div[0] : (sc == 1 ? pre.div[1] : pre.div[2]));
+                }
+                sx[r][k] = v;
+            } else {
+                sx[r][k] = (g >= 0 && g < n_floats) ? x[g] : 0.f;
+            }
         }
         __syncthreads();
         const u32 px0 = p0 + pl * C11_PX;
@@ -728,8 +747,33 @@ extern "C" int ssdhip_conv1_1_x3_nhwc(const float* x, const float* weight, const
     const long long n = (long long)B * H * W;
     long long blocks = (n + ssdhip::C11_TILE - 1) / ssdhip::C11_TILE;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(ssdhip::conv1_1_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, weight, bias, static_cast<uint4*>(y), H, W,
-                       (u32)n, relu ? 1 : 0);
+    hipLaunchKernelGGL(ssdhip::conv1_1_x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, weight, bias, static_cast<uint4*>(y), H, W,
+                       (u32)n, relu ? 1 : 0, ssdhip::C11Pre{});
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// ... with the graph's input pipeline in front (models/keras_ssd300.py:254-264): images [B, H, W, 3] float32 as they come from the
+// generator; mean_h / divide_h / swap_h: HOST arrays of three entries or NULL (no subtraction / no division / identity order).  conv1_1
+// sees (images[swap[c]] - mean[swap[c]]) / divide[swap[c]] -- bit for bit the framework's float32 expression.
+extern "C" int ssdhip_conv1_1_x3_pre_nhwc(const float* images, const float* weight, const float* bias, void* y, int B, int H, int W, int relu,
+                                          const float* mean_h, const float* divide_h, const int* swap_h, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!images || !weight || !y || B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W > 0x3fffffffLL) return SSDHIP_E_BADARG;
+    if (((uintptr_t)y) & 15) return SSDHIP_E_BADARG;
+    ssdhip::C11Pre pre;
+    for (int c = 0; c < 3; ++c) {
+        pre.mean[c] = mean_h ? mean_h[c] : 0.f;
+        pre.div[c] = divide_h ? divide_h[c] : 1.f;
+        pre.swap[c] = swap_h ? swap_h[c] : c;
+        if (pre.swap[c] < 0 || pre.swap[c] > 2) return SSDHIP_E_BADARG;
+    }
+    pre.on = 1;
+    pre.has_div = divide_h ? 1 : 0;
+    const long long n = (long long)B * H * W;
+    long long blocks = (n + ssdhip::C11_TILE - 1) / ssdhip::C11_TILE;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ssdhip::conv1_1_x3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, images, weight, bias, static_cast<uint4*>(y), H, W,
+                       (u32)n, relu ? 1 : 0, pre);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 

@@ -192,13 +192,46 @@ class PreciseForward:
     def _same3(conv):
         return conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
 
-    def _vgg(self, x):
+    def _raw_images(self, images):
+        """The generator's (B, H, W, 3) float32 batch itself when conv1_1's kernel can apply the input Lambdas while it stages its input
+        (round 6: mean subtraction, channel swap and the layout copy were three framework passes, 52 us of the step), else None."""
+        m = self.model
+        c11 = m.conv1_1
+        if (self._calibrating is not None or os.environ.get("SSDHIP_X3_NO_FUSED_INPUT", "0") == "1" or images.dim() != 4
+                or images.shape[-1] != 3 or images.shape[1] == 3 or getattr(m, "img_channels", 3) != 3 or not images.is_cuda
+                or images.dtype != torch.float32 or not images.is_contiguous()):
+            return None
+        if not (c11.in_channels == 3 and c11.out_channels == 64 and self._same3(c11) and self._scale.get(id(c11), 1.0) == 1.0
+                and c11.weight.dtype == torch.float32):
+            return None
+        return images
+
+    def _input_constants(self):
+        m = self.model
+
+        def three(v):
+            if v is None:
+                return None
+            v = [float(t) for t in v] if hasattr(v, "__len__") else [float(v)] * 3
+            return v if len(v) == 3 else None
+        mean, div = three(m.subtract_mean), three(m.divide_by_stddev)
+        if (m.subtract_mean is not None and mean is None) or (m.divide_by_stddev is not None and div is None):
+            raise ValueError("per-channel constants must have three entries")
+        swap = [int(t) for t in m.swap_channels] if m.swap_channels else None
+        if swap is not None and len(swap) != 3:
+            raise ValueError("swap_channels must have three entries here")
+        return mean, div, swap
+
+    def _vgg(self, x, raw=None):
         m = self.model
         c = self.conv
         # conv1_1: three input channels, K = 27 -- float32 vector arithmetic with the split written directly (ssdhip_conv1_1_x3_nhwc;
         # the framework's float32 convolution of a 3-channel NHWC image is MIOpen's naive kernel: 5.2 ms at batch 32)
         c11 = m.conv1_1
-        if self._calibrating is not None:
+        if raw is not None:
+            mean, div, swap = self._input_constants()
+            a = (nat.conv1_1_x3_pre(raw, c11.weight, c11.bias, mean, div, swap, relu=True), 1.0)
+        elif self._calibrating is not None:
             y = torch.relu(F.conv2d(x, c11.weight, c11.bias, c11.stride, c11.padding))
             self._calibrating[id(c11)] = float(y.abs().max())
             s11 = 1.0 if self._framework_calibration else self._divisor(self._calibrating[id(c11)])   # (the next layer's probe takes pairs)
@@ -374,8 +407,9 @@ class PreciseForward:
     @torch.no_grad()
     def _forward(self, images, decode=False):
         m = self.model
-        x = m.preprocess(images)                                              # float32, channels_last
-        conv4_3, fc7 = self._vgg(x)
+        raw = self._raw_images(images)
+        x = m.preprocess(images) if raw is None else None                     # float32, channels_last
+        conv4_3, fc7 = self._vgg(x, raw)
         n_heads = len(m.conf_heads)
         names = [(a, b) for a, b in self._EXTRA_NAMES if hasattr(m, a)]
         if 2 + len(names) != n_heads:
@@ -384,8 +418,8 @@ class PreciseForward:
         # most CUs idle (0.44 ms), the two trunk heads do not depend on it (0.42 ms), and each small head only needs its own source
         # map.  Main: the chain.  Side 1: conv4_3_norm + its head, fc7's head.  Side 2: the head of every extra map as soon as it
         # exists.  One after the other they took 1.2 ms of an 8.3 ms forward (profiles/r03ze_x3_timeline.json).
-        main = torch.cuda.current_stream(x.device)
-        side1, side2 = self._streams(x.device)
+        main = torch.cuda.current_stream(images.device)
+        side1, side2 = self._streams(images.device)
         one_stream = side1.cuda_stream == main.cuda_stream          # calibration: everything on the current stream
         trunk = torch.cuda.Event()
         trunk.record(main)
@@ -397,7 +431,7 @@ class PreciseForward:
                 ys[1] = self._head(1, fc7)
             nl = m.conv4_3_norm
             if nl.gamma is None:
-                nl.build(conv4_3[0].shape[1] // 2 if conv4_3[0].dtype == torch.float16 else conv4_3[0].shape[1], x.device)
+                nl.build(conv4_3[0].shape[1] // 2 if conv4_3[0].dtype == torch.float16 else conv4_3[0].shape[1], images.device)
             if (conv4_3[0].dtype == torch.float16 and conv4_3[0].is_cuda and nl.gamma.dtype == torch.float32 and nl.gamma.is_contiguous()
                     and os.environ.get("SSDHIP_X3_NO_PAIR_NORM", "0") != "1"):
                 # round 6: L2Normalization on the pair map itself (one pass; before: merge -> float32 normalisation -> split, 111 us
@@ -411,7 +445,10 @@ class PreciseForward:
         if not one_stream:
             conv4_3[0].record_stream(side1)
             fc7[0].record_stream(side1)
-        def small_head(k, act):
+        def small_head(k, act, on_main=False):
+            if on_main:                                   # (behind the one-launch tail the main stream has nothing else to do)
+                ys[2 + k] = self._head(2 + k, act)
+                return
             ready = torch.cuda.Event()
             ready.record(main)
             # (round 6: the small heads ALTERNATE between the two side streams -- on one stream the 3 x 3 and 1 x 1 maps' heads, ~75 us of
@@ -429,15 +466,22 @@ class PreciseForward:
                 # round 6: conv7_1 ... conv9_2 in ONE launch (csrc/ssdhip_chain.hip, conv_chain_x3_kernel; six launches of 22-102 us before)
                 tail = self._extras_chain(x2, [getattr(m, n) for pair in names[1:] for n in pair])
                 if tail is not None:
+                    # the tail's three maps exist at once: their heads on the main stream and on side stream 2 -- side stream 1 is busy
+                    # with the two trunk heads until later than that (r06zk timeline)
+                    on_main = os.environ.get("SSDHIP_X3_TAIL_HEADS_ON_MAIN", "1") == "1"
                     for kk, act in enumerate(tail, start=1):
-                        small_head(kk, act)
+                        if not (on_main and (kk & 1)):
+                            small_head(kk, act)
+                    for kk, act in enumerate(tail, start=1):
+                        if on_main and (kk & 1):
+                            small_head(kk, act, on_main=True)
                     break
             x2 = self.conv(getattr(m, b), self.conv(getattr(m, a), x2))       # main stream
             small_head(k, x2)
         if not one_stream:
             main.wait_stream(side1)
             main.wait_stream(side2)
-        b = x.shape[0]
+        b = images.shape[0]
         if self._calibrating is None and all(y.dtype == torch.float32 and y.is_cuda for y in ys) and not self._torch_assembly:
             if not one_stream:
                 for y in ys:

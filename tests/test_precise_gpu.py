@@ -358,3 +358,28 @@ def test_extras_chain_at_reference_precision_equals_the_layers_one_by_one():
             assert float((a - b).abs().max()) <= 2e-6 * scale
             assert float((a - r64).abs().max()) <= 4e-6 * scale
     assert pf._extras_chain(act, convs[1:]) is None                       # a 3 x 3 first layer: the caller runs the layers one by one
+
+
+@pytest.mark.parametrize("mean,div,swap", [([123.0, 117.0, 104.0], None, [2, 1, 0]), (None, None, None), ([1.5, 2.5, 3.5], [2.0, 3.0, 5.0], [1, 2, 0]),
+                                           (7.0, 2.0, None)])
+def test_first_layer_with_the_input_lambdas_fused(mean, div, swap):
+    """ssdhip_conv1_1_x3_pre_nhwc: conv1_1 of the float32 graph straight from the generator's images, the Lambdas of
+    models/keras_ssd300.py:254-264 applied while the kernel stages its input -- bit-identical to the framework's float32 preprocessing
+    followed by ssdhip_conv1_1_x3_nhwc."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(47)
+    images = torch.randint(0, 256, (3, 37, 53, 3), device="cuda", generator=g).float()
+    w = torch.randn((64, 3, 3, 3), device="cuda", generator=g) * 0.2
+    b = torch.randn((64,), device="cuda", generator=g)
+    three = lambda v: None if v is None else ([float(v)] * 3 if not hasattr(v, "__len__") else [float(t) for t in v])
+    x = images.permute(0, 3, 1, 2)
+    if mean is not None:
+        x = x - torch.tensor(three(mean), device="cuda").view(1, 3, 1, 1)
+    if div is not None:
+        x = x / torch.tensor(three(div), device="cuda").view(1, 3, 1, 1)
+    if swap is not None:
+        x = x.index_select(1, torch.tensor(swap, device="cuda"))
+    want = nat.conv1_1_x3(x.contiguous(memory_format=torch.channels_last), w, b, relu=True)
+    got = nat.conv1_1_x3_pre(images, w, b, three(mean), three(div), swap, relu=True)
+    assert torch.equal(got, want)
