@@ -484,6 +484,11 @@ int ssdhip_conv2d_same_group_nhwc_bf16(int n_problems, const void* const* x_h, c
  * Same numerics as ssdhip_conv2d_same[_pool2]_nhwc_bf16 (bit-identical results). */
 int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                  int Cin, int Cout, int relu, int pool, int n_workgroups, void* stream);
+/* The same layer followed by MaxPooling2D(2, 2, 'same') in the TRAINING step (round 6): one launch writes y_pooled [B, ceil(H/2), ceil(W/2),
+ * Cout] (as pool != 0 above) AND y_full [B, H, W, Cout], the activation the backward pass reads -- bit-identical to the un-pooled launch
+ * followed by ssdhip_bias_act_maxpool, without reading the full-resolution map back (conv1_2 -> pool1: 368 MB at batch 32). */
+int ssdhip_conv3x3_c64_pool_keep_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y_full, void* y_pooled, int B, int H,
+                                           int W, int Cin, int Cout, int relu, int n_workgroups, void* stream);
 
 /* 3x3 'same' convolution (stride 1, dilation 1) + bias + ReLU for the VGG blocks with Cin % 128 == 0 and Cout % 128 == 0 (conv2_2,
  * conv3_x, conv4_x, conv5_x: models/keras_ssd300.py:279-296, keras_ssd512.py twins), optionally with MaxPooling2D(2, 2, 'same')

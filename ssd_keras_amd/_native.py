@@ -1562,6 +1562,33 @@ def conv3x3_c64(x, weight, bias, relu=True, pool=False):
     return y
 
 
+def conv3x3_c64_pool_keep(x, weight, bias, relu=True):
+    """Conv2D(relu) -> MaxPooling2D(2, 2, 'same') of a 64-channel map in ONE launch that writes BOTH the full-resolution activation and
+    the pooled map (csrc/ssdhip_conv64.hip, KEEP: the training step needs the former for its backward pass).  Returns (y, pooled);
+    bit-identical to conv3x3_c64(pool=False) followed by bias_act_maxpool."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_c64k_bound", False):
+        lib.ssdhip_conv3x3_c64_pool_keep_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_c64_pool_keep_nhwc_bf16.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+        lib._c64k_bound = True
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    cout, cin_w, kh, kw = weight.shape
+    if weight.dtype != torch.bfloat16 or cin_w != cin or cin != 64 or kh != 3 or kw != 3:
+        raise SsdHipError("conv3x3_c64_pool_keep needs a bfloat16 (Cout, 64, 3, 3) weight and a 64-channel input")
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    pooled = torch.empty((b, (h + 1) // 2, (w + 1) // 2, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    key = str(x.device)
+    if key not in _CU_COUNT:
+        _CU_COUNT[key] = int(torch.cuda.get_device_properties(x.device).multi_processor_count)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_c64_pool_keep_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), _ptr(pooled), b, h, w, cin, cout, int(bool(relu)),
+                                                        _CU_COUNT[key], current_stream_ptr(x.device))
+    check(rc, "ssdhip_conv3x3_c64_pool_keep_nhwc_bf16")
+    return y, pooled
+
+
 def conv3x3_cin3(x, weight, bias, relu=True):
     """First layer: 3x3 'same' convolution of a 3-channel image into 64 channels + bias + ReLU (csrc/ssdhip_conv.hip)."""
     torch = _torch()

@@ -90,6 +90,7 @@ struct C64Params {
     const bf16_t* b1;            // FRONT: [64] first-layer bias or null
     int prio;                    // FRONT: raise the multiplying waves' issue priority over the producers'
     int xcd_pairs;               // slice / tile-sequence mapping that keeps a tile's n_slices workgroups on one XCD (needs G % (8 n_slices) == 0)
+    bf16_t* y2;                  // KEEP (training, round 6): the full-resolution activation [B, H, W, Cout] beside the pooled y
 };
 
 __device__ __forceinline__ u32 c64_f2bf_rn(float f) {
@@ -166,8 +167,11 @@ __device__ __forceinline__ i32x4 c64_rsrc(const void* base, int num_records) {
 // instead of reading them from LDS every step.  With the filters in LDS a step reads 3 KB per wave for two MFMAs -- 12 KB per 64 MFMA
 // cycles per CU, 75 % of what ds_read_b128 delivers (256 B/clk), and the producers' gathers and halo stores come on top: the fused
 // block was LDS-bound.  With WREG a step reads the two pixel fragments only (50 %).
-template <int CS, bool POOL, int NB, bool FRONT, bool WREG>
+// KEEP (POOL only; the training step's Conv2D(relu) -> MaxPooling2D pairs): the pooled epilogue ALSO stores the full-resolution activation
+// the backward pass needs -- the accumulators survive the first epilogue -- instead of a second launch that reads the 368 MB map back to pool it.
+template <int CS, bool POOL, int NB, bool FRONT, bool WREG, bool KEEP = false>
 __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* lds) {
+    static_assert(!KEEP || (POOL && !FRONT), "KEEP is a variant of the pooled, un-fused kernel");
     constexpr int CC = 1 << CS, RP = 64 >> CS;           // tile: RP row pairs x CC columns = 128 pixels
     constexpr int HC = CC + 2, HR = 2 * RP + 2;          // halo columns / rows
     constexpr int HPX = HR * HC;                         // halo pixels, one 144-byte LDS row each (128 data + 16 pad)
@@ -503,6 +507,11 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
     for (int pi = 0; pi < 2; ++pi) bbase[pi] = (u32)(H_OFF + ((2 * rp + pi) * HC + col) * 144 + khalf * 16);
     // output: byte offset of the lane's pixel (pooled form: its pooled pixel) from the tile origin, + its 16-byte column of a 32-byte pair (c64_store_runs)
     u32 ylane[2];
+    [[maybe_unused]] u32 yfull[2] = {0u, 0u};
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) yfull[pi] = (u32)((((2 * rp + pi) * p.W + col) * p.Cout) * 2 + khalf * 16);
+    }
     if constexpr (POOL) {
         ylane[0] = ylane[1] = (u32)(((rp * p.Wo + (col >> 1)) * p.Cout) * 2 + khalf * 16);
     } else {
@@ -606,6 +615,23 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
             asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
         } else
         if constexpr (POOL) {
+            if constexpr (KEEP) {                         // the un-pooled form's stores (below), into y2
+                const size_t img2 = (size_t)p.H * p.W * p.Cout * 2;
+                const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y2) + (size_t)b * img2, 0, (int)img2, 0x00020000);
+                const u32 sbase2 = (u32)(((h0 * p.W + w0) * p.Cout + co0 + wc * 32) * 2);
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) {
+                    const bool ok = ((h0 + 2 * rp + pi) < p.H) & ((w0 + col) < p.W);
+                    const u32 voff2 = yfull[pi] | (ok ? 0u : OOB);
+                    u32 lo[4], hi[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        lo[g] = c64_pkmax_i16(c64_pack2(acc[pi][4 * g] + bv[4 * g], acc[pi][4 * g + 1] + bv[4 * g + 1]), floor16);
+                        hi[g] = c64_pkmax_i16(c64_pack2(acc[pi][4 * g + 2] + bv[4 * g + 2], acc[pi][4 * g + 3] + bv[4 * g + 3]), floor16);
+                    }
+                    c64_store_runs(lo, hi, ry2, voff2, sbase2);
+                }
+            }
             const size_t img = (size_t)p.Ho * p.Wo * p.Cout * 2;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.y) + (size_t)b * img, 0, (int)img, 0x00020000);
             const u32 sbase = (u32)((((h0 >> 1) * p.Wo + (w0 >> 1)) * p.Cout + co0 + wc * 32) * 2);
@@ -667,11 +693,11 @@ __device__ __forceinline__ void conv64_body(const C64Params& p, unsigned char* l
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int CS, bool POOL, int NB, bool FRONT = false, bool WREG = false>
+template <int CS, bool POOL, int NB, bool FRONT = false, bool WREG = false, bool KEEP = false>
 __global__ __launch_bounds__(FRONT ? C64_FRONT_THREADS : C64_THREADS, 1) void conv64_kernel(C64Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[c64_lds_bytes(CS, NB, FRONT, WREG)];
-    conv64_body<CS, POOL, NB, FRONT, WREG>(p, lds);
+    conv64_body<CS, POOL, NB, FRONT, WREG, KEEP>(p, lds);
 #endif
 }
 
@@ -681,11 +707,12 @@ using namespace ssdhip;
 
 // pool != 0: MaxPooling2D(2, 2, 'same') fused; y is [B, ceil(H/2), ceil(W/2), Cout].  n_workgroups: persistent workgroups to
 // launch (the caller passes the CU count; 0 = 256).
-extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
-                                            int Cin, int Cout, int relu, int pool, int n_workgroups, void* stream_) {
+static int c64_launch(const void* x, const void* weight, const void* bias, void* y, void* y2, int B, int H, int W, int Cin, int Cout, int relu,
+                      int pool, int n_workgroups, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !y || B <= 0 || H <= 0 || W <= 0 || Cin != 64 || Cout <= 0 || (Cout % 64)) return SSDHIP_E_BADARG;
-    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)y2) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    if (y2 && !pool) return SSDHIP_E_BADARG;
     const long long xb = (long long)B * H * W * 128, wb = (long long)Cout * 1152;
     if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || (long long)B * H * W * Cout > 0x7fffffff0LL) return SSDHIP_E_BADARG;
     C64Params p;
@@ -695,6 +722,7 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb;
     p.x3 = nullptr; p.w1 = nullptr; p.b1 = nullptr;
+    p.y2 = static_cast<bf16_t*>(y2);
     { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 1; }   // multipliers first; equal within the spread since WREG (profiles/r03zd_*)
     p.n_slices = Cout / 64;
     int cs_best = 4;
@@ -718,13 +746,30 @@ extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, c
     static const bool wreg = []() { const char* e = getenv("SSDHIP_C64_WREG"); return e ? atoi(e) != 0 : true; }();
 #define C64_LAUNCH(CS_, POOL_) do { if (wreg) hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3, false, true>), dim3(G), dim3(C64_THREADS), 0, stream, p); \
                                     else hipLaunchKernelGGL((conv64_kernel<CS_, POOL_, 3>), dim3(G), dim3(C64_THREADS), 0, stream, p); } while (0)
-    if (pool) {
+    if (pool && y2) {                                    // KEEP: filters in registers only
+        if (cs_best == 3) hipLaunchKernelGGL((conv64_kernel<3, true, 3, false, true, true>), dim3(G), dim3(C64_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((conv64_kernel<4, true, 3, false, true, true>), dim3(G), dim3(C64_THREADS), 0, stream, p);
+    } else if (pool) {
         if (cs_best == 3) C64_LAUNCH(3, true); else C64_LAUNCH(4, true);
     } else {
         if (cs_best == 3) C64_LAUNCH(3, false); else C64_LAUNCH(4, false);
     }
 #undef C64_LAUNCH
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+extern "C" int ssdhip_conv3x3_c64_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
+                                            int Cin, int Cout, int relu, int pool, int n_workgroups, void* stream) {
+    return c64_launch(x, weight, bias, y, nullptr, B, H, W, Cin, Cout, relu, pool, n_workgroups, stream);
+}
+
+// Conv2D(relu) -> MaxPooling2D(2, 2, 'same') of the TRAINING step in one launch (round 6): y_pooled [B, ceil(H/2), ceil(W/2), Cout] as with
+// pool != 0 above AND y_full [B, H, W, Cout], the activation the backward pass needs -- bit-identical to the un-pooled launch followed by
+// ssdhip_bias_act_maxpool, without reading the full map back.
+extern "C" int ssdhip_conv3x3_c64_pool_keep_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y_full, void* y_pooled, int B,
+                                                      int H, int W, int Cin, int Cout, int relu, int n_workgroups, void* stream) {
+    if (!y_full) return SSDHIP_E_BADARG;
+    return c64_launch(x, weight, bias, y_pooled, y_full, B, H, W, Cin, Cout, relu, 1, n_workgroups, stream);
 }
 
 // conv1_1 -> conv1_2 [-> pool1] as ONE kernel (models/keras_ssd300.py:274-276, keras_ssd512.py twin): x3 [B, H, W, 3] bf16 (the
@@ -743,6 +788,7 @@ extern "C" int ssdhip_conv1_block_nhwc_bf16(const void* x3, const void* w1, cons
     p.x = nullptr; p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
     p.y = static_cast<bf16_t*>(y);
     p.x3 = static_cast<const bf16_t*>(x3); p.w1 = static_cast<const bf16_t*>(w1); p.b1 = static_cast<const bf16_t*>(b1);
+    p.y2 = nullptr;
     { const char* e = getenv("SSDHIP_C64_PRIO"); p.prio = e ? atoi(e) : 3; }   // bit 0: multipliers above the producers (equal since WREG, profiles/r03zd_*); bit 1: the producers' own MFMAs above everything
     p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu ? 1 : 0;
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;

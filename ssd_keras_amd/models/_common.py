@@ -229,8 +229,15 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             bb = bias.detach().to(torch.bfloat16) if bias is not None else None
-        y = run(xb, wb, bb)
-        p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
+        import os
+        if (xb.shape[1] == 64 and wb.shape[2:] == (3, 3) and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1)
+                and wb.shape[0] % 64 == 0 and xb.is_cuda and os.environ.get("SSDHIP_NO_POOL_KEEP", "0") != "1"):
+            # round 6: conv1_2 -> pool1 as ONE launch that writes the activation AND the pooled map (csrc/ssdhip_conv64.hip, KEEP): the
+            # pooling pass read the 368 MB map back (~95 us of the step)
+            y, p = nat.conv3x3_c64_pool_keep(xb, wb, bb, relu=True)
+        else:
+            y = run(xb, wb, bb)
+            p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
         ctx.save_for_backward(xb, wb, y, wt)
         ctx.conf = (stride, padding, dilation, weight.dtype, None if bias is None else bias.dtype, x.dtype)
         return p

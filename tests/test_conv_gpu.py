@@ -250,6 +250,9 @@ def test_resident_weight_conv_c64(case):
             wantp = nat.bias_act_maxpool(want, None, 2, 2, 0, True, relu=False)
             assert gotp.shape == wantp.shape
             assert torch.equal(gotp, wantp), "%d of %d pooled outputs differ" % (int((gotp != wantp).sum()), gotp.numel())
+            # round 6, the training step's form: ONE launch writes the activation and the pooled map
+            full, pooled = nat.conv3x3_c64_pool_keep(x, wt, b_, relu=relu)
+            assert torch.equal(full, want) and torch.equal(pooled, wantp)
     ref = torch.relu(F.conv2d(x.float(), wt.float(), bias.float(), 1, 1))
     got = nat.conv3x3_c64(x, wt, bias, relu=True, pool=False).float()
     rms = ref.pow(2).mean().sqrt().item()
