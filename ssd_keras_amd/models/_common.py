@@ -82,8 +82,10 @@ def resolve_anchor_config(n_predictor_layers, min_scale, max_scale, scales, aspe
 
 class _ConvBiasActFn(torch.autograd.Function):
     """A convolution layer of the TRAINING step with libssdhip's MFMA kernel in the forward pass (convolution + bias + ReLU, one
-    kernel, bf16 NHWC -- the same kernels the inference path runs) and PyTorch-ROCm's convolution backward (MIOpen data / weight
-    gradient kernels) behind it.  `run` is the libssdhip thunk picked for this layer shape: (x_bf16, w_bf16, b_bf16) -> y."""
+    kernel, bf16 NHWC -- the same kernels the inference path runs) and libssdhip's data / weight gradients behind it
+    (`_conv_input_weight_grads`: since round 6 every layer of SSD300 / SSD512 except a 4 x 4 or grouped convolution; the framework's
+    convolution_backward is the fallback for what the kernels do not cover).  `run` is the libssdhip thunk picked for this layer
+    shape: (x_bf16, w_bf16, b_bf16) -> y."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu, wb=None, bb=None, wt=None):
@@ -132,10 +134,12 @@ class _ConvBiasActFn(torch.autograd.Function):
 
 
 def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=None, bias_partial=None):
-    """dL/dx, dL/dw [and dL/db] of a convolution from the (masked) dL/dy: the data gradient of a stride-1 'same' layer through the
-    forward's MFMA kernel, the rest through aten.convolution_backward (MIOpen).  bias_partial: per-workgroup channel sums of gy
-    ([rows, Cout] float32); the third result is their ordered sum when the weight gradient's reduction launch could add them on the
-    side, None otherwise (the caller reduces them itself)."""
+    """dL/dx, dL/dw [and dL/db] of a convolution from the (masked) dL/dy.  Data gradient: a stride-1 'same' layer through the forward's
+    MFMA kernel on the transposed, tap-flipped filters; a strided or 'valid' 3 x 3 layer the same way behind an embedding launch (round
+    6).  Weight gradient: the position-grid kernel (3 x 3 'same', incl. fc6's dilation 6), the pixel GEMM (1 x 1), the tap-gathered pixel
+    GEMM (any other 3 x 3) -- csrc/ssdhip_wgrad.hip.  What none of them covers goes to aten.convolution_backward (MIOpen).
+    bias_partial: per-workgroup channel sums of gy ([rows, Cout] float32); the third result is their ordered sum when the weight
+    gradient's reduction launch could add them on the side, None otherwise (the caller reduces them itself)."""
     gx = None
     k = wb.shape[2]
     same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
@@ -219,7 +223,7 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
 
 class _ConvBiasActPoolFn(torch.autograd.Function):
     """Conv2D(relu) -> MaxPooling2D(2, 2, 'same') of the TRAINING step (pool1 .. pool3) as one autograd node: forward = the layer's
-    MFMA kernel + the one-pass pooling kernel; backward = max-pool gradient, ReLU mask and bias gradient in ONE pass over the
+    MFMA kernel + the one-pass pooling kernel (conv1_2 -> pool1: ONE launch that writes both maps, round 6); backward = max-pool gradient, ReLU mask and bias gradient in ONE pass over the
     full-resolution map (csrc/ssdhip_train.hip, maxpool2_relu_bwd_bias_kernel) -- the unmasked full-resolution gradient is never
     written -- then the convolution's gradients as in _ConvBiasActFn."""
 
