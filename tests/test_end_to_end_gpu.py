@@ -280,3 +280,4 @@ def test_graph_replay_follows_in_place_weight_updates():
             getattr(model, name).weight.mul_(-1.0)
         model.conv4_3_norm.gamma.add_(1.0)
         assert torch.equal(runner(images), model(images))
+
