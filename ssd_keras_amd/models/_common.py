@@ -367,6 +367,9 @@ class GraphedInference:
                 self.static_out = model(self.static_in)
         finally:
             model.__dict__["_head_overlap"] = had
+        # (see __call__: an OLDER graph of a model must not be replayed on a foreign stream once a newer one exists)
+        self._epoch = model.__dict__.get("_graph_epoch", 0) + 1
+        model.__dict__["_graph_epoch"] = self._epoch
 
         # What the recorded kernels read besides `static_in`: the parameters' own storage (in-place updates -- optimizer steps,
         # load_state_dict, load_keras_weights -- are seen by the next replay) and the PACKED head filters, separate tensors built from
@@ -389,6 +392,17 @@ class GraphedInference:
         if key != self._derived_key:
             self.model._refresh_derived_weights()
             self._derived_key = key
+        cur = torch.cuda.current_stream(self.static_in.device)
+        if self.model.__dict__.get("_graph_epoch", 0) != self._epoch and cur.cuda_stream != self.stream.cuda_stream:
+            # Another graph of this model was captured after this one.  On ROCm 7.2 replaying the OLDER of two such graphs on a stream
+            # other than its capture stream segfaults inside hipGraphLaunch (tools/debug_two_graphs.py: 2 graphs + foreign stream
+            # crashes, 1 graph or the capture stream does not; profiles/r06zq_two_steps_in_flight_negative.txt) -- so it is replayed
+            # on its capture stream, ordered behind and in front of the caller's stream.
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+            cur.wait_stream(self.stream)
+            return self.static_out
         self.graph.replay()
         return self.static_out
 

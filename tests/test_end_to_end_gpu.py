@@ -281,3 +281,16 @@ def test_graph_replay_follows_in_place_weight_updates():
         model.conv4_3_norm.gamma.add_(1.0)
         assert torch.equal(runner(images), model(images))
 
+
+
+def test_an_older_graph_of_a_model_survives_a_foreign_stream():
+    """models/_common.py, GraphedInference.__call__: two graphs captured from one model, the OLDER one replayed on a stream that is not
+    its capture stream -- hipGraphLaunch segfaults on that on ROCm 7.2 (tools/debug_two_graphs.py raw), so such a replay goes through the
+    capture stream.  In a subprocess: a crash must fail this test, not end the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_two_graphs.py"), "guarded"], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "OK guarded" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
