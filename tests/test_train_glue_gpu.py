@@ -292,3 +292,47 @@ def test_training_assembly_node_equals_the_framework_expression(C):
         assert bool((a[:, nb * (C + 4):] == 0).all())
         err = (a.float() - b_.float()).abs()
         assert bool((err <= 2.0 ** -7 * b_.float().abs() + 1e-6).all()), float(err.max())
+
+
+@pytest.mark.parametrize("which", ["ssd300_80_classes", "ssd512_coco"])
+def test_training_step_of_the_other_builders_runs_on_the_own_backward_kernels(which):
+    """models/_common.py, _conv_input_weight_grads (round 6): two training steps (HIP encoder, HIP SSDLoss, bf16 autocast) of SSD300 with
+    80 classes and of SSD512 -- finite losses and gradients, and aten.convolution_backward only where no kernel applies (SSD300:
+    nowhere; SSD512: its 4 x 4 conv10_2 and the two layers around it)."""
+    import torch
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.keras_loss_function.keras_ssd_loss import SSDLoss
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    from ssd_keras_amd.models.keras_ssd512 import ssd_512
+    from ssd_keras_amd.ssd_encoder_decoder.ssd_input_encoder import SSDInputEncoder
+    torch.manual_seed(1)
+    if which == "ssd512_coco":
+        cfg, size, allowed = syn.SSD512_COCO, 512, 3
+        model = ssd_512((512, 512, 3), cfg["n_classes"], mode="training", l2_regularization=0.0005, scales=cfg["scales"],
+                        aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"])
+    else:
+        cfg, size, allowed = dict(syn.SSD300_VOC, n_classes=80), 300, 0
+        model = ssd_300((300, 300, 3), 80, mode="training", l2_regularization=0.0005, scales=cfg["scales"],
+                        aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"])
+    model = model.cuda().to(memory_format=torch.channels_last).train()
+    B = 2
+    enc = SSDInputEncoder(matching_type='multi', pos_iou_threshold=0.5, neg_iou_limit=0.5, **cfg)
+    gt = syn.make_ground_truth(B, cfg["n_classes"], size, size, max_boxes=6, seed=3)
+    images = torch.from_numpy(np.random.RandomState(1).randint(0, 256, size=(B, size, size, 3)).astype(np.float32)).cuda()
+    lf = SSDLoss(neg_pos_ratio=3, n_neg_min=0, alpha=1.0)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-9, momentum=0.9)
+    losses, calls = [], []
+    for _ in range(2):
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            y_true, _, _ = enc.encode_to_device(gt, device=images.device)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y_pred = model(images)
+            loss = lf.compute_loss(y_true, y_pred.float()).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        losses.append(float(loss.detach()))
+        calls.append(sum(e.count for e in prof.key_averages() if "convolution_backward" in e.key))
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    assert np.isfinite(losses).all() and losses[1] != losses[0]
+    assert max(calls) <= allowed, calls
