@@ -425,8 +425,8 @@ def test_training_assembly_gate_is_the_kernels_lds_formula():
 def test_keras_h5_weight_files_without_h5py(tmp_path):
     """SURVEY 8f row 2 / VERDICT r5 item 9: a Keras `.h5` weight file read WITHOUT an HDF5 library (models/hdf5_lite.py: superblock 0,
     symbol-table groups under version-1 B-trees, local heaps, version-1 object headers with fixed-string attributes, contiguous
-    datasets -- what h5py's default libver writes for `model.save_weights`).  No HDF5 library and no real Keras file exist here, so this
-    is SELF-CONSISTENCY: (a) the writer's bytes carry the structures of the published format at their documented offsets; (b) an SSD300's
+    datasets -- what h5py's default libver writes for `model.save_weights`).  This test is the SELF-CONSISTENCY half (the real HDF5
+    library's files and the library reading the writer's: tests/test_h5_real_library_cpu.py): (a) the writer's bytes carry the structures of the published format at their documented offsets; (b) an SSD300's
     weighted layers go file -> fresh model bit for bit, with the library-default node size (several symbol table nodes, a B-tree
     over them) and through `model.save()`'s `model_weights` sub-group; (c) reader paths the writer does not produce: big-endian data,
     a version-3 attribute message, 80 links under a two-level B-tree, a continuation block."""
