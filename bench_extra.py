@@ -340,6 +340,8 @@ def fp32x3_forward_leg(dev, B, fp32_leg=None, reps=3):
             runner = model.graphed(images)
             out_g = runner(images).clone()
             out_e = pf(images, decode=True)
+            for _ in range(8):                                                # untimed: the clock ramp behind the capture (bench.py --graph-warmup)
+                runner(images)
             graph_ms = _events_ms(lambda: runner(images), max(reps, 10))
             graph_info = {"graph_step_ms": round(graph_ms, 3), "graph_output_equals_eager": bool(torch.equal(out_g, out_e)),
                           "eager_step_ms": round(step_ms, 3)}
@@ -558,7 +560,7 @@ def train_leg(dev, rank, world, B, steps=6, warmup=3, tame=True):
         if world == 1 and os.environ.get("SSD_TRAIN_GRAPH", "1" if safe_graph else "0") == "1":
             try:
                 capture()
-                for _ in range(2):
+                for _ in range(int(os.environ.get("SSD_TRAIN_GRAPH_WARMUP", "6"))):      # untimed replays: the clock ramp behind the capture (2 in rounds 3-6)
                     graph_step()
                 torch.cuda.synchronize()
                 run, how = graph_step, ("ONE hipGraph replay per step (forward + SSDLoss + backward + SGD captured once); the encoder eager"
