@@ -346,9 +346,10 @@ class GraphedInference:
     predictor heads exist before anything is recorded (allocations, host -> device copies and timing syncs are illegal inside a
     capture).  Inference only (no_grad)."""
 
-    def __init__(self, model, images, warmup=3):
+    def __init__(self, model, images, warmup=3, fn=None):
         if not images.is_cuda:
             raise ValueError("HIP graphs need a CUDA/HIP tensor")
+        run = fn if fn is not None else model            # fn: another callable of the model on the same input (model.head_outputs)
         self.model = model
         self.static_in = images
         dev = images.device
@@ -359,12 +360,12 @@ class GraphedInference:
         try:
             with torch.cuda.stream(self.stream), torch.no_grad():
                 for _ in range(max(1, warmup)):
-                    model(self.static_in)
+                    run(self.static_in)
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
-                self.static_out = model(self.static_in)
+                self.static_out = run(self.static_in)
         finally:
             model.__dict__["_head_overlap"] = had
         # (see __call__: an OLDER graph of a model must not be replayed on a foreign stream once a newer one exists)
@@ -1258,11 +1259,33 @@ class SSDModel(nn.Module):
     def forward(self, images):
         return self.raw_predictions(images, decode=self.decoder is not None)
 
-    def graphed(self, images, warmup=3):
+    def head_outputs(self, images):
+        """The convolution stack alone: the in-graph input pipeline, every trunk / extra layer and the packed predictor heads -- what
+        `forward` runs in front of DecodeDetections (or of the prediction assembly), nothing behind it.  Returns the list of packed
+        head maps (one per source map, conf | loc channels).  bench.py times a HIP graph of it for `conv_roofline.forward_ms`."""
+        if torch.is_grad_enabled():
+            raise RuntimeError("head_outputs is an inference-path probe: call it under torch.no_grad()")
+        self.__dict__["_shadow_fresh"] = False
+        self.__dict__["_in_forward"] = True
+        had = self.__dict__.get("_head_overlap")
+        if not had:
+            self.__dict__["_head_overlap"] = "4"           # outside a graph capture too: the graph step's two-stream schedule
+        try:
+            x = self.preprocess(images)
+            split = self._split_heads(x.to(next(self.parameters()).dtype))
+            if split is None:
+                raise RuntimeError("head_outputs: this model / input does not take the fused inference path")
+            return list(split[1])
+        finally:
+            self.__dict__["_head_overlap"] = had
+            self.__dict__["_in_forward"] = False
+
+    def graphed(self, images, warmup=3, heads_only=False):
         """`forward` for inputs of this shape captured ONCE into a HIP graph: a step is then a single graph launch instead of ~45
         kernel launches issued from Python (the step is 3 ms of GPU work; on a slow or busy host the eager launches alone can take
-        longer).  Returns a callable; see GraphedInference."""
-        return GraphedInference(self, images, warmup)
+        longer).  Returns a callable; see GraphedInference.  `heads_only`: the graph of `head_outputs` (the convolution stack with the
+        same two-stream schedule, no decode)."""
+        return GraphedInference(self, images, warmup, fn=self.head_outputs if heads_only else None)
 
     predict = forward
 

@@ -237,6 +237,46 @@ def test_graphed_step_and_two_stream_heads_equal_the_plain_step():
     assert int((plain_a[:, :, 0] > 0).sum()) > 0                 # the comparison is not between two empty outputs
 
 
+def test_head_outputs_graph_is_the_steps_convolution_stack():
+    """bench.py's `conv_roofline.forward_ms` is a HIP graph of `model.head_outputs` (the convolution stack of the step: input Lambdas,
+    trunk, extra layers, packed predictor heads on the step's two streams -- no decode): its head maps must be the ones the step
+    decodes.  Eager == graph bit for bit, DecodeDetections from the graph's head maps == `model(images)`, a second input through the
+    captured graph, and the step graph captured BEFORE it still replays (older-graph guard)."""
+    import torch
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(11)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="inference", scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"],
+                    confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400).cuda()
+    model = model.to(memory_format=torch.channels_last).eval().to(torch.bfloat16)
+    rs = np.random.RandomState(4)
+    img_a = torch.from_numpy(rs.randint(0, 256, size=(8, 300, 300, 3)).astype(np.float32)).cuda()
+    img_b = torch.from_numpy(rs.randint(0, 256, size=(8, 300, 300, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        want_a, want_b = model(img_a).clone(), model(img_b).clone()
+        step = model.graphed(img_a.clone())
+        heads_a = [h.clone() for h in model.head_outputs(img_a)]
+        assert len(heads_a) == 6 and all(h.dtype == torch.bfloat16 for h in heads_a)
+        runner = model.graphed(img_a.clone(), heads_only=True)
+        sizes = [(h.shape[2], h.shape[3]) for h in heads_a]
+        assert sizes == [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1)]
+        anchors = model.anchors_and_variances(sizes, img_a.device)
+        args = ([None] * 6, [ch.bias for ch in model.conf_heads], [lh.bias for lh in model.loc_heads],
+                [pb.n_boxes for pb in model.priorboxes], anchors, model.n_classes)
+        with torch.cuda.stream(runner.stream):
+            got = runner(img_a)
+            assert all(torch.equal(x, y) for x, y in zip(got, heads_a))
+            assert torch.equal(model.decoder.forward_from_heads(list(got), *args), want_a)
+            got_b = runner(img_b)
+            assert torch.equal(model.decoder.forward_from_heads(list(got_b), *args), want_b)
+        torch.cuda.synchronize()
+        assert torch.equal(step(img_a), want_a)                   # the older graph, through its capture stream
+    with pytest.raises(RuntimeError, match="no_grad"):
+        model.head_outputs(img_a)
+    assert int((want_a[:, :, 0] > 0).sum()) > 0
+
+
 def test_graph_replay_follows_in_place_weight_updates():
     """tensors DERIVED from parameters (the fragment-packed conv7_1 ... conv9_2 filters of the one-launch tail, the packed
     predictor heads, the float32 copy of conv4_3_norm's gamma) are baked into a captured graph by address.  After an in-place update
