@@ -498,6 +498,14 @@ int ssdhip_conv3x3_c64_pool_keep_nhwc_bf16(const void* x, const void* weight, co
 int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int relu, int pool, void* stream);
 
+/* The tiling the two slab entries pick for a batch of H x W maps (host arithmetic, no launch): plan[0] = 0 (padded position grid:
+ * unpooled maps up to 94 wide) | 4 (16 x 16 pixel tiles) | 5 (8 x 32), plan[1] = position tiles (x Cout / 128 = tile units; one
+ * persistent workgroup per CU walks them), plan[2] = row pitch of the STACKED batch -- pooled calls lay the images on top of each
+ * other with a gap of one or two zero rows and tile the stack when that needs fewer tiles than tiling every image (SSD300's conv3_3 +
+ * pool3 at batch 32: 760 instead of 800, six rounds of 256 CUs instead of seven) -- or 0, plan[3] = rows of tiles.  The results do
+ * not depend on the tiling (same accumulation order per output). */
+int ssdhip_conv3x3_halo_plan(int B, int H, int W, int pool, int* plan);
+
 /* A chain of small convolutions (+ bias + ReLU) in ONE launch, one workgroup per image, the intermediate maps in LDS: the tail of the SSD
  * extra layers conv7_1 ... conv9_2 (models/keras_ssd300.py:304-313).  x [B, H, W, C0] bf16 NHWC; layer i: k_i x k_i, stride_i, zero padding
  * pad_i, Cout_i, bias_i (bf16 or NULL), ReLU if relu_i != 0; y_h[i] != NULL: that layer's map is also written to y_h[i]

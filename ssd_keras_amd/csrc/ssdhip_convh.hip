@@ -88,6 +88,14 @@ struct ConvHParams {
     int xC, nx;
     const float* bias32;
     float oscale;
+    // 2-D tiles over the STACKED batch (round 6, fourth session; Hp > 0, pooled forms): the images are laid on top of each other at a
+    // pitch of Hp rows (even, >= H + 1: at least one row of zeros between two images, row pairs aligned with every image's first row)
+    // and the tile rows walk the stack -- HT = ceil(nB Hp / TR) rows of tiles for the whole batch instead of ceil(H / TR) per image.
+    // Row R of the stack is row R - b Hp of image b = R / Hp = umulhi(R, hp_magic); rows H .. Hp - 1 of an image read zeros and store
+    // nothing.  SSD300's conv3_3 + pool3 (75 x 75, 16 x 16 tiles): 152 x 5 = 760 position tiles instead of 32 x 25 = 800, i.e. 1 520
+    // tile-units = six rounds of 256 CUs where 1 600 needed a seventh.  Same accumulation order per output: bit-identical results.
+    int Hp = 0, nB = 0;
+    unsigned hp_magic = 0;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -149,9 +157,10 @@ __device__ __forceinline__ u32 ch_split2(float a, float b, u32& lo_out) {       
 // each 64 channels x 128 positions, ONE wave per SIMD with the 512-register budget) reads 24 fragments for 32 MFMAs per K-step
 // instead of 2 x 16 for 2 x 16: a quarter less LDS read traffic per FLOP, and no second wave competing for the SIMD's matrix pipe.
 // Same tile, same LDS image, same requests (each wave issues twice the pieces), same accumulation order: bit-identical results.
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8, bool STK = false>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
+    static_assert(!STK || (POOL && !((MODE & 16384) != 0 && !X3)), "stacked-batch tiles: the staged pooled epilogues");
     static_assert(NWV == 8 || (NWV == 4 && !X3), "8 waves, or 4 (bf16 forms only)");
     constexpr int NPI = 16 / NWV;                        // 32-position blocks per wave: 2 | 4
     constexpr int WPK = 8 / NWV;                         // 1 KiB request pieces a wave issues per 64-row chunk: 1 | 2
@@ -218,12 +227,27 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
     // slab row r <-> position q0 - (W + 2) + r; piece (k, wave) = rows 64 k + 8 wave .. + 7, lane -> row (lane >> 3), chunk slot
     // (lane & 7) holding source chunk (lane & 7) ^ ((row >> 1) & 7)
     const int SP = G2 ? (TR + 2) * SC2 : CH_BN + 2 * W + 4;   // slab rows a tile reads
+    // STK: the tile's first row of the stack is row h0 of image b; a row h0 + d (d <= TR + 1 <= Hp) of the tile belongs to image b
+    // (+ 1 once it reaches Hp: stack_row).  Row -1 of an image is the last row of the gap above it: zeros, like the top of image 0.
     auto tile_origin = [&](const int qt, int& b, int& h0, int& w0) {       // 2-D
         const int wt = qt % p.WT, r = qt / p.WT;
-        b = r / p.HT;
-        h0 = (r - b * p.HT) * TR;
+        if constexpr (STK) {
+            b = (int)__umulhi((u32)(r * TR), p.hp_magic);
+            h0 = r * TR - b * p.Hp;
+        } else {
+            b = r / p.HT;
+            h0 = (r - b * p.HT) * TR;
+        }
         w0 = wt * TC;
     };
+    auto stack_row = [&](int& b, int& hh) {
+        if constexpr (STK) {
+            const bool wrap = hh >= p.Hp;
+            hh -= wrap ? p.Hp : 0;
+            b += wrap ? 1 : 0;
+        }
+    };
+    [[maybe_unused]] const int stackB = STK ? p.nB : 0x7fffffff;
     // request piece idx = k WPK + u of a wave: slab rows (64 / WPK) idx + 8 wave .. + 7
     constexpr int NXO = SPW * WPK, XSTEP = 64 / WPK;
     u32 xoff[NXO];
@@ -238,9 +262,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 const int row = row0 + XSTEP * k;
                 const int j = (lane & 7) ^ ((row >> 1) & 7);
                 const int sr = row / SC2, sc = row - sr * SC2;
-                const int hh = h0 - 1 + sr, ww = w0 - 1 + sc;
-                const bool ok = row < SP && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-                xoff[k] = ok ? (u32)(((b * H + hh) * W + ww) * (XC * 2) + j * 16) : OOB;
+                int bb = b, hh = h0 - 1 + sr;
+                const int ww = w0 - 1 + sc;
+                stack_row(bb, hh);
+                const bool ok = row < SP && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W && (!STK || bb < stackB);
+                xoff[k] = ok ? (u32)(((bb * H + hh) * W + ww) * (XC * 2) + j * 16) : OOB;
             }
             return;
         }
@@ -566,11 +592,13 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             int b, h0, w0;
             tile_origin(q0, b, h0, w0);
             const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
-            const int ho = (h0 >> 1) + pair, wo = (w0 + col) >> 1;
+            int hr = h0 + 2 * pair;                       // the pair's first row (stacked batch: of its image b)
+            stack_row(b, hr);
+            const int ho = hr >> 1, wo = (w0 + col) >> 1;
             const bool okp = (!(r31 & 1)) & (ho < p.Ho) & (wo < p.Wo);
             const u32 off = (((u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64)) * 2u + (u32)khalf * 16u) | (okp ? 0u : OOB);
-            const u32 mrow1 = h0 + 2 * pair + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
-            const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
+            const u32 mrow1 = hr + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
+            const bool has_below = hr + 1 < H, has_right = w0 + col + 1 < W;
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci) {
                 u32 lo[4], hi[4];
@@ -614,8 +642,10 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             const int slot2p = slot2 + ph * 32;
             const int pair = slot2p >> CSH, col = slot2p & (TC - 1);
             unsigned char* pstage = stage + ph * 2048;
+            int hr = h0 + 2 * pair, bp = b;               // the pair's first row (stacked batch: of its image bp)
+            stack_row(bp, hr);
             if (p.relu) {
-                const u32 mrow1 = h0 + 2 * pair + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
+                const u32 mrow1 = hr + 1 < H ? 0xffffffffu : 0u, mcol = w0 + col < W ? 0xffffffffu : 0u;
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -632,7 +662,7 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         }
                     }
             } else {
-                const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
+                const bool has_below = hr + 1 < H, has_right = w0 + col + 1 < W;
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -662,9 +692,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             for (int j = 0; j < 2; ++j) {
                 const int idx = j * 64 + lane, px = idx >> 3, c = idx & 7;     // 16 pooled pixels x 8 chunks
                 const int se = wn * (16 * NPI) + ph * 32 + 2 * px;              // the even lane's slot
-                const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
+                int hs = h0 + 2 * (se >> CSH), bs = b;
+                stack_row(bs, hs);
+                const int ho = hs >> 1, wo = (w0 + (se & (TC - 1))) >> 1;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + ph * 2048 + px * 128 + ((c ^ (px & 7)) << 4));
-                store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64 + c * 8));
+                store16(v, ho < p.Ho && wo < p.Wo && (!STK || bs < stackB), (u32)((bs * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if constexpr (DIRECT) {
@@ -796,7 +828,9 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             int b, h0, w0;
             tile_origin(q0, b, h0, w0);
             const int pair = slot2 >> CSH, col = slot2 & (TC - 1);
-            const bool has_below = h0 + 2 * pair + 1 < H, has_right = w0 + col + 1 < W;
+            int hr = h0 + 2 * pair, bp = b;               // the pair's first row (stacked batch: of its image bp)
+            stack_row(bp, hr);
+            const bool has_below = hr + 1 < H, has_right = w0 + col + 1 < W;
 #pragma unroll
             for (int part = 0; part < (X3 ? 2 : 1); ++part) {             // X3: the hi parts, then the lo parts
 #pragma unroll
@@ -834,9 +868,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             for (int j = 0; j < 2; ++j) {
                 const int idx = j * 64 + lane, px = idx >> 3, c = idx & 7;     // 16 pooled pixels x 8 chunks
                 const int se = wn * 32 + 2 * px;                                // the even lane's slot
-                const int ho = (h0 >> 1) + (se >> CSH), wo = (w0 + (se & (TC - 1))) >> 1;
+                int hs = h0 + 2 * (se >> CSH), bs = b;
+                stack_row(bs, hs);
+                const int ho = hs >> 1, wo = (w0 + (se & (TC - 1))) >> 1;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
-                store16(v, ho < p.Ho && wo < p.Wo, (u32)((b * p.Ho + ho) * p.Wo + wo) * YC + (u32)(part * p.Cout + co0 + wm * 64 + c * 8));
+                store16(v, ho < p.Ho && wo < p.Wo && (!STK || bs < stackB), (u32)((bs * p.Ho + ho) * p.Wo + wo) * YC + (u32)(part * p.Cout + co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -935,11 +971,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8, bool STK = false>
 __global__ __launch_bounds__(64 * NWV) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
+    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV, STK>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
 #endif
 }
 
@@ -973,6 +1009,8 @@ __global__ __launch_bounds__(CH_THREADS) void convh_group_kernel(ConvHGroup g) {
 #endif
 }
 
+// the schedules that exist with stacked-batch tiles (ConvHParams::Hp): the product's pooled forms -- bf16 with the tolerant waits, X3
+constexpr bool convh_has_stk(int mode, bool x3) { return x3 ? mode == 128 : mode == 1152; }
 // geom: 0 = padded position grid; 4 | 5 = 2-D tiles of 16 x 16 | 8 x 32 pixels
 template <int MODE, bool X3 = false>
 static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hipStream_t stream) {
@@ -999,9 +1037,15 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
         else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false, X3>), g, t, 0, stream, p);
     } else
     if (geom == 4) {
+        if constexpr (convh_has_stk(MODE, X3)) {
+            if (pool && p.Hp) { hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, true, X3, 8, true>), g, t, 0, stream, p); return; }
+        }
         if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, true, X3>), g, t, 0, stream, p);
         else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 4, false, X3>), g, t, 0, stream, p);
     } else if (geom == 5) {
+        if constexpr (convh_has_stk(MODE, X3)) {
+            if (pool && p.Hp) { hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, true, X3, 8, true>), g, t, 0, stream, p); return; }
+        }
         if (pool) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, true, X3>), g, t, 0, stream, p);
         else hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 5, false, X3>), g, t, 0, stream, p);
     }
@@ -1024,6 +1068,52 @@ static int convh_cu_count() {
         cu_count = (n / 8) * 8 > 0 ? (n / 8) * 8 : 8;
     }
     return cu_count;
+}
+
+// 2-D tiles: 16 x 16 or 8 x 32 pixels, per image or -- pooled forms only -- over the stacked batch (ConvHParams::Hp), whichever covers
+// the batch with the fewest tiles (ties: per image, 16 x 16 first).  SSDHIP_CONVH_STACK=0 keeps the per-image tiles (A/B runs).
+static bool convh_pick_2d(ConvHParams& p, int B, int H, int W, int pool, int& geom, bool has_stk) {
+    long long best = -1;
+    p.Hp = 0; p.nB = B; p.hp_magic = 0;
+    for (int csh = 4; csh <= 5; ++csh) {
+        const long long wt = (W + (1 << csh) - 1) >> csh, ht = (H + (256 >> csh) - 1) / (256 >> csh);
+        if (best < 0 || (long long)B * wt * ht < best) { best = (long long)B * wt * ht; geom = csh; p.WT = (int)wt; p.HT = (int)ht; }
+    }
+    const char* e = getenv("SSDHIP_CONVH_STACK");
+    if (pool && has_stk && !(e && atoi(e) == 0)) {
+        const long long hp = H + 1 + ((H + 1) & 1);      // even, >= H + 1
+        for (int csh = 4; csh <= 5; ++csh) {
+            const long long tr = 256 >> csh, wt = (W + (1 << csh) - 1) >> csh, ht = ((long long)B * hp + tr - 1) / tr;
+            // umulhi(R, floor(2^32 / hp) + 1) == R / hp for every row R the kernel asks about (R < (ht + 1) tr) while R hp < 2^32
+            if (wt * ht < best && (ht + 1) * tr * hp < 0x7fffffffLL && tr + 2 <= hp) {      // (a tile's rows span at most two images)
+                best = wt * ht; geom = csh; p.WT = (int)wt; p.HT = (int)ht;
+                p.Hp = (int)hp; p.hp_magic = (unsigned)(0x100000000ULL / (unsigned long long)hp) + 1u;
+            }
+        }
+    }
+    if (best > 0x3fffff00LL) return false;
+    p.Q = 0;
+    p.q_tiles = (int)best;
+    return true;
+}
+
+// The tiling ssdhip_conv3x3_halo_nhwc_bf16 / ssdhip_conv3x3_halo_x3_nhwc_f16 pick for a (batch, map, pool) -- host arithmetic only, no
+// launch: plan[0] = 0 (padded position grid) | 4 (16 x 16 pixel tiles) | 5 (8 x 32), plan[1] = position tiles (x Cout / 128 = tile
+// units), plan[2] = the row pitch of the stacked batch (0: tiles per image), plan[3] = rows of tiles (per image, or of the stack).
+extern "C" int ssdhip_conv3x3_halo_plan(int B, int H, int W, int pool, int* plan) {
+    if (!plan || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    ConvHParams p;
+    int geom = 0;
+    if (pool || W > 94) {
+        if (!convh_pick_2d(p, B, H, W, pool, geom, true)) return SSDHIP_E_BADARG;
+    } else {
+        const long long Q = (long long)B * (H + 1) * (W + 1);
+        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+        p.HT = 0;
+    }
+    plan[0] = geom; plan[1] = p.q_tiles; plan[2] = p.Hp; plan[3] = p.HT;
+    return SSDHIP_OK;
 }
 
 // 3x3 convolution with stride 1 | 2 and zero padding 0 | 1 (torch.nn.Conv2d semantics) on a map up to 94 wide: the SSD extra layers
@@ -1131,15 +1221,7 @@ extern "C" int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight
     p.xC = 2 * C; p.nx = c64 ? 2 : C / 64; p.bias32 = bias; p.oscale = oscale;
     int geom = 0;
     if (pool || W > 94) {
-        long long best = -1;
-        for (int csh = 4; csh <= 5; ++csh) {
-            const long long wt = (W + (1 << csh) - 1) >> csh, ht = (H + (256 >> csh) - 1) / (256 >> csh);
-            if (best < 0 || wt * ht < best) { best = wt * ht; geom = csh; p.WT = (int)wt; p.HT = (int)ht; }
-        }
-        const long long tiles = (long long)B * p.HT * p.WT;
-        if (tiles > 0x3fffff00LL) return SSDHIP_E_BADARG;
-        p.Q = 0;
-        p.q_tiles = (int)tiles;
+        if (!convh_pick_2d(p, B, H, W, pool, geom, true)) return SSDHIP_E_BADARG;
     } else {
         const long long Q = (long long)B * (H + 1) * (W + 1);
         if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
@@ -1172,17 +1254,11 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
     p.HT = p.WT = 0;
     p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
+    int mode = pool ? 1152 : 128;                         // the schedule: see the switch below
+    if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     int geom = 0;
-    if (pool || W > 94) {                                 // 2-D tiles: 16 x 16 or 8 x 32 pixels, whichever pads the map less
-        long long best = -1;
-        for (int csh = 4; csh <= 5; ++csh) {
-            const long long wt = (W + (1 << csh) - 1) >> csh, ht = (H + (256 >> csh) - 1) / (256 >> csh);
-            if (best < 0 || wt * ht < best) { best = wt * ht; geom = csh; p.WT = (int)wt; p.HT = (int)ht; }
-        }
-        const long long tiles = (long long)B * p.HT * p.WT;
-        if (tiles > 0x3fffff00LL) return SSDHIP_E_BADARG;
-        p.Q = 0;
-        p.q_tiles = (int)tiles;
+    if (pool || W > 94) {
+        if (!convh_pick_2d(p, B, H, W, pool, geom, mode == 1152)) return SSDHIP_E_BADARG;
     } else {
         const long long Q = (long long)B * (H + 1) * (W + 1);
         if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
@@ -1198,8 +1274,6 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     // schedule with one workgroup per tile is gone: it bought nothing over 128 and its <3, 7> variant spilled registers.)
     // r03i / r03j / r03k A/Bs: the tolerant waits are worth 5-7 % on the pooled tiles (2 stores per wave and tile: the whole burst fits
     // the tolerance) and nothing measurable on the plain ones
-    int mode = pool ? 1152 : 128;
-    if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
 #if defined(SSDHIP_PROFILE)
     if (const char* e = getenv("SSDHIP_CONVH_WAVES")) { if (atoi(e) == 4) mode |= 4096; }
     if (const char* e = getenv("SSDHIP_CONVH_LAZY")) { if (atoi(e) == 1) mode |= 8192; }

@@ -344,6 +344,12 @@ HALO_2D_CASES = [  # B, H, W, Cin, Cout, bias, relu, pool      (2-D tiles: maps 
     (2, 9, 100, 128, 128, True, False, False),     # wide and flat, no ReLU
     (5, 2, 2, 128, 128, True, True, True),         # one pooling window per image
     (2, 16, 16, 256, 128, True, True, True),       # exactly one tile per image
+    # round 6, fourth session: pooled calls tile the STACKED batch when that takes fewer tiles (ssdhip_conv3x3_halo_plan)
+    (5, 75, 75, 128, 256, True, True, True),       # pitch 76: 24 x 5 tiles for 125; tiles straddle two images, the last row of tiles leaves the stack
+    (4, 75, 75, 256, 128, True, True, True),       # pitch 76: the stack is a whole number of tile rows
+    (6, 20, 20, 128, 128, True, True, True),       # even map: pitch 22 (two rows of zeros between images), 8 x 32 tiles
+    (5, 21, 21, 128, 128, False, False, True),     # the float pooling path (no ReLU), no bias
+    (9, 17, 40, 128, 128, True, True, True),       # pitch 18 = rows of a tile + 2: the smallest gap the stacked form takes
 ]
 
 
@@ -365,6 +371,32 @@ def test_slab_conv_2d_tiles_and_fused_pool(case, slab_mode):
     assert diff == 0, "%d of %d outputs differ from the implicit-GEMM kernel" % (diff, got.numel())
     for _ in range(8):
         assert torch.equal(nat.conv3x3_halo(x, wt, bias, relu=relu, pool=pool).view(torch.int16), got.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(32, 75, 75, 256, 256), (5, 75, 75, 128, 128), (6, 20, 20, 128, 128), (7, 33, 47, 128, 256)])
+def test_slab_conv_pool_on_the_stacked_batch_equals_tiles_per_image(shape, monkeypatch):
+    """conv3_3 -> pool3 of BASELINE configs[1] (and smaller stacks): the pooled slab kernel on tiles of the stacked batch (760 position
+    tiles at batch 32 where tiling every image takes 800) == the same kernel on tiles per image (SSDHIP_CONVH_STACK=0) == the
+    implicit-GEMM kernel, bit for bit, over repeated launches."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    B, H, W, Cin, Cout = shape
+    monkeypatch.delenv("SSDHIP_CONVH_STACK", raising=False)
+    monkeypatch.delenv("SSDHIP_CONVH_MODE", raising=False)
+    geom, tiles, pitch, rows = nat.conv3x3_halo_plan(B, H, W, True)
+    monkeypatch.setenv("SSDHIP_CONVH_STACK", "0")
+    geom0, tiles0, pitch0, _ = nat.conv3x3_halo_plan(B, H, W, True)
+    assert pitch > H and pitch % 2 == 0 and pitch0 == 0 and tiles < tiles0, "the case is meant to run on the stacked batch"
+    g = torch.Generator(device="cuda").manual_seed(B * H + W)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16)
+    per_image = nat.conv3x3_halo(x, wt, bias, relu=True, pool=True).view(torch.int16)
+    assert torch.equal(per_image, nat.conv2d_same_pool2(x, wt, bias, relu=True).view(torch.int16))
+    monkeypatch.delenv("SSDHIP_CONVH_STACK")
+    for _ in range(10):
+        got = nat.conv3x3_halo(x, wt, bias, relu=True, pool=True).view(torch.int16)
+        assert torch.equal(got, per_image), "%d of %d outputs differ" % (int((got != per_image).sum()), got.numel())
 
 
 def test_slab_conv_pool_full_batch_race_screen(slab_mode):
