@@ -506,6 +506,14 @@ int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void*
  * not depend on the tiling (same accumulation order per output). */
 int ssdhip_conv3x3_halo_plan(int B, int H, int W, int pool, int* plan);
 
+/* Training step: the data gradient of a 3x3 'same' layer whose input is the ReLU output of the layer below, with that layer's
+ * threshold_backward (keras Conv2D(activation='relu') under autodiff, models/keras_ssd300.py:279-291) in the epilogue: y = the 3x3
+ * 'same' convolution of x [B,H,W,Cin] with weight [Cout,3,3,Cin] (the transposed, tap-flipped filters; no bias, no activation) where
+ * mask [B,H,W,Cout] is > 0 or NaN, zero elsewhere.  Cin % 128 == 0, Cout % 128 == 0.  Bit-identical to ssdhip_conv3x3_halo_nhwc_bf16
+ * followed by the mask of ssdhip_relu_bwd_bias_nhwc_bf16; saves that pass's read of both maps and its write. */
+int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, const void* mask, void* y, int B, int H, int W, int Cin,
+                                         int Cout, void* stream);
+
 /* A chain of small convolutions (+ bias + ReLU) in ONE launch, one workgroup per image, the intermediate maps in LDS: the tail of the SSD
  * extra layers conv7_1 ... conv9_2 (models/keras_ssd300.py:304-313).  x [B, H, W, C0] bf16 NHWC; layer i: k_i x k_i, stride_i, zero padding
  * pad_i, Cout_i, bias_i (bf16 or NULL), ReLU if relu_i != 0; y_h[i] != NULL: that layer's map is also written to y_h[i]

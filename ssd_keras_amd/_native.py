@@ -790,6 +790,34 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
+def conv3x3_halo_masked(x, weight, mask):
+    """The 3x3 'same' convolution of x with weight (no bias, no activation) through the slab kernel, zeroed where `mask` (the output's
+    shape) is <= 0: a layer's data gradient with the threshold_backward of the ReLU layer below in the epilogue
+    (csrc/ssdhip_convh.hip, MSK).  None when the geometry is not the slab kernel's (Cin, Cout % 128)."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_halo_masked_bound", False):
+        lib.ssdhip_conv3x3_halo_masked_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_halo_masked_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        lib._halo_masked_bound = True
+    cout, cin_w, kh, kw = weight.shape
+    if (not x.is_cuda or x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or mask.dtype != torch.bfloat16 or kh != 3 or kw != 3
+            or cin_w % 128 or cout % 128 or x.shape[1] != cin_w):
+        return None
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    mask, mshape = _nhwc_bf16(mask, "mask")
+    if mshape != (b, h, w, cout):
+        raise SsdHipError("mask must have the output's shape %s, got %s" % ((b, h, w, cout), mshape))
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_halo_masked_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(mask), _ptr(y), b, h, w, cin, cout, current_stream_ptr(x.device))
+    if rc == -1:                                          # SSDHIP_E_BADARG: not the slab kernel's geometry
+        return None
+    check(rc, "ssdhip_conv3x3_halo_masked_nhwc_bf16")
+    return y
+
+
 def conv3x3_image_supported(x, weight, dilation=1):
     """Geometry of conv3x3_image: 3x3 filters, H * W <= 384 pixels, Cin % 64 == 0, Cout % 64 == 0, 1 <= dilation <= 16."""
     b, cin, h, w = x.shape

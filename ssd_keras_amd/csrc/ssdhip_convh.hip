@@ -96,6 +96,10 @@ struct ConvHParams {
     // tile-units = six rounds of 256 CUs where 1 600 needed a seventh.  Same accumulation order per output: bit-identical results.
     int Hp = 0, nB = 0;
     unsigned hp_magic = 0;
+    // MSK (training, round 6 fourth session): the data gradient of a layer whose input x is the ReLU output of the layer below leaves
+    // the kernel already masked by x > 0 -- mask = that activation, [B, H, W, Cout] like y; what threshold_backward(dL/dx, x, 0) would
+    // do in a pass of its own over both maps (csrc/ssdhip_train.hip, relu_bwd_bias_kernel)
+    const bf16_t* mask = nullptr;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -145,6 +149,13 @@ __device__ __forceinline__ i32x4 ch_rsrc(const void* base, int num_records) {
 // same column of the two rows of a row pair and lane ^ 1 is the neighbouring column, so POOL (MaxPooling2D(2, 2, 'same') fused:
 // models/keras_ssd300.py:279-283) takes the 2 x 2 maximum on the float32 accumulators in registers, as conv_igemm4_pool_kernel does.
 // SMALL: the map may be narrower than 7 pixels (the epilogue then steps its positions with a loop instead of one select).
+// threshold_backward's keep rule on two bf16 activations at once: all ones where the value is NOT <= 0 (positive, or NaN), zero elsewhere
+__device__ __forceinline__ u32 ch_keep2(u32 m) {
+    const ch_s16x2 h = __builtin_bit_cast(ch_s16x2, m);
+    const ch_s16x2 a = h & (short)0x7fff;
+    const ch_s16x2 k = (h > (short)0) | (a > (short)0x7f80);
+    return __builtin_bit_cast(u32, k);
+}
 typedef _Float16 ch_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u32 ch_split2(float a, float b, u32& lo_out) {        // two float32 -> packed float16 hi parts, lo parts
     const _Float16 ha = (_Float16)a, hb = (_Float16)b;
@@ -157,9 +168,10 @@ __device__ __forceinline__ u32 ch_split2(float a, float b, u32& lo_out) {       
 // each 64 channels x 128 positions, ONE wave per SIMD with the 512-register budget) reads 24 fragments for 32 MFMAs per K-step
 // instead of 2 x 16 for 2 x 16: a quarter less LDS read traffic per FLOP, and no second wave competing for the SIMD's matrix pipe.
 // Same tile, same LDS image, same requests (each wave issues twice the pieces), same accumulation order: bit-identical results.
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8, bool STK = false>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8, bool STK = false, bool MSK = false>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
+    static_assert(!MSK || (!POOL && !X3 && NWV == 8 && !(MODE & 16384)), "masked outputs: the staged bf16 epilogue without pooling");
     static_assert(!STK || (POOL && !((MODE & 16384) != 0 && !X3)), "stacked-batch tiles: the staged pooled epilogues");
     static_assert(NWV == 8 || (NWV == 4 && !X3), "8 waves, or 4 (bf16 forms only)");
     constexpr int NPI = 16 / NWV;                        // 32-position blocks per wave: 2 | 4
@@ -800,6 +812,16 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                         }
                 }
             }
+            // MSK: the activation at the lane's eight store addresses, requested before the packing and the LDS round trip below
+            // (an address that stores nothing reads zeros); the loads are the compiler's, it waits for them where they are used
+            [[maybe_unused]] ch_u32x4 mk[NPI][4];
+            if constexpr (MSK) {
+                const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.mask), 0, p.y_bytes, 0x00020000);
+#pragma unroll
+                for (int pi = 0; pi < NPI; ++pi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mk[pi][j] = __builtin_amdgcn_raw_buffer_load_b128(rm, soff[pi][j], 0, 0);
+            }
 #pragma unroll
             for (int pi = 0; pi < NPI; ++pi) {
 #pragma unroll
@@ -815,7 +837,12 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int px = j * 8 + (lane >> 3);                  // of this pass's 32 positions
-                    store16_at(*reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4)), soff[pi][j]);
+                    uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+                    if constexpr (MSK) {
+                        v.x &= ch_keep2(mk[pi][j][0]); v.y &= ch_keep2(mk[pi][j][1]);
+                        v.z &= ch_keep2(mk[pi][j][2]); v.w &= ch_keep2(mk[pi][j][3]);
+                    }
+                    store16_at(v, soff[pi][j]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
             }
@@ -971,11 +998,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8, bool STK = false>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8, bool STK = false, bool MSK = false>
 __global__ __launch_bounds__(64 * NWV) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV, STK>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
+    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV, STK, MSK>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
 #endif
 }
 
@@ -1054,6 +1081,18 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
     else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false, X3>), g, t, 0, stream, p);
     else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false, X3>), g, t, 0, stream, p);
     }
+}
+
+// the masked-output forms (ConvHParams::mask): persistent workgroups, no pooling
+static void convh_launch_masked(const ConvHParams& p, int geom, int n_cu, hipStream_t stream) {
+    int grid = p.total_ids;
+    if (grid > n_cu) grid = n_cu;
+    const dim3 g(grid), t(CH_THREADS);
+    if (geom == 4) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 4, false, false, 8, false, true>), g, t, 0, stream, p);
+    else if (geom == 5) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 5, false, false, 8, false, true>), g, t, 0, stream, p);
+    else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, 128, 0, false, false, 8, false, true>), g, t, 0, stream, p);
+    else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 0, false, false, 8, false, true>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((convh_kernel<3, 7, 128, 0, false, false, 8, false, true>), g, t, 0, stream, p);
 }
 
 }  // namespace ssdhip
@@ -1316,3 +1355,39 @@ extern "C" int ssdhip_profile_read_convh(unsigned long long* host_out, int reset
     return 0;
 }
 #endif
+
+// y = the 3x3 'same' convolution of x (no bias, no activation) where mask > 0 (or NaN), zero elsewhere: the data gradient of a layer
+// whose input is the ReLU output `mask` [B, H, W, Cout] of the layer below, with that layer's threshold_backward folded into the
+// epilogue (the training step: conv2_2 / conv3_2 / conv3_3 / conv4_2 / conv4_3 of models/keras_ssd300.py:279-291 towards the layer
+// under them).  Bit-identical to ssdhip_conv3x3_halo_nhwc_bf16 followed by ssdhip_relu_bwd_bias_nhwc_bf16's mask.
+extern "C" int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, const void* mask, void* y, int B, int H, int W,
+                                                    int Cin, int Cout, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !mask || !y || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)mask) & 15) return SSDHIP_E_BADARG;
+    const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, yb = (long long)B * H * W * Cout * 2;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || yb >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
+    ConvHParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
+    p.y = static_cast<bf16_t*>(y); p.mask = static_cast<const bf16_t*>(mask);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 0;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.HT = p.WT = 0;
+    p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
+    p.xC = 0; p.nx = 0; p.bias32 = nullptr; p.oscale = 1.f;
+    int geom = 0;
+    if (W > 94) {
+        if (!convh_pick_2d(p, B, H, W, 0, geom, false)) return SSDHIP_E_BADARG;
+    } else {
+        const long long Q = (long long)B * (H + 1) * (W + 1);
+        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        p.Q = (int)Q;
+        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
+    }
+    p.n_tiles = Cout / CH_BM;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)yb;
+    p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+    convh_launch_masked(p, geom, convh_cu_count(), stream);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}

@@ -80,6 +80,18 @@ def resolve_anchor_config(n_predictor_layers, min_scale, max_scale, scales, aspe
     return list(scales), ars, n_boxes, steps, offsets
 
 
+class _ReluLink:
+    """Training step, two ReLU convolutions in a row where the upper one is the lower one's ONLY consumer (conv2_1 -> conv2_2, conv3_1 ->
+    conv3_2 -> conv3_3, conv4_1 -> conv4_2 -> conv4_3): the upper layer's data gradient can leave its kernel already masked by its
+    input > 0 -- which is the lower layer's threshold_backward -- so the lower layer skips its pass over (dL/dy, y).  The link is how the
+    two autograd nodes agree: the upper node's backward sets `masked` only when its kernel really applied the mask, the lower node's
+    backward (which autograd runs after it) consumes the flag and falls back to its own mask otherwise."""
+    __slots__ = ("masked",)
+
+    def __init__(self):
+        self.masked = False
+
+
 class _ConvBiasActFn(torch.autograd.Function):
     """A convolution layer of the TRAINING step with libssdhip's MFMA kernel in the forward pass (convolution + bias + ReLU, one
     kernel, bf16 NHWC -- the same kernels the inference path runs) and libssdhip's data / weight gradients behind it
@@ -88,7 +100,7 @@ class _ConvBiasActFn(torch.autograd.Function):
     shape: (x_bf16, w_bf16, b_bf16) -> y."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu, wb=None, bb=None, wt=None):
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, relu, wb=None, bb=None, wt=None, link_in=None, link_out=None):
         xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         if wb is None:                                   # no bf16 shadow of the parameters at hand: cast here
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -98,6 +110,8 @@ class _ConvBiasActFn(torch.autograd.Function):
         #  version check covers it when the shadows are refreshed between this forward and its backward)
         ctx.save_for_backward(xb, wb, y if relu else None, wt)
         ctx.conf = (stride, padding, dilation, relu, weight.dtype, None if bias is None else bias.dtype, x.dtype)
+        # link_in: x is the ReLU output of a layer that feeds nothing else (_ReluLink); link_out: the same towards this layer's consumer
+        ctx.links = (link_in, link_out if relu else None)
         return y
 
     @staticmethod
@@ -113,33 +127,45 @@ class _ConvBiasActFn(torch.autograd.Function):
             # the first layer: no data gradient, so the masked gradient is only ever summed -- ReLU mask, bias gradient and weight gradient
             # in ONE pass that writes nothing but partial sums (csrc/ssdhip_train.hip, conv1_1_bwd_kernel)
             gw, gb = nat.conv1_1_backward(gy, y, xb)
-            return None, gw.to(wdt), (gb.to(bdt) if want_gb else None), None, None, None, None, None, None, None, None
+            return None, gw.to(wdt), (gb.to(bdt) if want_gb else None), None, None, None, None, None, None, None, None, None, None
+        link_in, link_out = ctx.links
         if relu:
-            # ReLU mask and the per-workgroup channel sums of the bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the rows
-            # are added by the weight gradient's reduction launch where that is ours, by one framework reduction otherwise
-            fused = nat.relu_bwd_bias(gy, y, reduce=False)
-            if fused is not None:
-                gy, partial = fused
+            premasked = link_out is not None and link_out.masked
+            if link_out is not None:
+                link_out.masked = False                  # consumed: the consumer's next backward sets it again
+            fused = None
+            if premasked:
+                # dL/dy arrived masked by y > 0 from the consumer's data-gradient kernel (_ReluLink): only the channel sums are left
+                if want_gb:
+                    partial = nat.channel_sums_partial(gy)
             else:
-                gy = torch.ops.aten.threshold_backward(gy, y, 0)
+                # ReLU mask and the per-workgroup channel sums of the bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the rows
+                # are added by the weight gradient's reduction launch where that is ours, by one framework reduction otherwise
+                fused = nat.relu_bwd_bias(gy, y, reduce=False)
+                if fused is not None:
+                    gy, partial = fused
+                else:
+                    gy = torch.ops.aten.threshold_backward(gy, y, 0)
         gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], wt,
-                                              partial if want_gb else None)
+                                              partial if want_gb else None, link_in)
         if want_gb:
             if gb is None:
                 gb = nat.row_sums(partial) if partial is not None else gy.sum(dim=(0, 2, 3), dtype=torch.float32)
             gb = gb.to(bdt)
         else:
             gb = None
-        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None, None
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None, None, None, None
 
 
-def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=None, bias_partial=None):
+def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=None, bias_partial=None, link_in=None):
     """dL/dx, dL/dw [and dL/db] of a convolution from the (masked) dL/dy.  Data gradient: a stride-1 'same' layer through the forward's
     MFMA kernel on the transposed, tap-flipped filters; a strided or 'valid' 3 x 3 layer the same way behind an embedding launch (round
     6).  Weight gradient: the position-grid kernel (3 x 3 'same', incl. fc6's dilation 6), the pixel GEMM (1 x 1), the tap-gathered pixel
     GEMM (any other 3 x 3) -- csrc/ssdhip_wgrad.hip.  What none of them covers goes to aten.convolution_backward (MIOpen).
     bias_partial: per-workgroup channel sums of gy ([rows, Cout] float32); the third result is their ordered sum when the weight
-    gradient's reduction launch could add them on the side, None otherwise (the caller reduces them itself)."""
+    gradient's reduction launch could add them on the side, None otherwise (the caller reduces them itself).
+    link_in (_ReluLink): xb is the ReLU output of a layer that feeds nothing else -- where the slab kernel runs the data gradient it
+    writes dL/dx masked by xb > 0 and sets the link (the layer below then skips its own mask pass)."""
     gx = None
     k = wb.shape[2]
     same = (stride == (1, 1) and k % 2 == 1 and padding == (dilation[0] * (k // 2),) * 2 and dilation[0] == dilation[1]
@@ -172,7 +198,14 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
         image1 = (k == 1 and gy.shape[2] * gy.shape[3] <= 384 and gy.shape[0] * (wt.shape[0] // 64) >= 128
                   and nat.conv2d_image_supported(gy, wt) and os.environ.get("SSDHIP_IMAGE2", "1") != "0"
                   and os.environ.get("SSDHIP_NO_IMAGE", "0") != "1")
-        if image:
+        masked = None
+        if (link_in is not None and halo and same and not image and gy.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16
+                and os.environ.get("SSDHIP_NO_MASKED_DGRAD", "0") != "1"):
+            masked = nat.conv3x3_halo_masked(gy, wt, xb)
+        if masked is not None:
+            gx = masked
+            link_in.masked = True
+        elif image:
             gx = nat.conv3x3_image(gy, wt, None, dilation=dilation[0], relu=False)
         elif image1:
             gx = nat.conv2d_image(gy, wt, None, relu=False)
@@ -228,11 +261,12 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
     written -- then the convolution's gradients as in _ConvBiasActFn."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, run, stride, padding, dilation, wb=None, bb=None, wt=None):
+    def forward(ctx, x, weight, bias, run, stride, padding, dilation, wb=None, bb=None, wt=None, link_in=None):
         xb = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             bb = bias.detach().to(torch.bfloat16) if bias is not None else None
+        ctx.link_in = link_in
         import os
         if (xb.shape[1] == 64 and wb.shape[2:] == (3, 3) and stride == (1, 1) and padding == (1, 1) and dilation == (1, 1)
                 and wb.shape[0] % 64 == 0 and xb.is_cuda and os.environ.get("SSDHIP_NO_POOL_KEEP", "0") != "1"):
@@ -257,12 +291,12 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
         gy, partial = fused
         want_gb = bdt is not None and ctx.needs_input_grad[2]
         gx, gw, gb = _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, ctx.needs_input_grad[0], wt,
-                                              partial if want_gb else None)
+                                              partial if want_gb else None, ctx.link_in)
         if want_gb:
             gb = (gb if gb is not None else nat.row_sums(partial)).to(bdt)
         else:
             gb = None
-        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt), gb, None, None, None, None, None, None, None, None
 
 
 class _PackedHeadFn(torch.autograd.Function):
@@ -584,7 +618,9 @@ class SSDModel(nn.Module):
         y2 = (torch._addmm_activation(conv.bias, x2, w2.t(), use_gelu=False) if relu else torch.addmm(conv.bias, x2, w2.t()))
         return y2.view(b, h, w, conv.out_channels).permute(0, 3, 1, 2)
 
-    def conv_act(self, conv, x, relu=True):
+    def conv_act(self, conv, x, relu=True, link_in=None, link_out=None):
+        """Conv2D(activation='relu' | None).  link_in / link_out (_ReluLink, training step only; see `relu_link`): x is the ReLU output of a
+        layer that feeds nothing but this one / this layer's output feeds exactly one layer, which holds the same link as its link_in."""
         if self._fused(x, conv):
             import os
             k = conv.kernel_size[0]
@@ -661,7 +697,8 @@ class SSDModel(nn.Module):
             run, _name = self._train_thunk(conv, x, relu)
             if run is not None:
                 wb, bb, wt = self._bf16_shadow(conv, with_transposed=True)
-                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu, wb, bb, wt)
+                return _ConvBiasActFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, relu, wb, bb, wt,
+                                            link_in, link_out)
         y = conv(x)
         return F.relu(y) if relu else y
 
@@ -834,7 +871,14 @@ class SSDModel(nn.Module):
                 name = "igemm"
         return cands[name], name
 
-    def conv_act_pool(self, conv, x, kernel, stride, pad=0, ceil_mode=False):
+    @staticmethod
+    def relu_link():
+        """A link between two consecutive ReLU convolutions of the training step (the lower one's output feeds ONLY the upper one):
+        pass it as `link_out` of the lower layer's conv_act and `link_in` of the upper layer's conv_act / conv_act_pool.  None outside
+        autograd -- the inference paths take no links."""
+        return _ReluLink() if torch.is_grad_enabled() else None
+
+    def conv_act_pool(self, conv, x, kernel, stride, pad=0, ceil_mode=False, link_in=None):
         if self._fused(x, conv):
             cands = {"miopen": lambda: nat.bias_act_maxpool(self._conv_nobias(conv, x), conv.bias, kernel, stride, pad, ceil_mode,
                                                             relu=True)}
@@ -869,8 +913,8 @@ class SSDModel(nn.Module):
             run, _name = self._train_thunk(conv, x, True)
             if run is not None:
                 wb, bb, wt = self._bf16_shadow(conv, with_transposed=True)
-                return _ConvBiasActPoolFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, wb, bb, wt)
-        return self.max_pool(self.conv_act(conv, x, relu=True), kernel, stride, pad, ceil_mode=ceil_mode)
+                return _ConvBiasActPoolFn.apply(x, conv.weight, conv.bias, run, conv.stride, conv.padding, conv.dilation, wb, bb, wt, link_in)
+        return self.max_pool(self.conv_act(conv, x, relu=True, link_in=link_in), kernel, stride, pad, ceil_mode=ceil_mode)
 
     def conv1_block_pool(self, c1, c2, x):
         """conv1_1 -> conv1_2 -> MaxPooling2D(2, 2, 'same') (models/keras_ssd300.py:274-276).  On the fused bf16 inference path the

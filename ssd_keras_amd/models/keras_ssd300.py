@@ -39,9 +39,12 @@ class _VGGBase(SSDModel):
     def _vgg_to_conv4_3(self, x):
         ca, cap = self.conv_act, self.conv_act_pool
         x = self.conv1_block_pool(self.conv1_1, self.conv1_2, x)                # conv1_1 -> conv1_2 -> pool1 ('same' pooling pads bottom/right)
-        x = cap(self.conv2_2, ca(self.conv2_1, x), 2, 2, ceil_mode=True)
-        x = cap(self.conv3_3, ca(self.conv3_2, ca(self.conv3_1, x)), 2, 2, ceil_mode=True)
-        return ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x)))
+        # (training step: each pair of consecutive ReLU layers shares a link -- the upper layer's data gradient leaves its kernel masked
+        #  by the lower layer's activation, which is that layer's ReLU backward: models/_common.py, _ReluLink; None under no_grad)
+        l2, l31, l32, l41, l42 = (self.relu_link() for _ in range(5))
+        x = cap(self.conv2_2, ca(self.conv2_1, x, link_out=l2), 2, 2, ceil_mode=True, link_in=l2)
+        x = cap(self.conv3_3, ca(self.conv3_2, ca(self.conv3_1, x, link_out=l31), link_in=l31, link_out=l32), 2, 2, ceil_mode=True, link_in=l32)
+        return ca(self.conv4_3, ca(self.conv4_2, ca(self.conv4_1, x, link_out=l41), link_in=l41, link_out=l42), link_in=l42)
 
     def _vgg_from_pool4(self, x):
         ca, cap = self.conv_act, self.conv_act_pool

@@ -336,3 +336,91 @@ def test_training_step_of_the_other_builders_runs_on_the_own_backward_kernels(wh
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
     assert np.isfinite(losses).all() and losses[1] != losses[0]
     assert max(calls) <= allowed, calls
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 128, 19, 19), (2, 256, 128, 38, 38), (2, 128, 256, 75, 75), (1, 128, 128, 150, 150),
+                                   (2, 128, 128, 9, 100), (1, 256, 128, 40, 130)])
+def test_data_gradient_with_the_relu_mask_of_the_layer_below_in_its_epilogue(shape):
+    """ssdhip_conv3x3_halo_masked_nhwc_bf16 (round 6, fourth session): the slab kernel's result zeroed where the activation of the
+    layer below is <= 0 == the slab kernel followed by relu_bwd_bias_kernel's mask (threshold_backward's rule: -0 and negative values
+    block, NaN of either sign lets the gradient through), bit for bit, on every tiling of the kernel (position grid with five / six /
+    seven slab pieces, 16 x 16 and 8 x 32 pixel tiles), repeated launches equal."""
+    torch, nat = _t()
+    B, Cy, Cx, H, W = shape                               # dL/dy channels, dL/dx channels
+    g = torch.Generator(device="cuda").manual_seed(H * W + Cx)
+    gy = torch.randn((B, Cy, H, W), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((Cx, Cy, 3, 3), device="cuda", generator=g) * (2.0 / (9 * Cy)) ** 0.5).to(torch.bfloat16)
+    wt = wt.contiguous(memory_format=torch.channels_last)
+    act = torch.randn((B, Cx, H, W), device="cuda", generator=g).clamp_min(0).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    flat = act.permute(0, 2, 3, 1).reshape(-1)           # (a view: the memory is NHWC)
+    flat[::97] = float("nan")
+    flat[5::193] = -0.0
+    flat[7::211] = -1.5                                  # not a ReLU output, but the rule is threshold_backward's
+    flat.view(torch.int16)[11::223] = -64                # 0xffc0: a NaN with the sign bit set
+    plain = nat.conv2d_same(gy, wt, None, dilation=1, relu=False, variant=7)
+    want = torch.ops.aten.threshold_backward(plain, act, 0)
+    fused = nat.relu_bwd_bias(plain, act, reduce=False)
+    assert fused is not None and torch.equal(fused[0].view(torch.int16), want.view(torch.int16))
+    got = nat.conv3x3_halo_masked(gy, wt, act)
+    assert got is not None and got.shape == want.shape
+    diff = int((got.view(torch.int16) != want.view(torch.int16)).sum())
+    assert diff == 0, "%d of %d outputs differ" % (diff, got.numel())
+    for _ in range(5):
+        assert torch.equal(nat.conv3x3_halo_masked(gy, wt, act).view(torch.int16), got.view(torch.int16))
+    # the channel sums the layer below still needs: the same rows as the one-pass kernel's
+    assert torch.equal(nat.channel_sums_partial(got), fused[1])
+    assert nat.conv3x3_halo_masked(gy[:, :64].contiguous(memory_format=torch.channels_last), wt[:, :64].contiguous(memory_format=torch.channels_last),
+                                   act) is None         # not the slab kernel's geometry: the caller keeps its own path
+
+
+def test_relu_links_of_the_training_step_change_no_gradient(monkeypatch):
+    """models/_common.py _ReluLink: conv2_2 / conv3_2 / conv3_3 / conv4_2 / conv4_3 hand the layer below a data gradient that is already
+    masked, and that layer skips its mask pass -- every parameter gradient of an SSD300 training step equals, BIT FOR BIT, the step with
+    the links off (SSDHIP_NO_MASKED_DGRAD=1), five masked launches were made and five mask passes were not."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    from ssd_keras_amd import synthetic as syn
+    from ssd_keras_amd.models.keras_ssd300 import ssd_300
+    cfg = syn.SSD300_VOC
+    torch.manual_seed(11)
+    model = ssd_300((300, 300, 3), cfg["n_classes"], mode="training", scales=cfg["scales"],
+                    aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"], steps=cfg["steps"], offsets=cfg["offsets"]).cuda()
+    model = model.to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        for head in list(model.conf_heads) + list(model.loc_heads):
+            head.weight.mul_(1e-3)
+    images = torch.from_numpy(np.random.RandomState(5).randint(0, 256, size=(3, 300, 300, 3)).astype(np.float32)).cuda()
+    w = torch.randn(3, 8732, 25, device="cuda")
+    counts = {"masked": 0, "relu": 0}
+    real_masked, real_relu = nat.conv3x3_halo_masked, nat.relu_bwd_bias
+
+    def counting_masked(*a, **k):
+        out = real_masked(*a, **k)
+        counts["masked"] += out is not None
+        return out
+
+    def counting_relu(*a, **k):
+        counts["relu"] += 1
+        return real_relu(*a, **k)
+
+    monkeypatch.setattr(nat, "conv3x3_halo_masked", counting_masked)
+    monkeypatch.setattr(nat, "relu_bwd_bias", counting_relu)
+
+    def run():
+        counts["masked"] = counts["relu"] = 0
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(images)
+        (pred[:, :, :25].float() * w).sum().backward()
+        return [p.grad.detach().clone() for p in model.parameters()], dict(counts)
+
+    monkeypatch.setenv("SSDHIP_NO_MASKED_DGRAD", "1")
+    g_off, c_off = run()
+    monkeypatch.delenv("SSDHIP_NO_MASKED_DGRAD")
+    g_on, c_on = run()
+    assert c_off["masked"] == 0 and c_on["masked"] == 5, (c_off, c_on)
+    assert c_on["relu"] == c_off["relu"] - 5, (c_off, c_on)
+    names = [n for n, _ in model.named_parameters()]
+    bad = [n for n, a, b in zip(names, g_on, g_off) if not torch.equal(a, b)]
+    assert not bad, bad
+    assert all(bool(torch.isfinite(g).all()) for g in g_on)
