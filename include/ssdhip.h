@@ -511,8 +511,12 @@ int ssdhip_conv3x3_halo_plan(int B, int H, int W, int pool, int* plan);
  * 'same' convolution of x [B,H,W,Cin] with weight [Cout,3,3,Cin] (the transposed, tap-flipped filters; no bias, no activation) where
  * mask [B,H,W,Cout] is > 0 or NaN, zero elsewhere.  Cin % 128 == 0, Cout % 128 == 0.  Bit-identical to ssdhip_conv3x3_halo_nhwc_bf16
  * followed by the mask of ssdhip_relu_bwd_bias_nhwc_bf16; saves that pass's read of both maps and its write. */
-int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, const void* mask, void* y, int B, int H, int W, int Cin,
-                                         int Cout, void* stream);
+int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, const void* mask, void* y, float* bias_partial,
+                                         int bias_rows, int B, int H, int W, int Cin, int Cout, void* stream);
+/* bias_partial (or NULL): [bias_rows][Cout] float32 whose column sums are the channel sums of y -- the bias gradient of the layer below,
+ * which then needs no pass over the map at all; every entry is written, in a fixed summation order.  bias_rows must be what this
+ * returns for the call's geometry (0: not supported). */
+int ssdhip_conv3x3_halo_masked_bias_rows(int B, int H, int W, int Cout);
 
 /* A chain of small convolutions (+ bias + ReLU) in ONE launch, one workgroup per image, the intermediate maps in LDS: the tail of the SSD
  * extra layers conv7_1 ... conv9_2 (models/keras_ssd300.py:304-313).  x [B, H, W, C0] bf16 NHWC; layer i: k_i x k_i, stride_i, zero padding

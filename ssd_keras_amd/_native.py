@@ -790,15 +790,19 @@ def conv3x3_halo(x, weight, bias, relu=True, pool=False):
     return y
 
 
-def conv3x3_halo_masked(x, weight, mask):
+def conv3x3_halo_masked(x, weight, mask, sums=False):
     """The 3x3 'same' convolution of x with weight (no bias, no activation) through the slab kernel, zeroed where `mask` (the output's
     shape) is <= 0: a layer's data gradient with the threshold_backward of the ReLU layer below in the epilogue
-    (csrc/ssdhip_convh.hip, MSK).  None when the geometry is not the slab kernel's (Cin, Cout % 128)."""
+    (csrc/ssdhip_convh.hip, MSK).  None when the geometry is not the slab kernel's (Cin, Cout % 128).
+    sums=True: returns (y, partial) -- partial [rows, Cout] float32 whose column sums are the channel sums of y (the bias gradient of the
+    layer below; conv3x3_wgrad(..., bias_partial=partial) adds the rows in its reduction launch)."""
     torch = _torch()
     lib = load()
     if not getattr(lib, "_halo_masked_bound", False):
         lib.ssdhip_conv3x3_halo_masked_nhwc_bf16.restype = ctypes.c_int
-        lib.ssdhip_conv3x3_halo_masked_nhwc_bf16.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        lib.ssdhip_conv3x3_halo_masked_nhwc_bf16.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+        lib.ssdhip_conv3x3_halo_masked_bias_rows.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_halo_masked_bias_rows.argtypes = [ctypes.c_int] * 4
         lib._halo_masked_bound = True
     cout, cin_w, kh, kw = weight.shape
     if (not x.is_cuda or x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or mask.dtype != torch.bfloat16 or kh != 3 or kw != 3
@@ -810,12 +814,19 @@ def conv3x3_halo_masked(x, weight, mask):
         raise SsdHipError("mask must have the output's shape %s, got %s" % ((b, h, w, cout), mshape))
     wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    partial, rows = None, 0
     with torch.cuda.device(x.device):
-        rc = lib.ssdhip_conv3x3_halo_masked_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(mask), _ptr(y), b, h, w, cin, cout, current_stream_ptr(x.device))
+        if sums:
+            rows = lib.ssdhip_conv3x3_halo_masked_bias_rows(b, h, w, cout)
+            if rows <= 0:
+                return None
+            partial = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        rc = lib.ssdhip_conv3x3_halo_masked_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(mask), _ptr(y), _ptr(partial), rows, b, h, w, cin, cout,
+                                                      current_stream_ptr(x.device))
     if rc == -1:                                          # SSDHIP_E_BADARG: not the slab kernel's geometry
         return None
     check(rc, "ssdhip_conv3x3_halo_masked_nhwc_bf16")
-    return y
+    return (y, partial) if sums else y
 
 
 def conv3x3_image_supported(x, weight, dilation=1):

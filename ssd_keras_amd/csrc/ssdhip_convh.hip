@@ -100,6 +100,11 @@ struct ConvHParams {
     // the kernel already masked by x > 0 -- mask = that activation, [B, H, W, Cout] like y; what threshold_backward(dL/dx, x, 0) would
     // do in a pass of its own over both maps (csrc/ssdhip_train.hip, relu_bwd_bias_kernel)
     const bf16_t* mask = nullptr;
+    // ... and the channel sums of the masked result (the bias gradient of the layer below) on the side: bsum [4 grid / n_tiles][Cout]
+    // float32 or null.  A workgroup keeps ONE channel tile over all its position tiles (the launch makes grid / 8 a multiple of n_tiles),
+    // so wave (wm, wn) of workgroup w owns row 4 ((w / 8 / n_tiles) 8 + w % 8) + wn, columns co0 + 64 wm ..: written by its first tile,
+    // added to by the later ones in program order -- no atomics, a fixed summation order; the weight gradient's reduction launch adds the rows
+    float* bsum = nullptr;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -200,7 +205,16 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
         return id < p.total_ids && qt < p.q_tiles;
     };
     int id = first_id, q0, co0;
-    if (!tile_of(id, q0, co0)) return;
+    if (!tile_of(id, q0, co0)) {
+        if constexpr (MSK) {                             // no tile at all (the ragged last group of eight ids): its rows of the channel sums are zeros
+            if (p.bsum) {
+                const int w_ = (int)threadIdx.x >> 6, l_ = (int)threadIdx.x & 63;
+                const int slot_ = first_id >> 3, cz = (slot_ % p.n_tiles) * CH_BM + (w_ >> 2) * 64 + l_;
+                p.bsum[(size_t)(4 * ((slot_ / p.n_tiles) * 8 + (first_id & 7)) + (w_ & 3)) * p.Cout + cz] = 0.f;
+            }
+        }
+        return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -815,12 +829,20 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
             // MSK: the activation at the lane's eight store addresses, requested before the packing and the LDS round trip below
             // (an address that stores nothing reads zeros); the loads are the compiler's, it waits for them where they are used
             [[maybe_unused]] ch_u32x4 mk[NPI][4];
+            [[maybe_unused]] float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // MSK: sums of the lane's eight channels over its eight positions
+            [[maybe_unused]] float4 bold0 = make_float4(0.f, 0.f, 0.f, 0.f), bold1 = bold0;  // what the wave's earlier tiles left in its row
+            [[maybe_unused]] float* brow = nullptr;
             if constexpr (MSK) {
                 const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.mask), 0, p.y_bytes, 0x00020000);
 #pragma unroll
                 for (int pi = 0; pi < NPI; ++pi)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mk[pi][j] = __builtin_amdgcn_raw_buffer_load_b128(rm, soff[pi][j], 0, 0);
+                if (p.bsum && lane < 8) {
+                    const int slot0 = first_id >> 3;
+                    brow = p.bsum + (size_t)(4 * ((slot0 / p.n_tiles) * 8 + (first_id & 7)) + wn) * p.Cout + co0 + wm * 64 + lane * 8;
+                    if (id != first_id) { bold0 = reinterpret_cast<const float4*>(brow)[0]; bold1 = reinterpret_cast<const float4*>(brow)[1]; }
+                }
             }
 #pragma unroll
             for (int pi = 0; pi < NPI; ++pi) {
@@ -841,10 +863,31 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                     if constexpr (MSK) {
                         v.x &= ch_keep2(mk[pi][j][0]); v.y &= ch_keep2(mk[pi][j][1]);
                         v.z &= ch_keep2(mk[pi][j][2]); v.w &= ch_keep2(mk[pi][j][3]);
+                        // (a position that stores nothing read a mask of zeros: it adds zeros)
+                        bs[0] += __uint_as_float(v.x << 16); bs[1] += __uint_as_float(v.x & 0xffff0000u);
+                        bs[2] += __uint_as_float(v.y << 16); bs[3] += __uint_as_float(v.y & 0xffff0000u);
+                        bs[4] += __uint_as_float(v.z << 16); bs[5] += __uint_as_float(v.z & 0xffff0000u);
+                        bs[6] += __uint_as_float(v.w << 16); bs[7] += __uint_as_float(v.w & 0xffff0000u);
                     }
                     store16_at(v, soff[pi][j]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is rewritten by the next pass
+            }
+            if constexpr (MSK) {
+                if (p.bsum) {
+                    // the eight lanes that share a channel group (lane & 7) hold eight positions each: xor-tree over lane bits 3 .. 5
+                    // (ds_bpermute; a fixed order), then lanes 0 .. 7 add the wave's 64 positions to their row
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        bs[q] += __shfl_xor(bs[q], 8);
+                        bs[q] += __shfl_xor(bs[q], 16);
+                        bs[q] += __shfl_xor(bs[q], 32);
+                    }
+                    if (lane < 8) {
+                        reinterpret_cast<float4*>(brow)[0] = make_float4(bold0.x + bs[0], bold0.y + bs[1], bold0.z + bs[2], bold0.w + bs[3]);
+                        reinterpret_cast<float4*>(brow)[1] = make_float4(bold1.x + bs[4], bold1.y + bs[5], bold1.z + bs[6], bold1.w + bs[7]);
+                    }
+                }
             }
         }
         } else
@@ -1084,9 +1127,12 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
 }
 
 // the masked-output forms (ConvHParams::mask): persistent workgroups, no pooling
-static void convh_launch_masked(const ConvHParams& p, int geom, int n_cu, hipStream_t stream) {
-    int grid = p.total_ids;
-    if (grid > n_cu) grid = n_cu;
+// workgroups of a masked launch: one per CU, and grid / 8 a multiple of the channel tiles so that a workgroup keeps its channel tile
+static int convh_masked_grid(int total_ids, int n_tiles, int n_cu) {
+    int grid = total_ids < n_cu ? total_ids : n_cu;
+    return (grid / (8 * n_tiles)) * (8 * n_tiles);       // (total_ids is a multiple of 8 n_tiles)
+}
+static void convh_launch_masked(const ConvHParams& p, int geom, int grid, hipStream_t stream) {
     const dim3 g(grid), t(CH_THREADS);
     if (geom == 4) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 4, false, false, 8, false, true>), g, t, 0, stream, p);
     else if (geom == 5) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 5, false, false, 8, false, true>), g, t, 0, stream, p);
@@ -1356,38 +1402,59 @@ extern "C" int ssdhip_profile_read_convh(unsigned long long* host_out, int reset
 }
 #endif
 
-// y = the 3x3 'same' convolution of x (no bias, no activation) where mask > 0 (or NaN), zero elsewhere: the data gradient of a layer
-// whose input is the ReLU output `mask` [B, H, W, Cout] of the layer below, with that layer's threshold_backward folded into the
-// epilogue (the training step: conv2_2 / conv3_2 / conv3_3 / conv4_2 / conv4_3 of models/keras_ssd300.py:279-291 towards the layer
-// under them).  Bit-identical to ssdhip_conv3x3_halo_nhwc_bf16 followed by ssdhip_relu_bwd_bias_nhwc_bf16's mask.
-extern "C" int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, const void* mask, void* y, int B, int H, int W,
-                                                    int Cin, int Cout, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!x || !weight || !mask || !y || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
-    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
-    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)mask) & 15) return SSDHIP_E_BADARG;
-    const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, yb = (long long)B * H * W * Cout * 2;
-    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || yb >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
-    ConvHParams p;
-    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
-    p.y = static_cast<bf16_t*>(y); p.mask = static_cast<const bf16_t*>(mask);
-    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 0;
-    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+// Tiling of a masked call: fills p.{HT, WT, Q, q_tiles, n_tiles, total_ids} and geom; false: sizes beyond the kernel's index range
+static bool convh_masked_plan(ConvHParams& p, int B, int H, int W, int Cout, int& geom) {
     p.HT = p.WT = 0;
-    p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
-    p.xC = 0; p.nx = 0; p.bias32 = nullptr; p.oscale = 1.f;
-    int geom = 0;
+    geom = 0;
     if (W > 94) {
-        if (!convh_pick_2d(p, B, H, W, 0, geom, false)) return SSDHIP_E_BADARG;
+        if (!convh_pick_2d(p, B, H, W, 0, geom, false)) return false;
     } else {
         const long long Q = (long long)B * (H + 1) * (W + 1);
-        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
+        if (Q > 0x3fffff00LL) return false;
         p.Q = (int)Q;
         p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
     }
     p.n_tiles = Cout / CH_BM;
-    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)yb;
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
-    convh_launch_masked(p, geom, convh_cu_count(), stream);
+    return true;
+}
+
+// rows of the channel-sum table a masked call fills ([rows][Cout] float32; 0: geometry not supported)
+extern "C" int ssdhip_conv3x3_halo_masked_bias_rows(int B, int H, int W, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % CH_BM)) return 0;
+    ConvHParams p;
+    int geom;
+    if (!convh_masked_plan(p, B, H, W, Cout, geom)) return 0;
+    const int grid = convh_masked_grid(p.total_ids, p.n_tiles, convh_cu_count());
+    return grid > 0 ? 4 * grid / p.n_tiles : 0;
+}
+
+// y = the 3x3 'same' convolution of x (no bias, no activation) where mask > 0 (or NaN), zero elsewhere: the data gradient of a layer
+// whose input is the ReLU output `mask` [B, H, W, Cout] of the layer below, with that layer's threshold_backward folded into the
+// epilogue (the training step: conv2_2 / conv3_2 / conv3_3 / conv4_2 / conv4_3 of models/keras_ssd300.py:279-291 towards the layer
+// under them).  Bit-identical to ssdhip_conv3x3_halo_nhwc_bf16 followed by ssdhip_relu_bwd_bias_nhwc_bf16's mask.
+// bias_partial (or NULL): [bias_rows][Cout] float32, bias_rows = ssdhip_conv3x3_halo_masked_bias_rows(B, H, W, Cout) -- every entry is
+// written; the column sums are the channel sums of y (the bias gradient of the layer below), added in a fixed order.
+extern "C" int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, const void* mask, void* y, float* bias_partial,
+                                                    int bias_rows, int B, int H, int W, int Cin, int Cout, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !mask || !y || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)mask | (uintptr_t)bias_partial) & 15) return SSDHIP_E_BADARG;
+    const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, yb = (long long)B * H * W * Cout * 2;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || yb >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
+    ConvHParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = nullptr;
+    p.y = static_cast<bf16_t*>(y); p.mask = static_cast<const bf16_t*>(mask); p.bsum = bias_partial;
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 0;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
+    p.xC = 0; p.nx = 0; p.bias32 = nullptr; p.oscale = 1.f;
+    int geom = 0;
+    if (!convh_masked_plan(p, B, H, W, Cout, geom)) return SSDHIP_E_BADARG;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)yb;
+    const int grid = convh_masked_grid(p.total_ids, p.n_tiles, convh_cu_count());
+    if (grid <= 0 || (bias_partial && bias_rows != 4 * grid / p.n_tiles)) return SSDHIP_E_BADARG;
+    convh_launch_masked(p, geom, grid, stream);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

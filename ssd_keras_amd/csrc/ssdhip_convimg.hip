@@ -65,6 +65,11 @@ struct ConvImgParams {
     int B, H, W, Cin, Cout, dil, relu;
     int n_cot;                   // Cout / BM
     int xcd_map;                 // the channel tiles of an image on one XCD (needs n_cot == 8 or a tile count that is a multiple of 8 n_cot)
+    int n_pxt;                   // pixel tiles per image (1 x 1 layers at stride 1 only, 128 pixels each with NPB = 1; 1: the whole image).
+                                 // Round 6, fourth session: a 1 x 1 step has no taps to reuse the slice over, so what a tile costs is what it
+                                 // pulls from L2 -- its pixels' rows + its channels' filters, Cin deep.  conv6_1 (1024 -> 256 on 19 x 19) as 32
+                                 // images x 4 tiles of 64 channels x the whole image moved 867 KB per tile on half the chip's CUs; as 32 x 2 x 3
+                                 // tiles of 128 channels x 128 pixels it moves 512 KB per tile on 192 CUs.
     int Ho, Wo, stride, pad;     // output map, stride and zero padding (the 3x3 'same' form: Ho = H, Wo = W, stride 1, pad = dil)
     // X3 (the reference-precision form, models/precise.py): x rows hold xC = 2 C float16 channels [hi | lo], the K loop walks Cin = 3 C
     // filter channels [w hi | w lo | w hi] and slice j reads x slice j < xslices ? j : j - xslices (hi, hi, lo); float32 bias, the
@@ -137,17 +142,23 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 
     // ---- tile: image b, channel tile ct ---------------------------------------------------------------------------------------
     int b, ct;
-    if (p.xcd_map) {                                     // blockIdx & 7 = the XCD (round-robin dispatch): an image's channel tiles share it
+    const int tpi = p.n_cot * p.n_pxt;                   // tiles per image
+    if (p.xcd_map) {                                     // blockIdx & 7 = the XCD (round-robin dispatch): an image's tiles share it
         const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        ct = j % p.n_cot;
-        b = xcd + 8 * (j / p.n_cot);
+        ct = j % tpi;
+        b = xcd + 8 * (j / tpi);
     } else {
-        b = (int)blockIdx.x / p.n_cot;
-        ct = (int)blockIdx.x - b * p.n_cot;
+        b = (int)blockIdx.x / tpi;
+        ct = (int)blockIdx.x - b * tpi;
     }
     if (b >= p.B) return;
+    const int pt = ct / p.n_cot;                         // pixel tile (0 unless n_pxt > 1: 1 x 1, stride 1 -- slab row r is pixel px0 + r)
+    ct -= pt * p.n_cot;
+    const int px0 = pt * (128 * NPB);
+    const int npx = (KS == 1 && p.n_pxt > 1) ? min(HW - px0, 128 * NPB) : HW;     // input pixels the tile's slab holds
     const int co0 = ct * BM;
     const int n_slices = p.Cin >> 6, n_steps = n_slices * NT;
+    constexpr int SR = (KS == 1 && NPB == 1) ? 3 : 7;    // slab request rounds of a slice (8 pieces each): 9 x 128 / 64 = 18 pieces | 9 x 384 / 64 = 54
 
     CI_PROF_DECL
     // ---- zero rows, descriptors ---------------------------------------------------------------------------------------------------
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         else reinterpret_cast<float*>(lds + CI_BIAS)[tid - 128] = p.bias ? __uint_as_float((u32)p.bias[co0 + tid - 128] << 16) : 0.f;
     }
     const int XC = X3 ? p.xC : p.Cin;                    // channels of an x row
-    const i32x4 rx = ci_rsrc(p.x + (size_t)b * HW * XC, (u32)((size_t)HW * XC * 2));
+    const i32x4 rx = ci_rsrc(p.x + ((size_t)b * HW + px0) * XC, (u32)((size_t)npx * XC * 2));
     const i32x4 rw = ci_rsrc(p.w + (size_t)co0 * NT * p.Cin, (u32)((size_t)BM * NT * p.Cin * 2));
 
     // ---- request plan.  Every wave issues exactly NFP + 1 LDS-DMA pieces per step, in this order: [NFP filter pieces of step i + 2 | one slab
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     auto issue_slab = [&](const int slice, const int t, const int buf) {
         const int piece = t * 8 + wave, n = piece * 64 + lane;
         const int px = n / 9, c = n - 9 * px;
-        const bool ok = (slice < n_slices) & (px < HW) & (c < 8);
-        const bool any = (slice < n_slices) & (piece * 64 < 9 * HW);          // wave-uniform: the piece holds at least one slot of the map
+        const bool ok = (slice < n_slices) & (px < npx) & (c < 8);
+        const bool any = (slice < n_slices) & (piece * 64 < 9 * npx);         // wave-uniform: the piece holds at least one slot of the map
         const int xs = (X3 && slice >= p.xslices) ? slice - p.xslices : slice;      // X3: the x slice this K slice multiplies (hi, hi, lo)
         ci_bload(ok ? (u32)((px * XC + xs * 64) * 2 + c * 16) : OOB, rx, any ? lds0 + buf * CI_SLAB + piece * 1024 : lds0 + CI_DUMP);
     };
@@ -207,13 +218,13 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
     u32 baddr[NT][NPB];                                  // current slab buffer: row of the tap's source pixel (or the zero row) + the lane's K half
 #pragma unroll
     for (int pi = 0; pi < NPB; ++pi) {
-        const int q = wn * (32 * NPB) + pi * 32 + r31;   // output pixel
+        const int q = px0 + wn * (32 * NPB) + pi * 32 + r31;   // output pixel (of the image)
         const int h = q / p.Wo, w = q - h * p.Wo;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int hh = h * p.stride - p.pad + p.dil * (t / KS), ww = w * p.stride - p.pad + p.dil * (t % KS);
             const bool ok = (q < HWo) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
-            baddr[t][pi] = (u32)((ok ? (hh * p.W + ww) * CI_ROW : CI_ZERO) + khalf * 16);
+            baddr[t][pi] = (u32)((ok ? (hh * p.W + ww - px0) * CI_ROW : CI_ZERO) + khalf * 16);
         }
     }
 
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 
     // ---- prologue: the whole slab of slice 0 (its nine piece rounds), filters of steps 0 and 1 -------------------------------------
 #pragma unroll
-    for (int t = 0; t < 7; ++t) issue_slab(0, t, 0);
+    for (int t = 0; t < SR; ++t) issue_slab(0, t, 0);
     issue_filters(0, 0);
     issue_filters(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,10 +295,16 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
                 if constexpr (KS == 3) {                                 // order: filters, slab
                     if (kk < NFP) issue_filter_piece(kk, s * NT + t + 2, stage_p2);
                     if (kk == NFP) issue_slab(s + 1, t, (s + 1) & 1);
-                } else {                                                 // order: the seven slab rounds, then the filters
+                } else if constexpr (SR == 7) {                          // order: the seven slab rounds, then the filters
                     if (kk < 3) { issue_slab(s + 1, 2 * kk, (s + 1) & 1); issue_slab(s + 1, 2 * kk + 1, (s + 1) & 1); }
                     else {
                         issue_slab(s + 1, 6, (s + 1) & 1);
+#pragma unroll
+                        for (int i = 0; i < NFP; ++i) issue_filter_piece(i, s + 2, stage_p2);
+                    }
+                } else {                                                 // 128-pixel slabs: three rounds, then the filters
+                    if (kk < 3) issue_slab(s + 1, kk, (s + 1) & 1);
+                    else {
 #pragma unroll
                         for (int i = 0; i < NFP; ++i) issue_filter_piece(i, s + 2, stage_p2);
                     }
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
             for (int pi = 0; pi < NPB; ++pi) {
-                const int q = wn * (32 * NPB) + pi * 32 + r31;
+                const int q = px0 + wn * (32 * NPB) + pi * 32 + r31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int chl = wm * WCH + ci * 32 + 8 * g + 4 * khalf;         // channel inside the tile
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
         }
 #pragma unroll
         for (int pi = 0; pi < NPB; ++pi) {
-            const int q = wn * (32 * NPB) + pi * 32 + r31;
+            const int q = px0 + wn * (32 * NPB) + pi * 32 + r31;
             const u32 voff = (u32)((q * p.Cout + co0 + wm * WCH + ci * 32) * 2 + khalf * 16) | (q < HWo ? 0u : OOB);
             u32 lo[4], hi[4];
 #pragma unroll
@@ -388,6 +405,29 @@ __global__ __launch_bounds__(CI_THREADS, 1) void conv_image_kernel(ConvImgParams
 }  // namespace ssdhip
 
 using namespace ssdhip;
+
+// Channel tile and pixel tiles of a launch.  Whole-image tiles: 128 channels where that already gives three quarters of a chip's worth of
+// tiles (fc6 / fc7 at batch 32: 256), else 64 (conv5_x, conv6_2 at batch 32: 256 tiles).  A 1 x 1 layer at stride 1 on a map of more than
+// 128 pixels may instead run on 128-pixel tiles (ConvImgParams::n_pxt): the cheaper of the two by rounds of `n_cu` tiles x bytes a tile
+// moves from L2 (its slab rows + its filters, Kc channels deep).  SSDHIP_CONVIMG_BM forces the channel tile, SSDHIP_CONVIMG_PXT=0 the
+// whole image (A/B runs).
+static void ci_pick_tiles(int B, int HW, int Kc, int Cout, int ksize, int stride, int padding, int HWo, int& bm, int& n_pxt) {
+    bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
+    if (const char* e = getenv("SSDHIP_CONVIMG_BM")) { const int v = atoi(e); if (v == 64 || (v == 128 && (Cout % 128) == 0)) bm = v; }
+    n_pxt = 1;
+    const char* e = getenv("SSDHIP_CONVIMG_PXT");
+    if (ksize != 1 || stride != 1 || padding != 0 || HWo <= 128 || (e && atoi(e) == 0) || getenv("SSDHIP_CONVIMG_BM")) return;
+    int n_cu = 256;
+    { int dev = 0, n = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) n_cu = n; }
+    auto cost = [&](long long tiles, long long px, long long co) { return ((tiles + n_cu - 1) / n_cu) * (px + co) * Kc * 2; };
+    long long best = cost((long long)B * (Cout / bm), HW, bm);
+    const int npt = (HWo + 127) / 128;
+    for (int co = 128; co >= 64; co -= 64) {
+        if (Cout % co) continue;
+        const long long c = cost((long long)B * (Cout / co) * npt, 128, co);
+        if (c < best) { best = c; bm = co; n_pxt = npt; }
+    }
+}
 
 // The general entry (round 6): k x k convolution, k in {1, 3}, of maps with H W <= 384 input pixels and at most 384 output pixels, one
 // image per tile: x [B, H, W, Cin] bf16, weight [Cout, k, k, Cin] bf16, bias [Cout] bf16 or NULL, y [B, Ho, Wo, Cout] bf16 with
@@ -415,14 +455,14 @@ extern "C" int ssdhip_conv2d_image_nhwc_bf16(const void* x, const void* weight, 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
     p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = padding;
     p.xC = Cin; p.xslices = Cin / 64; p.out_f32 = 0; p.bias32 = nullptr; p.oscale = 1.f;
-    // channel tile: 128 where that already gives three quarters of a chip's worth of tiles (fc6 / fc7 at batch 32: 256), else 64 (conv5_x,
-    // conv6_1, conv6_2 at batch 32: 256 / 128 / 256 tiles).  SSDHIP_CONVIMG_BM forces one (A/B runs).
-    int bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
-    if (const char* e = getenv("SSDHIP_CONVIMG_BM")) { const int v = atoi(e); if (v == 64 || (v == 128 && (Cout % 128) == 0)) bm = v; }
+    int bm;
+    ci_pick_tiles(B, H * W, Cin, Cout, ksize, stride, padding, Ho * Wo, bm, p.n_pxt);
     p.n_cot = Cout / bm;
-    const dim3 grid((unsigned)(B * p.n_cot)), block(CI_THREADS);
-    p.xcd_map = (B % 8 == 0) ? 1 : 0;                    // b = xcd + 8 (j / n_cot) covers 0 .. B - 1 exactly when B is a multiple of 8
-    const bool small = Ho * Wo <= 128;                   // one 32-pixel block per wave
+    const dim3 grid((unsigned)(B * p.n_cot * p.n_pxt)), block(CI_THREADS);
+    p.xcd_map = (B % 8 == 0) ? 1 : 0;                    // b = xcd + 8 (j / tiles per image) covers 0 .. B - 1 exactly when B is a multiple of 8
+    // one 32-pixel block per wave; a 1 x 1 tile of that form requests 128 slab rows per slice, so a STRIDED 1 x 1 layer whose input
+    // has more pixels than that stays on the three-block form whatever its output size
+    const bool small = (Ho * Wo <= 128 && (ksize == 3 || H * W <= 128)) || p.n_pxt > 1;
 #define CI_LAUNCH(BM_, KS_, NPB_) hipLaunchKernelGGL((conv_image_kernel<BM_, KS_, NPB_>), grid, block, 0, stream, p)
     if (ksize == 3) {
         if (bm == 128) { if (small) CI_LAUNCH(128, 3, 1); else CI_LAUNCH(128, 3, 3); }
@@ -460,12 +500,12 @@ extern "C" int ssdhip_conv2d_image_x3_nhwc_f16(const void* x, const void* weight
     p.B = B; p.H = H; p.W = W; p.Cin = 3 * C; p.Cout = Cout; p.dil = dilation; p.relu = relu ? 1 : 0;
     p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = padding;
     p.xC = 2 * C; p.xslices = C / 64; p.out_f32 = out_f32 ? 1 : 0; p.bias32 = bias; p.oscale = oscale;
-    int bm = ((Cout % 128) == 0 && (long long)B * (Cout / 128) >= 192) ? 128 : 64;
-    if (const char* e = getenv("SSDHIP_CONVIMG_BM")) { const int v = atoi(e); if (v == 64 || (v == 128 && (Cout % 128) == 0)) bm = v; }
+    int bm;
+    ci_pick_tiles(B, H * W, 3 * C, Cout, ksize, stride, padding, Ho * Wo, bm, p.n_pxt);
     p.n_cot = Cout / bm;
-    const dim3 grid((unsigned)(B * p.n_cot)), block(CI_THREADS);
+    const dim3 grid((unsigned)(B * p.n_cot * p.n_pxt)), block(CI_THREADS);
     p.xcd_map = (B % 8 == 0) ? 1 : 0;
-    const bool small = Ho * Wo <= 128;
+    const bool small = (Ho * Wo <= 128 && (ksize == 3 || H * W <= 128)) || p.n_pxt > 1;
 #define CI_LAUNCH3(BM_, KS_, NPB_) hipLaunchKernelGGL((conv_image_kernel<BM_, KS_, NPB_, true>), grid, block, 0, stream, p)
     if (ksize == 3) {
         if (bm == 128) { if (small) CI_LAUNCH3(128, 3, 1); else CI_LAUNCH3(128, 3, 3); }

@@ -86,10 +86,11 @@ class _ReluLink:
     input > 0 -- which is the lower layer's threshold_backward -- so the lower layer skips its pass over (dL/dy, y).  The link is how the
     two autograd nodes agree: the upper node's backward sets `masked` only when its kernel really applied the mask, the lower node's
     backward (which autograd runs after it) consumes the flag and falls back to its own mask otherwise."""
-    __slots__ = ("masked",)
+    __slots__ = ("masked", "partial")
 
     def __init__(self):
         self.masked = False
+        self.partial = None      # the masked gradient's channel sums by workgroup ([rows, C] float32): the lower layer's bias-gradient partials
 
 
 class _ConvBiasActFn(torch.autograd.Function):
@@ -132,11 +133,12 @@ class _ConvBiasActFn(torch.autograd.Function):
         if relu:
             premasked = link_out is not None and link_out.masked
             if link_out is not None:
+                partial, link_out.partial = link_out.partial, None
                 link_out.masked = False                  # consumed: the consumer's next backward sets it again
             fused = None
             if premasked:
-                # dL/dy arrived masked by y > 0 from the consumer's data-gradient kernel (_ReluLink): only the channel sums are left
-                if want_gb:
+                # dL/dy arrived masked by y > 0 from the consumer's data-gradient kernel (_ReluLink), its channel sums beside it
+                if want_gb and partial is None:
                     partial = nat.channel_sums_partial(gy)
             else:
                 # ReLU mask and the per-workgroup channel sums of the bias gradient in ONE libssdhip pass (csrc/ssdhip_train.hip); the rows
@@ -201,9 +203,9 @@ def _conv_input_weight_grads(gy, xb, wb, stride, padding, dilation, need_x, wt=N
         masked = None
         if (link_in is not None and halo and same and not image and gy.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16
                 and os.environ.get("SSDHIP_NO_MASKED_DGRAD", "0") != "1"):
-            masked = nat.conv3x3_halo_masked(gy, wt, xb)
+            masked = nat.conv3x3_halo_masked(gy, wt, xb, sums=os.environ.get("SSDHIP_NO_MASKED_SUMS", "0") != "1")
         if masked is not None:
-            gx = masked
+            gx, link_in.partial = masked if isinstance(masked, tuple) else (masked, None)
             link_in.masked = True
         elif image:
             gx = nat.conv3x3_image(gy, wt, None, dilation=dilation[0], relu=False)

@@ -631,6 +631,10 @@ IMAGE2_CASES = [  # B, H, W, Cin, Cout, k, stride, padding, dilation, bias, relu
     (2, 18, 20, 128, 64, 3, 3, 1, 1, True, True),        # stride 3 on a non-square map
     (3, 19, 19, 64, 128, 1, 2, 0, 1, True, True),        # a strided 1x1
     (2, 17, 17, 128, 128, 3, 1, 1, 6, True, True),       # padding smaller than the dilated reach: 17 x 17 -> 7 x 7
+    # round 6, fourth session: 1x1 layers on 128-pixel tiles where that moves fewer bytes per CU (ConvImgParams::n_pxt)
+    (5, 13, 10, 128, 128, 1, 1, 0, 1, True, True),       # 130 pixels: the second pixel tile holds two of them
+    (16, 19, 19, 256, 1024, 1, 1, 0, 1, False, True),    # conv6_1's data gradient geometry: 8 x 3 tiles per image
+    (7, 15, 20, 192, 64, 1, 1, 0, 1, True, False),       # 300 pixels, a 64-channel layer, the plain tile map (batch not a multiple of 8)
 ]
 
 
@@ -675,6 +679,24 @@ def test_general_image_conv_race_screen():
         for _ in range(30):
             bad += int((nat.conv2d_image(x, wt, bias, stride=stride, padding=pad, dilation=1, relu=True).view(torch.int16) != base).sum().item())
         assert bad == 0, (B, H, W, Cin, Cout, k, bad)
+
+
+def test_pixel_tiles_of_the_1x1_image_kernel_equal_whole_image_tiles(monkeypatch):
+    """conv6_1 at batch 32 (BASELINE configs[1]) and smaller batches of it: 128-channel x 128-pixel tiles (the default where they
+    move fewer bytes per CU) == whole-image tiles (SSDHIP_CONVIMG_PXT=0) == the implicit-GEMM kernel, bit for bit, twenty launches."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    for B in (32, 3):
+        g = torch.Generator(device="cuda").manual_seed(B)
+        x = torch.randn((B, 19, 19, 1024), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+        wt = (torch.randn((256, 1, 1, 1024), generator=g, device="cuda") / 32.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+        bias = torch.randn((256,), generator=g, device="cuda").to(torch.bfloat16)
+        base = nat.conv2d(x, wt, bias, stride=1, padding=0, dilation=1, relu=True).view(torch.int16)
+        monkeypatch.setenv("SSDHIP_CONVIMG_PXT", "0")
+        assert torch.equal(nat.conv2d_image(x, wt, bias, relu=True).view(torch.int16), base)
+        monkeypatch.delenv("SSDHIP_CONVIMG_PXT")
+        for _ in range(20):
+            assert torch.equal(nat.conv2d_image(x, wt, bias, relu=True).view(torch.int16), base)
 
 
 def test_general_image_conv_rejects_other_geometries():
