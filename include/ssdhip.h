@@ -518,6 +518,13 @@ int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* weight, cons
  * returns for the call's geometry (0: not supported). */
 int ssdhip_conv3x3_halo_masked_bias_rows(int B, int H, int W, int Cout);
 
+/* Training step: Conv2D(relu) -> MaxPooling2D(2, 2, 'same') (models/keras_ssd300.py:279-287: conv2_2 -> pool2, conv3_3 -> pool3) in ONE
+ * launch that writes the activation the backward pass needs, y_full [B,H,W,Cout], AND the pooled map y_pooled
+ * [B,ceil(H/2),ceil(W/2),Cout] -- the accumulators survive the pooled epilogue -- instead of an un-pooled launch and a pooling pass
+ * that reads the map back.  Cin % 128 == 0, Cout % 128 == 0.  Both maps bit-identical to ssdhip_conv3x3_halo_nhwc_bf16 (pool 0 / 1). */
+int ssdhip_conv3x3_halo_pool_keep_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y_full, void* y_pooled, int B, int H,
+                                            int W, int Cin, int Cout, int relu, void* stream);
+
 /* A chain of small convolutions (+ bias + ReLU) in ONE launch, one workgroup per image, the intermediate maps in LDS: the tail of the SSD
  * extra layers conv7_1 ... conv9_2 (models/keras_ssd300.py:304-313).  x [B, H, W, C0] bf16 NHWC; layer i: k_i x k_i, stride_i, zero padding
  * pad_i, Cout_i, bias_i (bf16 or NULL), ReLU if relu_i != 0; y_h[i] != NULL: that layer's map is also written to y_h[i]

@@ -1640,6 +1640,32 @@ def conv3x3_c64_pool_keep(x, weight, bias, relu=True):
     return y, pooled
 
 
+def conv3x3_halo_pool_keep(x, weight, bias, relu=True):
+    """Conv2D(relu) -> MaxPooling2D(2, 2, 'same') through the slab kernel in ONE launch that writes BOTH the full-resolution activation
+    and the pooled map (csrc/ssdhip_convh.hip, KEEP; Cin, Cout % 128 == 0).  Returns (y, pooled), bit-identical to conv3x3_halo(pool=False)
+    and conv3x3_halo(pool=True); None when the geometry is not the slab kernel's."""
+    torch = _torch()
+    lib = load()
+    if not getattr(lib, "_halo_keep_bound", False):
+        lib.ssdhip_conv3x3_halo_pool_keep_nhwc_bf16.restype = ctypes.c_int
+        lib.ssdhip_conv3x3_halo_pool_keep_nhwc_bf16.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+        lib._halo_keep_bound = True
+    cout, cin_w, kh, kw = weight.shape
+    if not x.is_cuda or x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or kh != 3 or kw != 3 or cin_w % 128 or cout % 128 or x.shape[1] != cin_w:
+        return None
+    x, (b, h, w, cin) = _nhwc_bf16(x, "x")
+    wt = weight if weight.permute(0, 2, 3, 1).is_contiguous() else weight.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    pooled = torch.empty((b, (h + 1) // 2, (w + 1) // 2, cout), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(x.device):
+        rc = lib.ssdhip_conv3x3_halo_pool_keep_nhwc_bf16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), _ptr(pooled), b, h, w, cin, cout, int(bool(relu)),
+                                                         current_stream_ptr(x.device))
+    if rc == -1:                                          # SSDHIP_E_BADARG: not the slab kernel's geometry
+        return None
+    check(rc, "ssdhip_conv3x3_halo_pool_keep_nhwc_bf16")
+    return y, pooled
+
+
 def conv3x3_cin3(x, weight, bias, relu=True):
     """First layer: 3x3 'same' convolution of a 3-channel image into 64 channels + bias + ReLU (csrc/ssdhip_conv.hip)."""
     torch = _torch()

@@ -105,6 +105,11 @@ struct ConvHParams {
     // so wave (wm, wn) of workgroup w owns row 4 ((w / 8 / n_tiles) 8 + w % 8) + wn, columns co0 + 64 wm ..: written by its first tile,
     // added to by the later ones in program order -- no atomics, a fixed summation order; the weight gradient's reduction launch adds the rows
     float* bsum = nullptr;
+    // KEEP (training, fourth session of round 6; pooled forms): the full-resolution activation [B, H, W, Cout] the backward pass needs is
+    // stored too -- the accumulators survive the pooled epilogue -- instead of an un-pooled launch followed by a pooling pass that reads
+    // the map back (conv2_2 -> pool2, conv3_3 -> pool3; conv1_2 -> pool1 is ssdhip_conv64.hip's KEEP)
+    bf16_t* y_full = nullptr;
+    int yf_bytes = 0;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -173,9 +178,11 @@ __device__ __forceinline__ u32 ch_split2(float a, float b, u32& lo_out) {       
 // each 64 channels x 128 positions, ONE wave per SIMD with the 512-register budget) reads 24 fragments for 32 MFMAs per K-step
 // instead of 2 x 16 for 2 x 16: a quarter less LDS read traffic per FLOP, and no second wave competing for the SIMD's matrix pipe.
 // Same tile, same LDS image, same requests (each wave issues twice the pieces), same accumulation order: bit-identical results.
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8, bool STK = false, bool MSK = false>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool SMALL, bool X3 = false, int NWV = 8, bool STK = false, bool MSK = false,
+          bool KEEP = false>
 __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* lds, const int first_id) {
     constexpr bool G2 = CSH != 0;
+    static_assert(!KEEP || (POOL && !X3 && NWV == 8 && !(MODE & (16384 | 1024))), "KEEP: the staged pooled bf16 epilogue, plain waits");
     static_assert(!MSK || (!POOL && !X3 && NWV == 8 && !(MODE & 16384)), "masked outputs: the staged bf16 epilogue without pooling");
     static_assert(!STK || (POOL && !((MODE & 16384) != 0 && !X3)), "stacked-batch tiles: the staged pooled epilogues");
     static_assert(NWV == 8 || (NWV == 4 && !X3), "8 waves, or 4 (bf16 forms only)");
@@ -725,6 +732,43 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
                 store16(v, ho < p.Ho && wo < p.Wo && (!STK || bs < stackB), (u32)((bs * p.Ho + ho) * p.Wo + wo) * YC + (u32)(co0 + wm * 64 + c * 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (KEEP) {
+                // ---- the same accumulators once more, un-pooled: bias + one rounding + activation, the LDS transpose, 16-byte stores into
+                //      y_full (the plain 2-D epilogue below; a row of the stacked batch finds its image as everywhere else) ----
+                const __amdgpu_buffer_rsrc_t ryf = __builtin_amdgcn_make_buffer_rsrc(p.y_full, 0, p.yf_bytes, 0x00020000);
+                const int c = lane & 7;
+                const u32 cb = (u32)(co0 + wm * 64 + c * 8) * 2u;
+#pragma unroll
+                for (int pi = 0; pi < NPI; ++pi) {
+                    u32 so[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int sl = wn * (16 * NPI) + (pi >> 1) * 32 + j * 8 + (lane >> 3);
+                        int hh = h0 + 2 * (sl >> CSH) + (pi & 1), bb = b;
+                        const int ww = w0 + (sl & (TC - 1));
+                        stack_row(bb, hh);
+                        so[j] = ((u32)((bb * H + hh) * W + ww) * (YC * 2u) + cb) | (((hh < H) & (ww < W) & (!STK || bb < stackB)) ? 0u : OOB);
+                    }
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            u32 p0, p1;
+                            pack4(ci, pi, g, p0, p1);
+                            const int chunk = ci * 4 + g;
+                            *reinterpret_cast<uint2*>(stage + r31 * 128 + ((chunk ^ (r31 & 7)) << 4) + khalf * 8) = make_uint2(p0, p1);
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int px = j * 8 + (lane >> 3);
+                        const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+                        const ch_u32x4 d = {v.x, v.y, v.z, v.w};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, ryf, so[j], 0, 0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
         } else if constexpr (DIRECT) {
             static_assert(NPI == 2, "eight-wave form");
             u32 soff1[NPI];                              // byte offset of the lane's position in block pi (+ its 16-byte column), or OOB
@@ -1041,11 +1085,11 @@ __device__ __forceinline__ void convh_body(const ConvHParams& p, unsigned char* 
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8, bool STK = false, bool MSK = false>
+template <int NW, int SPW, int MODE, int CSH, bool POOL, bool X3 = false, int NWV = 8, bool STK = false, bool MSK = false, bool KEEP = false>
 __global__ __launch_bounds__(64 * NWV) void convh_kernel(ConvHParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ch_lds_bytes(NW, SPW)];
-    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV, STK, MSK>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
+    convh_body<NW, SPW, MODE, CSH, POOL, SPW == 5, X3, NWV, STK, MSK, KEEP>(p, lds, (int)blockIdx.x);   // SPW == 5: maps up to 30 wide
 #endif
 }
 
@@ -1123,6 +1167,20 @@ static void convh_launch(const ConvHParams& p, int geom, int pool, int n_cu, hip
     else if (p.W <= 30) hipLaunchKernelGGL((convh_kernel<4, 5, MODE, 0, false, X3>), g, t, 0, stream, p);
     else if (p.W <= 62) hipLaunchKernelGGL((convh_kernel<4, 6, MODE, 0, false, X3>), g, t, 0, stream, p);
     else hipLaunchKernelGGL((convh_kernel<3, 7, MODE, 0, false, X3>), g, t, 0, stream, p);
+    }
+}
+
+// the pooled forms that also store the full-resolution map (ConvHParams::y_full): persistent workgroups, 2-D tiles per image or stacked
+static void convh_launch_keep(const ConvHParams& p, int geom, int n_cu, hipStream_t stream) {
+    int grid = p.total_ids;
+    if (grid > n_cu) grid = n_cu;
+    const dim3 g(grid), t(CH_THREADS);
+    if (geom == 4) {
+        if (p.Hp) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 4, true, false, 8, true, false, true>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<4, 6, 128, 4, true, false, 8, false, false, true>), g, t, 0, stream, p);
+    } else {
+        if (p.Hp) hipLaunchKernelGGL((convh_kernel<4, 6, 128, 5, true, false, 8, true, false, true>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((convh_kernel<4, 6, 128, 5, true, false, 8, false, false, true>), g, t, 0, stream, p);
     }
 }
 
@@ -1456,5 +1514,33 @@ extern "C" int ssdhip_conv3x3_halo_masked_nhwc_bf16(const void* x, const void* w
     const int grid = convh_masked_grid(p.total_ids, p.n_tiles, convh_cu_count());
     if (grid <= 0 || (bias_partial && bias_rows != 4 * grid / p.n_tiles)) return SSDHIP_E_BADARG;
     convh_launch_masked(p, geom, grid, stream);
+    return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
+}
+
+// Conv2D(relu) -> MaxPooling2D(2, 2, 'same') of the training step in ONE launch that writes the activation the backward pass needs
+// (y_full [B, H, W, Cout]) AND the pooled map (y_pooled [B, ceil(H/2), ceil(W/2), Cout]): models/keras_ssd300.py:279-287 (conv2_2 ->
+// pool2, conv3_3 -> pool3).  Cin % 128 == 0, Cout % 128 == 0.  Both maps bit-identical to ssdhip_conv3x3_halo_nhwc_bf16 (pool = 0 / 1).
+extern "C" int ssdhip_conv3x3_halo_pool_keep_nhwc_bf16(const void* x, const void* weight, const void* bias, void* y_full, void* y_pooled,
+                                                       int B, int H, int W, int Cin, int Cout, int relu, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !y_full || !y_pooled || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+    if (Cin <= 0 || (Cin % 128) || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
+    if (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y_full | (uintptr_t)y_pooled) & 15 || ((uintptr_t)bias & 1)) return SSDHIP_E_BADARG;
+    const long long xb = (long long)B * H * W * Cin * 2, wb = (long long)Cout * 9 * Cin * 2, yfb = (long long)B * H * W * Cout * 2;
+    if (xb >= 0x7ffff000LL || wb >= 0x7ffff000LL || yfb >= 0x7ffff000LL) return SSDHIP_E_BADARG;   // 31-bit byte offsets
+    ConvHParams p;
+    p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(weight); p.bias = static_cast<const bf16_t*>(bias);
+    p.y = static_cast<bf16_t*>(y_pooled); p.y_full = static_cast<bf16_t*>(y_full);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu ? 1 : 0;
+    p.Ho = (H + 1) / 2; p.Wo = (W + 1) / 2;
+    p.HT = p.WT = 0;
+    p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
+    p.xC = 0; p.nx = 0; p.bias32 = nullptr; p.oscale = 1.f;
+    int geom = 0;
+    if (!convh_pick_2d(p, B, H, W, 1, geom, true)) return SSDHIP_E_BADARG;
+    p.n_tiles = Cout / CH_BM;
+    p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)((long long)B * p.Ho * p.Wo * Cout * 2); p.yf_bytes = (int)yfb;
+    p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
+    convh_launch_keep(p, geom, convh_cu_count(), stream);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

@@ -276,8 +276,17 @@ class _ConvBiasActPoolFn(torch.autograd.Function):
             # pooling pass read the 368 MB map back (~95 us of the step)
             y, p = nat.conv3x3_c64_pool_keep(xb, wb, bb, relu=True)
         else:
-            y = run(xb, wb, bb)
-            p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
+            # fourth session: conv2_2 -> pool2 and conv3_3 -> pool3 the same way on the slab kernel (csrc/ssdhip_convh.hip, KEEP)
+            kept = None
+            if (xb.shape[1] % 128 == 0 and wb.shape[0] % 128 == 0 and wb.shape[2:] == (3, 3) and stride == (1, 1) and padding == (1, 1)
+                    and dilation == (1, 1) and xb.is_cuda and os.environ.get("SSDHIP_NO_POOL_KEEP", "0") != "1"
+                    and os.environ.get("SSDHIP_NO_HALO", "0") != "1" and os.environ.get("SSDHIP_NO_HALO_POOL_KEEP", "0") != "1"):
+                kept = nat.conv3x3_halo_pool_keep(xb, wb, bb, relu=True)
+            if kept is not None:
+                y, p = kept
+            else:
+                y = run(xb, wb, bb)
+                p = nat.bias_act_maxpool(y, None, 2, 2, 0, True, relu=False)
         ctx.save_for_backward(xb, wb, y, wt)
         ctx.conf = (stride, padding, dilation, weight.dtype, None if bias is None else bias.dtype, x.dtype)
         return p

@@ -399,6 +399,32 @@ def test_slab_conv_pool_on_the_stacked_batch_equals_tiles_per_image(shape, monke
         assert torch.equal(got, per_image), "%d of %d outputs differ" % (int((got != per_image).sum()), got.numel())
 
 
+@pytest.mark.parametrize("shape", [(2, 150, 150, 128, 128), (5, 75, 75, 256, 256), (3, 75, 75, 128, 128), (6, 20, 20, 128, 256),
+                                   (2, 16, 16, 256, 128), (5, 2, 2, 128, 128), (3, 37, 21, 128, 128)])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_slab_conv_pool_keep_writes_both_maps(shape, has_bias, monkeypatch):
+    """ssdhip_conv3x3_halo_pool_keep_nhwc_bf16 (the training step's conv2_2 -> pool2, conv3_3 -> pool3): ONE launch, the full-resolution
+    activation == the un-pooled slab kernel's and the pooled map == the pooled slab kernel's, bit for bit, on tiles per image and on
+    tiles of the stacked batch, over repeated launches."""
+    import torch
+    from ssd_keras_amd import _native as nat
+    monkeypatch.delenv("SSDHIP_CONVH_MODE", raising=False)
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(B * H + Cin)
+    x = torch.randn((B, H, W, Cin), generator=g, device="cuda").to(torch.bfloat16).permute(0, 3, 1, 2)
+    wt = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16).permute(0, 3, 1, 2)
+    bias = torch.randn((Cout,), generator=g, device="cuda").to(torch.bfloat16) if has_bias else None
+    want_full = nat.conv3x3_halo(x, wt, bias, relu=True, pool=False).view(torch.int16)
+    want_pool = nat.conv3x3_halo(x, wt, bias, relu=True, pool=True).view(torch.int16)
+    for _ in range(6):
+        full, pooled = nat.conv3x3_halo_pool_keep(x, wt, bias, relu=True)
+        assert full.shape == (B, Cout, H, W) and pooled.shape == (B, Cout, (H + 1) // 2, (W + 1) // 2)
+        assert torch.equal(full.view(torch.int16), want_full), "%d full-resolution outputs differ" % int((full.view(torch.int16) != want_full).sum())
+        assert torch.equal(pooled.view(torch.int16), want_pool), "%d pooled outputs differ" % int((pooled.view(torch.int16) != want_pool).sum())
+    assert nat.conv3x3_halo_pool_keep(x[:, :64].contiguous(memory_format=torch.channels_last),
+                                      wt[:, :64].contiguous(memory_format=torch.channels_last), bias) is None
+
+
 def test_slab_conv_pool_full_batch_race_screen(slab_mode):
     """conv2_2 -> pool2 at batch 32 (BASELINE configs[1]): 15 launches, all bit-identical to conv_igemm4_pool_kernel."""
     import torch
