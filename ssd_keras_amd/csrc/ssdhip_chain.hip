@@ -33,7 +33,13 @@ typedef float cc_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CC_MAX_LAYERS = 8;
 constexpr int CC_THREADS = 512;
 constexpr int CC_LDS = 156 * 1024;
-[[maybe_unused]] constexpr int CC_PF = 8;                                 // filter fragments a wave keeps in flight
+[[maybe_unused]] constexpr int CC_PF = 8;                                 // K-steps of a block (one tap x 128 channels: the pixel operands' unit)
+// Filter fragments a wave keeps in flight (the kernel's CC_RING: 8, 16 or 32; 1 KiB each).  Round 6, fourth session, measured and NOT
+// adopted (profiles/r06zz5_chain_ring_depth_negative.txt): if the K loops were chains of memory round trips, twice the fragments in
+// flight would halve them -- 16 is 7 % SLOWER than 8 back to back (45.3 against 42.1 us at batch 32; 181 against 149 VGPRs) and equal
+// inside the step, 32 spills 84 bytes per lane (74.7 us).  The loads are not what a step waits for.  SSDHIP_CHAIN_RING=8|16|32 selects at
+// launch (the forms stay instantiated: the test checks that the depth changes no bit).
+constexpr int CC_RING_DEFAULT = 8;
 
 struct ChainLayerDev {
     const uint4* wp;             // packed filters: [Cout / 32][k k][Cin / 16][64 lanes] x 16 bytes
@@ -56,7 +62,9 @@ __device__ __forceinline__ u32 cc_pack2(float a, float b) {
 }
 #endif
 
+template <int CC_RING>
 __global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
+    static_assert(CC_RING == 8 || CC_RING == 16 || CC_RING == 32, "ring depth: one, two or four blocks (the blocks alternate between the halves of `bq`)");
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) unsigned char lds[CC_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -94,9 +102,9 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
             cc_f32x16 acc, acc1;                          // even / odd K-steps: two dependency chains through the matrix pipe instead of one
 #pragma unroll
             for (int v = 0; v < 16; ++v) { acc[v] = 0.f; acc1[v] = 0.f; }
-            uint4 ring[CC_PF];
+            uint4 ring[CC_RING];
 #pragma unroll
-            for (int j = 0; j < CC_PF; ++j) ring[j] = wsrc[(size_t)j * 64];
+            for (int j = 0; j < CC_RING; ++j) ring[j] = wsrc[(size_t)(j < kt ? j : kt - 1) * 64];
             // the pixel operands of a block of eight K-steps (one tap, 128 channels) are read from LDS a whole block AHEAD, into the
             // other half of `bq`: read right before their MFMA, every step waited out an LDS round trip (r04o: 417 cycles per step)
             uint4 bq[2][CC_PF];
@@ -116,15 +124,15 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
 #pragma unroll
                 for (int j = 0; j < CC_PF; ++j) bq[HB][j] = *reinterpret_cast<const uint4*>(brow + j * step);
             };
-            auto mul_block = [&](auto hc, const int kb) {
-                constexpr int HB = decltype(hc)::value;
+            auto mul_block = [&](auto hc, auto sc, const int kb) {
+                constexpr int HB = decltype(hc)::value, SB = decltype(sc)::value;     // half of `bq`; first ring slot of the block
 #pragma unroll
                 for (int j = 0; j < CC_PF; ++j) {
-                    const uint4 a = ring[j];
+                    const uint4 a = ring[SB + j];
                     // (unconditional, the index clamped: a conditional load makes the compiler wait for ALL loads in flight at every
                     // step -- vmcnt(0) -- and the ring hides nothing)
-                    const int kn = kb + CC_PF + j;
-                    ring[j] = wsrc[(size_t)(kn < kt ? kn : kt - 1) * 64];
+                    const int kn = kb + CC_RING + j;
+                    ring[SB + j] = wsrc[(size_t)(kn < kt ? kn : kt - 1) * 64];
                     __builtin_amdgcn_sched_barrier(0);    // the refill is issued HERE, eight steps ahead of its use, not batched at the block's end
                     if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cc_bf16x8, a), __builtin_bit_cast(cc_bf16x8, bq[HB][j]), acc1, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cc_bf16x8, a), __builtin_bit_cast(cc_bf16x8, bq[HB][j]), acc, 0, 0, 0);
@@ -133,12 +141,27 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
             };
             using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
             read_block(H0{}, 0);
-            for (int kb = 0; kb < kt; kb += 2 * CC_PF) {                     // kt / 8 may be odd: the second half then multiplies nothing
+            // blocks of eight K-steps walk the ring's CC_RING / 8 block slots in turn and the two halves of `bq` alternately: the loop body
+            // is unrolled over the ring so that both are compile-time indices (kt / 8 need not be a multiple: a block past the end multiplies
+            // nothing)
+            for (int kb = 0; kb < kt; kb += CC_RING < 2 * CC_PF ? 2 * CC_PF : CC_RING) {
                 read_block(H1{}, kb + CC_PF);
-                mul_block(H0{}, kb);
+                mul_block(H0{}, std::integral_constant<int, 0>{}, kb);
                 if (kb + CC_PF < kt) {
                     read_block(H0{}, kb + 2 * CC_PF);
-                    mul_block(H1{}, kb + CC_PF);
+                    mul_block(H1{}, std::integral_constant<int, CC_RING >= 16 ? 8 : 0>{}, kb + CC_PF);
+                }
+                if constexpr (CC_RING == 32) {
+                    if (kb + 2 * CC_PF < kt) {
+                        read_block(H1{}, kb + 3 * CC_PF);
+                        mul_block(H0{}, std::integral_constant<int, 16>{}, kb + 2 * CC_PF);
+                    }
+                }
+                if constexpr (CC_RING == 32) {
+                    if (kb + 3 * CC_PF < kt) {
+                        read_block(H0{}, kb + 4 * CC_PF);
+                        mul_block(H1{}, std::integral_constant<int, 24>{}, kb + 3 * CC_PF);
+                    }
                 }
             }
 #pragma unroll
@@ -177,7 +200,10 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_kernel(ChainParams p) {
 // reference-precision step's critical path.
 // ======================================================================================
 typedef _Float16 cc_f16x8 __attribute__((ext_vector_type(8)));
-[[maybe_unused]] constexpr int CX_PF = 4;
+[[maybe_unused]] constexpr int CX_PF = 4;                                 // K-steps of a block (one tap x 64 channels)
+// K-steps of filter (hi, lo) twins a wave keeps in flight (CX_RING: 4 or 8 -- one or two blocks); 8 measured 3 % slower than 4
+// (104.4 against 101.2 us, same file): SSDHIP_CHAIN_X3_RING=4|8 selects at launch
+constexpr int CX_RING_DEFAULT = 4;
 
 struct ChainX3LayerDev {
     const uint4* wp;             // packed filters: [Cout / 32][k k][Cin / 16][2 = hi, lo][64 lanes] x 16 bytes
@@ -194,7 +220,9 @@ struct ChainX3Params {
     ChainX3LayerDev L[CC_MAX_LAYERS];
 };
 
+template <int CX_RING>
 __global__ __launch_bounds__(CC_THREADS) void conv_chain_x3_kernel(ChainX3Params p) {
+    static_assert(CX_RING == 4 || CX_RING == 8, "ring depth: one or two blocks");
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) unsigned char lds[CC_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -227,9 +255,13 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_x3_kernel(ChainX3Params
             cc_f32x16 a_hh, a_hl, a_lh;
 #pragma unroll
             for (int v = 0; v < 16; ++v) { a_hh[v] = 0.f; a_hl[v] = 0.f; a_lh[v] = 0.f; }
-            uint4 rh[CX_PF], rl[CX_PF];
+            uint4 rh[CX_RING], rl[CX_RING];
 #pragma unroll
-            for (int j = 0; j < CX_PF; ++j) { rh[j] = wsrc[(size_t)j * 128]; rl[j] = wsrc[(size_t)j * 128 + 64]; }
+            for (int j = 0; j < CX_RING; ++j) {
+                const size_t o = (size_t)(j < kt ? j : kt - 1) * 128;
+                rh[j] = wsrc[o];
+                rl[j] = wsrc[o + 64];
+            }
             uint4 bh[2][CX_PF], bl[2][CX_PF];
             // the lane's pixel row of K-block kb (one tap, 64 channels), or the row of zeros (padding tap / lane without a pixel / behind the end)
             auto read_block = [&](auto hc, const int kb) {
@@ -259,14 +291,14 @@ __global__ __launch_bounds__(CC_THREADS) void conv_chain_x3_kernel(ChainX3Params
                 }
             };
             auto mul_block = [&](auto hc, const int kb) {
-                constexpr int HB = decltype(hc)::value;
+                constexpr int HB = decltype(hc)::value, SB = CX_RING == 8 ? HB * CX_PF : 0;     // half of bh / bl; first ring slot of the block
 #pragma unroll
                 for (int j = 0; j < CX_PF; ++j) {
-                    const uint4 wh = rh[j], wl = rl[j];
-                    const int kn = kb + CX_PF + j;
+                    const uint4 wh = rh[SB + j], wl = rl[SB + j];
+                    const int kn = kb + CX_RING + j;
                     const size_t o = (size_t)(kn < kt ? kn : kt - 1) * 128;
-                    rh[j] = wsrc[o];
-                    rl[j] = wsrc[o + 64];
+                    rh[SB + j] = wsrc[o];
+                    rl[SB + j] = wsrc[o + 64];
                     __builtin_amdgcn_sched_barrier(0);
                     a_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cc_f16x8, wh), __builtin_bit_cast(cc_f16x8, bh[HB][j]), a_hh, 0, 0, 0);
                     a_hl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cc_f16x8, wh), __builtin_bit_cast(cc_f16x8, bl[HB][j]), a_hl, 0, 0, 0);
@@ -414,7 +446,11 @@ extern "C" int ssdhip_conv_chain_nhwc_bf16(const void* x, int B, int H, int W, i
         l.out_off = (i & 1) ? 0 : (int)off1;
     }
     for (int i = n_layers; i < CC_MAX_LAYERS; ++i) p.L[i] = p.L[0];
-    hipLaunchKernelGGL(conv_chain_kernel, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    int ring = CC_RING_DEFAULT;
+    if (const char* e = getenv("SSDHIP_CHAIN_RING")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) ring = v; }
+    if (ring == 8) hipLaunchKernelGGL(conv_chain_kernel<8>, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    else if (ring == 32) hipLaunchKernelGGL(conv_chain_kernel<32>, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_chain_kernel<16>, dim3(B), dim3(CC_THREADS), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }
 
@@ -481,6 +517,9 @@ extern "C" int ssdhip_conv_chain_x3_nhwc_f16(const void* x, int B, int H, int W,
         l.out_off = (i & 1) ? 0 : (int)off1;
     }
     for (int i = n_layers; i < CC_MAX_LAYERS; ++i) p.L[i] = p.L[0];
-    hipLaunchKernelGGL(conv_chain_x3_kernel, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    int ring = CX_RING_DEFAULT;
+    if (const char* e = getenv("SSDHIP_CHAIN_X3_RING")) { const int v = atoi(e); if (v == 4 || v == 8) ring = v; }
+    if (ring == 4) hipLaunchKernelGGL(conv_chain_x3_kernel<4>, dim3(B), dim3(CC_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_chain_x3_kernel<8>, dim3(B), dim3(CC_THREADS), 0, stream, p);
     return hipGetLastError() == hipSuccess ? SSDHIP_OK : SSDHIP_E_LAUNCH;
 }

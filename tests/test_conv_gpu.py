@@ -572,6 +572,20 @@ def test_conv_chain_matches_layer_by_layer_reference(case):
     again = nat.conv_chain(x, layers)
     for a, y in zip(again, got):
         assert torch.equal(a.view(torch.int16), y.view(torch.int16))
+    # the depth of the filter ring (fragments in flight per wave: 8 by default; 16 / 32 measured slower) changes when a fragment is requested, not what is
+    # multiplied in which order: every depth returns the same bits
+    import os
+    old = os.environ.get("SSDHIP_CHAIN_RING")
+    try:
+        for ring in ("8", "16", "32"):
+            os.environ["SSDHIP_CHAIN_RING"] = ring
+            for a, y in zip(nat.conv_chain(x, layers), got):
+                assert torch.equal(a.view(torch.int16), y.view(torch.int16)), ring
+    finally:
+        if old is None:
+            os.environ.pop("SSDHIP_CHAIN_RING", None)
+        else:
+            os.environ["SSDHIP_CHAIN_RING"] = old
 
 
 def test_conv_chain_in_the_ssd300_model_equals_the_layer_by_layer_path():

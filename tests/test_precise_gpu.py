@@ -343,6 +343,13 @@ def test_extras_chain_at_reference_precision_equals_the_layers_one_by_one():
         act = (nat.x3_split(x / 2.0), 2.0)
         tail = pf._extras_chain(act, convs)
         assert tail is not None and len(tail) == 3
+        import os
+        os.environ["SSDHIP_CHAIN_X3_RING"] = "8"          # the filter ring's depth (4 K-steps by default; 8 measured slower) changes no bit
+        try:
+            for (a, _), (b_, _) in zip(pf._extras_chain(act, convs), tail):
+                assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+        finally:
+            os.environ.pop("SSDHIP_CHAIN_X3_RING", None)
         one = act
         ref = x.double()
         singles, refs = [], []
