@@ -502,9 +502,11 @@ int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, const void*
  * unpooled maps up to 94 wide) | 4 (16 x 16 pixel tiles) | 5 (8 x 32), plan[1] = position tiles (x Cout / 128 = tile units; one
  * persistent workgroup per CU walks them), plan[2] = row pitch of the STACKED batch -- pooled calls lay the images on top of each
  * other with a gap of one or two zero rows and tile the stack when that needs fewer tiles than tiling every image (SSD300's conv3_3 +
- * pool3 at batch 32: 760 instead of 800, six rounds of 256 CUs instead of seven) -- or 0, plan[3] = rows of tiles.  The results do
- * not depend on the tiling (same accumulation order per output). */
-int ssdhip_conv3x3_halo_plan(int B, int H, int W, int pool, int* plan);
+ * pool3 at batch 32: 760 instead of 800, six rounds of 256 CUs instead of seven) -- or 0, plan[3] = rows of tiles.  An un-pooled map
+ * up to 94 wide leaves the position grid for 2-D tiles when those finish in fewer rounds of one workgroup per CU (Cout / 128 tile
+ * units per position tile: SSD512's conv4_x / conv5_x at batch 16 -- four rounds instead of five, one instead of two).  The results
+ * do not depend on the tiling (same accumulation order per output). */
+int ssdhip_conv3x3_halo_plan(int B, int H, int W, int Cout, int pool, int* plan);
 
 /* Training step: the data gradient of a 3x3 'same' layer whose input is the ReLU output of the layer below, with that layer's
  * threshold_backward (keras Conv2D(activation='relu') under autodiff, models/keras_ssd300.py:279-291) in the epilogue: y = the 3x3

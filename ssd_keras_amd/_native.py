@@ -755,15 +755,15 @@ def conv2d_same(x, weight, bias, dilation=1, relu=True, variant=None):
     return y
 
 
-def conv3x3_halo_plan(b, h, w, pool):
-    """(geometry, position tiles, stacked-batch row pitch, rows of tiles) the slab entries pick for a batch of h x w maps: geometry 0 =
-    padded position grid, 4 = 16 x 16 pixel tiles, 5 = 8 x 32; pitch 0 = tiles per image (csrc/ssdhip_convh.hip, convh_pick_2d).
-    Host arithmetic only: works without a GPU."""
+def conv3x3_halo_plan(b, h, w, pool, cout=128):
+    """(geometry, position tiles, stacked-batch row pitch, rows of tiles) the slab entries pick for a batch of h x w maps with `cout`
+    output channels: geometry 0 = padded position grid, 4 = 16 x 16 pixel tiles, 5 = 8 x 32; pitch 0 = tiles per image
+    (csrc/ssdhip_convh.hip, convh_pick_2d / convh_plan_unpooled).  Host arithmetic only: works without a GPU (256 CUs assumed)."""
     lib = load()
     lib.ssdhip_conv3x3_halo_plan.restype = ctypes.c_int
-    lib.ssdhip_conv3x3_halo_plan.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int)]
+    lib.ssdhip_conv3x3_halo_plan.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]
     plan = (ctypes.c_int * 4)()
-    check(lib.ssdhip_conv3x3_halo_plan(int(b), int(h), int(w), int(bool(pool)), plan), "ssdhip_conv3x3_halo_plan")
+    check(lib.ssdhip_conv3x3_halo_plan(int(b), int(h), int(w), int(cout), int(bool(pool)), plan), "ssdhip_conv3x3_halo_plan")
     return tuple(plan)
 
 

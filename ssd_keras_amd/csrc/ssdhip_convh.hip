@@ -1240,21 +1240,46 @@ static bool convh_pick_2d(ConvHParams& p, int B, int H, int W, int pool, int& ge
     return true;
 }
 
+// An un-pooled map up to 94 wide runs on the padded position grid -- unless 2-D tiles finish in FEWER ROUNDS of one workgroup per CU
+// (fourth session of round 6): SSD512's conv4_x at batch 16 is 265 position tiles x 4 channel tiles = 1 060 units = five rounds of 256 CUs
+// on the grid and 256 x 4 = 1 024 = exactly four on 16 x 16 tiles, its conv5_x 276 units (two rounds) against 256 (one).  SSD300's maps
+// (75, 38 wide) stay on the grid.  Fills the tile fields either way; false: sizes beyond the index range.  SSDHIP_CONVH_GRID=1 keeps the grid.
+static bool convh_plan_unpooled(ConvHParams& p, int B, int H, int W, int n_tiles, int& geom) {
+    geom = 0;
+    p.HT = p.WT = 0;
+    p.Hp = 0;
+    if (W > 94) return convh_pick_2d(p, B, H, W, 0, geom, false);
+    const long long Q = (long long)B * (H + 1) * (W + 1);
+    if (Q > 0x3fffff00LL) return false;
+    const long long grid_tiles = (Q + CH_BN - 1) / CH_BN;
+    const char* e = getenv("SSDHIP_CONVH_GRID");
+    if (!(e && atoi(e) == 1)) {
+        int g2 = 0;
+        if (convh_pick_2d(p, B, H, W, 0, g2, false)) {
+            const long long n_cu = convh_cu_count();
+            const long long r_grid = (((grid_tiles + 7) / 8) * 8 * n_tiles + n_cu - 1) / n_cu;
+            const long long r_2d = ((((long long)p.q_tiles + 7) / 8) * 8 * n_tiles + n_cu - 1) / n_cu;
+            if (r_2d < r_grid) { geom = g2; return true; }
+        }
+    }
+    p.HT = p.WT = 0;
+    p.Hp = 0;
+    p.Q = (int)Q;
+    p.q_tiles = (int)grid_tiles;
+    return true;
+}
+
 // The tiling ssdhip_conv3x3_halo_nhwc_bf16 / ssdhip_conv3x3_halo_x3_nhwc_f16 pick for a (batch, map, pool) -- host arithmetic only, no
 // launch: plan[0] = 0 (padded position grid) | 4 (16 x 16 pixel tiles) | 5 (8 x 32), plan[1] = position tiles (x Cout / 128 = tile
 // units), plan[2] = the row pitch of the stacked batch (0: tiles per image), plan[3] = rows of tiles (per image, or of the stack).
-extern "C" int ssdhip_conv3x3_halo_plan(int B, int H, int W, int pool, int* plan) {
-    if (!plan || B <= 0 || H <= 0 || W <= 0) return SSDHIP_E_BADARG;
+// (Cout: an un-pooled call's choice between grid and 2-D tiles counts rounds of tile units.)
+extern "C" int ssdhip_conv3x3_halo_plan(int B, int H, int W, int Cout, int pool, int* plan) {
+    if (!plan || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % CH_BM)) return SSDHIP_E_BADARG;
     ConvHParams p;
     int geom = 0;
-    if (pool || W > 94) {
+    if (pool) {
         if (!convh_pick_2d(p, B, H, W, pool, geom, true)) return SSDHIP_E_BADARG;
-    } else {
-        const long long Q = (long long)B * (H + 1) * (W + 1);
-        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
-        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
-        p.HT = 0;
-    }
+    } else if (!convh_plan_unpooled(p, B, H, W, Cout / CH_BM, geom)) return SSDHIP_E_BADARG;
     plan[0] = geom; plan[1] = p.q_tiles; plan[2] = p.Hp; plan[3] = p.HT;
     return SSDHIP_OK;
 }
@@ -1363,14 +1388,9 @@ extern "C" int ssdhip_conv3x3_halo_x3_nhwc_f16(const void* x, const void* weight
     p.os = 1; p.ooff = 0; p.Hs = H; p.Ws = W;
     p.xC = 2 * C; p.nx = c64 ? 2 : C / 64; p.bias32 = bias; p.oscale = oscale;
     int geom = 0;
-    if (pool || W > 94) {
+    if (pool) {
         if (!convh_pick_2d(p, B, H, W, pool, geom, true)) return SSDHIP_E_BADARG;
-    } else {
-        const long long Q = (long long)B * (H + 1) * (W + 1);
-        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
-        p.Q = (int)Q;
-        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
-    }
+    } else if (!convh_plan_unpooled(p, B, H, W, Cout / CH_BM, geom)) return SSDHIP_E_BADARG;
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)yb;
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
@@ -1400,14 +1420,9 @@ extern "C" int ssdhip_conv3x3_halo_nhwc_bf16(const void* x, const void* weight, 
     int mode = pool ? 1152 : 128;                         // the schedule: see the switch below
     if (const char* e = getenv("SSDHIP_CONVH_MODE")) mode = atoi(e);
     int geom = 0;
-    if (pool || W > 94) {
+    if (pool) {
         if (!convh_pick_2d(p, B, H, W, pool, geom, mode == 1152)) return SSDHIP_E_BADARG;
-    } else {
-        const long long Q = (long long)B * (H + 1) * (W + 1);
-        if (Q > 0x3fffff00LL) return SSDHIP_E_BADARG;
-        p.Q = (int)Q;
-        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
-    }
+    } else if (!convh_plan_unpooled(p, B, H, W, Cout / CH_BM, geom)) return SSDHIP_E_BADARG;
     p.n_tiles = Cout / CH_BM;
     p.x_bytes = (int)xb; p.w_bytes = (int)wb; p.y_bytes = (int)(pool ? (long long)B * p.Ho * p.Wo * Cout * 2 : (long long)B * H * W * Cout * 2);
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
@@ -1462,16 +1477,7 @@ extern "C" int ssdhip_profile_read_convh(unsigned long long* host_out, int reset
 
 // Tiling of a masked call: fills p.{HT, WT, Q, q_tiles, n_tiles, total_ids} and geom; false: sizes beyond the kernel's index range
 static bool convh_masked_plan(ConvHParams& p, int B, int H, int W, int Cout, int& geom) {
-    p.HT = p.WT = 0;
-    geom = 0;
-    if (W > 94) {
-        if (!convh_pick_2d(p, B, H, W, 0, geom, false)) return false;
-    } else {
-        const long long Q = (long long)B * (H + 1) * (W + 1);
-        if (Q > 0x3fffff00LL) return false;
-        p.Q = (int)Q;
-        p.q_tiles = (int)((Q + CH_BN - 1) / CH_BN);
-    }
+    if (!convh_plan_unpooled(p, B, H, W, Cout / CH_BM, geom)) return false;
     p.n_tiles = Cout / CH_BM;
     p.total_ids = ((p.q_tiles + 7) / 8) * p.n_tiles * 8;
     return true;

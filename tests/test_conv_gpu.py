@@ -272,6 +272,9 @@ HALO_CASES = [  # B, H, W, Cin, Cout, bias, relu      (csrc/ssdhip_convh.hip: 3x
     (1, 3, 63, 128, 128, True, True),        # W + 1 = 64
     (64, 38, 38, 128, 256, True, True),      # 3044 tiles: every persistent workgroup walks over ~12 of them
     (48, 19, 19, 256, 384, True, True),      # three channel tiles per position tile; tiles change channel tile between hops
+    # fourth session: an un-pooled map up to 94 wide leaves the position grid when 2-D tiles take fewer rounds of 256 workgroups
+    (16, 32, 32, 128, 512, True, True),      # SSD512 conv5_x at batch 16: 64 tiles of 16 x 16 x 4 channel tiles = one round (grid: 276 units = two)
+    (16, 64, 64, 128, 512, False, True),     # SSD512 conv4_x: 1 024 units = four rounds (grid: 1 060 = five)
 ]
 
 

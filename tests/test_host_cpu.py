@@ -428,11 +428,18 @@ def test_slab_kernel_tiling_plan_is_host_arithmetic(monkeypatch):
     of 800 (a seventh round) -- and only then; the magic reciprocal the kernel divides rows with is exact on every row it can ask about."""
     from ssd_keras_amd import _native as nat
     monkeypatch.delenv("SSDHIP_CONVH_STACK", raising=False)
+    monkeypatch.delenv("SSDHIP_CONVH_GRID", raising=False)
     assert nat.conv3x3_halo_plan(32, 75, 75, True) == (4, 760, 76, 152)
     assert nat.conv3x3_halo_plan(32, 150, 150, True) == (5, 3040, 0, 19)            # a tie stays on tiles per image
     assert nat.conv3x3_halo_plan(32, 75, 75, False) == (0, 722, 0, 0)               # unpooled, <= 94 wide: the padded position grid
     assert nat.conv3x3_halo_plan(32, 150, 150, False) == (5, 3040, 0, 19)           # unpooled 2-D tiles are never stacked
     assert nat.conv3x3_halo_plan(6, 20, 20, True) == (5, 17, 22, 17)                # even map: two rows of zeros between images
+    # un-pooled maps up to 94 wide: the position grid unless 2-D tiles take fewer rounds of 256 workgroups
+    assert nat.conv3x3_halo_plan(32, 38, 38, False, 512) == (0, 191, 0, 0)          # SSD300 conv4_x: 764 units, three rounds either way... the grid
+    assert nat.conv3x3_halo_plan(32, 75, 75, False, 256) == (0, 722, 0, 0)          # SSD300 conv3_x
+    assert nat.conv3x3_halo_plan(16, 64, 64, False, 512) == (4, 256, 0, 4)          # SSD512 conv4_x: 1 024 units = four rounds (grid: 1 060 = five)
+    assert nat.conv3x3_halo_plan(16, 32, 32, False, 512) == (4, 64, 0, 2)           # SSD512 conv5_x: 256 units = one round (grid: 276 = two)
+    assert nat.conv3x3_halo_plan(2, 64, 64, False, 512)[0] == 0                     # a small batch: one round either way
     assert nat.conv3x3_halo_plan(5, 2, 2, True)[2] == 0                             # a gap narrower than a tile's rows + 2: per image
     for b in range(1, 40):
         for h in (1, 2, 7, 16, 17, 18, 19, 37, 38, 75, 150, 300, 301):
@@ -449,6 +456,8 @@ def test_slab_kernel_tiling_plan_is_host_arithmetic(monkeypatch):
                         assert (r * magic) >> 32 == r // pitch
                 else:
                     assert tiles == per_image
+    monkeypatch.setenv("SSDHIP_CONVH_GRID", "1")
+    assert nat.conv3x3_halo_plan(16, 64, 64, False, 512) == (0, 265, 0, 0)
     monkeypatch.setenv("SSDHIP_CONVH_STACK", "0")
     assert nat.conv3x3_halo_plan(32, 75, 75, True) == (4, 800, 0, 5)
     with pytest.raises(nat.SsdHipError):

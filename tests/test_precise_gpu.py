@@ -13,6 +13,7 @@ CASES = [  # B, H, W, C, Cout, k, stride, pad, dil, relu, pool
     (2, 38, 38, 256, 512, 3, 1, 1, 1, True, False),
     (2, 75, 75, 128, 256, 3, 1, 1, 1, True, True),      # pooled, odd map ('same' pooling pads bottom / right)
     (5, 75, 75, 128, 128, 3, 1, 1, 1, True, True),      # the same on tiles of the STACKED batch (24 x 5 tiles for 125: csrc/ssdhip_convh.hip)
+    (16, 32, 32, 128, 512, 3, 1, 1, 1, True, False),    # un-pooled on 2-D tiles because they take one round where the position grid takes two
     (2, 150, 150, 128, 128, 3, 1, 1, 1, True, True),    # conv2_2 + pool2: 2-D tiles of the slab kernel
     (2, 19, 19, 512, 512, 3, 1, 1, 1, False, False),    # conv5_x shape, no activation
     (2, 150, 150, 64, 128, 3, 1, 1, 1, True, False),    # conv2_1: halo = the slab kernel's padded 64-channel form

@@ -339,7 +339,7 @@ def test_training_step_of_the_other_builders_runs_on_the_own_backward_kernels(wh
 
 
 @pytest.mark.parametrize("shape", [(3, 128, 128, 19, 19), (2, 256, 128, 38, 38), (2, 128, 256, 75, 75), (1, 128, 128, 150, 150),
-                                   (2, 128, 128, 9, 100), (1, 256, 128, 40, 130)])
+                                   (2, 128, 128, 9, 100), (1, 256, 128, 40, 130), (16, 128, 512, 32, 32)])
 def test_data_gradient_with_the_relu_mask_of_the_layer_below_in_its_epilogue(shape):
     """ssdhip_conv3x3_halo_masked_nhwc_bf16 (round 6, fourth session): the slab kernel's result zeroed where the activation of the
     layer below is <= 0 == the slab kernel followed by relu_bwd_bias_kernel's mask (threshold_backward's rule: -0 and negative values
