@@ -1061,8 +1061,11 @@ class SSDModel(nn.Module):
                 hc = {"per_layer": lambda: self._heads_per_layer(feats), "grouped": lambda: self._heads_grouped(feats)}
                 if self._halo_heads_ok(feats):
                     hc["halo_grouped"] = lambda: self._heads_halo_grouped(feats)
+                elif self._halo_heads_mixed_ok(feats):
+                    hc["halo_mixed"] = lambda: self._heads_halo_mixed(feats)
                 how = self._pick(("heads", tuple(tuple(f.shape) for f in feats), self.n_classes), hc)
             confs, locs = (self._heads_halo_grouped(feats) if how == "halo_grouped" else
+                           self._heads_halo_mixed(feats) if how == "halo_mixed" else
                            self._heads_grouped(feats) if how == "grouped" else self._heads_per_layer(feats))
             anchors = self.anchors_and_variances(sizes, x.device)
             head_args = (confs, locs, [ch.bias for ch in self.conf_heads], [lh.bias for lh in self.loc_heads],
@@ -1239,6 +1242,29 @@ class SSDModel(nn.Module):
         multiple of 128 output channels; the deepest head (fc7's: 144 K-steps) is dispatched first."""
         outs = nat.conv3x3_halo_group(list(feats), [self._packed_head_weight(l, 128) for l in range(len(feats))], None, relu=False)
         return outs, [None] * len(outs)
+
+    def _heads_halo_mixed(self, feats):
+        """Round 6, fourth session (SSD512: its conv4_3 map is 64 wide, two columns more than the grouped slab launch's LDS layout takes,
+        and ALL seven heads fell back to the implicit-GEMM group -- 223 us of a 3.0 ms step): the maps wider than 62 each through the
+        single-problem slab entry (which tiles them as it sees fit: 16 x 16-pixel tiles, one round of 256 workgroups at batch 16), the
+        others as the grouped slab launch."""
+        wide = [l for l, f in enumerate(feats) if f.shape[3] > 62]
+        rest = [l for l in range(len(feats)) if l not in wide]
+        outs = [None] * len(feats)
+        for l in wide:
+            outs[l] = nat.conv3x3_halo(feats[l], self._packed_head_weight(l, 128), None, relu=False, pool=False)
+        if rest:
+            got = nat.conv3x3_halo_group([feats[l] for l in rest], [self._packed_head_weight(l, 128) for l in rest], None, relu=False)
+            for l, y in zip(rest, got):
+                outs[l] = y
+        return outs, [None] * len(outs)
+
+    def _halo_heads_mixed_ok(self, feats):
+        import os
+        rest = [f for f in feats if f.shape[3] <= 62]
+        return (os.environ.get("SSDHIP_NO_HALO", "0") != "1" and os.environ.get("SSDHIP_NO_HALO_MIXED", "0") != "1"
+                and len(rest) <= 8 and len(rest) < len(feats)
+                and all(f.shape[1] % 128 == 0 for f in feats))
 
     def _halo_heads_ok(self, feats):
         import os

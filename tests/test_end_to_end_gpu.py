@@ -334,3 +334,26 @@ def test_an_older_graph_of_a_model_survives_a_foreign_stream():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_two_graphs.py"), "guarded"], cwd=root, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "OK guarded" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_ssd512_heads_through_the_slab_kernel_equal_the_implicit_gemm_group():
+    """models/_common.py `_heads_halo_mixed` (round 6, fourth session): SSD512's seven packed predictor heads with the 64-wide conv4_3
+    map through the single-problem slab entry and the six narrower maps as one grouped slab launch == all seven in the implicit-GEMM
+    group launch, bit for bit on every real channel (the two paddings differ: 128 against 64 channels)."""
+    import torch
+    from ssd_keras_amd.models.keras_ssd512 import ssd_512
+    cfg = syn.SSD512_COCO
+    torch.manual_seed(9)
+    model = ssd_512((512, 512, 3), 20, mode="inference", scales=cfg["scales"], aspect_ratios_per_layer=cfg["aspect_ratios_per_layer"],
+                    steps=cfg["steps"], offsets=cfg["offsets"], confidence_thresh=0.01, iou_threshold=0.45, top_k=200, nms_max_output_size=400)
+    model = model.cuda().to(memory_format=torch.channels_last).to(torch.bfloat16).eval()
+    images = torch.from_numpy(np.random.RandomState(2).randint(0, 256, size=(3, 512, 512, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        feats = model.features(model.preprocess(images) if hasattr(model, "preprocess") else images)
+        assert feats[0].shape[3] == 64 and not model._halo_heads_ok(feats) and model._halo_heads_mixed_ok(feats)
+        mixed, _ = model._heads_halo_mixed(feats)
+        group, _ = model._heads_grouped(feats)
+    for l, (a, b) in enumerate(zip(mixed, group)):
+        n = model.conf_heads[l].out_channels + model.loc_heads[l].out_channels
+        assert a.shape[1] >= n and b.shape[1] >= n and a.shape[2:] == b.shape[2:]
+        assert torch.equal(a[:, :n].contiguous().view(torch.int16), b[:, :n].contiguous().view(torch.int16)), l
